@@ -1,0 +1,182 @@
+/*
+ * neuman_hip.h -- C ABI of libneuman_hip.so: the NeuMan ray-march hot path on MI355X (gfx950).
+ *
+ * The reference (apple/ml-neuman) has no FFI seam: its hot path is the Python function level of
+ * utils/ray_utils.py, utils/render_utils.py and models/vanilla.py.  This header IS the seam a
+ * maintainer binds underneath those functions (ctypes stub: INTEGRATION.md).  Each entry point names
+ * the reference lines it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 (NM_OK) or a negative NM_ERR_* code; nm_last_error() returns a
+ *     thread-local human readable message for the last failure on the calling thread;
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch tensor.data_ptr()) unless the
+ *     parameter name starts with host_;  all tensors are dense, row-major, float32 / int32;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); kernels
+ *     are enqueued on it and the call returns without synchronising;
+ *   - no hidden allocation except inside the opaque nm_mlp_t handle; no global mutable state;
+ *   - there is NO CPU fallback: without a HIP device the compute entry points fail with NM_ERR_HIP.
+ */
+#ifndef NEUMAN_HIP_H
+#define NEUMAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NM_OK 0
+#define NM_ERR_ARG (-1)         /* bad argument (null pointer, size, unsupported shape) */
+#define NM_ERR_HIP (-2)         /* HIP runtime error (message carries hipGetErrorString) */
+#define NM_ERR_UNSUPPORTED (-3) /* valid request this build does not implement */
+
+#define NM_ABI_VERSION 1
+
+typedef void* nm_stream_t;
+
+/* precision of the MLP contraction (nm_mlp_forward*) */
+#define NM_PREC_FP32 0   /* exact-f32 FMA chains on the vector ALU: slow validation path            */
+#define NM_PREC_BF16X3 1 /* split-bf16 (hi+lo) x3 MFMA, f32 accumulate: the parity-grade default     */
+#define NM_PREC_BF16 2   /* single bf16 MFMA, f32 accumulate: fast, NOT parity grade     */
+
+/* positional-encoding kinds (reference models/vanilla.py:44-79) */
+#define NM_PE_POSENC 0 /* [x, sin(f0 x), cos(f0 x), sin(f1 x), ...]   vanilla.py:60-79,92 */
+#define NM_PE_ROTATE 1 /* [x, sin(x B^T), cos(x B^T)]                 vanilla.py:44-58,83-89 */
+
+int nm_version(void);
+const char* nm_last_error(void);
+/* number of visible HIP devices (0 when none): lets a host fail loudly before any compute call */
+int nm_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * a4  ray_to_samples -- reference utils/ray_utils.py:96-135
+ *   z = near*(1-t) + far*t  (or the lindisp form, :113-114); optional stratified jitter with a
+ *   caller-drawn, already clipped t_rand[R,S] (:116-129); pts = o + d*z (:131); dirs = d repeated.
+ *   t_vals[S] is the caller's torch.linspace(0,1,S) so both sides consume identical t.
+ *   pts [R,S,3] and dirs [R,S,3] are optional (NULL = do not materialise).
+ * ------------------------------------------------------------------------------------------- */
+int nm_ray_to_samples(const float* origin, const float* direction, const float* near, const float* far,
+                      int64_t R, int S, const float* t_vals, int lindisp, const float* t_rand,
+                      float* pts, float* dirs, float* z_vals, nm_stream_t stream);
+
+/* pts[i,s,:] = origin[i,:] + direction[i,:] * z[i,s]; dirs likewise (ray_utils.py:153-156). */
+int nm_z_to_points(const float* origin, const float* direction, const float* z_vals, int64_t R, int S,
+                   float* pts, float* dirs, nm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a5  raw2outputs -- reference utils/render_utils.py:69-105
+ *   raw [R,S,4] = (r,g,b,sigma), z [R,S], rays_d [R,3]; noise [R,S] optional (the caller's
+ *   torch.randn * raw_noise_std, :91-93).  Outputs: rgb [R,3], disp [R], acc [R], weights [R,S]
+ *   (optional), depth [R].  One wavefront per ray, transmittance by a wave prefix product.
+ * ------------------------------------------------------------------------------------------- */
+int nm_composite(const float* raw, const float* z_vals, const float* rays_d, int64_t R, int S, int white_bkg,
+                 const float* noise, float* rgb, float* disp, float* acc, float* weights, float* depth,
+                 nm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a6  sample_pdf (det=True) -- reference utils/ray_utils.py:164-194
+ *   bins [R,B], weights [R,B-1], u [N] (caller's torch.linspace(0,1,N)) -> samples [R,N]
+ * a7  ray_to_importance_samples -- reference utils/ray_utils.py:138-160
+ *   z [R,S], weights [R,S] (as returned by raw2outputs) -> z_out [R,S+N] sorted (including_old)
+ *   or [R,N] (not including_old).  Mid-points, weights[1:-1] slicing and the sort are fused.
+ * ------------------------------------------------------------------------------------------- */
+int nm_sample_pdf(const float* bins, const float* weights, int64_t R, int B, const float* u, int N,
+                  float* samples, nm_stream_t stream);
+int nm_importance_z(const float* z_vals, const float* weights, int64_t R, int S, const float* u, int N,
+                    int including_old, float* z_out, nm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a2  geometry_guided_near_far -- reference utils/ray_utils.py:197-233
+ *   near = min_v(z0 - dz), far = max_v(z0 + dz), dz = sqrt(tau^2 - (|v-o|^2 - z0^2)), NaN -> +-inf.
+ * a3  hit-ray compaction -- reference utils/render_utils.py:199-212 (boolean-mask indexing)
+ *   hit_idx receives the indices of rays with near < far in ascending order, miss_idx (optional)
+ *   the others; counts[0] = n_hit, counts[1] = n_miss (device int32[2]).  Wave ballot + prefix sum.
+ *   workspace: device int32, at least nm_compact_workspace_ints(R) entries.
+ * ------------------------------------------------------------------------------------------- */
+int nm_near_far(const float* origin, const float* direction, int64_t R, const float* verts, int V, double geo_threshold,
+                float* near, float* far, nm_stream_t stream);
+int64_t nm_compact_workspace_ints(int64_t R);
+int nm_compact_hits(const float* near, const float* far, int64_t R, int32_t* hit_idx, int32_t* miss_idx,
+                    int32_t* counts, int32_t* workspace, nm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a8/a9/a10  Joiner.forward = Embedder x2 + NeRF.forward -- reference models/vanilla.py:82-92,120-152,162-166
+ *
+ *   The net is the reference's default: depth 8, width 256, skip after layer 4, use_viewdirs
+ *   (options/options.py:52-57), pos PE -> 63 features, dir PE -> 27 features.
+ *   host_params: 24 HOST pointers to float32 arrays in the reference state_dict order
+ *     nerf.pts_linears.{0..7}.{weight,bias}, nerf.views_linears.0.{weight,bias},
+ *     nerf.feature_linear.{weight,bias}, nerf.alpha_linear.{weight,bias}, nerf.rgb_linear.{weight,bias}
+ *   (weights are [out,in] row-major as torch.nn.Linear stores them).
+ *   pe tables: posenc -> host_pos_tab[n_freqs] = the f32 frequency bands; rotate ->
+ *   host_pos_tab[3*n_freqs*3] = Embedder.bvals ([3N,3] row-major).
+ *   nm_mlp_create packs the weights into MFMA fragment order (split bf16 hi/lo) and uploads them;
+ *   the handle owns that device memory.  A handle is immutable: rebuild it after the weights change.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct nm_mlp_s* nm_mlp_t;
+
+typedef struct nm_mlp_desc {
+    int32_t depth;        /* 8 */
+    int32_t width;        /* 256 */
+    int32_t skip;         /* 4: cat([x_pe, h]) after pts_linears[4] */
+    int32_t pe_kind;      /* NM_PE_POSENC / NM_PE_ROTATE, used for both inputs (vanilla.py:216,225) */
+    int32_t pos_n_freqs;  /* 10 */
+    int32_t dir_n_freqs;  /* 4 */
+} nm_mlp_desc;
+
+int64_t nm_mlp_pack_bytes(const nm_mlp_desc* desc);
+/* host-only: write the packed weight image (what nm_mlp_create uploads) into host_out. */
+int nm_mlp_pack(const nm_mlp_desc* desc, const float* const* host_params, void* host_out);
+int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, const float* host_pos_tab,
+                  const float* host_dir_tab, nm_mlp_t* out);
+int nm_mlp_destroy(nm_mlp_t mlp);
+
+/* out[i,:] = NeRF(PE(pts[i]), PE(dirs[i])) * (1,1,1,sigma_scale);  pts/dirs [n,3], out [n,4].
+ * sigma_scale carries `out[..., -1] *= interval_comp` (render_utils.py:229); pass 1.0 otherwise. */
+int nm_mlp_forward(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision,
+                   float sigma_scale, float* out, nm_stream_t stream);
+/* Same with ray_to_samples' point construction fused: sample (r,s) is at origin[r] + direction[r]*z[r,s]
+ * with view direction direction[r] (ray_utils.py:131-132); out [R,S,4]. */
+int nm_mlp_forward_rays(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals,
+                        int64_t R, int S, int precision, float sigma_scale, float* out, nm_stream_t stream);
+/* Debug: stop after `stage` and write that stage's activations as f32 [n, width_of_stage]:
+ *   -1 -> position PE (64 wide, col 63 = 0);  0..7 -> relu(pts_linears[i]) (256);
+ *    8 -> feature_linear output (256);  9 -> relu(views_linears[0]) (128). */
+int nm_mlp_forward_debug(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision,
+                         int stage, float* hidden, nm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a11  warp_samples_to_canonical -- reference utils/ray_utils.py:48-66
+ *   closest point on the posed mesh (replaces igl.point_mesh_squared_distance, :53), barycentrics
+ *   (:55), blended per-vertex transform T (f64, [>=V,4,4]), 4x4 inverse, canonical point, and
+ *   finite-difference canonical directions along each ray (:62-64).
+ *   pts [R,S,3] f32, verts [V,3] f32, faces [F,3] int32, T [*,16] f64 -> can_pts, can_dirs [R,S,3] f32,
+ *   closest [R,S,3] f32 (optional).  workspace: device float, nm_warp_workspace_floats(F) entries,
+ *   64-byte aligned (per-triangle records rebuilt on every call: the posed mesh changes per frame).
+ * ------------------------------------------------------------------------------------------- */
+int64_t nm_warp_workspace_floats(int F);
+int nm_warp_to_canonical(const float* pts, int64_t R, int S, const float* verts, int V, const int32_t* faces, int F,
+                         const double* T, float* can_pts, float* can_dirs, float* closest, float* workspace,
+                         nm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a13  sorted merge of sample lists -- reference utils/render_utils.py:330-337, 441-448
+ *   Two lists per ray, each already sorted in z: (za [R,Sa], rawa [R,Sa,4]) and (zb, rawb).
+ *   Writes z_out [R,Sa+Sb] sorted and raw_out [R,Sa+Sb,4] gathered in the same order
+ *   (== torch.sort(cat(z)) + the three-index gather).  Apply repeatedly for k lists.
+ * ------------------------------------------------------------------------------------------- */
+int nm_merge_sorted(const float* za, const float* rawa, int Sa, const float* zb, const float* rawb, int Sb,
+                    int64_t R, float* z_out, float* raw_out, nm_stream_t stream);
+
+/* row gather / scatter of per-ray records (boolean-mask indexing of render_utils.py:206-212, 231-233):
+ *   dst[i, :] = src[idx[i], :]  for i < n (gather)   |   dst[idx[i], :] = src[i, :] (scatter)
+ * n is read from the device (counts pointer) so the host never synchronises on the hit count. */
+int nm_gather_rows(const float* src, const int32_t* idx, const int32_t* n_dev, int64_t n_max, int width,
+                   float* dst, nm_stream_t stream);
+int nm_scatter_rows(const float* src, const int32_t* idx, const int32_t* n_dev, int64_t n_max, int width,
+                    float* dst, nm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEUMAN_HIP_H */

@@ -1,0 +1,63 @@
+// Shared helpers for libneuman_hip.so (gfx950 only; no CUDA / multi-backend paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/neuman_hip.h"
+
+namespace nm {
+
+void set_error(const char* fmt, ...);
+// hipGetLastError() after a launch; sets the error string on failure.
+int check_launch(const char* what);
+int check_hip(hipError_t e, const char* what);
+
+constexpr int kWave = 64;  // CDNA wavefront width
+
+inline hipStream_t as_stream(nm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace nm
+
+#define NM_REQUIRE(cond, ...)          \
+    do {                               \
+        if (!(cond)) {                 \
+            nm::set_error(__VA_ARGS__); \
+            return NM_ERR_ARG;         \
+        }                              \
+    } while (0)
+
+// ---- wave-level primitives (64 lanes) -------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// inclusive prefix product / sum / max across the 64 lanes (Hillis-Steele over shuffles)
+__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(v, o, 64);
+        if (lane >= o) v *= t;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_add(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_max(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(v, o, 64);
+        if (lane >= o) v = fmaxf(v, t);
+    }
+    return v;
+}

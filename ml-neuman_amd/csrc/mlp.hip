@@ -1,0 +1,378 @@
+// Fused positional-encoding + 8x256 NeRF MLP for gfx950 (MI355X), the roofline kernel of the path.
+// Replaces reference models/vanilla.py Embedder.forward (:82-92), NeRF.forward (:120-152) and
+// Joiner.forward (:162-166); optionally also ray_to_samples' point construction (ray_utils.py:131).
+//
+// Design (see DESIGN.md "K4"):
+//   * one workgroup = 8 waves (512 threads) = one tile of 128 samples; grid-stride over tiles
+//     (persistent: the 2.3 MB split-bf16 weight image stays resident in every XCD's 4 MB L2);
+//   * activations never leave the CU: they sit in LDS as split bf16 (hi | lo arrays, 128 KB for the
+//     256-wide hidden state + 32 KB for the position / direction encodings = all 160 KB of the CU);
+//   * each layer is D[feature][sample] = W * X on v_mfma_f32_32x32x16_bf16; wave w owns output
+//     features 32w..32w+31 for all 128 samples (4 accumulator tiles = 64 VGPRs), so every weight
+//     fragment is fetched by exactly one wave, straight from L2 into VGPRs in MFMA A-operand order
+//     (pre-packed on the host: one coalesced 1 KB load per wave instruction, no LDS staging);
+//   * parity mode (NM_PREC_BF16X3): x = xh + xl, w = wh + wl, acc += wh*xl + wl*xh + wh*xh in f32
+//     (three MFMAs; the dropped wl*xl term is <= 2^-16 relative); NM_PREC_BF16 issues only wh*xh;
+//   * the epilogue adds nothing (bias is the accumulator's initial value), applies ReLU, splits to
+//     hi/lo with v_cvt_pk_bf16_f32 and writes one ds_write_b128 per 8 features in exactly the k-slot
+//     order the next layer's packed weights expect (mlp_layout.h).
+#include "common.h"
+#include "mlp_layout.h"
+#include "mlp_launch.h"
+
+namespace {
+
+using nm::kTileM;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kThreads = 512;
+// LDS map, in uint4 (16 B) units.  Chunk c of an array is [hi: 128 rows][lo: 128 rows] (4 KB), so the lo
+// half of any operand is a +2 KB immediate offset from its hi half (ds_read_b128 offset field is 16 bit).
+constexpr int kChunkU4 = 2 * kTileM;                    // 256
+constexpr int kLoU4 = kTileM;                           // 128
+constexpr int H_BASE = 0;
+constexpr int P_BASE = nm::kHChunks * kChunkU4;         // 8192
+constexpr int LDS_U4 = P_BASE + nm::kPeChunks * kChunkU4;   // 10240 -> 163840 B = the whole CU
+static_assert(LDS_U4 * 16 == 160 * 1024, "LDS plan must be exactly 160 KiB");
+
+struct PeSpec {
+    int kind;     // NM_PE_POSENC / NM_PE_ROTATE
+    int nfreq;
+};
+
+struct MlpArgs {
+    const uint4* wpack;      // packed split-bf16 weight fragments (mlp_layout.h)
+    const float* bias;       // kBiasFloats
+    const float* petab;      // [0..95] position table, [96..191] direction table
+    const float* pts;        // in_mode 0: [n,3]
+    const float* dirs;       // in_mode 0: [n,3]
+    const float* origin;     // in_mode 1: [R,3]
+    const float* direction;  // in_mode 1: [R,3]
+    const float* z;          // in_mode 1: [R,S]
+    float* out;              // [n,4]
+    float* dbg;              // debug dump or nullptr
+    int64_t n;
+    int S;
+    int in_mode;
+    int stop_stage;          // -2 = run everything
+    float sigma_scale;
+    PeSpec pos, dir;
+};
+
+// ---- positional encoding feature p of a 3-vector (reference models/vanilla.py:60-92) ---------------
+__device__ __forceinline__ float pe_feature(int p, float x0, float x1, float x2, PeSpec spec, const float* __restrict__ tab) {
+    const int m = p - 3;
+    float a = 0.f;
+    bool is_cos = false;
+    if (p >= 3 && m < 6 * spec.nfreq) {
+        if (spec.kind == NM_PE_POSENC) {                      // [sin(f_b x) (3), cos(f_b x) (3)] per band, vanilla.py:73-76
+            const int b = m / 6, r = m - 6 * b;
+            const int dim = r >= 3 ? r - 3 : r;
+            const float xv = dim == 0 ? x0 : (dim == 1 ? x1 : x2);
+            a = xv * tab[b];
+            is_cos = r >= 3;
+        } else {                                              // rotate: [sin(x B^T) (3N), cos(x B^T) (3N)], vanilla.py:85-88
+            const int n3 = 3 * spec.nfreq;
+            is_cos = m >= n3;
+            const float* b = tab + 3 * (is_cos ? m - n3 : m);
+            a = fmaf(x2, b[2], fmaf(x1, b[1], x0 * b[0]));
+        }
+    }
+    float sv, cv;
+    sincosf(a, &sv, &cv);                                     // full-range reduction (arguments reach 2^9 * |x|)
+    if (p < 3) return p == 0 ? x0 : (p == 1 ? x1 : x2);
+    if (m >= 6 * spec.nfreq) return 0.f;                      // zero padding slots
+    return is_cos ? cv : sv;
+}
+
+// split 8 f32 into bf16 hi and lo chunks (RNE both times; x - float(hi) is exact in f32)
+template <bool RELU>
+__device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        f32x2 a = {v[2 * p], v[2 * p + 1]};
+        if (RELU) {
+            a.x = fmaxf(a.x, 0.f);
+            a.y = fmaxf(a.y, 0.f);
+        }
+        const bf16x2 hb = __builtin_convertvector(a, bf16x2);
+        const f32x2 hf = __builtin_convertvector(hb, f32x2);
+        const f32x2 r = a - hf;
+        const bf16x2 lb = __builtin_convertvector(r, bf16x2);
+        h[p] = __builtin_bit_cast(unsigned, hb);
+        l[p] = __builtin_bit_cast(unsigned, lb);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// ---- one run of k-steps: acc[mb] += W(block) * X(rows row0 + 32*mb ..) -------------------------------
+//   wsrc    : buffer descriptor of the weight image (SGPRs); voff = lane*16 is the only per-lane address
+//   soff    : wave-uniform byte offset of (stage, block, first step of the run)
+//   xh      : this lane's pointer into the activation array at (first chunk + g, hi half, row0 + lane&31)
+//   nsteps  : even
+typedef __attribute__((vector_size(16))) unsigned int v4u;
+__device__ __forceinline__ bf16x8 ld_w(__amdgpu_buffer_rsrc_t wsrc, int voff, int soff) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wsrc, voff, soff, 0));
+}
+
+template <int MB, int PREC>
+__device__ __forceinline__ void k_run(f32x16 (&acc)[MB], __amdgpu_buffer_rsrc_t wsrc, int voff, int soff, const uint4* xh,
+                                      int nsteps) {
+    // 2-step-deep register prefetch of the weight stream (L2 -> VGPR); the image is padded so the
+    // reads past the last step of the net stay in bounds.
+    bf16x8 wh[2], wl[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        wh[u] = ld_w(wsrc, voff, soff + u * nm::kStepBytes);
+        if (PREC == NM_PREC_BF16X3) wl[u] = ld_w(wsrc, voff, soff + u * nm::kStepBytes + 1024);
+    }
+#pragma unroll 1
+    for (int t = 0; t < nsteps; t += 2) {
+        bf16x8 nh[2], nl[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            nh[u] = ld_w(wsrc, voff, soff + (t + 2 + u) * nm::kStepBytes);
+            if (PREC == NM_PREC_BF16X3) nl[u] = ld_w(wsrc, voff, soff + (t + 2 + u) * nm::kStepBytes + 1024);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint4* ph = xh + (t + u) * (2 * kChunkU4);
+            const uint4* pl = ph + kLoU4;
+            bf16x8 bh[MB], bl[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                bh[mb] = as_bf16x8(ph[mb * 32]);
+                if (PREC == NM_PREC_BF16X3) bl[mb] = as_bf16x8(pl[mb * 32]);
+            }
+            if (PREC == NM_PREC_BF16X3) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[u], bl[mb], acc[mb], 0, 0, 0);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[u], bh[mb], acc[mb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[u], bh[mb], acc[mb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            wh[u] = nh[u];
+            if (PREC == NM_PREC_BF16X3) wl[u] = nl[u];
+        }
+    }
+}
+
+// accumulator init = bias of feature (reg&3) + 8*(reg>>2) + 4*g of this block
+template <int MB>
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[MB], const float* __restrict__ bias_blk, int g) {
+    float b[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(bias_blk + 8 * q + 4 * g);
+        b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = b[r];
+}
+
+// write a wave's accumulators as the next layer's input: block blk, sample rows row0 + 32*mb + s
+template <int MB, bool RELU, int PREC>
+__device__ __forceinline__ void store_act(const f32x16 (&acc)[MB], uint4* lds, int blk, int row0, int g, int s) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[mb][8 * qp + e];
+            uint4 hi, lo;
+            split8<RELU>(v, hi, lo);
+            const int idx = H_BASE + (4 * blk + 2 * qp + g) * kChunkU4 + row0 + 32 * mb + s;
+            lds[idx] = hi;
+            if (PREC == NM_PREC_BF16X3) lds[idx + kLoU4] = lo;
+        }
+    }
+}
+
+// fill `nchunks` PE chunks for the tile: work item = (chunk, sample); 8 features -> one b128 write per array
+__device__ __forceinline__ void fill_pe(uint4* lds, int nchunks, bool is_dir, const MlpArgs& a, int64_t base, int tid) {
+    const PeSpec spec = is_dir ? a.dir : a.pos;
+    const float* tab = a.petab + (is_dir ? 96 : 0);
+    for (int item = tid; item < nchunks * kTileM; item += kThreads) {
+        const int c = item >> 7, row = item & (kTileM - 1);
+        int64_t i = base + row;
+        if (i >= a.n) i = a.n - 1;                              // tail rows recompute the last sample (never stored)
+        float x0, x1, x2;
+        if (a.in_mode == 0) {
+            const float* src = (is_dir ? a.dirs : a.pts) + i * 3;
+            x0 = src[0]; x1 = src[1]; x2 = src[2];
+        } else {
+            const int64_t r = i / a.S;
+            const float* d = a.direction + r * 3;
+            if (is_dir) {
+                x0 = d[0]; x1 = d[1]; x2 = d[2];                // ray_utils.py:132
+            } else {
+                const float zz = a.z[i];
+                const float* o = a.origin + r * 3;
+                x0 = o[0] + d[0] * zz;                          // ray_utils.py:131 (two roundings: built with -ffp-contract=off)
+                x1 = o[1] + d[1] * zz;
+                x2 = o[2] + d[2] * zz;
+            }
+        }
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = pe_feature(8 * c + e, x0, x1, x2, spec, tab);
+        uint4 hi, lo;
+        split8<false>(v, hi, lo);
+        lds[P_BASE + c * kChunkU4 + row] = hi;
+        lds[P_BASE + c * kChunkU4 + kLoU4 + row] = lo;
+    }
+}
+
+// debug: dump `width` features of the tile from the H (or P) arrays as f32 [n, width] in natural order
+__device__ __forceinline__ void dump_act(const uint4* lds, bool from_pe, int width, const MlpArgs& a, int64_t base, int tid) {
+    const unsigned short* hi = reinterpret_cast<const unsigned short*>(lds + (from_pe ? P_BASE : H_BASE));
+    const unsigned short* lo = hi + kLoU4 * 8;
+    for (int item = tid; item < kTileM * width; item += kThreads) {
+        const int row = item / width, n = item - row * width;
+        if (base + row >= a.n) continue;
+        const int c = from_pe ? (n >> 3) : nm::feature_chunk(n);
+        const int e = from_pe ? (n & 7) : nm::feature_elem(n);
+        const int off = (c * kChunkU4 + row) * 8 + e;
+        const float h = __uint_as_float((unsigned)hi[off] << 16);
+        const float l = __uint_as_float((unsigned)lo[off] << 16);
+        a.dbg[(base + row) * width + n] = h + l;
+    }
+}
+
+template <int PREC>
+__global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) {
+    __shared__ uint4 lds[LDS_U4];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, s = lane & 31;
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4*>(a.wpack), 0, (int)(nm::kWeightBytes + nm::kWeightPadBytes), 0x00020000);
+    const int voff = lane * 16;                                   // the only per-lane part of a weight address
+    const int64_t ntiles = (a.n + kTileM - 1) / kTileM;
+
+#pragma unroll 1
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = tile * kTileM;
+        // ---------------- position PE -> P
+        fill_pe(lds, nm::kPeChunks, false, a, base, tid);
+        __syncthreads();
+        if (a.stop_stage == -1) { dump_act(lds, true, 64, a, base, tid); __syncthreads(); continue; }
+
+        // ---------------- stages 0..7: 256-wide ReLU layers (wave w = output block w, all 4 sample blocks)
+        f32x16 acc[4];
+        bool stopped = false;
+#pragma unroll 1
+        for (int st = 0; st <= 7; ++st) {
+            const nm::StageShape sh = nm::stage_shape(st);
+            init_bias<4>(acc, a.bias + nm::stage_b_off(st) + 32 * w, g);
+            int soff = (int)nm::stage_w_off(st) + w * sh.steps * nm::kStepBytes;
+            if (sh.pe_steps) {
+                k_run<4, PREC>(acc, wsrc, voff, soff, lds + P_BASE + g * kChunkU4 + s, sh.pe_steps);
+                soff += sh.pe_steps * nm::kStepBytes;
+            }
+            if (sh.steps > sh.pe_steps)
+                k_run<4, PREC>(acc, wsrc, voff, soff, lds + H_BASE + g * kChunkU4 + s, sh.steps - sh.pe_steps);
+            __syncthreads();                                      // every wave has finished reading H (and P)
+            store_act<4, true, PREC>(acc, lds, w, 0, g, s);
+            if (st == 5) fill_pe(lds, 4, true, a, base, tid);     // P is free after the skip layer: direction PE -> P[0..3]
+            __syncthreads();
+            if (a.stop_stage == st) { dump_act(lds, false, 256, a, base, tid); stopped = true; break; }
+        }
+        if (stopped) { __syncthreads(); continue; }
+
+        // ---------------- stage 8: feature (linear, 256) + alpha block (waves 0..3, sample block w)
+        float sigma = 0.f;
+        {
+            const nm::StageShape sh = nm::stage_shape(8);
+            init_bias<4>(acc, a.bias + nm::stage_b_off(8) + 32 * w, g);
+            k_run<4, PREC>(acc, wsrc, voff, (int)nm::stage_w_off(8) + w * sh.steps * nm::kStepBytes,
+                           lds + H_BASE + g * kChunkU4 + s, sh.steps);
+            if (w < 4) {
+                f32x16 aacc[1];
+                init_bias<1>(aacc, a.bias + nm::stage_b_off(8) + 32 * 8, g);
+                k_run<1, PREC>(aacc, wsrc, voff, (int)nm::stage_w_off(8) + 8 * sh.steps * nm::kStepBytes,
+                               lds + H_BASE + g * kChunkU4 + 32 * w + s, sh.steps);
+                sigma = aacc[0][0];                               // feature row 0 of the block: lanes 0..31 (g == 0)
+            }
+            __syncthreads();
+            store_act<4, false, PREC>(acc, lds, w, 0, g, s);
+            __syncthreads();
+            if (a.stop_stage == 8) { dump_act(lds, false, 256, a, base, tid); __syncthreads(); continue; }
+        }
+
+        // ---------------- stage 9: views layer, K = feature(256) ++ d_pe(32), N = 128, ReLU
+        {
+            const nm::StageShape sh = nm::stage_shape(9);
+            const int nb = w & 3, row0 = 64 * (w >> 2);
+            f32x16 vacc[2];
+            init_bias<2>(vacc, a.bias + nm::stage_b_off(9) + 32 * nb, g);
+            const int soff = (int)nm::stage_w_off(9) + nb * sh.steps * nm::kStepBytes;
+            k_run<2, PREC>(vacc, wsrc, voff, soff, lds + H_BASE + g * kChunkU4 + row0 + s, sh.steps - sh.pe_steps);
+            k_run<2, PREC>(vacc, wsrc, voff, soff + (sh.steps - sh.pe_steps) * nm::kStepBytes,
+                           lds + P_BASE + g * kChunkU4 + row0 + s, sh.pe_steps);
+            __syncthreads();
+            store_act<2, true, PREC>(vacc, lds, nb, row0, g, s);
+            __syncthreads();
+            if (a.stop_stage == 9) { dump_act(lds, false, 128, a, base, tid); __syncthreads(); continue; }
+        }
+
+        // ---------------- stage 10: rgb (rows 0..2 of one 32-feature block), waves 0..3 take sample block w
+        if (w < 4) {
+            const nm::StageShape sh = nm::stage_shape(10);
+            f32x16 racc[1];
+            init_bias<1>(racc, a.bias + nm::stage_b_off(10), g);
+            k_run<1, PREC>(racc, wsrc, voff, (int)nm::stage_w_off(10), lds + H_BASE + g * kChunkU4 + 32 * w + s, sh.steps);
+            const int64_t i = base + 32 * w + s;
+            if (g == 0 && i < a.n)                                // rows 0,1,2 = regs 0,1,2 of the g == 0 half
+                reinterpret_cast<float4*>(a.out)[i] = make_float4(racc[0][0], racc[0][1], racc[0][2], sigma * a.sigma_scale);
+        }
+        __syncthreads();                                          // H / P are rewritten by the next tile
+    }
+}
+
+}  // namespace
+
+namespace nm {
+
+int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
+                    const float* z, int64_t n, int S, int in_mode, int precision, int stop_stage, float sigma_scale, float* out,
+                    float* dbg, hipStream_t stream) {
+    MlpArgs a;
+    a.wpack = reinterpret_cast<const uint4*>(L.wpack);
+    a.bias = L.bias;
+    a.petab = L.petab;
+    a.pts = pts; a.dirs = dirs; a.origin = origin; a.direction = direction; a.z = z;
+    a.out = out; a.dbg = dbg; a.n = n; a.S = S; a.in_mode = in_mode; a.stop_stage = stop_stage; a.sigma_scale = sigma_scale;
+    a.pos = PeSpec{L.pe_kind, L.pos_nfreq};
+    a.dir = PeSpec{L.pe_kind, L.dir_nfreq};
+    const int64_t ntiles = (n + kTileM - 1) / kTileM;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int grid = (int)(ntiles < cus ? ntiles : cus);          // one 160 KB workgroup per CU, grid-stride over tiles
+    if (precision == NM_PREC_BF16X3)
+        hipLaunchKernelGGL(nerf_mlp_kernel<NM_PREC_BF16X3>, dim3(grid), dim3(kThreads), 0, stream, a);
+    else
+        hipLaunchKernelGGL(nerf_mlp_kernel<NM_PREC_BF16>, dim3(grid), dim3(kThreads), 0, stream, a);
+    return check_launch("nerf_mlp_kernel");
+}
+
+}  // namespace nm

@@ -1,0 +1,23 @@
+// Launch descriptors shared by mlp_host.hip (dispatch) and the two kernel files.
+#pragma once
+#include "common.h"
+
+namespace nm {
+
+struct MlpLaunch {
+    const void* wpack; const float* bias; const float* petab;
+    int pe_kind, pos_nfreq, dir_nfreq;
+};
+struct RefLaunch {
+    const float* wt; const float* bias; int off[12]; int boff[12]; const float* petab;
+    int pe_kind, pos_nfreq, dir_nfreq;
+};
+
+int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
+                    const float* z, int64_t n, int S, int in_mode, int precision, int stop_stage, float sigma_scale, float* out,
+                    float* dbg, hipStream_t stream);
+int launch_mlp_ref(const RefLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
+                   const float* z, int64_t n, int S, int in_mode, int stop_stage, float sigma_scale, float* out, float* dbg,
+                   hipStream_t stream);
+
+}  // namespace nm

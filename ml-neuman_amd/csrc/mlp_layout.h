@@ -1,0 +1,87 @@
+// Layout contract between the host packer (mlp_pack.cpp), the MFMA kernel (mlp.hip) and the numpy
+// emulator in tests/test_mlp_pack.py.  Pure constexpr, host + device.
+//
+// The net (reference models/vanilla.py:95-152, options/options.py:52-71): 8 x 256 ReLU layers with
+// cat([x_pe, h]) after layer 4, then alpha (256->1) and feature (256->256, linear), views
+// (cat([feature, d_pe]) 283 -> 128, ReLU), rgb (128 -> 3).  It is executed as 11 GEMM "stages":
+//
+//   stage 0      K = x_pe(64 = 63 + zero pad)             N = 256   relu
+//   stage 1-4    K = h(256)                               N = 256   relu
+//   stage 5      K = x_pe(64) ++ h(256)                   N = 256   relu      (skip, vanilla.py:130-131)
+//   stage 6-7    K = h(256)                               N = 256   relu
+//   stage 8      K = h(256)                               N = 256 feature (linear) + 32-wide block whose
+//                                                             row 0 is alpha (vanilla.py:135-136)
+//   stage 9      K = feature(256) ++ d_pe(32 = 27 + pad)  N = 128   relu      (vanilla.py:137-141)
+//   stage 10     K = h(128)                               N = 32 (rows 0..2 = rgb, vanilla.py:143)
+//
+// GEMM orientation: D[feature][sample] = W[feature][k] * X[k][sample] on v_mfma_f32_32x32x16_bf16,
+// A operand = weights (32 output features x 16 k), B operand = activations (16 k x 32 samples).
+//
+// Activations live in LDS as 16-byte "chunks": chunk c of a sample holds 8 consecutive k-slots as
+// bf16; a k-step (16 k) reads chunks 2t (lanes 0-31) and 2t+1 (lanes 32-63).  The hi and lo halves of
+// the split-bf16 value are separate arrays with identical indexing.
+//
+// Which feature sits in k-slot (chunk c, element e) is fixed by what the epilogue can write with one
+// ds_write_b128: a lane of the 32x32 accumulator tile holds, for its sample, features
+// (reg&3) + 8*(reg>>2) + 4*(lane>>5); registers 8*qp .. 8*qp+7 (qp = 0,1) become one chunk.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define NM_HD __host__ __device__
+#else
+#define NM_HD
+#endif
+
+namespace nm {
+
+constexpr int kTileM = 128;      // samples per workgroup tile
+constexpr int kStages = 11;
+constexpr int kHChunks = 32;     // 256 features
+constexpr int kPeChunks = 8;     // 64 position-PE slots (dir PE uses the first 4)
+constexpr int kStepBytes = 2048; // one k-step of one 32-feature block: [hi|lo][64 lanes][8 bf16]
+
+struct StageShape {
+    int nblk;    // 32-feature output blocks (incl. the alpha block of stage 8)
+    int steps;   // k-steps (16 k each)
+    int pe_steps;  // of which read the PE buffer: before h for stage 0/5, after h for stage 9
+};
+
+NM_HD constexpr StageShape stage_shape(int s) {
+    return s == 0 ? StageShape{8, 4, 4}
+         : s == 5 ? StageShape{8, 20, 4}
+         : s == 8 ? StageShape{9, 16, 0}
+         : s == 9 ? StageShape{4, 18, 2}
+         : s == 10 ? StageShape{1, 8, 0}
+                   : StageShape{8, 16, 0};
+}
+
+// byte offset of stage s, block nb, k-step t inside the weight image
+NM_HD constexpr int64_t stage_w_off(int s) {
+    int64_t o = 0;
+    for (int i = 0; i < s; ++i) o += (int64_t)stage_shape(i).nblk * stage_shape(i).steps * kStepBytes;
+    return o;
+}
+NM_HD constexpr int64_t frag_off(int s, int nb, int t) {
+    return stage_w_off(s) + ((int64_t)nb * stage_shape(s).steps + t) * kStepBytes;
+}
+// float offset of stage s inside the bias image (32 floats per block, natural feature order)
+NM_HD constexpr int stage_b_off(int s) {
+    int o = 0;
+    for (int i = 0; i < s; ++i) o += stage_shape(i).nblk * 32;
+    return o;
+}
+constexpr int64_t kWeightBytes = stage_w_off(kStages);
+constexpr int64_t kWeightPadBytes = 4 * kStepBytes;   // the k-loop prefetches 2 steps past the end
+constexpr int kBiasFloats = stage_b_off(kStages);
+
+// feature held by k-slot (chunk c, element e) of a 256- or 128-wide activation written by the epilogue
+NM_HD constexpr int slot_feature(int c, int e) {
+    // c = 4*blk + 2*qp + h ;  feature = 32*blk + 8*(2*qp + (e>>2)) + 4*h + (e&3)
+    return 32 * (c >> 2) + 8 * (2 * ((c >> 1) & 1) + (e >> 2)) + 4 * (c & 1) + (e & 3);
+}
+// inverse: chunk and element of feature n
+NM_HD constexpr int feature_chunk(int n) { return 4 * (n >> 5) + 2 * ((n >> 4) & 1) + ((n >> 2) & 1); }
+NM_HD constexpr int feature_elem(int n) { return 4 * ((n >> 3) & 1) + (n & 3); }
+
+}  // namespace nm

@@ -1,0 +1,154 @@
+// SMPL-guided ray bounds and hit-ray compaction for gfx950.
+//
+// a2 geometry_guided_near_far (reference utils/ray_utils.py:197-233): the reference materialises four
+// [R,V,3] f32 tensors (4 x 169 MB at R=2048, V=6890).  Here one lane owns one ray and keeps min/max
+// in registers; the vertex index is wave-uniform so the vertex stream is read through the scalar
+// cache (s_load) and never occupies vector-memory bandwidth.  HBM traffic = 24 B in + 8 B out per ray.
+//
+// a3 compaction (reference utils/render_utils.py:199-212): boolean-mask indexing becomes a wave ballot
+// + popcount prefix inside the block and a two-level prefix sum across blocks; order is ascending ray
+// index like the reference's mask.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void near_far_kernel(const float* __restrict__ origin, const float* __restrict__ direction,
+                                                       int64_t R, const float* __restrict__ verts, int V, float tau2,
+                                                       float* __restrict__ near, float* __restrict__ far) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t r = i < R ? i : R - 1;
+    const float ox = origin[r * 3 + 0], oy = origin[r * 3 + 1], oz = origin[r * 3 + 2];
+    const float dx = direction[r * 3 + 0], dy = direction[r * 3 + 1], dz = direction[r * 3 + 2];
+    float n = INFINITY, f = -INFINITY;                                     // ray_utils.py:213-218 (NaN -> +-inf)
+#pragma unroll 4
+    for (int v = 0; v < V; ++v) {
+        const float vx = verts[v * 3 + 0] - ox, vy = verts[v * 3 + 1] - oy, vz = verts[v * 3 + 2] - oz;  // :209
+        const float z0 = vx * dx + vy * dy + vz * dz;                      // :210
+        const float nrm = sqrtf(vx * vx + vy * vy + vz * vz);              // torch.norm(orig_v, dim=2), :211
+        const float disc = tau2 - (nrm * nrm - z0 * z0);
+        if (disc >= 0.f) {                                                  // sqrt(negative) = NaN -> dropped
+            const float dzv = sqrtf(disc);
+            n = fminf(n, z0 - dzv);
+            f = fmaxf(f, z0 + dzv);
+        }
+    }
+    if (i < R) {
+        near[i] = n;
+        far[i] = f;
+    }
+}
+
+constexpr int kCompactBlock = 256;
+
+// pass 1: per-block number of hits
+__global__ __launch_bounds__(kCompactBlock) void count_hits_kernel(const float* __restrict__ near, const float* __restrict__ far,
+                                                                   int64_t R, int32_t* __restrict__ block_counts) {
+    __shared__ int wave_cnt[kCompactBlock / 64];
+    const int64_t i = blockIdx.x * (int64_t)kCompactBlock + threadIdx.x;
+    const bool hit = i < R && near[i] < far[i];
+    const unsigned long long b = __ballot(hit);
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0;
+        for (int w = 0; w < kCompactBlock / 64; ++w) c += wave_cnt[w];
+        block_counts[blockIdx.x] = c;
+    }
+}
+
+// pass 2: exclusive scan of the block counts (single block), totals into counts[0..1]
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(int32_t* __restrict__ block_counts, int nblocks, int64_t R,
+                                                           int32_t* __restrict__ counts) {
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nblocks ? block_counts[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) wave_tot[wid] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wave_tot[w];
+        const int carry = carry_s;
+        if (i < nblocks) block_counts[i] = carry + woff + inc - v;         // exclusive
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        counts[0] = carry_s;
+        counts[1] = (int32_t)(R - carry_s);
+    }
+}
+
+// pass 3: write the compacted index lists
+__global__ __launch_bounds__(kCompactBlock) void write_hits_kernel(const float* __restrict__ near, const float* __restrict__ far,
+                                                                   int64_t R, const int32_t* __restrict__ block_offsets,
+                                                                   int32_t* __restrict__ hit_idx, int32_t* __restrict__ miss_idx) {
+    __shared__ int wave_cnt[kCompactBlock / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t i = blockIdx.x * (int64_t)kCompactBlock + threadIdx.x;
+    const bool in = i < R;
+    const bool hit = in && near[i] < far[i];
+    const unsigned long long b = __ballot(hit);
+    if (lane == 0) wave_cnt[wid] = __popcll(b);
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wid; ++w) woff += wave_cnt[w];
+    const int rank = woff + __popcll(b & ((1ull << lane) - 1ull));          // hits before this lane in the block
+    const int hoff = block_offsets[blockIdx.x];
+    if (hit) {
+        hit_idx[hoff + rank] = (int32_t)i;
+    } else if (in && miss_idx) {
+        const int64_t before = blockIdx.x * (int64_t)kCompactBlock + threadIdx.x;   // rays before this one
+        miss_idx[before - (hoff + rank)] = (int32_t)i;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nm_near_far(const float* origin, const float* direction, int64_t R, const float* verts, int V, double geo_threshold,
+                float* near, float* far, nm_stream_t stream) {
+    NM_REQUIRE(origin && direction && verts && near && far, "nm_near_far: null pointer");
+    NM_REQUIRE(R >= 0 && V >= 1, "nm_near_far: bad sizes");
+    if (R == 0) return NM_OK;
+    const float tau2 = (float)(geo_threshold * geo_threshold);             // python float ** 2, then f32 (ray_utils.py:211)
+    const int blocks = (int)((R + 255) / 256);
+    hipLaunchKernelGGL(near_far_kernel, dim3(blocks), dim3(256), 0, nm::as_stream(stream), origin, direction, R, verts, V,
+                       tau2, near, far);
+    return nm::check_launch("near_far_kernel");
+}
+
+int64_t nm_compact_workspace_ints(int64_t R) { return (R + kCompactBlock - 1) / kCompactBlock + 2; }
+
+int nm_compact_hits(const float* near, const float* far, int64_t R, int32_t* hit_idx, int32_t* miss_idx, int32_t* counts,
+                    int32_t* workspace, nm_stream_t stream) {
+    NM_REQUIRE(near && far && hit_idx && counts && workspace, "nm_compact_hits: null pointer");
+    NM_REQUIRE(R >= 0 && R < (1ll << 31), "nm_compact_hits: R out of range");
+    hipStream_t st = nm::as_stream(stream);
+    const int nblocks = (int)((R + kCompactBlock - 1) / kCompactBlock);
+    if (nblocks > 0) {
+        hipLaunchKernelGGL(count_hits_kernel, dim3(nblocks), dim3(kCompactBlock), 0, st, near, far, R, workspace);
+        if (int e = nm::check_launch("count_hits_kernel")) return e;
+    }
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, workspace, nblocks, R, counts);
+    if (int e = nm::check_launch("scan_blocks_kernel")) return e;
+    if (nblocks > 0) {
+        hipLaunchKernelGGL(write_hits_kernel, dim3(nblocks), dim3(kCompactBlock), 0, st, near, far, R, workspace, hit_idx,
+                           miss_idx);
+        if (int e = nm::check_launch("write_hits_kernel")) return e;
+    }
+    return NM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,406 @@
+// Per-ray kernels of the NeuMan hot path for gfx950: stratified sampling, alpha compositing,
+// hierarchical (inverse-CDF) resampling with a fused sorted merge, two-list merge, row gather/scatter.
+//
+// All of them are HBM-bound, one wavefront (64 lanes) per ray with the ray's sample state staged in
+// LDS; reads and writes of a ray's S samples are contiguous so every wave instruction is a coalesced
+// 256 B - 1 KiB transaction.  Built with -ffp-contract=off: the reference evaluates `a*b + c` as two
+// roundings (torch elementwise ops), so nothing here may be fused unless written as fmaf().
+#include "common.h"
+
+namespace {
+
+constexpr int kRayWavesPerBlock = 4;
+
+// ------------------------------------------------------------------------------------------------
+// a4 ray_to_samples (reference utils/ray_utils.py:96-135)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lerp_z(float near, float far, float t, int lindisp) {
+    if (!lindisp) return near * (1.f - t) + far * t;                      // ray_utils.py:112
+    return 1.f / (1.f / near * (1.f - t) + 1.f / far * t);                 // ray_utils.py:114
+}
+
+__global__ __launch_bounds__(256) void ray_to_samples_kernel(
+    const float* __restrict__ origin, const float* __restrict__ direction, const float* __restrict__ near,
+    const float* __restrict__ far, int64_t R, int S, const float* __restrict__ t_vals, int lindisp,
+    const float* __restrict__ t_rand, float* __restrict__ pts, float* __restrict__ dirs, float* __restrict__ z_vals) {
+    const int64_t total = R * (int64_t)S;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / S;
+        const int s = (int)(i - r * S);
+        const float n = near[r], f = far[r];
+        float z = lerp_z(n, f, t_vals[s], lindisp);
+        if (t_rand) {                                                       // ray_utils.py:116-129
+            const float zm = s > 0 ? lerp_z(n, f, t_vals[s - 1], lindisp) : z;
+            const float zp = s < S - 1 ? lerp_z(n, f, t_vals[s + 1], lindisp) : z;
+            const float lower = s > 0 ? .5f * (z + zm) : z;
+            const float upper = s < S - 1 ? .5f * (zp + z) : z;
+            z = lower + (upper - lower) * t_rand[i];
+        }
+        z_vals[i] = z;
+        const float dx = direction[r * 3 + 0], dy = direction[r * 3 + 1], dz = direction[r * 3 + 2];
+        if (pts) {                                                          // ray_utils.py:131
+            pts[i * 3 + 0] = origin[r * 3 + 0] + dx * z;
+            pts[i * 3 + 1] = origin[r * 3 + 1] + dy * z;
+            pts[i * 3 + 2] = origin[r * 3 + 2] + dz * z;
+        }
+        if (dirs) {                                                         // ray_utils.py:132
+            dirs[i * 3 + 0] = dx;
+            dirs[i * 3 + 1] = dy;
+            dirs[i * 3 + 2] = dz;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void z_to_points_kernel(const float* __restrict__ origin, const float* __restrict__ direction,
+                                                          const float* __restrict__ z_vals, int64_t R, int S,
+                                                          float* __restrict__ pts, float* __restrict__ dirs) {
+    const int64_t total = R * (int64_t)S;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / S;
+        const float z = z_vals[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float d = direction[r * 3 + c];
+            if (pts) pts[i * 3 + c] = origin[r * 3 + c] + d * z;           // ray_utils.py:153
+            if (dirs) dirs[i * 3 + c] = d;                                  // ray_utils.py:155
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a5 raw2outputs (reference utils/render_utils.py:69-105): one wave per ray.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ __launch_bounds__(64 * kRayWavesPerBlock) void composite_kernel(
+    const float4* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ rays_d, int64_t R, int S,
+    int white_bkg, const float* __restrict__ noise, float* __restrict__ rgb, float* __restrict__ disp,
+    float* __restrict__ acc, float* __restrict__ weights, float* __restrict__ depth) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = blockIdx.x * (int64_t)kRayWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * kRayWavesPerBlock;
+    for (int64_t r = wave0; r < R; r += nwaves) {
+        const float dx = rays_d[r * 3 + 0], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
+        const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);            // render_utils.py:88
+        const float* zr = z_vals + r * S;
+        float t_carry = 1.f;
+        float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+        for (int c0 = 0; c0 < S; c0 += 64) {
+            const int s = c0 + lane;
+            const bool valid = s < S;
+            float w = 0.f, f = 1.f;
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            float z = 0.f;
+            if (valid) {
+                q = raw[r * S + s];
+                z = zr[s];
+                float dist = (s + 1 < S) ? (zr[s + 1] - z) : 1e10f;         // render_utils.py:85-86
+                dist = dist * dnorm;
+                float sigma = q.w;
+                if (noise) sigma = sigma + noise[r * S + s];               // render_utils.py:93-94
+                const float alpha = 1.f - expf(-fmaxf(sigma, 0.f) * dist);  // render_utils.py:81
+                w = alpha;
+                f = 1.f - alpha + 1e-10f;                                   // render_utils.py:95
+            }
+            const float incl = wave_scan_mul(f, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.f;
+            w = w * (t_carry * excl);
+            t_carry = t_carry * __shfl(incl, 63, 64);
+            if (valid) {
+                if (weights) weights[r * S + s] = w;
+                sr += w * sigmoidf_(q.x);                                   // render_utils.py:90, 96
+                sg += w * sigmoidf_(q.y);
+                sb += w * sigmoidf_(q.z);
+                sd += w * z;                                                // render_utils.py:98
+                sa += w;                                                    // render_utils.py:100
+            }
+        }
+        sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
+        if (lane == 0) {
+            if (white_bkg) {                                                // render_utils.py:102-103
+                const float bg = 1.f - sa;
+                sr = sr + bg; sg = sg + bg; sb = sb + bg;
+            }
+            rgb[r * 3 + 0] = sr; rgb[r * 3 + 1] = sg; rgb[r * 3 + 2] = sb;
+            depth[r] = sd;
+            acc[r] = sa;
+            if (disp) {
+                const float q = sd / sa;                                    // NaN when acc == 0, as torch.max propagates it
+                const float m = (q != q) ? q : fmaxf(1e-10f, q);            // render_utils.py:99
+                disp[r] = 1.f / m;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a6/a7 sample_pdf (det) + ray_to_importance_samples (reference utils/ray_utils.py:138-194)
+// one wave per ray; per-wave LDS: bins[B] | cdf[B] | zs[N]   (z itself is re-read from global / L1)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int upper_bound_lds(const float* a, int n, float v) {  // first i with a[i] > v
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] > v) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+__device__ __forceinline__ int lower_bound_lds(const float* a, int n, float v) {  // first i with a[i] >= v
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// MODE 0: bins/weights given (sample_pdf).  MODE 1: derive from z/w (importance), optionally merge.
+template <int MODE>
+__global__ __launch_bounds__(64 * kRayWavesPerBlock) void sample_pdf_kernel(
+    const float* __restrict__ in_a /* bins [R,B] | z [R,S] */, const float* __restrict__ in_w /* weights [R,B-1] | w [R,S] */,
+    int64_t R, int B, const float* __restrict__ u, int N, int including_old, float* __restrict__ out) {
+    extern __shared__ float lds_f[];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int S = B + 1;                       // MODE 1: samples per ray
+    const int per_wave = 2 * B + N + (MODE == 1 ? S : 0);
+    float* bins = lds_f + wib * per_wave;
+    float* cdf = bins + B;
+    float* zs = cdf + B;
+    float* zl = zs + N;                        // MODE 1 only: the ray's coarse z
+    const int nW = B - 1;                      // number of pdf weights
+    // block-uniform trip count so __syncthreads() is legal; a wave past the end idles on r = R-1 without storing
+    for (int64_t r0 = blockIdx.x * (int64_t)kRayWavesPerBlock; r0 < R; r0 += (int64_t)gridDim.x * kRayWavesPerBlock) {
+        const bool live = r0 + wib < R;
+        const int64_t r = live ? r0 + wib : R - 1;
+        // ---- bins and (weights + 1e-5)
+        float wsum = 0.f;
+        if (MODE == 0) {
+            for (int i = lane; i < B; i += 64) bins[i] = in_a[r * B + i];
+            for (int i = lane; i < nW; i += 64) wsum += in_w[r * nW + i] + 1e-5f;
+        } else {
+            const float* zr = in_a + r * S;
+            for (int i = lane; i < S; i += 64) zl[i] = zr[i];
+            for (int i = lane; i < B; i += 64) bins[i] = .5f * (zr[i + 1] + zr[i]);     // ray_utils.py:148
+            for (int i = lane; i < nW; i += 64) wsum += in_w[r * S + 1 + i] + 1e-5f;     // weights[..., 1:-1], :149
+        }
+        wsum = wave_sum(wsum);                                                           // ray_utils.py:167
+        // ---- cdf = [0, cumsum(pdf)]                                                   // ray_utils.py:168-169
+        float carry = 0.f;
+        if (lane == 0) cdf[0] = 0.f;
+        for (int c0 = 0; c0 < nW; c0 += 64) {
+            const int i = c0 + lane;
+            float p = 0.f;
+            if (i < nW) {
+                const float wv = (MODE == 0 ? in_w[r * nW + i] : in_w[r * S + 1 + i]) + 1e-5f;
+                p = wv / wsum;
+            }
+            const float inc = wave_scan_add(p, lane);
+            if (i < nW) cdf[i + 1] = carry + inc;
+            carry = carry + __shfl(inc, 63, 64);
+        }
+        __syncthreads();
+        // ---- invert the cdf at u                                                      // ray_utils.py:180-192
+        float run_max = -INFINITY;
+        for (int c0 = 0; c0 < N; c0 += 64) {
+            const int j = c0 + lane;
+            float smp = -INFINITY;
+            if (j < N) {
+                const float uj = u[j];
+                const int inds = upper_bound_lds(cdf, B, uj);                            // searchsorted(right=True)
+                const int below = max(0, inds - 1);
+                const int above = min(B - 1, inds);
+                const float cdf0 = cdf[below], cdf1 = cdf[above];
+                const float b0 = bins[below], b1 = bins[above];
+                float denom = cdf1 - cdf0;
+                if (denom < 1e-5f) denom = 1.f;
+                const float t = (uj - cdf0) / denom;
+                smp = b0 + t * (b1 - b0);
+            }
+            if (MODE == 1 && including_old) {
+                // torch.sort fixes the (1-ulp, rare) inversions of the inverse-CDF output; a running
+                // max does the same to the values the rank merge below relies on.
+                float m = wave_scan_max(smp, lane);
+                m = fmaxf(m, run_max);
+                run_max = __shfl(m, 63, 64);
+                if (j < N) zs[j] = m;
+            } else if (j < N && live) {
+                out[r * N + j] = smp;
+            }
+        }
+        __syncthreads();
+        if (MODE == 1 && including_old && live) {
+            // ---- rank merge of z (S, sorted) and zs (N, sorted) == sort(cat)              // ray_utils.py:151-152
+            float* o = out + r * (int64_t)(S + N);
+            for (int i = lane; i < S; i += 64) {
+                const float v = zl[i];
+                o[i + lower_bound_lds(zs, N, v)] = v;
+            }
+            for (int j = lane; j < N; j += 64) {
+                const float v = zs[j];
+                o[j + upper_bound_lds(zl, S, v)] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a13 two-list sorted merge with raw gather (reference utils/render_utils.py:330-337, 441-448)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kRayWavesPerBlock) void merge_sorted_kernel(
+    const float* __restrict__ za, const float4* __restrict__ rawa, int Sa, const float* __restrict__ zb,
+    const float4* __restrict__ rawb, int Sb, int64_t R, float* __restrict__ z_out, float4* __restrict__ raw_out) {
+    extern __shared__ float lds_f[];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    float* a = lds_f + wib * (Sa + Sb);
+    float* b = a + Sa;
+    for (int64_t r0 = blockIdx.x * (int64_t)kRayWavesPerBlock; r0 < R; r0 += (int64_t)gridDim.x * kRayWavesPerBlock) {
+        const bool live = r0 + wib < R;
+        const int64_t r = live ? r0 + wib : R - 1;
+        for (int i = lane; i < Sa; i += 64) a[i] = za[r * Sa + i];
+        for (int i = lane; i < Sb; i += 64) b[i] = zb[r * Sb + i];
+        __syncthreads();
+        const int64_t ob = r * (int64_t)(Sa + Sb);
+        for (int i = lane; i < Sa && live; i += 64) {         // ties: list a first (stable)
+            const float v = a[i];
+            const int k = i + lower_bound_lds(b, Sb, v);
+            z_out[ob + k] = v;
+            raw_out[ob + k] = rawa[r * Sa + i];
+        }
+        for (int j = lane; j < Sb && live; j += 64) {
+            const float v = b[j];
+            const int k = j + upper_bound_lds(a, Sa, v);
+            z_out[ob + k] = v;
+            raw_out[ob + k] = rawb[r * Sb + j];
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// row gather / scatter (boolean-mask indexing, reference utils/render_utils.py:206-212, 231-233)
+// ------------------------------------------------------------------------------------------------
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                   const int32_t* __restrict__ n_dev, int64_t n_max, int width,
+                                                   float* __restrict__ dst) {
+    const int64_t n = n_dev ? min((int64_t)n_dev[0], n_max) : n_max;
+    const int64_t total = n * width;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / width;
+        const int c = (int)(i - row * width);
+        const int64_t j = idx[row];
+        if (SCATTER) dst[j * width + c] = src[i];
+        else dst[i] = src[j * width + c];
+    }
+}
+
+inline int grid_for(int64_t work_items, int per_block, int max_blocks = 256 * 16) {
+    int64_t b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nm_ray_to_samples(const float* origin, const float* direction, const float* near, const float* far, int64_t R, int S,
+                      const float* t_vals, int lindisp, const float* t_rand, float* pts, float* dirs, float* z_vals,
+                      nm_stream_t stream) {
+    NM_REQUIRE(origin && direction && near && far && t_vals && z_vals, "nm_ray_to_samples: null pointer");
+    NM_REQUIRE(R >= 0 && S >= 1, "nm_ray_to_samples: bad sizes R=%lld S=%d", (long long)R, S);
+    if (R == 0) return NM_OK;
+    hipLaunchKernelGGL(ray_to_samples_kernel, dim3(grid_for(R * S, 256)), dim3(256), 0, nm::as_stream(stream), origin,
+                       direction, near, far, R, S, t_vals, lindisp, t_rand, pts, dirs, z_vals);
+    return nm::check_launch("ray_to_samples_kernel");
+}
+
+int nm_z_to_points(const float* origin, const float* direction, const float* z_vals, int64_t R, int S, float* pts,
+                   float* dirs, nm_stream_t stream) {
+    NM_REQUIRE(origin && direction && z_vals, "nm_z_to_points: null pointer");
+    NM_REQUIRE(R >= 0 && S >= 1, "nm_z_to_points: bad sizes");
+    if (R == 0) return NM_OK;
+    hipLaunchKernelGGL(z_to_points_kernel, dim3(grid_for(R * S, 256)), dim3(256), 0, nm::as_stream(stream), origin,
+                       direction, z_vals, R, S, pts, dirs);
+    return nm::check_launch("z_to_points_kernel");
+}
+
+int nm_composite(const float* raw, const float* z_vals, const float* rays_d, int64_t R, int S, int white_bkg,
+                 const float* noise, float* rgb, float* disp, float* acc, float* weights, float* depth,
+                 nm_stream_t stream) {
+    NM_REQUIRE(raw && z_vals && rays_d && rgb && acc && depth, "nm_composite: null pointer");
+    NM_REQUIRE(R >= 0 && S >= 1, "nm_composite: bad sizes R=%lld S=%d", (long long)R, S);
+    NM_REQUIRE((reinterpret_cast<uintptr_t>(raw) & 15) == 0, "nm_composite: raw must be 16-byte aligned");
+    if (R == 0) return NM_OK;
+    hipLaunchKernelGGL(composite_kernel, dim3(grid_for(R, kRayWavesPerBlock)), dim3(64 * kRayWavesPerBlock), 0,
+                       nm::as_stream(stream), reinterpret_cast<const float4*>(raw), z_vals, rays_d, R, S, white_bkg, noise,
+                       rgb, disp, acc, weights, depth);
+    return nm::check_launch("composite_kernel");
+}
+
+int nm_sample_pdf(const float* bins, const float* weights, int64_t R, int B, const float* u, int N, float* samples,
+                  nm_stream_t stream) {
+    NM_REQUIRE(bins && weights && u && samples, "nm_sample_pdf: null pointer");
+    NM_REQUIRE(R >= 0 && B >= 2 && N >= 1, "nm_sample_pdf: bad sizes");
+    const size_t lds = (size_t)kRayWavesPerBlock * (2 * B + N) * sizeof(float);
+    NM_REQUIRE(lds <= 64 * 1024, "nm_sample_pdf: B=%d N=%d exceed the per-wave LDS budget", B, N);
+    if (R == 0) return NM_OK;
+    hipLaunchKernelGGL(sample_pdf_kernel<0>, dim3(grid_for(R, kRayWavesPerBlock)), dim3(64 * kRayWavesPerBlock), lds,
+                       nm::as_stream(stream), bins, weights, R, B, u, N, 0, samples);
+    return nm::check_launch("sample_pdf_kernel<0>");
+}
+
+int nm_importance_z(const float* z_vals, const float* weights, int64_t R, int S, const float* u, int N,
+                    int including_old, float* z_out, nm_stream_t stream) {
+    NM_REQUIRE(z_vals && weights && u && z_out, "nm_importance_z: null pointer");
+    NM_REQUIRE(R >= 0 && S >= 3 && N >= 1, "nm_importance_z: bad sizes S=%d N=%d", S, N);
+    const int B = S - 1;
+    const size_t lds = (size_t)kRayWavesPerBlock * (2 * B + N + S) * sizeof(float);
+    NM_REQUIRE(lds <= 64 * 1024, "nm_importance_z: S=%d N=%d exceed the per-wave LDS budget", S, N);
+    if (R == 0) return NM_OK;
+    hipLaunchKernelGGL(sample_pdf_kernel<1>, dim3(grid_for(R, kRayWavesPerBlock)), dim3(64 * kRayWavesPerBlock), lds,
+                       nm::as_stream(stream), z_vals, weights, R, B, u, N, including_old, z_out);
+    return nm::check_launch("sample_pdf_kernel<1>");
+}
+
+int nm_merge_sorted(const float* za, const float* rawa, int Sa, const float* zb, const float* rawb, int Sb, int64_t R,
+                    float* z_out, float* raw_out, nm_stream_t stream) {
+    NM_REQUIRE(za && rawa && zb && rawb && z_out && raw_out, "nm_merge_sorted: null pointer");
+    NM_REQUIRE(R >= 0 && Sa >= 1 && Sb >= 1, "nm_merge_sorted: bad sizes");
+    NM_REQUIRE(((reinterpret_cast<uintptr_t>(rawa) | reinterpret_cast<uintptr_t>(rawb) | reinterpret_cast<uintptr_t>(raw_out)) & 15) == 0,
+               "nm_merge_sorted: raw arrays must be 16-byte aligned");
+    const size_t lds = (size_t)kRayWavesPerBlock * (Sa + Sb) * sizeof(float);
+    NM_REQUIRE(lds <= 64 * 1024, "nm_merge_sorted: Sa+Sb=%d exceeds the per-wave LDS budget", Sa + Sb);
+    if (R == 0) return NM_OK;
+    hipLaunchKernelGGL(merge_sorted_kernel, dim3(grid_for(R, kRayWavesPerBlock)), dim3(64 * kRayWavesPerBlock), lds,
+                       nm::as_stream(stream), za, reinterpret_cast<const float4*>(rawa), Sa, zb,
+                       reinterpret_cast<const float4*>(rawb), Sb, R, z_out, reinterpret_cast<float4*>(raw_out));
+    return nm::check_launch("merge_sorted_kernel");
+}
+
+int nm_gather_rows(const float* src, const int32_t* idx, const int32_t* n_dev, int64_t n_max, int width, float* dst,
+                   nm_stream_t stream) {
+    NM_REQUIRE(src && idx && dst, "nm_gather_rows: null pointer");
+    NM_REQUIRE(n_max >= 0 && width >= 1, "nm_gather_rows: bad sizes");
+    if (n_max == 0) return NM_OK;
+    hipLaunchKernelGGL(rows_kernel<false>, dim3(grid_for(n_max * width, 256)), dim3(256), 0, nm::as_stream(stream), src,
+                       idx, n_dev, n_max, width, dst);
+    return nm::check_launch("rows_kernel<gather>");
+}
+
+int nm_scatter_rows(const float* src, const int32_t* idx, const int32_t* n_dev, int64_t n_max, int width, float* dst,
+                    nm_stream_t stream) {
+    NM_REQUIRE(src && idx && dst, "nm_scatter_rows: null pointer");
+    NM_REQUIRE(n_max >= 0 && width >= 1, "nm_scatter_rows: bad sizes");
+    if (n_max == 0) return NM_OK;
+    hipLaunchKernelGGL(rows_kernel<true>, dim3(grid_for(n_max * width, 256)), dim3(256), 0, nm::as_stream(stream), src,
+                       idx, n_dev, n_max, width, dst);
+    return nm::check_launch("rows_kernel<scatter>");
+}
+
+}  // extern "C"

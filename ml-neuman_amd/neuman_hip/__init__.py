@@ -1,0 +1,42 @@
+"""neuman_hip -- MI355X-native NeuMan ray-march hot path behind the reference's own Python interface.
+
+    import neuman_hip
+    neuman_hip.install()        # inside the reference tree: rebinds utils.ray_utils / utils.render_utils /
+                                # models.vanilla so train-free scripts (render_360.py, render_test_views.py,
+                                # render_reposing.py, render_gathering.py) run on libneuman_hip.so unchanged.
+
+Sub-modules mirror the reference's: ``ray_utils`` (utils/ray_utils.py), ``render_utils`` (utils/render_utils.py:69-461),
+``vanilla`` (models/vanilla.py); ``parallel`` adds the ray-tile sharding for 1/2/4/8 GPUs; ``synthetic`` the
+asset-free workloads.  Nothing in this package evaluates the hot path on the CPU.
+"""
+from . import _lib, parallel, ray_utils, render_utils, synthetic, vanilla  # noqa: F401
+from ._lib import NeumanHipError  # noqa: F401
+
+__all__ = ["ray_utils", "render_utils", "vanilla", "parallel", "synthetic", "install", "NeumanHipError"]
+
+_RAY_FNS = ["shot_ray", "shot_rays", "shot_all_rays", "to_homogeneous", "ray_to_samples", "ray_to_importance_samples",
+            "sample_pdf", "geometry_guided_near_far", "geometry_guided_near_far_torch", "geometry_guided_near_far_np",
+            "warp_samples_to_canonical"]
+_RENDER_FNS = ["raw2outputs", "render_vanilla", "render_smpl_nerf", "render_hybrid_nerf", "render_hybrid_nerf_multi_persons"]
+_MODEL_CLASSES = ["Embedder", "NeRF", "Joiner", "build_nerf"]
+
+
+def install(ref_ray_utils=None, ref_render_utils=None, ref_vanilla=None):
+    """Rebind the hot-path names of the (already imported) reference modules to the HIP implementations.
+
+    Call it from the reference checkout before building `HumanNeRF`:
+        from utils import ray_utils, render_utils; from models import vanilla
+        neuman_hip.install(ray_utils, render_utils, vanilla)
+    With no arguments the three modules are imported by their reference names.
+    """
+    import importlib
+    ru = ref_ray_utils or importlib.import_module("utils.ray_utils")
+    rr = ref_render_utils or importlib.import_module("utils.render_utils")
+    mv = ref_vanilla or importlib.import_module("models.vanilla")
+    for n in _RAY_FNS:
+        setattr(ru, n, getattr(ray_utils, n))
+    for n in _RENDER_FNS:
+        setattr(rr, n, getattr(render_utils, n))
+    for n in _MODEL_CLASSES:
+        setattr(mv, n, getattr(vanilla, n))
+    return ru, rr, mv

@@ -1,0 +1,67 @@
+"""Multi-GPU frame rendering: ray tiles sharded across ranks, one gather per frame.
+
+Rays are independent, so there is no data-path collective: each rank renders the tiles t with
+``t % world == rank`` (interleaved, because human-hit rays cluster in the image centre and contiguous row
+blocks would be unbalanced) into a local [n_local, C] buffer; rank 0 receives one padded buffer per rank through
+``torch.distributed.gather`` (RCCL over xGMI with backend "nccl", gloo in the CPU tests) and permutes them into
+the frame.  The reference itself never shards renders (single device, sequential `rays_per_batch` loop).
+"""
+import torch
+import torch.distributed as dist
+
+
+def rank_world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def tile_ray_indices(total_rays, tile, rank, world, device='cpu'):
+    """Global ray indices owned by `rank`: tiles rank, rank+world, ... of `tile` consecutive rays each."""
+    n_tiles = (total_rays + tile - 1) // tile
+    tiles = torch.arange(rank, n_tiles, world, device=device)
+    idx = (tiles[:, None] * tile + torch.arange(tile, device=device)[None, :]).reshape(-1)
+    return idx[idx < total_rays]
+
+
+def max_local_rays(total_rays, tile, world):
+    n_tiles = (total_rays + tile - 1) // tile
+    return ((n_tiles + world - 1) // world) * tile
+
+
+def gather_frame(local, local_idx, total_rays, tile, dst=0):
+    """Assemble [total_rays, C] on rank `dst` from every rank's (local values, global indices).
+
+    local [n_local, C] float32; returns the frame on `dst`, None elsewhere.  One collective per frame; the payload
+    is padded to the largest shard so all ranks send equal sizes (a requirement of gather on RCCL).
+    """
+    rank, world = rank_world()
+    if world == 1:
+        out = torch.empty((total_rays, local.shape[1]), device=local.device, dtype=local.dtype)
+        out[local_idx] = local
+        return out
+    cap = max_local_rays(total_rays, tile, world)
+    send = torch.zeros((cap, local.shape[1]), device=local.device, dtype=local.dtype)
+    send[:local.shape[0]] = local
+    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, gather_list=bufs, dst=dst)
+    if rank != dst:
+        return None
+    out = torch.empty((total_rays, local.shape[1]), device=local.device, dtype=local.dtype)
+    for r in range(world):
+        idx = tile_ray_indices(total_rays, tile, r, world, device=local.device)
+        out[idx] = bufs[r][:idx.shape[0]]
+    return out
+
+
+def render_sharded(render_rays_fn, origins, dirs, tile=8192, dst=0):
+    """Render a frame's rays across all ranks.
+
+    render_rays_fn(o [n,3], d [n,3]) -> [n, C] on the same device.  `origins`/`dirs` are the full frame's rays
+    (every rank holds them; they are tiny next to the compute).  Returns [total, C] on rank dst, None elsewhere.
+    """
+    rank, world = rank_world()
+    total = origins.shape[0]
+    idx = tile_ray_indices(total, tile, rank, world, device=origins.device)
+    local = render_rays_fn(origins[idx].contiguous(), dirs[idx].contiguous())
+    return gather_frame(local, idx, total, tile, dst)

@@ -1,0 +1,261 @@
+"""HIP-backed mirror of the reference's utils/ray_utils.py (same function names and argument meaning).
+
+Ray generation (a1) stays on the host in float64 exactly like the reference; everything per-sample runs in
+libneuman_hip.so.  Functions that the reference defines on torch tensors take CUDA tensors here and raise
+on CPU tensors -- there is no host fallback.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+DEFAULT_GEO_THRESH = 0.2      # reference utils/constant.py:14
+PERTURB_EPSILON = 0.01        # reference utils/constant.py:15
+
+
+# ------------------------------------------------------------------------------------------------
+# a1 ray generation: host, float64 (reference ray_utils.py:13-38 + geometry/pcd_projector.py:85-153)
+# ------------------------------------------------------------------------------------------------
+def _unproject(xy, intrinsic, c2w):
+    """Pixel (x, y) at depth 1 -> world point.  K^-1 [x,y,1], then the 4x4 camera-to-world, all f64."""
+    pix = np.concatenate([xy.astype(np.float64), np.ones((xy.shape[0], 1))], axis=1)
+    cam = (np.linalg.inv(intrinsic) @ pix.T).T
+    world = (c2w @ np.concatenate([cam, np.ones((cam.shape[0], 1))], axis=1).T).T
+    return world[:, :3] / world[:, 3:4]
+
+
+def shot_rays(cap, xys):
+    """reference ray_utils.py:23-29: world points are cast to f32 before the (f64) centre is subtracted."""
+    c2w = cap.cam_pose.camera_to_world
+    centre = cap.cam_pose.camera_center_in_world
+    pts = _unproject(xys, cap.intrinsic_matrix, c2w).astype(np.float32)
+    orig = np.repeat(centre[None], xys.shape[0], axis=0)
+    d = pts - orig
+    return orig, d / np.linalg.norm(d, axis=1, keepdims=True)
+
+
+def shot_ray(cap, x, y):
+    """reference ray_utils.py:13-20."""
+    o, d = shot_rays(cap, np.array([[x, y]]))
+    return o[0], d[0]
+
+
+def shot_all_rays(cap):
+    """reference ray_utils.py:32-38: every pixel, row-major, integer pixel centres, float64 throughout."""
+    h, w = cap.size
+    ys, xs = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing='ij')
+    xy = np.stack([xs.reshape(-1), ys.reshape(-1)], axis=1)
+    centre = cap.cam_pose.camera_center_in_world
+    d = _unproject(xy, cap.intrinsic_matrix, cap.cam_pose.camera_to_world) - centre
+    d = d / np.linalg.norm(d, axis=1, keepdims=True)
+    return np.repeat(centre[None], d.shape[0], axis=0), d
+
+
+def to_homogeneous(pts):
+    """reference ray_utils.py:41-45."""
+    if isinstance(pts, torch.Tensor):
+        return torch.cat([pts, torch.ones_like(pts[..., 0:1])], dim=-1)
+    return np.concatenate([pts, np.ones_like(pts[..., 0:1])], axis=-1)
+
+
+# ------------------------------------------------------------------------------------------------
+# a4 / a6 / a7 sampling
+# ------------------------------------------------------------------------------------------------
+def _f32c(t, device=None):
+    t = t.to(device=device, dtype=torch.float32) if device is not None else t.to(torch.float32)
+    return t.contiguous()
+
+
+def sample_z(origin, direction, near, far, samples_per_ray, lindisp=False, perturb=0., want_points=False):
+    """Core of ray_to_samples on device tensors.  Returns (pts|None, dirs|None, z)."""
+    _lib.require_gpu()
+    dev = origin.device
+    R = origin.shape[0]
+    t_vals = torch.linspace(0., 1., steps=samples_per_ray, device=dev)                  # ray_utils.py:111
+    t_rand = None
+    if perturb > 0.:                                                                     # ray_utils.py:123-127
+        t_rand = torch.clip(torch.rand((R, samples_per_ray), device=dev), min=PERTURB_EPSILON, max=1 - PERTURB_EPSILON)
+    z = torch.empty((R, samples_per_ray), device=dev, dtype=torch.float32)
+    pts = torch.empty((R, samples_per_ray, 3), device=dev, dtype=torch.float32) if want_points else None
+    dirs = torch.empty((R, samples_per_ray, 3), device=dev, dtype=torch.float32) if want_points else None
+    _lib.check(_lib.lib().nm_ray_to_samples(
+        _lib.dev_ptr(origin, name='origin'), _lib.dev_ptr(direction, name='direction'), _lib.dev_ptr(near, name='near'),
+        _lib.dev_ptr(far, name='far'), R, samples_per_ray, _lib.dev_ptr(t_vals), int(bool(lindisp)), _lib.dev_ptr(t_rand),
+        _lib.dev_ptr(pts), _lib.dev_ptr(dirs), _lib.dev_ptr(z), _lib.stream_ptr()), "nm_ray_to_samples")
+    return pts, dirs, z
+
+
+def ray_to_samples(ray_batch, samples_per_ray, lindisp=False, perturb=0., device='cpu', append_t=None):
+    """reference ray_utils.py:96-135.  ray_batch tensors must live on the HIP device."""
+    o, d = _f32c(ray_batch['origin']), _f32c(ray_batch['direction'])
+    near, far = _f32c(ray_batch['near']).reshape(-1), _f32c(ray_batch['far']).reshape(-1)
+    assert near.shape[0] == far.shape[0] == o.shape[0]
+    pts, dirs, z = sample_z(o, d, near, far, samples_per_ray, lindisp, perturb, want_points=True)
+    if append_t is not None:
+        pts = torch.cat([pts, append_t.to(pts.device)], dim=-1)
+    return pts, dirs, z
+
+
+def z_to_points(origin, direction, z_vals):
+    """pts = o + d*z, dirs = d repeated (ray_utils.py:153-155) for given z."""
+    _lib.require_gpu()
+    R, S = z_vals.shape
+    pts = torch.empty((R, S, 3), device=z_vals.device, dtype=torch.float32)
+    dirs = torch.empty((R, S, 3), device=z_vals.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nm_z_to_points(_lib.dev_ptr(origin), _lib.dev_ptr(direction), _lib.dev_ptr(z_vals), R, S,
+                                         _lib.dev_ptr(pts), _lib.dev_ptr(dirs), _lib.stream_ptr()), "nm_z_to_points")
+    return pts, dirs
+
+
+def sample_pdf(bins, weights, N_samples, det=False, device='cpu'):
+    """reference ray_utils.py:164-194.  Only det=True (the reference hard-codes it at :149) is implemented."""
+    if not det:
+        raise NotImplementedError("sample_pdf(det=False) is never used by the reference (ray_utils.py:149)")
+    _lib.require_gpu()
+    bins, weights = _f32c(bins), _f32c(weights)
+    R, B = bins.shape
+    assert weights.shape == (R, B - 1)
+    u = torch.linspace(0., 1., steps=N_samples, device=bins.device)                     # ray_utils.py:173
+    out = torch.empty((R, N_samples), device=bins.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nm_sample_pdf(_lib.dev_ptr(bins), _lib.dev_ptr(weights), R, B, _lib.dev_ptr(u), N_samples,
+                                        _lib.dev_ptr(out), _lib.stream_ptr()), "nm_sample_pdf")
+    return out
+
+
+def importance_z(z_vals, weights, importance_samples_per_ray, including_old=True):
+    """z-only core of ray_to_importance_samples: mid-points, weights[1:-1], inverse CDF, sorted merge (one kernel)."""
+    _lib.require_gpu()
+    z_vals, weights = _f32c(z_vals), _f32c(weights.detach())
+    R, S = z_vals.shape
+    n_out = S + importance_samples_per_ray if including_old else importance_samples_per_ray
+    u = torch.linspace(0., 1., steps=importance_samples_per_ray, device=z_vals.device)
+    out = torch.empty((R, n_out), device=z_vals.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nm_importance_z(_lib.dev_ptr(z_vals), _lib.dev_ptr(weights), R, S, _lib.dev_ptr(u),
+                                          importance_samples_per_ray, int(bool(including_old)), _lib.dev_ptr(out),
+                                          _lib.stream_ptr()), "nm_importance_z")
+    return out
+
+
+def ray_to_importance_samples(ray_batch, z_vals, weights, importance_samples_per_ray, device='cpu', including_old=True,
+                              append_t=None):
+    """reference ray_utils.py:138-160."""
+    o, d = _f32c(ray_batch['origin']), _f32c(ray_batch['direction'])
+    z = importance_z(z_vals, weights, importance_samples_per_ray, including_old)
+    pts, dirs = z_to_points(o, d, z)
+    if append_t is not None:
+        pts = torch.cat([pts, append_t.to(pts.device)], dim=-1)
+    return pts, dirs, z
+
+
+# ------------------------------------------------------------------------------------------------
+# a2 / a3 SMPL-guided bounds and hit compaction
+# ------------------------------------------------------------------------------------------------
+def _near_far_dev(orig, direction, vert, geo_threshold):
+    R = orig.shape[0]
+    near = torch.empty(R, device=orig.device, dtype=torch.float32)
+    far = torch.empty(R, device=orig.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nm_near_far(_lib.dev_ptr(orig, name='orig'), _lib.dev_ptr(direction, name='dir'), R,
+                                      _lib.dev_ptr(vert, name='vert'), vert.shape[0], float(geo_threshold),
+                                      _lib.dev_ptr(near), _lib.dev_ptr(far), _lib.stream_ptr()), "nm_near_far")
+    return near, far
+
+
+def geometry_guided_near_far(orig, dir, vert, geo_threshold=DEFAULT_GEO_THRESH):
+    """reference ray_utils.py:197-233.  Dispatches on the type of `orig` like the reference: CUDA tensors in ->
+    tensors out; numpy in -> numpy out (the arrays make one round trip to the device, the arithmetic is the kernel's)."""
+    _lib.require_gpu()
+    if isinstance(orig, torch.Tensor):
+        return _near_far_dev(_f32c(orig), _f32c(dir), _f32c(vert if isinstance(vert, torch.Tensor) else torch.from_numpy(vert), orig.device),
+                             geo_threshold)
+    dev = torch.device('cuda')
+    n, f = _near_far_dev(_f32c(torch.from_numpy(np.ascontiguousarray(orig)), dev), _f32c(torch.from_numpy(np.ascontiguousarray(dir)), dev),
+                         _f32c(torch.from_numpy(np.ascontiguousarray(vert)), dev), geo_threshold)
+    return n.cpu().numpy(), f.cpu().numpy()
+
+
+geometry_guided_near_far_torch = geometry_guided_near_far
+geometry_guided_near_far_np = geometry_guided_near_far
+
+
+def compact_hits(near, far):
+    """Indices of rays with near < far (ascending) and of the others: the boolean masks of
+    render_utils.py:199-212 as int32 index lists.  One host sync to read the two counts."""
+    _lib.require_gpu()
+    R = near.shape[0]
+    dev = near.device
+    hit = torch.empty(R, device=dev, dtype=torch.int32)
+    miss = torch.empty(R, device=dev, dtype=torch.int32)
+    counts = torch.zeros(2, device=dev, dtype=torch.int32)
+    ws = torch.empty(int(_lib.lib().nm_compact_workspace_ints(R)), device=dev, dtype=torch.int32)
+    _lib.check(_lib.lib().nm_compact_hits(_lib.dev_ptr(near), _lib.dev_ptr(far), R, _lib.dev_ptr(hit, torch.int32),
+                                          _lib.dev_ptr(miss, torch.int32), _lib.dev_ptr(counts, torch.int32),
+                                          _lib.dev_ptr(ws, torch.int32), _lib.stream_ptr()), "nm_compact_hits")
+    n_hit, n_miss = counts.tolist()
+    return hit[:n_hit], miss[:n_miss]
+
+
+def gather_rows(src, idx):
+    """src[idx] for a [N, W] (or [N]) f32 tensor and an int32 index list."""
+    _lib.require_gpu()
+    flat = src.reshape(src.shape[0], -1).contiguous()
+    out = torch.empty((idx.shape[0], flat.shape[1]), device=src.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nm_gather_rows(_lib.dev_ptr(flat), _lib.dev_ptr(idx.contiguous(), torch.int32), None, idx.shape[0],
+                                         flat.shape[1], _lib.dev_ptr(out), _lib.stream_ptr()), "nm_gather_rows")
+    return out.reshape(idx.shape[0], *src.shape[1:])
+
+
+def scatter_rows(dst, idx, src):
+    """dst[idx] = src (in place) for f32 row tensors."""
+    _lib.require_gpu()
+    assert dst.is_contiguous()
+    flat = src.reshape(src.shape[0], -1).contiguous()
+    _lib.check(_lib.lib().nm_scatter_rows(_lib.dev_ptr(flat), _lib.dev_ptr(idx.contiguous(), torch.int32), None, idx.shape[0],
+                                          flat.shape[1], _lib.dev_ptr(dst), _lib.stream_ptr()), "nm_scatter_rows")
+    return dst
+
+
+# ------------------------------------------------------------------------------------------------
+# a11 observation -> canonical warp
+# ------------------------------------------------------------------------------------------------
+def warp_to_canonical_dev(pts, verts, faces, T, want_closest=False):
+    """Device-tensor core: pts [R,S,3] f32, verts [V,3] f32, faces [F,3] int32, T [>=V,4,4] f64 (all CUDA)."""
+    _lib.require_gpu()
+    R, S, _ = pts.shape
+    dev = pts.device
+    can_pts = torch.empty((R, S, 3), device=dev, dtype=torch.float32)
+    can_dirs = torch.empty((R, S, 3), device=dev, dtype=torch.float32)
+    closest = torch.empty((R, S, 3), device=dev, dtype=torch.float32) if want_closest else None
+    F = faces.shape[0]
+    ws = torch.empty(int(_lib.lib().nm_warp_workspace_floats(F)) + 16, device=dev, dtype=torch.float32)
+    off = (-ws.data_ptr() // 4) % 16                     # 64-byte alignment of the triangle records
+    ws = ws[off:off + int(_lib.lib().nm_warp_workspace_floats(F))]
+    _lib.check(_lib.lib().nm_warp_to_canonical(
+        _lib.dev_ptr(pts, name='pts'), R, S, _lib.dev_ptr(verts, name='verts'), verts.shape[0],
+        _lib.dev_ptr(faces, torch.int32, 'faces'), F, _lib.dev_ptr(T, torch.float64, 'T'), _lib.dev_ptr(can_pts),
+        _lib.dev_ptr(can_dirs), _lib.dev_ptr(closest), _lib.dev_ptr(ws), _lib.stream_ptr()), "nm_warp_to_canonical")
+    return can_pts, can_dirs, closest
+
+
+def mesh_to_device(verts, faces, T, device):
+    """Upload a posed mesh once per frame: verts f32, faces[:, :3] int32 (cols 3-5 are UV ids, utils/utils.py:213-221),
+    T f64 [*,4,4] (joint rows beyond V are never indexed)."""
+    v = torch.as_tensor(np.ascontiguousarray(verts, dtype=np.float32) if not isinstance(verts, torch.Tensor) else verts)
+    f = torch.as_tensor(np.ascontiguousarray(np.asarray(faces)[:, :3], dtype=np.int32) if not isinstance(faces, torch.Tensor) else faces[:, :3])
+    t = torch.as_tensor(np.ascontiguousarray(T, dtype=np.float64) if not isinstance(T, torch.Tensor) else T)
+    return (v.to(device, torch.float32).contiguous(), f.to(device, torch.int32).contiguous(),
+            t.to(device, torch.float64).reshape(-1, 16).contiguous())
+
+
+def warp_samples_to_canonical(pts, verts, faces, T):
+    """reference ray_utils.py:48-66.  numpy in -> numpy out like the reference (float32 here: the reference's callers
+    cast to float32 right away, render_utils.py:226-227); CUDA tensors in -> CUDA tensors out."""
+    assert len(pts.shape) == 3, 'pts should have shape [num_rays, num_samples, 3]'
+    assert pts.shape[-1] == 3
+    as_numpy = not isinstance(pts, torch.Tensor)
+    dev = torch.device('cuda') if as_numpy else pts.device
+    p = torch.as_tensor(np.ascontiguousarray(pts, dtype=np.float32)).to(dev) if as_numpy else _f32c(pts)
+    v, f, t = mesh_to_device(verts, faces, T, dev)
+    can_pts, can_dirs, closest = warp_to_canonical_dev(p, v, f, t, want_closest=True)
+    if as_numpy:
+        return can_pts.cpu().numpy(), can_dirs.cpu().numpy(), closest.cpu().numpy()
+    return can_pts, can_dirs, closest

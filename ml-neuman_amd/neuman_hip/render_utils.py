@@ -1,0 +1,286 @@
+"""HIP-backed mirror of the reference's utils/render_utils.py:69-461.
+
+Same public signatures and return conventions (numpy float32 frames) as the reference's raw2outputs and
+its four frame renderers.  What differs is the execution plan:
+
+* the reference loops over `rays_per_batch` chunks with 6-8 host<->device copies each; here a frame is
+  rendered in launches of up to `MAX_RAYS_PER_LAUNCH` rays (rays are independent, so chunking never changes a
+  pixel) and nothing returns to the host before the frame is assembled;
+* pts/dirs are never materialised for camera-ray passes: the MLP kernel builds `o + d*z` itself;
+* boolean-mask indexing is a ballot/prefix-sum compaction + row gather/scatter on the device.
+
+The `*_rays` functions work on device tensors (what bench.py and the multi-GPU path call); the reference
+named functions wrap them with ray generation and the final download.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, ray_utils
+from .ray_utils import DEFAULT_GEO_THRESH
+
+MAX_RAYS_PER_LAUNCH = int(os.environ.get("NEUMAN_MAX_RAYS_PER_LAUNCH", 1 << 20))
+
+
+# ------------------------------------------------------------------------------------------------
+# a5 raw2outputs
+# ------------------------------------------------------------------------------------------------
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkg=True, want_weights=True):
+    """reference render_utils.py:69-105 -> (rgb_map, disp_map, acc_map, weights, depth_map)."""
+    _lib.require_gpu()
+    raw = raw.to(torch.float32).contiguous()
+    z_vals = z_vals.to(torch.float32).contiguous()
+    rays_d = rays_d.to(torch.float32).contiguous()
+    R, S = z_vals.shape
+    dev = raw.device
+    noise = None
+    if raw_noise_std > 0.:
+        noise = (torch.randn((R, S), device=dev) * raw_noise_std).contiguous()          # render_utils.py:93
+    rgb = torch.empty((R, 3), device=dev, dtype=torch.float32)
+    disp = torch.empty(R, device=dev, dtype=torch.float32)
+    acc = torch.empty(R, device=dev, dtype=torch.float32)
+    depth = torch.empty(R, device=dev, dtype=torch.float32)
+    weights = torch.empty((R, S), device=dev, dtype=torch.float32) if want_weights else None
+    _lib.check(_lib.lib().nm_composite(_lib.dev_ptr(raw, name='raw'), _lib.dev_ptr(z_vals, name='z_vals'),
+                                       _lib.dev_ptr(rays_d, name='rays_d'), R, S, int(bool(white_bkg)), _lib.dev_ptr(noise),
+                                       _lib.dev_ptr(rgb), _lib.dev_ptr(disp), _lib.dev_ptr(acc), _lib.dev_ptr(weights),
+                                       _lib.dev_ptr(depth), _lib.stream_ptr()), "nm_composite")
+    return rgb, disp, acc, weights, depth
+
+
+def merge_sorted(za, rawa, zb, rawb):
+    """sort(cat([za, zb])) + gather of cat([rawa, rawb]) (render_utils.py:330-337); both lists sorted per ray."""
+    _lib.require_gpu()
+    R, Sa = za.shape
+    Sb = zb.shape[1]
+    z = torch.empty((R, Sa + Sb), device=za.device, dtype=torch.float32)
+    raw = torch.empty((R, Sa + Sb, 4), device=za.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nm_merge_sorted(_lib.dev_ptr(za.contiguous()), _lib.dev_ptr(rawa.contiguous()), Sa,
+                                          _lib.dev_ptr(zb.contiguous()), _lib.dev_ptr(rawb.contiguous()), Sb, R,
+                                          _lib.dev_ptr(z), _lib.dev_ptr(raw), _lib.stream_ptr()), "nm_merge_sorted")
+    return z, raw
+
+
+# ------------------------------------------------------------------------------------------------
+# device-level ray renderers
+# ------------------------------------------------------------------------------------------------
+def _chunks(n):
+    for i in range(0, n, MAX_RAYS_PER_LAUNCH):
+        yield i, min(i + MAX_RAYS_PER_LAUNCH, n)
+
+
+def bkg_pass_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, importance_samples_per_ray, white_bkg,
+                  precision=None):
+    """Coarse (+ fine) background evaluation of R rays -> (raw [R,S',4], z [R,S'])  (render_utils.py:131-151, 287-297)."""
+    _, _, z = ray_utils.sample_z(o, d, near, far, samples_per_ray)
+    raw = coarse_net.forward_rays(o, d, z, precision=precision)
+    if fine_net is not None:
+        _, _, _, w, _ = raw2outputs(raw, z, d, white_bkg=white_bkg)
+        z = ray_utils.importance_z(z, w, importance_samples_per_ray)
+        raw = fine_net.forward_rays(o, d, z, precision=precision)
+    return raw, z
+
+
+def render_vanilla_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, importance_samples_per_ray, white_bkg=True,
+                        precision=None):
+    """Device core of render_vanilla: o, d [R,3] CUDA f32, scalar near/far -> (rgb [R,3], depth [R]) CUDA."""
+    R = o.shape[0]
+    rgb = torch.empty((R, 3), device=o.device, dtype=torch.float32)
+    depth = torch.empty(R, device=o.device, dtype=torch.float32)
+    for i, j in _chunks(R):
+        oc, dc = o[i:j], d[i:j]
+        n = torch.full((j - i,), float(near), device=o.device, dtype=torch.float32)
+        f = torch.full((j - i,), float(far), device=o.device, dtype=torch.float32)
+        raw, z = bkg_pass_rays(coarse_net, fine_net, oc, dc, n, f, samples_per_ray, importance_samples_per_ray, white_bkg,
+                               precision)
+        rgb[i:j], _, _, _, depth[i:j] = raw2outputs(raw, z, dc, white_bkg=white_bkg, want_weights=False)
+    return rgb, depth
+
+
+def human_pass_rays(human_net, o, d, near, far, samples_per_ray, mesh=None, render_can=False, sigma_scale=1.0, precision=None):
+    """Human-net evaluation of (already compacted) hit rays -> (raw [R,S,4], z [R,S])  (render_utils.py:213-229, 320-329)."""
+    if render_can:
+        _, _, z = ray_utils.sample_z(o, d, near, far, samples_per_ray)
+        return human_net.forward_rays(o, d, z, precision=precision, sigma_scale=sigma_scale), z
+    pts, _, z = ray_utils.sample_z(o, d, near, far, samples_per_ray, want_points=True)
+    verts, faces, T = mesh
+    can_pts, can_dirs, _ = ray_utils.warp_to_canonical_dev(pts, verts, faces, T)
+    return human_net(can_pts, can_dirs, precision=precision, sigma_scale=sigma_scale), z
+
+
+def render_smpl_nerf_rays(human_net, o, d, posed_verts, mesh, samples_per_ray, white_bkg=True, render_can=False,
+                          geo_threshold=DEFAULT_GEO_THRESH, interval_comp=1.0, precision=None):
+    """Device core of render_smpl_nerf -> (rgb [R,3], depth [R], acc [R]) CUDA."""
+    R = o.shape[0]
+    rgb = torch.full((R, 3), 1.0 if white_bkg else 0.0, device=o.device, dtype=torch.float32)    # misses, :199-205
+    depth = torch.zeros(R, device=o.device, dtype=torch.float32)
+    acc = torch.zeros(R, device=o.device, dtype=torch.float32)
+    for i, j in _chunks(R):
+        oc, dc = o[i:j].contiguous(), d[i:j].contiguous()
+        near, far = ray_utils.geometry_guided_near_far(oc, dc, posed_verts, geo_threshold)
+        hit, _ = ray_utils.compact_hits(near, far)
+        if hit.numel() == 0:
+            continue
+        ho, hd = ray_utils.gather_rows(oc, hit), ray_utils.gather_rows(dc, hit)
+        hn, hf = ray_utils.gather_rows(near, hit), ray_utils.gather_rows(far, hit)
+        raw, z = human_pass_rays(human_net, ho, hd, hn, hf, samples_per_ray, mesh, render_can, interval_comp, precision)
+        _rgb, _, _acc, _, _depth = raw2outputs(raw, z, hd, white_bkg=white_bkg, want_weights=False)
+        ray_utils.scatter_rows(rgb[i:j], hit, _rgb)
+        ray_utils.scatter_rows(depth[i:j], hit, _depth)
+        ray_utils.scatter_rows(acc[i:j], hit, _acc)
+    return rgb, depth, acc
+
+
+def render_hybrid_rays(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far, posed_verts, mesh, samples_per_ray,
+                       importance_samples_per_ray, white_bkg=True, geo_threshold=DEFAULT_GEO_THRESH, precision=None):
+    """Device core of render_hybrid_nerf -> (rgb [R,3], depth [R], acc [R]) CUDA  (render_utils.py:276-356)."""
+    R = o.shape[0]
+    rgb = torch.empty((R, 3), device=o.device, dtype=torch.float32)
+    depth = torch.empty(R, device=o.device, dtype=torch.float32)
+    acc = torch.zeros(R, device=o.device, dtype=torch.float32)                                   # misses: acc forced 0, :311
+    for i, j in _chunks(R):
+        oc, dc = o[i:j].contiguous(), d[i:j].contiguous()
+        n = torch.full((j - i,), float(bkg_near), device=o.device, dtype=torch.float32)
+        f = torch.full((j - i,), float(bkg_far), device=o.device, dtype=torch.float32)
+        bkg_raw, bkg_z = bkg_pass_rays(coarse_bkg, fine_bkg, oc, dc, n, f, samples_per_ray, importance_samples_per_ray,
+                                       white_bkg, precision)
+        # every ray first gets the background-only composite (what the reference does for misses, :303-311) ...
+        rgb[i:j], _, _, _, depth[i:j] = raw2outputs(bkg_raw, bkg_z, dc, white_bkg=white_bkg, want_weights=False)
+        near, far = ray_utils.geometry_guided_near_far(oc, dc, posed_verts, geo_threshold)
+        hit, _ = ray_utils.compact_hits(near, far)
+        if hit.numel() == 0:
+            continue
+        # ... and hit rays are overwritten by the merged human + background composite (:313-353)
+        ho, hd = ray_utils.gather_rows(oc, hit), ray_utils.gather_rows(dc, hit)
+        hn, hf = ray_utils.gather_rows(near, hit), ray_utils.gather_rows(far, hit)
+        h_raw, h_z = human_pass_rays(human_net, ho, hd, hn, hf, samples_per_ray, mesh, False, 1.0, precision)
+        S_b = bkg_z.shape[1]
+        z_all, raw_all = merge_sorted(ray_utils.gather_rows(bkg_z, hit), ray_utils.gather_rows(bkg_raw.reshape(j - i, -1), hit).reshape(-1, S_b, 4),
+                                      h_z, h_raw)
+        _rgb, _, _, _, _depth = raw2outputs(raw_all, z_all, hd, white_bkg=white_bkg, want_weights=False)
+        _, _, _acc, _, _ = raw2outputs(h_raw, h_z, hd, white_bkg=white_bkg, want_weights=False)          # :345-350
+        ray_utils.scatter_rows(rgb[i:j], hit, _rgb)
+        ray_utils.scatter_rows(depth[i:j], hit, _depth)
+        ray_utils.scatter_rows(acc[i:j], hit, _acc)
+    return rgb, depth, acc
+
+
+def render_multi_rays(coarse_bkg, fine_bkg, human_nets, o, d, bkg_near, bkg_far, posed_verts, meshes, samples_per_ray,
+                      importance_samples_per_ray, white_bkg=True, geo_threshold=DEFAULT_GEO_THRESH, precision=None):
+    """Device core of render_hybrid_nerf_multi_persons -> (rgb [R,3], depth [R]) CUDA  (render_utils.py:390-456)."""
+    R = o.shape[0]
+    rgb = torch.empty((R, 3), device=o.device, dtype=torch.float32)
+    depth = torch.empty(R, device=o.device, dtype=torch.float32)
+    for i, j in _chunks(R):
+        oc, dc = o[i:j].contiguous(), d[i:j].contiguous()
+        nr = j - i
+        n = torch.full((nr,), float(bkg_near), device=o.device, dtype=torch.float32)
+        f = torch.full((nr,), float(bkg_far), device=o.device, dtype=torch.float32)
+        raw_all, z_all = bkg_pass_rays(coarse_bkg, fine_bkg, oc, dc, n, f, samples_per_ray, importance_samples_per_ray,
+                                       white_bkg, precision)
+        far_z = torch.linspace(float(bkg_far) * 2, float(bkg_far) * 3, samples_per_ray, device=o.device)   # :418-419
+        for net, verts, mesh in zip(human_nets, posed_verts, meshes):
+            near, far = ray_utils.geometry_guided_near_far(oc, dc, verts, geo_threshold)
+            h_raw = torch.zeros((nr, samples_per_ray, 4), device=o.device, dtype=torch.float32)
+            h_z = far_z[None].repeat(nr, 1).contiguous()
+            hit, _ = ray_utils.compact_hits(near, far)
+            if hit.numel() > 0:
+                ho, hd = ray_utils.gather_rows(oc, hit), ray_utils.gather_rows(dc, hit)
+                hn, hf = ray_utils.gather_rows(near, hit), ray_utils.gather_rows(far, hit)
+                r_, z_ = human_pass_rays(net, ho, hd, hn, hf, samples_per_ray, mesh, False, 1.0, precision)
+                ray_utils.scatter_rows(h_raw.reshape(nr, -1), hit, r_.reshape(hit.shape[0], -1))
+                ray_utils.scatter_rows(h_z, hit, z_)
+            z_all, raw_all = merge_sorted(z_all, raw_all, h_z, h_raw)                                   # :441-448, list by list
+        rgb[i:j], _, _, _, depth[i:j] = raw2outputs(raw_all, z_all, dc, white_bkg=white_bkg, want_weights=False)
+    return rgb, depth
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's frame renderers (same signatures, numpy out)
+# ------------------------------------------------------------------------------------------------
+def _device_of(net):
+    dev = next(net.parameters()).device
+    if dev.type != 'cuda':
+        raise _lib.NeumanHipError("the network must live on the HIP device (net.cuda()): there is no CPU render path")
+    return dev
+
+
+def _pixel_rays(cap, device):
+    coords = np.argwhere(np.ones(cap.shape))[:, ::-1]                                    # (x, y), row-major, :185
+    o, d = ray_utils.shot_rays(cap, coords)
+    return (torch.from_numpy(o).to(device, torch.float32).contiguous(),
+            torch.from_numpy(d).to(device, torch.float32).contiguous())
+
+
+def render_vanilla(coarse_net, cap, fine_net=None, rays_per_batch=32768, samples_per_ray=64, importance_samples_per_ray=128,
+                   white_bkg=True, near_far_source='bkg', return_depth=False, ablate_nerft=False):
+    """reference render_utils.py:108-161."""
+    if ablate_nerft:
+        raise NotImplementedError("ablate_nerft (time-conditioned ablation net) is outside the HIP path")
+    device = _device_of(coarse_net)
+    with torch.no_grad():
+        o, d = ray_utils.shot_all_rays(cap)
+        o = torch.from_numpy(o).to(device, torch.float32).contiguous()
+        d = torch.from_numpy(d).to(device, torch.float32).contiguous()
+        rgb, depth = render_vanilla_rays(coarse_net, fine_net, o, d, cap.near[near_far_source], cap.far[near_far_source],
+                                         samples_per_ray, importance_samples_per_ray, white_bkg)
+        rgb = rgb.reshape(*cap.shape, -1).cpu().numpy()
+        depth = depth.reshape(*cap.shape).cpu().numpy()
+    return (rgb, depth) if return_depth else rgb
+
+
+def render_smpl_nerf(net, cap, posed_verts, faces, Ts, rays_per_batch=32768, samples_per_ray=64, white_bkg=True,
+                     render_can=False, geo_threshold=DEFAULT_GEO_THRESH, return_depth=False, return_mask=False,
+                     interval_comp=1.0):
+    """reference render_utils.py:164-246."""
+    device = _device_of(net)
+    with torch.no_grad():
+        o, d = _pixel_rays(cap, device)
+        verts = torch.as_tensor(np.ascontiguousarray(posed_verts, dtype=np.float32)).to(device)
+        mesh = None if render_can else ray_utils.mesh_to_device(posed_verts, faces, Ts, device)
+        rgb, depth, acc = render_smpl_nerf_rays(net.coarse_human_net, o, d, verts, mesh, samples_per_ray, white_bkg, render_can,
+                                                geo_threshold, interval_comp)
+        rgb = rgb.reshape(*cap.shape, -1).cpu().numpy()
+        depth = depth.reshape(*cap.shape).cpu().numpy()
+        acc = acc.reshape(*cap.shape).cpu().numpy()
+    if return_depth and return_mask:
+        return rgb, depth, acc
+    if return_depth:
+        return rgb, depth
+    if return_mask:
+        return rgb, acc
+    return rgb
+
+
+def render_hybrid_nerf(net, cap, posed_verts, faces, Ts, rays_per_batch=32768, samples_per_ray=64,
+                       importance_samples_per_ray=128, white_bkg=True, geo_threshold=DEFAULT_GEO_THRESH, return_depth=False):
+    """reference render_utils.py:249-362."""
+    device = _device_of(net)
+    with torch.no_grad():
+        o, d = _pixel_rays(cap, device)
+        verts = torch.as_tensor(np.ascontiguousarray(posed_verts, dtype=np.float32)).to(device)
+        mesh = ray_utils.mesh_to_device(posed_verts, faces, Ts, device)
+        rgb, depth, _ = render_hybrid_rays(net.coarse_bkg_net, net.fine_bkg_net, net.coarse_human_net, o, d, cap.near['bkg'],
+                                           cap.far['bkg'], verts, mesh, samples_per_ray, importance_samples_per_ray, white_bkg,
+                                           geo_threshold)
+        rgb = rgb.reshape(*cap.shape, -1).cpu().numpy()
+        depth = depth.reshape(*cap.shape).cpu().numpy()
+    return (rgb, depth) if return_depth else rgb
+
+
+def render_hybrid_nerf_multi_persons(bkg_model, cap, human_models, posed_verts, faces, Ts, rays_per_batch=32768,
+                                     samples_per_ray=64, importance_samples_per_ray=128, white_bkg=True,
+                                     geo_threshold=DEFAULT_GEO_THRESH, return_depth=False):
+    """reference render_utils.py:365-461."""
+    device = _device_of(bkg_model)
+    with torch.no_grad():
+        o, d = _pixel_rays(cap, device)
+        verts = [torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)).to(device) for v in posed_verts]
+        meshes = [ray_utils.mesh_to_device(v, f, t, device) for v, f, t in zip(posed_verts, faces, Ts)]
+        rgb, depth = render_multi_rays(bkg_model.coarse_bkg_net, bkg_model.fine_bkg_net,
+                                       [m.coarse_human_net for m in human_models], o, d, cap.near['bkg'], cap.far['bkg'], verts,
+                                       meshes, samples_per_ray, importance_samples_per_ray, white_bkg, geo_threshold)
+        rgb = rgb.reshape(*cap.shape, -1).cpu().numpy()
+        depth = depth.reshape(*cap.shape).cpu().numpy()
+    return (rgb, depth) if return_depth else rgb

@@ -1,0 +1,124 @@
+"""Synthetic workloads for the hot path: no dataset, checkpoint or SMPL asset exists offline.
+
+Everything here is deterministic in its seed and is shared by tests/, bench.py and __graft_entry__.smoke()
+so that the HIP path and the CPU oracle consume identical rays, weights and meshes.
+"""
+import types
+
+import numpy as np
+import torch
+
+from . import vanilla
+
+
+def default_opt(**over):
+    """Render-time options with the reference defaults (options/options.py:47-81)."""
+    o = dict(use_cuda=False, nerf_depth=8, nerf_width=256, use_viewdirs=True, specular_can=True, raw_pos_dim=3,
+             pos_min_freq=0, pos_max_freq=9, pos_N_freqs=10, raw_dir_dim=3, dir_max_freq=3, dir_N_freqs=4,
+             log_sampling=True, include_input=True, can_posenc='rotate', rays_per_batch=2048, samples_per_ray=128,
+             white_bkg=True)
+    o.update(over)
+    return types.SimpleNamespace(**o)
+
+
+class _Pose:
+    def __init__(self, c2w):
+        self.camera_to_world = np.asarray(c2w, dtype=np.float64)
+
+    @property
+    def camera_center_in_world(self):
+        return self.camera_to_world[:3, 3]
+
+
+class SimpleCapture:
+    """The slice of the reference's capture duck-type the hot path consumes (cameras/captures.py:21-63)."""
+
+    def __init__(self, width, height, fx=None, fy=None, cx=None, cy=None, c2w=None, near=0.0, far=3.14):
+        self.width, self.height = int(width), int(height)
+        self.fx = 1.25 * width if fx is None else fx
+        self.fy = self.fx if fy is None else fy
+        self.cx = width / 2 if cx is None else cx
+        self.cy = height / 2 if cy is None else cy
+        self.cam_pose = _Pose(np.eye(4) if c2w is None else c2w)
+        self.near = {'bkg': near}
+        self.far = {'bkg': far}
+
+    @property
+    def shape(self):
+        return (self.height, self.width)
+
+    size = shape
+
+    @property
+    def intrinsic_matrix(self):
+        return np.array([[self.fx, 0., self.cx], [0., self.fy, self.cy], [0., 0., 1.]])
+
+
+def spherical_c2w(theta_deg, phi_deg, radius):
+    """Camera on a sphere looking at the origin (same convention as render_utils.pose_spherical, :42-56)."""
+    th, ph = np.deg2rad(theta_deg), np.deg2rad(phi_deg)
+    t = np.eye(4)
+    t[2, 3] = radius
+    rp = np.array([[1, 0, 0, 0], [0, np.cos(ph), -np.sin(ph), 0], [0, np.sin(ph), np.cos(ph), 0], [0, 0, 0, 1.]])
+    rt = np.array([[np.cos(th), 0, -np.sin(th), 0], [0, 1, 0, 0], [np.sin(th), 0, np.cos(th), 0], [0, 0, 0, 1.]])
+    c2w = np.array([[-1, 0, 0, 0], [0, 0, 1, 0], [0, 1, 0, 0], [0, 0, 0, 1.]]) @ rt @ rp @ t
+    return c2w @ np.diag([1., -1., -1., 1.])
+
+
+def make_joiner(seed, mapping='posenc', dense=True, pos_min_freq=0):
+    """One Joiner with torch.manual_seed(seed) default nn.Linear init; `dense` applies the synthetic-dense
+    preset of SURVEY 8d (alpha_linear.weight *= 40, alpha_linear.bias = 0.5, rgb_linear.weight *= 8) that keeps
+    sigma away from the 1e10-interval step at 0 and gives non-trivial transmittance."""
+    opt = default_opt(posenc=mapping, pos_min_freq=pos_min_freq)
+    torch.manual_seed(seed)
+    net, _ = vanilla.build_nerf(opt)
+    if dense:
+        with torch.no_grad():
+            net.nerf.alpha_linear.weight *= 40.
+            net.nerf.alpha_linear.bias.fill_(0.5)
+            net.nerf.rgb_linear.weight *= 8.
+    return net
+
+
+def state_numpy(joiner):
+    """Joiner weights as {reference state_dict name: f32 numpy} (what oracle/nerf_mlp.py consumes)."""
+    return {k: v.detach().cpu().numpy().astype(np.float32) for k, v in joiner.state_dict().items()}
+
+
+def human_vertex_cloud(seed=0, n=6890):
+    """Stand-in for SMPL vertices in canonical renders."""
+    return (np.random.default_rng(seed).normal(size=(n, 3)) * np.array([0.25, 0.6, 0.15])).astype(np.float32)
+
+
+def capsule_mesh(n_rings=84, n_seg=82, radius=(0.25, 0.6, 0.15)):
+    """Closed genus-0 triangle mesh with SMPL's counts for the defaults: V = 84*82 + 2 = 6890, F = 2*82*84 = 13776."""
+    th = np.linspace(0, np.pi, n_rings + 2)[1:-1]
+    ph = np.linspace(0, 2 * np.pi, n_seg, endpoint=False)
+    ring = np.stack([np.outer(np.sin(th), np.cos(ph)), np.outer(np.cos(th), np.ones_like(ph)),
+                     np.outer(np.sin(th), np.sin(ph))], -1).reshape(-1, 3)
+    verts = np.concatenate([[[0, 1, 0]], ring, [[0, -1, 0]]]) * np.asarray(radius)
+    idx = lambda r, s: 1 + r * n_seg + (s % n_seg)
+    faces = []
+    last = 1 + n_rings * n_seg
+    for s in range(n_seg):
+        faces.append([0, idx(0, s + 1), idx(0, s)])
+        faces.append([last, idx(n_rings - 1, s), idx(n_rings - 1, s + 1)])
+    for r in range(n_rings - 1):
+        for s in range(n_seg):
+            a, b, c, d = idx(r, s), idx(r, s + 1), idx(r + 1, s), idx(r + 1, s + 1)
+            faces.append([a, b, c])
+            faces.append([b, d, c])
+    return verts.astype(np.float32), np.asarray(faces, dtype=np.int64)
+
+
+def twist_transforms(can_verts, twist=0.8, shift=(0.05, -0.02, 0.03)):
+    """Per-vertex rigid canonical->observation transforms (f64 [V,4,4]): rotation about y by an angle
+    proportional to height, plus a translation -- a smooth stand-in for SMPL LBS.  Returns (posed_verts f32, T)."""
+    v = can_verts.astype(np.float64)
+    ang = twist * v[:, 1]
+    T = np.tile(np.eye(4), (v.shape[0], 1, 1))
+    T[:, 0, 0], T[:, 0, 2] = np.cos(ang), np.sin(ang)
+    T[:, 2, 0], T[:, 2, 2] = -np.sin(ang), np.cos(ang)
+    T[:, :3, 3] = np.asarray(shift)
+    posed = np.einsum('vij,vj->vi', T[:, :3, :3], v) + T[:, :3, 3]
+    return posed.astype(np.float32), T

@@ -1,0 +1,193 @@
+"""Host-side mirror of the reference's models/vanilla.py for the HIP path.
+
+Same class names, constructor arguments and state_dict keys as the reference (Embedder vanilla.py:17-92,
+NeRF :95-152, Joiner :155-166, build_nerf :208-250), so reference checkpoints load unchanged
+(`nerf.pts_linears.{i}.weight` ...).  The arithmetic is NOT here: ``Joiner.forward`` hands raw device
+pointers to ``nm_mlp_forward`` (fused PE + MLP kernel, csrc/mlp.hip).  There is no torch/CPU evaluation
+of the network in this package; calling it with CPU tensors or with autograd enabled raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+DEFAULT_PRECISION = os.environ.get("NEUMAN_PRECISION", "bf16x3")
+
+
+class Embedder(nn.Module):
+    """Positional-encoding *specification* (the encoding itself is computed inside the MLP kernel)."""
+
+    def __init__(self, input_dims, max_freq, N_freqs, log_sampling=True, include_input=True, min_freq=0, mapping='posenc'):
+        super().__init__()
+        if mapping not in ('posenc', 'rotate'):
+            raise ValueError(mapping)
+        if not (log_sampling and include_input):
+            raise NotImplementedError("the HIP path implements the reference defaults log_sampling=include_input=True")
+        self.input_dims, self.max_freq, self.min_freq, self.N_freqs = input_dims, max_freq, min_freq, N_freqs
+        self.log_sampling, self.include_input, self.mapping = log_sampling, include_input, mapping
+        self.out_dim = input_dims + 2 * input_dims * N_freqs if mapping == 'posenc' else 3 + 6 * N_freqs
+
+    def table(self):
+        """f32 table the kernel consumes: posenc -> bands[N]; rotate -> bvals[3N,3] (vanilla.py:44-55, 67-68)."""
+        if self.mapping == 'posenc':
+            return (2. ** torch.linspace(self.min_freq, self.max_freq, steps=self.N_freqs)).numpy().astype(np.float32)
+        bands = 2. ** np.linspace(self.min_freq, self.max_freq, num=self.N_freqs)
+        b = (np.eye(3)[None] * bands[:, None, None]).reshape(3 * self.N_freqs, 3)
+        c = 2 ** .5 / 2
+        b = b @ np.array([[c, -c, 0], [c, c, 0], [0, 0, 1]]).T
+        b = b @ np.array([[1, 0, 0], [0, c, -c], [0, c, c]]).T
+        return np.ascontiguousarray(b.astype(np.float32))
+
+    @property
+    def bvals(self):  # reference attribute name (vanilla.py:52-55)
+        return torch.from_numpy(self.table()) if self.mapping == 'rotate' else None
+
+    def forward(self, inputs, cur_iter=None):
+        raise _lib.NeumanHipError("Embedder.forward is fused into the HIP MLP kernel: call the Joiner")
+
+
+class NeRF(nn.Module):
+    """Parameter container with the reference's layer names (vanilla.py:95-118)."""
+
+    def __init__(self, depth=8, width=256, input_ch=3, input_ch_views=3, output_ch=4, skips=[4], use_viewdirs=False,
+                 scale=1.0, scale_type='no'):
+        super().__init__()
+        self.depth, self.width, self.input_ch, self.input_ch_views = depth, width, input_ch, input_ch_views
+        self.skips, self.use_viewdirs, self.scale, self.scale_type = skips, use_viewdirs, scale, scale_type
+        layers = [nn.Linear(input_ch, width)]
+        for i in range(depth - 1):
+            layers.append(nn.Linear(width + input_ch if i in skips else width, width))
+        self.pts_linears = nn.ModuleList(layers)
+        if use_viewdirs:
+            self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + width, width // 2)])
+            self.feature_linear = nn.Linear(width, width)
+            self.alpha_linear = nn.Linear(width, 1)
+            self.rgb_linear = nn.Linear(width // 2, 3)
+        else:
+            self.output_linear = nn.Linear(width, output_ch)
+
+    def ordered_params(self):
+        """The 24 tensors nm_mlp_create expects (include/neuman_hip.h), reference state_dict order."""
+        if not self.use_viewdirs:
+            raise NotImplementedError("HIP path implements the use_viewdirs=True net (options/options.py:54)")
+        out = []
+        for lin in list(self.pts_linears) + [self.views_linears[0], self.feature_linear, self.alpha_linear, self.rgb_linear]:
+            out += [lin.weight, lin.bias]
+        return out
+
+    def forward(self, input_pts, input_views=None):
+        raise _lib.NeumanHipError("NeRF.forward on pre-encoded inputs is not exposed: the HIP kernel fuses PE + MLP (use Joiner)")
+
+
+class Joiner(nn.Module):
+    """PE + MLP, evaluated by the fused HIP kernel (reference vanilla.py:155-166)."""
+
+    def __init__(self, pos_pe, dir_pe, nerf):
+        super().__init__()
+        self.pos_pe, self.dir_pe, self.nerf = pos_pe, dir_pe, nerf
+        self.precision = DEFAULT_PRECISION
+        self._handle = None
+        self._handle_key = None
+
+    # ---- weight-pack cache: rebuilt whenever a parameter's storage or version changes -------------
+    def _key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.nerf.ordered_params())
+
+    def _release(self):
+        if self._handle is not None:
+            _lib.lib().nm_mlp_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def handle(self):
+        key = self._key()
+        if self._handle is None or key != self._handle_key:
+            self._release()
+            n = self.nerf
+            if n.scale_type != 'no':
+                raise NotImplementedError("scale_type != 'no' (offset nets) is outside the HIP path")
+            if self.pos_pe.mapping != self.dir_pe.mapping:
+                raise NotImplementedError("mixed PE kinds")
+            desc = _lib.MlpDesc(n.depth, n.width, n.skips[0] if len(n.skips) == 1 else -1,
+                                _lib.NM_PE_ROTATE if self.pos_pe.mapping == 'rotate' else _lib.NM_PE_POSENC,
+                                self.pos_pe.N_freqs, self.dir_pe.N_freqs)
+            host = [p.detach().to('cpu', torch.float32).contiguous() for p in n.ordered_params()]
+            arr = (ctypes.c_void_p * 24)(*[t.data_ptr() for t in host])
+            pos_tab, dir_tab = self.pos_pe.table(), self.dir_pe.table()
+            out = ctypes.c_void_p()
+            _lib.check(_lib.lib().nm_mlp_create(ctypes.byref(desc), arr, pos_tab.ctypes.data, dir_tab.ctypes.data,
+                                                ctypes.byref(out)), "nm_mlp_create")
+            self._handle, self._handle_key = out, key
+        return self._handle
+
+    def _prec(self, precision):
+        return _lib.PRECISIONS[precision or self.precision]
+
+    @staticmethod
+    def _guard(*tensors):
+        _lib.require_gpu()
+        if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+            raise _lib.NeumanHipError("the HIP MLP kernel is forward-only (training is SURVEY 8f-1); wrap in torch.no_grad()")
+
+    def forward(self, input_pts, input_views=None, precision=None, sigma_scale=1.0):
+        """input_pts [..., 3], input_views [..., 3] (CUDA f32) -> [..., 4] = (r, g, b, sigma)."""
+        if input_views is None:
+            raise NotImplementedError("the HIP net is the use_viewdirs=True net: input_views is required")
+        self._guard(input_pts, input_views)
+        shp = input_pts.shape[:-1]
+        p = input_pts.detach().reshape(-1, 3).contiguous()
+        d = input_views.detach().reshape(-1, 3).contiguous()
+        out = torch.empty((p.shape[0], 4), device=p.device, dtype=torch.float32)
+        _lib.check(_lib.lib().nm_mlp_forward(self.handle(), _lib.dev_ptr(p, name='input_pts'), _lib.dev_ptr(d, name='input_views'),
+                                             p.shape[0], self._prec(precision), float(sigma_scale), _lib.dev_ptr(out),
+                                             _lib.stream_ptr()), "nm_mlp_forward")
+        return out.reshape(*shp, 4)
+
+    def forward_rays(self, origin, direction, z_vals, precision=None, sigma_scale=1.0):
+        """Fused ray_to_samples point construction + forward: origin/direction [R,3], z_vals [R,S] -> [R,S,4]."""
+        self._guard(origin, direction, z_vals)
+        R, S = z_vals.shape
+        out = torch.empty((R, S, 4), device=z_vals.device, dtype=torch.float32)
+        _lib.check(_lib.lib().nm_mlp_forward_rays(self.handle(), _lib.dev_ptr(origin, name='origin'),
+                                                  _lib.dev_ptr(direction, name='direction'), _lib.dev_ptr(z_vals, name='z_vals'),
+                                                  R, S, self._prec(precision), float(sigma_scale), _lib.dev_ptr(out),
+                                                  _lib.stream_ptr()), "nm_mlp_forward_rays")
+        return out
+
+    def forward_debug(self, input_pts, input_views, stage, precision=None):
+        """Activations after `stage` (include/neuman_hip.h: nm_mlp_forward_debug)."""
+        self._guard(input_pts, input_views)
+        p = input_pts.detach().reshape(-1, 3).contiguous()
+        d = input_views.detach().reshape(-1, 3).contiguous()
+        width = 64 if stage == -1 else (128 if stage == 9 else 256)
+        out = torch.zeros((p.shape[0], width), device=p.device, dtype=torch.float32)
+        _lib.check(_lib.lib().nm_mlp_forward_debug(self.handle(), _lib.dev_ptr(p), _lib.dev_ptr(d), p.shape[0],
+                                                   self._prec(precision), int(stage), _lib.dev_ptr(out), _lib.stream_ptr()),
+                   "nm_mlp_forward_debug")
+        return out
+
+
+def build_nerf(opt):
+    """Same construction order as the reference (vanilla.py:208-250): coarse NeRF first, then fine."""
+    mapping = opt.posenc if hasattr(opt, 'posenc') else 'posenc'
+    pos_pe = Embedder(opt.raw_pos_dim, opt.pos_max_freq, opt.pos_N_freqs, opt.log_sampling, opt.include_input,
+                      min_freq=opt.pos_min_freq, mapping=mapping)
+    dir_pe = Embedder(opt.raw_dir_dim, opt.dir_max_freq, opt.dir_N_freqs, opt.log_sampling, opt.include_input, mapping=mapping)
+    nets = []
+    for _ in range(2):
+        nerf = NeRF(depth=opt.nerf_depth, width=opt.nerf_width, input_ch=pos_pe.out_dim, input_ch_views=dir_pe.out_dim,
+                    use_viewdirs=opt.use_viewdirs)
+        nets.append(nerf)
+    coarse, fine = Joiner(pos_pe, dir_pe, nets[0]), Joiner(pos_pe, dir_pe, nets[1])
+    if opt.use_cuda:
+        coarse, fine = coarse.cuda(), fine.cuda()
+    return coarse, fine

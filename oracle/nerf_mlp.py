@@ -1,0 +1,111 @@
+"""Oracle: positional encodings and the 8x256 NeRF MLP.
+
+numpy float32 restatement of reference models/vanilla.py (Embedder :17-92,
+NeRF :95-152, Joiner :155-166).  Test infrastructure only.
+
+Weights are a dict keyed by the reference Joiner's state_dict names
+(``nerf.pts_linears.0.weight`` ... ``nerf.rgb_linear.bias``), values numpy f32.
+"""
+import numpy as np
+
+F32 = np.float32
+
+
+def rotate_bvals(min_freq, max_freq, n_freqs):
+    """reference models/vanilla.py:44-55: B = (I3 (x) bands) . Rz(45)^T . Rx(45)^T, cast to f32. [3N,3]."""
+    bvals = 2. ** np.linspace(min_freq, max_freq, num=n_freqs)
+    bvals = np.reshape(np.eye(3) * bvals[:, None, None], [len(bvals) * 3, 3])
+    rot = np.array([[(2 ** .5) / 2, -(2 ** .5) / 2, 0], [(2 ** .5) / 2, (2 ** .5) / 2, 0], [0, 0, 1]])
+    bvals = bvals @ rot.T
+    rot = np.array([[1, 0, 0], [0, (2 ** .5) / 2, -(2 ** .5) / 2], [0, (2 ** .5) / 2, (2 ** .5) / 2]])
+    bvals = bvals @ rot.T
+    return bvals.astype(F32)
+
+
+def posenc_bands(min_freq, max_freq, n_freqs):
+    """reference models/vanilla.py:67-68: 2**torch.linspace(min,max,N) in f32 (exact powers of two for the defaults)."""
+    return (F32(2.) ** np.linspace(min_freq, max_freq, n_freqs).astype(F32)).astype(F32)
+
+
+def embed_posenc(x, min_freq, max_freq, n_freqs, include_input=True):
+    """reference models/vanilla.py:60-79, 92: [x, sin(f0 x), cos(f0 x), sin(f1 x), ...]."""
+    x = x.astype(F32)
+    out = [x] if include_input else []
+    for f in posenc_bands(min_freq, max_freq, n_freqs):
+        xf = (x * f).astype(F32)
+        out.append(np.sin(xf, dtype=F32))
+        out.append(np.cos(xf, dtype=F32))
+    return np.concatenate(out, -1)
+
+
+def embed_rotate(x, min_freq, max_freq, n_freqs, include_input=True):
+    """reference models/vanilla.py:83-89: [x, sin(x B^T), cos(x B^T)]."""
+    x = x.astype(F32)
+    proj = (x @ rotate_bvals(min_freq, max_freq, n_freqs).T).astype(F32)
+    out = np.concatenate([np.sin(proj, dtype=F32), np.cos(proj, dtype=F32)], -1)
+    if include_input:
+        out = np.concatenate([x, out], -1)
+    return out
+
+
+def embed(x, mapping, min_freq, max_freq, n_freqs):
+    return (embed_rotate if mapping == 'rotate' else embed_posenc)(x, min_freq, max_freq, n_freqs)
+
+
+def _linear(h, w, b):
+    return (h @ w.T + b).astype(F32)
+
+
+def nerf_forward(weights, x_pe, d_pe, depth=8, skips=(4,), return_hidden=False):
+    """reference models/vanilla.py:120-152 (use_viewdirs=True, scale_type='no').
+
+    x_pe [N,63], d_pe [N,27] -> [N,4] = (r,g,b,sigma).  With return_hidden the
+    post-activation output of every layer is returned too (for layer-by-layer
+    kernel debugging).
+    """
+    hidden = []
+    h = x_pe
+    for i in range(depth):
+        h = np.maximum(_linear(h, weights[f'nerf.pts_linears.{i}.weight'], weights[f'nerf.pts_linears.{i}.bias']), F32(0.))
+        hidden.append(h)
+        if i in skips:
+            h = np.concatenate([x_pe, h], -1)
+    alpha = _linear(h, weights['nerf.alpha_linear.weight'], weights['nerf.alpha_linear.bias'])
+    feature = _linear(h, weights['nerf.feature_linear.weight'], weights['nerf.feature_linear.bias'])
+    hidden.append(feature)
+    h = np.concatenate([feature, d_pe], -1)
+    h = np.maximum(_linear(h, weights['nerf.views_linears.0.weight'], weights['nerf.views_linears.0.bias']), F32(0.))
+    hidden.append(h)
+    rgb = _linear(h, weights['nerf.rgb_linear.weight'], weights['nerf.rgb_linear.bias'])
+    out = np.concatenate([rgb, alpha], -1)
+    return (out, hidden) if return_hidden else out
+
+
+class JoinerSpec:
+    """What the reference's Joiner(pos_pe, dir_pe, nerf) is configured with (options/options.py:60-71)."""
+
+    def __init__(self, mapping='posenc', pos_min_freq=0, pos_max_freq=9, pos_n_freqs=10,
+                 dir_max_freq=3, dir_n_freqs=4, depth=8, width=256, skips=(4,)):
+        self.mapping = mapping
+        self.pos = (pos_min_freq, pos_max_freq, pos_n_freqs)
+        self.dir = (0, dir_max_freq, dir_n_freqs)
+        self.depth, self.width, self.skips = depth, width, tuple(skips)
+
+
+def joiner_forward(weights, spec, pts, dirs, chunk=65536, return_hidden=False):
+    """reference models/vanilla.py:162-166: PE both inputs then NeRF.forward.  pts/dirs [...,3] -> [...,4]."""
+    shp = pts.shape[:-1]
+    p = pts.reshape(-1, 3).astype(F32)
+    d = dirs.reshape(-1, 3).astype(F32)
+    outs, hid = [], None
+    for s in range(0, p.shape[0], chunk):
+        x_pe = embed(p[s:s + chunk], spec.mapping, *spec.pos)
+        d_pe = embed(d[s:s + chunk], spec.mapping, *spec.dir)
+        r = nerf_forward(weights, x_pe, d_pe, spec.depth, spec.skips, return_hidden)
+        if return_hidden:
+            outs.append(r[0])
+            hid = r[1] if hid is None else [np.concatenate([a, b], 0) for a, b in zip(hid, r[1])]
+        else:
+            outs.append(r)
+    out = np.concatenate(outs, 0).reshape(*shp, 4)
+    return (out, hid) if return_hidden else out

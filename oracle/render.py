@@ -1,0 +1,172 @@
+"""Oracle: whole-frame renderers.
+
+numpy restatement of reference utils/render_utils.py:108-461.  A "net" here is a
+pair ``(weights, JoinerSpec)`` (oracle/nerf_mlp.py); ``cap`` is the reference
+duck-type (``.shape``, ``.intrinsic_matrix``, ``.cam_pose.camera_to_world``,
+``.near['bkg']``, ``.far['bkg']``).  Test infrastructure only.
+"""
+import numpy as np
+
+from . import ray_ops, warp
+from .compositing import raw2outputs, merge_sorted
+from .nerf_mlp import joiner_forward
+
+F32 = np.float32
+
+
+def _net(net, pts, dirs):
+    return joiner_forward(net[0], net[1], pts, dirs)
+
+
+def render_vanilla(coarse_net, cap, fine_net=None, rays_per_batch=32768, samples_per_ray=64,
+                   importance_samples_per_ray=128, white_bkg=True, near_far_source='bkg', return_depth=False,
+                   max_rays=None, cdf_ulps=0):
+    """reference utils/render_utils.py:108-161.  ``max_rays`` renders only a prefix of the frame (bounded CPU baseline);
+    ``cdf_ulps`` is the conditioning probe of ray_ops.sample_pdf."""
+    origins, dirs = ray_ops.shot_all_rays(cap.intrinsic_matrix, cap.cam_pose.camera_to_world, cap.shape)
+    total = origins.shape[0] if max_rays is None else min(max_rays, origins.shape[0])
+    rgbs, depths = [], []
+    for i in range(0, total, rays_per_batch):
+        j = min(i + rays_per_batch, total)
+        o, d = origins[i:j].astype(F32), dirs[i:j].astype(F32)
+        near = np.full((j - i, 1), cap.near[near_far_source], F32)
+        far = np.full((j - i, 1), cap.far[near_far_source], F32)
+        pts, dd, z = ray_ops.ray_to_samples(o, d, near, far, samples_per_ray)
+        out = _net(coarse_net, pts, dd)
+        rgb, _, _, w, depth = raw2outputs(out, z, dd[:, 0, :], white_bkg=white_bkg)
+        if fine_net is not None:
+            pts, dd, z = ray_ops.ray_to_importance_samples(o, d, z, w, importance_samples_per_ray, cdf_ulps=cdf_ulps)
+            out = _net(fine_net, pts, dd)
+            rgb, _, _, w, depth = raw2outputs(out, z, dd[:, 0, :], white_bkg=white_bkg)
+        rgbs.append(rgb)
+        depths.append(depth)
+    rgb = np.concatenate(rgbs)
+    depth = np.concatenate(depths)
+    if max_rays is None:
+        rgb, depth = rgb.reshape(*cap.shape, -1), depth.reshape(*cap.shape)
+    return (rgb, depth) if return_depth else rgb
+
+
+def _frame_rays(cap):
+    coords = ray_ops.all_pixel_coords(cap.shape)
+    o, d = ray_ops.shot_rays(cap.intrinsic_matrix, cap.cam_pose.camera_to_world, coords)
+    return o, d
+
+
+def render_smpl_nerf(net, cap, posed_verts, faces, Ts, rays_per_batch=32768, samples_per_ray=64, white_bkg=True,
+                     render_can=False, geo_threshold=ray_ops.DEFAULT_GEO_THRESH, return_depth=False,
+                     return_mask=False, interval_comp=1.0):
+    """reference utils/render_utils.py:164-246.  ``net`` = coarse_human_net pair."""
+    origins, dirs = _frame_rays(cap)
+    total = origins.shape[0]
+    rgbs, depths, accs = [], [], []
+    for i in range(0, total, rays_per_batch):
+        o, d = origins[i:i + rays_per_batch].astype(F32), dirs[i:i + rays_per_batch].astype(F32)
+        rgb = np.zeros_like(o)
+        depth = np.zeros(o.shape[0], F32)
+        acc = np.zeros(o.shape[0], F32)
+        near, far = ray_ops.geometry_guided_near_far(o, d, posed_verts, geo_threshold)
+        miss, hit = near >= far, near < far
+        if miss.any():
+            rgb[miss] = 1.0 if white_bkg else 0.0
+        if hit.any():
+            pts, dd, z = ray_ops.ray_to_samples(o[hit], d[hit], near[hit][:, None], far[hit][:, None], samples_per_ray)
+            if render_can:
+                can_pts, can_dirs = pts, dd
+            else:
+                can_pts, can_dirs, _ = warp.warp_samples_to_canonical(pts, posed_verts, faces, Ts)
+            out = _net(net, can_pts.astype(F32), can_dirs.astype(F32)).copy()
+            out[..., -1] *= F32(interval_comp)
+            _rgb, _, _acc, _, _depth = raw2outputs(out, z, dd[:, 0, :], white_bkg=white_bkg)
+            rgb[hit], depth[hit], acc[hit] = _rgb, _depth, _acc
+        rgbs.append(rgb)
+        depths.append(depth)
+        accs.append(acc)
+    rgb = np.concatenate(rgbs).reshape(*cap.shape, -1)
+    depth = np.concatenate(depths).reshape(*cap.shape)
+    acc = np.concatenate(accs).reshape(*cap.shape)
+    if return_depth and return_mask:
+        return rgb, depth, acc
+    if return_depth:
+        return rgb, depth
+    if return_mask:
+        return rgb, acc
+    return rgb
+
+
+def _bkg_pass(coarse, fine, o, d, near_v, far_v, samples_per_ray, n_importance, white_bkg):
+    near = np.full((o.shape[0], 1), near_v, F32)
+    far = np.full((o.shape[0], 1), far_v, F32)
+    pts, dd, z = ray_ops.ray_to_samples(o, d, near, far, samples_per_ray)
+    out = _net(coarse, pts, dd)
+    if fine is not None:
+        _, _, _, w, _ = raw2outputs(out, z, dd[:, 0, :], white_bkg=white_bkg)
+        pts, dd, z = ray_ops.ray_to_importance_samples(o, d, z, w, n_importance)
+        out = _net(fine, pts, dd)
+    return out, z
+
+
+def render_hybrid_nerf(coarse_bkg, fine_bkg, human, cap, posed_verts, faces, Ts, rays_per_batch=32768,
+                       samples_per_ray=64, importance_samples_per_ray=128, white_bkg=True,
+                       geo_threshold=ray_ops.DEFAULT_GEO_THRESH, return_depth=False):
+    """reference utils/render_utils.py:249-362."""
+    origins, dirs = _frame_rays(cap)
+    total = origins.shape[0]
+    rgbs, depths = [], []
+    for i in range(0, total, rays_per_batch):
+        o, d = origins[i:i + rays_per_batch].astype(F32), dirs[i:i + rays_per_batch].astype(F32)
+        rgb = np.zeros_like(o)
+        depth = np.zeros(o.shape[0], F32)
+        bkg_out, bkg_z = _bkg_pass(coarse_bkg, fine_bkg, o, d, cap.near['bkg'], cap.far['bkg'],
+                                   samples_per_ray, importance_samples_per_ray, white_bkg)
+        near, far = ray_ops.geometry_guided_near_far(o, d, posed_verts, geo_threshold)
+        miss, hit = near >= far, near < far
+        if miss.any():
+            _rgb, _, _, _, _depth = raw2outputs(bkg_out[miss], bkg_z[miss], d[miss], white_bkg=white_bkg)
+            rgb[miss], depth[miss] = _rgb, _depth
+        if hit.any():
+            pts, dd, hz = ray_ops.ray_to_samples(o[hit], d[hit], near[hit][:, None], far[hit][:, None], samples_per_ray)
+            can_pts, can_dirs, _ = warp.warp_samples_to_canonical(pts, posed_verts, faces, Ts)
+            h_out = _net(human, can_pts.astype(F32), can_dirs.astype(F32))
+            z_all, raw_all = merge_sorted([bkg_z[hit], hz], [bkg_out[hit], h_out])
+            _rgb, _, _, _, _depth = raw2outputs(raw_all, z_all, d[hit], white_bkg=white_bkg)
+            rgb[hit], depth[hit] = _rgb, _depth
+        rgbs.append(rgb)
+        depths.append(depth)
+    rgb = np.concatenate(rgbs).reshape(*cap.shape, -1)
+    depth = np.concatenate(depths).reshape(*cap.shape)
+    return (rgb, depth) if return_depth else rgb
+
+
+def render_hybrid_nerf_multi_persons(coarse_bkg, fine_bkg, humans, cap, posed_verts, faces, Ts, rays_per_batch=32768,
+                                     samples_per_ray=64, importance_samples_per_ray=128, white_bkg=True,
+                                     geo_threshold=ray_ops.DEFAULT_GEO_THRESH, return_depth=False):
+    """reference utils/render_utils.py:365-461."""
+    origins, dirs = _frame_rays(cap)
+    total = origins.shape[0]
+    rgbs, depths = [], []
+    for i in range(0, total, rays_per_batch):
+        o, d = origins[i:i + rays_per_batch].astype(F32), dirs[i:i + rays_per_batch].astype(F32)
+        n = o.shape[0]
+        bkg_out, bkg_z = _bkg_pass(coarse_bkg, fine_bkg, o, d, cap.near['bkg'], cap.far['bkg'],
+                                   samples_per_ray, importance_samples_per_ray, white_bkg)
+        outs, zs = [bkg_out], [bkg_z]
+        for net, v, f, T in zip(humans, posed_verts, faces, Ts):
+            near, far = ray_ops.geometry_guided_near_far(o, d, v, geo_threshold)
+            h_out = np.zeros((n, samples_per_ray, 4), F32)
+            h_z = np.stack([ray_ops.linspace_f32(cap.far['bkg'] * 2, cap.far['bkg'] * 3, samples_per_ray)] * n)
+            hit = near < far
+            if hit.any():
+                pts, dd, hz = ray_ops.ray_to_samples(o[hit], d[hit], near[hit][:, None], far[hit][:, None], samples_per_ray)
+                can_pts, can_dirs, _ = warp.warp_samples_to_canonical(pts, v, f, T)
+                h_out[hit] = _net(net, can_pts.astype(F32), can_dirs.astype(F32))
+                h_z[hit] = hz
+            outs.append(h_out)
+            zs.append(h_z)
+        z_all, raw_all = merge_sorted(zs, outs)
+        rgb, _, _, _, depth = raw2outputs(raw_all, z_all, d, white_bkg=white_bkg)
+        rgbs.append(rgb)
+        depths.append(depth)
+    rgb = np.concatenate(rgbs).reshape(*cap.shape, -1)
+    depth = np.concatenate(depths).reshape(*cap.shape)
+    return (rgb, depth) if return_depth else rgb

@@ -1,0 +1,123 @@
+"""Oracle: observation -> canonical warp of ray samples.  **parity unpinned**.
+
+Restates reference utils/ray_utils.py:48-66 (warp_samples_to_canonical).  The
+reference calls libigl 2.2.1 (environment.yml:13, not vendored, not installable
+offline) for the closest-point query (:53) and the barycentrics (:55) and has
+no test that pins either, so this file follows the published definitions:
+
+* ``closest_point_on_mesh``: exact Euclidean closest point on every triangle
+  (Voronoi-region test, Ericson "Real-Time Collision Detection" 5.1.5), global
+  arg-min of the squared distance over the faces -- what
+  ``igl.point_mesh_squared_distance`` returns (sqrD, face id, closest point);
+* ``barycentric_coordinates_tri``: barycentrics of that point in the winning
+  triangle, ordered (v0, v1, v2), cross-checked against the reference's own
+  differentiable formula at utils/ray_utils.py:73-88.
+
+On shared edges/vertices the winning face id is implementation-defined, but the
+blended transform is continuous across faces, so parity is defined on
+(closest point, can_pts, can_dirs), never on the face id.  Test infrastructure only.
+"""
+import numpy as np
+
+F32 = np.float32
+
+
+def _dot(a, b):
+    return np.sum(a * b, axis=-1)
+
+
+def closest_point_on_triangles(p, a, b, c):
+    """p [N,1,3], a/b/c [1,F,3] (float64) -> closest point [N,F,3]."""
+    ab, ac, ap = b - a, c - a, p - a
+    d1, d2 = _dot(ab, ap), _dot(ac, ap)
+    bp = p - b
+    d3, d4 = _dot(ab, bp), _dot(ac, bp)
+    cp = p - c
+    d5, d6 = _dot(ab, cp), _dot(ac, cp)
+    vc = d1 * d4 - d3 * d2
+    vb = d5 * d2 - d1 * d6
+    va = d3 * d6 - d5 * d4
+    with np.errstate(divide='ignore', invalid='ignore'):
+        v_ab = d1 / (d1 - d3)
+        w_ac = d2 / (d2 - d6)
+        w_bc = (d4 - d3) / ((d4 - d3) + (d5 - d6))
+        denom = 1.0 / (va + vb + vc)
+    v_in, w_in = vb * denom, vc * denom
+    conds = [
+        (d1 <= 0) & (d2 <= 0),                         # vertex A
+        (d3 >= 0) & (d4 <= d3),                        # vertex B
+        (vc <= 0) & (d1 >= 0) & (d3 <= 0),             # edge AB
+        (d6 >= 0) & (d5 <= d6),                        # vertex C
+        (vb <= 0) & (d2 >= 0) & (d6 <= 0),             # edge AC
+        (va <= 0) & ((d4 - d3) >= 0) & ((d5 - d6) >= 0),   # edge BC
+    ]
+    zeros = np.zeros_like(d1)
+    # barycentric (v, w) of the closest point: q = a + v*ab + w*ac
+    v_sel = np.select(conds, [zeros, zeros + 1, v_ab, zeros, zeros, 1 - w_bc], default=v_in)
+    w_sel = np.select(conds, [zeros, zeros, zeros, zeros + 1, w_ac, w_bc], default=w_in)
+    return a + ab * v_sel[..., None] + ac * w_sel[..., None]
+
+
+def closest_point_on_mesh(pts, verts, faces, chunk=32):
+    """igl.point_mesh_squared_distance(P, V, F) -> (sqrD [N], face id [N], closest [N,3]).  float64 math."""
+    p = pts.astype(np.float64)
+    v = verts.astype(np.float64)
+    a, b, c = v[faces[:, 0]][None], v[faces[:, 1]][None], v[faces[:, 2]][None]
+    n = p.shape[0]
+    sqr = np.empty(n)
+    fid = np.empty(n, np.int64)
+    closest = np.empty((n, 3))
+    for s in range(0, n, chunk):
+        q = closest_point_on_triangles(p[s:s + chunk, None, :], a, b, c)
+        d2 = _dot(q - p[s:s + chunk, None, :], q - p[s:s + chunk, None, :])
+        i = np.argmin(d2, axis=1)
+        r = np.arange(i.shape[0])
+        fid[s:s + chunk] = i
+        sqr[s:s + chunk] = d2[r, i]
+        closest[s:s + chunk] = q[r, i]
+    return sqr, fid, closest
+
+
+def barycentric_coordinates_tri(p, a, b, c):
+    """igl.barycentric_coordinates_tri(P, A, B, C) -> [N,3] weights of (A,B,C)."""
+    v0, v1, v2 = b - a, c - a, p - a
+    d00, d01, d11 = _dot(v0, v0), _dot(v0, v1), _dot(v1, v1)
+    d20, d21 = _dot(v2, v0), _dot(v2, v1)
+    denom = d00 * d11 - d01 * d01
+    v = (d11 * d20 - d01 * d21) / denom
+    w = (d00 * d21 - d01 * d20) / denom
+    return np.stack([1.0 - v - w, v, w], axis=1)
+
+
+def barycentric_reference_diff_formula(p, a, b, c):
+    """The reference's own in-repo barycentric formula, utils/ray_utils.py:73-88 (ordering cross-check)."""
+    n = np.cross(b - a, c - a)
+    denom = _dot(n, n)
+    u = _dot(n, np.cross(c - b, p - b)) / denom
+    v = _dot(n, np.cross(a - c, p - c)) / denom
+    return np.stack([u, v, 1 - u - v], axis=1)
+
+
+def warp_samples_to_canonical(pts, verts, faces, T):
+    """reference utils/ray_utils.py:48-66.
+
+    pts [R,S,3] f32, verts [V,3] f32, faces [F,>=3] int, T [>=V,4,4] f64
+    -> can_pts [R,S,3], can_dirs [R,S,3], closest [R,S,3] (float64, callers cast
+    to f32 as utils/render_utils.py:226-227 does).
+    """
+    assert pts.ndim == 3 and pts.shape[-1] == 3
+    num_rays, num_samples, _ = pts.shape
+    flat = pts.reshape(-1, 3)
+    tri = faces[:, :3]
+    _, f_id, closest = closest_point_on_mesh(flat, verts, tri)
+    ctri = verts[tri[f_id]].astype(np.float64)
+    bary = barycentric_coordinates_tri(closest, ctri[:, 0], ctri[:, 1], ctri[:, 2])
+    T_interp = (T[tri[f_id]] * bary[..., None, None]).sum(axis=1)
+    T_inv = np.linalg.inv(T_interp)
+    hom = np.concatenate([flat.astype(np.float64), np.ones((flat.shape[0], 1))], -1)
+    can_pts = (T_inv @ hom[..., None])[:, :3, 0].reshape(num_rays, num_samples, 3)
+    closest = closest.reshape(num_rays, num_samples, 3)
+    can_dirs = can_pts[:, 1:] - can_pts[:, :-1]
+    can_dirs = np.concatenate([can_dirs, can_dirs[:, -1:]], axis=1)
+    can_dirs = can_dirs / np.linalg.norm(can_dirs, axis=2, keepdims=True)
+    return can_pts, can_dirs, closest
