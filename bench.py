@@ -1,0 +1,168 @@
+#!/usr/bin/env python
+"""bench.py -- rays/s of the NeuMan ray-march hot path on MI355X (BASELINE.json metric, config 2).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one 800x800 frame of the background NeRF: 128 coarse + 128 importance samples per ray (the reference
+evaluates the 8x256 MLP 128 + 256 = 384 times per ray, render_utils.py:108-161), synthetic-dense weights
+(SURVEY 8d), rays already resident in HBM when the timed region starts.  With N > 1 the frame's ray tiles are
+sharded across the ranks (no data-path collective) and assembled on rank 0 by one RCCL gather per frame, which is
+inside the timed region; total work is fixed, so `scaling` is "strong".
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (nerf_mlp_kernel, bf16x3): algorithmic FLOPs
+(1,186,816 per MLP evaluation) / its launch time measured with HIP events on the launch stream, against the
+2.5 PFLOP/s dense bf16 MFMA peak.  `cpu_baseline` times the CPU restatement of the reference (the numpy port under
+oracle/, kind "port") on a bounded prefix of the same frame, on this box's host cores (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "ml-neuman_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FLOP_PER_EVAL = 1186816            # 593,408 MAC per sample evaluation
+PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA, MI355X_MICROARCH.md
+W, H, S, NI = 800, 800, 128, 128
+EVALS_PER_RAY = S + (S + NI)
+TILE = 8192
+
+
+def cpu_baseline(max_rays=4096):
+    """CPU restatement of the reference renderer (oracle/render.py, numpy + BLAS on all host cores) on the first
+    `max_rays` rays of the same frame with the same weights and sampling.  Reported, never the thing shipped."""
+    from oracle import render as oracle_render
+    from oracle.nerf_mlp import JoinerSpec
+    from neuman_hip import synthetic
+    cap = synthetic.SimpleCapture(W, H)
+    nets = [(synthetic.state_numpy(synthetic.make_joiner(seed)), JoinerSpec()) for seed in (0, 1)]
+    oracle_render.render_vanilla(nets[0], cap, nets[1], rays_per_batch=2048, samples_per_ray=S,
+                                 importance_samples_per_ray=NI, max_rays=256)           # warm BLAS threads
+    t0 = time.perf_counter()
+    oracle_render.render_vanilla(nets[0], cap, nets[1], rays_per_batch=2048, samples_per_ray=S,
+                                 importance_samples_per_ray=NI, max_rays=max_rays)
+    dt = time.perf_counter() - t0
+    return {"value": max_rays / dt, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"first {max_rays} rays of the 800x800 frame, 128+128 samples/ray, rays_per_batch=2048, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback exists for the hot path)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from neuman_hip import parallel, ray_utils, render_utils, synthetic
+    dev = torch.device("cuda", local)
+    coarse = synthetic.make_joiner(0).to(dev)
+    fine = synthetic.make_joiner(1).to(dev)
+    coarse.precision = fine.precision = args.precision
+    cap = synthetic.SimpleCapture(W, H)
+    o_np, d_np = ray_utils.shot_all_rays(cap)
+    origins = torch.from_numpy(o_np).to(dev, torch.float32).contiguous()
+    dirs = torch.from_numpy(d_np).to(dev, torch.float32).contiguous()
+    total = origins.shape[0]
+    idx = parallel.tile_ray_indices(total, TILE, rank, world, device=dev)
+    o_loc, d_loc = origins[idx].contiguous(), dirs[idx].contiguous()       # this rank's rays, resident in HBM
+
+    # HIP events around every MLP launch (same stream the kernel is launched on: torch's current stream)
+    mlp_events = []
+    for net in (coarse, fine):
+        inner = net.forward_rays
+
+        def timed(o, d, z, precision=None, sigma_scale=1.0, _inner=inner):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = _inner(o, d, z, precision=precision, sigma_scale=sigma_scale)
+            e1.record()
+            mlp_events.append((e0, e1, z.numel()))
+            return out
+        net.forward_rays = timed
+
+    def step():
+        rgb, depth = render_utils.render_vanilla_rays(coarse, fine, o_loc, d_loc, cap.near['bkg'], cap.far['bkg'], S, NI, True)
+        return parallel.gather_frame(torch.cat([rgb, depth[:, None]], 1), idx, total, TILE)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            frame = step()
+        mlp_events.clear()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            frame = step()
+        sync()
+        dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = t.item()
+
+    evals = sum(n for _, _, n in mlp_events)
+    mlp_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in mlp_events)
+    achieved = evals * FLOP_PER_EVAL / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+
+    if rank == 0:
+        psnr = None
+        if args.precision != "fp32":            # quality check outside the timed region: first 32 rows vs the exact-f32 device path
+            with torch.no_grad():
+                n = 32 * W
+                for net in (coarse, fine):
+                    net.__dict__.pop('forward_rays', None)      # drop the event-recording wrappers
+                a, _ = render_utils.render_vanilla_rays(coarse, fine, origins[:n], dirs[:n], 0.0, 3.14, S, NI, True)
+                coarse.precision = fine.precision = "fp32"
+                b, _ = render_utils.render_vanilla_rays(coarse, fine, origins[:n], dirs[:n], 0.0, 3.14, S, NI, True)
+                psnr = float(10 * torch.log10(1.0 / torch.clamp(((a - b).double() ** 2).mean(), min=1e-30)))
+        line = {
+            "metric": "rays_per_sec (800x800 frame, 128 samples/ray coarse + 128 importance, NeuMan background NeRF)",
+            "value": total * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": {"bf16x3": "bf16x3 (split-bf16 hi+lo MFMA x3, f32 accumulate)", "bf16": "bf16 (f32 accumulate)", "fp32": "f32"}[args.precision],
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: background NeRF (models/vanilla.py 8x256, posenc), 800x800 = 640000 rays, "
+                                   "128 coarse + 256 fine MLP evaluations per ray, synthetic-dense weights (seeds 0/1), near 0 far 3.14",
+                       "rays_per_frame": total, "mlp_evals_per_ray": EVALS_PER_RAY, "parallelism": f"ray-tile sharding x{world}, 1 gather/frame",
+                       "tile_rays": TILE},
+            "psnr_db_vs_f32_device_path": psnr,
+            "roofline": {"bound": "mfma", "kernel": "nerf_mlp_kernel<bf16x3>" if args.precision == "bf16x3" else f"nerf_mlp ({args.precision})",
+                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+                         "traffic": None, "launches": len(mlp_events), "avg_launch_ms": mlp_ms / max(1, len(mlp_events)),
+                         "note": "algorithmic FLOPs = 1,186,816 per MLP evaluation; bf16x3 issues 3 MFMAs per algorithmic one, "
+                                 "so hardware MFMA utilisation is 3x frac"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,154 @@
+"""-m gpu: the fused PE + MLP kernel (MFMA split-bf16 and exact-f32 modes) vs the CPU oracle, layer by layer."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_mlp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu_nets(nets):
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    return {k: (j.cuda(), sd, spec) for k, (j, sd, spec) in nets.items()}
+
+
+def cu(x):
+    return torch.as_tensor(np.ascontiguousarray(x)).to('cuda', torch.float32).contiguous()
+
+
+def sample_inputs(n, seed=11):
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform(-1.5, 1.5, size=(n, 3)).astype(np.float32)
+    dirs = rng.normal(size=(n, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    return pts, dirs
+
+
+def report(tag, got, ref):
+    e = np.abs(got - ref)
+    print(f"[mlp] {tag}: max abs err {e.max():.3e} (ref scale {np.abs(ref).max():.3e}), mean {e.mean():.3e}")
+    return e.max()
+
+
+@pytest.mark.parametrize("seed", [0, 2])
+@pytest.mark.parametrize("prec", ["fp32", "bf16x3"])
+def test_stage_by_stage(gpu_nets, seed, prec):
+    """Every intermediate the kernel can dump (PE, the eight hidden layers, feature, views) vs the oracle."""
+    j, sd, spec = gpu_nets[seed]
+    pts, dirs = sample_inputs(300)
+    out, hidden = nerf_mlp.joiner_forward(sd, spec, pts, dirs, return_hidden=True)
+    x_pe = nerf_mlp.embed(pts, spec.mapping, *spec.pos)
+    pe = j.forward_debug(cu(pts), cu(dirs), -1, precision=prec).cpu().numpy()
+    # rotate PE: the argument x.B^T reaches ~1e3 rad, one f32 ulp of it is 6e-5 and the summation order is BLAS's
+    pe_tol = (3e-4 if spec.mapping == 'rotate' else 2e-6) + (1.6e-5 if prec == "bf16x3" else 0)
+    assert report(f"seed{seed} {prec} PE", pe[:, :63], x_pe) < pe_tol
+    assert np.abs(pe[:, 63]).max() == 0
+    scale = 30 if spec.mapping == 'rotate' else 1          # error inherited from the rotate PE argument
+    for st in range(10):
+        got = j.forward_debug(cu(pts), cu(dirs), st, precision=prec).cpu().numpy()
+        ref = hidden[st]
+        assert got.shape == ref.shape
+        tol = (2e-5 if prec == "fp32" else 6e-5) * scale * max(1.0, np.abs(ref).max())
+        assert report(f"seed{seed} {prec} stage {st}", got, ref) < tol, f"stage {st}"
+    got = j(cu(pts), cu(dirs), precision=prec).cpu().numpy()
+    assert report(f"seed{seed} {prec} rgb", got[:, :3], out[:, :3]) < 1e-4 * scale
+    assert report(f"seed{seed} {prec} sigma", got[:, 3], out[:, 3]) < 2e-4 * scale * max(1.0, np.abs(out[:, 3]).max())
+
+
+def test_golden_outputs(gpu_nets, golden):
+    g = golden['mlp']
+    for seed, mapping in [(0, 'posenc'), (2, 'rotate')]:
+        j = gpu_nets[seed][0]
+        got = j(cu(g['pts']), cu(g['dirs'])).cpu().numpy()
+        ref = g[f'{mapping}_out']
+        s = 30 if mapping == 'rotate' else 1
+        assert report(f"golden {mapping} rgb", got[:, :3], ref[:, :3]) < 1e-4 * s
+        assert report(f"golden {mapping} sigma", got[:, 3], ref[:, 3]) < 2e-4 * s * max(1.0, np.abs(ref[:, 3]).max())
+
+
+@pytest.mark.parametrize("n", [1, 31, 127, 128, 129, 1000, 128 * 300 + 5])
+def test_ragged_sizes_and_entry_points(gpu_nets, n):
+    j, sd, spec = gpu_nets[0]
+    pts, dirs = sample_inputs(n, seed=n)
+    a = j(cu(pts), cu(dirs))
+    b = j(cu(pts), cu(dirs), precision="fp32")
+    assert a.shape == (n, 4) and torch.isfinite(a).all()
+    assert (a[:, :3] - b[:, :3]).abs().max() < 5e-5
+    assert ((a[:, 3] - b[:, 3]).abs() / (1 + b[:, 3].abs())).max() < 2e-4
+    if n <= 1000:
+        ref = nerf_mlp.joiner_forward(sd, spec, pts, dirs)
+        assert np.abs(a.cpu().numpy()[:, :3] - ref[:, :3]).max() < 1e-4
+    # [..., 3] leading shapes are kept
+    if n == 1000:
+        c = j(cu(pts).reshape(10, 100, 3), cu(dirs).reshape(10, 100, 3))
+        assert c.shape == (10, 100, 4) and torch.equal(c.reshape(-1, 4), a)
+
+
+def test_forward_rays_equals_forward_on_built_points(gpu_nets):
+    """The fused point construction must be bit-identical to ray_to_samples + forward, and sigma_scale = `*= interval_comp`."""
+    from neuman_hip import ray_utils
+    j = gpu_nets[2][0]
+    rng = np.random.default_rng(3)
+    R, S = 77, 48
+    o = cu(rng.normal(size=(R, 3)) * 0.3)
+    d = rng.normal(size=(R, 3)).astype(np.float32)
+    d = cu(d / np.linalg.norm(d, axis=1, keepdims=True))
+    near, far = cu(rng.uniform(0.1, 0.5, R)), cu(rng.uniform(1.0, 2.0, R))
+    pts, dirs, z = ray_utils.sample_z(o, d, near, far, S, want_points=True)
+    a = j.forward_rays(o, d, z)
+    b = j(pts, dirs)
+    assert torch.equal(a, b)
+    c = j.forward_rays(o, d, z, sigma_scale=0.7)
+    assert torch.equal(c[..., :3], a[..., :3]) and torch.equal(c[..., 3], a[..., 3] * 0.7)
+    for prec in ("fp32",):
+        assert torch.equal(j.forward_rays(o, d, z, precision=prec), j(pts, dirs, precision=prec))
+
+
+def test_weight_cache_tracks_parameter_updates(gpu_nets):
+    j, sd, spec = gpu_nets[1]
+    pts, dirs = sample_inputs(200)
+    a = j(cu(pts), cu(dirs))
+    with torch.no_grad():
+        j.nerf.rgb_linear.bias.add_(0.25)
+    b = j(cu(pts), cu(dirs))
+    assert (b[:, :3] - a[:, :3] - 0.25).abs().max() < 1e-5
+    with torch.no_grad():
+        j.nerf.rgb_linear.bias.sub_(0.25)
+    assert torch.equal(j(cu(pts), cu(dirs)), a)
+
+
+def test_bf16_fast_mode_is_sane_but_not_parity_grade(gpu_nets):
+    j, sd, spec = gpu_nets[0]
+    pts, dirs = sample_inputs(4096)
+    ref = j(cu(pts), cu(dirs), precision="fp32")
+    fast = j(cu(pts), cu(dirs), precision="bf16")
+    par = j(cu(pts), cu(dirs), precision="bf16x3")
+    e_fast = (fast[:, :3] - ref[:, :3]).abs().max().item()
+    e_par = (par[:, :3] - ref[:, :3]).abs().max().item()
+    print(f"[mlp] rgb(raw) max err vs fp32: bf16 {e_fast:.3e}, bf16x3 {e_par:.3e}")
+    assert e_par < 5e-5 and e_fast < 0.5 and e_par < e_fast
+
+
+def test_full_size_bf16x3_vs_fp32_kernel(gpu_nets):
+    """BASELINE-size sample count through two independent device implementations (MFMA split-bf16 vs VALU f32)."""
+    j = gpu_nets[0][0]
+    g = torch.Generator(device='cuda').manual_seed(0)
+    n = 1 << 20
+    pts = (torch.rand((n, 3), device='cuda', generator=g) * 3 - 1.5).contiguous()
+    dirs = torch.nn.functional.normalize(torch.randn((n, 3), device='cuda', generator=g), dim=-1).contiguous()
+    a = j(pts, dirs, precision="bf16x3")
+    b = j(pts, dirs, precision="fp32")
+    e_rgb = (a[:, :3] - b[:, :3]).abs().max().item()
+    e_sig = ((a[:, 3] - b[:, 3]).abs() / (1 + b[:, 3].abs())).max().item()
+    print(f"[mlp] 1M samples: raw rgb max err {e_rgb:.3e}, sigma rel err {e_sig:.3e}")
+    assert e_rgb < 1e-4 and e_sig < 3e-4
+    # linearity in the last layer: rgb(raw) is affine in rgb_linear.bias -- a size-independent property
+    with torch.no_grad():
+        j.nerf.rgb_linear.bias.add_(1.0)
+    c = j(pts, dirs, precision="bf16x3")
+    with torch.no_grad():
+        j.nerf.rgb_linear.bias.sub_(1.0)
+    assert (c[:, :3] - a[:, :3] - 1.0).abs().max() < 1e-5 and torch.equal(c[:, 3], a[:, 3])

@@ -1,0 +1,113 @@
+"""CPU check of the MFMA weight image (nm_mlp_pack) against the oracle MLP.
+
+The packed image is consumed here by a numpy *emulation of the kernel's data flow* (csrc/mlp.hip): activations are
+addressed by (chunk, element) k-slots exactly as the LDS arrays are, weights are read back from the fragment
+positions a lane would load ([stage][block][k-step][hi|lo][lane][8]), and every layer output is re-slotted the way
+the epilogue's ds_write_b128 does.  If the emulation reproduces the oracle network, the host packer, the k-slot
+permutation (mlp_layout.h) and the stage table agree with each other -- without a GPU.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from neuman_hip import _lib
+from oracle import nerf_mlp
+
+STAGES = {0: (8, 4, 4), 5: (8, 20, 4), 8: (9, 16, 0), 9: (4, 18, 2), 10: (1, 8, 0)}  # nblk, steps, pe_steps
+
+
+def shape(s):
+    return STAGES.get(s, (8, 16, 0))
+
+
+def w_off(s):
+    return sum(shape(i)[0] * shape(i)[1] * 2048 for i in range(s))
+
+
+def b_off(s):
+    return sum(shape(i)[0] * 32 for i in range(s))
+
+
+def slot_feature(c, e):
+    return 32 * (c >> 2) + 8 * (2 * ((c >> 1) & 1) + (e >> 2)) + 4 * (c & 1) + (e & 3)
+
+
+def bf16_to_f32(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+def stage_weights(img, s):
+    """W_eff [nblk*32, steps*16] = hi + lo, columns ordered by k-slot (step, lane half g, element j)."""
+    nblk, steps, _ = shape(s)
+    frag = np.frombuffer(img, dtype=np.uint16, count=nblk * steps * 1024, offset=w_off(s)).reshape(nblk, steps, 2, 64, 8)
+    w = bf16_to_f32(frag[:, :, 0]) + bf16_to_f32(frag[:, :, 1])          # [nblk, steps, lane, j]
+    w = w.reshape(nblk, steps, 2, 32, 8)                                    # lane = g*32 + row
+    return w.transpose(0, 3, 1, 2, 4).reshape(nblk * 32, steps * 16)       # [n, (t, g, j)]
+
+
+def slots_from_features(h, nchunks):
+    """[N, F] natural features -> [N, nchunks*8] in k-slot order (what the epilogue leaves in LDS)."""
+    idx = np.array([slot_feature(c, e) for c in range(nchunks) for e in range(8)])
+    return h[:, idx]
+
+
+def emulate(img, pts, dirs, spec):
+    total_w = w_off(11)
+    bias = np.frombuffer(img, dtype=np.float32, offset=total_w + 4 * 2048)
+    x_pe = nerf_mlp.embed(pts, spec.mapping, *spec.pos)
+    d_pe = nerf_mlp.embed(dirs, spec.mapping, *spec.dir)
+    P = np.zeros((pts.shape[0], 64), np.float32)
+    P[:, :x_pe.shape[1]] = x_pe
+    Pd = np.zeros((pts.shape[0], 32), np.float32)
+    Pd[:, :d_pe.shape[1]] = d_pe
+
+    def run(s, act_slots, n_out):
+        W = stage_weights(img, s)
+        assert W.shape[1] == act_slots.shape[1], (s, W.shape, act_slots.shape)
+        b = bias[b_off(s):b_off(s) + W.shape[0]]
+        return (act_slots.astype(np.float64) @ W.T.astype(np.float64) + b)[:, :n_out].astype(np.float32)
+
+    h = np.maximum(run(0, P, 256), 0)
+    for s in range(1, 8):
+        a = slots_from_features(h, 32)
+        if s == 5:
+            a = np.concatenate([P, a], 1)                                   # PE steps first (mlp.hip stage loop)
+        h = np.maximum(run(s, a, 256), 0)
+    o8 = run(8, slots_from_features(h, 32), 288)
+    feature, sigma = o8[:, :256], o8[:, 256]
+    assert np.abs(o8[:, 257:]).max() == 0
+    v = np.maximum(run(9, np.concatenate([slots_from_features(feature, 32), Pd], 1), 128), 0)   # h steps first, then d_pe
+    o10 = run(10, slots_from_features(v, 16), 32)
+    assert np.abs(o10[:, 3:]).max() == 0
+    return np.concatenate([o10[:, :3], sigma[:, None]], 1)
+
+
+@pytest.mark.parametrize("seed", [0, 2])
+def test_pack_matches_oracle(nets, seed):
+    joiner, sd, spec = nets[seed]
+    lib = _lib.lib()
+    desc = _lib.MlpDesc(8, 256, 4, _lib.NM_PE_ROTATE if spec.mapping == 'rotate' else _lib.NM_PE_POSENC, 10, 4)
+    nbytes = lib.nm_mlp_pack_bytes(ctypes.byref(desc))
+    assert nbytes == w_off(11) + 4 * 2048 + 4 * b_off(11)
+    host = [p.detach().contiguous() for p in joiner.nerf.ordered_params()]
+    arr = (ctypes.c_void_p * 24)(*[t.data_ptr() for t in host])
+    img = ctypes.create_string_buffer(nbytes)
+    _lib.check(lib.nm_mlp_pack(ctypes.byref(desc), arr, img), "nm_mlp_pack")
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(-1.5, 1.5, size=(64, 3)).astype(np.float32)
+    dirs = rng.normal(size=(64, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    got = emulate(img.raw, pts, dirs, spec)
+    ref = nerf_mlp.joiner_forward(sd, spec, pts, dirs)
+    # weights carry 16 significant bits (bf16 hi + bf16 lo); activations are exact here
+    assert np.abs(got[:, :3] - ref[:, :3]).max() < 2e-4
+    assert np.abs(got[:, 3] - ref[:, 3]).max() < 2e-3 * max(1.0, np.abs(ref[:, 3]).max())
+
+
+def test_pack_rejects_unsupported_nets():
+    lib = _lib.lib()
+    for bad in [(6, 256, 4, 0, 10, 4), (8, 128, 4, 0, 10, 4), (8, 256, 4, 0, 11, 4), (8, 256, 4, 3, 10, 4)]:
+        desc = _lib.MlpDesc(*bad)
+        assert lib.nm_mlp_pack_bytes(ctypes.byref(desc)) == -1
+        assert b"nm_mlp" in lib.nm_last_error()

@@ -1,0 +1,67 @@
+"""Multi-rank ray-tile sharding + frame gather, on CPU with gloo (world_size 1, 2 and 4)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from neuman_hip import parallel
+
+
+def test_tile_assignment_is_a_partition():
+    for total, tile, world in [(4096, 256, 2), (1000, 64, 4), (640000, 8192, 8), (5, 8, 2)]:
+        seen = torch.cat([parallel.tile_ray_indices(total, tile, r, world) for r in range(world)])
+        assert seen.numel() == total and torch.equal(torch.sort(seen)[0], torch.arange(total))
+        sizes = [parallel.tile_ray_indices(total, tile, r, world).numel() for r in range(world)]
+        assert max(sizes) <= parallel.max_local_rays(total, tile, world)
+        assert max(sizes) - min(sizes) <= tile
+
+
+def _fake_render(o, d):
+    # deterministic per-ray "pixel": depends only on the ray, like the real renderer
+    return torch.stack([o[:, 0] + d[:, 1], o[:, 1] * d[:, 2], d[:, 0], (o * d).sum(-1)], 1)
+
+
+def _worker(rank, world, port, total, tile, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    o = torch.randn(total, 3, generator=g)
+    d = torch.randn(total, 3, generator=g)
+    frame = parallel.render_sharded(_fake_render, o, d, tile=tile, dst=0)
+    if rank == 0:
+        q.put(frame.numpy())
+    else:
+        assert frame is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,total,tile", [(2, 1000, 64), (4, 777, 32)])
+def test_sharded_render_matches_single_rank(world, total, tile):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, tile, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    frame = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(0)
+    o = torch.randn(total, 3, generator=g)
+    d = torch.randn(total, 3, generator=g)
+    np.testing.assert_array_equal(frame, _fake_render(o, d).numpy())
+
+
+def test_world_size_one_needs_no_process_group():
+    o, d = torch.randn(300, 3), torch.randn(300, 3)
+    frame = parallel.render_sharded(_fake_render, o, d, tile=64)
+    assert torch.equal(frame, _fake_render(o, d))
