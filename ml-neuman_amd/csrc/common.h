@@ -17,6 +17,7 @@ inline hipStream_t as_stream(nm_stream_t s) { return reinterpret_cast<hipStream_
 
 }  // namespace nm
 
+// entry points accept null pointers for an empty batch (R == 0): an empty torch tensor has data_ptr() == 0
 #define NM_REQUIRE(cond, ...)          \
     do {                               \
         if (!(cond)) {                 \

@@ -229,14 +229,14 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
 
 int nm_mlp_forward(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision, float sigma_scale,
                    float* out, nm_stream_t stream) {
-    NM_REQUIRE(pts && dirs && out, "nm_mlp_forward: null pointer");
+    NM_REQUIRE(n == 0 || (pts && dirs && out), "nm_mlp_forward: null pointer");
     NM_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "nm_mlp_forward: out must be 16-byte aligned");
     return mlp_dispatch(mlp, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, precision, -2, sigma_scale, out, nullptr, stream);
 }
 
 int nm_mlp_forward_rays(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals, int64_t R, int S,
                         int precision, float sigma_scale, float* out, nm_stream_t stream) {
-    NM_REQUIRE(origin && direction && z_vals && out, "nm_mlp_forward_rays: null pointer");
+    NM_REQUIRE(R == 0 || (origin && direction && z_vals && out), "nm_mlp_forward_rays: null pointer");
     NM_REQUIRE(R >= 0 && S >= 1, "nm_mlp_forward_rays: bad sizes");
     NM_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "nm_mlp_forward_rays: out must be 16-byte aligned");
     return mlp_dispatch(mlp, nullptr, nullptr, origin, direction, z_vals, R * (int64_t)S, S, 1, precision, -2, sigma_scale, out,
@@ -245,7 +245,7 @@ int nm_mlp_forward_rays(nm_mlp_t mlp, const float* origin, const float* directio
 
 int nm_mlp_forward_debug(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision, int stage,
                          float* hidden, nm_stream_t stream) {
-    NM_REQUIRE(pts && dirs && hidden, "nm_mlp_forward_debug: null pointer");
+    NM_REQUIRE(n == 0 || (pts && dirs && hidden), "nm_mlp_forward_debug: null pointer");
     NM_REQUIRE(stage >= -1 && stage <= 9, "nm_mlp_forward_debug: stage %d outside -1..9", stage);
     return mlp_dispatch(mlp, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, precision, stage, 1.f, nullptr, hidden, stream);
 }

@@ -119,7 +119,7 @@ extern "C" {
 
 int nm_near_far(const float* origin, const float* direction, int64_t R, const float* verts, int V, double geo_threshold,
                 float* near, float* far, nm_stream_t stream) {
-    NM_REQUIRE(origin && direction && verts && near && far, "nm_near_far: null pointer");
+    NM_REQUIRE(R == 0 || (origin && direction && verts && near && far), "nm_near_far: null pointer");
     NM_REQUIRE(R >= 0 && V >= 1, "nm_near_far: bad sizes");
     if (R == 0) return NM_OK;
     const float tau2 = (float)(geo_threshold * geo_threshold);             // python float ** 2, then f32 (ray_utils.py:211)

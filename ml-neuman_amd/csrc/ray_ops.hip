@@ -312,7 +312,7 @@ extern "C" {
 int nm_ray_to_samples(const float* origin, const float* direction, const float* near, const float* far, int64_t R, int S,
                       const float* t_vals, int lindisp, const float* t_rand, float* pts, float* dirs, float* z_vals,
                       nm_stream_t stream) {
-    NM_REQUIRE(origin && direction && near && far && t_vals && z_vals, "nm_ray_to_samples: null pointer");
+    NM_REQUIRE(R == 0 || (origin && direction && near && far && t_vals && z_vals), "nm_ray_to_samples: null pointer");
     NM_REQUIRE(R >= 0 && S >= 1, "nm_ray_to_samples: bad sizes R=%lld S=%d", (long long)R, S);
     if (R == 0) return NM_OK;
     hipLaunchKernelGGL(ray_to_samples_kernel, dim3(grid_for(R * S, 256)), dim3(256), 0, nm::as_stream(stream), origin,
@@ -322,7 +322,7 @@ int nm_ray_to_samples(const float* origin, const float* direction, const float* 
 
 int nm_z_to_points(const float* origin, const float* direction, const float* z_vals, int64_t R, int S, float* pts,
                    float* dirs, nm_stream_t stream) {
-    NM_REQUIRE(origin && direction && z_vals, "nm_z_to_points: null pointer");
+    NM_REQUIRE(R == 0 || (origin && direction && z_vals), "nm_z_to_points: null pointer");
     NM_REQUIRE(R >= 0 && S >= 1, "nm_z_to_points: bad sizes");
     if (R == 0) return NM_OK;
     hipLaunchKernelGGL(z_to_points_kernel, dim3(grid_for(R * S, 256)), dim3(256), 0, nm::as_stream(stream), origin,
@@ -333,7 +333,7 @@ int nm_z_to_points(const float* origin, const float* direction, const float* z_v
 int nm_composite(const float* raw, const float* z_vals, const float* rays_d, int64_t R, int S, int white_bkg,
                  const float* noise, float* rgb, float* disp, float* acc, float* weights, float* depth,
                  nm_stream_t stream) {
-    NM_REQUIRE(raw && z_vals && rays_d && rgb && acc && depth, "nm_composite: null pointer");
+    NM_REQUIRE(R == 0 || (raw && z_vals && rays_d && rgb && acc && depth), "nm_composite: null pointer");
     NM_REQUIRE(R >= 0 && S >= 1, "nm_composite: bad sizes R=%lld S=%d", (long long)R, S);
     NM_REQUIRE((reinterpret_cast<uintptr_t>(raw) & 15) == 0, "nm_composite: raw must be 16-byte aligned");
     if (R == 0) return NM_OK;
@@ -345,7 +345,7 @@ int nm_composite(const float* raw, const float* z_vals, const float* rays_d, int
 
 int nm_sample_pdf(const float* bins, const float* weights, int64_t R, int B, const float* u, int N, float* samples,
                   nm_stream_t stream) {
-    NM_REQUIRE(bins && weights && u && samples, "nm_sample_pdf: null pointer");
+    NM_REQUIRE(R == 0 || (bins && weights && u && samples), "nm_sample_pdf: null pointer");
     NM_REQUIRE(R >= 0 && B >= 2 && N >= 1, "nm_sample_pdf: bad sizes");
     const size_t lds = (size_t)kRayWavesPerBlock * (2 * B + N) * sizeof(float);
     NM_REQUIRE(lds <= 64 * 1024, "nm_sample_pdf: B=%d N=%d exceed the per-wave LDS budget", B, N);
@@ -357,7 +357,7 @@ int nm_sample_pdf(const float* bins, const float* weights, int64_t R, int B, con
 
 int nm_importance_z(const float* z_vals, const float* weights, int64_t R, int S, const float* u, int N,
                     int including_old, float* z_out, nm_stream_t stream) {
-    NM_REQUIRE(z_vals && weights && u && z_out, "nm_importance_z: null pointer");
+    NM_REQUIRE(R == 0 || (z_vals && weights && u && z_out), "nm_importance_z: null pointer");
     NM_REQUIRE(R >= 0 && S >= 3 && N >= 1, "nm_importance_z: bad sizes S=%d N=%d", S, N);
     const int B = S - 1;
     const size_t lds = (size_t)kRayWavesPerBlock * (2 * B + N + S) * sizeof(float);
@@ -370,7 +370,7 @@ int nm_importance_z(const float* z_vals, const float* weights, int64_t R, int S,
 
 int nm_merge_sorted(const float* za, const float* rawa, int Sa, const float* zb, const float* rawb, int Sb, int64_t R,
                     float* z_out, float* raw_out, nm_stream_t stream) {
-    NM_REQUIRE(za && rawa && zb && rawb && z_out && raw_out, "nm_merge_sorted: null pointer");
+    NM_REQUIRE(R == 0 || (za && rawa && zb && rawb && z_out && raw_out), "nm_merge_sorted: null pointer");
     NM_REQUIRE(R >= 0 && Sa >= 1 && Sb >= 1, "nm_merge_sorted: bad sizes");
     NM_REQUIRE(((reinterpret_cast<uintptr_t>(rawa) | reinterpret_cast<uintptr_t>(rawb) | reinterpret_cast<uintptr_t>(raw_out)) & 15) == 0,
                "nm_merge_sorted: raw arrays must be 16-byte aligned");
@@ -385,7 +385,7 @@ int nm_merge_sorted(const float* za, const float* rawa, int Sa, const float* zb,
 
 int nm_gather_rows(const float* src, const int32_t* idx, const int32_t* n_dev, int64_t n_max, int width, float* dst,
                    nm_stream_t stream) {
-    NM_REQUIRE(src && idx && dst, "nm_gather_rows: null pointer");
+    NM_REQUIRE(n_max == 0 || (src && idx && dst), "nm_gather_rows: null pointer");
     NM_REQUIRE(n_max >= 0 && width >= 1, "nm_gather_rows: bad sizes");
     if (n_max == 0) return NM_OK;
     hipLaunchKernelGGL(rows_kernel<false>, dim3(grid_for(n_max * width, 256)), dim3(256), 0, nm::as_stream(stream), src,
@@ -395,7 +395,7 @@ int nm_gather_rows(const float* src, const int32_t* idx, const int32_t* n_dev, i
 
 int nm_scatter_rows(const float* src, const int32_t* idx, const int32_t* n_dev, int64_t n_max, int width, float* dst,
                     nm_stream_t stream) {
-    NM_REQUIRE(src && idx && dst, "nm_scatter_rows: null pointer");
+    NM_REQUIRE(n_max == 0 || (src && idx && dst), "nm_scatter_rows: null pointer");
     NM_REQUIRE(n_max >= 0 && width >= 1, "nm_scatter_rows: bad sizes");
     if (n_max == 0) return NM_OK;
     hipLaunchKernelGGL(rows_kernel<true>, dim3(grid_for(n_max * width, 256)), dim3(256), 0, nm::as_stream(stream), src,

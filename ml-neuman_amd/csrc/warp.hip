@@ -180,7 +180,7 @@ int64_t nm_warp_workspace_floats(int F) { return (int64_t)F * 16; }
 int nm_warp_to_canonical(const float* pts, int64_t R, int S, const float* verts, int V, const int32_t* faces, int F,
                          const double* T, float* can_pts, float* can_dirs, float* closest, float* workspace,
                          nm_stream_t stream) {
-    NM_REQUIRE(pts && verts && faces && T && can_pts && can_dirs && workspace, "nm_warp_to_canonical: null pointer");
+    NM_REQUIRE(R == 0 || (pts && verts && faces && T && can_pts && can_dirs && workspace), "nm_warp_to_canonical: null pointer");
     NM_REQUIRE(R >= 0 && S >= 2 && V >= 3 && F >= 1, "nm_warp_to_canonical: bad sizes R=%lld S=%d V=%d F=%d", (long long)R, S, V, F);
     NM_REQUIRE((size_t)S * 24 <= 64 * 1024, "nm_warp_to_canonical: S=%d exceeds the LDS staging budget", S);
     NM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 63) == 0, "nm_warp_to_canonical: workspace must be 64-byte aligned");

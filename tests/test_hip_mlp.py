@@ -111,12 +111,13 @@ def test_weight_cache_tracks_parameter_updates(gpu_nets):
     j, sd, spec = gpu_nets[1]
     pts, dirs = sample_inputs(200)
     a = j(cu(pts), cu(dirs))
+    saved = j.nerf.rgb_linear.bias.detach().clone()
     with torch.no_grad():
         j.nerf.rgb_linear.bias.add_(0.25)
     b = j(cu(pts), cu(dirs))
     assert (b[:, :3] - a[:, :3] - 0.25).abs().max() < 1e-5
     with torch.no_grad():
-        j.nerf.rgb_linear.bias.sub_(0.25)
+        j.nerf.rgb_linear.bias.copy_(saved)
     assert torch.equal(j(cu(pts), cu(dirs)), a)
 
 
@@ -146,9 +147,10 @@ def test_full_size_bf16x3_vs_fp32_kernel(gpu_nets):
     print(f"[mlp] 1M samples: raw rgb max err {e_rgb:.3e}, sigma rel err {e_sig:.3e}")
     assert e_rgb < 1e-4 and e_sig < 3e-4
     # linearity in the last layer: rgb(raw) is affine in rgb_linear.bias -- a size-independent property
+    saved = j.nerf.rgb_linear.bias.detach().clone()
     with torch.no_grad():
         j.nerf.rgb_linear.bias.add_(1.0)
     c = j(pts, dirs, precision="bf16x3")
     with torch.no_grad():
-        j.nerf.rgb_linear.bias.sub_(1.0)
+        j.nerf.rgb_linear.bias.copy_(saved)
     assert (c[:, :3] - a[:, :3] - 1.0).abs().max() < 1e-5 and torch.equal(c[:, 3], a[:, 3])

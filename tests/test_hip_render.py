@@ -158,8 +158,13 @@ def test_warp_vs_oracle(G):
     ocp, ocd, ocl = OW.warp_samples_to_canonical(pts, posed, faces, T)
     assert isinstance(cp, np.ndarray) and cp.shape == (R, S, 3)
     print(f"[warp] closest Linf {np.abs(cl - ocl).max():.3e}, can_pts Linf {np.abs(cp - ocp).max():.3e}, can_dirs Linf {np.abs(cd - ocd).max():.3e}")
-    np.testing.assert_allclose(cl, ocl, atol=2e-5)
-    np.testing.assert_allclose(cp, ocp, atol=2e-4)
+    # the invariant of a closest-point query is the DISTANCE; inside the concave side of the surface a point can have two
+    # nearly equidistant feet on adjacent faces, and f32 (device) vs f64 (oracle) may pick either
+    np.testing.assert_allclose(np.linalg.norm(cl - pts, axis=-1), np.linalg.norm(ocl - pts, axis=-1), atol=2e-6)
+    same = np.abs(cl - ocl).max(-1) < 2e-5
+    assert same.mean() > 0.99 and np.abs(cl - ocl).max() < 2e-3
+    np.testing.assert_allclose(cp[same], ocp[same], atol=1e-5)
+    np.testing.assert_allclose(cp, ocp, atol=5e-4)
     # distance property: the returned closest point is no farther than any vertex (igl semantics)
     dmin = np.sqrt(((pts[:, :, None, :] - posed[None, None]) ** 2).sum(-1)).min(-1)
     assert (np.linalg.norm(cl - pts, axis=-1) <= dmin + 1e-6).all()
