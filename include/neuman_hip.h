@@ -144,6 +144,11 @@ int nm_mlp_forward_rays(nm_mlp_t mlp, const float* origin, const float* directio
  *    8 -> feature_linear output (256);  9 -> relu(views_linears[0]) (128). */
 int nm_mlp_forward_debug(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision,
                          int stage, float* hidden, nm_stream_t stream);
+/* Profiling build of the bf16x3 kernel: same result in `out`, plus per-wave s_memtime totals in
+ * cycles[(workgroup*8 + wave)*8 + bucket], bucket = {0 PE, 1 k-loops, 2 wait before epilogue, 3 epilogue,
+ * 4 wait after epilogue, 5 tile tail}; cycles must hold 64 * min(#CUs, ceil(n/128)) uint64. */
+int nm_mlp_forward_profile(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, float* out,
+                           uint64_t* cycles, nm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a11  warp_samples_to_canonical -- reference utils/ray_utils.py:48-66

@@ -55,6 +55,7 @@ struct MlpArgs {
     const float* z;          // in_mode 1: [R,S]
     float* out;              // [n,4]
     float* dbg;              // debug dump or nullptr
+    unsigned long long* prof;  // PROF instantiation only: [grid*8 waves][8] cycle buckets
     int64_t n;
     int S;
     int in_mode;
@@ -254,8 +255,18 @@ __device__ __forceinline__ void dump_act(const uint4* lds, bool from_pe, int wid
     }
 }
 
-template <int PREC>
+// PROF: accumulate s_memtime deltas per wave into 6 buckets {pe, k-loops, wait before epilogue, epilogue, wait after
+// epilogue, tail} (a.prof[(block*8 + wave)*8 + bucket]); a separate instantiation so the production kernel is untouched.
+template <int PREC, bool PROF>
 __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) {
+    unsigned long long pr[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = PROF ? __builtin_readcyclecounter() : 0;
+#define NM_TICK(b)                                                   \
+    if (PROF) {                                                      \
+        const unsigned long long t_now = __builtin_readcyclecounter(); \
+        pr[b] += t_now - t_prev;                                     \
+        t_prev = t_now;                                              \
+    }
     __shared__ uint4 lds[LDS_U4];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -272,6 +283,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
         // ---------------- position PE -> P
         fill_pe(lds, nm::kPeChunks, false, a, base, tid);
         __syncthreads();
+        NM_TICK(0)
         if (a.stop_stage == -1) { dump_act(lds, true, 64, a, base, tid); __syncthreads(); continue; }
 
         // ---------------- stages 0..7: 256-wide ReLU layers (wave w = output block w, all 4 sample blocks)
@@ -288,10 +300,14 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
             }
             if (sh.steps > sh.pe_steps)
                 k_run<4, PREC>(acc, wsrc, voff, soff, lds + H_BASE + g * kChunkU4 + s, sh.steps - sh.pe_steps);
+            NM_TICK(1)
             __syncthreads();                                      // every wave has finished reading H (and P)
+            NM_TICK(2)
             store_act<4, true, PREC>(acc, lds, w, 0, g, s);
             if (st == 5) fill_pe(lds, 4, true, a, base, tid);     // P is free after the skip layer: direction PE -> P[0..3]
+            NM_TICK(3)
             __syncthreads();
+            NM_TICK(4)
             if (a.stop_stage == st) { dump_act(lds, false, 256, a, base, tid); stopped = true; break; }
         }
         if (stopped) { __syncthreads(); continue; }
@@ -310,9 +326,13 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
                                lds + H_BASE + g * kChunkU4 + 32 * w + s, sh.steps);
                 sigma = aacc[0][0];                               // feature row 0 of the block: lanes 0..31 (g == 0)
             }
+            NM_TICK(1)
             __syncthreads();
+            NM_TICK(2)
             store_act<4, false, PREC>(acc, lds, w, 0, g, s);
+            NM_TICK(3)
             __syncthreads();
+            NM_TICK(4)
             if (a.stop_stage == 8) { dump_act(lds, false, 256, a, base, tid); __syncthreads(); continue; }
         }
 
@@ -326,9 +346,13 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
             k_run<2, PREC>(vacc, wsrc, voff, soff, lds + H_BASE + g * kChunkU4 + row0 + s, sh.steps - sh.pe_steps);
             k_run<2, PREC>(vacc, wsrc, voff, soff + (sh.steps - sh.pe_steps) * nm::kStepBytes,
                            lds + P_BASE + g * kChunkU4 + row0 + s, sh.pe_steps);
+            NM_TICK(1)
             __syncthreads();
+            NM_TICK(2)
             store_act<2, true, PREC>(vacc, lds, nb, row0, g, s);
+            NM_TICK(3)
             __syncthreads();
+            NM_TICK(4)
             if (a.stop_stage == 9) { dump_act(lds, false, 128, a, base, tid); __syncthreads(); continue; }
         }
 
@@ -342,8 +366,15 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
             if (g == 0 && i < a.n)                                // rows 0,1,2 = regs 0,1,2 of the g == 0 half
                 reinterpret_cast<float4*>(a.out)[i] = make_float4(racc[0][0], racc[0][1], racc[0][2], sigma * a.sigma_scale);
         }
+        NM_TICK(1)
         __syncthreads();                                          // H / P are rewritten by the next tile
+        NM_TICK(5)
     }
+    if (PROF && lane == 0) {
+#pragma unroll
+        for (int b = 0; b < 6; ++b) a.prof[((int64_t)blockIdx.x * 8 + w) * 8 + b] = pr[b];
+    }
+#undef NM_TICK
 }
 
 }  // namespace
@@ -352,13 +383,13 @@ namespace nm {
 
 int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
                     const float* z, int64_t n, int S, int in_mode, int precision, int stop_stage, float sigma_scale, float* out,
-                    float* dbg, hipStream_t stream) {
+                    float* dbg, void* prof, hipStream_t stream) {
     MlpArgs a;
     a.wpack = reinterpret_cast<const uint4*>(L.wpack);
     a.bias = L.bias;
     a.petab = L.petab;
     a.pts = pts; a.dirs = dirs; a.origin = origin; a.direction = direction; a.z = z;
-    a.out = out; a.dbg = dbg; a.n = n; a.S = S; a.in_mode = in_mode; a.stop_stage = stop_stage; a.sigma_scale = sigma_scale;
+    a.out = out; a.dbg = dbg; a.prof = reinterpret_cast<unsigned long long*>(prof); a.n = n; a.S = S; a.in_mode = in_mode; a.stop_stage = stop_stage; a.sigma_scale = sigma_scale;
     a.pos = PeSpec{L.pe_kind, L.pos_nfreq};
     a.dir = PeSpec{L.pe_kind, L.dir_nfreq};
     const int64_t ntiles = (n + kTileM - 1) / kTileM;
@@ -368,10 +399,12 @@ int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, con
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     const int grid = (int)(ntiles < cus ? ntiles : cus);          // one 160 KB workgroup per CU, grid-stride over tiles
-    if (precision == NM_PREC_BF16X3)
-        hipLaunchKernelGGL(nerf_mlp_kernel<NM_PREC_BF16X3>, dim3(grid), dim3(kThreads), 0, stream, a);
+    if (prof)
+        hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_BF16X3, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+    else if (precision == NM_PREC_BF16X3)
+        hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_BF16X3, false>), dim3(grid), dim3(kThreads), 0, stream, a);
     else
-        hipLaunchKernelGGL(nerf_mlp_kernel<NM_PREC_BF16>, dim3(grid), dim3(kThreads), 0, stream, a);
+        hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_BF16, false>), dim3(grid), dim3(kThreads), 0, stream, a);
     return check_launch("nerf_mlp_kernel");
 }
 

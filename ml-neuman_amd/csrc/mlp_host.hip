@@ -204,7 +204,7 @@ int nm_mlp_destroy(nm_mlp_t m) {
 
 static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const float* origin, const float* direction,
                         const float* z, int64_t n, int S, int in_mode, int precision, int stop_stage, float sigma_scale,
-                        float* out, float* dbg, nm_stream_t stream) {
+                        float* out, float* dbg, nm_stream_t stream, void* prof = nullptr) {
     NM_REQUIRE(m, "nm_mlp_forward: null handle");
     NM_REQUIRE(n >= 0, "nm_mlp_forward: negative n");
     NM_REQUIRE(precision == NM_PREC_FP32 || precision == NM_PREC_BF16X3 || precision == NM_PREC_BF16,
@@ -224,7 +224,7 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
     L.petab = m->d_petab;
     L.pe_kind = m->desc.pe_kind; L.pos_nfreq = m->desc.pos_n_freqs; L.dir_nfreq = m->desc.dir_n_freqs;
     return nm::launch_mlp_mfma(L, pts, dirs, origin, direction, z, n, S, in_mode, precision, stop_stage, sigma_scale, out, dbg,
-                               nm::as_stream(stream));
+                               prof, nm::as_stream(stream));
 }
 
 int nm_mlp_forward(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision, float sigma_scale,
@@ -241,6 +241,12 @@ int nm_mlp_forward_rays(nm_mlp_t mlp, const float* origin, const float* directio
     NM_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "nm_mlp_forward_rays: out must be 16-byte aligned");
     return mlp_dispatch(mlp, nullptr, nullptr, origin, direction, z_vals, R * (int64_t)S, S, 1, precision, -2, sigma_scale, out,
                         nullptr, stream);
+}
+
+int nm_mlp_forward_profile(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, float* out, uint64_t* cycles,
+                           nm_stream_t stream) {
+    NM_REQUIRE(n == 0 || (pts && dirs && out && cycles), "nm_mlp_forward_profile: null pointer");
+    return mlp_dispatch(mlp, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, NM_PREC_BF16X3, -2, 1.f, out, nullptr, stream, cycles);
 }
 
 int nm_mlp_forward_debug(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision, int stage,

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64 * kRayWavesPerBlock) void composite_kernel(
         const float dx = rays_d[r * 3 + 0], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
         const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);            // render_utils.py:88
         const float* zr = z_vals + r * S;
-        float t_carry = 1.f;
+        double t_carry = 1.0;
         float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
         for (int c0 = 0; c0 < S; c0 += 64) {
             const int s = c0 + lane;
@@ -102,10 +102,17 @@ __global__ __launch_bounds__(64 * kRayWavesPerBlock) void composite_kernel(
                 w = alpha;
                 f = 1.f - alpha + 1e-10f;                                   // render_utils.py:95
             }
-            const float incl = wave_scan_mul(f, lane);
-            float excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = 1.f;
-            w = w * (t_carry * excl);
+            // transmittance: running product in f64, rounded to f32 per entry -- order independent, and what torch's
+            // CPU cumprod computes for f32 inputs (the weights feed the inverse-CDF step function)
+            double incl = (double)f;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const double t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl *= t;
+            }
+            double excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0;
+            w = w * (float)(t_carry * excl);
             t_carry = t_carry * __shfl(incl, 63, 64);
             if (valid) {
                 if (weights) weights[r * S + s] = w;
@@ -175,19 +182,25 @@ __global__ __launch_bounds__(64 * kRayWavesPerBlock) void sample_pdf_kernel(
         const bool live = r0 + wib < R;
         const int64_t r = live ? r0 + wib : R - 1;
         // ---- bins and (weights + 1e-5)
-        float wsum = 0.f;
+        // The inverse-CDF lookup below is a step function of the f32 cdf entries, so the two
+        // reductions are done the way that is independent of the reduction ORDER: the normaliser is the correctly
+        // rounded f32 sum (f64 accumulate) and the running sum accumulates in f64 and rounds every entry to f32 -- which
+        // is what torch's CPU cumsum does (acc_type<float> = double) and what oracle/ray_ops.py restates.
+        double wsum_d = 0.0;
         if (MODE == 0) {
             for (int i = lane; i < B; i += 64) bins[i] = in_a[r * B + i];
-            for (int i = lane; i < nW; i += 64) wsum += in_w[r * nW + i] + 1e-5f;
+            for (int i = lane; i < nW; i += 64) wsum_d += (double)(in_w[r * nW + i] + 1e-5f);
         } else {
             const float* zr = in_a + r * S;
             for (int i = lane; i < S; i += 64) zl[i] = zr[i];
             for (int i = lane; i < B; i += 64) bins[i] = .5f * (zr[i + 1] + zr[i]);     // ray_utils.py:148
-            for (int i = lane; i < nW; i += 64) wsum += in_w[r * S + 1 + i] + 1e-5f;     // weights[..., 1:-1], :149
+            for (int i = lane; i < nW; i += 64) wsum_d += (double)(in_w[r * S + 1 + i] + 1e-5f);   // weights[..., 1:-1], :149
         }
-        wsum = wave_sum(wsum);                                                           // ray_utils.py:167
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wsum_d += __shfl_xor(wsum_d, o, 64);
+        const float wsum = (float)wsum_d;                                                // ray_utils.py:167
         // ---- cdf = [0, cumsum(pdf)]                                                   // ray_utils.py:168-169
-        float carry = 0.f;
+        double carry = 0.0;
         if (lane == 0) cdf[0] = 0.f;
         for (int c0 = 0; c0 < nW; c0 += 64) {
             const int i = c0 + lane;
@@ -196,8 +209,13 @@ __global__ __launch_bounds__(64 * kRayWavesPerBlock) void sample_pdf_kernel(
                 const float wv = (MODE == 0 ? in_w[r * nW + i] : in_w[r * S + 1 + i]) + 1e-5f;
                 p = wv / wsum;
             }
-            const float inc = wave_scan_add(p, lane);
-            if (i < nW) cdf[i + 1] = carry + inc;
+            double inc = (double)p;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const double t = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += t;
+            }
+            if (i < nW) cdf[i + 1] = (float)(carry + inc);
             carry = carry + __shfl(inc, 63, 64);
         }
         __syncthreads();
