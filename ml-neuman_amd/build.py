@@ -18,6 +18,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "lib", "libneuman_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("NM_EXTRA_FLAGS", "").split()      # experiment knobs, e.g. -DNM_PRIO_MODE=2
 
 
 def _newer(target, deps):

@@ -42,6 +42,7 @@ static_assert(LDS_U4 * 16 == 160 * 1024, "LDS plan must be exactly 160 KiB");
 struct PeSpec {
     int kind;     // NM_PE_POSENC / NM_PE_ROTATE
     int nfreq;
+    int octaves;  // 1: bands are consecutive powers of two -> octave recurrence (fill_pe_fast)
 };
 
 struct MlpArgs {
@@ -124,84 +125,135 @@ __device__ __forceinline__ bf16x8 ld_w(__amdgpu_buffer_rsrc_t wsrc, int voff, in
     return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wsrc, voff, soff, 0));
 }
 
-template <int MB, int PREC>
-__device__ __forceinline__ void k_run(f32x16 (&acc)[MB], __amdgpu_buffer_rsrc_t wsrc, int voff, int soff, const uint4* xh,
-                                      int nsteps) {
-    // 2-step-deep register prefetch of the weight stream (L2 -> VGPR); the image is padded so the
-    // reads past the last step of the net stay in bounds.
-    bf16x8 wh[2], wl[2];
+// The wave's weight stream is one register-resident pipeline across runs, stages and tiles: W holds the fragments of
+// the next two k-steps to be consumed.  The last iteration of a run does not prefetch past its own end but the first
+// two steps of the NEXT run (next_soff), so the L2 latency of every run's head is hidden behind the epilogue /
+// barriers in between instead of being exposed 13 times per tile.
+struct WPre {
+    bf16x8 h[2], l[2];
+};
+template <int PREC>
+__device__ __forceinline__ void w_prefetch(WPre& W, __amdgpu_buffer_rsrc_t wsrc, int voff, int soff) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        wh[u] = ld_w(wsrc, voff, soff + u * nm::kStepBytes);
-        if (PREC == NM_PREC_BF16X3) wl[u] = ld_w(wsrc, voff, soff + u * nm::kStepBytes + 1024);
-    }
-#pragma unroll 1
-    for (int t = 0; t < nsteps; t += 2) {
-        bf16x8 nh[2], nl[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            nh[u] = ld_w(wsrc, voff, soff + (t + 2 + u) * nm::kStepBytes);
-            if (PREC == NM_PREC_BF16X3) nl[u] = ld_w(wsrc, voff, soff + (t + 2 + u) * nm::kStepBytes + 1024);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint4* ph = xh + (t + u) * (2 * kChunkU4);
-            const uint4* pl = ph + kLoU4;
-            bf16x8 bh[MB], bl[MB];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                bh[mb] = as_bf16x8(ph[mb * 32]);
-                if (PREC == NM_PREC_BF16X3) bl[mb] = as_bf16x8(pl[mb * 32]);
-            }
-            if (PREC == NM_PREC_BF16X3) {
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[u], bl[mb], acc[mb], 0, 0, 0);
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[u], bh[mb], acc[mb], 0, 0, 0);
-            }
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[u], bh[mb], acc[mb], 0, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            wh[u] = nh[u];
-            if (PREC == NM_PREC_BF16X3) wl[u] = nl[u];
-        }
+        W.h[u] = ld_w(wsrc, voff, soff + u * nm::kStepBytes);
+        if (PREC == NM_PREC_BF16X3) W.l[u] = ld_w(wsrc, voff, soff + u * nm::kStepBytes + 1024);
+#ifdef NM_L2_PROBE   // experiment: double the L2 -> CU weight traffic (second, distinct 2 KB per step) to measure headroom
+        bf16x8 d0 = ld_w(wsrc, voff, (soff + u * nm::kStepBytes + 65536) % (2 * 1024 * 1024));
+        bf16x8 d1 = ld_w(wsrc, voff, (soff + u * nm::kStepBytes + 65536 + 1024) % (2 * 1024 * 1024));
+        asm volatile("" ::"v"(d0), "v"(d1));
+#endif
     }
 }
 
-// accumulator init = bias of feature (reg&3) + 8*(reg>>2) + 4*g of this block
-template <int MB>
-__device__ __forceinline__ void init_bias(f32x16 (&acc)[MB], const float* __restrict__ bias_blk, int g) {
-    float b[16];
+#ifndef NM_PRIO_MODE
+#define NM_PRIO_MODE 0      // experiment knob (tools/mlp_profile.py): MFMA-pipe arbitration between the two waves of a SIMD
+#endif
+template <int MB, int PREC>
+__device__ __forceinline__ void k_run(f32x16 (&acc)[MB], WPre& W, __amdgpu_buffer_rsrc_t wsrc, int voff, int soff, int next_soff,
+                                      const uint4* xh, int nsteps, bool prio_phase = false) {
+    // activation fragments are software-pipelined one k-step ahead in two register sets (x[0] / x[1]): the LDS latency
+    // of step t+1 is covered by the 12 MFMAs of step t instead of being exposed at the head of every step
+    bf16x8 bh[2][MB], bl[2][MB];
+    auto load_x = [&](int set, int t) {
+        const uint4* ph = xh + t * (2 * kChunkU4);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(bias_blk + 8 * q + 4 * g);
-        b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+        for (int mb = 0; mb < MB; ++mb) {
+            bh[set][mb] = as_bf16x8(ph[mb * 32]);
+            if (PREC == NM_PREC_BF16X3) bl[set][mb] = as_bf16x8(ph[kLoU4 + mb * 32]);
+        }
+    };
+    auto mfmas = [&](int set, bf16x8 ah, bf16x8 al) {
+        if (PREC == NM_PREC_BF16X3) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[set][mb], acc[mb], 0, 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[set][mb], acc[mb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[set][mb], acc[mb], 0, 0, 0);
+    };
+    load_x(0, 0);
+#pragma unroll 1
+    for (int t = 0; t < nsteps; t += 2) {
+        const int pf = (t + 2 < nsteps) ? soff + (t + 2) * nm::kStepBytes : next_soff;   // wave-uniform
+        WPre N;
+        w_prefetch<PREC>(N, wsrc, voff, pf);
+        load_x(1, t + 1);
+#if NM_PRIO_MODE == 2
+        __builtin_amdgcn_s_setprio(1);
+#elif NM_PRIO_MODE == 3
+        __builtin_amdgcn_s_setprio(prio_phase ? 0 : 1);
+#endif
+        mfmas(0, W.h[0], W.l[0]);
+        if (t + 2 < nsteps) load_x(0, t + 2);
+#if NM_PRIO_MODE == 2
+        __builtin_amdgcn_s_setprio(0);
+#elif NM_PRIO_MODE == 3
+        __builtin_amdgcn_s_setprio(prio_phase ? 1 : 0);
+#endif
+        mfmas(1, W.h[1], W.l[1]);
+        W = N;
     }
+}
+
+// bias of this lane's 16 features (reg&3) + 8*(reg>>2) + 4*g of a 32-feature block: loaded early (before the previous
+// stage's epilogue), used as the accumulators' initial value
+struct BiasRegs {
+    float4 q[4];
+};
+__device__ __forceinline__ void bias_prefetch(BiasRegs& B, const float* __restrict__ bias_blk, int g) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) B.q[q] = *reinterpret_cast<const float4*>(bias_blk + 8 * q + 4 * g);
+}
+template <int MB>
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[MB], const BiasRegs& B) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mb][r] = b[r];
+        for (int q = 0; q < 4; ++q) {
+            acc[mb][4 * q + 0] = B.q[q].x; acc[mb][4 * q + 1] = B.q[q].y;
+            acc[mb][4 * q + 2] = B.q[q].z; acc[mb][4 * q + 3] = B.q[q].w;
+        }
 }
 
 // write a wave's accumulators as the next layer's input: block blk, sample rows row0 + 32*mb + s
-template <int MB, bool RELU, int PREC>
-__device__ __forceinline__ void store_act(const f32x16 (&acc)[MB], uint4* lds, int blk, int row0, int g, int s) {
+// The epilogue is split around the "all reads of H done" barrier: the VALU half (ReLU + hi/lo split) runs BEFORE it --
+// the wave that finishes its k-loop first (the older wave of each SIMD wins MFMA arbitration) converts while its partner
+// is still issuing MFMAs, on the otherwise idle VALU -- and only the ds_write_b128s remain after the barrier.
+#ifdef NM_EPI_LATE      // experiment knob: convert after the barrier (the pre-split behaviour)
+#define NM_BAR_A __syncthreads();
+#define NM_BAR_B
+#else
+#define NM_BAR_A
+#define NM_BAR_B __syncthreads();
+#endif
+template <int MB>
+struct ActRegs {
+    uint4 hi[MB][2], lo[MB][2];
+};
+template <int MB, bool RELU>
+__device__ __forceinline__ void convert_act(const f32x16 (&acc)[MB], ActRegs<MB>& r) {
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = acc[mb][8 * qp + e];
-            uint4 hi, lo;
-            split8<RELU>(v, hi, lo);
-            const int idx = H_BASE + (4 * blk + 2 * qp + g) * kChunkU4 + row0 + 32 * mb + s;
-            lds[idx] = hi;
-            if (PREC == NM_PREC_BF16X3) lds[idx + kLoU4] = lo;
+            split8<RELU>(v, r.hi[mb][qp], r.lo[mb][qp]);
         }
-    }
+}
+template <int MB, int PREC>
+__device__ __forceinline__ void write_act(const ActRegs<MB>& r, uint4* lds, int blk, int row0, int g, int s) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+            const int idx = H_BASE + (4 * blk + 2 * qp + g) * kChunkU4 + row0 + 32 * mb + s;
+            lds[idx] = r.hi[mb][qp];
+            if (PREC == NM_PREC_BF16X3) lds[idx + kLoU4] = r.lo[mb][qp];
+        }
 }
 
 // fill `nchunks` PE chunks for the tile: work item = (chunk, sample); 8 features -> one b128 write per array
@@ -237,6 +289,71 @@ __device__ __forceinline__ void fill_pe(uint4* lds, int nchunks, bool is_dir, co
         lds[P_BASE + c * kChunkU4 + row] = hi;
         lds[P_BASE + c * kChunkU4 + kLoU4 + row] = lo;
     }
+}
+
+// Octave recurrence for the encodings (valid when the bands are consecutive powers of two -- the reference defaults,
+// checked on the host): f32 scaling by 2^b is exact, so the argument of band b is exactly 2^b * a0, where a0 is the band-0
+// argument (x_j for posenc, fmaf-chain(x, B[j]) for rotate).  One f64 sincos(a0) per (sample, component) and the double
+// angle formulas in f64 (error doubles per octave from 1e-16: 1e-13 at band 9) give sin/cos(2^b a0) rounded to f32 --
+// within an ulp of the reference's sinf(fl(x * f_b)) -- for ~1/6 of the instructions of 2N full-range sincosf calls.
+// Work item = (component j, sample); each of the 2N values is one 2-byte LDS store per half.
+__device__ __forceinline__ void fill_pe_fast(uint4* lds, bool is_dir, const MlpArgs& a, int64_t base, int tid) {
+    const PeSpec spec = is_dir ? a.dir : a.pos;
+    const float* tab = a.petab + (is_dir ? 96 : 0);
+    if (tid >= 3 * kTileM) return;
+    const int j = tid >> 7, row = tid & (kTileM - 1);          // j is wave-uniform (128 = 2 waves per component)
+    int64_t i = base + row;
+    if (i >= a.n) i = a.n - 1;
+    float x0, x1, x2;
+    if (a.in_mode == 0) {
+        const float* src = (is_dir ? a.dirs : a.pts) + i * 3;
+        x0 = src[0]; x1 = src[1]; x2 = src[2];
+    } else {
+        const int64_t r = i / a.S;
+        const float* d = a.direction + r * 3;
+        if (is_dir) {
+            x0 = d[0]; x1 = d[1]; x2 = d[2];
+        } else {
+            const float zz = a.z[i];
+            const float* o = a.origin + r * 3;
+            x0 = o[0] + d[0] * zz; x1 = o[1] + d[1] * zz; x2 = o[2] + d[2] * zz;     // ray_utils.py:131
+        }
+    }
+    const float xj = j == 0 ? x0 : (j == 1 ? x1 : x2);
+    float a0;
+    if (spec.kind == NM_PE_POSENC) a0 = xj * tab[0];
+    else a0 = fmaf(x2, tab[3 * j + 2], fmaf(x1, tab[3 * j + 1], x0 * tab[3 * j]));
+    unsigned short* hi = reinterpret_cast<unsigned short*>(lds + P_BASE);
+    unsigned short* lo = hi + kLoU4 * 8;
+    auto put = [&](int p, float v) {                          // feature slot p of this row: chunk p>>3, element p&7
+        const bf16x2 hb = __builtin_convertvector((f32x2){v, 0.f}, bf16x2);
+        const f32x2 hf = __builtin_convertvector(hb, f32x2);
+        const bf16x2 lb = __builtin_convertvector((f32x2){v - hf.x, 0.f}, bf16x2);
+        const int off = ((p >> 3) * kChunkU4 + row) * 8 + (p & 7);
+        hi[off] = (unsigned short)(__builtin_bit_cast(unsigned, hb) & 0xffffu);
+        lo[off] = (unsigned short)(__builtin_bit_cast(unsigned, lb) & 0xffffu);
+    };
+    put(j, xj);                                               // include_input: features 0..2
+    double sn, cs;
+    sincos((double)a0, &sn, &cs);
+    const int n3 = 3 * spec.nfreq;
+    for (int b = 0; b < spec.nfreq; ++b) {
+        if (spec.kind == NM_PE_POSENC) {                      // [sin(f_b x)(3), cos(f_b x)(3)] per band, vanilla.py:73-76
+            put(3 + 6 * b + j, (float)sn);
+            put(3 + 6 * b + 3 + j, (float)cs);
+        } else {                                              // [sin(x B^T)(3N), cos(x B^T)(3N)], vanilla.py:85-88
+            put(3 + 3 * b + j, (float)sn);
+            put(3 + n3 + 3 * b + j, (float)cs);
+        }
+        const double s2 = 2.0 * sn * cs, c2 = 1.0 - 2.0 * sn * sn;
+        sn = s2;
+        cs = c2;
+    }
+}
+
+__device__ __forceinline__ void fill_pe_any(uint4* lds, bool is_dir, const MlpArgs& a, int64_t base, int tid) {
+    if ((is_dir ? a.dir : a.pos).octaves) fill_pe_fast(lds, is_dir, a, base, tid);
+    else fill_pe(lds, is_dir ? 4 : nm::kPeChunks, is_dir, a, base, tid);
 }
 
 // debug: dump `width` features of the tile from the H (or P) arrays as f32 [n, width] in natural order
@@ -277,11 +394,28 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
     const int voff = lane * 16;                                   // the only per-lane part of a weight address
     const int64_t ntiles = (a.n + kTileM - 1) / kTileM;
 
+    // wave-uniform offsets of this wave's weight streams (bytes into the image)
+    auto wo = [](int st, int blk) { return (int)nm::stage_w_off(st) + blk * nm::stage_shape(st).steps * nm::kStepBytes; };
+    const int so_s0 = wo(0, w);
+    const int so_s8a = wo(8, 8), so_s9 = wo(9, w & 3), so_s10 = wo(10, 0);
+#if NM_PRIO_MODE == 1
+    if (w >= 4) __builtin_amdgcn_s_setprio(1);
+#elif NM_PRIO_MODE == 4
+    if (w < 4) __builtin_amdgcn_s_setprio(1);
+#endif
+    // pad slots of the encodings (63; 27..31) are never written by the octave path: give them a finite value once
+    for (int i = tid; i < nm::kPeChunks * kChunkU4; i += kThreads) lds[P_BASE + i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    WPre W;
+    BiasRegs B;
+    w_prefetch<PREC>(W, wsrc, voff, so_s0);
+    bias_prefetch(B, a.bias + nm::stage_b_off(0) + 32 * w, g);
+
 #pragma unroll 1
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t base = tile * kTileM;
         // ---------------- position PE -> P
-        fill_pe(lds, nm::kPeChunks, false, a, base, tid);
+        fill_pe_any(lds, false, a, base, tid);
         __syncthreads();
         NM_TICK(0)
         if (a.stop_stage == -1) { dump_act(lds, true, 64, a, base, tid); __syncthreads(); continue; }
@@ -292,76 +426,108 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
 #pragma unroll 1
         for (int st = 0; st <= 7; ++st) {
             const nm::StageShape sh = nm::stage_shape(st);
-            init_bias<4>(acc, a.bias + nm::stage_b_off(st) + 32 * w, g);
-            int soff = (int)nm::stage_w_off(st) + w * sh.steps * nm::kStepBytes;
-            if (sh.pe_steps) {
-                k_run<4, PREC>(acc, wsrc, voff, soff, lds + P_BASE + g * kChunkU4 + s, sh.pe_steps);
-                soff += sh.pe_steps * nm::kStepBytes;
-            }
+            init_bias<4>(acc, B);
+            const int soff = wo(st, w), next = wo(st + 1, w);
+            if (sh.pe_steps)
+                k_run<4, PREC>(acc, W, wsrc, voff, soff, sh.steps > sh.pe_steps ? soff + sh.pe_steps * nm::kStepBytes : next,
+                               lds + P_BASE + g * kChunkU4 + s, sh.pe_steps, w >= 4);
             if (sh.steps > sh.pe_steps)
-                k_run<4, PREC>(acc, wsrc, voff, soff, lds + H_BASE + g * kChunkU4 + s, sh.steps - sh.pe_steps);
+                k_run<4, PREC>(acc, W, wsrc, voff, soff + sh.pe_steps * nm::kStepBytes, next, lds + H_BASE + g * kChunkU4 + s,
+                               sh.steps - sh.pe_steps, w >= 4);
+            bias_prefetch(B, a.bias + nm::stage_b_off(st + 1) + 32 * w, g);     // next stage (st + 1 <= 8), block w
             NM_TICK(1)
-            __syncthreads();                                      // every wave has finished reading H (and P)
+            NM_BAR_A
+            ActRegs<4> ar;
+            convert_act<4, true>(acc, ar);
+            NM_TICK(3)
+            NM_BAR_B                                              // every wave has finished reading H (and P)
             NM_TICK(2)
-            store_act<4, true, PREC>(acc, lds, w, 0, g, s);
-            if (st == 5) fill_pe(lds, 4, true, a, base, tid);     // P is free after the skip layer: direction PE -> P[0..3]
+            write_act<4, PREC>(ar, lds, w, 0, g, s);
+            if (st == 5) fill_pe_any(lds, true, a, base, tid);     // P is free after the skip layer: direction PE -> P[0..3]
             NM_TICK(3)
             __syncthreads();
             NM_TICK(4)
             if (a.stop_stage == st) { dump_act(lds, false, 256, a, base, tid); stopped = true; break; }
         }
-        if (stopped) { __syncthreads(); continue; }
+        if (stopped) {                                            // debug exit: restart the weight / bias pipelines
+            __syncthreads();
+            w_prefetch<PREC>(W, wsrc, voff, so_s0);
+            bias_prefetch(B, a.bias + nm::stage_b_off(0) + 32 * w, g);
+            continue;
+        }
 
         // ---------------- stage 8: feature (linear, 256) + alpha block (waves 0..3, sample block w)
         float sigma = 0.f;
         {
             const nm::StageShape sh = nm::stage_shape(8);
-            init_bias<4>(acc, a.bias + nm::stage_b_off(8) + 32 * w, g);
-            k_run<4, PREC>(acc, wsrc, voff, (int)nm::stage_w_off(8) + w * sh.steps * nm::kStepBytes,
-                           lds + H_BASE + g * kChunkU4 + s, sh.steps);
+            init_bias<4>(acc, B);
+            k_run<4, PREC>(acc, W, wsrc, voff, wo(8, w), w < 4 ? so_s8a : so_s9, lds + H_BASE + g * kChunkU4 + s, sh.steps);
             if (w < 4) {
                 f32x16 aacc[1];
-                init_bias<1>(aacc, a.bias + nm::stage_b_off(8) + 32 * 8, g);
-                k_run<1, PREC>(aacc, wsrc, voff, (int)nm::stage_w_off(8) + 8 * sh.steps * nm::kStepBytes,
-                               lds + H_BASE + g * kChunkU4 + 32 * w + s, sh.steps);
+                bias_prefetch(B, a.bias + nm::stage_b_off(8) + 32 * 8, g);
+                init_bias<1>(aacc, B);
+                k_run<1, PREC>(aacc, W, wsrc, voff, so_s8a, so_s9, lds + H_BASE + g * kChunkU4 + 32 * w + s, sh.steps);
                 sigma = aacc[0][0];                               // feature row 0 of the block: lanes 0..31 (g == 0)
             }
+            bias_prefetch(B, a.bias + nm::stage_b_off(9) + 32 * (w & 3), g);
             NM_TICK(1)
-            __syncthreads();
+            NM_BAR_A
+            ActRegs<4> ar;
+            convert_act<4, false>(acc, ar);
+            NM_TICK(3)
+            NM_BAR_B
             NM_TICK(2)
-            store_act<4, false, PREC>(acc, lds, w, 0, g, s);
+            write_act<4, PREC>(ar, lds, w, 0, g, s);
             NM_TICK(3)
             __syncthreads();
             NM_TICK(4)
-            if (a.stop_stage == 8) { dump_act(lds, false, 256, a, base, tid); __syncthreads(); continue; }
+            if (a.stop_stage == 8) {
+                dump_act(lds, false, 256, a, base, tid);
+                __syncthreads();
+                w_prefetch<PREC>(W, wsrc, voff, so_s0);
+                bias_prefetch(B, a.bias + nm::stage_b_off(0) + 32 * w, g);
+                continue;
+            }
         }
 
         // ---------------- stage 9: views layer, K = feature(256) ++ d_pe(32), N = 128, ReLU
         {
             const nm::StageShape sh = nm::stage_shape(9);
             const int nb = w & 3, row0 = 64 * (w >> 2);
+            const int hsteps = sh.steps - sh.pe_steps;
             f32x16 vacc[2];
-            init_bias<2>(vacc, a.bias + nm::stage_b_off(9) + 32 * nb, g);
-            const int soff = (int)nm::stage_w_off(9) + nb * sh.steps * nm::kStepBytes;
-            k_run<2, PREC>(vacc, wsrc, voff, soff, lds + H_BASE + g * kChunkU4 + row0 + s, sh.steps - sh.pe_steps);
-            k_run<2, PREC>(vacc, wsrc, voff, soff + (sh.steps - sh.pe_steps) * nm::kStepBytes,
+            init_bias<2>(vacc, B);
+            k_run<2, PREC>(vacc, W, wsrc, voff, so_s9, so_s9 + hsteps * nm::kStepBytes, lds + H_BASE + g * kChunkU4 + row0 + s, hsteps);
+            k_run<2, PREC>(vacc, W, wsrc, voff, so_s9 + hsteps * nm::kStepBytes, w < 4 ? so_s10 : so_s0,
                            lds + P_BASE + g * kChunkU4 + row0 + s, sh.pe_steps);
+            bias_prefetch(B, w < 4 ? a.bias + nm::stage_b_off(10) : a.bias + nm::stage_b_off(0) + 32 * w, g);
             NM_TICK(1)
-            __syncthreads();
+            NM_BAR_A
+            ActRegs<2> ar;
+            convert_act<2, true>(vacc, ar);
+            NM_TICK(3)
+            NM_BAR_B
             NM_TICK(2)
-            store_act<2, true, PREC>(vacc, lds, nb, row0, g, s);
+            write_act<2, PREC>(ar, lds, nb, row0, g, s);
             NM_TICK(3)
             __syncthreads();
             NM_TICK(4)
-            if (a.stop_stage == 9) { dump_act(lds, false, 128, a, base, tid); __syncthreads(); continue; }
+            if (a.stop_stage == 9) {
+                dump_act(lds, false, 128, a, base, tid);
+                __syncthreads();
+                w_prefetch<PREC>(W, wsrc, voff, so_s0);
+                bias_prefetch(B, a.bias + nm::stage_b_off(0) + 32 * w, g);
+                continue;
+            }
         }
 
         // ---------------- stage 10: rgb (rows 0..2 of one 32-feature block), waves 0..3 take sample block w
         if (w < 4) {
             const nm::StageShape sh = nm::stage_shape(10);
             f32x16 racc[1];
-            init_bias<1>(racc, a.bias + nm::stage_b_off(10), g);
-            k_run<1, PREC>(racc, wsrc, voff, (int)nm::stage_w_off(10), lds + H_BASE + g * kChunkU4 + 32 * w + s, sh.steps);
+            init_bias<1>(racc, B);
+            k_run<1, PREC>(racc, W, wsrc, voff, so_s10, so_s0, lds + H_BASE + g * kChunkU4 + 32 * w + s, sh.steps);
+            bias_prefetch(B, a.bias + nm::stage_b_off(0) + 32 * w, g);
             const int64_t i = base + 32 * w + s;
             if (g == 0 && i < a.n)                                // rows 0,1,2 = regs 0,1,2 of the g == 0 half
                 reinterpret_cast<float4*>(a.out)[i] = make_float4(racc[0][0], racc[0][1], racc[0][2], sigma * a.sigma_scale);
@@ -390,8 +556,8 @@ int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, con
     a.petab = L.petab;
     a.pts = pts; a.dirs = dirs; a.origin = origin; a.direction = direction; a.z = z;
     a.out = out; a.dbg = dbg; a.prof = reinterpret_cast<unsigned long long*>(prof); a.n = n; a.S = S; a.in_mode = in_mode; a.stop_stage = stop_stage; a.sigma_scale = sigma_scale;
-    a.pos = PeSpec{L.pe_kind, L.pos_nfreq};
-    a.dir = PeSpec{L.pe_kind, L.dir_nfreq};
+    a.pos = PeSpec{L.pe_kind, L.pos_nfreq, L.pos_octaves};
+    a.dir = PeSpec{L.pe_kind, L.dir_nfreq, L.dir_octaves};
     const int64_t ntiles = (n + kTileM - 1) / kTileM;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {

@@ -123,6 +123,7 @@ struct nm_mlp_s {
     float* d_petab;        // 192 floats
     float* d_ref;          // transposed f32 weights | natural biases (NM_PREC_FP32 path)
     int ref_off[12], ref_boff[12];
+    int pos_octaves, dir_octaves;
 };
 
 extern "C" {
@@ -180,6 +181,17 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     const int ndir = desc->pe_kind == NM_PE_POSENC ? desc->dir_n_freqs : 9 * desc->dir_n_freqs;
     memcpy(tab, host_pos_tab, (size_t)npos * 4);
     memcpy(tab + 96, host_dir_tab, (size_t)ndir * 4);
+    // octave structure: every band table entry is exactly twice the previous band's (true for the reference defaults
+    // 2**linspace(0, N-1, N); vanilla.py:46-51, 67-68) -> the kernel may use the double-angle recurrence
+    auto octaves = [&](const float* t, int nfreq) {
+        const int per = desc->pe_kind == NM_PE_POSENC ? 1 : 9;
+        for (int b = 0; b + 1 < nfreq; ++b)
+            for (int k = 0; k < per; ++k)
+                if (t[(b + 1) * per + k] != 2.f * t[b * per + k]) return 0;
+        return 1;
+    };
+    m->pos_octaves = octaves(tab, desc->pos_n_freqs);
+    m->dir_octaves = octaves(tab + 96, desc->dir_n_freqs);
 
     m->d_image = nullptr; m->d_petab = nullptr; m->d_ref = nullptr;
     int rc = nm::check_hip(hipMalloc(&m->d_image, (size_t)bytes), "nm_mlp_create: hipMalloc(image)");
@@ -223,6 +235,7 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
     L.bias = reinterpret_cast<const float*>(m->d_image + nm::kWeightBytes + nm::kWeightPadBytes);
     L.petab = m->d_petab;
     L.pe_kind = m->desc.pe_kind; L.pos_nfreq = m->desc.pos_n_freqs; L.dir_nfreq = m->desc.dir_n_freqs;
+    L.pos_octaves = m->pos_octaves; L.dir_octaves = m->dir_octaves;
     return nm::launch_mlp_mfma(L, pts, dirs, origin, direction, z, n, S, in_mode, precision, stop_stage, sigma_scale, out, dbg,
                                prof, nm::as_stream(stream));
 }

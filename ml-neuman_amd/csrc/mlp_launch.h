@@ -7,6 +7,7 @@ namespace nm {
 struct MlpLaunch {
     const void* wpack; const float* bias; const float* petab;
     int pe_kind, pos_nfreq, dir_nfreq;
+    int pos_octaves, dir_octaves;   // encodings whose bands are consecutive powers of two (octave recurrence allowed)
 };
 struct RefLaunch {
     const float* wt; const float* bias; int off[12]; int boff[12]; const float* petab;
