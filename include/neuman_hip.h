@@ -155,14 +155,24 @@ int nm_mlp_forward_profile(nm_mlp_t mlp, const float* pts, const float* dirs, in
  *   closest point on the posed mesh (replaces igl.point_mesh_squared_distance, :53), barycentrics
  *   (:55), blended per-vertex transform T (f64, [>=V,4,4]), 4x4 inverse, canonical point, and
  *   finite-difference canonical directions along each ray (:62-64).
- *   pts [R,S,3] f32, verts [V,3] f32, faces [F,3] int32, T [*,16] f64 -> can_pts, can_dirs [R,S,3] f32,
- *   closest [R,S,3] f32 (optional).  workspace: device float, nm_warp_workspace_floats(F) entries,
- *   64-byte aligned (per-triangle records rebuilt on every call: the posed mesh changes per frame).
+ *
+ *   nm_mesh_create builds, once per posed mesh (per frame and actor), an exact search structure on the
+ *   device: per-triangle records and a uniform grid whose cells list, in distance rings, every triangle
+ *   that can be the closest one for a point of the cell.  verts [V,3] f32 and faces [F,3] int32 are
+ *   DEVICE pointers and are copied into the handle.  `reach` = the largest distance query points have
+ *   from the vertices (geo_threshold in the render paths); farther points are still answered exactly,
+ *   by an all-triangles loop.  The call synchronises the stream twice (grid sizing, list length).
+ *   nm_warp_to_canonical: pts [R,S,3] f32, T [*,16] f64 -> can_pts, can_dirs [R,S,3] f32,
+ *   closest [R,S,3] f32 (optional).
  * ------------------------------------------------------------------------------------------- */
-int64_t nm_warp_workspace_floats(int F);
-int nm_warp_to_canonical(const float* pts, int64_t R, int S, const float* verts, int V, const int32_t* faces, int F,
-                         const double* T, float* can_pts, float* can_dirs, float* closest, float* workspace,
-                         nm_stream_t stream);
+typedef struct nm_mesh_s* nm_mesh_t;
+int nm_mesh_create(const float* verts, int V, const int32_t* faces, int F, float reach, nm_mesh_t* out,
+                   nm_stream_t stream);
+int nm_mesh_destroy(nm_mesh_t mesh);
+/* grid dimensions, total candidate-list length and cell size of a built mesh (diagnostics) */
+int nm_mesh_info(nm_mesh_t mesh, int32_t* cells_xyz, int64_t* list_len, float* cell_size);
+int nm_warp_to_canonical(nm_mesh_t mesh, const float* pts, int64_t R, int S, const double* T, float* can_pts,
+                         float* can_dirs, float* closest, nm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a13  sorted merge of sample lists -- reference utils/render_utils.py:330-337, 441-448

@@ -217,33 +217,58 @@ def scatter_rows(dst, idx, src):
 # ------------------------------------------------------------------------------------------------
 # a11 observation -> canonical warp
 # ------------------------------------------------------------------------------------------------
-def warp_to_canonical_dev(pts, verts, faces, T, want_closest=False):
-    """Device-tensor core: pts [R,S,3] f32, verts [V,3] f32, faces [F,3] int32, T [>=V,4,4] f64 (all CUDA)."""
+class Mesh:
+    """A posed mesh on the device plus its closest-point search structure (nm_mesh_create).  Built once per frame and
+    actor; `T` are the per-vertex canonical->observation transforms (f64 [>=V,4,4], joint rows beyond V never indexed)."""
+
+    def __init__(self, verts, faces, T, device, reach=DEFAULT_GEO_THRESH):
+        import ctypes
+        _lib.require_gpu()
+        v = verts if isinstance(verts, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(verts, dtype=np.float32))
+        f = faces[:, :3] if isinstance(faces, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(np.asarray(faces)[:, :3], dtype=np.int32))
+        t = T if isinstance(T, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(T, dtype=np.float64))
+        self.verts = v.to(device, torch.float32).contiguous()
+        self.faces = f.to(device, torch.int32).contiguous()          # cols 3-5 of scene.faces are UV ids (utils/utils.py:213-221)
+        self.T = t.to(device, torch.float64).reshape(-1, 16).contiguous()
+        self.handle = ctypes.c_void_p()
+        _lib.check(_lib.lib().nm_mesh_create(_lib.dev_ptr(self.verts), self.verts.shape[0], _lib.dev_ptr(self.faces, torch.int32),
+                                             self.faces.shape[0], float(reach), ctypes.byref(self.handle), _lib.stream_ptr()),
+                   "nm_mesh_create")
+
+    def info(self):
+        import ctypes
+        cells = (ctypes.c_int32 * 3)()
+        n = ctypes.c_int64()
+        h = ctypes.c_float()
+        _lib.check(_lib.lib().nm_mesh_info(self.handle, cells, ctypes.byref(n), ctypes.byref(h)), "nm_mesh_info")
+        return {"cells": tuple(cells), "list_len": n.value, "cell_size": h.value}
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.lib().nm_mesh_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def mesh_to_device(verts, faces, T, device, reach=DEFAULT_GEO_THRESH):
+    return Mesh(verts, faces, T, device, reach)
+
+
+def warp_to_canonical_dev(pts, mesh, want_closest=False):
+    """Device-tensor core: pts [R,S,3] f32 CUDA, mesh = Mesh -> can_pts, can_dirs (, closest) [R,S,3] f32."""
     _lib.require_gpu()
     R, S, _ = pts.shape
     dev = pts.device
     can_pts = torch.empty((R, S, 3), device=dev, dtype=torch.float32)
     can_dirs = torch.empty((R, S, 3), device=dev, dtype=torch.float32)
     closest = torch.empty((R, S, 3), device=dev, dtype=torch.float32) if want_closest else None
-    F = faces.shape[0]
-    ws = torch.empty(int(_lib.lib().nm_warp_workspace_floats(F)) + 16, device=dev, dtype=torch.float32)
-    off = (-ws.data_ptr() // 4) % 16                     # 64-byte alignment of the triangle records
-    ws = ws[off:off + int(_lib.lib().nm_warp_workspace_floats(F))]
-    _lib.check(_lib.lib().nm_warp_to_canonical(
-        _lib.dev_ptr(pts, name='pts'), R, S, _lib.dev_ptr(verts, name='verts'), verts.shape[0],
-        _lib.dev_ptr(faces, torch.int32, 'faces'), F, _lib.dev_ptr(T, torch.float64, 'T'), _lib.dev_ptr(can_pts),
-        _lib.dev_ptr(can_dirs), _lib.dev_ptr(closest), _lib.dev_ptr(ws), _lib.stream_ptr()), "nm_warp_to_canonical")
+    _lib.check(_lib.lib().nm_warp_to_canonical(mesh.handle, _lib.dev_ptr(pts, name='pts'), R, S,
+                                               _lib.dev_ptr(mesh.T, torch.float64, 'T'), _lib.dev_ptr(can_pts),
+                                               _lib.dev_ptr(can_dirs), _lib.dev_ptr(closest), _lib.stream_ptr()),
+               "nm_warp_to_canonical")
     return can_pts, can_dirs, closest
-
-
-def mesh_to_device(verts, faces, T, device):
-    """Upload a posed mesh once per frame: verts f32, faces[:, :3] int32 (cols 3-5 are UV ids, utils/utils.py:213-221),
-    T f64 [*,4,4] (joint rows beyond V are never indexed)."""
-    v = torch.as_tensor(np.ascontiguousarray(verts, dtype=np.float32) if not isinstance(verts, torch.Tensor) else verts)
-    f = torch.as_tensor(np.ascontiguousarray(np.asarray(faces)[:, :3], dtype=np.int32) if not isinstance(faces, torch.Tensor) else faces[:, :3])
-    t = torch.as_tensor(np.ascontiguousarray(T, dtype=np.float64) if not isinstance(T, torch.Tensor) else T)
-    return (v.to(device, torch.float32).contiguous(), f.to(device, torch.int32).contiguous(),
-            t.to(device, torch.float64).reshape(-1, 16).contiguous())
 
 
 def warp_samples_to_canonical(pts, verts, faces, T):
@@ -254,8 +279,7 @@ def warp_samples_to_canonical(pts, verts, faces, T):
     as_numpy = not isinstance(pts, torch.Tensor)
     dev = torch.device('cuda') if as_numpy else pts.device
     p = torch.as_tensor(np.ascontiguousarray(pts, dtype=np.float32)).to(dev) if as_numpy else _f32c(pts)
-    v, f, t = mesh_to_device(verts, faces, T, dev)
-    can_pts, can_dirs, closest = warp_to_canonical_dev(p, v, f, t, want_closest=True)
+    can_pts, can_dirs, closest = warp_to_canonical_dev(p, Mesh(verts, faces, T, dev), want_closest=True)
     if as_numpy:
         return can_pts.cpu().numpy(), can_dirs.cpu().numpy(), closest.cpu().numpy()
     return can_pts, can_dirs, closest

@@ -104,8 +104,7 @@ def human_pass_rays(human_net, o, d, near, far, samples_per_ray, mesh=None, rend
         _, _, z = ray_utils.sample_z(o, d, near, far, samples_per_ray)
         return human_net.forward_rays(o, d, z, precision=precision, sigma_scale=sigma_scale), z
     pts, _, z = ray_utils.sample_z(o, d, near, far, samples_per_ray, want_points=True)
-    verts, faces, T = mesh
-    can_pts, can_dirs, _ = ray_utils.warp_to_canonical_dev(pts, verts, faces, T)
+    can_pts, can_dirs, _ = ray_utils.warp_to_canonical_dev(pts, mesh)
     return human_net(can_pts, can_dirs, precision=precision, sigma_scale=sigma_scale), z
 
 
@@ -238,7 +237,7 @@ def render_smpl_nerf(net, cap, posed_verts, faces, Ts, rays_per_batch=32768, sam
     with torch.no_grad():
         o, d = _pixel_rays(cap, device)
         verts = torch.as_tensor(np.ascontiguousarray(posed_verts, dtype=np.float32)).to(device)
-        mesh = None if render_can else ray_utils.mesh_to_device(posed_verts, faces, Ts, device)
+        mesh = None if render_can else ray_utils.mesh_to_device(posed_verts, faces, Ts, device, geo_threshold)
         rgb, depth, acc = render_smpl_nerf_rays(net.coarse_human_net, o, d, verts, mesh, samples_per_ray, white_bkg, render_can,
                                                 geo_threshold, interval_comp)
         rgb = rgb.reshape(*cap.shape, -1).cpu().numpy()
@@ -260,7 +259,7 @@ def render_hybrid_nerf(net, cap, posed_verts, faces, Ts, rays_per_batch=32768, s
     with torch.no_grad():
         o, d = _pixel_rays(cap, device)
         verts = torch.as_tensor(np.ascontiguousarray(posed_verts, dtype=np.float32)).to(device)
-        mesh = ray_utils.mesh_to_device(posed_verts, faces, Ts, device)
+        mesh = ray_utils.mesh_to_device(posed_verts, faces, Ts, device, geo_threshold)
         rgb, depth, _ = render_hybrid_rays(net.coarse_bkg_net, net.fine_bkg_net, net.coarse_human_net, o, d, cap.near['bkg'],
                                            cap.far['bkg'], verts, mesh, samples_per_ray, importance_samples_per_ray, white_bkg,
                                            geo_threshold)
@@ -277,7 +276,7 @@ def render_hybrid_nerf_multi_persons(bkg_model, cap, human_models, posed_verts, 
     with torch.no_grad():
         o, d = _pixel_rays(cap, device)
         verts = [torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)).to(device) for v in posed_verts]
-        meshes = [ray_utils.mesh_to_device(v, f, t, device) for v, f, t in zip(posed_verts, faces, Ts)]
+        meshes = [ray_utils.mesh_to_device(v, f, t, device, geo_threshold) for v, f, t in zip(posed_verts, faces, Ts)]
         rgb, depth = render_multi_rays(bkg_model.coarse_bkg_net, bkg_model.fine_bkg_net,
                                        [m.coarse_human_net for m in human_models], o, d, cap.near['bkg'], cap.far['bkg'], verts,
                                        meshes, samples_per_ray, importance_samples_per_ray, white_bkg, geo_threshold)
