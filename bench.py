@@ -69,6 +69,22 @@ def cpu_baseline(max_rays=4096):
                       f"with {best[0]} BLAS threads (best of a 16..{ncpu} probe) on a {ncpu}-thread host"}
 
 
+def pmc_traffic_per_launch():
+    """HBM bytes per MLP launch from the committed PMC passes of this same command (FETCH_SIZE and WRITE_SIZE are
+    collected in separate rocprofv3 runs, so they cannot be measured inside this process): mean over the coarse and the
+    fine launch of FETCH_SIZE*2 (gfx950 reports half the bytes of wide streaming reads, MI355X_MICROARCH.md) + WRITE_SIZE,
+    KiB -> bytes.  None when the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.json")
+    try:
+        with open(path) as f:
+            s = json.load(f)
+        fetch = [x["FETCH_SIZE"] for x in s["fetch"] if "nerf_mlp_kernel" in x["kernel"]][:2]
+        write = [x["WRITE_SIZE"] for x in s["write"] if "nerf_mlp_kernel" in x["kernel"]][:2]
+        return (2 * sum(fetch) / len(fetch) + sum(write) / len(write)) * 1024.0
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,7 +183,9 @@ def main():
             "psnr_db_vs_f32_device_path": psnr,
             "roofline": {"bound": "mfma", "kernel": "nerf_mlp_kernel<bf16x3>" if args.precision == "bf16x3" else f"nerf_mlp ({args.precision})",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                         "traffic": None, "launches": len(mlp_events), "avg_launch_ms": mlp_ms / max(1, len(mlp_events)),
+                         "traffic": pmc_traffic_per_launch(), "traffic_unit": "bytes of HBM traffic per launch (FETCH_SIZE*2 + WRITE_SIZE, "
+                         "rocprofv3 --pmc pass of this command, profiles/r01_bench_pmc_summary.json; algorithmic: 16 B/sample out + 4 B/sample z in)",
+                         "launches": len(mlp_events), "avg_launch_ms": mlp_ms / max(1, len(mlp_events)),
                          "note": "algorithmic FLOPs = 1,186,816 per MLP evaluation; bf16x3 issues 3 MFMAs per algorithmic one, "
                                  "so hardware MFMA utilisation is 3x frac"},
         }

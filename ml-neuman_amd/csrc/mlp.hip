@@ -152,47 +152,36 @@ __device__ __forceinline__ void w_prefetch(WPre& W, __amdgpu_buffer_rsrc_t wsrc,
 template <int MB, int PREC>
 __device__ __forceinline__ void k_run(f32x16 (&acc)[MB], WPre& W, __amdgpu_buffer_rsrc_t wsrc, int voff, int soff, int next_soff,
                                       const uint4* xh, int nsteps, bool prio_phase = false) {
-    // activation fragments are software-pipelined one k-step ahead in two register sets (x[0] / x[1]): the LDS latency
-    // of step t+1 is covered by the 12 MFMAs of step t instead of being exposed at the head of every step
-    bf16x8 bh[2][MB], bl[2][MB];
-    auto load_x = [&](int set, int t) {
-        const uint4* ph = xh + t * (2 * kChunkU4);
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            bh[set][mb] = as_bf16x8(ph[mb * 32]);
-            if (PREC == NM_PREC_BF16X3) bl[set][mb] = as_bf16x8(ph[kLoU4 + mb * 32]);
-        }
-    };
-    auto mfmas = [&](int set, bf16x8 ah, bf16x8 al) {
-        if (PREC == NM_PREC_BF16X3) {
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[set][mb], acc[mb], 0, 0, 0);
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[set][mb], acc[mb], 0, 0, 0);
-        }
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[set][mb], acc[mb], 0, 0, 0);
-    };
-    load_x(0, 0);
+    // One activation register set per k-step: with two waves per SIMD the partner's MFMAs cover the ds_read latency, and
+    // a second (software-pipelined) set measured 0 % while pushing the kernel into scratch spills.
 #pragma unroll 1
     for (int t = 0; t < nsteps; t += 2) {
         const int pf = (t + 2 < nsteps) ? soff + (t + 2) * nm::kStepBytes : next_soff;   // wave-uniform
         WPre N;
         w_prefetch<PREC>(N, wsrc, voff, pf);
-        load_x(1, t + 1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint4* ph = xh + (t + u) * (2 * kChunkU4);
+            bf16x8 bh[MB], bl[MB];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                bh[mb] = as_bf16x8(ph[mb * 32]);
+                if (PREC == NM_PREC_BF16X3) bl[mb] = as_bf16x8(ph[kLoU4 + mb * 32]);
+            }
 #if NM_PRIO_MODE == 2
-        __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(u == 0 ? 1 : 0);
 #elif NM_PRIO_MODE == 3
-        __builtin_amdgcn_s_setprio(prio_phase ? 0 : 1);
+            __builtin_amdgcn_s_setprio((u == 0) != prio_phase ? 1 : 0);
 #endif
-        mfmas(0, W.h[0], W.l[0]);
-        if (t + 2 < nsteps) load_x(0, t + 2);
-#if NM_PRIO_MODE == 2
-        __builtin_amdgcn_s_setprio(0);
-#elif NM_PRIO_MODE == 3
-        __builtin_amdgcn_s_setprio(prio_phase ? 1 : 0);
-#endif
-        mfmas(1, W.h[1], W.l[1]);
+            if (PREC == NM_PREC_BF16X3) {
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.h[u], bl[mb], acc[mb], 0, 0, 0);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.l[u], bh[mb], acc[mb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.h[u], bh[mb], acc[mb], 0, 0, 0);
+        }
         W = N;
     }
 }
@@ -297,6 +286,28 @@ __device__ __forceinline__ void fill_pe(uint4* lds, int nchunks, bool is_dir, co
 // angle formulas in f64 (error doubles per octave from 1e-16: 1e-13 at band 9) give sin/cos(2^b a0) rounded to f32 --
 // within an ulp of the reference's sinf(fl(x * f_b)) -- for ~1/6 of the instructions of 2N full-range sincosf calls.
 // Work item = (component j, sample); each of the 2N values is one 2-byte LDS store per half.
+// f64 sin/cos for the band-0 arguments (|a| up to a few scene units; valid to |a| ~ 1e9): two-term Cody-Waite reduction
+// by pi/2 with fma, then the fdlibm minimax kernels on [-pi/4, pi/4].  Absolute error ~1e-16.  Written out instead of
+// calling ocml's sincos(double) because that one carries a Payne-Hanek path with a private (scratch) array, and any
+// scratch in this kernel competes with the 2.4 MB weight image for the XCD's 4 MB L2.
+__device__ __forceinline__ void sincos_f64(double a, double& sn, double& cs) {
+    const double fn = rint(a * 6.36619772367581382433e-01);
+    double r = fma(-fn, 1.5707963267948966, a);
+    r = fma(-fn, 6.123233995736766e-17, r);
+    const double z = r * r;
+    const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                      z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    const double s = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+    const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const double c = 1.0 - (0.5 * z - z * pc);
+    const int q = (int)fn & 3;                              // a = r + q*pi/2 (mod 2 pi)
+    sn = (q & 1) ? c : s;
+    cs = (q & 1) ? s : c;
+    if (q == 1 || q == 2) cs = -cs;
+    if (q >= 2) sn = -sn;
+}
+
 __device__ __forceinline__ void fill_pe_fast(uint4* lds, bool is_dir, const MlpArgs& a, int64_t base, int tid) {
     const PeSpec spec = is_dir ? a.dir : a.pos;
     const float* tab = a.petab + (is_dir ? 96 : 0);
@@ -335,7 +346,7 @@ __device__ __forceinline__ void fill_pe_fast(uint4* lds, bool is_dir, const MlpA
     };
     put(j, xj);                                               // include_input: features 0..2
     double sn, cs;
-    sincos((double)a0, &sn, &cs);
+    sincos_f64((double)a0, sn, cs);
     const int n3 = 3 * spec.nfreq;
     for (int b = 0; b < spec.nfreq; ++b) {
         if (spec.kind == NM_PE_POSENC) {                      // [sin(f_b x)(3), cos(f_b x)(3)] per band, vanilla.py:73-76
