@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "i8x3", "bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -174,7 +174,7 @@ def main():
             "metric": "rays_per_sec (800x800 frame, 128 samples/ray coarse + 128 importance, NeuMan background NeRF)",
             "value": total * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": {"bf16x3": "bf16x3 (split-bf16 hi+lo MFMA x3, f32 accumulate)", "bf16": "bf16 (f32 accumulate)", "fp32": "f32"}[args.precision],
+            "dtype": {"bf16x3": "bf16x3 (split-bf16 hi+lo MFMA x3, f32 accumulate)", "i8x3": "i8x3 (per-row-scaled int16 as 2 int8 limbs, i8 MFMA x3, exact int32 accumulate; encodings on bf16x3)", "bf16": "bf16 (f32 accumulate)", "fp32": "f32"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "BASELINE config 2: background NeRF (models/vanilla.py 8x256, posenc), 800x800 = 640000 rays, "
                                    "128 coarse + 256 fine MLP evaluations per ray, synthetic-dense weights (seeds 0/1), near 0 far 3.14",

@@ -173,6 +173,29 @@ __device__ __forceinline__ void k_run(f32x16 (&acc)[MB], WPre& W, __amdgpu_buffe
 #elif NM_PRIO_MODE == 3
             __builtin_amdgcn_s_setprio((u == 0) != prio_phase ? 1 : 0);
 #endif
+#ifdef NM_I8_PROBE   // throughput experiment only (results are garbage): i8 MFMA covers 32 k per instruction -> half the steps
+            if (u == 1) continue;
+            typedef __attribute__((ext_vector_type(4))) int i32x4;
+            typedef __attribute__((ext_vector_type(16))) int i32x16;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                i32x16 c = __builtin_bit_cast(i32x16, acc[mb]);
+                c = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, W.h[u]), __builtin_bit_cast(i32x4, bl[mb]), c, 0, 0, 0);
+                acc[mb] = __builtin_bit_cast(f32x16, c);
+            }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                i32x16 c = __builtin_bit_cast(i32x16, acc[mb]);
+                c = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, W.l[u]), __builtin_bit_cast(i32x4, bh[mb]), c, 0, 0, 0);
+                acc[mb] = __builtin_bit_cast(f32x16, c);
+            }
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                i32x16 c = __builtin_bit_cast(i32x16, acc[mb]);
+                c = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, W.h[u]), __builtin_bit_cast(i32x4, bh[mb]), c, 0, 0, 0);
+                acc[mb] = __builtin_bit_cast(f32x16, c);
+            }
+#else
             if (PREC == NM_PREC_BF16X3) {
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.h[u], bl[mb], acc[mb], 0, 0, 0);
@@ -181,6 +204,7 @@ __device__ __forceinline__ void k_run(f32x16 (&acc)[MB], WPre& W, __amdgpu_buffe
             }
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.h[u], bh[mb], acc[mb], 0, 0, 0);
+#endif
         }
         W = N;
     }
@@ -554,6 +578,301 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
 #undef NM_TICK
 }
 
+// =====================================================================================================================
+// NM_PREC_I8X3: the hidden layers in 16-bit fixed point on v_mfma_i32_32x32x32_i8 (mlp_layout.h, DESIGN.md "K4-i8").
+//
+// Per sample row the 256-/128-wide hidden operand is X = rint(x / sx), sx = max|x| / 32639, stored in LDS as two balanced
+// int8 limbs (X = 256*hi + lo); weights likewise per output feature (host).  x.w = sx*sw*(65536*hi.hi + 256*(hi.lo + lo.hi)
+// [+ lo.lo, dropped: <= 2^-16 of full scale]) with EXACT int32 accumulation: three i8 MFMAs of K = 32 replace three bf16
+// MFMAs of K = 16, so the MFMA time and the L2 weight traffic both halve.  The encodings keep the split-bf16 path (they
+// need absolute precision): stage 0 is bf16 only, stages 5 / 9 add their PE part in f32 on top of the dequantised sum.
+// The row maxima need all 8 waves' features: partial maxima go through a small LDS array around the barrier that the
+// epilogue needs anyway.  Activations take 64 KB of LDS instead of 128 KB; scales and biases of all stages sit in LDS.
+// =====================================================================================================================
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(16))) int i32x16;
+typedef __attribute__((ext_vector_type(2))) short i16x2;
+
+constexpr int H8_BASE = 0;                                   // [16 chunks][hi: 128 rows | lo: 128 rows][16 B]  (64 KB)
+constexpr int S8_MAX = 16 * kChunkU4;                        // 4096: row-max partials [8][128] f32
+constexpr int S8_SCALE = S8_MAX + 8 * kTileM / 4;            // 4352: row scales [128] f32
+constexpr int S8_CONST = S8_SCALE + kTileM / 4;              // 4384: [weight scales | biases] of all stages
+constexpr int kConst8Floats = 2 * nm::kBiasFloats;
+static_assert(S8_CONST + kConst8Floats / 4 <= P_BASE && kConst8Floats % 4 == 0, "i8 scratch must fit below the PE buffer");
+
+struct MlpArgs8 {
+    MlpArgs a;
+    const uint4* wpack8;
+    const float* consts8;     // scales (kBiasFloats) then biases (kBiasFloats)
+};
+
+template <int MB>
+__device__ __forceinline__ void k_run8(i32x16 (&ah)[MB], i32x16 (&ac)[MB], WPre& W, __amdgpu_buffer_rsrc_t wsrc, int voff, int soff,
+                                       int next_soff, const uint4* xh, int nsteps) {
+#pragma unroll 1
+    for (int t = 0; t < nsteps; t += 2) {
+        const int pf = (t + 2 < nsteps) ? soff + (t + 2) * nm::kStepBytes : next_soff;
+        WPre N;
+        w_prefetch<NM_PREC_BF16X3>(N, wsrc, voff, pf);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint4* ph = xh + (t + u) * (2 * kChunkU4);
+            const i32x4 wh = __builtin_bit_cast(i32x4, W.h[u]), wl = __builtin_bit_cast(i32x4, W.l[u]);
+            // two int32 accumulator sets (128 VGPRs at MB = 4) leave no room for all activation fragments of a step:
+            // they are loaded two sample blocks at a time (the partner wave of the SIMD covers the LDS latency)
+#pragma unroll
+            for (int m0 = 0; m0 < MB; m0 += 2) {
+                i32x4 bh[2], bl[2];
+#pragma unroll
+                for (int k = 0; k < 2 && m0 + k < MB; ++k) {
+                    bh[k] = __builtin_bit_cast(i32x4, ph[(m0 + k) * 32]);
+                    bl[k] = __builtin_bit_cast(i32x4, ph[kLoU4 + (m0 + k) * 32]);
+                }
+#pragma unroll
+                for (int k = 0; k < 2 && m0 + k < MB; ++k) ac[m0 + k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wh, bl[k], ac[m0 + k], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 2 && m0 + k < MB; ++k) ac[m0 + k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wl, bh[k], ac[m0 + k], 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 2 && m0 + k < MB; ++k) ah[m0 + k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wh, bh[k], ah[m0 + k], 0, 0, 0);
+            }
+        }
+        W = N;
+    }
+}
+
+template <int MB>
+__device__ __forceinline__ void zero8(i32x16 (&ah)[MB], i32x16 (&ac)[MB]) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ah[mb][r] = 0; ac[mb][r] = 0; }
+}
+
+// f = (256*hh + cross) * (256 * sx[row] * sw[feature]) + bias[feature]; the scales / biases of this lane's 16 features of
+// block `cblk` (float offset into the stage tables) come from the LDS copy
+template <int MB>
+__device__ __forceinline__ void dequant8(f32x16 (&f)[MB], const i32x16 (&ah)[MB], const i32x16 (&ac)[MB], const float (&sxin)[MB],
+                                         const float* cst, int cblk, int g) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 sw = *reinterpret_cast<const float4*>(cst + cblk + 8 * q + 4 * g);
+        const float4 bs = *reinterpret_cast<const float4*>(cst + nm::kBiasFloats + cblk + 8 * q + 4 * g);
+        const float swv[4] = {sw.x, sw.y, sw.z, sw.w}, bsv[4] = {bs.x, bs.y, bs.z, bs.w};
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = 4 * q + j;
+                const int t = (ah[mb][r] << 8) + ac[mb][r];
+                f[mb][r] = fmaf((float)t, (sxin[mb] * 256.f) * swv[j], bsv[j]);
+            }
+    }
+}
+
+// accumulator init from the LDS bias table (stage 0: bf16 only)
+template <int MB>
+__device__ __forceinline__ void init_bias8(f32x16 (&f)[MB], const float* cst, int cblk, int g) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 bs = *reinterpret_cast<const float4*>(cst + nm::kBiasFloats + cblk + 8 * q + 4 * g);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) { f[mb][4 * q] = bs.x; f[mb][4 * q + 1] = bs.y; f[mb][4 * q + 2] = bs.z; f[mb][4 * q + 3] = bs.w; }
+    }
+}
+
+// per-row partial maximum of this wave's 32 features -> smax[part][row]
+template <int MB, bool RELU>
+__device__ __forceinline__ void rowmax8(const f32x16 (&f)[MB], float* smax, int part, int row0, int g, int s) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        float m = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, RELU ? f[mb][r] : fabsf(f[mb][r]));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        if (g == 0) smax[part * kTileM + row0 + 32 * mb + s] = m;
+    }
+}
+
+// quantise this wave's features of its rows with the row scale (max over `nparts` partials) and store the two limbs
+template <int MB, bool RELU>
+__device__ __forceinline__ void quant_store8(const f32x16 (&f)[MB], uint4* lds, const float* smax, float* sscale, int nparts, int blk,
+                                             int row0, int g, int s, bool write_scale) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int row = row0 + 32 * mb + s;
+        float M = 0.f;
+        for (int p = 0; p < nparts; ++p) M = fmaxf(M, smax[p * kTileM + row]);
+        // cvt_pknorm maps [-1,1] to rint(y * 32767): X = rint(v * 32639 / M).  (Offset coding of the non-negative ReLU rows
+        // for a 17th bit was measured: composited error 1.9e-5 -> 1.8e-5 for -7 % throughput; not kept.)
+        const float c = (float)nm::kFixedMax / 32767.f;
+        const float inv = M > 0.f ? c / M : 0.f;
+        if (write_scale && g == 0) sscale[row] = M > 0.f ? M / (float)nm::kFixedMax : 1.f;
+        i16x2 P[8], Y[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            i16x2 p = __builtin_amdgcn_cvt_pknorm_i16(f[mb][2 * i] * inv, f[mb][2 * i + 1] * inv);
+            if (RELU) p = __builtin_elementwise_max(p, (i16x2){0, 0});
+            P[i] = p;
+            Y[i] = p + (i16x2){128, 128};
+        }
+        unsigned lo[4], hi[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            lo[k] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, P[2 * k + 1]), __builtin_bit_cast(unsigned, P[2 * k]), 0x06040200u);
+            hi[k] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, Y[2 * k + 1]), __builtin_bit_cast(unsigned, Y[2 * k]), 0x07050301u);
+        }
+        const int idx = H8_BASE + (2 * blk + g) * kChunkU4 + row;
+        lds[idx] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        lds[idx + kLoU4] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    }
+}
+
+__device__ __forceinline__ void dump_act8(const uint4* lds, int width, int offset, const MlpArgs& a, int64_t base, int tid) {
+    const signed char* hi = reinterpret_cast<const signed char*>(lds + H8_BASE);
+    const signed char* lo = hi + kLoU4 * 16;
+    const float* sscale = reinterpret_cast<const float*>(lds + S8_SCALE);
+    for (int item = tid; item < kTileM * width; item += kThreads) {
+        const int row = item / width, n = item - row * width;
+        if (base + row >= a.n) continue;
+        const int off = (nm::feature_chunk8(n) * kChunkU4 + row) * 16 + nm::feature_elem8(n);
+        a.dbg[(base + row) * width + n] = sscale[row] * (float)(256 * (int)hi[off] + (int)lo[off] + offset);
+    }
+}
+
+__global__ __launch_bounds__(kThreads, 2) void nerf_mlp_i8_kernel(const MlpArgs8 A) {
+    __shared__ uint4 lds[LDS_U4];
+    const MlpArgs& a = A.a;
+    const int tid0 = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint4*>(A.wpack8), 0, (int)(nm::kWeightBytes8 + nm::kWeightPadBytes), 0x00020000);
+    const int64_t ntiles = (a.n + kTileM - 1) / kTileM;
+    float* smax = reinterpret_cast<float*>(lds + S8_MAX);
+    float* sscale = reinterpret_cast<float*>(lds + S8_SCALE);
+    float* cst = reinterpret_cast<float*>(lds + S8_CONST);
+
+    for (int i = tid0; i < nm::kPeChunks * kChunkU4; i += kThreads) lds[P_BASE + i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid0; i < kConst8Floats / 4; i += kThreads) lds[S8_CONST + i] = reinterpret_cast<const uint4*>(A.consts8)[i];
+    __syncthreads();
+
+    auto wo = [](int st, int blk) {
+        const nm::StageShape8 sh = nm::stage_shape8(st);
+        return (int)nm::stage_w_off8(st) + blk * (sh.i8steps + sh.bfsteps) * nm::kStepBytes;
+    };
+    const int so_s0 = wo(0, w), so_s8a = wo(8, 8), so_s9 = wo(9, w & 3), so_s10 = wo(10, 0);
+    WPre W;
+    w_prefetch<NM_PREC_BF16X3>(W, wsrc, (tid0 & 63) * 16, so_s0);
+
+#pragma unroll 1
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = tile * kTileM;
+        // Re-derive every lane-constant index from an opaque copy of the thread id once per tile: otherwise the compiler
+        // hoists dozens of per-lane addresses out of this loop and spills them to scratch, and scratch competes with the
+        // weight image for the XCD's L2.
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        const int g = lane >> 5, s = lane & 31;
+        const int voff = lane * 16;
+        const uint4* xH = lds + H8_BASE + g * kChunkU4 + s;
+        const uint4* xP = lds + P_BASE + g * kChunkU4 + s;
+        fill_pe_any(lds, false, a, base, tid);
+        __syncthreads();
+        if (a.stop_stage == -1) { dump_act(lds, true, 64, a, base, tid); __syncthreads(); continue; }
+
+        // ---------------- stages 0..7
+        bool stopped = false;
+#pragma unroll 1
+        for (int st = 0; st <= 7; ++st) {
+            const int soff = wo(st, w), next = wo(st + 1, w);
+            const int cblk = nm::stage_b_off(st) + 32 * w;
+            f32x16 f[4];
+            if (st == 0) {
+                init_bias8<4>(f, cst, cblk, g);
+                k_run<4, NM_PREC_BF16X3>(f, W, wsrc, voff, soff, next, xP, 4);
+            } else {
+                i32x16 ah[4], ac[4];
+                zero8<4>(ah, ac);
+                float sxin[4];
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) sxin[mb] = sscale[32 * mb + s];
+                k_run8<4>(ah, ac, W, wsrc, voff, soff, st == 5 ? soff + 8 * nm::kStepBytes : next, xH, 8);
+                dequant8<4>(f, ah, ac, sxin, cst, cblk, g);
+                if (st == 5) k_run<4, NM_PREC_BF16X3>(f, W, wsrc, voff, soff + 8 * nm::kStepBytes, next, xP, 4);
+            }
+            rowmax8<4, true>(f, smax, w, 0, g, s);
+            __syncthreads();                                      // all reads of H (and P) done; partial maxima visible
+            quant_store8<4, true>(f, lds, smax, sscale, 8, w, 0, g, s, w == 0);
+            if (st == 5) fill_pe_any(lds, true, a, base, tid);
+            __syncthreads();
+            if (a.stop_stage == st) { dump_act8(lds, 256, 0, a, base, tid); stopped = true; break; }
+        }
+        if (stopped) { __syncthreads(); w_prefetch<NM_PREC_BF16X3>(W, wsrc, voff, so_s0); continue; }
+
+        // ---------------- stage 8: feature (linear) + alpha block
+        float sigma = 0.f;
+        {
+            f32x16 f[4];
+            {
+                i32x16 ah[4], ac[4];
+                zero8<4>(ah, ac);
+                float sxin[4];
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) sxin[mb] = sscale[32 * mb + s];
+                k_run8<4>(ah, ac, W, wsrc, voff, wo(8, w), w < 4 ? so_s8a : so_s9, xH, 8);
+                dequant8<4>(f, ah, ac, sxin, cst, nm::stage_b_off(8) + 32 * w, g);
+            }
+            if (w < 4) {
+                i32x16 ah[1], ac[1];
+                f32x16 fa[1];
+                zero8<1>(ah, ac);
+                const float sx1[1] = {sscale[32 * w + s]};
+                k_run8<1>(ah, ac, W, wsrc, voff, so_s8a, so_s9, xH + 32 * w, 8);
+                dequant8<1>(fa, ah, ac, sx1, cst, nm::stage_b_off(8) + 32 * 8, g);
+                sigma = fa[0][0];
+            }
+            rowmax8<4, false>(f, smax, w, 0, g, s);
+            __syncthreads();
+            quant_store8<4, false>(f, lds, smax, sscale, 8, w, 0, g, s, w == 0);
+            __syncthreads();
+            if (a.stop_stage == 8) { dump_act8(lds, 256, 0, a, base, tid); __syncthreads(); w_prefetch<NM_PREC_BF16X3>(W, wsrc, voff, so_s0); continue; }
+        }
+
+        // ---------------- stage 9: views layer = hidden part on i8, then the direction encoding on split bf16
+        {
+            const int nb = w & 3, row0 = 64 * (w >> 2);
+            f32x16 f[2];
+            {
+                i32x16 ah[2], ac[2];
+                zero8<2>(ah, ac);
+                const float sxin[2] = {sscale[row0 + s], sscale[row0 + 32 + s]};
+                k_run8<2>(ah, ac, W, wsrc, voff, so_s9, so_s9 + 8 * nm::kStepBytes, xH + row0, 8);
+                dequant8<2>(f, ah, ac, sxin, cst, nm::stage_b_off(9) + 32 * nb, g);
+            }
+            k_run<2, NM_PREC_BF16X3>(f, W, wsrc, voff, so_s9 + 8 * nm::kStepBytes, w < 4 ? so_s10 : so_s0, xP + row0, 2);
+            rowmax8<2, true>(f, smax, nb, row0, g, s);
+            __syncthreads();
+            quant_store8<2, true>(f, lds, smax, sscale, 4, nb, row0, g, s, nb == 0);
+            __syncthreads();
+            if (a.stop_stage == 9) { dump_act8(lds, 128, 0, a, base, tid); __syncthreads(); w_prefetch<NM_PREC_BF16X3>(W, wsrc, voff, so_s0); continue; }
+        }
+
+        // ---------------- stage 10: rgb
+        if (w < 4) {
+            i32x16 ah[1], ac[1];
+            f32x16 fr[1];
+            zero8<1>(ah, ac);
+            const float sx1[1] = {sscale[32 * w + s]};
+            k_run8<1>(ah, ac, W, wsrc, voff, so_s10, so_s0, xH + 32 * w, 4);
+            dequant8<1>(fr, ah, ac, sx1, cst, nm::stage_b_off(10), g);
+            const int64_t i = base + 32 * w + s;
+            if (g == 0 && i < a.n)
+                reinterpret_cast<float4*>(a.out)[i] = make_float4(fr[0][0], fr[0][1], fr[0][2], sigma * a.sigma_scale);
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 namespace nm {
@@ -576,6 +895,14 @@ int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, con
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     const int grid = (int)(ntiles < cus ? ntiles : cus);          // one 160 KB workgroup per CU, grid-stride over tiles
+    if (precision == NM_PREC_I8X3 && !prof) {
+        MlpArgs8 a8;
+        a8.a = a;
+        a8.wpack8 = reinterpret_cast<const uint4*>(L.wpack8);
+        a8.consts8 = L.scales8;                                   // scales, then biases (contiguous in the image)
+        hipLaunchKernelGGL(nerf_mlp_i8_kernel, dim3(grid), dim3(kThreads), 0, stream, a8);
+        return check_launch("nerf_mlp_i8_kernel");
+    }
     if (prof)
         hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_BF16X3, true>), dim3(grid), dim3(kThreads), 0, stream, a);
     else if (precision == NM_PREC_BF16X3)

@@ -115,11 +115,90 @@ static void pack_image(const nm_mlp_desc* d, const float* const* P, uint8_t* img
     }
 }
 
+// ---- NM_PREC_I8X3 image: [fragments (i8 limb steps, then bf16 PE steps) | pad | weight scales | biases] ---------------
+// Per output feature n of a stage the hidden-part weights are quantised to int16 with scale sw[n] = max|w| / 32639 and
+// stored as balanced int8 limbs in MFMA A-operand order; PE-part weights keep the split-bf16 fragments of pack_image.
+static inline int64_t image8_bytes() { return kWeightBytes8 + kWeightPadBytes + 2 * (int64_t)kBiasFloats * 4; }
+
+// hidden-part weight of output feature n for hidden input feature f (the i8 operand), and the number of hidden features
+static const float* hidden_row(const nm_mlp_desc* d, const float* const* P, int st, int n, int* stride, int* col0) {
+    const int kpe = 3 + 6 * d->pos_n_freqs;
+    switch (st) {
+        case 5: *stride = kpe + 256; *col0 = kpe; return P[P_PTS_W + 10] + (int64_t)n * (kpe + 256);
+        case 8:
+            *stride = 256; *col0 = 0;
+            if (n < 256) return P[P_FEAT_W] + (int64_t)n * 256;
+            return n == 256 ? P[P_ALPHA_W] : nullptr;
+        case 9: { const int K = 256 + 3 + 6 * d->dir_n_freqs; *stride = K; *col0 = 0; return P[P_VIEWS_W] + (int64_t)n * K; }
+        case 10: *stride = 128; *col0 = 0; return n < 3 ? P[P_RGB_W] + (int64_t)n * 128 : nullptr;
+        default: *stride = 256; *col0 = 0; return P[P_PTS_W + 2 * st] + (int64_t)n * 256;
+    }
+}
+
+static void pack_image8(const nm_mlp_desc* d, const float* const* P, uint8_t* img) {
+    memset(img, 0, (size_t)image8_bytes());
+    float* scales = reinterpret_cast<float*>(img + kWeightBytes8 + kWeightPadBytes);
+    float* bias = scales + kBiasFloats;
+    for (int st = 0; st < kStages; ++st) {
+        const StageShape8 sh = stage_shape8(st);
+        const int nh = sh.i8steps * 32;                       // hidden input width of the i8 part
+        for (int nb = 0; nb < sh.nblk; ++nb) {
+            // ---- i8 limb steps
+            for (int r = 0; r < 32 && sh.i8steps; ++r) {
+                const int n = 32 * nb + r;
+                int stride = 0, col0 = 0;
+                const float* row = hidden_row(d, P, st, n, &stride, &col0);
+                float mx = 0.f;
+                if (row) for (int f = 0; f < nh; ++f) mx = fmaxf(mx, fabsf(row[col0 + f]));
+                const float sw = mx > 0.f ? mx / (float)kFixedMax : 1.f;
+                scales[stage_b_off(st) + n] = sw;
+                for (int t = 0; t < sh.i8steps; ++t) {
+                    int8_t* hi = reinterpret_cast<int8_t*>(img + frag_off8(st, nb, t));
+                    int8_t* lo = hi + 1024;
+                    for (int g = 0; g < 2; ++g)
+                        for (int e = 0; e < 16; ++e) {
+                            const int f = slot_feature8(2 * t + g, e);
+                            const float w = row ? row[col0 + f] : 0.f;
+                            int q = (int)lrintf(w / sw);
+                            if (q > kFixedMax) q = kFixedMax;
+                            if (q < -kFixedMax) q = -kFixedMax;
+                            const int l = ((q + 128) & 255) - 128;
+                            const int h = (q - l) >> 8;
+                            hi[(g * 32 + r) * 16 + e] = (int8_t)h;
+                            lo[(g * 32 + r) * 16 + e] = (int8_t)l;
+                        }
+                }
+            }
+            // ---- split-bf16 PE steps: same values as the bf16 image's PE steps of this stage
+            for (int t = 0; t < sh.bfsteps; ++t) {
+                uint16_t* hi = reinterpret_cast<uint16_t*>(img + frag_off8(st, nb, sh.i8steps + t));
+                uint16_t* lo = hi + 64 * 8;
+                // chunk index of PE step t inside the bf16 stage's chunk sequence: stage 0/5 put the PE first, stage 9 last
+                const int cc0 = st == 9 ? 32 : 0;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const float wv = stage_weight(d, P, st, 32 * nb + (lane & 31), cc0 + 2 * t + (lane >> 5), j);
+                        const uint16_t h = f32_to_bf16(wv);
+                        hi[lane * 8 + j] = h;
+                        lo[lane * 8 + j] = f32_to_bf16(wv - bf16_to_f32(h));
+                    }
+            }
+        }
+        float* b = bias + stage_b_off(st);
+        if (st <= 7) memcpy(b, P[P_PTS_W + 2 * st + 1], 256 * 4);
+        else if (st == 8) { memcpy(b, P[P_FEAT_B], 256 * 4); b[256] = P[P_ALPHA_B][0]; }
+        else if (st == 9) memcpy(b, P[P_VIEWS_B], 128 * 4);
+        else memcpy(b, P[P_RGB_B], 3 * 4);
+        if (!sh.i8steps) for (int n = 0; n < sh.nblk * 32; ++n) scales[stage_b_off(st) + n] = 1.f;
+    }
+}
+
 }  // namespace nm
 
 struct nm_mlp_s {
     nm_mlp_desc desc;
     uint8_t* d_image;      // weight fragments | pad | bias
+    uint8_t* d_image8;     // NM_PREC_I8X3: limb fragments | pad | weight scales | bias
     float* d_petab;        // 192 floats
     float* d_ref;          // transposed f32 weights | natural biases (NM_PREC_FP32 path)
     int ref_off[12], ref_boff[12];
@@ -149,6 +228,19 @@ int nm_mlp_pack(const nm_mlp_desc* desc, const float* const* host_params, void* 
     return NM_OK;
 }
 
+int64_t nm_mlp_pack_i8_bytes(const nm_mlp_desc* desc) {
+    if (nm::validate_desc(desc) != NM_OK) return -1;
+    return nm::image8_bytes();
+}
+
+int nm_mlp_pack_i8(const nm_mlp_desc* desc, const float* const* host_params, void* host_out) {
+    if (int e = nm::validate_desc(desc)) return e;
+    NM_REQUIRE(host_params && host_out, "nm_mlp_pack_i8: null pointer");
+    for (int i = 0; i < 24; ++i) NM_REQUIRE(host_params[i], "nm_mlp_pack_i8: host_params[%d] is null", i);
+    nm::pack_image8(desc, host_params, static_cast<uint8_t*>(host_out));
+    return NM_OK;
+}
+
 int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, const float* host_pos_tab,
                   const float* host_dir_tab, nm_mlp_t* out) {
     if (int e = nm::validate_desc(desc)) return e;
@@ -157,6 +249,8 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     const int64_t bytes = nm_mlp_pack_bytes(desc);
     std::vector<uint8_t> img((size_t)bytes);
     nm::pack_image(desc, host_params, img.data());
+    std::vector<uint8_t> img8((size_t)nm::image8_bytes());
+    nm::pack_image8(desc, host_params, img8.data());
 
     // reference-layout image for the exact-f32 kernel
     const int kpe = 3 + 6 * desc->pos_n_freqs, kdpe = 3 + 6 * desc->dir_n_freqs;
@@ -193,8 +287,10 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     m->pos_octaves = octaves(tab, desc->pos_n_freqs);
     m->dir_octaves = octaves(tab + 96, desc->dir_n_freqs);
 
-    m->d_image = nullptr; m->d_petab = nullptr; m->d_ref = nullptr;
+    m->d_image = nullptr; m->d_image8 = nullptr; m->d_petab = nullptr; m->d_ref = nullptr;
     int rc = nm::check_hip(hipMalloc(&m->d_image, (size_t)bytes), "nm_mlp_create: hipMalloc(image)");
+    if (!rc) rc = nm::check_hip(hipMalloc(&m->d_image8, img8.size()), "nm_mlp_create: hipMalloc(image8)");
+    if (!rc) rc = nm::check_hip(hipMemcpy(m->d_image8, img8.data(), img8.size(), hipMemcpyHostToDevice), "nm_mlp_create: upload image8");
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_petab, sizeof(tab)), "nm_mlp_create: hipMalloc(petab)");
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_ref, ref.size() * 4), "nm_mlp_create: hipMalloc(ref)");
     if (!rc) rc = nm::check_hip(hipMemcpy(m->d_image, img.data(), (size_t)bytes, hipMemcpyHostToDevice), "nm_mlp_create: upload image");
@@ -208,6 +304,7 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
 int nm_mlp_destroy(nm_mlp_t m) {
     if (!m) return NM_OK;
     if (m->d_image) (void)hipFree(m->d_image);
+    if (m->d_image8) (void)hipFree(m->d_image8);
     if (m->d_petab) (void)hipFree(m->d_petab);
     if (m->d_ref) (void)hipFree(m->d_ref);
     delete m;
@@ -219,7 +316,7 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
                         float* out, float* dbg, nm_stream_t stream, void* prof = nullptr) {
     NM_REQUIRE(m, "nm_mlp_forward: null handle");
     NM_REQUIRE(n >= 0, "nm_mlp_forward: negative n");
-    NM_REQUIRE(precision == NM_PREC_FP32 || precision == NM_PREC_BF16X3 || precision == NM_PREC_BF16,
+    NM_REQUIRE(precision == NM_PREC_FP32 || precision == NM_PREC_BF16X3 || precision == NM_PREC_BF16 || precision == NM_PREC_I8X3,
                "nm_mlp_forward: bad precision %d", precision);
     if (n == 0) return NM_OK;
     if (precision == NM_PREC_FP32) {
@@ -236,6 +333,9 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
     L.petab = m->d_petab;
     L.pe_kind = m->desc.pe_kind; L.pos_nfreq = m->desc.pos_n_freqs; L.dir_nfreq = m->desc.dir_n_freqs;
     L.pos_octaves = m->pos_octaves; L.dir_octaves = m->dir_octaves;
+    L.wpack8 = m->d_image8;
+    L.scales8 = reinterpret_cast<const float*>(m->d_image8 + nm::kWeightBytes8 + nm::kWeightPadBytes);
+    L.bias8 = L.scales8 + nm::kBiasFloats;
     return nm::launch_mlp_mfma(L, pts, dirs, origin, direction, z, n, S, in_mode, precision, stop_stage, sigma_scale, out, dbg,
                                prof, nm::as_stream(stream));
 }

@@ -84,4 +84,39 @@ NM_HD constexpr int slot_feature(int c, int e) {
 NM_HD constexpr int feature_chunk(int n) { return 4 * (n >> 5) + 2 * ((n >> 4) & 1) + ((n >> 2) & 1); }
 NM_HD constexpr int feature_elem(int n) { return 4 * ((n >> 3) & 1) + (n & 3); }
 
+// ---- NM_PREC_I8X3: 16-bit fixed-point limbs on v_mfma_i32_32x32x32_i8 ------------------------------------------
+// The 256-/128-wide hidden operands are per-row scaled int16, stored as two balanced int8 limbs (X = 256*hi + lo,
+// hi, lo in [-128,127], |X| <= 32639); weights likewise per output feature.  A k-step covers 32 k (one 16-byte chunk of
+// 16 int8 per lane half), so k-step t of a stage reads exactly the 32 features of block t.  The position / direction
+// encodings keep the split-bf16 path (they need absolute, not row-relative, precision): stage 0 is bf16 only, stages 5
+// and 9 run their hidden part on i8 first and then accumulate the PE part in f32 on top of the dequantised sum.
+struct StageShape8 {
+    int nblk;     // 32-feature output blocks
+    int i8steps;  // 32-k steps over the hidden input (i8 limbs)
+    int bfsteps;  // 16-k steps over the PE buffer (split bf16), after the i8 steps in the stream
+};
+NM_HD constexpr StageShape8 stage_shape8(int s) {
+    return s == 0 ? StageShape8{8, 0, 4}
+         : s == 5 ? StageShape8{8, 8, 4}
+         : s == 8 ? StageShape8{9, 8, 0}
+         : s == 9 ? StageShape8{4, 8, 2}
+         : s == 10 ? StageShape8{1, 4, 0}
+                   : StageShape8{8, 8, 0};
+}
+NM_HD constexpr int64_t stage_w_off8(int s) {
+    int64_t o = 0;
+    for (int i = 0; i < s; ++i) o += (int64_t)stage_shape8(i).nblk * (stage_shape8(i).i8steps + stage_shape8(i).bfsteps) * kStepBytes;
+    return o;
+}
+NM_HD constexpr int64_t frag_off8(int s, int nb, int step) {   // step counts i8 steps first, then bf steps
+    return stage_w_off8(s) + ((int64_t)nb * (stage_shape8(s).i8steps + stage_shape8(s).bfsteps) + step) * kStepBytes;
+}
+constexpr int64_t kWeightBytes8 = stage_w_off8(kStages);
+// after the fragments (+ the same prefetch pad): per-feature weight scales, then biases, both laid out like stage_b_off()
+constexpr int kFixedMax = 32639;   // 127*256 + 127: largest magnitude whose balanced limbs fit int8
+// feature held by k-slot (16-slot chunk c, element e) of an i8 activation: c = 2*blk + g, e = reg index of the accumulator
+NM_HD constexpr int slot_feature8(int c, int e) { return 32 * (c >> 1) + (e & 3) + 8 * (e >> 2) + 4 * (c & 1); }
+NM_HD constexpr int feature_chunk8(int n) { return 2 * (n >> 5) + ((n >> 2) & 1); }
+NM_HD constexpr int feature_elem8(int n) { return (n & 3) + 4 * ((n >> 3) & 3); }
+
 }  // namespace nm

@@ -154,3 +154,55 @@ def test_full_size_bf16x3_vs_fp32_kernel(gpu_nets):
     with torch.no_grad():
         j.nerf.rgb_linear.bias.copy_(saved)
     assert (c[:, :3] - a[:, :3] - 1.0).abs().max() < 1e-5 and torch.equal(c[:, 3], a[:, 3])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# NM_PREC_I8X3: hidden layers as per-row-scaled int16 (two int8 limbs) on the i8 MFMA
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", [0, 2])
+def test_i8x3_stage_by_stage(gpu_nets, seed):
+    j, sd, spec = gpu_nets[seed]
+    pts, dirs = sample_inputs(300)
+    out, hidden = nerf_mlp.joiner_forward(sd, spec, pts, dirs, return_hidden=True)
+    scale = 30 if spec.mapping == 'rotate' else 1
+    for st in range(10):
+        got = j.forward_debug(cu(pts), cu(dirs), st, precision="i8x3").cpu().numpy()
+        ref = hidden[st]
+        # 16-bit fixed point per row: absolute error ~ rowmax * 2^-16 per requantisation, accumulated over the layers
+        tol = 3e-4 * scale * max(1.0, np.abs(ref).max())
+        assert report(f"seed{seed} i8x3 stage {st}", got, ref) < tol, f"stage {st}"
+    got = j(cu(pts), cu(dirs), precision="i8x3").cpu().numpy()
+    assert report(f"seed{seed} i8x3 rgb", got[:, :3], out[:, :3]) < 4e-4 * scale
+    assert report(f"seed{seed} i8x3 sigma", got[:, 3], out[:, 3]) < 2e-3 * scale * max(1.0, np.abs(out[:, 3]).max())
+
+
+@pytest.mark.parametrize("n", [1, 127, 129, 1000, 128 * 300 + 5])
+def test_i8x3_ragged_sizes_vs_fp32(gpu_nets, n):
+    j = gpu_nets[0][0]
+    pts, dirs = sample_inputs(n, seed=n)
+    a = j(cu(pts), cu(dirs), precision="i8x3")
+    b = j(cu(pts), cu(dirs), precision="fp32")
+    assert a.shape == (n, 4) and torch.isfinite(a).all()
+    assert (a[:, :3] - b[:, :3]).abs().max() < 4e-4
+    assert ((a[:, 3] - b[:, 3]).abs() / (1 + b[:, 3].abs())).max() < 2e-3
+
+
+def test_i8x3_composited_parity_and_full_size(gpu_nets):
+    """What the contract is about: composited colours.  i8x3 vs the exact-f32 device kernel on 1 M samples (16384 rays x 64)."""
+    from neuman_hip import ray_utils, render_utils
+    j = gpu_nets[0][0]
+    g = torch.Generator(device='cuda').manual_seed(1)
+    R, S = 16384, 64
+    o = torch.zeros((R, 3), device='cuda')
+    d = torch.nn.functional.normalize(torch.randn((R, 3), device='cuda', generator=g) * torch.tensor([0.3, 0.3, 0.05], device='cuda')
+                                      + torch.tensor([0., 0., 1.], device='cuda'), dim=-1).contiguous()
+    near, far = torch.zeros(R, device='cuda'), torch.full((R,), 3.14, device='cuda')
+    _, _, z = ray_utils.sample_z(o, d, near, far, S)
+    res = {}
+    for prec in ("fp32", "bf16x3", "i8x3"):
+        raw = j.forward_rays(o, d, z, precision=prec)
+        res[prec] = render_utils.raw2outputs(raw, z, d)[0]
+    e3 = (res["bf16x3"] - res["fp32"]).abs().max().item()
+    e8 = (res["i8x3"] - res["fp32"]).abs().max().item()
+    print(f"[mlp] composited RGB Linf vs f32 kernel over {R} rays: bf16x3 {e3:.3e}, i8x3 {e8:.3e}")
+    assert e3 < 2e-5 and e8 < 1e-4

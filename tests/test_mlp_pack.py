@@ -111,3 +111,111 @@ def test_pack_rejects_unsupported_nets():
         desc = _lib.MlpDesc(*bad)
         assert lib.nm_mlp_pack_bytes(ctypes.byref(desc)) == -1
         assert b"nm_mlp" in lib.nm_last_error()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# NM_PREC_I8X3 image: per-row-scaled int16 as two int8 limbs (mlp_layout.h), emulated with exact integer arithmetic
+# ---------------------------------------------------------------------------------------------------------------------
+STAGES8 = {0: (8, 0, 4), 5: (8, 8, 4), 8: (9, 8, 0), 9: (4, 8, 2), 10: (1, 4, 0)}   # nblk, i8 steps (32 k), bf steps (16 k)
+
+
+def shape8(s):
+    return STAGES8.get(s, (8, 8, 0))
+
+
+def w_off8(s):
+    return sum(shape8(i)[0] * (shape8(i)[1] + shape8(i)[2]) * 2048 for i in range(s))
+
+
+def slot_feature8(c, e):
+    return 32 * (c >> 1) + (e & 3) + 8 * (e >> 2) + 4 * (c & 1)
+
+
+def stage_weights8(img, s):
+    """(Wq [nblk*32, i8steps*32] int64 in k-slot order, Wpe [nblk*32, bfsteps*16] f32 in k-slot order)."""
+    nblk, n8, nbf = shape8(s)
+    per = n8 + nbf
+    raw = np.frombuffer(img, dtype=np.uint8, count=nblk * per * 2048, offset=w_off8(s)).reshape(nblk, per, 2048)
+    wq = np.zeros((nblk * 32, n8 * 32), np.int64)
+    if n8:
+        limbs = raw[:, :n8].copy().view(np.int8).reshape(nblk, n8, 2, 2, 32, 16).astype(np.int64)    # [nb, t, limb, g, r, e]
+        q = 256 * limbs[:, :, 0] + limbs[:, :, 1]                                                      # [nb, t, g, r, e]
+        wq = q.transpose(0, 3, 1, 2, 4).reshape(nblk * 32, n8 * 32)                                     # [n, (t, g, e)]
+    wpe = np.zeros((nblk * 32, nbf * 16), np.float32)
+    if nbf:
+        frag = raw[:, n8:].copy().view(np.uint16).reshape(nblk, nbf, 2, 2, 32, 8)                      # [nb, t, hi|lo, g, r, j]
+        w = bf16_to_f32(frag[:, :, 0]) + bf16_to_f32(frag[:, :, 1])
+        wpe = w.transpose(0, 3, 1, 2, 4).reshape(nblk * 32, nbf * 16)
+    return wq, wpe
+
+
+def quant_rows(h):
+    """X = rint(x / sx), sx = max|x| / 32639 per row, split into balanced int8 limbs."""
+    m = np.abs(h).max(axis=1, keepdims=True)
+    s = np.where(m > 0, m / 32639.0, 1.0).astype(np.float32)
+    q = np.rint(h / s).astype(np.int64)
+    lo = ((q + 128) & 255) - 128
+    hi = (q - lo) >> 8
+    assert np.abs(hi).max() <= 128 and np.abs(lo).max() <= 128 and (256 * hi + lo == q).all()
+    return s, hi, lo
+
+
+def emulate8(img, pts, dirs, spec):
+    tail = w_off8(11) + 4 * 2048
+    nb_f = b_off(11)
+    scales = np.frombuffer(img, dtype=np.float32, count=nb_f, offset=tail)
+    bias = np.frombuffer(img, dtype=np.float32, count=nb_f, offset=tail + 4 * nb_f)
+    x_pe = nerf_mlp.embed(pts, spec.mapping, *spec.pos)
+    d_pe = nerf_mlp.embed(dirs, spec.mapping, *spec.dir)
+    P = np.zeros((pts.shape[0], 64), np.float32)
+    P[:, :x_pe.shape[1]] = x_pe
+    Pd = np.zeros((pts.shape[0], 32), np.float32)
+    Pd[:, :d_pe.shape[1]] = d_pe
+
+    def run(s, h, pe, n_out):
+        wq, wpe = stage_weights8(img, s)
+        nrow = wq.shape[0]
+        out = np.zeros((pts.shape[0], nrow), np.float64)
+        if h is not None:
+            nchunks = wq.shape[1] // 16
+            idx = np.array([slot_feature8(c, e) for c in range(nchunks) for e in range(16)])
+            sx, xh, xl = quant_rows(h[:, idx])
+            wl = ((wq + 128) & 255) - 128
+            wh = (wq - wl) >> 8
+            t = 65536 * (xh @ wh.T) + 256 * (xh @ wl.T + xl @ wh.T)            # the xl*wl term is dropped, like the kernel
+            assert np.abs(t // 256).max() < 2 ** 31                             # the kernel combines (hh << 8) + cross in int32
+            out += t * sx.astype(np.float64) * scales[b_off(s):b_off(s) + nrow].astype(np.float64)
+        if pe is not None:
+            out += pe.astype(np.float64) @ wpe.T.astype(np.float64)
+        return (out + bias[b_off(s):b_off(s) + nrow])[:, :n_out].astype(np.float32)
+
+    h = np.maximum(run(0, None, P, 256), 0)
+    for s in range(1, 8):
+        h = np.maximum(run(s, h, P if s == 5 else None, 256), 0)
+    o8 = run(8, h, None, 288)
+    feature, sigma = o8[:, :256], o8[:, 256]
+    v = np.maximum(run(9, feature, Pd, 128), 0)
+    o10 = run(10, v, None, 32)
+    return np.concatenate([o10[:, :3], sigma[:, None]], 1)
+
+
+@pytest.mark.parametrize("seed", [0, 2])
+def test_pack_i8_matches_oracle(nets, seed):
+    joiner, sd, spec = nets[seed]
+    lib = _lib.lib()
+    desc = _lib.MlpDesc(8, 256, 4, _lib.NM_PE_ROTATE if spec.mapping == 'rotate' else _lib.NM_PE_POSENC, 10, 4)
+    nbytes = lib.nm_mlp_pack_i8_bytes(ctypes.byref(desc))
+    assert nbytes == w_off8(11) + 4 * 2048 + 8 * b_off(11)
+    host = [p.detach().contiguous() for p in joiner.nerf.ordered_params()]
+    arr = (ctypes.c_void_p * 24)(*[t.data_ptr() for t in host])
+    img = ctypes.create_string_buffer(nbytes)
+    _lib.check(lib.nm_mlp_pack_i8(ctypes.byref(desc), arr, img), "nm_mlp_pack_i8")
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(-1.5, 1.5, size=(64, 3)).astype(np.float32)
+    dirs = rng.normal(size=(64, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    got = emulate8(img.raw, pts, dirs, spec)
+    ref = nerf_mlp.joiner_forward(sd, spec, pts, dirs)
+    print(np.abs(got[:, :3] - ref[:, :3]).max(), np.abs(got[:, 3] - ref[:, 3]).max())
+    assert np.abs(got[:, :3] - ref[:, :3]).max() < 3e-4
+    assert np.abs(got[:, 3] - ref[:, 3]).max() < 2e-3 * max(1.0, np.abs(ref[:, 3]).max())

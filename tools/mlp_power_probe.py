@@ -16,7 +16,7 @@ for tag in ("random", "zero-weights"):
         with torch.no_grad():
             for p in j.parameters():
                 p.zero_()
-    for prec in ("bf16x3", "bf16"):
+    for prec in ("bf16x3", "i8x3", "bf16"):
         j(pts, dirs, precision=prec)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
