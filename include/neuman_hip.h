@@ -149,10 +149,12 @@ int nm_mlp_forward_rays(nm_mlp_t mlp, const float* origin, const float* directio
  *    8 -> feature_linear output (256);  9 -> relu(views_linears[0]) (128). */
 int nm_mlp_forward_debug(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision,
                          int stage, float* hidden, nm_stream_t stream);
-/* Profiling build of the bf16x3 kernel: same result in `out`, plus per-wave s_memtime totals in
- * cycles[(workgroup*8 + wave)*8 + bucket], bucket = {0 PE, 1 k-loops, 2 wait before epilogue, 3 epilogue,
- * 4 wait after epilogue, 5 tile tail}; cycles must hold 64 * min(#CUs, ceil(n/128)) uint64. */
-int nm_mlp_forward_profile(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, float* out,
+/* Profiling build of the NM_PREC_BF16X3 or NM_PREC_I8X3 kernel: same result in `out`, plus per-wave s_memtime
+ * totals in cycles[(workgroup*8 + wave)*8 + bucket]; cycles must hold 64 * min(#CUs, ceil(n/128)) uint64.
+ *   bf16x3 buckets: {0 PE, 1 k-loops, 2 wait before epilogue, 3 epilogue, 4 wait after epilogue, 5 tile tail}
+ *   i8x3 buckets:   {0 PE fill, 1 k-loops, 2 end barrier of an M slot, 3 epilogue part 1, 4 its middle barrier,
+ *                    5 epilogue part 2, 6 end barrier of an E slot, 7 rest}  (csrc/mlp.hip) */
+int nm_mlp_forward_profile(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision, float* out,
                            uint64_t* cycles, nm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

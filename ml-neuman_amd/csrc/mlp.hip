@@ -104,7 +104,7 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
         }
         const bf16x2 hb = __builtin_convertvector(a, bf16x2);
         const f32x2 hf = __builtin_convertvector(hb, f32x2);
-        const f32x2 r = a - hf;
+        const f32x2 r = {a.x - hf.x, a.y - hf.y};              // two scalar v_sub_f32: v_pk_add_f32 is slow beside MFMAs on gfx950
         const bf16x2 lb = __builtin_convertvector(r, bf16x2);
         h[p] = __builtin_bit_cast(unsigned, hb);
         l[p] = __builtin_bit_cast(unsigned, lb);
@@ -270,11 +270,13 @@ __device__ __forceinline__ void write_act(const ActRegs<MB>& r, uint4* lds, int 
 }
 
 // fill `nchunks` PE chunks for the tile: work item = (chunk, sample); 8 features -> one b128 write per array
-__device__ __forceinline__ void fill_pe(uint4* lds, int nchunks, bool is_dir, const MlpArgs& a, int64_t base, int tid) {
+// (`nthreads` threads numbered by tid cover rows row0 .. row0 + 2^rshift - 1: the whole tile, or one wave group's half)
+__device__ __forceinline__ void fill_pe(uint4* lds, int nchunks, bool is_dir, const MlpArgs& a, int64_t base, int tid,
+                                        int nthreads = kThreads, int row0 = 0, int rshift = 7) {
     const PeSpec spec = is_dir ? a.dir : a.pos;
     const float* tab = a.petab + (is_dir ? 96 : 0);
-    for (int item = tid; item < nchunks * kTileM; item += kThreads) {
-        const int c = item >> 7, row = item & (kTileM - 1);
+    for (int item = tid; item < (nchunks << rshift); item += nthreads) {
+        const int c = item >> rshift, row = row0 + (item & ((1 << rshift) - 1));
         int64_t i = base + row;
         if (i >= a.n) i = a.n - 1;                              // tail rows recompute the last sample (never stored)
         float x0, x1, x2;
@@ -332,11 +334,12 @@ __device__ __forceinline__ void sincos_f64(double a, double& sn, double& cs) {
     if (q >= 2) sn = -sn;
 }
 
-__device__ __forceinline__ void fill_pe_fast(uint4* lds, bool is_dir, const MlpArgs& a, int64_t base, int tid) {
+__device__ __forceinline__ void fill_pe_fast(uint4* lds, bool is_dir, const MlpArgs& a, int64_t base, int tid, int row0 = 0,
+                                             int rshift = 7) {
     const PeSpec spec = is_dir ? a.dir : a.pos;
     const float* tab = a.petab + (is_dir ? 96 : 0);
-    if (tid >= 3 * kTileM) return;
-    const int j = tid >> 7, row = tid & (kTileM - 1);          // j is wave-uniform (128 = 2 waves per component)
+    if (tid >= (3 << rshift)) return;
+    const int j = tid >> rshift, row = row0 + (tid & ((1 << rshift) - 1));   // j is wave-uniform (rshift >= 6)
     int64_t i = base + row;
     if (i >= a.n) i = a.n - 1;
     float x0, x1, x2;
@@ -386,17 +389,19 @@ __device__ __forceinline__ void fill_pe_fast(uint4* lds, bool is_dir, const MlpA
     }
 }
 
-__device__ __forceinline__ void fill_pe_any(uint4* lds, bool is_dir, const MlpArgs& a, int64_t base, int tid) {
-    if ((is_dir ? a.dir : a.pos).octaves) fill_pe_fast(lds, is_dir, a, base, tid);
-    else fill_pe(lds, is_dir ? 4 : nm::kPeChunks, is_dir, a, base, tid);
+__device__ __forceinline__ void fill_pe_any(uint4* lds, bool is_dir, const MlpArgs& a, int64_t base, int tid,
+                                            int nthreads = kThreads, int row0 = 0, int rshift = 7) {
+    if ((is_dir ? a.dir : a.pos).octaves) fill_pe_fast(lds, is_dir, a, base, tid, row0, rshift);
+    else fill_pe(lds, is_dir ? 4 : nm::kPeChunks, is_dir, a, base, tid, nthreads, row0, rshift);
 }
 
 // debug: dump `width` features of the tile from the H (or P) arrays as f32 [n, width] in natural order
-__device__ __forceinline__ void dump_act(const uint4* lds, bool from_pe, int width, const MlpArgs& a, int64_t base, int tid) {
+__device__ __forceinline__ void dump_act(const uint4* lds, bool from_pe, int width, const MlpArgs& a, int64_t base, int tid,
+                                         int nthreads = kThreads, int row0 = 0, int nrows = kTileM) {
     const unsigned short* hi = reinterpret_cast<const unsigned short*>(lds + (from_pe ? P_BASE : H_BASE));
     const unsigned short* lo = hi + kLoU4 * 8;
-    for (int item = tid; item < kTileM * width; item += kThreads) {
-        const int row = item / width, n = item - row * width;
+    for (int item = tid; item < nrows * width; item += nthreads) {
+        const int row = row0 + item / width, n = item % width;
         if (base + row >= a.n) continue;
         const int c = from_pe ? (n >> 3) : nm::feature_chunk(n);
         const int e = from_pe ? (n & 7) : nm::feature_elem(n);
@@ -582,12 +587,14 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
 // NM_PREC_I8X3: the hidden layers in 16-bit fixed point on v_mfma_i32_32x32x32_i8 (mlp_layout.h, DESIGN.md "K4-i8").
 //
 // Per sample row the 256-/128-wide hidden operand is X = rint(x / sx), sx = max|x| / 32639, stored in LDS as two balanced
-// int8 limbs (X = 256*hi + lo); weights likewise per output feature (host).  x.w = sx*sw*(65536*hi.hi + 256*(hi.lo + lo.hi)
-// [+ lo.lo, dropped: <= 2^-16 of full scale]) with EXACT int32 accumulation: three i8 MFMAs of K = 32 replace three bf16
-// MFMAs of K = 16, so the MFMA time and the L2 weight traffic both halve.  The encodings keep the split-bf16 path (they
-// need absolute precision): stage 0 is bf16 only, stages 5 / 9 add their PE part in f32 on top of the dequantised sum.
-// The row maxima need all 8 waves' features: partial maxima go through a small LDS array around the barrier that the
-// epilogue needs anyway.  Activations take 64 KB of LDS instead of 128 KB; scales and biases of all stages sit in LDS.
+// int8 limbs (X = 256*hi + lo); the weights are int16 limbs too, per output feature, with the per-feature steps folded
+// into the next layer's columns on the host (mlp_host.hip pack_image8), so that
+//     out[n] / unit[n] = sx * kappa * (65536*hi.hi + 256*(hi.lo + lo.hi) [+ lo.lo, dropped: <= 2^-16 of full scale]) + bias'[n]
+// with EXACT int32 accumulation: three i8 MFMAs of K = 32 replace three bf16 MFMAs of K = 16 -- half the MFMA time and
+// half the weight bytes.  The encodings keep the split-bf16 path (they need absolute precision): stage 0 is bf16 only,
+// stages 5 / 9 add their PE part in f32 on top of the dequantised sum.  The row maxima need every wave's features:
+// partial maxima go through a small LDS array around a barrier.  Activations take 64 KB of LDS instead of 128 KB; units,
+// biases and kappa of all stages sit in LDS.
 // =====================================================================================================================
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(16))) int i32x16;
@@ -596,49 +603,15 @@ typedef __attribute__((ext_vector_type(2))) short i16x2;
 constexpr int H8_BASE = 0;                                   // [16 chunks][hi: 128 rows | lo: 128 rows][16 B]  (64 KB)
 constexpr int S8_MAX = 16 * kChunkU4;                        // 4096: row-max partials [8][128] f32
 constexpr int S8_SCALE = S8_MAX + 8 * kTileM / 4;            // 4352: row scales [128] f32
-constexpr int S8_CONST = S8_SCALE + kTileM / 4;              // 4384: [weight scales | biases] of all stages
-constexpr int kConst8Floats = 2 * nm::kBiasFloats;
+constexpr int S8_CONST = S8_SCALE + kTileM / 4;              // 4384: [units | biases | kappa] of all stages (mlp_host.hip)
+constexpr int kConst8Floats = 2 * nm::kBiasFloats + 16;
 static_assert(S8_CONST + kConst8Floats / 4 <= P_BASE && kConst8Floats % 4 == 0, "i8 scratch must fit below the PE buffer");
 
 struct MlpArgs8 {
     MlpArgs a;
-    const uint4* wpack8;
-    const float* consts8;     // scales (kBiasFloats) then biases (kBiasFloats)
+    const float* consts8;     // units (kBiasFloats), biases in those units (kBiasFloats), kappa (16)
+    const uint4* wstream8;    // the limb / bf16 fragments as per-wave streams (mlp_layout.h wstream_*)
 };
-
-template <int MB>
-__device__ __forceinline__ void k_run8(i32x16 (&ah)[MB], i32x16 (&ac)[MB], WPre& W, __amdgpu_buffer_rsrc_t wsrc, int voff, int soff,
-                                       int next_soff, const uint4* xh, int nsteps) {
-#pragma unroll 1
-    for (int t = 0; t < nsteps; t += 2) {
-        const int pf = (t + 2 < nsteps) ? soff + (t + 2) * nm::kStepBytes : next_soff;
-        WPre N;
-        w_prefetch<NM_PREC_BF16X3>(N, wsrc, voff, pf);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint4* ph = xh + (t + u) * (2 * kChunkU4);
-            const i32x4 wh = __builtin_bit_cast(i32x4, W.h[u]), wl = __builtin_bit_cast(i32x4, W.l[u]);
-            // two int32 accumulator sets (128 VGPRs at MB = 4) leave no room for all activation fragments of a step:
-            // they are loaded two sample blocks at a time (the partner wave of the SIMD covers the LDS latency)
-#pragma unroll
-            for (int m0 = 0; m0 < MB; m0 += 2) {
-                i32x4 bh[2], bl[2];
-#pragma unroll
-                for (int k = 0; k < 2 && m0 + k < MB; ++k) {
-                    bh[k] = __builtin_bit_cast(i32x4, ph[(m0 + k) * 32]);
-                    bl[k] = __builtin_bit_cast(i32x4, ph[kLoU4 + (m0 + k) * 32]);
-                }
-#pragma unroll
-                for (int k = 0; k < 2 && m0 + k < MB; ++k) ac[m0 + k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wh, bl[k], ac[m0 + k], 0, 0, 0);
-#pragma unroll
-                for (int k = 0; k < 2 && m0 + k < MB; ++k) ac[m0 + k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wl, bh[k], ac[m0 + k], 0, 0, 0);
-#pragma unroll
-                for (int k = 0; k < 2 && m0 + k < MB; ++k) ah[m0 + k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wh, bh[k], ah[m0 + k], 0, 0, 0);
-            }
-        }
-        W = N;
-    }
-}
 
 template <int MB>
 __device__ __forceinline__ void zero8(i32x16 (&ah)[MB], i32x16 (&ac)[MB]) {
@@ -646,27 +619,6 @@ __device__ __forceinline__ void zero8(i32x16 (&ah)[MB], i32x16 (&ac)[MB]) {
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { ah[mb][r] = 0; ac[mb][r] = 0; }
-}
-
-// f = (256*hh + cross) * (256 * sx[row] * sw[feature]) + bias[feature]; the scales / biases of this lane's 16 features of
-// block `cblk` (float offset into the stage tables) come from the LDS copy
-template <int MB>
-__device__ __forceinline__ void dequant8(f32x16 (&f)[MB], const i32x16 (&ah)[MB], const i32x16 (&ac)[MB], const float (&sxin)[MB],
-                                         const float* cst, int cblk, int g) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 sw = *reinterpret_cast<const float4*>(cst + cblk + 8 * q + 4 * g);
-        const float4 bs = *reinterpret_cast<const float4*>(cst + nm::kBiasFloats + cblk + 8 * q + 4 * g);
-        const float swv[4] = {sw.x, sw.y, sw.z, sw.w}, bsv[4] = {bs.x, bs.y, bs.z, bs.w};
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = 4 * q + j;
-                const int t = (ah[mb][r] << 8) + ac[mb][r];
-                f[mb][r] = fmaf((float)t, (sxin[mb] * 256.f) * swv[j], bsv[j]);
-            }
-    }
 }
 
 // accumulator init from the LDS bias table (stage 0: bf16 only)
@@ -680,197 +632,490 @@ __device__ __forceinline__ void init_bias8(f32x16 (&f)[MB], const float* cst, in
     }
 }
 
-// per-row partial maximum of this wave's 32 features -> smax[part][row]
-template <int MB, bool RELU>
-__device__ __forceinline__ void rowmax8(const f32x16 (&f)[MB], float* smax, int part, int row0, int g, int s) {
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        float m = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) m = fmaxf(m, RELU ? f[mb][r] : fabsf(f[mb][r]));
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
-        if (g == 0) smax[part * kTileM + row0 + 32 * mb + s] = m;
-    }
-}
-
-// quantise this wave's features of its rows with the row scale (max over `nparts` partials) and store the two limbs
-template <int MB, bool RELU>
-__device__ __forceinline__ void quant_store8(const f32x16 (&f)[MB], uint4* lds, const float* smax, float* sscale, int nparts, int blk,
-                                             int row0, int g, int s, bool write_scale) {
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        const int row = row0 + 32 * mb + s;
-        float M = 0.f;
-        for (int p = 0; p < nparts; ++p) M = fmaxf(M, smax[p * kTileM + row]);
-        // cvt_pknorm maps [-1,1] to rint(y * 32767): X = rint(v * 32639 / M).  (Offset coding of the non-negative ReLU rows
-        // for a 17th bit was measured: composited error 1.9e-5 -> 1.8e-5 for -7 % throughput; not kept.)
-        const float c = (float)nm::kFixedMax / 32767.f;
-        const float inv = M > 0.f ? c / M : 0.f;
-        if (write_scale && g == 0) sscale[row] = M > 0.f ? M / (float)nm::kFixedMax : 1.f;
-        i16x2 P[8], Y[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            i16x2 p = __builtin_amdgcn_cvt_pknorm_i16(f[mb][2 * i] * inv, f[mb][2 * i + 1] * inv);
-            if (RELU) p = __builtin_elementwise_max(p, (i16x2){0, 0});
-            P[i] = p;
-            Y[i] = p + (i16x2){128, 128};
-        }
-        unsigned lo[4], hi[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            lo[k] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, P[2 * k + 1]), __builtin_bit_cast(unsigned, P[2 * k]), 0x06040200u);
-            hi[k] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, Y[2 * k + 1]), __builtin_bit_cast(unsigned, Y[2 * k]), 0x07050301u);
-        }
-        const int idx = H8_BASE + (2 * blk + g) * kChunkU4 + row;
-        lds[idx] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-        lds[idx + kLoU4] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-    }
-}
-
-__device__ __forceinline__ void dump_act8(const uint4* lds, int width, int offset, const MlpArgs& a, int64_t base, int tid) {
+__device__ __forceinline__ void dump_act8(const uint4* lds, int width, const float* units, const MlpArgs& a, int64_t base, int tid,
+                                          int nthreads = kThreads, int row0 = 0, int nrows = kTileM) {
     const signed char* hi = reinterpret_cast<const signed char*>(lds + H8_BASE);
     const signed char* lo = hi + kLoU4 * 16;
     const float* sscale = reinterpret_cast<const float*>(lds + S8_SCALE);
-    for (int item = tid; item < kTileM * width; item += kThreads) {
-        const int row = item / width, n = item - row * width;
+    for (int item = tid; item < nrows * width; item += nthreads) {
+        const int row = row0 + item / width, n = item % width;
         if (base + row >= a.n) continue;
         const int off = (nm::feature_chunk8(n) * kChunkU4 + row) * 16 + nm::feature_elem8(n);
-        a.dbg[(base + row) * width + n] = sscale[row] * (float)(256 * (int)hi[off] + (int)lo[off] + offset);
+        a.dbg[(base + row) * width + n] = sscale[row] * (float)(256 * (int)hi[off] + (int)lo[off]) * units[n];
     }
 }
 
-__global__ __launch_bounds__(kThreads, 2) void nerf_mlp_i8_kernel(const MlpArgs8 A) {
+// =====================================================================================================================
+// NM_PREC_I8X3, wave-specialised: the two waves of every SIMD work half a stage out of phase.
+//
+// With all 8 waves running k-loop -> dequantise / row-max -> barrier -> quantise / store in lock step (the layout of
+// nerf_mlp_kernel; measured 650 TFLOP/s) the MFMA pipe idles through every epilogue, ~45 % of the time: requantisation
+// costs ~6 VALU instructions per accumulator and a barrier.  Here the tile is split into two 64-sample halves owned by
+// wave groups A = waves 0..3 and B = waves 4..7 (one wave of each per SIMD); wave q of a group owns output features
+// 64q..64q+63 (two 32-feature blocks) of its 64 samples (two 32-sample blocks).  Time is cut into slots, each
+// `part 1 | barrier | part 2 | barrier`; a group alternates M slots (k-loop of block 2q | barrier | k-loop of block 2q+1)
+// and E slots (dequantise + row-max | barrier | quantise + store), and group B runs the same sequence one slot later:
+// while one wave of a SIMD issues MFMAs, the other does its epilogue on the VALU.  The barriers are workgroup-wide and
+// both groups execute the same number of them (B two extra before its first slot, A two after its last), so the phase
+// relation is fixed by construction.
+//
+// In an M slot a wave is alone on its SIMD's MFMA pipe, so only its own instruction order hides latency:
+//   * its weights are one linear stream (mlp_layout.h wstream_*) prefetched kRing k-steps ahead through a register ring;
+//   * the activation fragments of step t + 1 are requested before the MFMAs of step t;
+//   * the hh / cross accumulators of a block are combined to one int32 (hh * 256 + cross) as soon as its k-loop ends,
+//     so at most 96 accumulator registers are live and nothing spills (scratch would evict the weights from L2).
+// Cost: both groups stream the whole weight image (2 x 1.2 MB per 128-sample tile = what bf16x3 streams).
+// =====================================================================================================================
+#ifndef NM_W_PRIO
+#define NM_W_PRIO 2          // issue priority of a wave inside its k-loop (its SIMD partner is in an epilogue)
+#endif
+#ifndef NM_E_PRIO
+#define NM_E_PRIO 0          // ... and outside it (epilogues, fills)
+#endif
+#ifndef NM_W_RING
+#define NM_W_RING 4          // k-steps of weights in flight per wave (8 VGPRs each)
+#endif
+#ifndef NM_W_XD
+#define NM_W_XD 1            // k-steps of activation fragments in flight
+#endif
+constexpr int kXD = NM_W_XD;
+constexpr int kRing = NM_W_RING;
+static_assert(kRing == 4 || kRing == 8, "runs are multiples of 4 steps");
+static_assert(kRing <= nm::kW8Pad, "the stream is padded for the ring's overrun");
+
+struct WStep {
+    v4u h, l;                                        // hi / lo limb (or bf16 hi / lo) fragment of one k-step
+};
+struct WRing {
+    WStep s[kRing];                                  // the next kRing steps of the stream; slot = step index mod kRing
+};
+__device__ __forceinline__ void w_step_load(WStep& S, __amdgpu_buffer_rsrc_t wsrc, int voff, int soff) {
+    S.h = __builtin_amdgcn_raw_buffer_load_b128(wsrc, voff, soff, 0);
+    S.l = __builtin_amdgcn_raw_buffer_load_b128(wsrc, voff, soff + 1024, 0);
+}
+
+// NSTEPS k-steps of one feature block x MB sample blocks, fully unrolled.  PH = ring slot of the first step; `pos` is the
+// stream offset of the step the ring loads next (kRing ahead of the step being consumed).  I8: limbs on the i8 MFMA into
+// (ah, ac); otherwise split bf16 into f32 accumulators passed as ah (bit pattern) -- see the two wrappers below.
+template <bool I8, int MB, int NSTEPS, int PH>
+__device__ __forceinline__ void w_run(i32x16 (&ah)[MB], i32x16 (&ac)[MB], f32x16 (&ff)[MB], WRing& R, __amdgpu_buffer_rsrc_t wsrc,
+                                      int voff, int& pos, const uint4* xh) {
+    // activation fragments kXD steps ahead, in a rotating set of kXD + 1 register groups (static indices: the loop is unrolled)
+    uint4 xq[kXD + 1][2][MB];
+#pragma unroll
+    for (int d = 0; d < kXD && d < NSTEPS; ++d)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            xq[d][0][m] = xh[d * (2 * kChunkU4) + m * 32];
+            xq[d][1][m] = xh[d * (2 * kChunkU4) + kLoU4 + m * 32];
+        }
+    __builtin_amdgcn_s_setprio(NM_W_PRIO);
+#pragma unroll
+    for (int t = 0; t < NSTEPS; ++t) {
+        const int slot = (PH + t) % kRing;
+        uint4 xhc[MB], xlc[MB];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) { xhc[m] = xq[t % (kXD + 1)][0][m]; xlc[m] = xq[t % (kXD + 1)][1][m]; }
+        if (t + kXD < NSTEPS) {
+            const uint4* ph = xh + (t + kXD) * (2 * kChunkU4);
+#pragma unroll
+            for (int m = 0; m < MB; ++m) { xq[(t + kXD) % (kXD + 1)][0][m] = ph[m * 32]; xq[(t + kXD) % (kXD + 1)][1][m] = ph[kLoU4 + m * 32]; }
+        }
+        const v4u wh = R.s[slot].h, wl = R.s[slot].l;
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef NM_W_NO_MFMA     // experiment: everything but the matrix work (results are garbage)
+        if (I8) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m) { ac[m][0] += (int)(wh[0] + wl[0] + xlc[m].x + xhc[m].x); ah[m][0] += 1; }
+        } else {
+#pragma unroll
+            for (int m = 0; m < MB; ++m) ff[m][0] += (float)(wh[0] + wl[0] + xlc[m].x + xhc[m].x);
+        }
+        if (false)
+#endif
+        if (I8) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+                ac[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, wh), __builtin_bit_cast(i32x4, xlc[m]), ac[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+                ac[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, wl), __builtin_bit_cast(i32x4, xhc[m]), ac[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+                ah[m] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, wh), __builtin_bit_cast(i32x4, xhc[m]), ah[m], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int m = 0; m < MB; ++m) ff[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh), as_bf16x8(xlc[m]), ff[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MB; ++m) ff[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wl), as_bf16x8(xhc[m]), ff[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MB; ++m) ff[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh), as_bf16x8(xhc[m]), ff[m], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        w_step_load(R.s[slot], wsrc, voff, pos);       // the slot just consumed <- the step kRing ahead
+        pos += nm::kStepBytes;
+    }
+    __builtin_amdgcn_s_setprio(NM_E_PRIO);
+}
+template <int MB, int NSTEPS, int PH>
+__device__ __forceinline__ void w_run8(i32x16 (&ah)[MB], i32x16 (&ac)[MB], WRing& R, __amdgpu_buffer_rsrc_t wsrc, int voff, int& pos,
+                                       const uint4* xh) {
+    f32x16 none[MB];
+    w_run<true, MB, NSTEPS, PH>(ah, ac, none, R, wsrc, voff, pos, xh);
+}
+template <int MB, int NSTEPS, int PH>
+__device__ __forceinline__ void w_runbf(f32x16 (&f)[MB], WRing& R, __amdgpu_buffer_rsrc_t wsrc, int voff, int& pos, const uint4* xh) {
+    i32x16 none[MB];
+    w_run<false, MB, NSTEPS, PH>(none, none, f, R, wsrc, voff, pos, xh);
+}
+
+// t = hh * 256 + cross (exact: |t| * 256 is the full 32-bit product sum)
+template <int MB>
+__device__ __forceinline__ void combine8(i32x16 (&t)[MB], const i32x16 (&ah)[MB], const i32x16 (&ac)[MB]) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[mb][r] = (ah[mb][r] << 8) + ac[mb][r];
+}
+// f = t * sx256[row block] + bias'[feature], sx256 = 256 * sx * kappa_stage: the stage's output in its per-feature units.
+// (scalar v_fma_f32 on purpose: packed f32 VALU costs ~20 extra cycles per instruction beside MFMAs, MI355X_MICROARCH.md)
+template <int MB>
+__device__ __forceinline__ void dequantw(f32x16 (&f)[MB], const i32x16 (&t)[MB], const float (&sx256)[MB], const float* cst, int cblk, int g) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 bs = *reinterpret_cast<const float4*>(cst + nm::kBiasFloats + cblk + 8 * q + 4 * g);
+        const float bsv[4] = {bs.x, bs.y, bs.z, bs.w};
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[mb][4 * q + j] = fmaf((float)t[mb][4 * q + j], sx256[mb], bsv[j]);
+    }
+}
+
+// per-row partial maximum over this wave's NB blocks -> smax[part][row]; the two lane halves (features +4) meet through
+// v_permlane32_swap instead of an LDS round trip
+template <int NB, int MB, bool RELU>
+__device__ __forceinline__ void rowmaxw(const f32x16 (&f)[NB][MB], float* smax, int part, int row0, int g, int s) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    float m[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        m[mb] = 0.f;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m[mb] = fmaxf(m[mb], RELU ? f[b][mb][r] : fabsf(f[b][mb][r]));
+        const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m[mb]), __float_as_uint(m[mb]), false, false);
+        m[mb] = fmaxf(__uint_as_float(sw.x), __uint_as_float(sw.y));
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) smax[part * kTileM + row0 + 32 * mb + s] = m[mb];
+    }
+}
+
+// quantise the wave's NB blocks with the row scales (max over the 4 partials) and store the limbs.  All partial maxima
+// are read up front: in an E slot this wave has no partner to cover an LDS round trip per block.
+template <int NB, int MB, bool RELU>
+__device__ __forceinline__ void quant_storew(const f32x16 (&f)[NB][MB], uint4* lds, const float* smax, float* sscale, int blk0, int row0,
+                                             int g, int s, bool write_scale) {
+    float part[MB][4];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) part[mb][p] = smax[p * kTileM + row0 + 32 * mb + s];
+    float inv1[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const float M = fmaxf(fmaxf(part[mb][0], part[mb][1]), fmaxf(part[mb][2], part[mb][3]));
+        const float c = (float)nm::kFixedMax / 32767.f;        // cvt_pknorm maps [-1, 1] to rint(y * 32767)
+        const float inv = M > 0.f ? c * __builtin_amdgcn_rcpf(M) : 0.f;
+        inv1[mb] = inv;
+        if (write_scale && g == 0) sscale[row0 + 32 * mb + s] = M > 0.f ? M * (1.f / (float)nm::kFixedMax) : 1.f;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            i16x2 P[8], Y[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                i16x2 p = __builtin_amdgcn_cvt_pknorm_i16(f[b][mb][2 * i] * inv1[mb], f[b][mb][2 * i + 1] * inv1[mb]);
+                if (RELU) p = __builtin_elementwise_max(p, (i16x2){0, 0});
+                P[i] = p;
+                Y[i] = p + (i16x2){128, 128};
+            }
+            unsigned lo[4], hi[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                lo[k] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, P[2 * k + 1]), __builtin_bit_cast(unsigned, P[2 * k]), 0x06040200u);
+                hi[k] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, Y[2 * k + 1]), __builtin_bit_cast(unsigned, Y[2 * k]), 0x07050301u);
+            }
+            const int idx = H8_BASE + (2 * (blk0 + b) + g) * kChunkU4 + row0 + 32 * mb + s;
+            lds[idx] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            lds[idx + kLoU4] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+}
+
+// PROF buckets (a.prof[(block*8 + wave)*8 + b]): 0 fill, 1 k-loops (incl. their middle barrier), 2 end barrier of an M slot,
+// 3 epilogue part 1, 4 its middle barrier, 5 epilogue part 2, 6 end barrier of an E slot, 7 the rest
+template <bool PROF>
+__global__ __launch_bounds__(kThreads, 2) void nerf_mlp_i8w_kernel(const MlpArgs8 A) {
+    unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = PROF ? __builtin_readcyclecounter() : 0;
+#define NM_TICK(b)                                                   \
+    if (PROF) {                                                      \
+        const unsigned long long t_now = __builtin_readcyclecounter(); \
+        pr[b] += t_now - t_prev;                                     \
+        t_prev = t_now;                                              \
+    }
     __shared__ uint4 lds[LDS_U4];
     const MlpArgs& a = A.a;
     const int tid0 = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const int G = w >> 2, wq = w & 3;                          // wave group (tile half) and this wave's feature quarter
+    const int row0 = 64 * G;
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint4*>(A.wpack8), 0, (int)(nm::kWeightBytes8 + nm::kWeightPadBytes), 0x00020000);
+        const_cast<uint4*>(A.wstream8), 0, (int)nm::kWeightBytes8w, 0x00020000);
+    const int stream0 = (int)nm::wstream_off(wq);              // this wave's stream (wq is wave-uniform: scalar arithmetic)
     const int64_t ntiles = (a.n + kTileM - 1) / kTileM;
     float* smax = reinterpret_cast<float*>(lds + S8_MAX);
     float* sscale = reinterpret_cast<float*>(lds + S8_SCALE);
     float* cst = reinterpret_cast<float*>(lds + S8_CONST);
+    constexpr int kS = nm::kStepBytes;
+    constexpr int kKap = 2 * nm::kBiasFloats;                  // float offset of kappa[stage] in cst
 
     for (int i = tid0; i < nm::kPeChunks * kChunkU4; i += kThreads) lds[P_BASE + i] = make_uint4(0, 0, 0, 0);
     for (int i = tid0; i < kConst8Floats / 4; i += kThreads) lds[S8_CONST + i] = reinterpret_cast<const uint4*>(A.consts8)[i];
     __syncthreads();
 
-    auto wo = [](int st, int blk) {
-        const nm::StageShape8 sh = nm::stage_shape8(st);
-        return (int)nm::stage_w_off8(st) + blk * (sh.i8steps + sh.bfsteps) * nm::kStepBytes;
+    // thread index for the rarely executed paths, opaque so that their address arithmetic is not hoisted and spilled
+    auto cold_gt = [tid0]() {
+        int t = tid0;
+        asm volatile("" : "+v"(t));
+        return t & 255;
     };
-    const int so_s0 = wo(0, w), so_s8a = wo(8, 8), so_s9 = wo(9, w & 3), so_s10 = wo(10, 0);
-    WPre W;
-    w_prefetch<NM_PREC_BF16X3>(W, wsrc, (tid0 & 63) * 16, so_s0);
+
+    if (G == 1) { __syncthreads(); __syncthreads(); }          // group B runs one slot behind group A
 
 #pragma unroll 1
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t base = tile * kTileM;
         // Re-derive every lane-constant index from an opaque copy of the thread id once per tile: otherwise the compiler
-        // hoists dozens of per-lane addresses out of this loop and spills them to scratch, and scratch competes with the
-        // weight image for the XCD's L2.
+        // hoists dozens of per-lane addresses out of this loop and spills them, and scratch competes with the weights for L2
         int tid = tid0;
         asm volatile("" : "+v"(tid));
-        const int lane = tid & 63;
+        const int lane = tid & 63, gt = tid & 255;
         const int g = lane >> 5, s = lane & 31;
         const int voff = lane * 16;
-        const uint4* xH = lds + H8_BASE + g * kChunkU4 + s;
-        const uint4* xP = lds + P_BASE + g * kChunkU4 + s;
-        fill_pe_any(lds, false, a, base, tid);
-        __syncthreads();
-        if (a.stop_stage == -1) { dump_act(lds, true, 64, a, base, tid); __syncthreads(); continue; }
+        const uint4* xH = lds + H8_BASE + g * kChunkU4 + row0 + s;
+        const uint4* xP = lds + P_BASE + g * kChunkU4 + row0 + s;
 
-        // ---------------- stages 0..7
-        bool stopped = false;
-#pragma unroll 1
-        for (int st = 0; st <= 7; ++st) {
-            const int soff = wo(st, w), next = wo(st + 1, w);
-            const int cblk = nm::stage_b_off(st) + 32 * w;
-            f32x16 f[4];
-            if (st == 0) {
-                init_bias8<4>(f, cst, cblk, g);
-                k_run<4, NM_PREC_BF16X3>(f, W, wsrc, voff, soff, next, xP, 4);
-            } else {
-                i32x16 ah[4], ac[4];
-                zero8<4>(ah, ac);
-                float sxin[4];
+        // ---------------- slot F (shared with the previous tile's stage 10): position encoding of this group's rows;
+        // the weight stream restarts behind it (the fill's f64 sin/cos needs the registers, the barriers cover the latency)
+        NM_TICK(7)
+        fill_pe_any(lds, false, a, base, gt, 256, row0, 6);
+        WRing R;
+        int pos = stream0;
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) sxin[mb] = sscale[32 * mb + s];
-                k_run8<4>(ah, ac, W, wsrc, voff, soff, st == 5 ? soff + 8 * nm::kStepBytes : next, xH, 8);
-                dequant8<4>(f, ah, ac, sxin, cst, cblk, g);
-                if (st == 5) k_run<4, NM_PREC_BF16X3>(f, W, wsrc, voff, soff + 8 * nm::kStepBytes, next, xP, 4);
-            }
-            rowmax8<4, true>(f, smax, w, 0, g, s);
-            __syncthreads();                                      // all reads of H (and P) done; partial maxima visible
-            quant_store8<4, true>(f, lds, smax, sscale, 8, w, 0, g, s, w == 0);
-            if (st == 5) fill_pe_any(lds, true, a, base, tid);
+        for (int i = 0; i < kRing; ++i, pos += kS) w_step_load(R.s[i], wsrc, voff, pos);
+        NM_TICK(0)
+        __syncthreads();
+        __syncthreads();
+        NM_TICK(7)
+        if (a.stop_stage == -1) {                                  // (one empty slot: the dump must finish before the next fill)
+            dump_act(lds, true, 64, a, base, cold_gt(), 256, row0, 64);
             __syncthreads();
-            if (a.stop_stage == st) { dump_act8(lds, 256, 0, a, base, tid); stopped = true; break; }
+            __syncthreads();
+            continue;
         }
-        if (stopped) { __syncthreads(); w_prefetch<NM_PREC_BF16X3>(W, wsrc, voff, so_s0); continue; }
 
-        // ---------------- stage 8: feature (linear) + alpha block
+        // ---------------- stage 0: encodings only (split bf16)
+        bool stopped = false;
+        {
+            f32x16 f[2][2];
+            init_bias8<2>(f[0], cst, 64 * wq, g);
+            init_bias8<2>(f[1], cst, 64 * wq + 32, g);
+            w_runbf<2, 4, 0>(f[0], R, wsrc, voff, pos, xP);
+            __syncthreads();
+            w_runbf<2, 4, 4 % kRing>(f[1], R, wsrc, voff, pos, xP);
+            NM_TICK(1)
+            __syncthreads();
+            NM_TICK(2)
+            rowmaxw<2, 2, true>(f, smax, wq, row0, g, s);
+            NM_TICK(3)
+            __syncthreads();
+            NM_TICK(4)
+            quant_storew<2, 2, true>(f, lds, smax, sscale, 2 * wq, row0, g, s, wq == 0);
+            NM_TICK(5)
+            __syncthreads();
+            NM_TICK(6)
+            if (a.stop_stage == 0) { dump_act8(lds, 256, cst, a, base, cold_gt(), 256, row0, 64); stopped = true; }
+        }
+
+        // ---------------- stages 1..7
+#pragma unroll 1
+        for (int st = 1; st <= 7 && !stopped; ++st) {
+            const int cblk = 256 * st + 64 * wq;                    // = stage_b_off(st) + 64 wq
+            f32x16 f[2][2];
+            {
+                i32x16 t[2][2];
+                {
+                    i32x16 ah[2], ac[2];
+                    zero8<2>(ah, ac);
+                    w_run8<2, 8, 0>(ah, ac, R, wsrc, voff, pos, xH);
+                    combine8<2>(t[0], ah, ac);
+                }
+                __syncthreads();
+                {
+                    i32x16 ah[2], ac[2];
+                    zero8<2>(ah, ac);
+                    w_run8<2, 8, 0>(ah, ac, R, wsrc, voff, pos, xH);
+                    combine8<2>(t[1], ah, ac);
+                }
+                if (st != 5) {
+                    NM_TICK(1)
+                    __syncthreads();
+                    NM_TICK(2)
+                }
+                const float k256 = 256.f * cst[kKap + st];
+                const float sxin[2] = {sscale[row0 + s] * k256, sscale[row0 + 32 + s] * k256};
+                dequantw<2>(f[0], t[0], sxin, cst, cblk, g);
+                dequantw<2>(f[1], t[1], sxin, cst, cblk + 32, g);
+            }
+            if (st == 5) {                                          // skip layer: the position encoding on top, then this M slot ends
+                w_runbf<2, 4, 0>(f[0], R, wsrc, voff, pos, xP);
+                w_runbf<2, 4, 4 % kRing>(f[1], R, wsrc, voff, pos, xP);
+                NM_TICK(1)
+                __syncthreads();
+                NM_TICK(2)
+            }
+            rowmaxw<2, 2, true>(f, smax, wq, row0, g, s);
+            NM_TICK(3)
+            __syncthreads();
+            NM_TICK(4)
+            quant_storew<2, 2, true>(f, lds, smax, sscale, 2 * wq, row0, g, s, wq == 0);
+            NM_TICK(5)
+            if (st == 5) fill_pe_any(lds, true, a, base, cold_gt(), 256, row0, 6);     // (opaque index: not hoisted out of the stage loop)
+            NM_TICK(0)
+            __syncthreads();
+            NM_TICK(6)
+            if (a.stop_stage == st) { dump_act8(lds, 256, cst + 256 * st, a, base, cold_gt(), 256, row0, 64); stopped = true; }
+        }
+        if (stopped) continue;
+
+        // ---------------- stage 8: feature (linear) + alpha block (waves 0, 1 of the group: one 32-sample block each)
         float sigma = 0.f;
         {
-            f32x16 f[4];
+            f32x16 f[2][2];
             {
-                i32x16 ah[4], ac[4];
-                zero8<4>(ah, ac);
-                float sxin[4];
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) sxin[mb] = sscale[32 * mb + s];
-                k_run8<4>(ah, ac, W, wsrc, voff, wo(8, w), w < 4 ? so_s8a : so_s9, xH, 8);
-                dequant8<4>(f, ah, ac, sxin, cst, nm::stage_b_off(8) + 32 * w, g);
+                i32x16 t[2][2], ta[1];
+                {
+                    i32x16 ah[2], ac[2];
+                    zero8<2>(ah, ac);
+                    w_run8<2, 8, 0>(ah, ac, R, wsrc, voff, pos, xH);
+                    combine8<2>(t[0], ah, ac);
+                }
+                __syncthreads();
+                {
+                    i32x16 ah[2], ac[2];
+                    zero8<2>(ah, ac);
+                    w_run8<2, 8, 0>(ah, ac, R, wsrc, voff, pos, xH);
+                    combine8<2>(t[1], ah, ac);
+                }
+                if (wq < 2) {
+                    i32x16 ah[1], ac[1];
+                    zero8<1>(ah, ac);
+                    w_run8<1, 8, 0>(ah, ac, R, wsrc, voff, pos, xH + 32 * wq);
+                    combine8<1>(ta, ah, ac);
+                }
+                NM_TICK(1)
+                __syncthreads();
+                NM_TICK(2)
+                const float k256 = 256.f * cst[kKap + 8];
+                const float sxin[2] = {sscale[row0 + s] * k256, sscale[row0 + 32 + s] * k256};
+                dequantw<2>(f[0], t[0], sxin, cst, nm::stage_b_off(8) + 64 * wq, g);
+                dequantw<2>(f[1], t[1], sxin, cst, nm::stage_b_off(8) + 64 * wq + 32, g);
+                if (wq < 2) {
+                    f32x16 fa[1];
+                    const float sx1[1] = {sscale[row0 + 32 * wq + s] * k256};
+                    dequantw<1>(fa, ta, sx1, cst, nm::stage_b_off(8) + 32 * 8, g);
+                    sigma = fa[0][0] * cst[nm::stage_b_off(8) + 256];
+                }
             }
-            if (w < 4) {
-                i32x16 ah[1], ac[1];
-                f32x16 fa[1];
-                zero8<1>(ah, ac);
-                const float sx1[1] = {sscale[32 * w + s]};
-                k_run8<1>(ah, ac, W, wsrc, voff, so_s8a, so_s9, xH + 32 * w, 8);
-                dequant8<1>(fa, ah, ac, sx1, cst, nm::stage_b_off(8) + 32 * 8, g);
-                sigma = fa[0][0];
+            rowmaxw<2, 2, false>(f, smax, wq, row0, g, s);
+            NM_TICK(3)
+            __syncthreads();
+            NM_TICK(4)
+            quant_storew<2, 2, false>(f, lds, smax, sscale, 2 * wq, row0, g, s, wq == 0);
+            NM_TICK(5)
+            __syncthreads();
+            NM_TICK(6)
+            if (a.stop_stage == 8) {
+                dump_act8(lds, 256, cst + nm::stage_b_off(8), a, base, cold_gt(), 256, row0, 64);
+                continue;
             }
-            rowmax8<4, false>(f, smax, w, 0, g, s);
-            __syncthreads();
-            quant_store8<4, false>(f, lds, smax, sscale, 8, w, 0, g, s, w == 0);
-            __syncthreads();
-            if (a.stop_stage == 8) { dump_act8(lds, 256, 0, a, base, tid); __syncthreads(); w_prefetch<NM_PREC_BF16X3>(W, wsrc, voff, so_s0); continue; }
         }
 
-        // ---------------- stage 9: views layer = hidden part on i8, then the direction encoding on split bf16
+        // ---------------- stage 9: views layer (one 32-feature block per wave), hidden part on i8 + direction encoding on bf16
         {
-            const int nb = w & 3, row0 = 64 * (w >> 2);
-            f32x16 f[2];
+            f32x16 f[1][2];
             {
-                i32x16 ah[2], ac[2];
-                zero8<2>(ah, ac);
-                const float sxin[2] = {sscale[row0 + s], sscale[row0 + 32 + s]};
-                k_run8<2>(ah, ac, W, wsrc, voff, so_s9, so_s9 + 8 * nm::kStepBytes, xH + row0, 8);
-                dequant8<2>(f, ah, ac, sxin, cst, nm::stage_b_off(9) + 32 * nb, g);
+                i32x16 t[2];
+                {
+                    i32x16 ah[2], ac[2];
+                    zero8<2>(ah, ac);
+                    w_run8<2, 4, 0>(ah, ac, R, wsrc, voff, pos, xH);
+                    __syncthreads();
+                    w_run8<2, 4, 4 % kRing>(ah, ac, R, wsrc, voff, pos, xH + 4 * (2 * kChunkU4));
+                    combine8<2>(t, ah, ac);
+                }
+                const float k256 = 256.f * cst[kKap + 9];
+                const float sxin[2] = {sscale[row0 + s] * k256, sscale[row0 + 32 + s] * k256};
+                dequantw<2>(f[0], t, sxin, cst, nm::stage_b_off(9) + 32 * wq, g);
             }
-            k_run<2, NM_PREC_BF16X3>(f, W, wsrc, voff, so_s9 + 8 * nm::kStepBytes, w < 4 ? so_s10 : so_s0, xP + row0, 2);
-            rowmax8<2, true>(f, smax, nb, row0, g, s);
+            w_runbf<2, 4, 0>(f[0], R, wsrc, voff, pos, xP);          // 2 steps of direction encoding + 2 zero steps (chunks 4..7 of P
+            NM_TICK(1)                                              //  hold finite leftovers of the position encoding: 0 * x = 0)
             __syncthreads();
-            quant_store8<2, true>(f, lds, smax, sscale, 4, nb, row0, g, s, nb == 0);
+            NM_TICK(2)
+            rowmaxw<1, 2, true>(f, smax, wq, row0, g, s);
+            NM_TICK(3)
             __syncthreads();
-            if (a.stop_stage == 9) { dump_act8(lds, 128, 0, a, base, tid); __syncthreads(); w_prefetch<NM_PREC_BF16X3>(W, wsrc, voff, so_s0); continue; }
+            NM_TICK(4)
+            quant_storew<1, 2, true>(f, lds, smax, sscale, wq, row0, g, s, wq == 0);
+            NM_TICK(5)
+            __syncthreads();
+            NM_TICK(6)
+            if (a.stop_stage == 9) {
+                dump_act8(lds, 128, cst + nm::stage_b_off(9), a, base, cold_gt(), 256, row0, 64);
+                continue;
+            }
         }
 
-        // ---------------- stage 10: rgb
-        if (w < 4) {
-            i32x16 ah[1], ac[1];
+        // ---------------- stage 10: rgb (waves 0, 1: one 32-sample block each); shares the next tile's slot F
+        if (wq < 2) {
+            i32x16 ah[1], ac[1], t[1];
             f32x16 fr[1];
             zero8<1>(ah, ac);
-            const float sx1[1] = {sscale[32 * w + s]};
-            k_run8<1>(ah, ac, W, wsrc, voff, so_s10, so_s0, xH + 32 * w, 4);
-            dequant8<1>(fr, ah, ac, sx1, cst, nm::stage_b_off(10), g);
-            const int64_t i = base + 32 * w + s;
+            const float sx1[1] = {sscale[row0 + 32 * wq + s] * (256.f * cst[kKap + 10])};
+            w_run8<1, 4, 4 % kRing>(ah, ac, R, wsrc, voff, pos, xH + 32 * wq);
+            combine8<1>(t, ah, ac);
+            dequantw<1>(fr, t, sx1, cst, nm::stage_b_off(10), g);
+            int ls = s;
+            asm volatile("" : "+v"(ls));
+            const int64_t i = base + row0 + 32 * wq + ls;
             if (g == 0 && i < a.n)
-                reinterpret_cast<float4*>(a.out)[i] = make_float4(fr[0][0], fr[0][1], fr[0][2], sigma * a.sigma_scale);
+                reinterpret_cast<float4*>(a.out)[i] = make_float4(fr[0][0] * cst[nm::stage_b_off(10)], fr[0][1] * cst[nm::stage_b_off(10) + 1],
+                                                                  fr[0][2] * cst[nm::stage_b_off(10) + 2], sigma * a.sigma_scale);
         }
-        __syncthreads();
     }
+    if (G == 0) { __syncthreads(); __syncthreads(); }
+    NM_TICK(7)
+    if (PROF && (tid0 & 63) == 0) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) a.prof[((int64_t)blockIdx.x * 8 + w) * 8 + b] = pr[b];
+    }
+#undef NM_TICK
 }
 
 }  // namespace
@@ -895,13 +1140,14 @@ int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, con
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     const int grid = (int)(ntiles < cus ? ntiles : cus);          // one 160 KB workgroup per CU, grid-stride over tiles
-    if (precision == NM_PREC_I8X3 && !prof) {
+    if (precision == NM_PREC_I8X3) {
         MlpArgs8 a8;
         a8.a = a;
-        a8.wpack8 = reinterpret_cast<const uint4*>(L.wpack8);
-        a8.consts8 = L.scales8;                                   // scales, then biases (contiguous in the image)
-        hipLaunchKernelGGL(nerf_mlp_i8_kernel, dim3(grid), dim3(kThreads), 0, stream, a8);
-        return check_launch("nerf_mlp_i8_kernel");
+        a8.consts8 = L.consts8;
+        a8.wstream8 = reinterpret_cast<const uint4*>(L.wstream8);
+        if (prof) hipLaunchKernelGGL(nerf_mlp_i8w_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, a8);
+        else hipLaunchKernelGGL(nerf_mlp_i8w_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, a8);
+        return check_launch("nerf_mlp_i8w_kernel");
     }
     if (prof)
         hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_BF16X3, true>), dim3(grid), dim3(kThreads), 0, stream, a);

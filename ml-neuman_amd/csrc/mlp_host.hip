@@ -3,6 +3,7 @@
 // validation kernel (mlp_ref.hip).  Also the library-level basics (version, errors, device count).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -115,61 +116,96 @@ static void pack_image(const nm_mlp_desc* d, const float* const* P, uint8_t* img
     }
 }
 
-// ---- NM_PREC_I8X3 image: [fragments (i8 limb steps, then bf16 PE steps) | pad | weight scales | biases] ---------------
-// Per output feature n of a stage the hidden-part weights are quantised to int16 with scale sw[n] = max|w| / 32639 and
-// stored as balanced int8 limbs in MFMA A-operand order; PE-part weights keep the split-bf16 fragments of pack_image.
-static inline int64_t image8_bytes() { return kWeightBytes8 + kWeightPadBytes + 2 * (int64_t)kBiasFloats * 4; }
+// ---- NM_PREC_I8X3 image: [fragments (i8 limb steps, then bf16 PE steps) | pad | units | biases | kappa] ----------------
+// The hidden state of stage L is kept in per-feature units u_L[n] (true value = stored value * u_L[n]) chosen so that the
+// epilogue needs no per-feature multiplication: the hidden-part weights of output feature n are folded with the units of
+// their inputs, w_eff[n][f] = W[n][f] * u_in[f], quantised to int16 with step q[n] = max_f |w_eff| / 32639 and stored as
+// balanced int8 limbs in MFMA A-operand order; then sx * sum_f Wq[n][f] * X[f] = out[n] / q[n] directly.  To keep the units
+// O(1) through the layers every stage carries one scalar kappa_L = max_n q[n] (folded into the row scale in the kernel):
+// u_L[n] = q[n] / kappa_L.  Biases and the rows of the encoding (split-bf16) parts are divided by u_L[n] (ReLU commutes
+// with positive scaling).  Stage 0 has u = 1.  sigma (stage 8 row 256) and rgb (stage 10 rows 0..2) are multiplied by
+// their unit at the output.  `units` holds u_L[n] for every stage in the bias table's layout.
+constexpr int kKappaFloats = 16;
+static inline int64_t image8_bytes() { return kWeightBytes8 + kWeightPadBytes + (2 * (int64_t)kBiasFloats + kKappaFloats) * 4; }
 
-// hidden-part weight of output feature n for hidden input feature f (the i8 operand), and the number of hidden features
-static const float* hidden_row(const nm_mlp_desc* d, const float* const* P, int st, int n, int* stride, int* col0) {
+// hidden-part weights of output feature n (the i8 operand): row pointer, first hidden column
+static const float* hidden_row(const nm_mlp_desc* d, const float* const* P, int st, int n, int* col0) {
     const int kpe = 3 + 6 * d->pos_n_freqs;
+    *col0 = 0;
     switch (st) {
-        case 5: *stride = kpe + 256; *col0 = kpe; return P[P_PTS_W + 10] + (int64_t)n * (kpe + 256);
+        case 5: *col0 = kpe; return P[P_PTS_W + 10] + (int64_t)n * (kpe + 256);
         case 8:
-            *stride = 256; *col0 = 0;
             if (n < 256) return P[P_FEAT_W] + (int64_t)n * 256;
             return n == 256 ? P[P_ALPHA_W] : nullptr;
-        case 9: { const int K = 256 + 3 + 6 * d->dir_n_freqs; *stride = K; *col0 = 0; return P[P_VIEWS_W] + (int64_t)n * K; }
-        case 10: *stride = 128; *col0 = 0; return n < 3 ? P[P_RGB_W] + (int64_t)n * 128 : nullptr;
-        default: *stride = 256; *col0 = 0; return P[P_PTS_W + 2 * st] + (int64_t)n * 256;
+        case 9: return P[P_VIEWS_W] + (int64_t)n * (256 + 3 + 6 * d->dir_n_freqs);
+        case 10: return n < 3 ? P[P_RGB_W] + (int64_t)n * 128 : nullptr;
+        default: return P[P_PTS_W + 2 * st] + (int64_t)n * 256;
     }
 }
 
 static void pack_image8(const nm_mlp_desc* d, const float* const* P, uint8_t* img) {
     memset(img, 0, (size_t)image8_bytes());
-    float* scales = reinterpret_cast<float*>(img + kWeightBytes8 + kWeightPadBytes);
-    float* bias = scales + kBiasFloats;
+    float* units = reinterpret_cast<float*>(img + kWeightBytes8 + kWeightPadBytes);
+    float* bias = units + kBiasFloats;
+    float* kappa = bias + kBiasFloats;
+    std::vector<float> weff(256);
     for (int st = 0; st < kStages; ++st) {
         const StageShape8 sh = stage_shape8(st);
         const int nh = sh.i8steps * 32;                       // hidden input width of the i8 part
-        for (int nb = 0; nb < sh.nblk; ++nb) {
-            // ---- i8 limb steps
-            for (int r = 0; r < 32 && sh.i8steps; ++r) {
-                const int n = 32 * nb + r;
-                int stride = 0, col0 = 0;
-                const float* row = hidden_row(d, P, st, n, &stride, &col0);
+        const int nrows = sh.nblk * 32;
+        float* u = units + stage_b_off(st);
+        float* b = bias + stage_b_off(st);
+        if (st <= 7) memcpy(b, P[P_PTS_W + 2 * st + 1], 256 * 4);
+        else if (st == 8) { memcpy(b, P[P_FEAT_B], 256 * 4); b[256] = P[P_ALPHA_B][0]; }
+        else if (st == 9) memcpy(b, P[P_VIEWS_B], 128 * 4);
+        else memcpy(b, P[P_RGB_B], 3 * 4);
+        kappa[st] = 1.f;
+        for (int n = 0; n < nrows; ++n) u[n] = 1.f;
+        if (sh.i8steps) {
+            // units of this stage's hidden input: the previous stage's (stage 9 reads the 256 feature rows of stage 8)
+            const float* uin = units + stage_b_off(st - 1);
+            std::vector<float> q(nrows, 0.f);
+            float kap = 0.f;
+            for (int n = 0; n < nrows; ++n) {
+                int col0 = 0;
+                const float* row = hidden_row(d, P, st, n, &col0);
                 float mx = 0.f;
-                if (row) for (int f = 0; f < nh; ++f) mx = fmaxf(mx, fabsf(row[col0 + f]));
-                const float sw = mx > 0.f ? mx / (float)kFixedMax : 1.f;
-                scales[stage_b_off(st) + n] = sw;
-                for (int t = 0; t < sh.i8steps; ++t) {
-                    int8_t* hi = reinterpret_cast<int8_t*>(img + frag_off8(st, nb, t));
-                    int8_t* lo = hi + 1024;
-                    for (int g = 0; g < 2; ++g)
-                        for (int e = 0; e < 16; ++e) {
-                            const int f = slot_feature8(2 * t + g, e);
-                            const float w = row ? row[col0 + f] : 0.f;
-                            int q = (int)lrintf(w / sw);
-                            if (q > kFixedMax) q = kFixedMax;
-                            if (q < -kFixedMax) q = -kFixedMax;
-                            const int l = ((q + 128) & 255) - 128;
-                            const int h = (q - l) >> 8;
-                            hi[(g * 32 + r) * 16 + e] = (int8_t)h;
-                            lo[(g * 32 + r) * 16 + e] = (int8_t)l;
-                        }
-                }
+                if (row) for (int f = 0; f < nh; ++f) mx = fmaxf(mx, fabsf(row[col0 + f] * uin[f]));
+                q[n] = mx / (float)kFixedMax;
+                kap = fmaxf(kap, q[n]);
             }
-            // ---- split-bf16 PE steps: same values as the bf16 image's PE steps of this stage
+            if (!(kap > 0.f)) kap = 1.f;
+            kappa[st] = kap;
+            for (int n = 0; n < nrows; ++n) {
+                if (!(q[n] > 0.f)) q[n] = kap;                // all-zero (or padding) row: any unit works
+                u[n] = q[n] / kap;
+            }
+            for (int nb = 0; nb < sh.nblk; ++nb)
+                for (int r = 0; r < 32; ++r) {
+                    const int n = 32 * nb + r;
+                    int col0 = 0;
+                    const float* row = hidden_row(d, P, st, n, &col0);
+                    for (int t = 0; t < sh.i8steps; ++t) {
+                        int8_t* hi = reinterpret_cast<int8_t*>(img + frag_off8(st, nb, t));
+                        int8_t* lo = hi + 1024;
+                        for (int g = 0; g < 2; ++g)
+                            for (int e = 0; e < 16; ++e) {
+                                const int f = slot_feature8(2 * t + g, e);
+                                const float w = row ? row[col0 + f] * uin[f] : 0.f;
+                                int v = (int)lrintf(w / q[n]);
+                                if (v > kFixedMax) v = kFixedMax;
+                                if (v < -kFixedMax) v = -kFixedMax;
+                                const int l = ((v + 128) & 255) - 128;
+                                const int h = (v - l) >> 8;
+                                hi[(g * 32 + r) * 16 + e] = (int8_t)h;
+                                lo[(g * 32 + r) * 16 + e] = (int8_t)l;
+                            }
+                    }
+                }
+        }
+        for (int n = 0; n < nrows; ++n) b[n] /= u[n];
+        // ---- split-bf16 encoding steps: the bf16 image's values for these k-slots, in this stage's output units
+        for (int nb = 0; nb < sh.nblk; ++nb)
             for (int t = 0; t < sh.bfsteps; ++t) {
                 uint16_t* hi = reinterpret_cast<uint16_t*>(img + frag_off8(st, nb, sh.i8steps + t));
                 uint16_t* lo = hi + 64 * 8;
@@ -177,19 +213,35 @@ static void pack_image8(const nm_mlp_desc* d, const float* const* P, uint8_t* im
                 const int cc0 = st == 9 ? 32 : 0;
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
-                        const float wv = stage_weight(d, P, st, 32 * nb + (lane & 31), cc0 + 2 * t + (lane >> 5), j);
+                        const int n = 32 * nb + (lane & 31);
+                        const float wv = stage_weight(d, P, st, n, cc0 + 2 * t + (lane >> 5), j) / u[n];
                         const uint16_t h = f32_to_bf16(wv);
                         hi[lane * 8 + j] = h;
                         lo[lane * 8 + j] = f32_to_bf16(wv - bf16_to_f32(h));
                     }
             }
+    }
+}
+
+// per-wave stream image (mlp_layout.h wstream_*): the steps of the NM_PREC_I8X3 image in each wave's consumption order
+static void pack_stream8(const uint8_t* img8, uint8_t* out) {
+    memset(out, 0, (size_t)kWeightBytes8w);
+    for (int q = 0; q < 4; ++q) {
+        uint8_t* dst = out + wstream_off(q);
+        auto put = [&](int st, int nb, int t0, int n) {
+            for (int t = 0; t < n; ++t, dst += kStepBytes) memcpy(dst, img8 + frag_off8(st, nb, t0 + t), (size_t)kStepBytes);
+        };
+        put(0, 2 * q, 0, 4); put(0, 2 * q + 1, 0, 4);
+        for (int st = 1; st <= 8; ++st) {
+            put(st, 2 * q, 0, 8); put(st, 2 * q + 1, 0, 8);
+            if (st == 5) { put(5, 2 * q, 8, 4); put(5, 2 * q + 1, 8, 4); }
         }
-        float* b = bias + stage_b_off(st);
-        if (st <= 7) memcpy(b, P[P_PTS_W + 2 * st + 1], 256 * 4);
-        else if (st == 8) { memcpy(b, P[P_FEAT_B], 256 * 4); b[256] = P[P_ALPHA_B][0]; }
-        else if (st == 9) memcpy(b, P[P_VIEWS_B], 128 * 4);
-        else memcpy(b, P[P_RGB_B], 3 * 4);
-        if (!sh.i8steps) for (int n = 0; n < sh.nblk * 32; ++n) scales[stage_b_off(st) + n] = 1.f;
+        if (q < 2) put(8, 8, 0, 8);
+        put(9, q, 0, 8); put(9, q, 8, 2);
+        dst += 2 * kStepBytes;
+        if (q < 2) put(10, 0, 0, 4);
+        dst += kW8Pad * kStepBytes;
+        if (dst != out + wstream_off(q) + (int64_t)wstream_steps(q) * kStepBytes) abort();
     }
 }
 
@@ -198,7 +250,8 @@ static void pack_image8(const nm_mlp_desc* d, const float* const* P, uint8_t* im
 struct nm_mlp_s {
     nm_mlp_desc desc;
     uint8_t* d_image;      // weight fragments | pad | bias
-    uint8_t* d_image8;     // NM_PREC_I8X3: limb fragments | pad | weight scales | bias
+    float* d_consts8;      // NM_PREC_I8X3: units | biases | kappa (the tail of the nm_mlp_pack_i8 image)
+    uint8_t* d_stream8;    // NM_PREC_I8X3: the image's fragments as per-wave streams (nerf_mlp_i8w_kernel)
     float* d_petab;        // 192 floats
     float* d_ref;          // transposed f32 weights | natural biases (NM_PREC_FP32 path)
     int ref_off[12], ref_boff[12];
@@ -251,6 +304,8 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     nm::pack_image(desc, host_params, img.data());
     std::vector<uint8_t> img8((size_t)nm::image8_bytes());
     nm::pack_image8(desc, host_params, img8.data());
+    std::vector<uint8_t> str8((size_t)nm::kWeightBytes8w);
+    nm::pack_stream8(img8.data(), str8.data());
 
     // reference-layout image for the exact-f32 kernel
     const int kpe = 3 + 6 * desc->pos_n_freqs, kdpe = 3 + 6 * desc->dir_n_freqs;
@@ -287,10 +342,13 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     m->pos_octaves = octaves(tab, desc->pos_n_freqs);
     m->dir_octaves = octaves(tab + 96, desc->dir_n_freqs);
 
-    m->d_image = nullptr; m->d_image8 = nullptr; m->d_petab = nullptr; m->d_ref = nullptr;
+    m->d_image = nullptr; m->d_consts8 = nullptr; m->d_stream8 = nullptr; m->d_petab = nullptr; m->d_ref = nullptr;
     int rc = nm::check_hip(hipMalloc(&m->d_image, (size_t)bytes), "nm_mlp_create: hipMalloc(image)");
-    if (!rc) rc = nm::check_hip(hipMalloc(&m->d_image8, img8.size()), "nm_mlp_create: hipMalloc(image8)");
-    if (!rc) rc = nm::check_hip(hipMemcpy(m->d_image8, img8.data(), img8.size(), hipMemcpyHostToDevice), "nm_mlp_create: upload image8");
+    const size_t consts_off = (size_t)(nm::kWeightBytes8 + nm::kWeightPadBytes), consts_bytes = img8.size() - consts_off;
+    if (!rc) rc = nm::check_hip(hipMalloc(&m->d_consts8, consts_bytes), "nm_mlp_create: hipMalloc(consts8)");
+    if (!rc) rc = nm::check_hip(hipMemcpy(m->d_consts8, img8.data() + consts_off, consts_bytes, hipMemcpyHostToDevice), "nm_mlp_create: upload consts8");
+    if (!rc) rc = nm::check_hip(hipMalloc(&m->d_stream8, str8.size()), "nm_mlp_create: hipMalloc(stream8)");
+    if (!rc) rc = nm::check_hip(hipMemcpy(m->d_stream8, str8.data(), str8.size(), hipMemcpyHostToDevice), "nm_mlp_create: upload stream8");
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_petab, sizeof(tab)), "nm_mlp_create: hipMalloc(petab)");
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_ref, ref.size() * 4), "nm_mlp_create: hipMalloc(ref)");
     if (!rc) rc = nm::check_hip(hipMemcpy(m->d_image, img.data(), (size_t)bytes, hipMemcpyHostToDevice), "nm_mlp_create: upload image");
@@ -304,7 +362,8 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
 int nm_mlp_destroy(nm_mlp_t m) {
     if (!m) return NM_OK;
     if (m->d_image) (void)hipFree(m->d_image);
-    if (m->d_image8) (void)hipFree(m->d_image8);
+    if (m->d_consts8) (void)hipFree(m->d_consts8);
+    if (m->d_stream8) (void)hipFree(m->d_stream8);
     if (m->d_petab) (void)hipFree(m->d_petab);
     if (m->d_ref) (void)hipFree(m->d_ref);
     delete m;
@@ -333,9 +392,8 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
     L.petab = m->d_petab;
     L.pe_kind = m->desc.pe_kind; L.pos_nfreq = m->desc.pos_n_freqs; L.dir_nfreq = m->desc.dir_n_freqs;
     L.pos_octaves = m->pos_octaves; L.dir_octaves = m->dir_octaves;
-    L.wpack8 = m->d_image8;
-    L.scales8 = reinterpret_cast<const float*>(m->d_image8 + nm::kWeightBytes8 + nm::kWeightPadBytes);
-    L.bias8 = L.scales8 + nm::kBiasFloats;
+    L.wstream8 = m->d_stream8;
+    L.consts8 = m->d_consts8;
     return nm::launch_mlp_mfma(L, pts, dirs, origin, direction, z, n, S, in_mode, precision, stop_stage, sigma_scale, out, dbg,
                                prof, nm::as_stream(stream));
 }
@@ -356,10 +414,12 @@ int nm_mlp_forward_rays(nm_mlp_t mlp, const float* origin, const float* directio
                         nullptr, stream);
 }
 
-int nm_mlp_forward_profile(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, float* out, uint64_t* cycles,
-                           nm_stream_t stream) {
+int nm_mlp_forward_profile(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision, float* out,
+                           uint64_t* cycles, nm_stream_t stream) {
     NM_REQUIRE(n == 0 || (pts && dirs && out && cycles), "nm_mlp_forward_profile: null pointer");
-    return mlp_dispatch(mlp, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, NM_PREC_BF16X3, -2, 1.f, out, nullptr, stream, cycles);
+    NM_REQUIRE(precision == NM_PREC_BF16X3 || precision == NM_PREC_I8X3, "nm_mlp_forward_profile: precision %d has no profiling build",
+               precision);
+    return mlp_dispatch(mlp, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, precision, -2, 1.f, out, nullptr, stream, cycles);
 }
 
 int nm_mlp_forward_debug(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision, int stage,

@@ -8,7 +8,7 @@ struct MlpLaunch {
     const void* wpack; const float* bias; const float* petab;
     int pe_kind, pos_nfreq, dir_nfreq;
     int pos_octaves, dir_octaves;   // encodings whose bands are consecutive powers of two (octave recurrence allowed)
-    const void* wpack8; const float* scales8; const float* bias8;   // NM_PREC_I8X3 image (mlp_layout.h)
+    const void* wstream8; const float* consts8;   // NM_PREC_I8X3: per-wave fragment streams; units | biases | kappa (mlp_layout.h)
 };
 struct RefLaunch {
     const float* wt; const float* bias; int off[12]; int boff[12]; const float* petab;

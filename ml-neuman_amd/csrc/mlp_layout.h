@@ -119,4 +119,21 @@ NM_HD constexpr int slot_feature8(int c, int e) { return 32 * (c >> 1) + (e & 3)
 NM_HD constexpr int feature_chunk8(int n) { return 2 * (n >> 5) + ((n >> 2) & 1); }
 NM_HD constexpr int feature_elem8(int n) { return (n & 3) + 4 * ((n >> 3) & 3); }
 
+// ---- stream image of the wave-specialised i8x3 kernel (nerf_mlp_i8w_kernel) -----------------------------------------------
+// Wave q (0..3) of a group owns feature blocks 2q, 2q+1 of the 256-wide stages, block q of stage 9 and -- q < 2 only -- one
+// 32-sample half of the alpha block and of stage 10.  Its k-steps are stored in exactly the order it consumes them, so the
+// whole weight traffic of a wave is ONE linear stream (base + i * kStepBytes) that a deep register ring can prefetch with
+// no address logic.  Order (steps of kStepBytes, fragment format as above):
+//   stage 0: blk 2q bf 0..3, blk 2q+1 bf 0..3 | stages 1-4,6,7: blk 2q i8 0..7, blk 2q+1 i8 0..7
+//   stage 5: blk 2q i8, blk 2q+1 i8, blk 2q bf 0..3, blk 2q+1 bf 0..3 | stage 8: blk 2q i8, blk 2q+1 i8, [q < 2: alpha blk i8 0..7]
+//   stage 9: blk q i8 0..7, bf 0..1, two zero steps | [q < 2: stage 10 blk 0 i8 0..3] | kW8Pad zero steps (prefetch overrun)
+constexpr int kW8Pad = 8;
+NM_HD constexpr int wstream_steps(int q) { return 8 + 6 * 16 + 24 + 16 + (q < 2 ? 8 : 0) + 12 + (q < 2 ? 4 : 0) + kW8Pad; }
+NM_HD constexpr int64_t wstream_off(int q) {
+    int64_t o = 0;
+    for (int i = 0; i < q; ++i) o += (int64_t)wstream_steps(i) * kStepBytes;
+    return o;
+}
+constexpr int64_t kWeightBytes8w = wstream_off(4);
+
 }  // namespace nm

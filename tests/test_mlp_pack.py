@@ -163,8 +163,11 @@ def quant_rows(h):
 def emulate8(img, pts, dirs, spec):
     tail = w_off8(11) + 4 * 2048
     nb_f = b_off(11)
-    scales = np.frombuffer(img, dtype=np.float32, count=nb_f, offset=tail)
+    # hidden state of stage s is kept in per-feature units: true value = stored * units[s][n] (mlp_host.hip pack_image8);
+    # biases and the encoding rows are stored in those units, kappa[s] is the stage's scalar folded into the row scale
+    units = np.frombuffer(img, dtype=np.float32, count=nb_f, offset=tail)
     bias = np.frombuffer(img, dtype=np.float32, count=nb_f, offset=tail + 4 * nb_f)
+    kappa = np.frombuffer(img, dtype=np.float32, count=16, offset=tail + 8 * nb_f)
     x_pe = nerf_mlp.embed(pts, spec.mapping, *spec.pos)
     d_pe = nerf_mlp.embed(dirs, spec.mapping, *spec.dir)
     P = np.zeros((pts.shape[0], 64), np.float32)
@@ -184,7 +187,7 @@ def emulate8(img, pts, dirs, spec):
             wh = (wq - wl) >> 8
             t = 65536 * (xh @ wh.T) + 256 * (xh @ wl.T + xl @ wh.T)            # the xl*wl term is dropped, like the kernel
             assert np.abs(t // 256).max() < 2 ** 31                             # the kernel combines (hh << 8) + cross in int32
-            out += t * sx.astype(np.float64) * scales[b_off(s):b_off(s) + nrow].astype(np.float64)
+            out += t * (sx * kappa[s]).astype(np.float64)
         if pe is not None:
             out += pe.astype(np.float64) @ wpe.T.astype(np.float64)
         return (out + bias[b_off(s):b_off(s) + nrow])[:, :n_out].astype(np.float32)
@@ -193,9 +196,10 @@ def emulate8(img, pts, dirs, spec):
     for s in range(1, 8):
         h = np.maximum(run(s, h, P if s == 5 else None, 256), 0)
     o8 = run(8, h, None, 288)
-    feature, sigma = o8[:, :256], o8[:, 256]
+    feature, sigma = o8[:, :256], o8[:, 256] * units[b_off(8) + 256]
     v = np.maximum(run(9, feature, Pd, 128), 0)
-    o10 = run(10, v, None, 32)
+    o10 = run(10, v, None, 32) * units[b_off(10):b_off(10) + 32]
+    assert all(0 < units[b_off(s):b_off(s + 1)].min() and units[b_off(s):b_off(s + 1)].max() <= 1.0 for s in range(11))
     return np.concatenate([o10[:, :3], sigma[:, None]], 1)
 
 
@@ -205,7 +209,7 @@ def test_pack_i8_matches_oracle(nets, seed):
     lib = _lib.lib()
     desc = _lib.MlpDesc(8, 256, 4, _lib.NM_PE_ROTATE if spec.mapping == 'rotate' else _lib.NM_PE_POSENC, 10, 4)
     nbytes = lib.nm_mlp_pack_i8_bytes(ctypes.byref(desc))
-    assert nbytes == w_off8(11) + 4 * 2048 + 8 * b_off(11)
+    assert nbytes == w_off8(11) + 4 * 2048 + 8 * b_off(11) + 64
     host = [p.detach().contiguous() for p in joiner.nerf.ordered_params()]
     arr = (ctypes.c_void_p * 24)(*[t.data_ptr() for t in host])
     img = ctypes.create_string_buffer(nbytes)

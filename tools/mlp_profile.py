@@ -29,7 +29,7 @@ for prec in ("bf16x3", "bf16"):
 cus = torch.cuda.get_device_properties(0).multi_processor_count
 grid = min(cus, (n + 127) // 128)
 cyc = torch.zeros((grid * 8, 8), device='cuda', dtype=torch.int64)
-_lib.check(_lib.lib().nm_mlp_forward_profile(j.handle(), _lib.dev_ptr(pts), _lib.dev_ptr(dirs), n, _lib.dev_ptr(out),
+_lib.check(_lib.lib().nm_mlp_forward_profile(j.handle(), _lib.dev_ptr(pts), _lib.dev_ptr(dirs), n, _lib.NM_PREC_BF16X3, _lib.dev_ptr(out),
                                              ctypes.c_void_p(cyc.data_ptr()), _lib.stream_ptr()), "profile")
 torch.cuda.synchronize()
 c = cyc.cpu().double().reshape(grid, 8, 8)[:, :, :6]
