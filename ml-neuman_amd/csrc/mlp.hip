@@ -149,11 +149,56 @@ __device__ __forceinline__ void w_prefetch(WPre& W, __amdgpu_buffer_rsrc_t wsrc,
 #ifndef NM_PRIO_MODE
 #define NM_PRIO_MODE 0      // experiment knob (tools/mlp_profile.py): MFMA-pipe arbitration between the two waves of a SIMD
 #endif
+#ifndef NM_X_PIPE
+#define NM_X_PIPE 0         // 1: also software-pipeline the activation fragments of the bf16x3 k-loops (measured: -2.5 %)
+#endif
+template <int MB, int PREC>
+__device__ __forceinline__ void x_load(uint4 (&h)[MB], uint4 (&l)[MB], const uint4* ph) {
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        h[mb] = ph[mb * 32];
+        if (PREC == NM_PREC_BF16X3) l[mb] = ph[kLoU4 + mb * 32];
+    }
+}
+template <int MB, int PREC>
+__device__ __forceinline__ void mfma_step(f32x16 (&acc)[MB], bf16x8 wh, bf16x8 wl, const uint4 (&xh)[MB], const uint4 (&xl)[MB]) {
+    if (PREC == NM_PREC_BF16X3) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, as_bf16x8(xl[mb]), acc[mb], 0, 0, 0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, as_bf16x8(xh[mb]), acc[mb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, as_bf16x8(xh[mb]), acc[mb], 0, 0, 0);
+}
 template <int MB, int PREC>
 __device__ __forceinline__ void k_run(f32x16 (&acc)[MB], WPre& W, __amdgpu_buffer_rsrc_t wsrc, int voff, int soff, int next_soff,
                                       const uint4* xh, int nsteps, bool prio_phase = false) {
-    // One activation register set per k-step: with two waves per SIMD the partner's MFMAs cover the ds_read latency, and
-    // a second (software-pipelined) set measured 0 % while pushing the kernel into scratch spills.
+    // Activation fragments of step t + 1 requested before the MFMAs of step t (two register sets): pays for the single-MFMA
+    // NM_PREC_BF16 steps (+6 %), where an LDS round trip per step is exposed; with three MFMAs per step (bf16x3) the partner
+    // wave of the SIMD already covers it and the extra registers cost more than they buy (-2.5 %, same GPU, A/B).
+    if (NM_X_PIPE || PREC == NM_PREC_BF16) {
+    uint4 xah[MB], xal[MB];
+    x_load<MB, PREC>(xah, xal, xh);
+#pragma unroll 1
+    for (int t = 0; t < nsteps; t += 2) {
+        const int pf = (t + 2 < nsteps) ? soff + (t + 2) * nm::kStepBytes : next_soff;   // wave-uniform
+        WPre N;
+        w_prefetch<PREC>(N, wsrc, voff, pf);
+        uint4 xbh[MB], xbl[MB];
+        x_load<MB, PREC>(xbh, xbl, xh + (t + 1) * (2 * kChunkU4));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step<MB, PREC>(acc, W.h[0], W.l[0], xah, xal);
+        __builtin_amdgcn_sched_barrier(0);
+        const int tn = t + 2 < nsteps ? t + 2 : t + 1;                                   // (last iteration: a harmless re-read)
+        x_load<MB, PREC>(xah, xal, xh + tn * (2 * kChunkU4));
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_step<MB, PREC>(acc, W.h[1], W.l[1], xbh, xbl);
+        __builtin_amdgcn_sched_barrier(0);
+        W = N;
+    }
+    return;
+    }
 #pragma unroll 1
     for (int t = 0; t < nsteps; t += 2) {
         const int pf = (t + 2 < nsteps) ? soff + (t + 2) * nm::kStepBytes : next_soff;   // wave-uniform
@@ -161,50 +206,14 @@ __device__ __forceinline__ void k_run(f32x16 (&acc)[MB], WPre& W, __amdgpu_buffe
         w_prefetch<PREC>(N, wsrc, voff, pf);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const uint4* ph = xh + (t + u) * (2 * kChunkU4);
-            bf16x8 bh[MB], bl[MB];
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                bh[mb] = as_bf16x8(ph[mb * 32]);
-                if (PREC == NM_PREC_BF16X3) bl[mb] = as_bf16x8(ph[kLoU4 + mb * 32]);
-            }
+            uint4 bh[MB], bl[MB];
+            x_load<MB, PREC>(bh, bl, xh + (t + u) * (2 * kChunkU4));
 #if NM_PRIO_MODE == 2
             __builtin_amdgcn_s_setprio(u == 0 ? 1 : 0);
 #elif NM_PRIO_MODE == 3
             __builtin_amdgcn_s_setprio((u == 0) != prio_phase ? 1 : 0);
 #endif
-#ifdef NM_I8_PROBE   // throughput experiment only (results are garbage): i8 MFMA covers 32 k per instruction -> half the steps
-            if (u == 1) continue;
-            typedef __attribute__((ext_vector_type(4))) int i32x4;
-            typedef __attribute__((ext_vector_type(16))) int i32x16;
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                i32x16 c = __builtin_bit_cast(i32x16, acc[mb]);
-                c = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, W.h[u]), __builtin_bit_cast(i32x4, bl[mb]), c, 0, 0, 0);
-                acc[mb] = __builtin_bit_cast(f32x16, c);
-            }
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                i32x16 c = __builtin_bit_cast(i32x16, acc[mb]);
-                c = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, W.l[u]), __builtin_bit_cast(i32x4, bh[mb]), c, 0, 0, 0);
-                acc[mb] = __builtin_bit_cast(f32x16, c);
-            }
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                i32x16 c = __builtin_bit_cast(i32x16, acc[mb]);
-                c = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, W.h[u]), __builtin_bit_cast(i32x4, bh[mb]), c, 0, 0, 0);
-                acc[mb] = __builtin_bit_cast(f32x16, c);
-            }
-#else
-            if (PREC == NM_PREC_BF16X3) {
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.h[u], bl[mb], acc[mb], 0, 0, 0);
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.l[u], bh[mb], acc[mb], 0, 0, 0);
-            }
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W.h[u], bh[mb], acc[mb], 0, 0, 0);
-#endif
+            mfma_step<MB, PREC>(acc, W.h[u], W.l[u], bh, bl);
         }
         W = N;
     }
@@ -1010,6 +1019,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_i8w_kernel(const MlpArgs
             f32x16 f[2][2];
             {
                 i32x16 t[2][2], ta[1];
+                zero8<1>(ta, ta);                                  // (defined on every path: an undefined value would be carried -- and spilled -- around the tile loop)
                 {
                     i32x16 ah[2], ac[2];
                     zero8<2>(ah, ac);
