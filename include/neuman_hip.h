@@ -39,7 +39,8 @@ typedef void* nm_stream_t;
 #define NM_PREC_BF16X3 1 /* split-bf16 (hi+lo) x3 MFMA, f32 accumulate: the parity-grade default     */
 #define NM_PREC_BF16 2   /* single bf16 MFMA, f32 accumulate: fast, NOT parity grade     */
 #define NM_PREC_I8X3 3   /* hidden layers as per-row-scaled int16 = two int8 limbs on the i8 MFMA (hh + hl + lh, exact
-                            int32 accumulate), encodings on split bf16: parity grade with a smaller margin */
+                            int32 accumulate), encodings on split bf16: the labelled FAST mode -- composited colours within
+                            2e-5 of f32 on identical samples, 4x the bf16x3 error, NOT the parity path */
 
 /* positional-encoding kinds (reference models/vanilla.py:44-79) */
 #define NM_PE_POSENC 0 /* [x, sin(f0 x), cos(f0 x), sin(f1 x), ...]   vanilla.py:60-79,92 */
@@ -129,7 +130,8 @@ typedef struct nm_mlp_desc {
 int64_t nm_mlp_pack_bytes(const nm_mlp_desc* desc);
 /* host-only: write the packed weight image (what nm_mlp_create uploads) into host_out. */
 int nm_mlp_pack(const nm_mlp_desc* desc, const float* const* host_params, void* host_out);
-/* host-only: the NM_PREC_I8X3 image (limb fragments | pad | per-feature weight scales | biases). */
+/* host-only: the NM_PREC_I8X3 image by stage and block (limb fragments | pad | per-feature units | biases in those
+ * units | one scalar per stage); nm_mlp_create uploads its fragments re-ordered into per-wave streams. */
 int64_t nm_mlp_pack_i8_bytes(const nm_mlp_desc* desc);
 int nm_mlp_pack_i8(const nm_mlp_desc* desc, const float* const* host_params, void* host_out);
 int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, const float* host_pos_tab,
