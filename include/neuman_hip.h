@@ -200,6 +200,34 @@ int nm_gather_rows(const float* src, const int32_t* idx, const int32_t* n_dev, i
 int nm_scatter_rows(const float* src, const int32_t* idx, const int32_t* n_dev, int64_t n_max, int width,
                     float* dst, nm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * a1  shot_rays / shot_all_rays on the device -- reference utils/ray_utils.py:23-38 via
+ *     geometry/pcd_projector.py:85-120 (pcd_2d_to_pcd_3d) and :209-227 (integer pixel grid, no +0.5)
+ *   pixel (x, y) at depth 1 -> K^-1 [x,y,1] -> camera-to-world (4x4) -> / w, all in f64, then
+ *     mode 0 (shot_all_rays, :32-38): dir = (p - centre) / |p - centre| in f64, cast to f32
+ *     mode 1 (shot_rays, :23-29):     p is cast to f32 first (:25), then the same (numpy promotes to an f64 centre)
+ *     mode 2 (shot_rays, f32 pose):   as the reference's own CameraPose (f32 matrix from f32 quaternions,
+ *                                     cameras/camera_pose.py:29-45) makes numpy do it: subtraction, norm and division in f32
+ *   xy: device int32 [n,2] pixel coordinates, or NULL = the full grid of `width` columns in
+ *   row-major order (render_utils.py:185).  inv_intrinsic (3x3) and cam2world (4x4) are HOST f64
+ *   row-major matrices (25 by-value parameters, like the reference's numpy arrays); the centre is
+ *   cam2world[:3,3] (cameras/camera_pose.py:94-95).  origin [n,3] (centre repeated), direction [n,3].
+ * ------------------------------------------------------------------------------------------- */
+int nm_shot_rays(const int32_t* xy, int64_t n, int width, int mode, const double* inv_intrinsic,
+                 const double* cam2world, float* origin, float* direction, nm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * frame egress -- reference render_test_views.py:83-88, render_360.py:77-81 (imageio.imsave of the
+ *   renderer's f32 [H,W,3] frame) and render_test_views.py:35 (PSNR of the uint8 frames).
+ *   imageio is a conda dependency (environment.yml:22, unpinned), not vendored: nm_frame_to_uint8
+ *   restates its published float -> uint8 rule (v2 image_as_uint: clip to [0,1], x*255 + 0.499999999,
+ *   truncate).  nm_ssd_u8 returns the exact integer sum of squared differences of two uint8 arrays;
+ *   PSNR = 10 log10(255^2 * n / ssd) is skimage.metrics.peak_signal_noise_ratio (environment.yml:30)
+ *   for uint8 inputs.  ssd: device uint64[1].
+ * ------------------------------------------------------------------------------------------- */
+int nm_frame_to_uint8(const float* src, int64_t n, uint8_t* dst, nm_stream_t stream);
+int nm_ssd_u8(const uint8_t* a, const uint8_t* b, int64_t n, uint64_t* ssd, nm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,10 @@ SIGNATURES = {
     "nm_merge_sorted": (i32, [c_f32p, c_f32p, i32, c_f32p, c_f32p, i32, i64, c_f32p, c_f32p, c_stream]),
     "nm_gather_rows": (i32, [c_f32p, c_i32p, c_i32p, i64, i32, c_f32p, c_stream]),
     "nm_scatter_rows": (i32, [c_f32p, c_i32p, c_i32p, i64, i32, c_f32p, c_stream]),
+    "nm_shot_rays": (i32, [c_i32p, i64, i32, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_f32p, c_f32p,
+                           c_stream]),
+    "nm_frame_to_uint8": (i32, [c_f32p, i64, ctypes.c_void_p, c_stream]),
+    "nm_ssd_u8": (i32, [ctypes.c_void_p, ctypes.c_void_p, i64, ctypes.c_void_p, c_stream]),
 }
 
 _lib = None

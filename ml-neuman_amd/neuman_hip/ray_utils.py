@@ -1,9 +1,12 @@
 """HIP-backed mirror of the reference's utils/ray_utils.py (same function names and argument meaning).
 
-Ray generation (a1) stays on the host in float64 exactly like the reference; everything per-sample runs in
-libneuman_hip.so.  Functions that the reference defines on torch tensors take CUDA tensors here and raise
+Ray generation (a1) exists twice: the reference-named host functions in float64 numpy exactly like the reference, and
+`shot_all_rays_dev` / `shot_rays_dev`, the same chain per ray on the device (what the renderers use); everything per-sample
+runs in libneuman_hip.so.  Functions that the reference defines on torch tensors take CUDA tensors here and raise
 on CPU tensors -- there is no host fallback.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -49,6 +52,40 @@ def shot_all_rays(cap):
     d = _unproject(xy, cap.intrinsic_matrix, cap.cam_pose.camera_to_world) - centre
     d = d / np.linalg.norm(d, axis=1, keepdims=True)
     return np.repeat(centre[None], d.shape[0], axis=0), d
+
+
+def _cam_matrices(cap):
+    kinv = np.ascontiguousarray(np.linalg.inv(np.asarray(cap.intrinsic_matrix, dtype=np.float64)))
+    c2w = np.ascontiguousarray(np.asarray(cap.cam_pose.camera_to_world, dtype=np.float64))
+    as_p = lambda m: m.ctypes.data_as(ctypes.POINTER(ctypes.c_double))           # noqa: E731
+    return kinv, c2w, as_p
+
+
+def shot_all_rays_dev(cap, device):
+    """shot_all_rays (reference ray_utils.py:32-38) on the device: f32 origins / directions [H*W,3], row-major pixels.
+    The f64 chain of the reference runs per ray in nm_shot_rays; nothing but 25 doubles crosses the boundary."""
+    _lib.require_gpu()
+    h, w = cap.size
+    kinv, c2w, as_p = _cam_matrices(cap)
+    o = torch.empty((h * w, 3), device=device, dtype=torch.float32)
+    d = torch.empty_like(o)
+    _lib.check(_lib.lib().nm_shot_rays(None, h * w, w, 0, as_p(kinv), as_p(c2w), _lib.dev_ptr(o), _lib.dev_ptr(d), _lib.stream_ptr()),
+               "nm_shot_rays")
+    return o, d
+
+
+def shot_rays_dev(cap, xys):
+    """shot_rays (reference ray_utils.py:23-29) for a device int32 [N,2] list of (x, y) pixels."""
+    _lib.require_gpu()
+    xys = xys.to(torch.int32).contiguous()
+    kinv, c2w, as_p = _cam_matrices(cap)
+    o = torch.empty((xys.shape[0], 3), device=xys.device, dtype=torch.float32)
+    d = torch.empty_like(o)
+    # numpy's result type follows the pose matrix: the reference's CameraPose yields float32 (f32 subtraction and norm)
+    mode = 2 if np.asarray(cap.cam_pose.camera_to_world).dtype == np.float32 else 1
+    _lib.check(_lib.lib().nm_shot_rays(_lib.dev_ptr(xys, torch.int32), xys.shape[0], cap.size[1], mode, as_p(kinv), as_p(c2w),
+                                       _lib.dev_ptr(o), _lib.dev_ptr(d), _lib.stream_ptr()), "nm_shot_rays")
+    return o, d
 
 
 def to_homogeneous(pts):

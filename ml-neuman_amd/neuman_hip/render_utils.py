@@ -7,11 +7,14 @@ its four frame renderers.  What differs is the execution plan:
   rendered in launches of up to `MAX_RAYS_PER_LAUNCH` rays (rays are independent, so chunking never changes a
   pixel) and nothing returns to the host before the frame is assembled;
 * pts/dirs are never materialised for camera-ray passes: the MLP kernel builds `o + d*z` itself;
-* boolean-mask indexing is a ballot/prefix-sum compaction + row gather/scatter on the device.
+* boolean-mask indexing is a ballot/prefix-sum compaction + row gather/scatter on the device;
+* rays are generated on the device too (the reference's f64 chain per ray, `nm_shot_rays`): 25 doubles cross the
+  boundary per frame instead of 15 MB of rays.
 
 The `*_rays` functions work on device tensors (what bench.py and the multi-GPU path call); the reference
 named functions wrap them with ray generation and the final download.
 """
+import ctypes
 import os
 
 import numpy as np
@@ -205,11 +208,55 @@ def _device_of(net):
     return dev
 
 
+HOST_RAYS = os.environ.get("NEUMAN_HOST_RAYS", "0") == "1"     # A/B switch: generate rays with the host (numpy) mirror and upload them
+
+
 def _pixel_rays(cap, device):
-    coords = np.argwhere(np.ones(cap.shape))[:, ::-1]                                    # (x, y), row-major, :185
-    o, d = ray_utils.shot_rays(cap, coords)
-    return (torch.from_numpy(o).to(device, torch.float32).contiguous(),
-            torch.from_numpy(d).to(device, torch.float32).contiguous())
+    """shot_rays over every pixel, (x, y) row-major (render_utils.py:185-186)."""
+    h, w = cap.shape
+    if HOST_RAYS:
+        coords = np.argwhere(np.ones(cap.shape))[:, ::-1]
+        o, d = ray_utils.shot_rays(cap, coords)
+        return (torch.from_numpy(o).to(device, torch.float32).contiguous(),
+                torch.from_numpy(d).to(device, torch.float32).contiguous())
+    i = torch.arange(h * w, device=device, dtype=torch.int32)
+    return ray_utils.shot_rays_dev(cap, torch.stack([i % w, i // w], dim=1))
+
+
+def _all_rays(cap, device):
+    """shot_all_rays (render_utils.py:125-128)."""
+    if HOST_RAYS:
+        o, d = ray_utils.shot_all_rays(cap)
+        return (torch.from_numpy(o).to(device, torch.float32).contiguous(),
+                torch.from_numpy(d).to(device, torch.float32).contiguous())
+    return ray_utils.shot_all_rays_dev(cap, device)
+
+
+# ------------------------------------------------------------------------------------------------
+# frame egress (reference render_test_views.py:83-92, 27-41): uint8 pixels and their PSNR, on the device
+# ------------------------------------------------------------------------------------------------
+def frame_to_uint8(frame):
+    """What `imageio.imsave(path, out)` makes of a renderer's float frame before encoding: clip to [0, 1],
+    `uint8(x * 255 + 0.499999999)`.  CUDA f32 tensor of any shape -> uint8 tensor of the same shape."""
+    _lib.require_gpu()
+    src = frame.to(torch.float32).contiguous()
+    dst = torch.empty(src.shape, device=src.device, dtype=torch.uint8)
+    _lib.check(_lib.lib().nm_frame_to_uint8(_lib.dev_ptr(src), src.numel(), ctypes.c_void_p(dst.data_ptr()), _lib.stream_ptr()),
+               "nm_frame_to_uint8")
+    return dst
+
+
+def psnr_uint8(gt, pred):
+    """skimage.metrics.peak_signal_noise_ratio(gt, pred) for uint8 frames (render_test_views.py:35): 10 log10(255^2 / mse)."""
+    _lib.require_gpu()
+    if gt.dtype != torch.uint8 or pred.dtype != torch.uint8 or gt.shape != pred.shape or not (gt.is_cuda and pred.is_cuda):
+        raise _lib.NeumanHipError("psnr_uint8 takes two CUDA uint8 tensors of the same shape")
+    gt, pred = gt.contiguous(), pred.contiguous()
+    ssd = torch.empty(1, device=gt.device, dtype=torch.int64)
+    _lib.check(_lib.lib().nm_ssd_u8(ctypes.c_void_p(gt.data_ptr()), ctypes.c_void_p(pred.data_ptr()), gt.numel(),
+                                    ctypes.c_void_p(ssd.data_ptr()), _lib.stream_ptr()), "nm_ssd_u8")
+    mse = float(ssd.item()) / gt.numel()
+    return float('inf') if mse == 0 else 10.0 * float(np.log10(255.0 ** 2 / mse))
 
 
 def render_vanilla(coarse_net, cap, fine_net=None, rays_per_batch=32768, samples_per_ray=64, importance_samples_per_ray=128,
@@ -219,9 +266,7 @@ def render_vanilla(coarse_net, cap, fine_net=None, rays_per_batch=32768, samples
         raise NotImplementedError("ablate_nerft (time-conditioned ablation net) is outside the HIP path")
     device = _device_of(coarse_net)
     with torch.no_grad():
-        o, d = ray_utils.shot_all_rays(cap)
-        o = torch.from_numpy(o).to(device, torch.float32).contiguous()
-        d = torch.from_numpy(d).to(device, torch.float32).contiguous()
+        o, d = _all_rays(cap, device)
         rgb, depth = render_vanilla_rays(coarse_net, fine_net, o, d, cap.near[near_far_source], cap.far[near_far_source],
                                          samples_per_ray, importance_samples_per_ray, white_bkg)
         rgb = rgb.reshape(*cap.shape, -1).cpu().numpy()
