@@ -10,10 +10,17 @@ evaluates the 8x256 MLP 128 + 256 = 384 times per ray, render_utils.py:108-161),
 sharded across the ranks (no data-path collective) and assembled on rank 0 by one RCCL gather per frame, which is
 inside the timed region; total work is fixed, so `scaling` is "strong".
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (nerf_mlp_kernel, bf16x3): algorithmic FLOPs
-(1,186,816 per MLP evaluation) / its launch time measured with HIP events on the launch stream, against the
-2.5 PFLOP/s dense bf16 MFMA peak.  `cpu_baseline` times the CPU restatement of the reference (the numpy port under
-oracle/, kind "port") on a bounded prefix of the same frame, on this box's host cores (N = 1 only).
+Precision (`--precision`, default "mixed" = the package default): the coarse pass, whose compositing weights place the
+importance samples, runs split-bf16 x3; the fine pass, whose output is composited into the frame, runs the 16-bit
+fixed-point limbs on the i8 MFMA.  Sample positions are bit-identical to the all-bf16x3 path and every pixel stays
+within 1e-4 of the oracle on identical samples (tests/test_hip_render.py, measured 1.6e-5); the bench line also
+reports the all-bf16x3 and all-i8x3 frame rates measured in the same run (`other_precisions`).
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel -- the fine launch (163.84 M of the frame's
+245.76 M evaluations): algorithmic FLOPs (1,186,816 per MLP evaluation) / its launch time measured with HIP
+events on the launch stream, against the 2.5 PFLOP/s dense bf16 MFMA peak; `roofline_coarse` is the same for the
+coarse launch.  `cpu_baseline` times the CPU restatement of the reference (the numpy port under oracle/, kind "port") on
+a bounded prefix of the same frame, on this box's host cores (N = 1 only).
 """
 import argparse
 import json
@@ -25,7 +32,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ml-neuman_amd"))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -34,6 +40,14 @@ PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA, MI355X_MICROARCH.md
 W, H, S, NI = 800, 800, 128, 128
 EVALS_PER_RAY = S + (S + NI)
 TILE = 8192
+DTYPES = {
+    "mixed": "coarse (sampling) pass: split-bf16 hi+lo MFMA x3, f32 accumulate; fine (shading) pass: per-row-scaled int16 as two "
+             "int8 limbs on the i8 MFMA x3, exact int32 accumulate, encodings on split bf16",
+    "bf16x3": "bf16x3 (split-bf16 hi+lo MFMA x3, f32 accumulate)",
+    "i8x3": "i8x3 (per-row-scaled int16 as 2 int8 limbs, i8 MFMA x3, exact int32 accumulate; encodings on bf16x3)",
+    "bf16": "bf16 (f32 accumulate)", "fp32": "f32"}
+KERNEL_OF = {"bf16x3": "nerf_mlp_kernel<1, false>", "i8x3": "nerf_mlp_i8w_kernel<false>", "bf16": "nerf_mlp_kernel<2, false>",
+             "fp32": "nerf_mlp_ref_kernel"}
 
 
 def cpu_baseline(max_rays=4096):
@@ -69,18 +83,19 @@ def cpu_baseline(max_rays=4096):
                       f"with {best[0]} BLAS threads (best of a 16..{ncpu} probe) on a {ncpu}-thread host"}
 
 
-def pmc_traffic_per_launch():
-    """HBM bytes per MLP launch from the committed PMC passes of this same command (FETCH_SIZE and WRITE_SIZE are
-    collected in separate rocprofv3 runs, so they cannot be measured inside this process): mean over the coarse and the
-    fine launch of FETCH_SIZE*2 (gfx950 reports half the bytes of wide streaming reads, MI355X_MICROARCH.md) + WRITE_SIZE,
-    KiB -> bytes.  None when the summary is absent."""
+def pmc_traffic_per_launch(kernel, launch):
+    """HBM bytes of one MLP launch from the committed PMC passes of this same command (FETCH_SIZE and WRITE_SIZE are
+    collected in separate rocprofv3 runs, so they cannot be measured inside this process): FETCH_SIZE*2 (gfx950 reports
+    half the bytes of wide streaming reads, MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes, of dispatch `launch` of
+    `kernel` in a --steps 1 --warmup 0 --timed-only run (exactly one coarse and one fine launch).  None when absent."""
     path = os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.json")
     try:
         with open(path) as f:
             s = json.load(f)
-        fetch = [x["FETCH_SIZE"] for x in s["fetch"] if "nerf_mlp_kernel" in x["kernel"]][:2]
-        write = [x["WRITE_SIZE"] for x in s["write"] if "nerf_mlp_kernel" in x["kernel"]][:2]
-        return (2 * sum(fetch) / len(fetch) + sum(write) / len(write)) * 1024.0
+        key = kernel.split("<")[0]
+        fetch = [x["FETCH_SIZE"] for x in s["fetch"] if x["kernel"].split("<")[0] == key]
+        write = [x["WRITE_SIZE"] for x in s["write"] if x["kernel"].split("<")[0] == key]
+        return (2 * fetch[launch] + write[launch]) * 1024.0
     except Exception:
         return None
 
@@ -90,11 +105,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "i8x3", "bf16", "fp32"])
+    ap.add_argument("--precision", default="mixed", choices=list(DTYPES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fast-mode", action="store_true", help="skip the extra i8x3 measurement reported beside the headline")
+    ap.add_argument("--no-other-precisions", action="store_true",
+                    help="skip the all-bf16x3 / all-i8x3 frame rates reported beside the headline")
     ap.add_argument("--timed-only", action="store_true", help="profiling runs: nothing but the warm-up and the timed steps "
-                    "(no quality check, fast mode or CPU baseline), so every MLP launch rocprofv3 sees is a timed one")
+                    "(no quality check, other precisions or CPU baseline), so every MLP launch rocprofv3 sees is a timed one")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,24 +129,22 @@ def main():
     fine = synthetic.make_joiner(1).to(dev)
     coarse.precision = fine.precision = args.precision
     cap = synthetic.SimpleCapture(W, H)
-    o_np, d_np = ray_utils.shot_all_rays(cap)
-    origins = torch.from_numpy(o_np).to(dev, torch.float32).contiguous()
-    dirs = torch.from_numpy(d_np).to(dev, torch.float32).contiguous()
+    origins, dirs = ray_utils.shot_all_rays_dev(cap, dev)                  # a1 on the device
     total = origins.shape[0]
     idx = parallel.tile_ray_indices(total, TILE, rank, world, device=dev)
     o_loc, d_loc = origins[idx].contiguous(), dirs[idx].contiguous()       # this rank's rays, resident in HBM
 
     # HIP events around every MLP launch (same stream the kernel is launched on: torch's current stream)
-    mlp_events = []
-    for net in (coarse, fine):
+    mlp_events = {"coarse": [], "fine": []}
+    for name, net in (("coarse", coarse), ("fine", fine)):
         inner = net.forward_rays
 
-        def timed(o, d, z, precision=None, sigma_scale=1.0, _inner=inner):
+        def timed(o, d, z, precision=None, sigma_scale=1.0, role=None, _inner=inner, _log=mlp_events[name]):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = _inner(o, d, z, precision=precision, sigma_scale=sigma_scale)
+            out = _inner(o, d, z, precision=precision, sigma_scale=sigma_scale, role=role)
             e1.record()
-            mlp_events.append((e0, e1, z.numel()))
+            _log.append((e0, e1, z.numel()))
             return out
         net.forward_rays = timed
 
@@ -145,12 +159,13 @@ def main():
 
     with torch.no_grad():
         for _ in range(args.warmup):
-            frame = step()
-        mlp_events.clear()
+            step()
+        for log in mlp_events.values():
+            log.clear()
         sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            frame = step()
+            step()
         sync()
         dt = time.perf_counter() - t0
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -158,13 +173,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
 
-    evals = sum(n for _, _, n in mlp_events)
-    mlp_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in mlp_events)
-    achieved = evals * FLOP_PER_EVAL / (mlp_ms * 1e-3) / 1e12 if mlp_ms > 0 else 0.0
+    def roofline(which, precision, launch_index):
+        log = mlp_events[which]
+        evals = sum(n for _, _, n in log)
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in log)
+        achieved = evals * FLOP_PER_EVAL / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        kernel = KERNEL_OF[precision]
+        return {"bound": "mfma", "kernel": kernel,
+                "launch": f"{which} pass, {evals // max(1, len(log))} evaluations per launch on this rank",
+                "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+                "traffic": pmc_traffic_per_launch(kernel, launch_index) if world == 1 else None,
+                "traffic_unit": "bytes of HBM traffic per launch (FETCH_SIZE*2 + WRITE_SIZE, rocprofv3 --pmc passes of this command, "
+                                "profiles/r01_bench_pmc_summary.json; algorithmic: 16 B/evaluation out + 4 B/evaluation z in)",
+                "launches": len(log), "avg_launch_ms": ms / max(1, len(log)),
+                "note": "algorithmic FLOPs = 1,186,816 per MLP evaluation; bf16x3 and i8x3 both issue 3 MFMAs per algorithmic one "
+                        "(i8 at twice the bf16 rate), so hardware MFMA work is 3x the algorithmic figure"}
+
+    p_coarse = "bf16x3" if args.precision == "mixed" else args.precision
+    p_fine = "i8x3" if args.precision == "mixed" else args.precision
+    same_kernel = p_coarse == p_fine                                        # then the fine launch is that kernel's second dispatch
 
     if rank == 0:
-        psnr = None
-        fast = None
         for net in (coarse, fine):
             net.__dict__.pop('forward_rays', None)              # drop the event-recording wrappers
         n = 32 * W
@@ -176,44 +205,50 @@ def main():
         def psnr_db(a, b):
             return float(10 * torch.log10(1.0 / torch.clamp(((a - b).double() ** 2).mean(), min=1e-30)))
 
-        if args.precision != "fp32" and not args.timed_only:            # quality check outside the timed region: first 32 rows vs the exact-f32 device path
+        psnr, versus, others = None, None, None
+        if args.precision != "fp32" and not args.timed_only:   # quality checks outside the timed region: first 32 rows of the frame
             with torch.no_grad():
-                ref32 = first_rows("fp32")
-                psnr = psnr_db(first_rows(args.precision), ref32)
-                if args.precision == "bf16x3" and world == 1 and not args.no_fast_mode:
-                    # the labelled fast mode, for reference next to the headline (same frame, same timing brackets); never `value`
-                    coarse.precision = fine.precision = "i8x3"
-                    step()
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    for _ in range(args.steps):
+                ref32 = first_rows("fp32")                      # the exact-f32 validation kernel on the same path
+                mine = first_rows(args.precision)
+                psnr = psnr_db(mine, ref32)
+                if args.precision == "mixed":
+                    b3 = first_rows("bf16x3")
+                    versus = {"what": "first 32 rows (25,600 rays) of the frame, mixed vs bf16x3 in both passes: identical sample "
+                                      "positions by construction, so this is the fine pass's arithmetic alone",
+                              "rgb_linf": float((mine - b3).abs().max()), "psnr_db_bf16x3_vs_f32_device_path": psnr_db(b3, ref32)}
+                if world == 1 and not args.no_other_precisions:
+                    others = {}
+                    for p in ("bf16x3", "i8x3"):
+                        if p == args.precision:
+                            continue
+                        coarse.precision = fine.precision = p
                         step()
-                    torch.cuda.synchronize()
-                    dt8 = time.perf_counter() - t1
-                    fast = {"precision": "i8x3 (16-bit fixed-point limbs on the i8 MFMA; composited RGB within 2e-5 of the f32 kernel on "
-                                         "identical samples, tests/test_hip_mlp.py, but 4x the bf16x3 error: not the parity path)",
-                            "value": total * args.steps / dt8, "unit": "rays/s", "ms_per_step": dt8 / args.steps * 1e3,
-                            "psnr_db_vs_f32_device_path": psnr_db(first_rows("i8x3"), ref32)}
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        for _ in range(args.steps):
+                            step()
+                        torch.cuda.synchronize()
+                        dtp = time.perf_counter() - t1
+                        others[p] = {"value": total * args.steps / dtp, "unit": "rays/s", "ms_per_step": dtp / args.steps * 1e3,
+                                     "psnr_db_vs_f32_device_path": psnr_db(first_rows(p), ref32)}
+                    others["note"] = ("same frame and timing brackets, both passes in the named precision; bf16x3 = the reference-grade "
+                                      "arithmetic everywhere, i8x3 = the fast mode (4x the bf16x3 error in the coarse pass moves importance "
+                                      "samples across bin edges: not parity grade end to end); never `value`")
                 coarse.precision = fine.precision = args.precision
         line = {
             "metric": "rays_per_sec (800x800 frame, 128 samples/ray coarse + 128 importance, NeuMan background NeRF)",
             "value": total * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": {"bf16x3": "bf16x3 (split-bf16 hi+lo MFMA x3, f32 accumulate)", "i8x3": "i8x3 (per-row-scaled int16 as 2 int8 limbs, i8 MFMA x3, exact int32 accumulate; encodings on bf16x3)", "bf16": "bf16 (f32 accumulate)", "fp32": "f32"}[args.precision],
-            "data": "synthetic",
+            "dtype": DTYPES[args.precision], "data": "synthetic",
             "config": {"workload": "BASELINE config 2: background NeRF (models/vanilla.py 8x256, posenc), 800x800 = 640000 rays, "
                                    "128 coarse + 256 fine MLP evaluations per ray, synthetic-dense weights (seeds 0/1), near 0 far 3.14",
-                       "rays_per_frame": total, "mlp_evals_per_ray": EVALS_PER_RAY, "parallelism": f"ray-tile sharding x{world}, 1 gather/frame",
-                       "tile_rays": TILE},
+                       "rays_per_frame": total, "mlp_evals_per_ray": EVALS_PER_RAY,
+                       "parallelism": f"ray-tile sharding x{world}, 1 gather/frame", "tile_rays": TILE, "precision": args.precision},
             "psnr_db_vs_f32_device_path": psnr,
-            "fast_mode": fast,
-            "roofline": {"bound": "mfma", "kernel": "nerf_mlp_kernel<bf16x3>" if args.precision == "bf16x3" else f"nerf_mlp ({args.precision})",
-                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                         "traffic": pmc_traffic_per_launch() if args.precision == "bf16x3" else None, "traffic_unit": "bytes of HBM traffic per launch (FETCH_SIZE*2 + WRITE_SIZE, "
-                         "rocprofv3 --pmc pass of this command, profiles/r01_bench_pmc_summary.json; algorithmic: 16 B/sample out + 4 B/sample z in)",
-                         "launches": len(mlp_events), "avg_launch_ms": mlp_ms / max(1, len(mlp_events)),
-                         "note": "algorithmic FLOPs = 1,186,816 per MLP evaluation; bf16x3 issues 3 MFMAs per algorithmic one, "
-                                 "so hardware MFMA utilisation is 3x frac"},
+            "versus_all_bf16x3": versus,
+            "other_precisions": others,
+            "roofline": roofline("fine", p_fine, 1 if same_kernel else 0),
+            "roofline_coarse": roofline("coarse", p_coarse, 0),
         }
         if world == 1 and not args.no_cpu_baseline and not args.timed_only:
             line["cpu_baseline"] = cpu_baseline()

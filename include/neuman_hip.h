@@ -39,8 +39,9 @@ typedef void* nm_stream_t;
 #define NM_PREC_BF16X3 1 /* split-bf16 (hi+lo) x3 MFMA, f32 accumulate: the parity-grade default     */
 #define NM_PREC_BF16 2   /* single bf16 MFMA, f32 accumulate: fast, NOT parity grade     */
 #define NM_PREC_I8X3 3   /* hidden layers as per-row-scaled int16 = two int8 limbs on the i8 MFMA (hh + hl + lh, exact
-                            int32 accumulate), encodings on split bf16: the labelled FAST mode -- composited colours within
-                            2e-5 of f32 on identical samples, 4x the bf16x3 error, NOT the parity path */
+                            int32 accumulate), encodings on split bf16: composited colours within 2e-5 of f32 on identical
+                            samples -- parity grade for passes that are only composited (the host's default policy uses it
+                            there), NOT for a pass whose weights place importance samples */
 
 /* positional-encoding kinds (reference models/vanilla.py:44-79) */
 #define NM_PE_POSENC 0 /* [x, sin(f0 x), cos(f0 x), sin(f1 x), ...]   vanilla.py:60-79,92 */

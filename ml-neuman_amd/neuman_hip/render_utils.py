@@ -77,11 +77,13 @@ def bkg_pass_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, import
                   precision=None):
     """Coarse (+ fine) background evaluation of R rays -> (raw [R,S',4], z [R,S'])  (render_utils.py:131-151, 287-297)."""
     _, _, z = ray_utils.sample_z(o, d, near, far, samples_per_ray)
-    raw = coarse_net.forward_rays(o, d, z, precision=precision)
+    # with a fine net the coarse pass only places the importance samples; otherwise it is the pass that is composited
+    # ('shading' role of the mixed precision policy, vanilla.Joiner._prec)
+    raw = coarse_net.forward_rays(o, d, z, precision=precision, role=None if fine_net is not None else 'shading')
     if fine_net is not None:
         _, _, _, w, _ = raw2outputs(raw, z, d, white_bkg=white_bkg)
         z = ray_utils.importance_z(z, w, importance_samples_per_ray)
-        raw = fine_net.forward_rays(o, d, z, precision=precision)
+        raw = fine_net.forward_rays(o, d, z, precision=precision, role='shading')
     return raw, z
 
 
@@ -105,10 +107,10 @@ def human_pass_rays(human_net, o, d, near, far, samples_per_ray, mesh=None, rend
     """Human-net evaluation of (already compacted) hit rays -> (raw [R,S,4], z [R,S])  (render_utils.py:213-229, 320-329)."""
     if render_can:
         _, _, z = ray_utils.sample_z(o, d, near, far, samples_per_ray)
-        return human_net.forward_rays(o, d, z, precision=precision, sigma_scale=sigma_scale), z
+        return human_net.forward_rays(o, d, z, precision=precision, sigma_scale=sigma_scale, role='shading'), z
     pts, _, z = ray_utils.sample_z(o, d, near, far, samples_per_ray, want_points=True)
     can_pts, can_dirs, _ = ray_utils.warp_to_canonical_dev(pts, mesh)
-    return human_net(can_pts, can_dirs, precision=precision, sigma_scale=sigma_scale), z
+    return human_net(can_pts, can_dirs, precision=precision, sigma_scale=sigma_scale, role='shading'), z
 
 
 def render_smpl_nerf_rays(human_net, o, d, posed_verts, mesh, samples_per_ray, white_bkg=True, render_can=False,
