@@ -16,6 +16,9 @@ fixed-point limbs on the i8 MFMA.  Sample positions are bit-identical to the all
 within 1e-4 of the oracle on identical samples (tests/test_hip_render.py, measured 1.6e-5); the bench line also
 reports the all-bf16x3 and all-i8x3 frame rates measured in the same run (`other_precisions`).
 
+The coarse pass evaluates the density head only (the reference computes the coarse colours, composites them and
+discards the result, render_utils.py:139-141): sigma is bit-identical, 17 % of that pass's MACs are not issued.
+
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel -- the fine launch (163.84 M of the frame's
 245.76 M evaluations): algorithmic FLOPs (1,186,816 per MLP evaluation) / its launch time measured with HIP
 events on the launch stream, against the 2.5 PFLOP/s dense bf16 MFMA peak; `roofline_coarse` is the same for the
@@ -139,10 +142,10 @@ def main():
     for name, net in (("coarse", coarse), ("fine", fine)):
         inner = net.forward_rays
 
-        def timed(o, d, z, precision=None, sigma_scale=1.0, role=None, _inner=inner, _log=mlp_events[name]):
+        def timed(o, d, z, precision=None, sigma_scale=1.0, role=None, sigma_only=False, _inner=inner, _log=mlp_events[name]):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = _inner(o, d, z, precision=precision, sigma_scale=sigma_scale, role=role)
+            out = _inner(o, d, z, precision=precision, sigma_scale=sigma_scale, role=role, sigma_only=sigma_only)
             e1.record()
             _log.append((e0, e1, z.numel()))
             return out
@@ -175,6 +178,7 @@ def main():
 
     def roofline(which, precision, launch_index):
         log = mlp_events[which]
+        density_only = which == "coarse" and precision in ("bf16x3", "bf16")
         evals = sum(n for _, _, n in log)
         ms = sum(e0.elapsed_time(e1) for e0, e1, _ in log)
         achieved = evals * FLOP_PER_EVAL / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -186,8 +190,11 @@ def main():
                 "traffic_unit": "bytes of HBM traffic per launch (FETCH_SIZE*2 + WRITE_SIZE, rocprofv3 --pmc passes of this command, "
                                 "profiles/r01_bench_pmc_summary.json; algorithmic: 16 B/evaluation out + 4 B/evaluation z in)",
                 "launches": len(log), "avg_launch_ms": ms / max(1, len(log)),
-                "note": "algorithmic FLOPs = 1,186,816 per MLP evaluation; bf16x3 and i8x3 both issue 3 MFMAs per algorithmic one "
-                        "(i8 at twice the bf16 rate), so hardware MFMA work is 3x the algorithmic figure"}
+                "note": "algorithmic FLOPs = 1,186,816 per MLP evaluation (what the reference performs); bf16x3 and i8x3 both issue 3 MFMAs "
+                        "per algorithmic one (i8 at twice the bf16 rate), so hardware MFMA work is 3x the algorithmic figure"
+                        + ("; this launch evaluates the density head only (nm_mlp_sigma_rays): the reference composites the coarse "
+                           "colours and discards them (render_utils.py:139-141), so feature/views/rgb layers -- 102,144 of the 593,408 "
+                           "MACs per evaluation -- are not issued; sigma is bit-identical" if density_only else "")}
 
     p_coarse = "bf16x3" if args.precision == "mixed" else args.precision
     p_fine = "i8x3" if args.precision == "mixed" else args.precision

@@ -147,6 +147,14 @@ int nm_mlp_forward(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n,
  * with view direction direction[r] (ray_utils.py:131-132); out [R,S,4]. */
 int nm_mlp_forward_rays(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals,
                         int64_t R, int S, int precision, float sigma_scale, float* out, nm_stream_t stream);
+/* Density only, for a pass whose colours the caller discards -- the coarse pass of a two-pass render: the reference
+ * composites it (render_utils.py:139) and keeps nothing but the weights that place the importance samples (:141), which
+ * depend on sigma alone.  Same arguments as nm_mlp_forward_rays; out [R,S,4] receives (0, 0, 0, sigma * sigma_scale) with
+ * sigma BIT-IDENTICAL to nm_mlp_forward_rays' (same instruction sequence for the alpha row); feature_linear,
+ * views_linears and rgb_linear -- 17 % of the MACs -- are not evaluated.  NM_PREC_BF16X3 / NM_PREC_BF16; the other
+ * precisions evaluate everything and return the colours too. */
+int nm_mlp_sigma_rays(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals,
+                      int64_t R, int S, int precision, float sigma_scale, float* out, nm_stream_t stream);
 /* Debug: stop after `stage` and write that stage's activations as f32 [n, width_of_stage]:
  *   -1 -> position PE (64 wide, col 63 = 0);  0..7 -> relu(pts_linears[i]) (256);
  *    8 -> feature_linear output (256);  9 -> relu(views_linears[0]) (128). */

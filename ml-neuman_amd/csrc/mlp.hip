@@ -62,6 +62,8 @@ struct MlpArgs {
     int in_mode;
     int stop_stage;          // -2 = run everything
     float sigma_scale;
+    int sigma_only;          // 1: only the density head is wanted (a pass whose colours the renderer discards): skip the
+                             //    feature / views / rgb layers and write (0, 0, 0, sigma)
     PeSpec pos, dir;
 };
 
@@ -476,7 +478,8 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
         for (int st = 0; st <= 7; ++st) {
             const nm::StageShape sh = nm::stage_shape(st);
             init_bias<4>(acc, B);
-            const int soff = wo(st, w), next = wo(st + 1, w);
+            const int soff = wo(st, w);
+            const int next = (st == 7 && a.sigma_only) ? (w < 4 ? so_s8a : so_s0) : wo(st + 1, w);
             if (sh.pe_steps)
                 k_run<4, PREC>(acc, W, wsrc, voff, soff, sh.steps > sh.pe_steps ? soff + sh.pe_steps * nm::kStepBytes : next,
                                lds + P_BASE + g * kChunkU4 + s, sh.pe_steps, w >= 4);
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
             NM_BAR_B                                              // every wave has finished reading H (and P)
             NM_TICK(2)
             write_act<4, PREC>(ar, lds, w, 0, g, s);
-            if (st == 5) fill_pe_any(lds, true, a, base, tid);     // P is free after the skip layer: direction PE -> P[0..3]
+            if (st == 5 && !a.sigma_only) fill_pe_any(lds, true, a, base, tid);   // P is free after the skip layer: direction PE -> P[0..3]
             NM_TICK(3)
             __syncthreads();
             NM_TICK(4)
@@ -502,6 +505,26 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
             __syncthreads();
             w_prefetch<PREC>(W, wsrc, voff, so_s0);
             bias_prefetch(B, a.bias + nm::stage_b_off(0) + 32 * w, g);
+            continue;
+        }
+
+        // ---------------- density only (the coarse pass of a two-pass render: the reference composites its colours into a
+        // frame it then discards, render_utils.py:139-141): the alpha block of stage 8 and nothing after it.  Same
+        // instruction sequence as the alpha block below, so sigma is bit-identical to the full evaluation's.
+        if (a.sigma_only) {
+            if (w < 4) {
+                const nm::StageShape sh = nm::stage_shape(8);
+                f32x16 aacc[1];
+                bias_prefetch(B, a.bias + nm::stage_b_off(8) + 32 * 8, g);
+                init_bias<1>(aacc, B);
+                k_run<1, PREC>(aacc, W, wsrc, voff, so_s8a, so_s0, lds + H_BASE + g * kChunkU4 + 32 * w + s, sh.steps);
+                const int64_t i = base + 32 * w + s;
+                if (g == 0 && i < a.n) reinterpret_cast<float4*>(a.out)[i] = make_float4(0.f, 0.f, 0.f, aacc[0][0] * a.sigma_scale);
+            }
+            bias_prefetch(B, a.bias + nm::stage_b_off(0) + 32 * w, g);
+            NM_TICK(1)
+            __syncthreads();                                      // H / P are rewritten by the next tile
+            NM_TICK(5)
             continue;
         }
 
@@ -1134,13 +1157,14 @@ namespace nm {
 
 int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
                     const float* z, int64_t n, int S, int in_mode, int precision, int stop_stage, float sigma_scale, float* out,
-                    float* dbg, void* prof, hipStream_t stream) {
+                    float* dbg, void* prof, hipStream_t stream, int sigma_only) {
     MlpArgs a;
     a.wpack = reinterpret_cast<const uint4*>(L.wpack);
     a.bias = L.bias;
     a.petab = L.petab;
     a.pts = pts; a.dirs = dirs; a.origin = origin; a.direction = direction; a.z = z;
     a.out = out; a.dbg = dbg; a.prof = reinterpret_cast<unsigned long long*>(prof); a.n = n; a.S = S; a.in_mode = in_mode; a.stop_stage = stop_stage; a.sigma_scale = sigma_scale;
+    a.sigma_only = (sigma_only && precision != NM_PREC_I8X3) ? 1 : 0;   // (the i8x3 kernel always evaluates the colour head)
     a.pos = PeSpec{L.pe_kind, L.pos_nfreq, L.pos_octaves};
     a.dir = PeSpec{L.pe_kind, L.dir_nfreq, L.dir_octaves};
     const int64_t ntiles = (n + kTileM - 1) / kTileM;

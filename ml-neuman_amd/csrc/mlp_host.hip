@@ -372,7 +372,7 @@ int nm_mlp_destroy(nm_mlp_t m) {
 
 static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const float* origin, const float* direction,
                         const float* z, int64_t n, int S, int in_mode, int precision, int stop_stage, float sigma_scale,
-                        float* out, float* dbg, nm_stream_t stream, void* prof = nullptr) {
+                        float* out, float* dbg, nm_stream_t stream, void* prof = nullptr, int sigma_only = 0) {
     NM_REQUIRE(m, "nm_mlp_forward: null handle");
     NM_REQUIRE(n >= 0, "nm_mlp_forward: negative n");
     NM_REQUIRE(precision == NM_PREC_FP32 || precision == NM_PREC_BF16X3 || precision == NM_PREC_BF16 || precision == NM_PREC_I8X3,
@@ -395,7 +395,7 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
     L.wstream8 = m->d_stream8;
     L.consts8 = m->d_consts8;
     return nm::launch_mlp_mfma(L, pts, dirs, origin, direction, z, n, S, in_mode, precision, stop_stage, sigma_scale, out, dbg,
-                               prof, nm::as_stream(stream));
+                               prof, nm::as_stream(stream), sigma_only);
 }
 
 int nm_mlp_forward(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision, float sigma_scale,
@@ -412,6 +412,15 @@ int nm_mlp_forward_rays(nm_mlp_t mlp, const float* origin, const float* directio
     NM_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "nm_mlp_forward_rays: out must be 16-byte aligned");
     return mlp_dispatch(mlp, nullptr, nullptr, origin, direction, z_vals, R * (int64_t)S, S, 1, precision, -2, sigma_scale, out,
                         nullptr, stream);
+}
+
+int nm_mlp_sigma_rays(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals, int64_t R, int S,
+                      int precision, float sigma_scale, float* out, nm_stream_t stream) {
+    NM_REQUIRE(R == 0 || (origin && direction && z_vals && out), "nm_mlp_sigma_rays: null pointer");
+    NM_REQUIRE(R >= 0 && S >= 1, "nm_mlp_sigma_rays: bad sizes");
+    NM_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "nm_mlp_sigma_rays: out must be 16-byte aligned");
+    return mlp_dispatch(mlp, nullptr, nullptr, origin, direction, z_vals, R * (int64_t)S, S, 1, precision, -2, sigma_scale, out,
+                        nullptr, stream, nullptr, 1);
 }
 
 int nm_mlp_forward_profile(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision, float* out,

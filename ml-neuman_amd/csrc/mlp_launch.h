@@ -17,7 +17,7 @@ struct RefLaunch {
 
 int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
                     const float* z, int64_t n, int S, int in_mode, int precision, int stop_stage, float sigma_scale, float* out,
-                    float* dbg, void* prof, hipStream_t stream);
+                    float* dbg, void* prof, hipStream_t stream, int sigma_only = 0);
 int launch_mlp_ref(const RefLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
                    const float* z, int64_t n, int S, int in_mode, int stop_stage, float sigma_scale, float* out, float* dbg,
                    hipStream_t stream);

@@ -79,7 +79,9 @@ def bkg_pass_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, import
     _, _, z = ray_utils.sample_z(o, d, near, far, samples_per_ray)
     # with a fine net the coarse pass only places the importance samples; otherwise it is the pass that is composited
     # ('shading' role of the mixed precision policy, vanilla.Joiner._prec)
-    raw = coarse_net.forward_rays(o, d, z, precision=precision, role=None if fine_net is not None else 'shading')
+    # (and only its density is used, render_utils.py:139-141: the colour head is skipped)
+    raw = coarse_net.forward_rays(o, d, z, precision=precision, role=None if fine_net is not None else 'shading',
+                                  sigma_only=fine_net is not None)
     if fine_net is not None:
         _, _, _, w, _ = raw2outputs(raw, z, d, white_bkg=white_bkg)
         z = ray_utils.importance_z(z, w, importance_samples_per_ray)

@@ -162,15 +162,17 @@ class Joiner(nn.Module):
                                              _lib.stream_ptr()), "nm_mlp_forward")
         return out.reshape(*shp, 4)
 
-    def forward_rays(self, origin, direction, z_vals, precision=None, sigma_scale=1.0, role=None):
-        """Fused ray_to_samples point construction + forward: origin/direction [R,3], z_vals [R,S] -> [R,S,4]."""
+    def forward_rays(self, origin, direction, z_vals, precision=None, sigma_scale=1.0, role=None, sigma_only=False):
+        """Fused ray_to_samples point construction + forward: origin/direction [R,3], z_vals [R,S] -> [R,S,4].
+        sigma_only: the caller uses nothing but out[..., 3] (a coarse pass that only places importance samples) -- the
+        colour head is skipped where the kernel can (out[..., :3] = 0), sigma is bit-identical either way."""
         self._guard(origin, direction, z_vals)
         R, S = z_vals.shape
         out = torch.empty((R, S, 4), device=z_vals.device, dtype=torch.float32)
-        _lib.check(_lib.lib().nm_mlp_forward_rays(self.handle(), _lib.dev_ptr(origin, name='origin'),
-                                                  _lib.dev_ptr(direction, name='direction'), _lib.dev_ptr(z_vals, name='z_vals'),
-                                                  R, S, self._prec(precision, role), float(sigma_scale), _lib.dev_ptr(out),
-                                                  _lib.stream_ptr()), "nm_mlp_forward_rays")
+        entry = _lib.lib().nm_mlp_sigma_rays if sigma_only else _lib.lib().nm_mlp_forward_rays
+        _lib.check(entry(self.handle(), _lib.dev_ptr(origin, name='origin'), _lib.dev_ptr(direction, name='direction'),
+                         _lib.dev_ptr(z_vals, name='z_vals'), R, S, self._prec(precision, role), float(sigma_scale),
+                         _lib.dev_ptr(out), _lib.stream_ptr()), "nm_mlp_sigma_rays" if sigma_only else "nm_mlp_forward_rays")
         return out
 
     def forward_debug(self, input_pts, input_views, stage, precision=None):

@@ -206,3 +206,23 @@ def test_i8x3_composited_parity_and_full_size(gpu_nets):
     e8 = (res["i8x3"] - res["fp32"]).abs().max().item()
     print(f"[mlp] composited RGB Linf vs f32 kernel over {R} rays: bf16x3 {e3:.3e}, i8x3 {e8:.3e}")
     assert e3 < 2e-5 and e8 < 1e-4
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16", "i8x3", "fp32"])
+@pytest.mark.parametrize("R,S", [(1, 1), (3, 43), (64, 128), (700, 37)])
+def test_sigma_only_is_bit_identical(gpu_nets, prec, R, S):
+    """nm_mlp_sigma_rays (the coarse pass of a two-pass render): sigma bit-identical to the full evaluation for every
+    precision and ragged size; the colours are 0 where the colour head is skipped (bf16x3 / bf16)."""
+    j = gpu_nets[0][0]
+    g = torch.Generator(device='cuda').manual_seed(R * 1000 + S)
+    o = torch.randn((R, 3), device='cuda', generator=g) * 0.3
+    d = torch.nn.functional.normalize(torch.randn((R, 3), device='cuda', generator=g), dim=-1)
+    z = torch.sort(torch.rand((R, S), device='cuda', generator=g) * 3.0, dim=1).values.contiguous()
+    full = j.forward_rays(o, d, z, precision=prec, sigma_scale=1.7)
+    dens = j.forward_rays(o, d, z, precision=prec, sigma_scale=1.7, sigma_only=True)
+    assert dens.shape == full.shape == (R, S, 4)
+    assert torch.equal(dens[..., 3], full[..., 3])
+    if prec in ("bf16x3", "bf16"):
+        assert (dens[..., :3] == 0).all()
+    else:
+        assert torch.equal(dens, full)
