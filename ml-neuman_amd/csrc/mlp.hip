@@ -729,17 +729,29 @@ __device__ __forceinline__ void w_step_load(WStep& S, __amdgpu_buffer_rsrc_t wsr
 // NSTEPS k-steps of one feature block x MB sample blocks, fully unrolled.  PH = ring slot of the first step; `pos` is the
 // stream offset of the step the ring loads next (kRing ahead of the step being consumed).  I8: limbs on the i8 MFMA into
 // (ah, ac); otherwise split bf16 into f32 accumulators passed as ah (bit pattern) -- see the two wrappers below.
-template <bool I8, int MB, int NSTEPS, int PH>
+// PRE: the fragments of this run's first step were requested by the previous run (xp); POST: request the first step of the
+// next run (at xnext) during this run's last step -- the two k-loops of an M slot read the same rows, so the second one's
+// first LDS round trip is taken off the matrix pipe's critical path and out from behind the slot's middle barrier.
+template <int MB>
+struct XPre {
+    uint4 h[MB], l[MB];
+};
+template <bool I8, int MB, int NSTEPS, int PH, bool PRE, bool POST>
 __device__ __forceinline__ void w_run(i32x16 (&ah)[MB], i32x16 (&ac)[MB], f32x16 (&ff)[MB], WRing& R, __amdgpu_buffer_rsrc_t wsrc,
-                                      int voff, int& pos, const uint4* xh) {
+                                      int voff, int& pos, const uint4* xh, XPre<MB>& xp, const uint4* xnext) {
     // activation fragments kXD steps ahead, in a rotating set of kXD + 1 register groups (static indices: the loop is unrolled)
     uint4 xq[kXD + 1][2][MB];
 #pragma unroll
     for (int d = 0; d < kXD && d < NSTEPS; ++d)
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
-            xq[d][0][m] = xh[d * (2 * kChunkU4) + m * 32];
-            xq[d][1][m] = xh[d * (2 * kChunkU4) + kLoU4 + m * 32];
+            if (PRE && d == 0) {
+                xq[0][0][m] = xp.h[m];
+                xq[0][1][m] = xp.l[m];
+            } else {
+                xq[d][0][m] = xh[d * (2 * kChunkU4) + m * 32];
+                xq[d][1][m] = xh[d * (2 * kChunkU4) + kLoU4 + m * 32];
+            }
         }
     __builtin_amdgcn_s_setprio(NM_W_PRIO);
 #pragma unroll
@@ -752,6 +764,10 @@ __device__ __forceinline__ void w_run(i32x16 (&ah)[MB], i32x16 (&ac)[MB], f32x16
             const uint4* ph = xh + (t + kXD) * (2 * kChunkU4);
 #pragma unroll
             for (int m = 0; m < MB; ++m) { xq[(t + kXD) % (kXD + 1)][0][m] = ph[m * 32]; xq[(t + kXD) % (kXD + 1)][1][m] = ph[kLoU4 + m * 32]; }
+        }
+        if (POST && t == NSTEPS - 1) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m) { xp.h[m] = xnext[m * 32]; xp.l[m] = xnext[kLoU4 + m * 32]; }
         }
         const v4u wh = R.s[slot].h, wl = R.s[slot].l;
         __builtin_amdgcn_sched_barrier(0);
@@ -793,12 +809,27 @@ template <int MB, int NSTEPS, int PH>
 __device__ __forceinline__ void w_run8(i32x16 (&ah)[MB], i32x16 (&ac)[MB], WRing& R, __amdgpu_buffer_rsrc_t wsrc, int voff, int& pos,
                                        const uint4* xh) {
     f32x16 none[MB];
-    w_run<true, MB, NSTEPS, PH>(ah, ac, none, R, wsrc, voff, pos, xh);
+    XPre<MB> xp;
+    w_run<true, MB, NSTEPS, PH, false, false>(ah, ac, none, R, wsrc, voff, pos, xh, xp, nullptr);
 }
 template <int MB, int NSTEPS, int PH>
 __device__ __forceinline__ void w_runbf(f32x16 (&f)[MB], WRing& R, __amdgpu_buffer_rsrc_t wsrc, int voff, int& pos, const uint4* xh) {
     i32x16 none[MB];
-    w_run<false, MB, NSTEPS, PH>(none, none, f, R, wsrc, voff, pos, xh);
+    XPre<MB> xp;
+    w_run<false, MB, NSTEPS, PH, false, false>(none, none, f, R, wsrc, voff, pos, xh, xp, nullptr);
+}
+// the two k-loops of an M slot (PH1 / PH2: ring slots of their first steps), the second one's first fragments requested by the first
+template <int MB, int NSTEPS, int PH, bool PRE, bool POST>
+__device__ __forceinline__ void w_run8x(i32x16 (&ah)[MB], i32x16 (&ac)[MB], WRing& R, __amdgpu_buffer_rsrc_t wsrc, int voff, int& pos,
+                                        const uint4* xh, XPre<MB>& xp, const uint4* xnext) {
+    f32x16 none[MB];
+    w_run<true, MB, NSTEPS, PH, PRE, POST>(ah, ac, none, R, wsrc, voff, pos, xh, xp, xnext);
+}
+template <int MB, int NSTEPS, int PH, bool PRE, bool POST>
+__device__ __forceinline__ void w_runbfx(f32x16 (&f)[MB], WRing& R, __amdgpu_buffer_rsrc_t wsrc, int voff, int& pos, const uint4* xh,
+                                         XPre<MB>& xp, const uint4* xnext) {
+    i32x16 none[MB];
+    w_run<false, MB, NSTEPS, PH, PRE, POST>(none, none, f, R, wsrc, voff, pos, xh, xp, xnext);
 }
 
 // t = hh * 256 + cross (exact: |t| * 256 is the full 32-bit product sum)
@@ -968,9 +999,10 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_i8w_kernel(const MlpArgs
             f32x16 f[2][2];
             init_bias8<2>(f[0], cst, 64 * wq, g);
             init_bias8<2>(f[1], cst, 64 * wq + 32, g);
-            w_runbf<2, 4, 0>(f[0], R, wsrc, voff, pos, xP);
+            XPre<2> xp;
+            w_runbfx<2, 4, 0, false, true>(f[0], R, wsrc, voff, pos, xP, xp, xP);
             __syncthreads();
-            w_runbf<2, 4, 4 % kRing>(f[1], R, wsrc, voff, pos, xP);
+            w_runbfx<2, 4, 4 % kRing, true, false>(f[1], R, wsrc, voff, pos, xP, xp, nullptr);
             NM_TICK(1)
             __syncthreads();
             NM_TICK(2)
@@ -992,17 +1024,18 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_i8w_kernel(const MlpArgs
             f32x16 f[2][2];
             {
                 i32x16 t[2][2];
+                XPre<2> xp;
                 {
                     i32x16 ah[2], ac[2];
                     zero8<2>(ah, ac);
-                    w_run8<2, 8, 0>(ah, ac, R, wsrc, voff, pos, xH);
+                    w_run8x<2, 8, 0, false, true>(ah, ac, R, wsrc, voff, pos, xH, xp, xH);
                     combine8<2>(t[0], ah, ac);
                 }
                 __syncthreads();
                 {
                     i32x16 ah[2], ac[2];
                     zero8<2>(ah, ac);
-                    w_run8<2, 8, 0>(ah, ac, R, wsrc, voff, pos, xH);
+                    w_run8x<2, 8, 0, true, false>(ah, ac, R, wsrc, voff, pos, xH, xp, nullptr);
                     combine8<2>(t[1], ah, ac);
                 }
                 if (st != 5) {
@@ -1043,17 +1076,18 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_i8w_kernel(const MlpArgs
             {
                 i32x16 t[2][2], ta[1];
                 zero8<1>(ta, ta);                                  // (defined on every path: an undefined value would be carried -- and spilled -- around the tile loop)
+                XPre<2> xp;
                 {
                     i32x16 ah[2], ac[2];
                     zero8<2>(ah, ac);
-                    w_run8<2, 8, 0>(ah, ac, R, wsrc, voff, pos, xH);
+                    w_run8x<2, 8, 0, false, true>(ah, ac, R, wsrc, voff, pos, xH, xp, xH);
                     combine8<2>(t[0], ah, ac);
                 }
                 __syncthreads();
                 {
                     i32x16 ah[2], ac[2];
                     zero8<2>(ah, ac);
-                    w_run8<2, 8, 0>(ah, ac, R, wsrc, voff, pos, xH);
+                    w_run8x<2, 8, 0, true, false>(ah, ac, R, wsrc, voff, pos, xH, xp, nullptr);
                     combine8<2>(t[1], ah, ac);
                 }
                 if (wq < 2) {
@@ -1098,9 +1132,10 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_i8w_kernel(const MlpArgs
                 {
                     i32x16 ah[2], ac[2];
                     zero8<2>(ah, ac);
-                    w_run8<2, 4, 0>(ah, ac, R, wsrc, voff, pos, xH);
+                    XPre<2> xp;
+                    w_run8x<2, 4, 0, false, true>(ah, ac, R, wsrc, voff, pos, xH, xp, xH + 4 * (2 * kChunkU4));
                     __syncthreads();
-                    w_run8<2, 4, 4 % kRing>(ah, ac, R, wsrc, voff, pos, xH + 4 * (2 * kChunkU4));
+                    w_run8x<2, 4, 4 % kRing, true, false>(ah, ac, R, wsrc, voff, pos, xH + 4 * (2 * kChunkU4), xp, nullptr);
                     combine8<2>(t, ah, ac);
                 }
                 const float k256 = 256.f * cst[kKap + 9];
