@@ -903,8 +903,12 @@ __device__ __forceinline__ void quant_storew(const f32x16 (&f)[NB][MB], uint4* l
             i16x2 P[8], Y[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                i16x2 p = __builtin_amdgcn_cvt_pknorm_i16(f[b][mb][2 * i] * inv1[mb], f[b][mb][2 * i + 1] * inv1[mb]);
-                if (RELU) p = __builtin_elementwise_max(p, (i16x2){0, 0});
+                float y0 = f[b][mb][2 * i] * inv1[mb], y1 = f[b][mb][2 * i + 1] * inv1[mb];
+                if (RELU) {                                     // y <= 32639/32767 < 1: clamping to [0, 1] is the ReLU, and it folds
+                    y0 = __builtin_amdgcn_fmed3f(y0, 0.f, 1.f);  // into the multiply's clamp modifier (no instruction of its own)
+                    y1 = __builtin_amdgcn_fmed3f(y1, 0.f, 1.f);
+                }
+                const i16x2 p = __builtin_amdgcn_cvt_pknorm_i16(y0, y1);
                 P[i] = p;
                 Y[i] = p + (i16x2){128, 128};
             }
