@@ -800,7 +800,9 @@ __device__ __forceinline__ void w_run(i32x16 (&ah)[MB], i32x16 (&ac)[MB], f32x16
             for (int m = 0; m < MB; ++m) ff[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh), as_bf16x8(xhc[m]), ff[m], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-#ifndef NM_W_NO_WLOAD    // (experiment: weights never reloaded -- the ceiling if the weight stream were free; results garbage)
+#if defined(NM_W_HALF_WLOAD)   // (experiment: every other step reloaded -- half the weight stream; results garbage)
+        if (((PH + t) & 1) == 0) w_step_load(R.s[slot], wsrc, voff, pos);
+#elif !defined(NM_W_NO_WLOAD)  // (experiment: weights never reloaded -- the ceiling if the weight stream were free; results garbage)
         w_step_load(R.s[slot], wsrc, voff, pos);       // the slot just consumed <- the step kRing ahead
 #endif
         pos += nm::kStepBytes;
