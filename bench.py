@@ -183,7 +183,14 @@ def main():
         ms = sum(e0.elapsed_time(e1) for e0, e1, _ in log)
         achieved = evals * FLOP_PER_EVAL / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         kernel = KERNEL_OF[precision]
-        return {"bound": "mfma", "kernel": kernel,
+        # what the matrix pipe really executes: MFMA ops per algorithmic FLOP x the share of the layers evaluated, against the
+        # dense peak of the MFMA type in use (MI355X_MICROARCH.md: bf16 2.5 PFLOP/s; i8 ~2x the bf16 rate)
+        issued = {"bf16x3": 3.0, "i8x3": 3.0, "bf16": 1.0}.get(precision, 0.0) * ((593408 - 102144) / 593408 if density_only else 1.0)
+        hw_peak = 5000.0 if precision == "i8x3" else PEAK_BF16_TFLOPS
+        hardware = {"mfma_type": "i8 (v_mfma_i32_32x32x32_i8; 256 + 32 encoding inputs on bf16)" if precision == "i8x3" else "bf16",
+                    "mfma_ops_per_algorithmic_flop": issued, "rate": achieved * issued, "peak": hw_peak, "unit": "Tops/s",
+                    "frac": achieved * issued / hw_peak} if issued else None
+        return {"bound": "mfma", "kernel": kernel, "hardware": hardware,
                 "launch": f"{which} pass, {evals // max(1, len(log))} evaluations per launch on this rank",
                 "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
                 "traffic": pmc_traffic_per_launch(kernel, launch_index) if world == 1 else None,
