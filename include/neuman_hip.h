@@ -175,20 +175,22 @@ int nm_mlp_forward_profile(nm_mlp_t mlp, const float* pts, const float* dirs, in
  *   finite-difference canonical directions along each ray (:62-64).
  *
  *   nm_mesh_create builds, once per posed mesh (per frame and actor), an exact search structure on the
- *   device: per-triangle records and a uniform grid whose cells list, in distance rings, every triangle
- *   that can be the closest one for a point of the cell.  verts [V,3] f32 and faces [F,3] int32 are
- *   DEVICE pointers and are copied into the handle.  `reach` = the largest distance query points have
- *   from the vertices (geo_threshold in the render paths); farther points are still answered exactly,
- *   by an all-triangles loop.  The call synchronises the stream twice (grid sizing, list length).
+ *   device: triangle records in Morton order and an implicit 4-ary tree of child boxes over them
+ *   (NM_SEARCH_TREE).  verts [V,3] f32 and faces [F,3] int32 are DEVICE pointers and are copied into the
+ *   handle; F <= 2^24.  NM_SEARCH_ALL makes the query loop over every triangle instead (diagnostics and
+ *   tests: both modes return bit-identical results, ties between equidistant triangles going to the lowest
+ *   face id).  The call synchronises the stream once (non-finite vertices are an error).
  *   nm_warp_to_canonical: pts [R,S,3] f32, T [*,16] f64 -> can_pts, can_dirs [R,S,3] f32,
  *   closest [R,S,3] f32 (optional).
  * ------------------------------------------------------------------------------------------- */
+#define NM_SEARCH_TREE 0
+#define NM_SEARCH_ALL 1
 typedef struct nm_mesh_s* nm_mesh_t;
-int nm_mesh_create(const float* verts, int V, const int32_t* faces, int F, float reach, nm_mesh_t* out,
+int nm_mesh_create(const float* verts, int V, const int32_t* faces, int F, int search, nm_mesh_t* out,
                    nm_stream_t stream);
 int nm_mesh_destroy(nm_mesh_t mesh);
-/* grid dimensions, total candidate-list length and cell size of a built mesh (diagnostics) */
-int nm_mesh_info(nm_mesh_t mesh, int32_t* cells_xyz, int64_t* list_len, float* cell_size);
+/* tree levels, node count and device bytes of a built mesh (diagnostics) */
+int nm_mesh_info(nm_mesh_t mesh, int32_t* levels, int64_t* nodes, int64_t* bytes);
 int nm_warp_to_canonical(nm_mesh_t mesh, const float* pts, int64_t R, int S, const double* T, float* can_pts,
                          float* can_dirs, float* closest, nm_stream_t stream);
 

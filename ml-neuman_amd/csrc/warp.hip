@@ -3,45 +3,100 @@
 // libigl's CPU AABB tree behind a device->host->device round trip per ray batch
 // (utils/render_utils.py:218-227).  Here the whole warp stays on the GPU.
 //
-// nm_mesh_create (once per posed mesh, i.e. per frame and actor) builds an exact acceleration structure:
-//   * per triangle a 64 B record {a, b, c, bounding sphere};
-//   * a uniform grid over the vertex AABB inflated by `reach` (the largest distance a query point can have from
-//     the vertices: geo_threshold for the render paths).  For each cell C with centre c and half diagonal hd,
-//     ub(C) = |c - nearest vertex| + hd bounds the mesh distance of every point of C, so only triangles with
-//     key(t) = |sphere centre - c| - sphere radius <= ub(C) + hd can be the closest triangle of a point in C.
-//     Those candidates are stored per cell, bucketed by key into kRings distance rings (counting sort).
-// warp_kernel (one workgroup per ray, one lane per sample) walks the rings of its cell in order and stops as soon as a
-// ring's lower bound exceeds the best distance found; each candidate first gets a bounding-sphere test, then the exact
-// Voronoi-region closest-point test (f32, like the reference's f32 query).  Cells farther than `reach` from every
-// vertex hold no list; points there (never produced by the render paths) take the brute-force loop over all triangles,
-// so the result is exact everywhere.  The winning triangle's barycentrics, the blended 4x4 (f64, the reference's T is
-// f64), its inverse and the canonical point are f64; the ray's canonical points are staged in LDS so the
-// finite-difference directions (:62-64) need no second pass over HBM.
+// nm_mesh_create (once per posed mesh, i.e. per frame and actor) builds an exact search tree on the device:
+//   * per triangle a 64 B record {bounding sphere, a, b, c, face id}, sorted along a 30-bit Morton curve of the
+//     centroids (rank sort: F is a body mesh, 13,776 faces for SMPL);
+//   * an implicit 4-ary tree over the sorted order: node i of level l covers the sorted triangles
+//     [i 4^(L-l), (i+1) 4^(L-l)), level L are the triangles themselves.  A node record holds the AABBs of its four
+//     children as six float4 (SoA), so one visit = six 16 B loads and four slab distances.
+// warp_kernel (one workgroup per ray, one lane per sample) runs a depth-first, nearest-child-first search per lane with
+// the stack in LDS.  A subtree is skipped when the distance to its box exceeds the best distance found, inflated by a
+// rounding margin (1e-4 relative + ~80 ulp of the coordinates) so that no triangle whose COMPUTED distance could tie
+// or beat the best one is ever skipped: the result is bit-identical to the all-triangles loop (tested), ties going to
+// the lowest face id whatever the visiting order.  The loop is written "while-while": a lane walks the tree until it
+// holds a triangle, then all lanes of the wave that hold one run the exact Voronoi-region closest-point test (f32,
+// like the reference's f32 query) together -- the test is ~100 instructions with seven exits, and running it under
+// the divergent walk is what made the round's first (grid) kernel 15x slower than this one.
+// The winning triangle's barycentrics, the blended 4x4 (f64, the reference's T is f64), its inverse and the canonical
+// point are f64; the ray's canonical points are staged in LDS so the finite-difference directions (:62-64) need no
+// second pass over HBM.
+#include <float.h>
 #include <math.h>
 #include <string.h>
-
-#include <vector>
 
 #include "common.h"
 
 namespace {
 
-constexpr int kRings = 8;
-constexpr int kMaxCells = 48 * 1024;
+constexpr int kMaxLevels = 12;           // 4^12 = 16.7 M triangles
 
 struct TriRec {          // 16 floats
-    float sx, sy, sz, sr;   // bounding sphere (first 16 B: the cull test reads only this)
+    float sx, sy, sz, sr;   // bounding sphere (first 16 B: the all-triangles loop's cull test reads only this)
     float ax, ay, az, bx, by, bz, cx, cy, cz;
-    float pad[3];
+    int face;               // id in the caller's face array (records are stored in Morton order)
+    float pad[2];
 };
 
-struct Grid {
-    float lox, loy, loz, h, inv_h, half_diag, ring_w, reach;
-    int nx, ny, nz, ncells;
+struct Node {            // the four children's boxes, SoA
+    float4 lox, loy, loz, hix, hiy, hiz;
 };
 
+struct Tree {
+    int L;                       // levels of nodes; level L = triangles
+    int off[kMaxLevels + 1];     // first node of level l in the node array
+    int F;
+    float scale;                 // largest |coordinate| of the mesh: sizes the absolute part of the pruning margin
+};
+
+// ---- build ---------------------------------------------------------------------------------------------------------
+// vertex AABB + a non-finite flag: out[0..2] = lo, out[3..5] = hi, out[6] = 1 if any coordinate is NaN/Inf
+__global__ __launch_bounds__(1024) void bbox_kernel(const float* __restrict__ verts, int V, float* __restrict__ out) {
+    __shared__ float red[16][7];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, bad = 0.f;
+    for (int v = threadIdx.x; v < V; v += blockDim.x)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float x = verts[v * 3 + k];
+            if (!(fabsf(x) <= FLT_MAX)) bad = 1.f;
+            lo[k] = fminf(lo[k], x);
+            hi[k] = fmaxf(hi[k], x);
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], o, 64));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], o, 64));
+        }
+        bad = fmaxf(bad, __shfl_xor(bad, o, 64));
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 3; ++k) { red[w][k] = lo[k]; red[w][3 + k] = hi[k]; }
+        red[w][6] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const int k = threadIdx.x;
+        float r = red[0][k];
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = k < 3 ? fminf(r, red[i][k]) : fmaxf(r, red[i][k]);
+        out[k] = r;
+    }
+}
+
+__device__ __forceinline__ uint32_t spread10(uint32_t x) {      // 10 bits -> every third bit
+    x &= 1023u;
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+
+// triangle records in the caller's order + sort keys (Morton code of the centroid << 32 | face id: all distinct)
 __global__ __launch_bounds__(256) void tri_prep_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces, int F,
-                                                       TriRec* __restrict__ rec) {
+                                                       const float* __restrict__ bbox, TriRec* __restrict__ rec,
+                                                       unsigned long long* __restrict__ keys) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
     const int i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
@@ -56,98 +111,80 @@ __global__ __launch_bounds__(256) void tri_prep_kernel(const float* __restrict__
     const float db = (t.bx - t.sx) * (t.bx - t.sx) + (t.by - t.sy) * (t.by - t.sy) + (t.bz - t.sz) * (t.bz - t.sz);
     const float dc = (t.cx - t.sx) * (t.cx - t.sx) + (t.cy - t.sy) * (t.cy - t.sy) + (t.cz - t.sz) * (t.cz - t.sz);
     t.sr = sqrtf(fmaxf(da, fmaxf(db, dc))) * 1.0001f + 1e-7f;
-    t.pad[0] = t.pad[1] = t.pad[2] = 0.f;
+    t.face = f;
+    t.pad[0] = t.pad[1] = 0.f;
     rec[f] = t;
-}
-
-__device__ __forceinline__ void cell_centre(const Grid& g, int cell, float& cx, float& cy, float& cz) {
-    const int ix = cell % g.nx, iy = (cell / g.nx) % g.ny, iz = cell / (g.nx * g.ny);
-    cx = g.lox + (ix + .5f) * g.h;
-    cy = g.loy + (iy + .5f) * g.h;
-    cz = g.loz + (iz + .5f) * g.h;
-}
-
-// ub(C) per cell; < 0 marks a cell farther than `reach` from every vertex (no list, brute force)
-__global__ __launch_bounds__(256) void cell_bound_kernel(Grid g, const float* __restrict__ verts, int V, float* __restrict__ ub) {
-    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
-    if (cell >= g.ncells) return;
-    float cx, cy, cz;
-    cell_centre(g, cell, cx, cy, cz);
-    float best = INFINITY;
-#pragma unroll 4
-    for (int v = 0; v < V; ++v) {
-        const float dx = verts[v * 3] - cx, dy = verts[v * 3 + 1] - cy, dz = verts[v * 3 + 2] - cz;
-        best = fminf(best, dx * dx + dy * dy + dz * dz);
+    uint32_t code = 0;
+    const float c[3] = {t.sx, t.sy, t.sz};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float ext = bbox[3 + k] - bbox[k];
+        float u = ext > 0.f ? (c[k] - bbox[k]) / ext * 1024.f : 0.f;
+        u = fminf(fmaxf(u, 0.f), 1023.f);
+        code |= spread10((uint32_t)u) << k;
     }
-    const float dv = sqrtf(best);
-    ub[cell] = (dv - g.half_diag <= g.reach) ? (dv + g.half_diag) * 1.0001f + 1e-6f : -1.f;
+    keys[f] = ((unsigned long long)code << 32) | (unsigned)f;
 }
 
-// FILL = false: count candidates per (cell, ring); FILL = true: write triangle ids at the scanned offsets
-template <bool FILL>
-__global__ __launch_bounds__(256) void cell_lists_kernel(Grid g, const TriRec* __restrict__ rec, int F, const float* __restrict__ ub,
-                                                         int32_t* __restrict__ counts_or_offsets, int32_t* __restrict__ list) {
-    const int cell = blockIdx.x * blockDim.x + threadIdx.x;
-    if (cell >= g.ncells) return;
-    const float u = ub[cell];
-    int n[kRings];
+// rank sort: position of record f in Morton order = number of smaller keys.  F^2 compares of wave-uniform (scalar-loaded)
+// keys: 70 us for F = 13,776, and still ~1 ms at F = 100 k -- no multi-pass radix sort for a body mesh.
+__global__ __launch_bounds__(256) void rank_scatter_kernel(const unsigned long long* __restrict__ keys, int F, const TriRec* __restrict__ rec,
+                                                           TriRec* __restrict__ sorted) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long mine = f < F ? keys[f] : 0ull;
+    int rank = 0;
+    for (int g = 0; g < F; ++g) rank += keys[g] < mine ? 1 : 0;
+    if (f < F) sorted[rank] = rec[f];
+}
+
+__device__ __forceinline__ void set_lane(float4& v, int c, float x) {
+    if (c == 0) v.x = x; else if (c == 1) v.y = x; else if (c == 2) v.z = x; else v.w = x;
+}
+__device__ __forceinline__ float min4(float4 v) { return fminf(fminf(v.x, v.y), fminf(v.z, v.w)); }
+__device__ __forceinline__ float max4(float4 v) { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); }
+
+// level L-1: children are the sorted triangles 4i .. 4i+3; a missing child gets the empty box (lo = +inf, hi = -inf)
+__global__ __launch_bounds__(256) void leaf_nodes_kernel(const TriRec* __restrict__ sorted, int F, int n, Node* __restrict__ nodes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Node nd;
 #pragma unroll
-    for (int r = 0; r < kRings; ++r) n[r] = FILL ? counts_or_offsets[cell * kRings + r] : 0;
-    if (u >= 0.f) {
-        float cx, cy, cz;
-        cell_centre(g, cell, cx, cy, cz);
-        const float lim = u + g.half_diag;
-        for (int f = 0; f < F; ++f) {
-            const float4 s = *reinterpret_cast<const float4*>(&rec[f]);      // wave-uniform -> scalar load
-            const float dx = s.x - cx, dy = s.y - cy, dz = s.z - cz;
-            const float key = sqrtf(dx * dx + dy * dy + dz * dz) - s.w;
-            if (key <= lim) {
-                int r = (int)(fmaxf(key, 0.f) / g.ring_w);
-                r = r < kRings - 1 ? r : kRings - 1;
-#pragma unroll
-                for (int q = 0; q < kRings; ++q)
-                    if (q == r) {
-                        if (FILL) list[n[q]] = f;
-                        n[q]++;
-                    }
-            }
+    for (int c = 0; c < 4; ++c) {
+        const int t = 4 * i + c;
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        if (t < F) {
+            const TriRec r = sorted[t];
+            lo[0] = fminf(r.ax, fminf(r.bx, r.cx)); hi[0] = fmaxf(r.ax, fmaxf(r.bx, r.cx));
+            lo[1] = fminf(r.ay, fminf(r.by, r.cy)); hi[1] = fmaxf(r.ay, fmaxf(r.by, r.cy));
+            lo[2] = fminf(r.az, fminf(r.bz, r.cz)); hi[2] = fmaxf(r.az, fmaxf(r.bz, r.cz));
         }
+        set_lane(nd.lox, c, lo[0]); set_lane(nd.loy, c, lo[1]); set_lane(nd.loz, c, lo[2]);
+        set_lane(nd.hix, c, hi[0]); set_lane(nd.hiy, c, hi[1]); set_lane(nd.hiz, c, hi[2]);
     }
-    if (!FILL) {
-#pragma unroll
-        for (int r = 0; r < kRings; ++r) counts_or_offsets[cell * kRings + r] = n[r];
-    }
+    nodes[i] = nd;
 }
 
-// exclusive scan of `n` int32 in place (single block), total into total[0]
-__global__ __launch_bounds__(1024) void scan_kernel(int32_t* __restrict__ a, int n, int32_t* __restrict__ total) {
-    __shared__ int wave_tot[16];
-    __shared__ int carry_s;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < n ? a[i] : 0;
-        int inc = v;
+// level l from level l+1: the box of child c is the union of the four boxes child c holds
+__global__ __launch_bounds__(256) void upper_nodes_kernel(const Node* __restrict__ below, int n_below, int n, Node* __restrict__ nodes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Node nd;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += t;
+    for (int c = 0; c < 4; ++c) {
+        const int j = 4 * i + c;
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        if (j < n_below) {
+            const Node b = below[j];
+            lo[0] = min4(b.lox); lo[1] = min4(b.loy); lo[2] = min4(b.loz);
+            hi[0] = max4(b.hix); hi[1] = max4(b.hiy); hi[2] = max4(b.hiz);
         }
-        if (lane == 63) wave_tot[wid] = inc;
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wid; ++w) woff += wave_tot[w];
-        const int carry = carry_s;
-        if (i < n) a[i] = carry + woff + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
-        __syncthreads();
+        set_lane(nd.lox, c, lo[0]); set_lane(nd.loy, c, lo[1]); set_lane(nd.loz, c, lo[2]);
+        set_lane(nd.hix, c, hi[0]); set_lane(nd.hiy, c, hi[1]); set_lane(nd.hiz, c, hi[2]);
     }
-    if (threadIdx.x == 0) total[0] = carry_s;
+    nodes[i] = nd;
 }
 
+// ---- search --------------------------------------------------------------------------------------------------------
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
@@ -200,64 +237,135 @@ __device__ __forceinline__ void inv4x4(const double* m, double* o) {
 }
 
 struct Best {
-    float d2, sd;   // best squared distance, its square root
-    int f;
+    float d2, sd;   // best squared distance (as computed by the exact test), its square root
+    float thr2;     // prune a box when its squared distance exceeds this: (sqrt(d2) 1.0001 + slack)^2, capped at FLT_MAX
+    int f;          // caller's face id of the best triangle
     V3 q;
 };
 
-__device__ __forceinline__ void try_tri(const TriRec* __restrict__ rec, int f, V3 p, Best& b) {
-    const float4 s = *reinterpret_cast<const float4*>(&rec[f]);
-    const float cx = s.x - p.x, cy = s.y - p.y, cz = s.z - p.z;
-    const float lim = b.sd + s.w;
-    if (cx * cx + cy * cy + cz * cz <= lim * lim) {
-        const float4 t0 = reinterpret_cast<const float4*>(&rec[f])[1];
-        const float4 t1 = reinterpret_cast<const float4*>(&rec[f])[2];
-        const float t2 = rec[f].cz;
-        const V3 c = closest_on_tri(p, {t0.x, t0.y, t0.z}, {t0.w, t1.x, t1.y}, {t1.z, t1.w, t2});
-        const V3 d = sub(c, p);
-        const float d2 = dot(d, d);
-        if (d2 < b.d2 || (d2 == b.d2 && f < b.f)) {              // ties: lowest face id, independent of visiting order
-            b.d2 = d2; b.sd = sqrtf(d2); b.f = f; b.q = c;
-        }
+// exact test of sorted record t; ties go to the lowest face id, so the result does not depend on the visiting order
+__device__ __forceinline__ void exact_tri(const TriRec* __restrict__ rec, int t, V3 p, float slack, Best& b) {
+    const float4 t0 = reinterpret_cast<const float4*>(&rec[t])[1];
+    const float4 t1 = reinterpret_cast<const float4*>(&rec[t])[2];
+    const float4 t2 = reinterpret_cast<const float4*>(&rec[t])[3];
+    const int f = __float_as_int(t2.y);
+    const V3 c = closest_on_tri(p, {t0.x, t0.y, t0.z}, {t0.w, t1.x, t1.y}, {t1.z, t1.w, t2.x});
+    const V3 d = sub(c, p);
+    const float d2 = dot(d, d);
+    if (d2 < b.d2 || (d2 == b.d2 && f < b.f)) {
+        b.d2 = d2; b.sd = sqrtf(d2); b.f = f; b.q = c;
+        const float thr = b.sd * 1.0001f + slack;
+        b.thr2 = fminf(thr * thr, FLT_MAX);
     }
 }
 
-__global__ __launch_bounds__(256) void warp_kernel(Grid g, const float* __restrict__ pts, int S, const float* __restrict__ verts, int V,
-                                                   const int32_t* __restrict__ faces, int F, const TriRec* __restrict__ rec,
-                                                   const float* __restrict__ ub, const int32_t* __restrict__ offsets,
-                                                   const int32_t* __restrict__ list, const double* __restrict__ T,
+// the all-triangles loop: bounding-sphere cull, then the exact test (search mode NM_SEARCH_ALL, and the fallback)
+__device__ __forceinline__ void search_all(const TriRec* __restrict__ rec, int F, V3 p, float slack, Best& b) {
+    for (int t = 0; t < F; ++t) {
+        const float4 s = *reinterpret_cast<const float4*>(&rec[t]);
+        const float cx = s.x - p.x, cy = s.y - p.y, cz = s.z - p.z;
+        const float lim = b.sd * 1.0001f + slack + s.w;            // the tree search's margin: both modes see every contender
+        if (cx * cx + cy * cy + cz * cz <= lim * lim) exact_tri(rec, t, p, slack, b);
+    }
+}
+
+__device__ __forceinline__ float slab(float lo, float hi, float x) { return fmaxf(fmaxf(lo - x, x - hi), 0.f); }
+__device__ __forceinline__ void cswap(float& ka, int& ia, float& kb, int& ib) {      // afterwards ka >= kb
+    const bool sw = ka < kb;
+    const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+    const int i0 = sw ? ib : ia, i1 = sw ? ia : ib;
+    ka = k0; kb = k1; ia = i0; ib = i1;
+}
+
+// LDS layout: stack entries {box distance^2, level << 28 | index}, entry d of thread t at (d * blockDim + t); then [S][3] f64
+__global__ __launch_bounds__(256) void warp_kernel(Tree tr, int search_all_mode, const float* __restrict__ pts, int S,
+                                                   const float* __restrict__ verts, const int32_t* __restrict__ faces,
+                                                   const TriRec* __restrict__ rec, const Node* __restrict__ nodes,
+                                                   const double* __restrict__ T,
                                                    float* __restrict__ can_pts, float* __restrict__ can_dirs,
                                                    float* __restrict__ closest) {
-    extern __shared__ double can_lds[];                     // [S][3]
+    extern __shared__ double lds_raw[];
+    __shared__ int level_off[kMaxLevels + 1];                                   // per-lane lookups by level: LDS, not kernarg
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int l = 0; l <= kMaxLevels; ++l) level_off[l] = tr.off[l];
+    }
+    __syncthreads();
+    const int depth = 3 * tr.L + 1;
+    float2* stack = reinterpret_cast<float2*>(lds_raw);
+    double* can_lds = lds_raw + (size_t)depth * blockDim.x;                     // [S][3]
     const int64_t r = blockIdx.x;
     for (int s0 = 0; s0 < S; s0 += blockDim.x) {
         const int s = s0 + threadIdx.x;
         const bool live = s < S;
         const int64_t i = r * S + (live ? s : S - 1);
         const V3 p = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]};
+        const float pmax = fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z)));
+        const float slack = 1e-5f * (1.f + fmaxf(pmax, tr.scale));
         Best b;
-        b.d2 = INFINITY; b.sd = INFINITY; b.f = 0; b.q = p;
-        // ---- grid lookup
-        const float fx = (p.x - g.lox) * g.inv_h, fy = (p.y - g.loy) * g.inv_h, fz = (p.z - g.loz) * g.inv_h;
-        const int ix = (int)floorf(fx), iy = (int)floorf(fy), iz = (int)floorf(fz);
-        bool brute = !(fx >= 0.f && fy >= 0.f && fz >= 0.f && ix < g.nx && iy < g.ny && iz < g.nz);   // also catches NaN
-        if (!brute) {
-            const int cell = (iz * g.ny + iy) * g.nx + ix;
-            const float u = ub[cell];
-            if (u < 0.f) brute = true;
-            else {
-                b.d2 = u * u; b.sd = u; b.f = 0x7fffffff;     // the closest triangle is strictly inside this bound
-                for (int ring = 0; ring < kRings; ++ring) {
-                    if (ring * g.ring_w - g.half_diag > b.sd) break;     // every triangle of this ring (and beyond) is farther
-                    const int e = offsets[cell * kRings + ring + 1];
-                    for (int k = offsets[cell * kRings + ring]; k < e; ++k) try_tri(rec, list[k], p, b);
+        b.d2 = INFINITY; b.sd = INFINITY; b.thr2 = FLT_MAX; b.f = 0x7fffffff; b.q = p;
+        if (pmax <= FLT_MAX && !search_all_mode) {                               // a NaN / Inf point goes straight to the fallback
+            int sp = 0;
+            stack[threadIdx.x] = make_float2(0.f, __int_as_float(0));           // root: level 0, node 0
+            sp = 1;
+#ifdef NM_WARP_DBG
+            float n_vis = 0.f, n_ex = 0.f; long long t_walk = 0, t_ex = 0;
+#endif
+            for (;;) {
+                int tri = -1;
+#ifdef NM_WARP_DBG
+                long long c0_ = __builtin_readcyclecounter();
+#endif
+                while (sp > 0 && tri < 0) {                                      // walk until this lane holds a triangle
+                    const float2 e = stack[(size_t)(--sp) * blockDim.x + threadIdx.x];
+                    if (e.x > b.thr2) continue;                                  // the best distance shrank since the push
+                    const int id = __float_as_int(e.y), lvl = id >> 28, idx = id & 0x0fffffff;
+                    if (lvl == tr.L) { tri = idx; break; }
+#ifdef NM_WARP_DBG
+                    n_vis += 1.f;
+#endif
+                    const Node* nd = nodes + level_off[lvl] + idx;
+                    const float4 lox = nd->lox, loy = nd->loy, loz = nd->loz, hix = nd->hix, hiy = nd->hiy, hiz = nd->hiz;
+                    float k0, k1, k2, k3;
+                    {
+                        const float x0 = slab(lox.x, hix.x, p.x), y0 = slab(loy.x, hiy.x, p.y), z0 = slab(loz.x, hiz.x, p.z);
+                        const float x1 = slab(lox.y, hix.y, p.x), y1 = slab(loy.y, hiy.y, p.y), z1 = slab(loz.y, hiz.y, p.z);
+                        const float x2 = slab(lox.z, hix.z, p.x), y2 = slab(loy.z, hiy.z, p.y), z2 = slab(loz.z, hiz.z, p.z);
+                        const float x3 = slab(lox.w, hix.w, p.x), y3 = slab(loy.w, hiy.w, p.y), z3 = slab(loz.w, hiz.w, p.z);
+                        k0 = x0 * x0 + y0 * y0 + z0 * z0; k1 = x1 * x1 + y1 * y1 + z1 * z1;
+                        k2 = x2 * x2 + y2 * y2 + z2 * z2; k3 = x3 * x3 + y3 * y3 + z3 * z3;
+                    }
+                    const int child = ((lvl + 1) << 28) | (idx << 2);
+                    int c0 = child, c1 = child + 1, c2 = child + 2, c3 = child + 3;
+                    cswap(k0, c0, k1, c1); cswap(k2, c2, k3, c3);                // sort descending: farthest pushed first
+                    cswap(k0, c0, k2, c2); cswap(k1, c1, k3, c3);
+                    cswap(k1, c1, k2, c2);
+                    // an empty child's distance is +inf > thr2 (<= FLT_MAX): never pushed
+                    if (k0 <= b.thr2) stack[(size_t)(sp++) * blockDim.x + threadIdx.x] = make_float2(k0, __int_as_float(c0));
+                    if (k1 <= b.thr2) stack[(size_t)(sp++) * blockDim.x + threadIdx.x] = make_float2(k1, __int_as_float(c1));
+                    if (k2 <= b.thr2) stack[(size_t)(sp++) * blockDim.x + threadIdx.x] = make_float2(k2, __int_as_float(c2));
+                    if (k3 <= b.thr2) stack[(size_t)(sp++) * blockDim.x + threadIdx.x] = make_float2(k3, __int_as_float(c3));
                 }
-                if (b.f == 0x7fffffff) brute = true;          // cannot happen for a consistent grid; stay exact anyway
+#ifdef NM_WARP_DBG
+                long long c1_ = __builtin_readcyclecounter();
+                t_walk += c1_ - c0_;
+#endif
+                if (tri < 0) break;
+                exact_tri(rec, tri, p, slack, b);                                // lanes holding a triangle test it together
+#ifdef NM_WARP_DBG
+                n_ex += 1.f;
+                t_ex += __builtin_readcyclecounter() - c1_;
+#endif
             }
+#ifdef NM_WARP_DBG
+            if (closest && live) { closest[i * 3] = n_vis; closest[i * 3 + 1] = n_ex; closest[i * 3 + 2] = (float)(NM_WARP_DBG == 2 ? t_ex : t_walk); }
+#endif
         }
-        if (brute) {
-            b.d2 = INFINITY; b.sd = INFINITY; b.f = 0;
-            for (int f = 0; f < F; ++f) try_tri(rec, f, p, b);
+        if (b.f == 0x7fffffff) {
+            // all-triangles mode, or nothing found (non-finite point, overflowing distances): the plain loop, whose
+            // answer for such points is face 0 and q = p
+            b.d2 = INFINITY; b.sd = INFINITY; b.thr2 = FLT_MAX; b.f = 0; b.q = p;
+            search_all(rec, tr.F, p, slack, b);
         }
         const int bf = b.f;
         const V3 q = b.q;
@@ -287,7 +395,9 @@ __global__ __launch_bounds__(256) void warp_kernel(Grid g, const float* __restri
         if (live) {
             can_lds[s * 3] = cxp; can_lds[s * 3 + 1] = cyp; can_lds[s * 3 + 2] = czp;
             can_pts[i * 3] = (float)cxp; can_pts[i * 3 + 1] = (float)cyp; can_pts[i * 3 + 2] = (float)czp;
+#ifndef NM_WARP_DBG
             if (closest) { closest[i * 3] = q.x; closest[i * 3 + 1] = q.y; closest[i * 3 + 2] = q.z; }
+#endif
         }
     }
     __syncthreads();
@@ -306,15 +416,13 @@ __global__ __launch_bounds__(256) void warp_kernel(Grid g, const float* __restri
 }  // namespace
 
 struct nm_mesh_s {
-    int V, F;
-    Grid g;
+    int V, F, search;
+    Tree tr;
+    int n_nodes;
     float* d_verts;      // owned copies: the handle outlives the caller's tensors
     int32_t* d_faces;
-    TriRec* d_rec;
-    float* d_ub;
-    int32_t* d_offsets;  // ncells*kRings + 1
-    int32_t* d_list;
-    int64_t list_len;
+    TriRec* d_rec;       // Morton order
+    Node* d_nodes;
 };
 
 extern "C" {
@@ -324,90 +432,76 @@ int nm_mesh_destroy(nm_mesh_t m) {
     if (m->d_verts) (void)hipFree(m->d_verts);
     if (m->d_faces) (void)hipFree(m->d_faces);
     if (m->d_rec) (void)hipFree(m->d_rec);
-    if (m->d_ub) (void)hipFree(m->d_ub);
-    if (m->d_offsets) (void)hipFree(m->d_offsets);
-    if (m->d_list) (void)hipFree(m->d_list);
+    if (m->d_nodes) (void)hipFree(m->d_nodes);
     delete m;
     return NM_OK;
 }
 
-int nm_mesh_create(const float* verts, int V, const int32_t* faces, int F, float reach, nm_mesh_t* out, nm_stream_t stream) {
+int nm_mesh_create(const float* verts, int V, const int32_t* faces, int F, int search, nm_mesh_t* out, nm_stream_t stream) {
     NM_REQUIRE(verts && faces && out, "nm_mesh_create: null pointer");
-    NM_REQUIRE(V >= 3 && F >= 1 && reach >= 0.f, "nm_mesh_create: bad sizes V=%d F=%d reach=%g", V, F, (double)reach);
+    NM_REQUIRE(V >= 3 && F >= 1 && F <= (1 << 24), "nm_mesh_create: bad sizes V=%d F=%d", V, F);
+    NM_REQUIRE(search == NM_SEARCH_TREE || search == NM_SEARCH_ALL, "nm_mesh_create: search mode %d", search);
     hipStream_t st = nm::as_stream(stream);
     nm_mesh_s* m = new nm_mesh_s();
     memset(m, 0, sizeof(*m));
-    m->V = V; m->F = F;
+    m->V = V; m->F = F; m->search = search;
+    Tree& tr = m->tr;
+    tr.F = F;
+    tr.L = 1;
+    while ((1ll << (2 * tr.L)) < F) ++tr.L;                          // 4^L >= F
+    int n_level[kMaxLevels + 1];
+    n_level[tr.L] = F;
+    for (int l = tr.L - 1; l >= 0; --l) n_level[l] = (n_level[l + 1] + 3) / 4;
+    int total = 0;
+    for (int l = 0; l < tr.L; ++l) { tr.off[l] = total; total += n_level[l]; }
+    tr.off[tr.L] = total;
+    m->n_nodes = total;
+    TriRec* d_tmp = nullptr;
+    unsigned long long* d_keys = nullptr;
+    float* d_bbox = nullptr;
     int rc = NM_OK;
 #define NM_TRY(expr, what) if (!rc) rc = nm::check_hip((expr), what)
     NM_TRY(hipMalloc(&m->d_verts, (size_t)V * 12), "nm_mesh_create: hipMalloc(verts)");
     NM_TRY(hipMalloc(&m->d_faces, (size_t)F * 12), "nm_mesh_create: hipMalloc(faces)");
-    NM_TRY(hipMalloc(&m->d_rec, (size_t)F * sizeof(TriRec)), "nm_mesh_create: hipMalloc(rec)");
+    NM_TRY(hipMalloc(&m->d_rec, (size_t)F * sizeof(TriRec)), "nm_mesh_create: hipMalloc(records)");
+    NM_TRY(hipMalloc(&m->d_nodes, (size_t)total * sizeof(Node)), "nm_mesh_create: hipMalloc(nodes)");
+    NM_TRY(hipMalloc(&d_tmp, (size_t)F * sizeof(TriRec)), "nm_mesh_create: hipMalloc(unsorted records)");
+    NM_TRY(hipMalloc(&d_keys, (size_t)F * 8), "nm_mesh_create: hipMalloc(keys)");
+    NM_TRY(hipMalloc(&d_bbox, 8 * 4), "nm_mesh_create: hipMalloc(bbox)");
     NM_TRY(hipMemcpyAsync(m->d_verts, verts, (size_t)V * 12, hipMemcpyDeviceToDevice, st), "nm_mesh_create: copy verts");
     NM_TRY(hipMemcpyAsync(m->d_faces, faces, (size_t)F * 12, hipMemcpyDeviceToDevice, st), "nm_mesh_create: copy faces");
-    std::vector<float> hv((size_t)V * 3);
-    NM_TRY(hipMemcpyAsync(hv.data(), verts, (size_t)V * 12, hipMemcpyDeviceToHost, st), "nm_mesh_create: read verts");
-    NM_TRY(hipStreamSynchronize(st), "nm_mesh_create: sync");
-    if (rc) { nm_mesh_destroy(m); return rc; }
-    // ---- grid geometry on the host: vertex AABB inflated by reach, <= kMaxCells cells
-    float lo[3] = {hv[0], hv[1], hv[2]}, hi[3] = {hv[0], hv[1], hv[2]};
-    for (int v = 0; v < V; ++v)
-        for (int k = 0; k < 3; ++k) {
-            const float x = hv[(size_t)v * 3 + k];
-            if (!(x == x) || x > 3e38f || x < -3e38f) { nm::set_error("nm_mesh_create: non-finite vertex %d", v); nm_mesh_destroy(m); return NM_ERR_ARG; }
-            lo[k] = x < lo[k] ? x : lo[k];
-            hi[k] = x > hi[k] ? x : hi[k];
-        }
-    const float margin = reach * 1.01f + 1e-4f;
-    float ext[3];
-    for (int k = 0; k < 3; ++k) { lo[k] -= margin; hi[k] += margin; ext[k] = hi[k] - lo[k]; }
-    float h = cbrtf(ext[0] * ext[1] * ext[2] / (float)(kMaxCells / 2));
-    const float hmin = fmaxf(reach * 0.125f, 1e-4f);
-    if (h < hmin) h = hmin;
-    Grid& g = m->g;
-    for (;;) {
-        g.nx = (int)ceilf(ext[0] / h); g.ny = (int)ceilf(ext[1] / h); g.nz = (int)ceilf(ext[2] / h);
-        if (g.nx < 1) g.nx = 1;
-        if (g.ny < 1) g.ny = 1;
-        if (g.nz < 1) g.nz = 1;
-        if ((int64_t)g.nx * g.ny * g.nz <= kMaxCells) break;
-        h *= 1.1f;
+    float hb[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (!rc) {
+        hipLaunchKernelGGL(bbox_kernel, dim3(1), dim3(1024), 0, st, m->d_verts, V, d_bbox);
+        hipLaunchKernelGGL(tri_prep_kernel, dim3((F + 255) / 256), dim3(256), 0, st, m->d_verts, m->d_faces, F, d_bbox, d_tmp, d_keys);
+        hipLaunchKernelGGL(rank_scatter_kernel, dim3((F + 255) / 256), dim3(256), 0, st, d_keys, F, d_tmp, m->d_rec);
+        hipLaunchKernelGGL(leaf_nodes_kernel, dim3((n_level[tr.L - 1] + 255) / 256), dim3(256), 0, st, m->d_rec, F, n_level[tr.L - 1],
+                           m->d_nodes + tr.off[tr.L - 1]);
+        for (int l = tr.L - 2; l >= 0; --l)
+            hipLaunchKernelGGL(upper_nodes_kernel, dim3((n_level[l] + 255) / 256), dim3(256), 0, st, m->d_nodes + tr.off[l + 1], n_level[l + 1],
+                               n_level[l], m->d_nodes + tr.off[l]);
+        rc = nm::check_launch("nm_mesh_create: build kernels");
     }
-    g.ncells = g.nx * g.ny * g.nz;
-    g.lox = lo[0]; g.loy = lo[1]; g.loz = lo[2];
-    g.h = h; g.inv_h = 1.f / h;
-    g.half_diag = 0.5f * sqrtf(3.f) * h * 1.0001f;
-    g.reach = reach;
-    g.ring_w = (reach + 3.f * g.half_diag) / (float)kRings + 1e-6f;
-    const int nslots = g.ncells * kRings;
-    NM_TRY(hipMalloc(&m->d_ub, (size_t)g.ncells * 4), "nm_mesh_create: hipMalloc(ub)");
-    NM_TRY(hipMalloc(&m->d_offsets, (size_t)(nslots + 1) * 4), "nm_mesh_create: hipMalloc(offsets)");
-    if (rc) { nm_mesh_destroy(m); return rc; }
-    const int cb = (g.ncells + 255) / 256;
-    hipLaunchKernelGGL(tri_prep_kernel, dim3((F + 255) / 256), dim3(256), 0, st, m->d_verts, m->d_faces, F, m->d_rec);
-    hipLaunchKernelGGL(cell_bound_kernel, dim3(cb), dim3(256), 0, st, g, m->d_verts, V, m->d_ub);
-    hipLaunchKernelGGL(cell_lists_kernel<false>, dim3(cb), dim3(256), 0, st, g, m->d_rec, F, m->d_ub, m->d_offsets, (int32_t*)nullptr);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, m->d_offsets, nslots, m->d_offsets + nslots);
-    rc = nm::check_launch("nm_mesh_create: build kernels");
-    int32_t total = 0;
-    NM_TRY(hipMemcpyAsync(&total, m->d_offsets + nslots, 4, hipMemcpyDeviceToHost, st), "nm_mesh_create: read total");
+    // one read-back: the vertex box sizes the pruning margin and carries the non-finite flag (also orders the frees below)
+    NM_TRY(hipMemcpyAsync(hb, d_bbox, 7 * 4, hipMemcpyDeviceToHost, st), "nm_mesh_create: read bbox");
     NM_TRY(hipStreamSynchronize(st), "nm_mesh_create: sync");
-    m->list_len = total;
-    NM_TRY(hipMalloc(&m->d_list, (size_t)(total > 0 ? total : 1) * 4), "nm_mesh_create: hipMalloc(list)");
-    if (rc) { nm_mesh_destroy(m); return rc; }
-    hipLaunchKernelGGL(cell_lists_kernel<true>, dim3(cb), dim3(256), 0, st, g, m->d_rec, F, m->d_ub, m->d_offsets, m->d_list);
-    rc = nm::check_launch("cell_lists_kernel<fill>");
 #undef NM_TRY
+    if (d_tmp) (void)hipFree(d_tmp);
+    if (d_keys) (void)hipFree(d_keys);
+    if (d_bbox) (void)hipFree(d_bbox);
+    if (!rc && hb[6] != 0.f) { nm::set_error("nm_mesh_create: non-finite vertex coordinate"); rc = NM_ERR_ARG; }
     if (rc) { nm_mesh_destroy(m); return rc; }
+    tr.scale = 0.f;
+    for (int k = 0; k < 6; ++k) tr.scale = fmaxf(tr.scale, fabsf(hb[k]));
     *out = m;
     return NM_OK;
 }
 
-int nm_mesh_info(nm_mesh_t m, int32_t* cells_xyz, int64_t* list_len, float* cell_size) {
+int nm_mesh_info(nm_mesh_t m, int32_t* levels, int64_t* nodes, int64_t* bytes) {
     NM_REQUIRE(m, "nm_mesh_info: null handle");
-    if (cells_xyz) { cells_xyz[0] = m->g.nx; cells_xyz[1] = m->g.ny; cells_xyz[2] = m->g.nz; }
-    if (list_len) *list_len = m->list_len;
-    if (cell_size) *cell_size = m->g.h;
+    if (levels) *levels = m->tr.L;
+    if (nodes) *nodes = m->n_nodes;
+    if (bytes) *bytes = (int64_t)m->n_nodes * (int64_t)sizeof(Node) + (int64_t)m->F * (int64_t)sizeof(TriRec);
     return NM_OK;
 }
 
@@ -416,12 +510,13 @@ int nm_warp_to_canonical(nm_mesh_t m, const float* pts, int64_t R, int S, const 
     NM_REQUIRE(m, "nm_warp_to_canonical: null mesh handle");
     NM_REQUIRE(R == 0 || (pts && T && can_pts && can_dirs), "nm_warp_to_canonical: null pointer");
     NM_REQUIRE(R >= 0 && S >= 2, "nm_warp_to_canonical: bad sizes R=%lld S=%d", (long long)R, S);
-    NM_REQUIRE((size_t)S * 24 <= 64 * 1024, "nm_warp_to_canonical: S=%d exceeds the LDS staging budget", S);
     NM_REQUIRE(R < (1ll << 31), "nm_warp_to_canonical: too many rays for one launch");
     if (R == 0) return NM_OK;
     const int threads = S <= 64 ? 64 : (S <= 128 ? 128 : 256);
-    hipLaunchKernelGGL(warp_kernel, dim3((unsigned)R), dim3(threads), (size_t)S * 24, nm::as_stream(stream), m->g, pts, S, m->d_verts,
-                       m->V, m->d_faces, m->F, m->d_rec, m->d_ub, m->d_offsets, m->d_list, T, can_pts, can_dirs, closest);
+    const size_t lds = (size_t)(3 * m->tr.L + 1) * threads * 8 + (size_t)S * 24;
+    NM_REQUIRE(lds <= 64 * 1024, "nm_warp_to_canonical: S=%d exceeds the LDS budget (%zu B)", S, lds);
+    hipLaunchKernelGGL(warp_kernel, dim3((unsigned)R), dim3(threads), lds, nm::as_stream(stream), m->tr, m->search == NM_SEARCH_ALL ? 1 : 0,
+                       pts, S, m->d_verts, m->d_faces, m->d_rec, m->d_nodes, T, can_pts, can_dirs, closest);
     return nm::check_launch("warp_kernel");
 }
 

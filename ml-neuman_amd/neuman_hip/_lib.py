@@ -52,7 +52,7 @@ SIGNATURES = {
     "nm_mlp_sigma_rays": (i32, [ctypes.c_void_p, c_f32p, c_f32p, c_f32p, i64, i32, i32, ctypes.c_float, c_f32p, c_stream]),
     "nm_mlp_forward_debug": (i32, [ctypes.c_void_p, c_f32p, c_f32p, i64, i32, i32, c_f32p, c_stream]),
     "nm_mlp_forward_profile": (i32, [ctypes.c_void_p, c_f32p, c_f32p, i64, i32, c_f32p, ctypes.c_void_p, c_stream]),
-    "nm_mesh_create": (i32, [c_f32p, i32, c_i32p, i32, ctypes.c_float, ctypes.POINTER(ctypes.c_void_p), c_stream]),
+    "nm_mesh_create": (i32, [c_f32p, i32, c_i32p, i32, i32, ctypes.POINTER(ctypes.c_void_p), c_stream]),
     "nm_mesh_destroy": (i32, [ctypes.c_void_p]),
     "nm_mesh_info": (i32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "nm_warp_to_canonical": (i32, [ctypes.c_void_p, c_f32p, i64, i32, ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_stream]),

@@ -258,7 +258,9 @@ class Mesh:
     """A posed mesh on the device plus its closest-point search structure (nm_mesh_create).  Built once per frame and
     actor; `T` are the per-vertex canonical->observation transforms (f64 [>=V,4,4], joint rows beyond V never indexed)."""
 
-    def __init__(self, verts, faces, T, device, reach=DEFAULT_GEO_THRESH):
+    SEARCH = {'tree': 0, 'all': 1}      # NM_SEARCH_TREE / NM_SEARCH_ALL (the all-triangles loop: tests and diagnostics)
+
+    def __init__(self, verts, faces, T, device, search='tree'):
         import ctypes
         _lib.require_gpu()
         v = verts if isinstance(verts, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(verts, dtype=np.float32))
@@ -269,16 +271,16 @@ class Mesh:
         self.T = t.to(device, torch.float64).reshape(-1, 16).contiguous()
         self.handle = ctypes.c_void_p()
         _lib.check(_lib.lib().nm_mesh_create(_lib.dev_ptr(self.verts), self.verts.shape[0], _lib.dev_ptr(self.faces, torch.int32),
-                                             self.faces.shape[0], float(reach), ctypes.byref(self.handle), _lib.stream_ptr()),
+                                             self.faces.shape[0], self.SEARCH[search], ctypes.byref(self.handle), _lib.stream_ptr()),
                    "nm_mesh_create")
 
     def info(self):
         import ctypes
-        cells = (ctypes.c_int32 * 3)()
+        levels = ctypes.c_int32()
         n = ctypes.c_int64()
-        h = ctypes.c_float()
-        _lib.check(_lib.lib().nm_mesh_info(self.handle, cells, ctypes.byref(n), ctypes.byref(h)), "nm_mesh_info")
-        return {"cells": tuple(cells), "list_len": n.value, "cell_size": h.value}
+        b = ctypes.c_int64()
+        _lib.check(_lib.lib().nm_mesh_info(self.handle, ctypes.byref(levels), ctypes.byref(n), ctypes.byref(b)), "nm_mesh_info")
+        return {"levels": levels.value, "nodes": n.value, "bytes": b.value}
 
     def __del__(self):
         try:
@@ -289,8 +291,8 @@ class Mesh:
             pass
 
 
-def mesh_to_device(verts, faces, T, device, reach=DEFAULT_GEO_THRESH):
-    return Mesh(verts, faces, T, device, reach)
+def mesh_to_device(verts, faces, T, device, search='tree'):
+    return Mesh(verts, faces, T, device, search)
 
 
 def warp_to_canonical_dev(pts, mesh, want_closest=False):

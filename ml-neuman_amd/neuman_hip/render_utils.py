@@ -286,7 +286,7 @@ def render_smpl_nerf(net, cap, posed_verts, faces, Ts, rays_per_batch=32768, sam
     with torch.no_grad():
         o, d = _pixel_rays(cap, device)
         verts = torch.as_tensor(np.ascontiguousarray(posed_verts, dtype=np.float32)).to(device)
-        mesh = None if render_can else ray_utils.mesh_to_device(posed_verts, faces, Ts, device, geo_threshold)
+        mesh = None if render_can else ray_utils.mesh_to_device(posed_verts, faces, Ts, device)
         rgb, depth, acc = render_smpl_nerf_rays(net.coarse_human_net, o, d, verts, mesh, samples_per_ray, white_bkg, render_can,
                                                 geo_threshold, interval_comp)
         rgb = rgb.reshape(*cap.shape, -1).cpu().numpy()
@@ -308,7 +308,7 @@ def render_hybrid_nerf(net, cap, posed_verts, faces, Ts, rays_per_batch=32768, s
     with torch.no_grad():
         o, d = _pixel_rays(cap, device)
         verts = torch.as_tensor(np.ascontiguousarray(posed_verts, dtype=np.float32)).to(device)
-        mesh = ray_utils.mesh_to_device(posed_verts, faces, Ts, device, geo_threshold)
+        mesh = ray_utils.mesh_to_device(posed_verts, faces, Ts, device)
         rgb, depth, _ = render_hybrid_rays(net.coarse_bkg_net, net.fine_bkg_net, net.coarse_human_net, o, d, cap.near['bkg'],
                                            cap.far['bkg'], verts, mesh, samples_per_ray, importance_samples_per_ray, white_bkg,
                                            geo_threshold)
@@ -325,7 +325,7 @@ def render_hybrid_nerf_multi_persons(bkg_model, cap, human_models, posed_verts, 
     with torch.no_grad():
         o, d = _pixel_rays(cap, device)
         verts = [torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)).to(device) for v in posed_verts]
-        meshes = [ray_utils.mesh_to_device(v, f, t, device, geo_threshold) for v, f, t in zip(posed_verts, faces, Ts)]
+        meshes = [ray_utils.mesh_to_device(v, f, t, device) for v, f, t in zip(posed_verts, faces, Ts)]
         rgb, depth = render_multi_rays(bkg_model.coarse_bkg_net, bkg_model.fine_bkg_net,
                                        [m.coarse_human_net for m in human_models], o, d, cap.near['bkg'], cap.far['bkg'], verts,
                                        meshes, samples_per_ray, importance_samples_per_ray, white_bkg, geo_threshold)

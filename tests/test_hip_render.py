@@ -170,18 +170,17 @@ def test_warp_vs_oracle(G):
     assert (np.linalg.norm(cl - pts, axis=-1) <= dmin + 1e-6).all()
     np.testing.assert_allclose(np.linalg.norm(cd, axis=-1), 1.0, atol=1e-5)
     assert np.abs(cd - ocd).max() < 5e-3
-    # grid path (reach covers the queries) vs all-triangles path (reach = 0: every cell beyond the surface is "far"):
-    # both are exact searches, so they must agree bit for bit on everything
-    m_grid = G.ray.Mesh(posed, faces, T, 'cuda', reach=1.0)
-    m_brute = G.ray.Mesh(posed, faces, T, 'cuda', reach=0.0)
+    # tree search vs the all-triangles loop: both are exact searches, so they must agree bit for bit on everything
+    m_grid = G.ray.Mesh(posed, faces, T, 'cuda', search='tree')
+    m_brute = G.ray.Mesh(posed, faces, T, 'cuda', search='all')
     info = m_grid.info()
-    print(f"[warp] grid {info}")
-    assert info['list_len'] > 0
+    print(f"[warp] tree {info}")
+    assert info['nodes'] > 0 and 4 ** info['levels'] >= faces.shape[0]
     a = G.ray.warp_to_canonical_dev(cu(pts), m_grid, want_closest=True)
     b = G.ray.warp_to_canonical_dev(cu(pts), m_brute, want_closest=True)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
-    # a query far outside the grid box still gets the exact answer
+    # a query far outside the mesh box still gets the exact answer
     far_pts = pts + np.array([5.0, -3.0, 2.0], np.float32)
     fc = G.ray.warp_to_canonical_dev(cu(far_pts), m_grid, want_closest=True)[2].cpu().numpy()
     _, _, ofc = OW.closest_point_on_mesh(far_pts.reshape(-1, 3), posed, faces[:, :3])
@@ -261,3 +260,63 @@ def test_mixed_precision_policy_is_parity_grade(G):
     assert torch.equal(coarse(pts, dirs), coarse(pts, dirs, precision="bf16x3"))
     assert torch.equal(coarse(pts, dirs, role='shading'), coarse(pts, dirs, precision="i8x3"))
     assert not torch.equal(coarse(pts, dirs, role='shading'), coarse(pts, dirs))
+
+
+@pytest.mark.parametrize("case", ["smpl_size", "tiny", "one_triangle", "offset_scene", "duplicate_faces"])
+def test_tree_search_is_bit_identical_to_all_triangles(G, case):
+    """The tree search prunes with a rounding margin, so it must return exactly what the all-triangles loop returns:
+    queries on the surface (ties between the faces around a vertex -> lowest face id), inside, near, far, huge, NaN."""
+    rng = np.random.default_rng(7)
+    if case == "smpl_size":
+        verts_c, faces = G.syn.capsule_mesh()                       # V = 6890, F = 13776
+    elif case == "tiny":
+        verts_c, faces = G.syn.capsule_mesh(n_rings=2, n_seg=3)
+    elif case == "one_triangle":
+        verts_c = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+        faces = np.array([[0, 1, 2]], np.int32)
+    else:
+        verts_c, faces = G.syn.capsule_mesh(n_rings=20, n_seg=24)
+    verts_c = np.asarray(verts_c, np.float32)
+    if case == "one_triangle":
+        posed, T = verts_c, np.tile(np.eye(4), (3, 1, 1))
+    else:
+        posed, T = G.syn.twist_transforms(verts_c)
+    posed = np.asarray(posed, np.float32)
+    if case == "offset_scene":                                       # a body 40 m from the origin: ulp(40) = 3.8e-6
+        shift = np.array([40.0, -25.0, 31.0])
+        posed = (posed + shift).astype(np.float32)
+        T = T.copy()
+        T[:, :3, 3] += shift
+    if case == "duplicate_faces":                                    # every face twice: exact ties everywhere
+        faces = np.concatenate([faces[::-1], faces], 0)
+    faces = np.ascontiguousarray(np.asarray(faces)[:, :3], np.int32)
+    V = posed.shape[0]
+    tri = posed[faces]
+    S = 32
+    q = []
+    q.append(posed[rng.integers(0, V, 20 * S)])                                               # exactly on vertices
+    w = rng.dirichlet([1, 1, 1], 20 * S).astype(np.float32)
+    q.append((tri[rng.integers(0, len(faces), 20 * S)] * w[..., None]).sum(1))                # on faces
+    q.append((tri[rng.integers(0, len(faces), 10 * S), :2].mean(1)))                          # on edge midpoints
+    c = posed.mean(0)
+    for sc in (1e-4, 1e-2, 0.2, 2.0, 50.0):
+        q.append(posed[rng.integers(0, V, 20 * S)] + rng.normal(size=(20 * S, 3)) * sc)
+    q.append(np.tile(c, (S, 1)))                                                               # the centre (deep inside)
+    q.append(c + rng.normal(size=(S, 3)) * 1e6)
+    bad = np.tile(c, (S, 1)).astype(np.float32)
+    bad[0, 0] = np.nan; bad[1, 1] = np.inf; bad[2, 2] = -np.inf; bad[3] = 3e38; bad[4] = 1e20
+    q.append(bad)
+    pts = np.concatenate(q, 0).astype(np.float32).reshape(-1, S, 3)
+    m_tree = G.ray.Mesh(posed, faces, T, 'cuda', search='tree')
+    m_all = G.ray.Mesh(posed, faces, T, 'cuda', search='all')
+    a = G.ray.warp_to_canonical_dev(cu(pts), m_tree, want_closest=True)
+    b = G.ray.warp_to_canonical_dev(cu(pts), m_all, want_closest=True)
+    for x, y, name in zip(a, b, ("can_pts", "can_dirs", "closest")):
+        same = (x == y) | (x.isnan() & y.isnan())
+        assert bool(same.all()), f"{case}: {name} differs at {int((~same).sum())} of {same.numel()} values"
+    # and the answer is the right one: distance vs the f64 oracle on the finite, moderate queries
+    fin = np.isfinite(pts).all(-1) & (np.abs(pts).max(-1) < 1e3)
+    cl = a[2].cpu().numpy()[fin]
+    _, _, ocl = OW.closest_point_on_mesh(pts[fin][:2000], posed, faces)
+    dist = np.linalg.norm(cl[:2000] - pts[fin][:2000], axis=-1)
+    np.testing.assert_allclose(dist, np.linalg.norm(ocl - pts[fin][:2000], axis=-1), atol=2e-5 * (1 + np.abs(posed).max()), rtol=1e-5)

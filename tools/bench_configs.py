@@ -49,8 +49,8 @@ def report(name, cap, fn, extra=None):
 
 with torch.no_grad():
     v_dev = torch.from_numpy(posed).to(dev)
-    mesh = ray_utils.mesh_to_device(posed, faces, T, dev, 0.2)
-    print(json.dumps({'mesh_grid': mesh.info()}), flush=True)
+    mesh = ray_utils.mesh_to_device(posed, faces, T, dev)
+    print(json.dumps({'mesh_tree': mesh.info()}), flush=True)
     # ---- C3: canonical 360 view of the human net, 512x512, 128 samples, hit rays only
     res = 128 if small else 512
     cap = synthetic.SimpleCapture(res, res, fx=1.6 * res, c2w=synthetic.spherical_c2w(40., 0., 3.0))
@@ -81,6 +81,6 @@ with torch.no_grad():
         T2 = T.copy()
         T2[:, :3, 3] += np.array([dx, 0, 0.1 * k])
         vs.append(torch.from_numpy(p2).to(dev))
-        ms.append(ray_utils.mesh_to_device(p2, faces, T2, dev, 0.2))
+        ms.append(ray_utils.mesh_to_device(p2, faces, T2, dev))
     report("C5-like 3 actors 1920x1080, bkg 192+128, 3 x 192", cap,
            lambda: render_utils.render_multi_rays(coarse, fine, [human] * 3, o, d, 0.0, 3.14, vs, ms, 192, 128, True, 0.2))
