@@ -43,10 +43,17 @@ struct Node {            // the four children's boxes, SoA
 
 struct Tree {
     int L;                       // levels of nodes; level L = triangles
-    int off[kMaxLevels + 1];     // first node of level l in the node array
+    int first_lp;                // first node of level L-1 (the "leaf parents", whose children are triangles)
     int F;
     float scale;                 // largest |coordinate| of the mesh: sizes the absolute part of the pruning margin
 };
+// Nodes are stored in heap order -- level l starts at (4^l - 1) / 3, the children of node g are 4g+1 .. 4g+4 -- so a
+// stack entry is one integer and a descent needs no per-level table.  Slots of a level beyond its last node are never
+// written or read: the parent's record holds the empty box for them.
+__host__ __device__ inline int level_base(int l) { return (int)(((1ll << (2 * l)) - 1) / 3); }
+
+constexpr int kPending = 4;              // a lane keeps walking until it holds this many untested triangles
+constexpr int kTriSlots = kPending + 3;  // one more expansion can add four
 
 // ---- build ---------------------------------------------------------------------------------------------------------
 // vertex AABB + a non-finite flag: out[0..2] = lo, out[3..5] = hi, out[6] = 1 if any coordinate is NaN/Inf
@@ -277,7 +284,15 @@ __device__ __forceinline__ void cswap(float& ka, int& ia, float& kb, int& ib) { 
     ka = k0; kb = k1; ia = i0; ib = i1;
 }
 
-// LDS layout: stack entries {box distance^2, level << 28 | index}, entry d of thread t at (d * blockDim + t); then [S][3] f64
+// Per-lane LDS: node stack, entries {box distance^2, node} (entry d of thread t at d * blockDim + t), 3 (L - 1) deep -- the
+// nearest child of an expanded node stays in registers --; a list of pending triangles, kTriSlots ints; then [S][3] f64.
+//
+// The search alternates two wave-wide phases.  WALK: every lane that has nodes left and fewer than kPending pending
+// triangles expands one node per iteration, and the phase lasts until no lane is left without a pending triangle --
+// lanes that found theirs early keep walking ahead ("speculative traversal") instead of idling.  TEST: every lane with
+// a pending triangle runs the exact test on the nearest one.  Pending triangles are tested against a slightly stale
+// bound; that costs a few extra tests and cannot change the result (any superset of the contenders gives the same
+// minimum, ties going to the lowest face id).
 __global__ __launch_bounds__(256) void warp_kernel(Tree tr, int search_all_mode, const float* __restrict__ pts, int S,
                                                    const float* __restrict__ verts, const int32_t* __restrict__ faces,
                                                    const TriRec* __restrict__ rec, const Node* __restrict__ nodes,
@@ -285,15 +300,10 @@ __global__ __launch_bounds__(256) void warp_kernel(Tree tr, int search_all_mode,
                                                    float* __restrict__ can_pts, float* __restrict__ can_dirs,
                                                    float* __restrict__ closest) {
     extern __shared__ double lds_raw[];
-    __shared__ int level_off[kMaxLevels + 1];                                   // per-lane lookups by level: LDS, not kernarg
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int l = 0; l <= kMaxLevels; ++l) level_off[l] = tr.off[l];
-    }
-    __syncthreads();
-    const int depth = 3 * tr.L + 1;
-    float2* stack = reinterpret_cast<float2*>(lds_raw);
-    double* can_lds = lds_raw + (size_t)depth * blockDim.x;                     // [S][3]
+    const int depth = 3 * (tr.L - 1);
+    float2* nstack = reinterpret_cast<float2*>(lds_raw);
+    int* tlist = reinterpret_cast<int*>(nstack + (size_t)depth * blockDim.x);
+    double* can_lds = reinterpret_cast<double*>(tlist + (size_t)(kTriSlots + 1) * blockDim.x);     // [S][3]; +1 keeps it 8 B aligned
     const int64_t r = blockIdx.x;
     for (int s0 = 0; s0 < S; s0 += blockDim.x) {
         const int s = s0 + threadIdx.x;
@@ -304,56 +314,78 @@ __global__ __launch_bounds__(256) void warp_kernel(Tree tr, int search_all_mode,
         const float slack = 1e-5f * (1.f + fmaxf(pmax, tr.scale));
         Best b;
         b.d2 = INFINITY; b.sd = INFINITY; b.thr2 = FLT_MAX; b.f = 0x7fffffff; b.q = p;
-        if (pmax <= FLT_MAX && !search_all_mode) {                               // a NaN / Inf point goes straight to the fallback
-            int sp = 0;
-            stack[threadIdx.x] = make_float2(0.f, __int_as_float(0));           // root: level 0, node 0
-            sp = 1;
 #ifdef NM_WARP_DBG
-            float n_vis = 0.f, n_ex = 0.f; long long t_walk = 0, t_ex = 0;
+        float n_vis = 0.f, n_ex = 0.f; long long t_walk = 0, t_ex = 0;
 #endif
+        {
+            // a NaN / Inf point, and the all-triangles mode, go straight to the loop below
+            bool has_cur = pmax <= FLT_MAX && !search_all_mode;
+            float ck = 0.f;
+            int cid = 0;                                                         // the root
+            int nsp = 0, ntri = 0;
             for (;;) {
-                int tri = -1;
 #ifdef NM_WARP_DBG
                 long long c0_ = __builtin_readcyclecounter();
 #endif
-                while (sp > 0 && tri < 0) {                                      // walk until this lane holds a triangle
-                    const float2 e = stack[(size_t)(--sp) * blockDim.x + threadIdx.x];
-                    if (e.x > b.thr2) continue;                                  // the best distance shrank since the push
-                    const int id = __float_as_int(e.y), lvl = id >> 28, idx = id & 0x0fffffff;
-                    if (lvl == tr.L) { tri = idx; break; }
+                for (;;) {                                                       // ---- WALK
+                    const bool can_walk = (has_cur || nsp > 0) && ntri < kPending;
+                    if (!__any(can_walk && ntri == 0)) break;
+                    if (can_walk) {
+                        while (!has_cur && nsp > 0) {                            // next entry the bound has not overtaken
+                            const float2 e = nstack[(size_t)(--nsp) * blockDim.x + threadIdx.x];
+                            if (e.x <= b.thr2) { ck = e.x; cid = __float_as_int(e.y); has_cur = true; }
+                        }
+                        if (has_cur && ck > b.thr2) has_cur = false;
+                        if (has_cur) {
 #ifdef NM_WARP_DBG
-                    n_vis += 1.f;
+                            n_vis += 1.f;
 #endif
-                    const Node* nd = nodes + level_off[lvl] + idx;
-                    const float4 lox = nd->lox, loy = nd->loy, loz = nd->loz, hix = nd->hix, hiy = nd->hiy, hiz = nd->hiz;
-                    float k0, k1, k2, k3;
-                    {
-                        const float x0 = slab(lox.x, hix.x, p.x), y0 = slab(loy.x, hiy.x, p.y), z0 = slab(loz.x, hiz.x, p.z);
-                        const float x1 = slab(lox.y, hix.y, p.x), y1 = slab(loy.y, hiy.y, p.y), z1 = slab(loz.y, hiz.y, p.z);
-                        const float x2 = slab(lox.z, hix.z, p.x), y2 = slab(loy.z, hiy.z, p.y), z2 = slab(loz.z, hiz.z, p.z);
-                        const float x3 = slab(lox.w, hix.w, p.x), y3 = slab(loy.w, hiy.w, p.y), z3 = slab(loz.w, hiz.w, p.z);
-                        k0 = x0 * x0 + y0 * y0 + z0 * z0; k1 = x1 * x1 + y1 * y1 + z1 * z1;
-                        k2 = x2 * x2 + y2 * y2 + z2 * z2; k3 = x3 * x3 + y3 * y3 + z3 * z3;
+                            const Node* nd = nodes + cid;
+                            const float4 lox = nd->lox, loy = nd->loy, loz = nd->loz, hix = nd->hix, hiy = nd->hiy, hiz = nd->hiz;
+                            float k0, k1, k2, k3;
+                            {
+                                const float x0 = slab(lox.x, hix.x, p.x), y0 = slab(loy.x, hiy.x, p.y), z0 = slab(loz.x, hiz.x, p.z);
+                                const float x1 = slab(lox.y, hix.y, p.x), y1 = slab(loy.y, hiy.y, p.y), z1 = slab(loz.y, hiz.y, p.z);
+                                const float x2 = slab(lox.z, hix.z, p.x), y2 = slab(loy.z, hiy.z, p.y), z2 = slab(loz.z, hiz.z, p.z);
+                                const float x3 = slab(lox.w, hix.w, p.x), y3 = slab(loy.w, hiy.w, p.y), z3 = slab(loz.w, hiz.w, p.z);
+                                k0 = fmaf(z0, z0, fmaf(y0, y0, x0 * x0)); k1 = fmaf(z1, z1, fmaf(y1, y1, x1 * x1));
+                                k2 = fmaf(z2, z2, fmaf(y2, y2, x2 * x2)); k3 = fmaf(z3, z3, fmaf(y3, y3, x3 * x3));
+                            }
+                            const bool lp = cid >= tr.first_lp;                  // children are triangles
+                            const int child = lp ? 4 * (cid - tr.first_lp) : 4 * cid + 1;
+                            int c0 = child, c1 = child + 1, c2 = child + 2, c3 = child + 3;
+                            cswap(k0, c0, k1, c1); cswap(k2, c2, k3, c3);        // sort descending: k0 >= k1 >= k2 >= k3
+                            cswap(k0, c0, k2, c2); cswap(k1, c1, k3, c3);
+                            cswap(k1, c1, k2, c2);
+                            // an empty child's distance is +inf > thr2 (<= FLT_MAX): never kept
+                            if (lp) {                                            // farthest first: the list is popped from its end
+                                if (k0 <= b.thr2) tlist[(size_t)(ntri++) * blockDim.x + threadIdx.x] = c0;
+                                if (k1 <= b.thr2) tlist[(size_t)(ntri++) * blockDim.x + threadIdx.x] = c1;
+                                if (k2 <= b.thr2) tlist[(size_t)(ntri++) * blockDim.x + threadIdx.x] = c2;
+                                if (k3 <= b.thr2) tlist[(size_t)(ntri++) * blockDim.x + threadIdx.x] = c3;
+                                has_cur = false;
+                            } else {
+                                if (k0 <= b.thr2) nstack[(size_t)(nsp++) * blockDim.x + threadIdx.x] = make_float2(k0, __int_as_float(c0));
+                                if (k1 <= b.thr2) nstack[(size_t)(nsp++) * blockDim.x + threadIdx.x] = make_float2(k1, __int_as_float(c1));
+                                if (k2 <= b.thr2) nstack[(size_t)(nsp++) * blockDim.x + threadIdx.x] = make_float2(k2, __int_as_float(c2));
+                                has_cur = k3 <= b.thr2;                          // the nearest child is expanded next, from registers
+                                ck = k3; cid = c3;
+                            }
+                        }
                     }
-                    const int child = ((lvl + 1) << 28) | (idx << 2);
-                    int c0 = child, c1 = child + 1, c2 = child + 2, c3 = child + 3;
-                    cswap(k0, c0, k1, c1); cswap(k2, c2, k3, c3);                // sort descending: farthest pushed first
-                    cswap(k0, c0, k2, c2); cswap(k1, c1, k3, c3);
-                    cswap(k1, c1, k2, c2);
-                    // an empty child's distance is +inf > thr2 (<= FLT_MAX): never pushed
-                    if (k0 <= b.thr2) stack[(size_t)(sp++) * blockDim.x + threadIdx.x] = make_float2(k0, __int_as_float(c0));
-                    if (k1 <= b.thr2) stack[(size_t)(sp++) * blockDim.x + threadIdx.x] = make_float2(k1, __int_as_float(c1));
-                    if (k2 <= b.thr2) stack[(size_t)(sp++) * blockDim.x + threadIdx.x] = make_float2(k2, __int_as_float(c2));
-                    if (k3 <= b.thr2) stack[(size_t)(sp++) * blockDim.x + threadIdx.x] = make_float2(k3, __int_as_float(c3));
                 }
 #ifdef NM_WARP_DBG
                 long long c1_ = __builtin_readcyclecounter();
                 t_walk += c1_ - c0_;
 #endif
-                if (tri < 0) break;
-                exact_tri(rec, tri, p, slack, b);                                // lanes holding a triangle test it together
+                if (!__any(ntri > 0)) break;                                     // ---- TEST (no pending triangle anywhere: all done)
+                if (ntri > 0) {
+                    exact_tri(rec, tlist[(size_t)(--ntri) * blockDim.x + threadIdx.x], p, slack, b);
 #ifdef NM_WARP_DBG
-                n_ex += 1.f;
+                    n_ex += 1.f;
+#endif
+                }
+#ifdef NM_WARP_DBG
                 t_ex += __builtin_readcyclecounter() - c1_;
 #endif
             }
@@ -452,9 +484,8 @@ int nm_mesh_create(const float* verts, int V, const int32_t* faces, int F, int s
     int n_level[kMaxLevels + 1];
     n_level[tr.L] = F;
     for (int l = tr.L - 1; l >= 0; --l) n_level[l] = (n_level[l + 1] + 3) / 4;
-    int total = 0;
-    for (int l = 0; l < tr.L; ++l) { tr.off[l] = total; total += n_level[l]; }
-    tr.off[tr.L] = total;
+    tr.first_lp = level_base(tr.L - 1);
+    const int total = tr.first_lp + n_level[tr.L - 1];               // heap order: the last level is stored up to its last node
     m->n_nodes = total;
     TriRec* d_tmp = nullptr;
     unsigned long long* d_keys = nullptr;
@@ -476,10 +507,10 @@ int nm_mesh_create(const float* verts, int V, const int32_t* faces, int F, int s
         hipLaunchKernelGGL(tri_prep_kernel, dim3((F + 255) / 256), dim3(256), 0, st, m->d_verts, m->d_faces, F, d_bbox, d_tmp, d_keys);
         hipLaunchKernelGGL(rank_scatter_kernel, dim3((F + 255) / 256), dim3(256), 0, st, d_keys, F, d_tmp, m->d_rec);
         hipLaunchKernelGGL(leaf_nodes_kernel, dim3((n_level[tr.L - 1] + 255) / 256), dim3(256), 0, st, m->d_rec, F, n_level[tr.L - 1],
-                           m->d_nodes + tr.off[tr.L - 1]);
+                           m->d_nodes + tr.first_lp);
         for (int l = tr.L - 2; l >= 0; --l)
-            hipLaunchKernelGGL(upper_nodes_kernel, dim3((n_level[l] + 255) / 256), dim3(256), 0, st, m->d_nodes + tr.off[l + 1], n_level[l + 1],
-                               n_level[l], m->d_nodes + tr.off[l]);
+            hipLaunchKernelGGL(upper_nodes_kernel, dim3((n_level[l] + 255) / 256), dim3(256), 0, st, m->d_nodes + level_base(l + 1),
+                               n_level[l + 1], n_level[l], m->d_nodes + level_base(l));
         rc = nm::check_launch("nm_mesh_create: build kernels");
     }
     // one read-back: the vertex box sizes the pruning margin and carries the non-finite flag (also orders the frees below)
@@ -513,7 +544,7 @@ int nm_warp_to_canonical(nm_mesh_t m, const float* pts, int64_t R, int S, const 
     NM_REQUIRE(R < (1ll << 31), "nm_warp_to_canonical: too many rays for one launch");
     if (R == 0) return NM_OK;
     const int threads = S <= 64 ? 64 : (S <= 128 ? 128 : 256);
-    const size_t lds = (size_t)(3 * m->tr.L + 1) * threads * 8 + (size_t)S * 24;
+    const size_t lds = (size_t)(3 * (m->tr.L - 1)) * threads * 8 + (size_t)(kTriSlots + 1) * threads * 4 + (size_t)S * 24;
     NM_REQUIRE(lds <= 64 * 1024, "nm_warp_to_canonical: S=%d exceeds the LDS budget (%zu B)", S, lds);
     hipLaunchKernelGGL(warp_kernel, dim3((unsigned)R), dim3(threads), lds, nm::as_stream(stream), m->tr, m->search == NM_SEARCH_ALL ? 1 : 0,
                        pts, S, m->d_verts, m->d_faces, m->d_rec, m->d_nodes, T, can_pts, can_dirs, closest);
