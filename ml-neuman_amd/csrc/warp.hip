@@ -52,7 +52,10 @@ struct Tree {
 // written or read: the parent's record holds the empty box for them.
 __host__ __device__ inline int level_base(int l) { return (int)(((1ll << (2 * l)) - 1) / 3); }
 
-constexpr int kPending = 4;              // a lane keeps walking until it holds this many untested triangles
+#ifndef NM_WARP_PENDING
+#define NM_WARP_PENDING 6
+#endif
+constexpr int kPending = NM_WARP_PENDING;              // a lane keeps walking until it holds this many untested triangles
 constexpr int kTriSlots = kPending + 3;  // one more expansion can add four
 
 // ---- build ---------------------------------------------------------------------------------------------------------
@@ -324,70 +327,67 @@ __global__ __launch_bounds__(256) void warp_kernel(Tree tr, int search_all_mode,
             int cid = 0;                                                         // the root
             int nsp = 0, ntri = 0;
             for (;;) {
+                const bool can_walk = (has_cur || nsp > 0) && ntri < kPending;
+                const unsigned long long bw = __ballot(can_walk), bt = __ballot(ntri > 0);
+                if (!(bw | bt)) break;
+                if (__popcll(bt) < __popcll(bw)) {                               // ---- WALK: expand one node per lane
 #ifdef NM_WARP_DBG
-                long long c0_ = __builtin_readcyclecounter();
+                    t_walk += 1;
 #endif
-                for (;;) {                                                       // ---- WALK
-                    const bool can_walk = (has_cur || nsp > 0) && ntri < kPending;
-                    if (!__any(can_walk && ntri == 0)) break;
                     if (can_walk) {
-                        while (!has_cur && nsp > 0) {                            // next entry the bound has not overtaken
-                            const float2 e = nstack[(size_t)(--nsp) * blockDim.x + threadIdx.x];
-                            if (e.x <= b.thr2) { ck = e.x; cid = __float_as_int(e.y); has_cur = true; }
-                        }
-                        if (has_cur && ck > b.thr2) has_cur = false;
-                        if (has_cur) {
+                    while (!has_cur && nsp > 0) {                            // next entry the bound has not overtaken
+                        const float2 e = nstack[(size_t)(--nsp) * blockDim.x + threadIdx.x];
+                        if (e.x <= b.thr2) { ck = e.x; cid = __float_as_int(e.y); has_cur = true; }
+                    }
+                    if (has_cur && ck > b.thr2) has_cur = false;
+                    if (has_cur) {
 #ifdef NM_WARP_DBG
-                            n_vis += 1.f;
+                        n_vis += 1.f;
 #endif
-                            const Node* nd = nodes + cid;
-                            const float4 lox = nd->lox, loy = nd->loy, loz = nd->loz, hix = nd->hix, hiy = nd->hiy, hiz = nd->hiz;
-                            float k0, k1, k2, k3;
-                            {
-                                const float x0 = slab(lox.x, hix.x, p.x), y0 = slab(loy.x, hiy.x, p.y), z0 = slab(loz.x, hiz.x, p.z);
-                                const float x1 = slab(lox.y, hix.y, p.x), y1 = slab(loy.y, hiy.y, p.y), z1 = slab(loz.y, hiz.y, p.z);
-                                const float x2 = slab(lox.z, hix.z, p.x), y2 = slab(loy.z, hiy.z, p.y), z2 = slab(loz.z, hiz.z, p.z);
-                                const float x3 = slab(lox.w, hix.w, p.x), y3 = slab(loy.w, hiy.w, p.y), z3 = slab(loz.w, hiz.w, p.z);
-                                k0 = fmaf(z0, z0, fmaf(y0, y0, x0 * x0)); k1 = fmaf(z1, z1, fmaf(y1, y1, x1 * x1));
-                                k2 = fmaf(z2, z2, fmaf(y2, y2, x2 * x2)); k3 = fmaf(z3, z3, fmaf(y3, y3, x3 * x3));
-                            }
-                            const bool lp = cid >= tr.first_lp;                  // children are triangles
-                            const int child = lp ? 4 * (cid - tr.first_lp) : 4 * cid + 1;
-                            int c0 = child, c1 = child + 1, c2 = child + 2, c3 = child + 3;
-                            cswap(k0, c0, k1, c1); cswap(k2, c2, k3, c3);        // sort descending: k0 >= k1 >= k2 >= k3
-                            cswap(k0, c0, k2, c2); cswap(k1, c1, k3, c3);
-                            cswap(k1, c1, k2, c2);
-                            // an empty child's distance is +inf > thr2 (<= FLT_MAX): never kept
-                            if (lp) {                                            // farthest first: the list is popped from its end
-                                if (k0 <= b.thr2) tlist[(size_t)(ntri++) * blockDim.x + threadIdx.x] = c0;
-                                if (k1 <= b.thr2) tlist[(size_t)(ntri++) * blockDim.x + threadIdx.x] = c1;
-                                if (k2 <= b.thr2) tlist[(size_t)(ntri++) * blockDim.x + threadIdx.x] = c2;
-                                if (k3 <= b.thr2) tlist[(size_t)(ntri++) * blockDim.x + threadIdx.x] = c3;
-                                has_cur = false;
-                            } else {
-                                if (k0 <= b.thr2) nstack[(size_t)(nsp++) * blockDim.x + threadIdx.x] = make_float2(k0, __int_as_float(c0));
-                                if (k1 <= b.thr2) nstack[(size_t)(nsp++) * blockDim.x + threadIdx.x] = make_float2(k1, __int_as_float(c1));
-                                if (k2 <= b.thr2) nstack[(size_t)(nsp++) * blockDim.x + threadIdx.x] = make_float2(k2, __int_as_float(c2));
-                                has_cur = k3 <= b.thr2;                          // the nearest child is expanded next, from registers
-                                ck = k3; cid = c3;
-                            }
+                        const Node* nd = nodes + cid;
+                        const float4 lox = nd->lox, loy = nd->loy, loz = nd->loz, hix = nd->hix, hiy = nd->hiy, hiz = nd->hiz;
+                        float k0, k1, k2, k3;
+                        {
+                            const float x0 = slab(lox.x, hix.x, p.x), y0 = slab(loy.x, hiy.x, p.y), z0 = slab(loz.x, hiz.x, p.z);
+                            const float x1 = slab(lox.y, hix.y, p.x), y1 = slab(loy.y, hiy.y, p.y), z1 = slab(loz.y, hiz.y, p.z);
+                            const float x2 = slab(lox.z, hix.z, p.x), y2 = slab(loy.z, hiy.z, p.y), z2 = slab(loz.z, hiz.z, p.z);
+                            const float x3 = slab(lox.w, hix.w, p.x), y3 = slab(loy.w, hiy.w, p.y), z3 = slab(loz.w, hiz.w, p.z);
+                            k0 = fmaf(z0, z0, fmaf(y0, y0, x0 * x0)); k1 = fmaf(z1, z1, fmaf(y1, y1, x1 * x1));
+                            k2 = fmaf(z2, z2, fmaf(y2, y2, x2 * x2)); k3 = fmaf(z3, z3, fmaf(y3, y3, x3 * x3));
+                        }
+                        const bool lp = cid >= tr.first_lp;                  // children are triangles
+                        const int child = lp ? 4 * (cid - tr.first_lp) : 4 * cid + 1;
+                        int c0 = child, c1 = child + 1, c2 = child + 2, c3 = child + 3;
+                        cswap(k0, c0, k1, c1); cswap(k2, c2, k3, c3);        // sort descending: k0 >= k1 >= k2 >= k3
+                        cswap(k0, c0, k2, c2); cswap(k1, c1, k3, c3);
+                        cswap(k1, c1, k2, c2);
+                        // an empty child's distance is +inf > thr2 (<= FLT_MAX): never kept
+                        if (lp) {                                            // farthest first: the list is popped from its end
+                            if (k0 <= b.thr2) tlist[(size_t)(ntri++) * blockDim.x + threadIdx.x] = c0;
+                            if (k1 <= b.thr2) tlist[(size_t)(ntri++) * blockDim.x + threadIdx.x] = c1;
+                            if (k2 <= b.thr2) tlist[(size_t)(ntri++) * blockDim.x + threadIdx.x] = c2;
+                            if (k3 <= b.thr2) tlist[(size_t)(ntri++) * blockDim.x + threadIdx.x] = c3;
+                            has_cur = false;
+                        } else {
+                            if (k0 <= b.thr2) nstack[(size_t)(nsp++) * blockDim.x + threadIdx.x] = make_float2(k0, __int_as_float(c0));
+                            if (k1 <= b.thr2) nstack[(size_t)(nsp++) * blockDim.x + threadIdx.x] = make_float2(k1, __int_as_float(c1));
+                            if (k2 <= b.thr2) nstack[(size_t)(nsp++) * blockDim.x + threadIdx.x] = make_float2(k2, __int_as_float(c2));
+                            has_cur = k3 <= b.thr2;                          // the nearest child is expanded next, from registers
+                            ck = k3; cid = c3;
                         }
                     }
+                    }
+                } else {                                                         // ---- TEST: one pending triangle per lane
+#ifdef NM_WARP_DBG
+                    t_ex += 1;
+#endif
+                    if (ntri > 0) {
+                        exact_tri(rec, tlist[(size_t)(--ntri) * blockDim.x + threadIdx.x], p, slack, b);
+#ifdef NM_WARP_DBG
+                        n_ex += 1.f;
+#endif
+                    }
                 }
-#ifdef NM_WARP_DBG
-                long long c1_ = __builtin_readcyclecounter();
-                t_walk += c1_ - c0_;
-#endif
-                if (!__any(ntri > 0)) break;                                     // ---- TEST (no pending triangle anywhere: all done)
-                if (ntri > 0) {
-                    exact_tri(rec, tlist[(size_t)(--ntri) * blockDim.x + threadIdx.x], p, slack, b);
-#ifdef NM_WARP_DBG
-                    n_ex += 1.f;
-#endif
-                }
-#ifdef NM_WARP_DBG
-                t_ex += __builtin_readcyclecounter() - c1_;
-#endif
             }
 #ifdef NM_WARP_DBG
             if (closest && live) { closest[i * 3] = n_vis; closest[i * 3 + 1] = n_ex; closest[i * 3 + 2] = (float)(NM_WARP_DBG == 2 ? t_ex : t_walk); }
