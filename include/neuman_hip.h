@@ -185,6 +185,7 @@ int nm_mlp_forward_profile(nm_mlp_t mlp, const float* pts, const float* dirs, in
  * ------------------------------------------------------------------------------------------- */
 #define NM_SEARCH_TREE 0
 #define NM_SEARCH_ALL 1
+#define NM_SEARCH_TREE_WIDE 2 /* the tree search with the stack layout of meshes beyond 65,536 nodes (tests) */
 typedef struct nm_mesh_s* nm_mesh_t;
 int nm_mesh_create(const float* verts, int V, const int32_t* faces, int F, int search, nm_mesh_t* out,
                    nm_stream_t stream);

@@ -199,7 +199,10 @@ struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
-// exact closest point on triangle (a,b,c) to p: Voronoi-region test (Ericson, RTCD 5.1.5)
+// exact closest point on triangle (a,b,c) to p: Voronoi-region test (Ericson, RTCD 5.1.5), written without branches --
+// the seven regions become selects applied in reverse priority, the four quotients use v_rcp_f32 (1 ulp; the error it
+// leaves in q is ~1e-7 of an edge length, far below one ulp of the coordinates) -- because 64 lanes testing 64 different
+// triangles would otherwise run every region's code one after the other.
 __device__ __forceinline__ V3 closest_on_tri(V3 p, V3 a, V3 b, V3 c) {
     const V3 ab = sub(b, a), ac = sub(c, a), ap = sub(p, a);
     const float d1 = dot(ab, ap), d2 = dot(ac, ap);
@@ -208,20 +211,24 @@ __device__ __forceinline__ V3 closest_on_tri(V3 p, V3 a, V3 b, V3 c) {
     const V3 cp = sub(p, c);
     const float d5 = dot(ab, cp), d6 = dot(ac, cp);
     const float vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
-    float v, w;   // q = a + v*ab + w*ac
-    if (d1 <= 0.f && d2 <= 0.f) { v = 0.f; w = 0.f; }                              // vertex A
-    else if (d3 >= 0.f && d4 <= d3) { v = 1.f; w = 0.f; }                          // vertex B
-    else if (vc <= 0.f && d1 >= 0.f && d3 <= 0.f) { v = d1 / (d1 - d3); w = 0.f; } // edge AB
-    else if (d6 >= 0.f && d5 <= d6) { v = 0.f; w = 1.f; }                          // vertex C
-    else if (vb <= 0.f && d2 >= 0.f && d6 <= 0.f) { v = 0.f; w = d2 / (d2 - d6); } // edge AC
-    else if (va <= 0.f && (d4 - d3) >= 0.f && (d5 - d6) >= 0.f) {                  // edge BC
-        w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
-        v = 1.f - w;
-    } else {                                                                       // interior
-        const float denom = 1.f / (va + vb + vc);
-        v = vb * denom;
-        w = vc * denom;
-    }
+    const float e43 = d4 - d3, e56 = d5 - d6;
+    const float t_ab = d1 * __builtin_amdgcn_rcpf(d1 - d3);
+    const float t_ac = d2 * __builtin_amdgcn_rcpf(d2 - d6);
+    const float t_bc = e43 * __builtin_amdgcn_rcpf(e43 + e56);
+    const float den = __builtin_amdgcn_rcpf(va + vb + vc);
+    float v = vb * den, w = vc * den;                                               // interior; q = a + v*ab + w*ac
+    const bool r_bc = va <= 0.f && e43 >= 0.f && e56 >= 0.f;                         // edge BC
+    v = r_bc ? 1.f - t_bc : v;  w = r_bc ? t_bc : w;
+    const bool r_ac = vb <= 0.f && d2 >= 0.f && d6 <= 0.f;                           // edge AC
+    v = r_ac ? 0.f : v;         w = r_ac ? t_ac : w;
+    const bool r_c = d6 >= 0.f && d5 <= d6;                                          // vertex C
+    v = r_c ? 0.f : v;          w = r_c ? 1.f : w;
+    const bool r_ab = vc <= 0.f && d1 >= 0.f && d3 <= 0.f;                           // edge AB
+    v = r_ab ? t_ab : v;        w = r_ab ? 0.f : w;
+    const bool r_b = d3 >= 0.f && d4 <= d3;                                          // vertex B
+    v = r_b ? 1.f : v;          w = r_b ? 0.f : w;
+    const bool r_a = d1 <= 0.f && d2 <= 0.f;                                         // vertex A
+    v = r_a ? 0.f : v;          w = r_a ? 0.f : w;
     return {a.x + ab.x * v + ac.x * w, a.y + ab.y * v + ac.y * w, a.z + ab.z * v + ac.z * w};
 }
 
@@ -296,6 +303,7 @@ __device__ __forceinline__ void cswap(float& ka, int& ia, float& kb, int& ib) { 
 // a pending triangle runs the exact test on the nearest one.  Pending triangles are tested against a slightly stale
 // bound; that costs a few extra tests and cannot change the result (any superset of the contenders gives the same
 // minimum, ties going to the lowest face id).
+template <bool SMALL>
 __global__ __launch_bounds__(256) void warp_kernel(Tree tr, int search_all_mode, const float* __restrict__ pts, int S,
                                                    const float* __restrict__ verts, const int32_t* __restrict__ faces,
                                                    const TriRec* __restrict__ rec, const Node* __restrict__ nodes,
@@ -304,8 +312,25 @@ __global__ __launch_bounds__(256) void warp_kernel(Tree tr, int search_all_mode,
                                                    float* __restrict__ closest) {
     extern __shared__ double lds_raw[];
     const int depth = 3 * (tr.L - 1);
+    // node stack entry: {distance^2, node} as float2, or -- SMALL: the tree has at most 65,536 nodes -- one dword holding the
+    // distance^2 truncated to its upper 16 bits (rounded towards zero: still a lower bound) above the node index.  Half the
+    // LDS lets eight workgroups of 128 share a CU instead of six, and the search is latency-bound.
     float2* nstack = reinterpret_cast<float2*>(lds_raw);
-    int* tlist = reinterpret_cast<int*>(nstack + (size_t)depth * blockDim.x);
+    uint32_t* nstack_s = reinterpret_cast<uint32_t*>(lds_raw);
+    int* tlist = SMALL ? reinterpret_cast<int*>(nstack_s + (size_t)depth * blockDim.x) : reinterpret_cast<int*>(nstack + (size_t)depth * blockDim.x);
+    auto push_node = [&](int slot, float k, int id) {
+        if (SMALL) nstack_s[(size_t)slot * blockDim.x + threadIdx.x] = (__float_as_uint(k) & 0xffff0000u) | (uint32_t)id;
+        else nstack[(size_t)slot * blockDim.x + threadIdx.x] = make_float2(k, __int_as_float(id));
+    };
+    auto pop_node = [&](int slot, float& k, int& id) {
+        if (SMALL) {
+            const uint32_t e = nstack_s[(size_t)slot * blockDim.x + threadIdx.x];
+            k = __uint_as_float(e & 0xffff0000u); id = (int)(e & 0xffffu);
+        } else {
+            const float2 e = nstack[(size_t)slot * blockDim.x + threadIdx.x];
+            k = e.x; id = __float_as_int(e.y);
+        }
+    };
     double* can_lds = reinterpret_cast<double*>(tlist + (size_t)(kTriSlots + 1) * blockDim.x);     // [S][3]; +1 keeps it 8 B aligned
     const int64_t r = blockIdx.x;
     for (int s0 = 0; s0 < S; s0 += blockDim.x) {
@@ -336,8 +361,9 @@ __global__ __launch_bounds__(256) void warp_kernel(Tree tr, int search_all_mode,
 #endif
                     if (can_walk) {
                     while (!has_cur && nsp > 0) {                            // next entry the bound has not overtaken
-                        const float2 e = nstack[(size_t)(--nsp) * blockDim.x + threadIdx.x];
-                        if (e.x <= b.thr2) { ck = e.x; cid = __float_as_int(e.y); has_cur = true; }
+                        float ek; int eid;
+                        pop_node(--nsp, ek, eid);
+                        if (ek <= b.thr2) { ck = ek; cid = eid; has_cur = true; }
                     }
                     if (has_cur && ck > b.thr2) has_cur = false;
                     if (has_cur) {
@@ -369,9 +395,9 @@ __global__ __launch_bounds__(256) void warp_kernel(Tree tr, int search_all_mode,
                             if (k3 <= b.thr2) tlist[(size_t)(ntri++) * blockDim.x + threadIdx.x] = c3;
                             has_cur = false;
                         } else {
-                            if (k0 <= b.thr2) nstack[(size_t)(nsp++) * blockDim.x + threadIdx.x] = make_float2(k0, __int_as_float(c0));
-                            if (k1 <= b.thr2) nstack[(size_t)(nsp++) * blockDim.x + threadIdx.x] = make_float2(k1, __int_as_float(c1));
-                            if (k2 <= b.thr2) nstack[(size_t)(nsp++) * blockDim.x + threadIdx.x] = make_float2(k2, __int_as_float(c2));
+                            if (k0 <= b.thr2) push_node(nsp++, k0, c0);
+                            if (k1 <= b.thr2) push_node(nsp++, k1, c1);
+                            if (k2 <= b.thr2) push_node(nsp++, k2, c2);
                             has_cur = k3 <= b.thr2;                          // the nearest child is expanded next, from registers
                             ck = k3; cid = c3;
                         }
@@ -449,6 +475,7 @@ __global__ __launch_bounds__(256) void warp_kernel(Tree tr, int search_all_mode,
 
 struct nm_mesh_s {
     int V, F, search;
+    bool force_wide;     // tests: use the two-dword stack entries even for a small tree
     Tree tr;
     int n_nodes;
     float* d_verts;      // owned copies: the handle outlives the caller's tensors
@@ -472,11 +499,13 @@ int nm_mesh_destroy(nm_mesh_t m) {
 int nm_mesh_create(const float* verts, int V, const int32_t* faces, int F, int search, nm_mesh_t* out, nm_stream_t stream) {
     NM_REQUIRE(verts && faces && out, "nm_mesh_create: null pointer");
     NM_REQUIRE(V >= 3 && F >= 1 && F <= (1 << 24), "nm_mesh_create: bad sizes V=%d F=%d", V, F);
-    NM_REQUIRE(search == NM_SEARCH_TREE || search == NM_SEARCH_ALL, "nm_mesh_create: search mode %d", search);
+    NM_REQUIRE(search == NM_SEARCH_TREE || search == NM_SEARCH_ALL || search == NM_SEARCH_TREE_WIDE, "nm_mesh_create: search mode %d", search);
     hipStream_t st = nm::as_stream(stream);
     nm_mesh_s* m = new nm_mesh_s();
     memset(m, 0, sizeof(*m));
-    m->V = V; m->F = F; m->search = search;
+    m->V = V; m->F = F;
+    m->search = search == NM_SEARCH_ALL ? NM_SEARCH_ALL : NM_SEARCH_TREE;
+    m->force_wide = search == NM_SEARCH_TREE_WIDE;
     Tree& tr = m->tr;
     tr.F = F;
     tr.L = 1;
@@ -544,10 +573,15 @@ int nm_warp_to_canonical(nm_mesh_t m, const float* pts, int64_t R, int S, const 
     NM_REQUIRE(R < (1ll << 31), "nm_warp_to_canonical: too many rays for one launch");
     if (R == 0) return NM_OK;
     const int threads = S <= 64 ? 64 : (S <= 128 ? 128 : 256);
-    const size_t lds = (size_t)(3 * (m->tr.L - 1)) * threads * 8 + (size_t)(kTriSlots + 1) * threads * 4 + (size_t)S * 24;
+    const bool small = m->n_nodes <= 65536 && !m->force_wide;
+    const size_t lds = (size_t)(3 * (m->tr.L - 1)) * threads * (small ? 4 : 8) + (size_t)(kTriSlots + 1) * threads * 4 + (size_t)S * 24;
     NM_REQUIRE(lds <= 64 * 1024, "nm_warp_to_canonical: S=%d exceeds the LDS budget (%zu B)", S, lds);
-    hipLaunchKernelGGL(warp_kernel, dim3((unsigned)R), dim3(threads), lds, nm::as_stream(stream), m->tr, m->search == NM_SEARCH_ALL ? 1 : 0,
-                       pts, S, m->d_verts, m->d_faces, m->d_rec, m->d_nodes, T, can_pts, can_dirs, closest);
+    if (small)
+        hipLaunchKernelGGL(warp_kernel<true>, dim3((unsigned)R), dim3(threads), lds, nm::as_stream(stream), m->tr,
+                           m->search == NM_SEARCH_ALL ? 1 : 0, pts, S, m->d_verts, m->d_faces, m->d_rec, m->d_nodes, T, can_pts, can_dirs, closest);
+    else
+        hipLaunchKernelGGL(warp_kernel<false>, dim3((unsigned)R), dim3(threads), lds, nm::as_stream(stream), m->tr,
+                           m->search == NM_SEARCH_ALL ? 1 : 0, pts, S, m->d_verts, m->d_faces, m->d_rec, m->d_nodes, T, can_pts, can_dirs, closest);
     return nm::check_launch("warp_kernel");
 }
 

@@ -258,7 +258,7 @@ class Mesh:
     """A posed mesh on the device plus its closest-point search structure (nm_mesh_create).  Built once per frame and
     actor; `T` are the per-vertex canonical->observation transforms (f64 [>=V,4,4], joint rows beyond V never indexed)."""
 
-    SEARCH = {'tree': 0, 'all': 1}      # NM_SEARCH_TREE / NM_SEARCH_ALL (the all-triangles loop: tests and diagnostics)
+    SEARCH = {'tree': 0, 'all': 1, 'tree_wide': 2}      # NM_SEARCH_TREE / NM_SEARCH_ALL (the all-triangles loop: tests and diagnostics)
 
     def __init__(self, verts, faces, T, device, search='tree'):
         import ctypes

@@ -311,9 +311,11 @@ def test_tree_search_is_bit_identical_to_all_triangles(G, case):
     m_all = G.ray.Mesh(posed, faces, T, 'cuda', search='all')
     a = G.ray.warp_to_canonical_dev(cu(pts), m_tree, want_closest=True)
     b = G.ray.warp_to_canonical_dev(cu(pts), m_all, want_closest=True)
-    for x, y, name in zip(a, b, ("can_pts", "can_dirs", "closest")):
-        same = (x == y) | (x.isnan() & y.isnan())
-        assert bool(same.all()), f"{case}: {name} differs at {int((~same).sum())} of {same.numel()} values"
+    w = G.ray.warp_to_canonical_dev(cu(pts), G.ray.Mesh(posed, faces, T, 'cuda', search='tree_wide'), want_closest=True)
+    for x, y, z, name in zip(a, b, w, ("can_pts", "can_dirs", "closest")):
+        for other, what in ((y, "all-triangles"), (z, "wide-stack tree")):
+            same = (x == other) | (x.isnan() & other.isnan())
+            assert bool(same.all()), f"{case}: {name} differs from the {what} search at {int((~same).sum())} of {same.numel()} values"
     # and the answer is the right one: distance vs the f64 oracle on the finite, moderate queries
     fin = np.isfinite(pts).all(-1) & (np.abs(pts).max(-1) < 1e3)
     cl = a[2].cpu().numpy()[fin]
