@@ -28,6 +28,10 @@
 
 namespace {
 
+// five waves per SIMD (<= 96 VGPRs, no spills): the tree walk is latency-bound
+#ifndef NM_WARP_ATTR
+#define NM_WARP_ATTR __attribute__((amdgpu_waves_per_eu(5)))
+#endif
 constexpr int kMaxLevels = 12;           // 4^12 = 16.7 M triangles
 
 struct TriRec {          // 16 floats
@@ -304,7 +308,7 @@ __device__ __forceinline__ void cswap(float& ka, int& ia, float& kb, int& ib) { 
 // bound; that costs a few extra tests and cannot change the result (any superset of the contenders gives the same
 // minimum, ties going to the lowest face id).
 template <bool SMALL>
-__global__ __launch_bounds__(256) void warp_kernel(Tree tr, int search_all_mode, const float* __restrict__ pts, int S,
+__global__ __launch_bounds__(256) NM_WARP_ATTR void warp_kernel(Tree tr, int search_all_mode, const float* __restrict__ pts, int S,
                                                    const float* __restrict__ verts, const int32_t* __restrict__ faces,
                                                    const TriRec* __restrict__ rec, const Node* __restrict__ nodes,
                                                    const double* __restrict__ T,
@@ -317,7 +321,16 @@ __global__ __launch_bounds__(256) void warp_kernel(Tree tr, int search_all_mode,
     // LDS lets eight workgroups of 128 share a CU instead of six, and the search is latency-bound.
     float2* nstack = reinterpret_cast<float2*>(lds_raw);
     uint32_t* nstack_s = reinterpret_cast<uint32_t*>(lds_raw);
-    int* tlist = SMALL ? reinterpret_cast<int*>(nstack_s + (size_t)depth * blockDim.x) : reinterpret_cast<int*>(nstack + (size_t)depth * blockDim.x);
+    // pending triangles: int, or -- SMALL: F <= 65,536 as well -- uint16
+    int* tlist = reinterpret_cast<int*>(nstack + (size_t)depth * blockDim.x);
+    uint16_t* tlist_s = reinterpret_cast<uint16_t*>(nstack_s + (size_t)depth * blockDim.x);
+    auto push_tri = [&](int slot, int t) {
+        if (SMALL) tlist_s[(size_t)slot * blockDim.x + threadIdx.x] = (uint16_t)t;
+        else tlist[(size_t)slot * blockDim.x + threadIdx.x] = t;
+    };
+    auto pop_tri = [&](int slot) -> int {
+        return SMALL ? (int)tlist_s[(size_t)slot * blockDim.x + threadIdx.x] : tlist[(size_t)slot * blockDim.x + threadIdx.x];
+    };
     auto push_node = [&](int slot, float k, int id) {
         if (SMALL) nstack_s[(size_t)slot * blockDim.x + threadIdx.x] = (__float_as_uint(k) & 0xffff0000u) | (uint32_t)id;
         else nstack[(size_t)slot * blockDim.x + threadIdx.x] = make_float2(k, __int_as_float(id));
@@ -331,7 +344,8 @@ __global__ __launch_bounds__(256) void warp_kernel(Tree tr, int search_all_mode,
             k = e.x; id = __float_as_int(e.y);
         }
     };
-    double* can_lds = reinterpret_cast<double*>(tlist + (size_t)(kTriSlots + 1) * blockDim.x);     // [S][3]; +1 keeps it 8 B aligned
+    double* can_lds = SMALL ? reinterpret_cast<double*>(tlist_s + (size_t)(kTriSlots + 1) * blockDim.x)      // [S][3]; the +1 slot keeps
+                            : reinterpret_cast<double*>(tlist + (size_t)(kTriSlots + 1) * blockDim.x);       // it 8 B aligned
     const int64_t r = blockIdx.x;
     for (int s0 = 0; s0 < S; s0 += blockDim.x) {
         const int s = s0 + threadIdx.x;
@@ -389,10 +403,10 @@ __global__ __launch_bounds__(256) void warp_kernel(Tree tr, int search_all_mode,
                         cswap(k1, c1, k2, c2);
                         // an empty child's distance is +inf > thr2 (<= FLT_MAX): never kept
                         if (lp) {                                            // farthest first: the list is popped from its end
-                            if (k0 <= b.thr2) tlist[(size_t)(ntri++) * blockDim.x + threadIdx.x] = c0;
-                            if (k1 <= b.thr2) tlist[(size_t)(ntri++) * blockDim.x + threadIdx.x] = c1;
-                            if (k2 <= b.thr2) tlist[(size_t)(ntri++) * blockDim.x + threadIdx.x] = c2;
-                            if (k3 <= b.thr2) tlist[(size_t)(ntri++) * blockDim.x + threadIdx.x] = c3;
+                            if (k0 <= b.thr2) push_tri(ntri++, c0);
+                            if (k1 <= b.thr2) push_tri(ntri++, c1);
+                            if (k2 <= b.thr2) push_tri(ntri++, c2);
+                            if (k3 <= b.thr2) push_tri(ntri++, c3);
                             has_cur = false;
                         } else {
                             if (k0 <= b.thr2) push_node(nsp++, k0, c0);
@@ -408,7 +422,7 @@ __global__ __launch_bounds__(256) void warp_kernel(Tree tr, int search_all_mode,
                     t_ex += 1;
 #endif
                     if (ntri > 0) {
-                        exact_tri(rec, tlist[(size_t)(--ntri) * blockDim.x + threadIdx.x], p, slack, b);
+                        exact_tri(rec, pop_tri(--ntri), p, slack, b);
 #ifdef NM_WARP_DBG
                         n_ex += 1.f;
 #endif
@@ -573,8 +587,8 @@ int nm_warp_to_canonical(nm_mesh_t m, const float* pts, int64_t R, int S, const 
     NM_REQUIRE(R < (1ll << 31), "nm_warp_to_canonical: too many rays for one launch");
     if (R == 0) return NM_OK;
     const int threads = S <= 64 ? 64 : (S <= 128 ? 128 : 256);
-    const bool small = m->n_nodes <= 65536 && !m->force_wide;
-    const size_t lds = (size_t)(3 * (m->tr.L - 1)) * threads * (small ? 4 : 8) + (size_t)(kTriSlots + 1) * threads * 4 + (size_t)S * 24;
+    const bool small = m->n_nodes <= 65536 && m->F <= 65536 && !m->force_wide;
+    const size_t lds = (size_t)(3 * (m->tr.L - 1)) * threads * (small ? 4 : 8) + (size_t)(kTriSlots + 1) * threads * (small ? 2 : 4) + (size_t)S * 24;
     NM_REQUIRE(lds <= 64 * 1024, "nm_warp_to_canonical: S=%d exceeds the LDS budget (%zu B)", S, lds);
     if (small)
         hipLaunchKernelGGL(warp_kernel<true>, dim3((unsigned)R), dim3(threads), lds, nm::as_stream(stream), m->tr,
