@@ -22,7 +22,10 @@
 // second pass over HBM.
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
+
+#include <vector>
 
 #include "common.h"
 
@@ -298,147 +301,177 @@ __device__ __forceinline__ void cswap(float& ka, int& ia, float& kb, int& ib) { 
     ka = k0; kb = k1; ia = i0; ib = i1;
 }
 
-// Per-lane LDS: node stack, entries {box distance^2, node} (entry d of thread t at d * blockDim + t), 3 (L - 1) deep -- the
-// nearest child of an expanded node stays in registers --; a list of pending triangles, kTriSlots ints; then [S][3] f64.
-//
-// The search alternates two wave-wide phases.  WALK: every lane that has nodes left and fewer than kPending pending
-// triangles expands one node per iteration, and the phase lasts until no lane is left without a pending triangle --
-// lanes that found theirs early keep walking ahead ("speculative traversal") instead of idling.  TEST: every lane with
-// a pending triangle runs the exact test on the nearest one.  Pending triangles are tested against a slightly stale
+// ---- search_kernel: closest triangle and closest point per sample --------------------------------------------------------------
+// One wave per workgroup; a wave owns kChunk consecutive samples and its lanes are persistent: a lane that finishes its
+// sample takes the next one of the chunk, so the wave stays full although per-sample work varies 3x (a sample 20 cm off
+// the body has ~10x the contenders of one at the surface).
+// Per-lane LDS: node stack, entries {box distance^2, node}, 3 (L - 1) deep -- the nearest child of an expanded node stays
+// in registers --, and a list of pending triangles (kTriSlots).  Entry d of lane t is at d * 64 + t.
+// Every iteration runs ONE of two wave-wide phases, whichever has more lanes ready for it:
+//   WALK: each lane with nodes left and fewer than kPending pending triangles expands one node (four child boxes, kept
+//         children pushed farthest first);
+//   TEST: each lane with a pending triangle runs the exact closest-point test on the nearest one.
+// Lanes walk ahead of their tests ("speculative traversal"), so pending triangles are tested against a slightly stale
 // bound; that costs a few extra tests and cannot change the result (any superset of the contenders gives the same
 // minimum, ties going to the lowest face id).
+// Output: q -> q_out[i*3 ..], face -> f_out[i*3] (the caller passes can_pts / can_dirs: tail_kernel consumes and overwrites them).
+constexpr int kChunk = 512;
+constexpr int kRefill = 8;               // idle lanes that trigger a refill (or any, when no lane has work)
+
 template <bool SMALL>
-__global__ __launch_bounds__(256) NM_WARP_ATTR void warp_kernel(Tree tr, int search_all_mode, const float* __restrict__ pts, int S,
-                                                   const float* __restrict__ verts, const int32_t* __restrict__ faces,
-                                                   const TriRec* __restrict__ rec, const Node* __restrict__ nodes,
-                                                   const double* __restrict__ T,
-                                                   float* __restrict__ can_pts, float* __restrict__ can_dirs,
-                                                   float* __restrict__ closest) {
+__global__ __launch_bounds__(64) NM_WARP_ATTR void search_kernel(Tree tr, int search_all_mode, const float* __restrict__ pts, int64_t N,
+                                                                 const TriRec* __restrict__ rec, const Node* __restrict__ nodes,
+                                                                 float* __restrict__ q_out, int32_t* __restrict__ f_out
+#ifdef NM_WARP_DBG
+                                                                 , float* __restrict__ dbg
+#endif
+                                                                 ) {
     extern __shared__ double lds_raw[];
     const int depth = 3 * (tr.L - 1);
-    // node stack entry: {distance^2, node} as float2, or -- SMALL: the tree has at most 65,536 nodes -- one dword holding the
-    // distance^2 truncated to its upper 16 bits (rounded towards zero: still a lower bound) above the node index.  Half the
-    // LDS lets eight workgroups of 128 share a CU instead of six, and the search is latency-bound.
+    // node stack entry: {distance^2, node} as float2, or -- SMALL: at most 65,536 nodes and triangles -- one dword holding the
+    // distance^2 truncated to its upper 16 bits (rounded towards zero: still a lower bound) above the node index, and
+    // uint16 pending triangles.  LDS per lane decides how many waves share a CU, and the walk is latency-bound.
     float2* nstack = reinterpret_cast<float2*>(lds_raw);
     uint32_t* nstack_s = reinterpret_cast<uint32_t*>(lds_raw);
-    // pending triangles: int, or -- SMALL: F <= 65,536 as well -- uint16
-    int* tlist = reinterpret_cast<int*>(nstack + (size_t)depth * blockDim.x);
-    uint16_t* tlist_s = reinterpret_cast<uint16_t*>(nstack_s + (size_t)depth * blockDim.x);
+    int* tlist = reinterpret_cast<int*>(nstack + (size_t)depth * 64);
+    uint16_t* tlist_s = reinterpret_cast<uint16_t*>(nstack_s + (size_t)depth * 64);
     auto push_tri = [&](int slot, int t) {
-        if (SMALL) tlist_s[(size_t)slot * blockDim.x + threadIdx.x] = (uint16_t)t;
-        else tlist[(size_t)slot * blockDim.x + threadIdx.x] = t;
+        if (SMALL) tlist_s[slot * 64 + threadIdx.x] = (uint16_t)t;
+        else tlist[slot * 64 + threadIdx.x] = t;
     };
-    auto pop_tri = [&](int slot) -> int {
-        return SMALL ? (int)tlist_s[(size_t)slot * blockDim.x + threadIdx.x] : tlist[(size_t)slot * blockDim.x + threadIdx.x];
-    };
+    auto pop_tri = [&](int slot) -> int { return SMALL ? (int)tlist_s[slot * 64 + threadIdx.x] : tlist[slot * 64 + threadIdx.x]; };
     auto push_node = [&](int slot, float k, int id) {
-        if (SMALL) nstack_s[(size_t)slot * blockDim.x + threadIdx.x] = (__float_as_uint(k) & 0xffff0000u) | (uint32_t)id;
-        else nstack[(size_t)slot * blockDim.x + threadIdx.x] = make_float2(k, __int_as_float(id));
+        if (SMALL) nstack_s[slot * 64 + threadIdx.x] = (__float_as_uint(k) & 0xffff0000u) | (uint32_t)id;
+        else nstack[slot * 64 + threadIdx.x] = make_float2(k, __int_as_float(id));
     };
     auto pop_node = [&](int slot, float& k, int& id) {
         if (SMALL) {
-            const uint32_t e = nstack_s[(size_t)slot * blockDim.x + threadIdx.x];
+            const uint32_t e = nstack_s[slot * 64 + threadIdx.x];
             k = __uint_as_float(e & 0xffff0000u); id = (int)(e & 0xffffu);
         } else {
-            const float2 e = nstack[(size_t)slot * blockDim.x + threadIdx.x];
+            const float2 e = nstack[slot * 64 + threadIdx.x];
             k = e.x; id = __float_as_int(e.y);
         }
     };
-    double* can_lds = SMALL ? reinterpret_cast<double*>(tlist_s + (size_t)(kTriSlots + 1) * blockDim.x)      // [S][3]; the +1 slot keeps
-                            : reinterpret_cast<double*>(tlist + (size_t)(kTriSlots + 1) * blockDim.x);       // it 8 B aligned
+    int64_t next = (int64_t)blockIdx.x * kChunk;                                 // wave-uniform: first sample not handed out
+    const int64_t end = next + kChunk < N ? next + kChunk : N;
+    bool active = false;
+    int64_t i = 0;
+    V3 p = {0.f, 0.f, 0.f};
+    float slack = 0.f;
+    Best b;
+    b.d2 = INFINITY; b.sd = INFINITY; b.thr2 = FLT_MAX; b.f = 0x7fffffff; b.q = p;
+    bool has_cur = false;
+    float ck = 0.f;
+    int cid = 0, nsp = 0, ntri = 0;
+#ifdef NM_WARP_DBG
+    float n_iter_w = 0.f, n_iter_t = 0.f;
+#endif
+    for (;;) {
+        bool can_walk = active && (has_cur || nsp > 0) && ntri < kPending;
+        unsigned long long bw = __ballot(can_walk), bt = __ballot(active && ntri > 0);
+        const unsigned long long bi = __ballot(!active);
+        if (next < end && (__popcll(bi) >= kRefill || !(bw | bt))) {               // ---- hand out samples to the idle lanes
+            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bi, 0));
+            if (!active && next + rank < end) {
+                i = next + rank;
+                p = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]};
+                const float pmax = fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z)));
+                slack = 1e-5f * (1.f + fmaxf(pmax, tr.scale));
+                b.d2 = INFINITY; b.sd = INFINITY; b.thr2 = FLT_MAX; b.f = 0x7fffffff; b.q = p;
+                has_cur = pmax <= FLT_MAX && !search_all_mode;                   // NaN / Inf, all-triangles mode: straight to the loop
+                ck = 0.f; cid = 0; nsp = 0; ntri = 0;                            // the root
+                active = true;
+            }
+            next += __popcll(bi);
+            can_walk = active && (has_cur || nsp > 0) && ntri < kPending;
+            bw = __ballot(can_walk); bt = __ballot(active && ntri > 0);
+        }
+        if (__popcll(bt) < __popcll(bw)) {                                       // ---- WALK: expand one node per lane
+#ifdef NM_WARP_DBG
+            n_iter_w += 1.f;
+#endif
+            if (can_walk) {
+        while (!has_cur && nsp > 0) {                            // next entry the bound has not overtaken
+            float ek; int eid;
+            pop_node(--nsp, ek, eid);
+            if (ek <= b.thr2) { ck = ek; cid = eid; has_cur = true; }
+        }
+        if (has_cur && ck > b.thr2) has_cur = false;
+        if (has_cur) {
+            const Node* nd = nodes + cid;
+            const float4 lox = nd->lox, loy = nd->loy, loz = nd->loz, hix = nd->hix, hiy = nd->hiy, hiz = nd->hiz;
+            float k0, k1, k2, k3;
+            {
+                const float x0 = slab(lox.x, hix.x, p.x), y0 = slab(loy.x, hiy.x, p.y), z0 = slab(loz.x, hiz.x, p.z);
+                const float x1 = slab(lox.y, hix.y, p.x), y1 = slab(loy.y, hiy.y, p.y), z1 = slab(loz.y, hiz.y, p.z);
+                const float x2 = slab(lox.z, hix.z, p.x), y2 = slab(loy.z, hiy.z, p.y), z2 = slab(loz.z, hiz.z, p.z);
+                const float x3 = slab(lox.w, hix.w, p.x), y3 = slab(loy.w, hiy.w, p.y), z3 = slab(loz.w, hiz.w, p.z);
+                k0 = fmaf(z0, z0, fmaf(y0, y0, x0 * x0)); k1 = fmaf(z1, z1, fmaf(y1, y1, x1 * x1));
+                k2 = fmaf(z2, z2, fmaf(y2, y2, x2 * x2)); k3 = fmaf(z3, z3, fmaf(y3, y3, x3 * x3));
+            }
+            const bool lp = cid >= tr.first_lp;                  // children are triangles
+            const int child = lp ? 4 * (cid - tr.first_lp) : 4 * cid + 1;
+            int c0 = child, c1 = child + 1, c2 = child + 2, c3 = child + 3;
+            cswap(k0, c0, k1, c1); cswap(k2, c2, k3, c3);        // sort descending: k0 >= k1 >= k2 >= k3
+            cswap(k0, c0, k2, c2); cswap(k1, c1, k3, c3);
+            cswap(k1, c1, k2, c2);
+            // an empty child's distance is +inf > thr2 (<= FLT_MAX): never kept
+            if (lp) {                                            // farthest first: the list is popped from its end
+                if (k0 <= b.thr2) push_tri(ntri++, c0);
+                if (k1 <= b.thr2) push_tri(ntri++, c1);
+                if (k2 <= b.thr2) push_tri(ntri++, c2);
+                if (k3 <= b.thr2) push_tri(ntri++, c3);
+                has_cur = false;
+            } else {
+                if (k0 <= b.thr2) push_node(nsp++, k0, c0);
+                if (k1 <= b.thr2) push_node(nsp++, k1, c1);
+                if (k2 <= b.thr2) push_node(nsp++, k2, c2);
+                has_cur = k3 <= b.thr2;                          // the nearest child is expanded next, from registers
+                ck = k3; cid = c3;
+            }
+        }
+            }
+        } else if (bt) {                                                         // ---- TEST: one pending triangle per lane
+#ifdef NM_WARP_DBG
+            n_iter_t += 1.f;
+#endif
+            if (active && ntri > 0) exact_tri(rec, pop_tri(--ntri), p, slack, b);
+        }
+        if (active && !has_cur && nsp == 0 && ntri == 0) {                       // ---- this lane's sample is done
+            if (b.f == 0x7fffffff) {
+                // all-triangles mode, or nothing found (non-finite point, overflowing distances): the plain loop, whose
+                // answer for such points is face 0 and q = p
+                b.d2 = INFINITY; b.sd = INFINITY; b.thr2 = FLT_MAX; b.f = 0; b.q = p;
+                search_all(rec, tr.F, p, slack, b);
+            }
+            q_out[i * 3] = b.q.x; q_out[i * 3 + 1] = b.q.y; q_out[i * 3 + 2] = b.q.z;
+            f_out[i * 3] = b.f;
+            active = false;
+        }
+        if (next >= end && !__any(active)) break;
+    }
+#ifdef NM_WARP_DBG
+    if (dbg && threadIdx.x == 0) { dbg[blockIdx.x * 2] = n_iter_w; dbg[blockIdx.x * 2 + 1] = n_iter_t; }
+#endif
+}
+
+// ---- tail_kernel: one workgroup per ray, one lane per sample ---------------------------------------------------------------------
+// reads the search result from can_pts (q) and can_dirs (face id) and overwrites both with the outputs
+__global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ pts, int S, const float* __restrict__ verts,
+                                                   const int32_t* __restrict__ faces, const double* __restrict__ T,
+                                                   float* __restrict__ can_pts, float* __restrict__ can_dirs, float* __restrict__ closest) {
+    extern __shared__ double can_lds[];                     // [S][3]
     const int64_t r = blockIdx.x;
     for (int s0 = 0; s0 < S; s0 += blockDim.x) {
         const int s = s0 + threadIdx.x;
         const bool live = s < S;
-        const int64_t i = r * S + (live ? s : S - 1);
+        if (!live) continue;
+        const int64_t i = r * S + s;
         const V3 p = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]};
-        const float pmax = fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z)));
-        const float slack = 1e-5f * (1.f + fmaxf(pmax, tr.scale));
         Best b;
-        b.d2 = INFINITY; b.sd = INFINITY; b.thr2 = FLT_MAX; b.f = 0x7fffffff; b.q = p;
-#ifdef NM_WARP_DBG
-        float n_vis = 0.f, n_ex = 0.f; long long t_walk = 0, t_ex = 0;
-#endif
-        {
-            // a NaN / Inf point, and the all-triangles mode, go straight to the loop below
-            bool has_cur = pmax <= FLT_MAX && !search_all_mode;
-            float ck = 0.f;
-            int cid = 0;                                                         // the root
-            int nsp = 0, ntri = 0;
-            for (;;) {
-                const bool can_walk = (has_cur || nsp > 0) && ntri < kPending;
-                const unsigned long long bw = __ballot(can_walk), bt = __ballot(ntri > 0);
-                if (!(bw | bt)) break;
-                if (__popcll(bt) < __popcll(bw)) {                               // ---- WALK: expand one node per lane
-#ifdef NM_WARP_DBG
-                    t_walk += 1;
-#endif
-                    if (can_walk) {
-                    while (!has_cur && nsp > 0) {                            // next entry the bound has not overtaken
-                        float ek; int eid;
-                        pop_node(--nsp, ek, eid);
-                        if (ek <= b.thr2) { ck = ek; cid = eid; has_cur = true; }
-                    }
-                    if (has_cur && ck > b.thr2) has_cur = false;
-                    if (has_cur) {
-#ifdef NM_WARP_DBG
-                        n_vis += 1.f;
-#endif
-                        const Node* nd = nodes + cid;
-                        const float4 lox = nd->lox, loy = nd->loy, loz = nd->loz, hix = nd->hix, hiy = nd->hiy, hiz = nd->hiz;
-                        float k0, k1, k2, k3;
-                        {
-                            const float x0 = slab(lox.x, hix.x, p.x), y0 = slab(loy.x, hiy.x, p.y), z0 = slab(loz.x, hiz.x, p.z);
-                            const float x1 = slab(lox.y, hix.y, p.x), y1 = slab(loy.y, hiy.y, p.y), z1 = slab(loz.y, hiz.y, p.z);
-                            const float x2 = slab(lox.z, hix.z, p.x), y2 = slab(loy.z, hiy.z, p.y), z2 = slab(loz.z, hiz.z, p.z);
-                            const float x3 = slab(lox.w, hix.w, p.x), y3 = slab(loy.w, hiy.w, p.y), z3 = slab(loz.w, hiz.w, p.z);
-                            k0 = fmaf(z0, z0, fmaf(y0, y0, x0 * x0)); k1 = fmaf(z1, z1, fmaf(y1, y1, x1 * x1));
-                            k2 = fmaf(z2, z2, fmaf(y2, y2, x2 * x2)); k3 = fmaf(z3, z3, fmaf(y3, y3, x3 * x3));
-                        }
-                        const bool lp = cid >= tr.first_lp;                  // children are triangles
-                        const int child = lp ? 4 * (cid - tr.first_lp) : 4 * cid + 1;
-                        int c0 = child, c1 = child + 1, c2 = child + 2, c3 = child + 3;
-                        cswap(k0, c0, k1, c1); cswap(k2, c2, k3, c3);        // sort descending: k0 >= k1 >= k2 >= k3
-                        cswap(k0, c0, k2, c2); cswap(k1, c1, k3, c3);
-                        cswap(k1, c1, k2, c2);
-                        // an empty child's distance is +inf > thr2 (<= FLT_MAX): never kept
-                        if (lp) {                                            // farthest first: the list is popped from its end
-                            if (k0 <= b.thr2) push_tri(ntri++, c0);
-                            if (k1 <= b.thr2) push_tri(ntri++, c1);
-                            if (k2 <= b.thr2) push_tri(ntri++, c2);
-                            if (k3 <= b.thr2) push_tri(ntri++, c3);
-                            has_cur = false;
-                        } else {
-                            if (k0 <= b.thr2) push_node(nsp++, k0, c0);
-                            if (k1 <= b.thr2) push_node(nsp++, k1, c1);
-                            if (k2 <= b.thr2) push_node(nsp++, k2, c2);
-                            has_cur = k3 <= b.thr2;                          // the nearest child is expanded next, from registers
-                            ck = k3; cid = c3;
-                        }
-                    }
-                    }
-                } else {                                                         // ---- TEST: one pending triangle per lane
-#ifdef NM_WARP_DBG
-                    t_ex += 1;
-#endif
-                    if (ntri > 0) {
-                        exact_tri(rec, pop_tri(--ntri), p, slack, b);
-#ifdef NM_WARP_DBG
-                        n_ex += 1.f;
-#endif
-                    }
-                }
-            }
-#ifdef NM_WARP_DBG
-            if (closest && live) { closest[i * 3] = n_vis; closest[i * 3 + 1] = n_ex; closest[i * 3 + 2] = (float)(NM_WARP_DBG == 2 ? t_ex : t_walk); }
-#endif
-        }
-        if (b.f == 0x7fffffff) {
-            // all-triangles mode, or nothing found (non-finite point, overflowing distances): the plain loop, whose
-            // answer for such points is face 0 and q = p
-            b.d2 = INFINITY; b.sd = INFINITY; b.thr2 = FLT_MAX; b.f = 0; b.q = p;
-            search_all(rec, tr.F, p, slack, b);
-        }
+        b.f = reinterpret_cast<const int32_t*>(can_dirs)[i * 3];
+        b.q = {can_pts[i * 3], can_pts[i * 3 + 1], can_pts[i * 3 + 2]};
         const int bf = b.f;
         const V3 q = b.q;
         // ---- barycentrics of q in the winning triangle, igl.barycentric_coordinates_tri (ray_utils.py:55), f64
@@ -585,18 +618,37 @@ int nm_warp_to_canonical(nm_mesh_t m, const float* pts, int64_t R, int S, const 
     NM_REQUIRE(R == 0 || (pts && T && can_pts && can_dirs), "nm_warp_to_canonical: null pointer");
     NM_REQUIRE(R >= 0 && S >= 2, "nm_warp_to_canonical: bad sizes R=%lld S=%d", (long long)R, S);
     NM_REQUIRE(R < (1ll << 31), "nm_warp_to_canonical: too many rays for one launch");
+    NM_REQUIRE((size_t)S * 24 <= 64 * 1024, "nm_warp_to_canonical: S=%d exceeds the LDS staging budget", S);
     if (R == 0) return NM_OK;
-    const int threads = S <= 64 ? 64 : (S <= 128 ? 128 : 256);
     const bool small = m->n_nodes <= 65536 && m->F <= 65536 && !m->force_wide;
-    const size_t lds = (size_t)(3 * (m->tr.L - 1)) * threads * (small ? 4 : 8) + (size_t)(kTriSlots + 1) * threads * (small ? 2 : 4) + (size_t)S * 24;
-    NM_REQUIRE(lds <= 64 * 1024, "nm_warp_to_canonical: S=%d exceeds the LDS budget (%zu B)", S, lds);
-    if (small)
-        hipLaunchKernelGGL(warp_kernel<true>, dim3((unsigned)R), dim3(threads), lds, nm::as_stream(stream), m->tr,
-                           m->search == NM_SEARCH_ALL ? 1 : 0, pts, S, m->d_verts, m->d_faces, m->d_rec, m->d_nodes, T, can_pts, can_dirs, closest);
-    else
-        hipLaunchKernelGGL(warp_kernel<false>, dim3((unsigned)R), dim3(threads), lds, nm::as_stream(stream), m->tr,
-                           m->search == NM_SEARCH_ALL ? 1 : 0, pts, S, m->d_verts, m->d_faces, m->d_rec, m->d_nodes, T, can_pts, can_dirs, closest);
-    return nm::check_launch("warp_kernel");
+    const int64_t N = R * (int64_t)S;
+    NM_REQUIRE(N < (1ll << 31) * (int64_t)kChunk, "nm_warp_to_canonical: too many samples for one launch");
+    const unsigned waves = (unsigned)((N + kChunk - 1) / kChunk);
+    const size_t lds = (size_t)(3 * (m->tr.L - 1)) * 64 * (small ? 4 : 8) + (size_t)kTriSlots * 64 * (small ? 2 : 4);
+    hipStream_t st = nm::as_stream(stream);
+    int32_t* f_out = reinterpret_cast<int32_t*>(can_dirs);
+    const int all = m->search == NM_SEARCH_ALL ? 1 : 0;
+#ifdef NM_WARP_DBG
+    float* dbg = nullptr;
+    (void)hipMalloc(&dbg, (size_t)waves * 8);
+    if (small) hipLaunchKernelGGL(search_kernel<true>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_nodes, can_pts, f_out, dbg);
+    else hipLaunchKernelGGL(search_kernel<false>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_nodes, can_pts, f_out, dbg);
+    {
+        std::vector<float> h((size_t)waves * 2);
+        (void)hipMemcpy(h.data(), dbg, h.size() * 4, hipMemcpyDeviceToHost);
+        double w = 0, t = 0;
+        for (unsigned k = 0; k < waves; ++k) { w += h[2 * k]; t += h[2 * k + 1]; }
+        fprintf(stderr, "[warp dbg] waves %u, walk iterations / wave %.1f, test iterations / wave %.1f\n", waves, w / waves, t / waves);
+        (void)hipFree(dbg);
+    }
+#else
+    if (small) hipLaunchKernelGGL(search_kernel<true>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_nodes, can_pts, f_out);
+    else hipLaunchKernelGGL(search_kernel<false>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_nodes, can_pts, f_out);
+#endif
+    if (int rc = nm::check_launch("search_kernel")) return rc;
+    const int threads = S <= 64 ? 64 : (S <= 128 ? 128 : 256);
+    hipLaunchKernelGGL(tail_kernel, dim3((unsigned)R), dim3(threads), (size_t)S * 24, st, pts, S, m->d_verts, m->d_faces, T, can_pts, can_dirs, closest);
+    return nm::check_launch("tail_kernel");
 }
 
 }  // extern "C"
