@@ -37,11 +37,12 @@ namespace {
 #endif
 constexpr int kMaxLevels = 12;           // 4^12 = 16.7 M triangles
 
-struct TriRec {          // 16 floats
-    float sx, sy, sz, sr;   // bounding sphere (first 16 B: the all-triangles loop's cull test reads only this)
-    float ax, ay, az, bx, by, bz, cx, cy, cz;
-    int face;               // id in the caller's face array (records are stored in Morton order)
-    float pad[2];
+// A triangle as the exact test wants it: a corner, the two edges from it, and every quantity of the Voronoi-region test that
+// depends on the triangle alone -- the Gram products and the four reciprocals the test would otherwise compute per query.
+struct TriRec {          // 16 floats = 64 B = four 16 B loads
+    float ax, ay, az, abx, aby, abz, acx, acy, acz;
+    float abab, abac, acac;                    // ab.ab, ab.ac, ac.ac
+    float i_abab, i_acac, i_bcbc, i_den;       // 1 / |ab|^2, 1 / |ac|^2, 1 / |bc|^2, 1 / |ab x ac|^2
 };
 
 struct Node {            // the four children's boxes, SoA
@@ -117,22 +118,23 @@ __global__ __launch_bounds__(256) void tri_prep_kernel(const float* __restrict__
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
     const int i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
+    const float ax = verts[i0 * 3], ay = verts[i0 * 3 + 1], az = verts[i0 * 3 + 2];
+    const float bx = verts[i1 * 3], by = verts[i1 * 3 + 1], bz = verts[i1 * 3 + 2];
+    const float cx = verts[i2 * 3], cy = verts[i2 * 3 + 1], cz = verts[i2 * 3 + 2];
     TriRec t;
-    t.ax = verts[i0 * 3]; t.ay = verts[i0 * 3 + 1]; t.az = verts[i0 * 3 + 2];
-    t.bx = verts[i1 * 3]; t.by = verts[i1 * 3 + 1]; t.bz = verts[i1 * 3 + 2];
-    t.cx = verts[i2 * 3]; t.cy = verts[i2 * 3 + 1]; t.cz = verts[i2 * 3 + 2];
-    t.sx = (t.ax + t.bx + t.cx) * (1.f / 3.f);
-    t.sy = (t.ay + t.by + t.cy) * (1.f / 3.f);
-    t.sz = (t.az + t.bz + t.cz) * (1.f / 3.f);
-    const float da = (t.ax - t.sx) * (t.ax - t.sx) + (t.ay - t.sy) * (t.ay - t.sy) + (t.az - t.sz) * (t.az - t.sz);
-    const float db = (t.bx - t.sx) * (t.bx - t.sx) + (t.by - t.sy) * (t.by - t.sy) + (t.bz - t.sz) * (t.bz - t.sz);
-    const float dc = (t.cx - t.sx) * (t.cx - t.sx) + (t.cy - t.sy) * (t.cy - t.sy) + (t.cz - t.sz) * (t.cz - t.sz);
-    t.sr = sqrtf(fmaxf(da, fmaxf(db, dc))) * 1.0001f + 1e-7f;
-    t.face = f;
-    t.pad[0] = t.pad[1] = 0.f;
+    t.ax = ax; t.ay = ay; t.az = az;
+    t.abx = bx - ax; t.aby = by - ay; t.abz = bz - az;
+    t.acx = cx - ax; t.acy = cy - ay; t.acz = cz - az;
+    t.abab = fmaf(t.abz, t.abz, fmaf(t.aby, t.aby, t.abx * t.abx));
+    t.abac = fmaf(t.abz, t.acz, fmaf(t.aby, t.acy, t.abx * t.acx));
+    t.acac = fmaf(t.acz, t.acz, fmaf(t.acy, t.acy, t.acx * t.acx));
+    t.i_abab = 1.f / t.abab;
+    t.i_acac = 1.f / t.acac;
+    t.i_bcbc = 1.f / (t.abab - 2.f * t.abac + t.acac);
+    t.i_den = 1.f / (t.abab * t.acac - t.abac * t.abac);
     rec[f] = t;
     uint32_t code = 0;
-    const float c[3] = {t.sx, t.sy, t.sz};
+    const float c[3] = {(ax + bx + cx) * (1.f / 3.f), (ay + by + cy) * (1.f / 3.f), (az + bz + cz) * (1.f / 3.f)};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float ext = bbox[3 + k] - bbox[k];
@@ -146,12 +148,12 @@ __global__ __launch_bounds__(256) void tri_prep_kernel(const float* __restrict__
 // rank sort: position of record f in Morton order = number of smaller keys.  F^2 compares of wave-uniform (scalar-loaded)
 // keys: 70 us for F = 13,776, and still ~1 ms at F = 100 k -- no multi-pass radix sort for a body mesh.
 __global__ __launch_bounds__(256) void rank_scatter_kernel(const unsigned long long* __restrict__ keys, int F, const TriRec* __restrict__ rec,
-                                                           TriRec* __restrict__ sorted) {
+                                                           TriRec* __restrict__ sorted, int32_t* __restrict__ face_of) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long mine = f < F ? keys[f] : 0ull;
     int rank = 0;
     for (int g = 0; g < F; ++g) rank += keys[g] < mine ? 1 : 0;
-    if (f < F) sorted[rank] = rec[f];
+    if (f < F) { sorted[rank] = rec[f]; face_of[rank] = f; }
 }
 
 __device__ __forceinline__ void set_lane(float4& v, int c, float x) {
@@ -160,8 +162,10 @@ __device__ __forceinline__ void set_lane(float4& v, int c, float x) {
 __device__ __forceinline__ float min4(float4 v) { return fminf(fminf(v.x, v.y), fminf(v.z, v.w)); }
 __device__ __forceinline__ float max4(float4 v) { return fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)); }
 
-// level L-1: children are the sorted triangles 4i .. 4i+3; a missing child gets the empty box (lo = +inf, hi = -inf)
-__global__ __launch_bounds__(256) void leaf_nodes_kernel(const TriRec* __restrict__ sorted, int F, int n, Node* __restrict__ nodes) {
+// level L-1: children are the sorted triangles 4i .. 4i+3 (boxes of the caller's vertices); a missing child gets the empty box
+// (lo = +inf, hi = -inf)
+__global__ __launch_bounds__(256) void leaf_nodes_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces,
+                                                         const int32_t* __restrict__ face_of, int F, int n, Node* __restrict__ nodes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Node nd;
@@ -170,10 +174,16 @@ __global__ __launch_bounds__(256) void leaf_nodes_kernel(const TriRec* __restric
         const int t = 4 * i + c;
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         if (t < F) {
-            const TriRec r = sorted[t];
-            lo[0] = fminf(r.ax, fminf(r.bx, r.cx)); hi[0] = fmaxf(r.ax, fmaxf(r.bx, r.cx));
-            lo[1] = fminf(r.ay, fminf(r.by, r.cy)); hi[1] = fmaxf(r.ay, fmaxf(r.by, r.cy));
-            lo[2] = fminf(r.az, fminf(r.bz, r.cz)); hi[2] = fmaxf(r.az, fmaxf(r.bz, r.cz));
+            const int f = face_of[t];
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const int iv = faces[f * 3 + v];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    lo[k] = fminf(lo[k], verts[iv * 3 + k]);
+                    hi[k] = fmaxf(hi[k], verts[iv * 3 + k]);
+                }
+            }
         }
         set_lane(nd.lox, c, lo[0]); set_lane(nd.loy, c, lo[1]); set_lane(nd.loz, c, lo[2]);
         set_lane(nd.hix, c, hi[0]); set_lane(nd.hiy, c, hi[1]); set_lane(nd.hiz, c, hi[2]);
@@ -206,39 +216,6 @@ struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
-// exact closest point on triangle (a,b,c) to p: Voronoi-region test (Ericson, RTCD 5.1.5), written without branches --
-// the seven regions become selects applied in reverse priority, the four quotients use v_rcp_f32 (1 ulp; the error it
-// leaves in q is ~1e-7 of an edge length, far below one ulp of the coordinates) -- because 64 lanes testing 64 different
-// triangles would otherwise run every region's code one after the other.
-__device__ __forceinline__ V3 closest_on_tri(V3 p, V3 a, V3 b, V3 c) {
-    const V3 ab = sub(b, a), ac = sub(c, a), ap = sub(p, a);
-    const float d1 = dot(ab, ap), d2 = dot(ac, ap);
-    const V3 bp = sub(p, b);
-    const float d3 = dot(ab, bp), d4 = dot(ac, bp);
-    const V3 cp = sub(p, c);
-    const float d5 = dot(ab, cp), d6 = dot(ac, cp);
-    const float vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
-    const float e43 = d4 - d3, e56 = d5 - d6;
-    const float t_ab = d1 * __builtin_amdgcn_rcpf(d1 - d3);
-    const float t_ac = d2 * __builtin_amdgcn_rcpf(d2 - d6);
-    const float t_bc = e43 * __builtin_amdgcn_rcpf(e43 + e56);
-    const float den = __builtin_amdgcn_rcpf(va + vb + vc);
-    float v = vb * den, w = vc * den;                                               // interior; q = a + v*ab + w*ac
-    const bool r_bc = va <= 0.f && e43 >= 0.f && e56 >= 0.f;                         // edge BC
-    v = r_bc ? 1.f - t_bc : v;  w = r_bc ? t_bc : w;
-    const bool r_ac = vb <= 0.f && d2 >= 0.f && d6 <= 0.f;                           // edge AC
-    v = r_ac ? 0.f : v;         w = r_ac ? t_ac : w;
-    const bool r_c = d6 >= 0.f && d5 <= d6;                                          // vertex C
-    v = r_c ? 0.f : v;          w = r_c ? 1.f : w;
-    const bool r_ab = vc <= 0.f && d1 >= 0.f && d3 <= 0.f;                           // edge AB
-    v = r_ab ? t_ab : v;        w = r_ab ? 0.f : w;
-    const bool r_b = d3 >= 0.f && d4 <= d3;                                          // vertex B
-    v = r_b ? 1.f : v;          w = r_b ? 0.f : w;
-    const bool r_a = d1 <= 0.f && d2 <= 0.f;                                         // vertex A
-    v = r_a ? 0.f : v;          w = r_a ? 0.f : w;
-    return {a.x + ab.x * v + ac.x * w, a.y + ab.y * v + ac.y * w, a.z + ab.z * v + ac.z * w};
-}
-
 // inverse of a general 4x4 (row-major) by cofactors, f64; only the first three rows are produced
 __device__ __forceinline__ void inv4x4(const double* m, double* o) {
     const double s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2], s2 = m[0] * m[7] - m[4] * m[3];
@@ -267,38 +244,65 @@ struct Best {
     V3 q;
 };
 
-// exact test of sorted record t; ties go to the lowest face id, so the result does not depend on the visiting order
-__device__ __forceinline__ void exact_tri(const TriRec* __restrict__ rec, int t, V3 p, float slack, Best& b) {
-    const float4 t0 = reinterpret_cast<const float4*>(&rec[t])[1];
-    const float4 t1 = reinterpret_cast<const float4*>(&rec[t])[2];
-    const float4 t2 = reinterpret_cast<const float4*>(&rec[t])[3];
-    const int f = __float_as_int(t2.y);
-    const V3 c = closest_on_tri(p, {t0.x, t0.y, t0.z}, {t0.w, t1.x, t1.y}, {t1.z, t1.w, t2.x});
-    const V3 d = sub(c, p);
-    const float d2 = dot(d, d);
-    if (d2 < b.d2 || (d2 == b.d2 && f < b.f)) {
-        b.d2 = d2; b.sd = sqrtf(d2); b.f = f; b.q = c;
-        const float thr = b.sd * 1.0001f + slack;
-        b.thr2 = fminf(thr * thr, FLT_MAX);
+// Exact closest point of sorted triangle t to p: the Voronoi-region test (Ericson, RTCD 5.1.5) without branches -- 64 lanes
+// testing 64 different triangles would otherwise run every region's code one after the other.  With bp = ap - ab and
+// cp = ap - ac the six dot products reduce to two (d3 = d1 - ab.ab, ...), and the four denominators -- |ab|^2, |ac|^2,
+// |bc|^2 and va + vb + vc = |ab x ac|^2 -- are constants of the triangle, stored as reciprocals.  The seven regions become
+// selects applied in reverse priority.  Ties between equidistant triangles go to the lowest face id, so the result does not
+// depend on the visiting order; the face id is read only when a triangle ties or wins.
+__device__ __forceinline__ void exact_tri(const TriRec* __restrict__ rec, const int32_t* __restrict__ face_of, int t, V3 p, float slack,
+                                          Best& b) {
+    const float4 r0 = reinterpret_cast<const float4*>(&rec[t])[0];      // ax ay az abx
+    const float4 r1 = reinterpret_cast<const float4*>(&rec[t])[1];      // aby abz acx acy
+    const float4 r2 = reinterpret_cast<const float4*>(&rec[t])[2];      // acz abab abac acac
+    const float4 r3 = reinterpret_cast<const float4*>(&rec[t])[3];      // i_abab i_acac i_bcbc i_den
+    const float apx = p.x - r0.x, apy = p.y - r0.y, apz = p.z - r0.z;
+    const float d1 = fmaf(r1.y, apz, fmaf(r1.x, apy, r0.w * apx));      // ab.ap
+    const float d2 = fmaf(r2.x, apz, fmaf(r1.w, apy, r1.z * apx));      // ac.ap
+    const float d3 = d1 - r2.y, d4 = d2 - r2.z;                         // ab.bp, ac.bp
+    const float d5 = d1 - r2.z, d6 = d2 - r2.w;                         // ab.cp, ac.cp
+    const float vc = fmaf(d1, d4, -(d3 * d2)), vb = fmaf(d5, d2, -(d1 * d6)), va = fmaf(d3, d6, -(d5 * d4));
+    const float e43 = d4 - d3, e56 = d5 - d6;
+    const float t_ab = d1 * r3.x, t_ac = d2 * r3.y, t_bc = e43 * r3.z;
+    float v = vb * r3.w, w = vc * r3.w;                                              // interior; q = a + v*ab + w*ac
+    const bool r_bc = va <= 0.f && e43 >= 0.f && e56 >= 0.f;                         // edge BC
+    v = r_bc ? 1.f - t_bc : v;  w = r_bc ? t_bc : w;
+    const bool r_ac = vb <= 0.f && d2 >= 0.f && d6 <= 0.f;                           // edge AC
+    v = r_ac ? 0.f : v;         w = r_ac ? t_ac : w;
+    const bool r_c = d6 >= 0.f && d5 <= d6;                                          // vertex C
+    v = r_c ? 0.f : v;          w = r_c ? 1.f : w;
+    const bool r_ab = vc <= 0.f && d1 >= 0.f && d3 <= 0.f;                           // edge AB
+    v = r_ab ? t_ab : v;        w = r_ab ? 0.f : w;
+    const bool r_b = d3 >= 0.f && d4 <= d3;                                          // vertex B
+    v = r_b ? 1.f : v;          w = r_b ? 0.f : w;
+    const bool r_a = d1 <= 0.f && d2 <= 0.f;                                         // vertex A
+    v = r_a ? 0.f : v;          w = r_a ? 0.f : w;
+    const V3 c = {fmaf(r1.z, w, fmaf(r0.w, v, r0.x)), fmaf(r1.w, w, fmaf(r1.x, v, r0.y)), fmaf(r2.x, w, fmaf(r1.y, v, r0.z))};
+    const float dx = c.x - p.x, dy = c.y - p.y, dz = c.z - p.z;
+    const float dd = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    if (dd <= b.d2) {
+        const int f = face_of[t];
+        if (dd < b.d2 || f < b.f) {
+            b.d2 = dd; b.sd = sqrtf(dd); b.f = f; b.q = c;
+            const float thr = b.sd * 1.0001f + slack;
+            b.thr2 = fminf(thr * thr, FLT_MAX);
+        }
     }
 }
 
-// the all-triangles loop: bounding-sphere cull, then the exact test (search mode NM_SEARCH_ALL, and the fallback)
-__device__ __forceinline__ void search_all(const TriRec* __restrict__ rec, int F, V3 p, float slack, Best& b) {
-    for (int t = 0; t < F; ++t) {
-        const float4 s = *reinterpret_cast<const float4*>(&rec[t]);
-        const float cx = s.x - p.x, cy = s.y - p.y, cz = s.z - p.z;
-        const float lim = b.sd * 1.0001f + slack + s.w;            // the tree search's margin: both modes see every contender
-        if (cx * cx + cy * cy + cz * cz <= lim * lim) exact_tri(rec, t, p, slack, b);
-    }
+// the all-triangles loop (search mode NM_SEARCH_ALL, and the fallback for points the tree search cannot order)
+__device__ __forceinline__ void search_all(const TriRec* __restrict__ rec, const int32_t* __restrict__ face_of, int F, V3 p, float slack,
+                                           Best& b) {
+    for (int t = 0; t < F; ++t) exact_tri(rec, face_of, t, p, slack, b);
 }
 
 __device__ __forceinline__ float slab(float lo, float hi, float x) { return fmaxf(fmaxf(lo - x, x - hi), 0.f); }
-__device__ __forceinline__ void cswap(float& ka, int& ia, float& kb, int& ib) {      // afterwards ka >= kb
-    const bool sw = ka < kb;
-    const float k0 = sw ? kb : ka, k1 = sw ? ka : kb;
-    const int i0 = sw ? ib : ia, i1 = sw ? ia : ib;
-    ka = k0; kb = k1; ia = i0; ib = i1;
+// child order: the distance^2 (>= 0, so its bit pattern orders like the value) with the child slot in the two low mantissa
+// bits -- cleared bits round the distance down, which keeps it a lower bound -- sorts with one min and one max per exchange
+__device__ __forceinline__ uint32_t child_key(float k, uint32_t c) { return (__float_as_uint(k) & ~3u) | c; }
+__device__ __forceinline__ void cswap(uint32_t& a, uint32_t& b) {                   // afterwards a >= b
+    const uint32_t hi = a > b ? a : b, lo = a > b ? b : a;
+    a = hi; b = lo;
 }
 
 // ---- search_kernel: closest triangle and closest point per sample --------------------------------------------------------------
@@ -320,8 +324,9 @@ constexpr int kRefill = 8;               // idle lanes that trigger a refill (or
 
 template <bool SMALL>
 __global__ __launch_bounds__(64) NM_WARP_ATTR void search_kernel(Tree tr, int search_all_mode, const float* __restrict__ pts, int64_t N,
-                                                                 const TriRec* __restrict__ rec, const Node* __restrict__ nodes,
-                                                                 float* __restrict__ q_out, int32_t* __restrict__ f_out
+                                                                 const TriRec* __restrict__ rec, const int32_t* __restrict__ face_of,
+                                                                 const Node* __restrict__ nodes, float* __restrict__ q_out,
+                                                                 int32_t* __restrict__ f_out
 #ifdef NM_WARP_DBG
                                                                  , float* __restrict__ dbg
 #endif
@@ -392,58 +397,56 @@ __global__ __launch_bounds__(64) NM_WARP_ATTR void search_kernel(Tree tr, int se
             n_iter_w += 1.f;
 #endif
             if (can_walk) {
-        while (!has_cur && nsp > 0) {                            // next entry the bound has not overtaken
-            float ek; int eid;
-            pop_node(--nsp, ek, eid);
-            if (ek <= b.thr2) { ck = ek; cid = eid; has_cur = true; }
-        }
-        if (has_cur && ck > b.thr2) has_cur = false;
-        if (has_cur) {
-            const Node* nd = nodes + cid;
-            const float4 lox = nd->lox, loy = nd->loy, loz = nd->loz, hix = nd->hix, hiy = nd->hiy, hiz = nd->hiz;
-            float k0, k1, k2, k3;
-            {
-                const float x0 = slab(lox.x, hix.x, p.x), y0 = slab(loy.x, hiy.x, p.y), z0 = slab(loz.x, hiz.x, p.z);
-                const float x1 = slab(lox.y, hix.y, p.x), y1 = slab(loy.y, hiy.y, p.y), z1 = slab(loz.y, hiz.y, p.z);
-                const float x2 = slab(lox.z, hix.z, p.x), y2 = slab(loy.z, hiy.z, p.y), z2 = slab(loz.z, hiz.z, p.z);
-                const float x3 = slab(lox.w, hix.w, p.x), y3 = slab(loy.w, hiy.w, p.y), z3 = slab(loz.w, hiz.w, p.z);
-                k0 = fmaf(z0, z0, fmaf(y0, y0, x0 * x0)); k1 = fmaf(z1, z1, fmaf(y1, y1, x1 * x1));
-                k2 = fmaf(z2, z2, fmaf(y2, y2, x2 * x2)); k3 = fmaf(z3, z3, fmaf(y3, y3, x3 * x3));
-            }
-            const bool lp = cid >= tr.first_lp;                  // children are triangles
-            const int child = lp ? 4 * (cid - tr.first_lp) : 4 * cid + 1;
-            int c0 = child, c1 = child + 1, c2 = child + 2, c3 = child + 3;
-            cswap(k0, c0, k1, c1); cswap(k2, c2, k3, c3);        // sort descending: k0 >= k1 >= k2 >= k3
-            cswap(k0, c0, k2, c2); cswap(k1, c1, k3, c3);
-            cswap(k1, c1, k2, c2);
-            // an empty child's distance is +inf > thr2 (<= FLT_MAX): never kept
-            if (lp) {                                            // farthest first: the list is popped from its end
-                if (k0 <= b.thr2) push_tri(ntri++, c0);
-                if (k1 <= b.thr2) push_tri(ntri++, c1);
-                if (k2 <= b.thr2) push_tri(ntri++, c2);
-                if (k3 <= b.thr2) push_tri(ntri++, c3);
-                has_cur = false;
-            } else {
-                if (k0 <= b.thr2) push_node(nsp++, k0, c0);
-                if (k1 <= b.thr2) push_node(nsp++, k1, c1);
-                if (k2 <= b.thr2) push_node(nsp++, k2, c2);
-                has_cur = k3 <= b.thr2;                          // the nearest child is expanded next, from registers
-                ck = k3; cid = c3;
-            }
-        }
+                while (!has_cur && nsp > 0) {                                    // next entry the bound has not overtaken
+                    float ek; int eid;
+                    pop_node(--nsp, ek, eid);
+                    if (ek <= b.thr2) { ck = ek; cid = eid; has_cur = true; }
+                }
+                if (has_cur && ck > b.thr2) has_cur = false;
+                if (has_cur) {
+                    const Node* nd = nodes + cid;
+                    const float4 lox = nd->lox, loy = nd->loy, loz = nd->loz, hix = nd->hix, hiy = nd->hiy, hiz = nd->hiz;
+                    const float x0 = slab(lox.x, hix.x, p.x), y0 = slab(loy.x, hiy.x, p.y), z0 = slab(loz.x, hiz.x, p.z);
+                    const float x1 = slab(lox.y, hix.y, p.x), y1 = slab(loy.y, hiy.y, p.y), z1 = slab(loz.y, hiz.y, p.z);
+                    const float x2 = slab(lox.z, hix.z, p.x), y2 = slab(loy.z, hiy.z, p.y), z2 = slab(loz.z, hiz.z, p.z);
+                    const float x3 = slab(lox.w, hix.w, p.x), y3 = slab(loy.w, hiy.w, p.y), z3 = slab(loz.w, hiz.w, p.z);
+                    uint32_t k0 = child_key(fmaf(z0, z0, fmaf(y0, y0, x0 * x0)), 0), k1 = child_key(fmaf(z1, z1, fmaf(y1, y1, x1 * x1)), 1);
+                    uint32_t k2 = child_key(fmaf(z2, z2, fmaf(y2, y2, x2 * x2)), 2), k3 = child_key(fmaf(z3, z3, fmaf(y3, y3, x3 * x3)), 3);
+                    cswap(k0, k1); cswap(k2, k3);                                // sort descending: k0 >= k1 >= k2 >= k3
+                    cswap(k0, k2); cswap(k1, k3);
+                    cswap(k1, k2);
+                    // keep a child when its key is <= the bound's (4 ulp of slop on the keeping side); an empty child's
+                    // distance is +inf, above any bound (thr2 <= FLT_MAX): never kept
+                    const uint32_t tb = __float_as_uint(b.thr2) | 3u;
+                    const bool lp = cid >= tr.first_lp;                          // children are triangles
+                    const int child = lp ? 4 * (cid - tr.first_lp) : 4 * cid + 1;
+                    if (lp) {                                                    // farthest first: the list is popped from its end
+                        if (k0 <= tb) push_tri(ntri++, child + (int)(k0 & 3u));
+                        if (k1 <= tb) push_tri(ntri++, child + (int)(k1 & 3u));
+                        if (k2 <= tb) push_tri(ntri++, child + (int)(k2 & 3u));
+                        if (k3 <= tb) push_tri(ntri++, child + (int)(k3 & 3u));
+                        has_cur = false;
+                    } else {
+                        if (k0 <= tb) push_node(nsp++, __uint_as_float(k0 & ~3u), child + (int)(k0 & 3u));
+                        if (k1 <= tb) push_node(nsp++, __uint_as_float(k1 & ~3u), child + (int)(k1 & 3u));
+                        if (k2 <= tb) push_node(nsp++, __uint_as_float(k2 & ~3u), child + (int)(k2 & 3u));
+                        has_cur = k3 <= tb;                                      // the nearest child is expanded next, from registers
+                        ck = __uint_as_float(k3 & ~3u); cid = child + (int)(k3 & 3u);
+                    }
+                }
             }
         } else if (bt) {                                                         // ---- TEST: one pending triangle per lane
 #ifdef NM_WARP_DBG
             n_iter_t += 1.f;
 #endif
-            if (active && ntri > 0) exact_tri(rec, pop_tri(--ntri), p, slack, b);
+            if (active && ntri > 0) exact_tri(rec, face_of, pop_tri(--ntri), p, slack, b);
         }
         if (active && !has_cur && nsp == 0 && ntri == 0) {                       // ---- this lane's sample is done
             if (b.f == 0x7fffffff) {
                 // all-triangles mode, or nothing found (non-finite point, overflowing distances): the plain loop, whose
                 // answer for such points is face 0 and q = p
                 b.d2 = INFINITY; b.sd = INFINITY; b.thr2 = FLT_MAX; b.f = 0; b.q = p;
-                search_all(rec, tr.F, p, slack, b);
+                search_all(rec, face_of, tr.F, p, slack, b);
             }
             q_out[i * 3] = b.q.x; q_out[i * 3 + 1] = b.q.y; q_out[i * 3 + 2] = b.q.z;
             f_out[i * 3] = b.f;
@@ -528,6 +531,7 @@ struct nm_mesh_s {
     float* d_verts;      // owned copies: the handle outlives the caller's tensors
     int32_t* d_faces;
     TriRec* d_rec;       // Morton order
+    int32_t* d_face;     // caller's face id of sorted triangle t
     Node* d_nodes;
 };
 
@@ -538,6 +542,7 @@ int nm_mesh_destroy(nm_mesh_t m) {
     if (m->d_verts) (void)hipFree(m->d_verts);
     if (m->d_faces) (void)hipFree(m->d_faces);
     if (m->d_rec) (void)hipFree(m->d_rec);
+    if (m->d_face) (void)hipFree(m->d_face);
     if (m->d_nodes) (void)hipFree(m->d_nodes);
     delete m;
     return NM_OK;
@@ -571,6 +576,7 @@ int nm_mesh_create(const float* verts, int V, const int32_t* faces, int F, int s
     NM_TRY(hipMalloc(&m->d_verts, (size_t)V * 12), "nm_mesh_create: hipMalloc(verts)");
     NM_TRY(hipMalloc(&m->d_faces, (size_t)F * 12), "nm_mesh_create: hipMalloc(faces)");
     NM_TRY(hipMalloc(&m->d_rec, (size_t)F * sizeof(TriRec)), "nm_mesh_create: hipMalloc(records)");
+    NM_TRY(hipMalloc(&m->d_face, (size_t)F * 4), "nm_mesh_create: hipMalloc(face ids)");
     NM_TRY(hipMalloc(&m->d_nodes, (size_t)total * sizeof(Node)), "nm_mesh_create: hipMalloc(nodes)");
     NM_TRY(hipMalloc(&d_tmp, (size_t)F * sizeof(TriRec)), "nm_mesh_create: hipMalloc(unsorted records)");
     NM_TRY(hipMalloc(&d_keys, (size_t)F * 8), "nm_mesh_create: hipMalloc(keys)");
@@ -581,9 +587,9 @@ int nm_mesh_create(const float* verts, int V, const int32_t* faces, int F, int s
     if (!rc) {
         hipLaunchKernelGGL(bbox_kernel, dim3(1), dim3(1024), 0, st, m->d_verts, V, d_bbox);
         hipLaunchKernelGGL(tri_prep_kernel, dim3((F + 255) / 256), dim3(256), 0, st, m->d_verts, m->d_faces, F, d_bbox, d_tmp, d_keys);
-        hipLaunchKernelGGL(rank_scatter_kernel, dim3((F + 255) / 256), dim3(256), 0, st, d_keys, F, d_tmp, m->d_rec);
-        hipLaunchKernelGGL(leaf_nodes_kernel, dim3((n_level[tr.L - 1] + 255) / 256), dim3(256), 0, st, m->d_rec, F, n_level[tr.L - 1],
-                           m->d_nodes + tr.first_lp);
+        hipLaunchKernelGGL(rank_scatter_kernel, dim3((F + 255) / 256), dim3(256), 0, st, d_keys, F, d_tmp, m->d_rec, m->d_face);
+        hipLaunchKernelGGL(leaf_nodes_kernel, dim3((n_level[tr.L - 1] + 255) / 256), dim3(256), 0, st, m->d_verts, m->d_faces, m->d_face, F,
+                           n_level[tr.L - 1], m->d_nodes + tr.first_lp);
         for (int l = tr.L - 2; l >= 0; --l)
             hipLaunchKernelGGL(upper_nodes_kernel, dim3((n_level[l] + 255) / 256), dim3(256), 0, st, m->d_nodes + level_base(l + 1),
                                n_level[l + 1], n_level[l], m->d_nodes + level_base(l));
@@ -608,7 +614,7 @@ int nm_mesh_info(nm_mesh_t m, int32_t* levels, int64_t* nodes, int64_t* bytes) {
     NM_REQUIRE(m, "nm_mesh_info: null handle");
     if (levels) *levels = m->tr.L;
     if (nodes) *nodes = m->n_nodes;
-    if (bytes) *bytes = (int64_t)m->n_nodes * (int64_t)sizeof(Node) + (int64_t)m->F * (int64_t)sizeof(TriRec);
+    if (bytes) *bytes = (int64_t)m->n_nodes * (int64_t)sizeof(Node) + (int64_t)m->F * (int64_t)(sizeof(TriRec) + 4);
     return NM_OK;
 }
 
@@ -631,8 +637,8 @@ int nm_warp_to_canonical(nm_mesh_t m, const float* pts, int64_t R, int S, const 
 #ifdef NM_WARP_DBG
     float* dbg = nullptr;
     (void)hipMalloc(&dbg, (size_t)waves * 8);
-    if (small) hipLaunchKernelGGL(search_kernel<true>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_nodes, can_pts, f_out, dbg);
-    else hipLaunchKernelGGL(search_kernel<false>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_nodes, can_pts, f_out, dbg);
+    if (small) hipLaunchKernelGGL(search_kernel<true>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, can_pts, f_out, dbg);
+    else hipLaunchKernelGGL(search_kernel<false>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, can_pts, f_out, dbg);
     {
         std::vector<float> h((size_t)waves * 2);
         (void)hipMemcpy(h.data(), dbg, h.size() * 4, hipMemcpyDeviceToHost);
@@ -642,8 +648,8 @@ int nm_warp_to_canonical(nm_mesh_t m, const float* pts, int64_t R, int S, const 
         (void)hipFree(dbg);
     }
 #else
-    if (small) hipLaunchKernelGGL(search_kernel<true>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_nodes, can_pts, f_out);
-    else hipLaunchKernelGGL(search_kernel<false>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_nodes, can_pts, f_out);
+    if (small) hipLaunchKernelGGL(search_kernel<true>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, can_pts, f_out);
+    else hipLaunchKernelGGL(search_kernel<false>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, can_pts, f_out);
 #endif
     if (int rc = nm::check_launch("search_kernel")) return rc;
     const int threads = S <= 64 ? 64 : (S <= 128 ? 128 : 256);
