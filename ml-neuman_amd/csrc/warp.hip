@@ -338,8 +338,8 @@ __global__ __launch_bounds__(64) NM_WARP_ATTR void search_kernel(Tree tr, int se
     // uint16 pending triangles.  LDS per lane decides how many waves share a CU, and the walk is latency-bound.
     float2* nstack = reinterpret_cast<float2*>(lds_raw);
     uint32_t* nstack_s = reinterpret_cast<uint32_t*>(lds_raw);
-    int* tlist = reinterpret_cast<int*>(nstack + (size_t)depth * 64);
-    uint16_t* tlist_s = reinterpret_cast<uint16_t*>(nstack_s + (size_t)depth * 64);
+    int* tlist = reinterpret_cast<int*>(nstack + (size_t)(depth + 1) * 64);                          // + 1: the spare slot
+    uint16_t* tlist_s = reinterpret_cast<uint16_t*>(nstack_s + (size_t)(depth + 1) * 64);
     auto push_tri = [&](int slot, int t) {
         if (SMALL) tlist_s[slot * 64 + threadIdx.x] = (uint16_t)t;
         else tlist[slot * 64 + threadIdx.x] = t;
@@ -420,17 +420,25 @@ __global__ __launch_bounds__(64) NM_WARP_ATTR void search_kernel(Tree tr, int se
                     const uint32_t tb = __float_as_uint(b.thr2) | 3u;
                     const bool lp = cid >= tr.first_lp;                          // children are triangles
                     const int child = lp ? 4 * (cid - tr.first_lp) : 4 * cid + 1;
-                    if (lp) {                                                    // farthest first: the list is popped from its end
-                        if (k0 <= tb) push_tri(ntri++, child + (int)(k0 & 3u));
-                        if (k1 <= tb) push_tri(ntri++, child + (int)(k1 & 3u));
-                        if (k2 <= tb) push_tri(ntri++, child + (int)(k2 & 3u));
-                        if (k3 <= tb) push_tri(ntri++, child + (int)(k3 & 3u));
+                    // The keys are sorted, so the kept children are the last `kept` of the four.  They are stored farthest first
+                    // (the stack and the list are popped from their ends) without branches: child j goes to slot
+                    // top + j - (4 - kept), and a child that is not kept goes to the lane's spare slot instead.
+                    const int kept = (k0 <= tb) + (k1 <= tb) + (k2 <= tb) + (k3 <= tb);
+                    if (lp) {
+                        const int base = ntri - (4 - kept);
+                        push_tri(k0 <= tb ? base : kTriSlots, child + (int)(k0 & 3u));
+                        push_tri(k1 <= tb ? base + 1 : kTriSlots, child + (int)(k1 & 3u));
+                        push_tri(k2 <= tb ? base + 2 : kTriSlots, child + (int)(k2 & 3u));
+                        push_tri(k3 <= tb ? base + 3 : kTriSlots, child + (int)(k3 & 3u));
+                        ntri += kept;
                         has_cur = false;
                     } else {
-                        if (k0 <= tb) push_node(nsp++, __uint_as_float(k0 & ~3u), child + (int)(k0 & 3u));
-                        if (k1 <= tb) push_node(nsp++, __uint_as_float(k1 & ~3u), child + (int)(k1 & 3u));
-                        if (k2 <= tb) push_node(nsp++, __uint_as_float(k2 & ~3u), child + (int)(k2 & 3u));
-                        has_cur = k3 <= tb;                                      // the nearest child is expanded next, from registers
+                        const int base = nsp - (4 - kept);
+                        push_node(k0 <= tb ? base : depth, __uint_as_float(k0 & ~3u), child + (int)(k0 & 3u));
+                        push_node(k1 <= tb ? base + 1 : depth, __uint_as_float(k1 & ~3u), child + (int)(k1 & 3u));
+                        push_node(k2 <= tb ? base + 2 : depth, __uint_as_float(k2 & ~3u), child + (int)(k2 & 3u));
+                        nsp += kept > 0 ? kept - 1 : 0;
+                        has_cur = kept > 0;                                      // the nearest child is expanded next, from registers
                         ck = __uint_as_float(k3 & ~3u); cid = child + (int)(k3 & 3u);
                     }
                 }
@@ -630,7 +638,7 @@ int nm_warp_to_canonical(nm_mesh_t m, const float* pts, int64_t R, int S, const 
     const int64_t N = R * (int64_t)S;
     NM_REQUIRE(N < (1ll << 31) * (int64_t)kChunk, "nm_warp_to_canonical: too many samples for one launch");
     const unsigned waves = (unsigned)((N + kChunk - 1) / kChunk);
-    const size_t lds = (size_t)(3 * (m->tr.L - 1)) * 64 * (small ? 4 : 8) + (size_t)kTriSlots * 64 * (small ? 2 : 4);
+    const size_t lds = (size_t)(3 * (m->tr.L - 1) + 1) * 64 * (small ? 4 : 8) + (size_t)(kTriSlots + 1) * 64 * (small ? 2 : 4);
     hipStream_t st = nm::as_stream(stream);
     int32_t* f_out = reinterpret_cast<int32_t*>(can_dirs);
     const int all = m->search == NM_SEARCH_ALL ? 1 : 0;
