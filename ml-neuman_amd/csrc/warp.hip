@@ -3,35 +3,33 @@
 // libigl's CPU AABB tree behind a device->host->device round trip per ray batch
 // (utils/render_utils.py:218-227).  Here the whole warp stays on the GPU.
 //
-// nm_mesh_create (once per posed mesh, i.e. per frame and actor) builds an exact search tree on the device:
-//   * per triangle a 64 B record {bounding sphere, a, b, c, face id}, sorted along a 30-bit Morton curve of the
-//     centroids (rank sort: F is a body mesh, 13,776 faces for SMPL);
+// nm_mesh_create (once per posed mesh, i.e. per frame and actor) builds an exact search tree on the device (~1 ms for SMPL):
+//   * per triangle a 64 B record {a, ab, ac, Gram products, reciprocals of the closest-point test's denominators}, sorted along
+//     a 30-bit Morton curve of the centroids (rank sort: F is a body mesh, 13,776 faces for SMPL);
 //   * an implicit 4-ary tree over the sorted order: node i of level l covers the sorted triangles
 //     [i 4^(L-l), (i+1) 4^(L-l)), level L are the triangles themselves.  A node record holds the AABBs of its four
 //     children as six float4 (SoA), so one visit = six 16 B loads and four slab distances.
-// warp_kernel (one workgroup per ray, one lane per sample) runs a depth-first, nearest-child-first search per lane with
-// the stack in LDS.  A subtree is skipped when the distance to its box exceeds the best distance found, inflated by a
-// rounding margin (1e-4 relative + ~80 ulp of the coordinates) so that no triangle whose COMPUTED distance could tie
-// or beat the best one is ever skipped: the result is bit-identical to the all-triangles loop (tested), ties going to
-// the lowest face id whatever the visiting order.  The loop is written "while-while": a lane walks the tree until it
-// holds a triangle, then all lanes of the wave that hold one run the exact Voronoi-region closest-point test (f32,
-// like the reference's f32 query) together -- the test is ~100 instructions with seven exits, and running it under
-// the divergent walk is what made the round's first (grid) kernel 15x slower than this one.
-// The winning triangle's barycentrics, the blended 4x4 (f64, the reference's T is f64), its inverse and the canonical
-// point are f64; the ray's canonical points are staged in LDS so the finite-difference directions (:62-64) need no
-// second pass over HBM.
+// nm_warp_to_canonical runs two kernels:
+//   search_kernel -- per sample, a depth-first, nearest-child-first search with the stack in LDS.  A subtree is skipped when the
+//     distance to its box exceeds the best distance found, inflated by a rounding margin (1e-4 relative + ~80 ulp of the
+//     coordinates) so that no triangle whose COMPUTED distance could tie or beat the best one is ever skipped: the result is
+//     bit-identical to the all-triangles loop (tested), ties going to the lowest face id whatever the visiting order.
+//     What makes it fast is how the wave is scheduled, see the kernel: persistent lanes, and two wave-wide phases (expand a
+//     node / test a triangle) of which the one with more ready lanes runs.  The round's first version (a per-cell candidate
+//     grid, the exact test inside the divergent candidate loop) took 39.5 ms + 10.6 ms of build for the 7.3 M samples of a
+//     512 x 512 frame; this one takes 7.8 ms + 1.0 ms, VALU-bound (90 % busy).
+//   tail_kernel -- one workgroup per ray: the winning triangle's barycentrics, the blended 4x4 (f64, the reference's T is f64),
+//     its inverse and the canonical point in f64; the ray's canonical points are staged in LDS so the finite-difference
+//     directions (:62-64) need no second pass over HBM.
 #include <float.h>
 #include <math.h>
-#include <stdio.h>
 #include <string.h>
-
-#include <vector>
 
 #include "common.h"
 
 namespace {
 
-// five waves per SIMD (<= 96 VGPRs, no spills): the tree walk is latency-bound
+// at least five waves per SIMD for the search (it needs 38 VGPRs; the bound matters when the kernel grows)
 #ifndef NM_WARP_ATTR
 #define NM_WARP_ATTR __attribute__((amdgpu_waves_per_eu(5)))
 #endif
@@ -61,7 +59,7 @@ struct Tree {
 __host__ __device__ inline int level_base(int l) { return (int)(((1ll << (2 * l)) - 1) / 3); }
 
 #ifndef NM_WARP_PENDING
-#define NM_WARP_PENDING 6
+#define NM_WARP_PENDING 8
 #endif
 constexpr int kPending = NM_WARP_PENDING;              // a lane keeps walking until it holds this many untested triangles
 constexpr int kTriSlots = kPending + 3;  // one more expansion can add four
@@ -320,16 +318,16 @@ __device__ __forceinline__ void cswap(uint32_t& a, uint32_t& b) {               
 // minimum, ties going to the lowest face id).
 // Output: q -> q_out[i*3 ..], face -> f_out[i*3] (the caller passes can_pts / can_dirs: tail_kernel consumes and overwrites them).
 constexpr int kChunk = 512;
-constexpr int kRefill = 8;               // idle lanes that trigger a refill (or any, when no lane has work)
+#ifndef NM_WARP_REFILL
+#define NM_WARP_REFILL 8
+#endif
+constexpr int kRefill = NM_WARP_REFILL;               // idle lanes that trigger a refill (or any, when no lane has work)
 
 template <bool SMALL>
 __global__ __launch_bounds__(64) NM_WARP_ATTR void search_kernel(Tree tr, int search_all_mode, const float* __restrict__ pts, int64_t N,
                                                                  const TriRec* __restrict__ rec, const int32_t* __restrict__ face_of,
                                                                  const Node* __restrict__ nodes, float* __restrict__ q_out,
                                                                  int32_t* __restrict__ f_out
-#ifdef NM_WARP_DBG
-                                                                 , float* __restrict__ dbg
-#endif
                                                                  ) {
     extern __shared__ double lds_raw[];
     const int depth = 3 * (tr.L - 1);
@@ -369,9 +367,6 @@ __global__ __launch_bounds__(64) NM_WARP_ATTR void search_kernel(Tree tr, int se
     bool has_cur = false;
     float ck = 0.f;
     int cid = 0, nsp = 0, ntri = 0;
-#ifdef NM_WARP_DBG
-    float n_iter_w = 0.f, n_iter_t = 0.f;
-#endif
     for (;;) {
         bool can_walk = active && (has_cur || nsp > 0) && ntri < kPending;
         unsigned long long bw = __ballot(can_walk), bt = __ballot(active && ntri > 0);
@@ -393,9 +388,6 @@ __global__ __launch_bounds__(64) NM_WARP_ATTR void search_kernel(Tree tr, int se
             bw = __ballot(can_walk); bt = __ballot(active && ntri > 0);
         }
         if (__popcll(bt) < __popcll(bw)) {                                       // ---- WALK: expand one node per lane
-#ifdef NM_WARP_DBG
-            n_iter_w += 1.f;
-#endif
             if (can_walk) {
                 while (!has_cur && nsp > 0) {                                    // next entry the bound has not overtaken
                     float ek; int eid;
@@ -444,9 +436,6 @@ __global__ __launch_bounds__(64) NM_WARP_ATTR void search_kernel(Tree tr, int se
                 }
             }
         } else if (bt) {                                                         // ---- TEST: one pending triangle per lane
-#ifdef NM_WARP_DBG
-            n_iter_t += 1.f;
-#endif
             if (active && ntri > 0) exact_tri(rec, face_of, pop_tri(--ntri), p, slack, b);
         }
         if (active && !has_cur && nsp == 0 && ntri == 0) {                       // ---- this lane's sample is done
@@ -462,9 +451,6 @@ __global__ __launch_bounds__(64) NM_WARP_ATTR void search_kernel(Tree tr, int se
         }
         if (next >= end && !__any(active)) break;
     }
-#ifdef NM_WARP_DBG
-    if (dbg && threadIdx.x == 0) { dbg[blockIdx.x * 2] = n_iter_w; dbg[blockIdx.x * 2 + 1] = n_iter_t; }
-#endif
 }
 
 // ---- tail_kernel: one workgroup per ray, one lane per sample ---------------------------------------------------------------------
@@ -511,9 +497,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ pts
         if (live) {
             can_lds[s * 3] = cxp; can_lds[s * 3 + 1] = cyp; can_lds[s * 3 + 2] = czp;
             can_pts[i * 3] = (float)cxp; can_pts[i * 3 + 1] = (float)cyp; can_pts[i * 3 + 2] = (float)czp;
-#ifndef NM_WARP_DBG
             if (closest) { closest[i * 3] = q.x; closest[i * 3 + 1] = q.y; closest[i * 3 + 2] = q.z; }
-#endif
         }
     }
     __syncthreads();
@@ -642,23 +626,8 @@ int nm_warp_to_canonical(nm_mesh_t m, const float* pts, int64_t R, int S, const 
     hipStream_t st = nm::as_stream(stream);
     int32_t* f_out = reinterpret_cast<int32_t*>(can_dirs);
     const int all = m->search == NM_SEARCH_ALL ? 1 : 0;
-#ifdef NM_WARP_DBG
-    float* dbg = nullptr;
-    (void)hipMalloc(&dbg, (size_t)waves * 8);
-    if (small) hipLaunchKernelGGL(search_kernel<true>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, can_pts, f_out, dbg);
-    else hipLaunchKernelGGL(search_kernel<false>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, can_pts, f_out, dbg);
-    {
-        std::vector<float> h((size_t)waves * 2);
-        (void)hipMemcpy(h.data(), dbg, h.size() * 4, hipMemcpyDeviceToHost);
-        double w = 0, t = 0;
-        for (unsigned k = 0; k < waves; ++k) { w += h[2 * k]; t += h[2 * k + 1]; }
-        fprintf(stderr, "[warp dbg] waves %u, walk iterations / wave %.1f, test iterations / wave %.1f\n", waves, w / waves, t / waves);
-        (void)hipFree(dbg);
-    }
-#else
     if (small) hipLaunchKernelGGL(search_kernel<true>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, can_pts, f_out);
     else hipLaunchKernelGGL(search_kernel<false>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, can_pts, f_out);
-#endif
     if (int rc = nm::check_launch("search_kernel")) return rc;
     const int threads = S <= 64 ? 64 : (S <= 128 ? 128 : 256);
     hipLaunchKernelGGL(tail_kernel, dim3((unsigned)R), dim3(threads), (size_t)S * 24, st, pts, S, m->d_verts, m->d_faces, T, can_pts, can_dirs, closest);
