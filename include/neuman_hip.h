@@ -196,6 +196,34 @@ int nm_warp_to_canonical(nm_mesh_t mesh, const float* pts, int64_t R, int S, con
                          float* can_dirs, float* closest, nm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * a12  SMPL linear blend skinning, batched over frames -- reference models/smpl.py:266-360 (lbs),
+ *   :407-438 (batch_rodrigues), :454-505 (batch_rigid_transform), :109-216 (SMPL.verts_transformations /
+ *   forward); callers data_io/neuman_helper.py:288-330 (read_smpls) and models/human_nerf.py:92-122
+ *   (HumanNeRF.vertex_forward).
+ *
+ *   nm_smpl_create copies the model to the device.  HOST pointers, float32 as the reference registers them
+ *   (smpl.py:74-107): v_template [V,3], shapedirs [V,3,NB], j_regressor [J,V], parents [J] (parents[0]
+ *   ignored, parents[j] < j), lbs_weights [V,J], da_pose [J*3] (the canonical pose: neuman_helper.py:294-299).
+ *   J <= 64, NB <= 32.
+ *   nm_smpl_frames, per frame b of B (DEVICE pointers): poses [B,J*3] f32, betas [B,NB] f32,
+ *   alignments [B,4,4] f64 = the matrix whose TRANSPOSE the reference applies (read_smpls' temp_alignment,
+ *   vertex_forward's alignments[idx]).  Rows 0..V-1 are vertices, rows V..V+J-1 the joints
+ *   (concat_joints=True):
+ *     T_out      [B,V+J,4,4] f64  T_da2scene = S(scale) align^T T_t2pose inv(T_t2da)
+ *     world_out  [B,V+J,3]   f32  T_da2scene [da-pose point; 1]   (world_verts | joints_3d)
+ *     static_out [B,V+J,3]   f32  the da-pose points              (static_vert | static_joints_3d)
+ *   precise = 1: read_smpls' arithmetic (float32 up to T_da2pose, float64 after); precise = 0:
+ *   vertex_forward's (float32 throughout; T_out then holds float32 values).
+ *   The first call with a larger B than any before allocates workspace (synchronises).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct nm_smpl_s* nm_smpl_t;
+int nm_smpl_create(const float* v_template, const float* shapedirs, const float* j_regressor, const int32_t* parents,
+                   const float* lbs_weights, const float* da_pose, int V, int J, int NB, nm_smpl_t* out);
+int nm_smpl_destroy(nm_smpl_t smpl);
+int nm_smpl_frames(nm_smpl_t smpl, const float* poses, const float* betas, const double* alignments, int B, double scale,
+                   int precise, double* T_out, float* world_out, float* static_out, nm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a13  sorted merge of sample lists -- reference utils/render_utils.py:330-337, 441-448
  *   Two lists per ray, each already sorted in z: (za [R,Sa], rawa [R,Sa,4]) and (zb, rawb).
  *   Writes z_out [R,Sa+Sb] sorted and raw_out [R,Sa+Sb,4] gathered in the same order

@@ -1,0 +1,321 @@
+// a12 SMPL linear blend skinning for gfx950: per-frame posed vertices and per-vertex canonical ("da" pose) -> scene transforms,
+// batched over frames.  Replaces, on the device,
+//   * reference models/smpl.py:266-360 (lbs), :407-438 (batch_rodrigues), :454-505 (batch_rigid_transform), float32;
+//   * data_io/neuman_helper.py:288-330 (read_smpls: the numpy chain of the render scripts -- a float32 4x4 inverse and product,
+//     then float64 from the alignment on) when `precise`, models/human_nerf.py:92-122 (vertex_forward: float32 throughout) else.
+// It is ~3 MFLOP per frame: the point is not speed but that a whole sequence's meshes and transforms are produced where the
+// renderers consume them ("device LBS batched over frames"), with no host round trip per frame.
+//   smpl_joints_kernel  one workgroup per frame: shape blend + joint regression (the 6890-long reductions), Rodrigues for the
+//                       frame's pose and for the da pose, the two kinematic chains (sequential over the 24 joints).
+//   smpl_rows_kernel    one lane per (frame, vertex or joint row): skinning blend of the 24 joint transforms for both poses,
+//                       da-pose vertex, T_da2pose = T_t2pose inv(T_t2da), alignment and scale, world vertex.
+// Sums run in index order in float32 where the reference uses a float32 BLAS call (unspecified order): agreement with the
+// reference is to float32 rounding (~1e-6), tested at 2e-5 of the values' magnitude.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxJoints = 64;
+constexpr int kMaxBetas = 32;
+
+struct SmplDims { int V, J, NB; };
+
+__device__ __forceinline__ void rodrigues(const float* __restrict__ rv, float* __restrict__ R) {   // smpl.py:407-438
+    const float x = rv[0] + 1e-8f, y = rv[1] + 1e-8f, z = rv[2] + 1e-8f;
+    const float angle = sqrtf(x * x + y * y + z * z);
+    const float rx = rv[0] / angle, ry = rv[1] / angle, rz = rv[2] / angle;
+    const float c = cosf(angle), s = sinf(angle), omc = 1.f - c;
+    const float K[9] = {0.f, -rz, ry, rz, 0.f, -rx, -ry, rx, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float kk = K[i * 3] * K[j] + K[i * 3 + 1] * K[3 + j] + K[i * 3 + 2] * K[6 + j];
+            R[i * 3 + j] = (i == j ? 1.f : 0.f) + s * K[i * 3 + j] + omc * kk;
+        }
+}
+
+__device__ __forceinline__ void mat4_mul(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[i * 4 + j] = a[i * 4] * b[j] + a[i * 4 + 1] * b[4 + j] + a[i * 4 + 2] * b[8 + j] + a[i * 4 + 3] * b[12 + j];
+}
+
+// workspace per frame: J [Jn,3] rest joints | Jda [Jn,3] posed joints of the da pose | A_pose [Jn,16] | A_da [Jn,16]
+__device__ __host__ inline int ws_floats(int J) { return J * (3 + 3 + 16 + 16); }
+
+__global__ __launch_bounds__(256) void smpl_joints_kernel(SmplDims d, const float* __restrict__ v_template, const float* __restrict__ shapedirs,
+                                                          const float* __restrict__ j_reg, const int32_t* __restrict__ parents,
+                                                          const float* __restrict__ poses, const float* __restrict__ betas,
+                                                          const float* __restrict__ da_pose, float* __restrict__ ws) {
+    __shared__ float beta[kMaxBetas];
+    __shared__ float red[4][3];
+    __shared__ float Js[kMaxJoints][3];
+    __shared__ float Rm[2][kMaxJoints][9];
+    __shared__ float chain[2][kMaxJoints][16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float* w = ws + (size_t)b * ws_floats(d.J);
+    if (tid < d.NB) beta[tid] = betas[(size_t)b * d.NB + tid];
+    __syncthreads();
+    // rest joints J = J_regressor v_shaped (smpl.py:312-316): one strided pass over the vertices per joint
+    for (int j = 0; j < d.J; ++j) {
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int v = tid; v < d.V; v += blockDim.x) {
+            const float r = j_reg[(size_t)j * d.V + v];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float vs = 0.f;
+                for (int l = 0; l < d.NB; ++l) vs += beta[l] * shapedirs[((size_t)v * 3 + k) * d.NB + l];
+                vs = v_template[v * 3 + k] + vs;
+                acc[k] += r * vs;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[k] = wave_sum(acc[k]);
+        if ((tid & 63) == 0)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) red[tid >> 6][k] = acc[k];
+        __syncthreads();
+        if (tid < 3) {
+            float s = 0.f;
+            for (int q = 0; q < (int)(blockDim.x >> 6); ++q) s += red[q][tid];
+            Js[j][tid] = s;
+        }
+        __syncthreads();
+    }
+    // Rodrigues: the frame's pose (set 0) and the da pose (set 1)
+    if (tid < 2 * d.J) {
+        const int set = tid / d.J, j = tid % d.J;
+        rodrigues(set == 0 ? poses + (size_t)b * d.J * 3 + j * 3 : da_pose + j * 3, Rm[set][j]);
+    }
+    __syncthreads();
+    // kinematic chains (smpl.py:474-493): sequential over the joints, one lane per pose
+    if (tid < 2) {
+        const int set = tid;
+        for (int j = 0; j < d.J; ++j) {
+            const int p = j == 0 ? -1 : parents[j];
+            float m[16];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) m[i * 4 + k] = Rm[set][j][i * 3 + k];
+                m[i * 4 + 3] = p < 0 ? Js[j][i] : Js[j][i] - Js[p][i];
+            }
+            m[12] = m[13] = m[14] = 0.f; m[15] = 1.f;
+            if (p < 0) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) chain[set][j][q] = m[q];
+            } else {
+                mat4_mul(chain[set][p], m, chain[set][j]);
+            }
+        }
+    }
+    __syncthreads();
+    // rel_transforms = transforms - pad(transforms [J;0]) (smpl.py:499-503): only the last column changes
+    if (tid < 2 * d.J) {
+        const int set = tid / d.J, j = tid % d.J;
+        const float* t = chain[set][j];
+        float* A = w + d.J * 6 + ((size_t)set * d.J + j) * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float tj = t[i * 4] * Js[j][0] + t[i * 4 + 1] * Js[j][1] + t[i * 4 + 2] * Js[j][2] + t[i * 4 + 3] * 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) A[i * 4 + k] = t[i * 4 + k];
+            A[i * 4 + 3] = t[i * 4 + 3] - tj;
+        }
+        if (set == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w[j * 3 + k] = Js[j][k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w[d.J * 3 + j * 3 + k] = t[k * 4 + 3];                      // posed joints of the da pose
+        }
+    }
+}
+
+// general 4x4 inverse by cofactors in f64 (the blended matrices are affine only up to the rounding of sum(w) = 1)
+__device__ __forceinline__ void inv4x4_full(const double* m, double* o) {
+    const double s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2], s2 = m[0] * m[7] - m[4] * m[3];
+    const double s3 = m[1] * m[6] - m[5] * m[2], s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
+    const double c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11], c3 = m[9] * m[14] - m[13] * m[10];
+    const double c2 = m[8] * m[15] - m[12] * m[11], c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
+    const double inv = 1.0 / (s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0);
+    o[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * inv;
+    o[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * inv;
+    o[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * inv;
+    o[3] = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * inv;
+    o[4] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * inv;
+    o[5] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * inv;
+    o[6] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * inv;
+    o[7] = (m[8] * s5 - m[10] * s2 + m[11] * s1) * inv;
+    o[8] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * inv;
+    o[9] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * inv;
+    o[10] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * inv;
+    o[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * inv;
+    o[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * inv;
+    o[13] = (m[0] * c3 - m[1] * c1 + m[2] * c0) * inv;
+    o[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * inv;
+    o[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * inv;
+}
+
+__global__ __launch_bounds__(256) void smpl_rows_kernel(SmplDims d, int B, const float* __restrict__ v_template, const float* __restrict__ shapedirs,
+                                                        const float* __restrict__ lbs_weights, const float* __restrict__ betas,
+                                                        const double* __restrict__ alignments, double scale, int precise,
+                                                        const float* __restrict__ ws, double* __restrict__ T_out, float* __restrict__ world,
+                                                        float* __restrict__ stat) {
+    const int rows = d.V + d.J;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (int64_t)B * rows) return;
+    const int b = (int)(gid / rows), r = (int)(gid % rows);
+    const float* w = ws + (size_t)b * ws_floats(d.J);
+    const float* A_pose = w + d.J * 6;
+    const float* A_da = A_pose + d.J * 16;
+    float Tp[16], Td[16], pt[3], dap[3];
+    if (r < d.V) {
+        // T = W A (smpl.py:343-344), both poses; v_shaped (:309); the da-pose vertex T_da [v_shaped; 1] (:355-358)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Tp[q] = Td[q] = 0.f;
+        for (int j = 0; j < d.J; ++j) {
+            const float wj = lbs_weights[(size_t)r * d.J + j];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { Tp[q] += wj * A_pose[j * 16 + q]; Td[q] += wj * A_da[j * 16 + q]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float vs = 0.f;
+            for (int l = 0; l < d.NB; ++l) vs += betas[(size_t)b * d.NB + l] * shapedirs[((size_t)r * 3 + k) * d.NB + l];
+            pt[k] = v_template[r * 3 + k] + vs;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dap[k] = Td[k * 4] * pt[0] + Td[k * 4 + 1] * pt[1] + Td[k * 4 + 2] * pt[2] + Td[k * 4 + 3] * 1.f;
+    } else {
+        const int j = r - d.V;                                       // joint rows (concat_joints=True, smpl.py:347-349)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { Tp[q] = A_pose[j * 16 + q]; Td[q] = A_da[j * 16 + q]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dap[k] = w[d.J * 3 + j * 3 + k];
+    }
+    // T_da2pose = T_t2pose inv(T_t2da): a float32 inverse and product in the reference (neuman_helper.py:314, human_nerf.py:109)
+    double Tdd[16], inv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Tdd[q] = (double)Td[q];
+    inv4x4_full(Tdd, inv);
+    float invf[16], Tdp[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) invf[q] = (float)inv[q];
+    mat4_mul(Tp, invf, Tdp);
+    const double* al = alignments + (size_t)b * 16;
+    double T[16];
+    if (precise) {
+        // float64 from here: T = S (align^T T_da2pose) (neuman_helper.py:315-318)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double t = al[0 * 4 + i] * (double)Tdp[j] + al[1 * 4 + i] * (double)Tdp[4 + j] + al[2 * 4 + i] * (double)Tdp[8 + j] +
+                                 al[3 * 4 + i] * (double)Tdp[12 + j];
+                T[i * 4 + j] = i < 3 ? scale * t : t;
+            }
+    } else {
+        // float32 throughout (human_nerf.py:110-113)
+        const float sc = (float)scale;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = (float)al[0 * 4 + i] * Tdp[j] + (float)al[1 * 4 + i] * Tdp[4 + j] + (float)al[2 * 4 + i] * Tdp[8 + j] +
+                                (float)al[3 * 4 + i] * Tdp[12 + j];
+                T[i * 4 + j] = (double)(i < 3 ? sc * t : t);
+            }
+    }
+    double* To = T_out + ((size_t)b * rows + r) * 16;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) To[q] = T[q];
+    float* wo = world + ((size_t)b * rows + r) * 3;
+    float* so = stat + ((size_t)b * rows + r) * 3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (precise)
+            wo[k] = (float)(T[k * 4] * (double)dap[0] + T[k * 4 + 1] * (double)dap[1] + T[k * 4 + 2] * (double)dap[2] + T[k * 4 + 3]);
+        else
+            wo[k] = (float)T[k * 4] * dap[0] + (float)T[k * 4 + 1] * dap[1] + (float)T[k * 4 + 2] * dap[2] + (float)T[k * 4 + 3] * 1.f;
+        so[k] = dap[k];
+    }
+}
+
+}  // namespace
+
+struct nm_smpl_s {
+    SmplDims d;
+    float *v_template, *shapedirs, *j_reg, *weights, *da_pose, *ws;
+    int32_t* parents;
+    int ws_frames;
+};
+
+extern "C" {
+
+int nm_smpl_destroy(nm_smpl_t m) {
+    if (!m) return NM_OK;
+    void* p[] = {m->v_template, m->shapedirs, m->j_reg, m->weights, m->da_pose, m->ws, m->parents};
+    for (void* q : p)
+        if (q) (void)hipFree(q);
+    delete m;
+    return NM_OK;
+}
+
+int nm_smpl_create(const float* v_template, const float* shapedirs, const float* j_regressor, const int32_t* parents, const float* lbs_weights,
+                   const float* da_pose, int V, int J, int NB, nm_smpl_t* out) {
+    NM_REQUIRE(v_template && shapedirs && j_regressor && parents && lbs_weights && da_pose && out, "nm_smpl_create: null pointer");
+    NM_REQUIRE(V >= 1 && J >= 1 && J <= kMaxJoints && NB >= 0 && NB <= kMaxBetas, "nm_smpl_create: bad sizes V=%d J=%d NB=%d (J <= %d, NB <= %d)", V,
+               J, NB, kMaxJoints, kMaxBetas);
+    for (int j = 1; j < J; ++j)
+        NM_REQUIRE(parents[j] >= 0 && parents[j] < j, "nm_smpl_create: parents[%d] = %d is not an earlier joint", j, parents[j]);
+    nm_smpl_s* m = new nm_smpl_s();
+    memset(m, 0, sizeof(*m));
+    m->d = {V, J, NB};
+    int rc = NM_OK;
+    auto up = [&](auto** dst, const void* src, size_t bytes, const char* what) {
+        if (rc) return;
+        rc = nm::check_hip(hipMalloc(reinterpret_cast<void**>(dst), bytes ? bytes : 4), what);
+        if (!rc && bytes) rc = nm::check_hip(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice), what);
+    };
+    up(&m->v_template, v_template, (size_t)V * 3 * 4, "nm_smpl_create: v_template");
+    up(&m->shapedirs, shapedirs, (size_t)V * 3 * NB * 4, "nm_smpl_create: shapedirs");
+    up(&m->j_reg, j_regressor, (size_t)J * V * 4, "nm_smpl_create: J_regressor");
+    up(&m->weights, lbs_weights, (size_t)V * J * 4, "nm_smpl_create: lbs_weights");
+    up(&m->da_pose, da_pose, (size_t)J * 3 * 4, "nm_smpl_create: da pose");
+    up(&m->parents, parents, (size_t)J * 4, "nm_smpl_create: parents");
+    if (rc) { nm_smpl_destroy(m); return rc; }
+    *out = m;
+    return NM_OK;
+}
+
+int nm_smpl_frames(nm_smpl_t m, const float* poses, const float* betas, const double* alignments, int B, double scale, int precise,
+                   double* T_out, float* world_out, float* static_out, nm_stream_t stream) {
+    NM_REQUIRE(m, "nm_smpl_frames: null handle");
+    NM_REQUIRE(B >= 0, "nm_smpl_frames: negative batch");
+    if (B == 0) return NM_OK;
+    NM_REQUIRE(poses && betas && alignments && T_out && world_out && static_out, "nm_smpl_frames: null pointer");
+    hipStream_t st = nm::as_stream(stream);
+    if (B > m->ws_frames) {                                           // grows with the largest batch seen; frees synchronise
+        if (m->ws) (void)hipFree(m->ws);
+        m->ws = nullptr; m->ws_frames = 0;
+        if (int rc = nm::check_hip(hipMalloc(&m->ws, (size_t)B * ws_floats(m->d.J) * 4), "nm_smpl_frames: workspace")) return rc;
+        m->ws_frames = B;
+    }
+    hipLaunchKernelGGL(smpl_joints_kernel, dim3(B), dim3(256), 0, st, m->d, m->v_template, m->shapedirs, m->j_reg, m->parents, poses, betas,
+                       m->da_pose, m->ws);
+    if (int rc = nm::check_launch("smpl_joints_kernel")) return rc;
+    const int64_t n = (int64_t)B * (m->d.V + m->d.J);
+    hipLaunchKernelGGL(smpl_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m->d, B, m->v_template, m->shapedirs, m->weights, betas,
+                       alignments, scale, precise, m->ws, T_out, world_out, static_out);
+    return nm::check_launch("smpl_rows_kernel");
+}
+
+}  // extern "C"

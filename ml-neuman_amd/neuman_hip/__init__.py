@@ -6,13 +6,14 @@
                                 # render_reposing.py, render_gathering.py) run on libneuman_hip.so unchanged.
 
 Sub-modules mirror the reference's: ``ray_utils`` (utils/ray_utils.py), ``render_utils`` (utils/render_utils.py:69-461),
-``vanilla`` (models/vanilla.py); ``parallel`` adds the ray-tile sharding for 1/2/4/8 GPUs; ``synthetic`` the
+``vanilla`` (models/vanilla.py), ``smpl`` (models/smpl.py skinning + data_io/neuman_helper.py:read_smpls, batched on the
+device); ``parallel`` adds the ray-tile sharding for 1/2/4/8 GPUs; ``synthetic`` the
 asset-free workloads.  Nothing in this package evaluates the hot path on the CPU.
 """
-from . import _lib, parallel, ray_utils, render_utils, synthetic, vanilla  # noqa: F401
+from . import _lib, parallel, ray_utils, render_utils, smpl, synthetic, vanilla  # noqa: F401
 from ._lib import NeumanHipError  # noqa: F401
 
-__all__ = ["ray_utils", "render_utils", "vanilla", "parallel", "synthetic", "install", "NeumanHipError"]
+__all__ = ["ray_utils", "render_utils", "vanilla", "smpl", "parallel", "synthetic", "install", "NeumanHipError"]
 
 _RAY_FNS = ["shot_ray", "shot_rays", "shot_all_rays", "to_homogeneous", "ray_to_samples", "ray_to_importance_samples",
             "sample_pdf", "geometry_guided_near_far", "geometry_guided_near_far_torch", "geometry_guided_near_far_np",

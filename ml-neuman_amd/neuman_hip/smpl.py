@@ -1,0 +1,133 @@
+"""a12 SMPL linear blend skinning on the device -- host-side mirror of the reference interface.
+
+    SMPL                      models/smpl.py:54-216      (constructor reads the same SMPL_{GENDER}.pkl; verts_transformations, __call__)
+    read_smpls                data_io/neuman_helper.py:258-331 (same files: smpl_output_{type}.pkl via joblib, alignments.npy)
+    vertex_forward            models/human_nerf.py:92-122
+
+All arithmetic runs in libneuman_hip (csrc/smpl.hip, `nm_smpl_frames`), batched over frames; there is no CPU path.
+"""
+import ctypes
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def da_pose(n_joints=24):
+    """The canonical "da" pose, legs apart (neuman_helper.py:294-299, human_nerf.py:24-29)."""
+    da = np.zeros((n_joints, 3), np.float32)
+    da[1] = (0, 0, 1.0)
+    da[2] = (0, 0, -1.0)
+    return da.reshape(-1)
+
+
+def _dense_f32(x):
+    if 'scipy.sparse' in str(type(x)):
+        x = x.todense()
+    return np.ascontiguousarray(np.asarray(x), dtype=np.float32)
+
+
+class SMPL:
+    """`SMPL(model_path, gender, device)` as the reference; `model_path` may also be the unpickled dict."""
+
+    def __init__(self, model_path, gender='neutral', device='cuda'):
+        _lib.require_gpu()
+        if isinstance(model_path, dict):
+            data = model_path
+        else:
+            path = os.path.join(model_path, f'SMPL_{gender.upper()}.pkl') if os.path.isdir(model_path) else model_path
+            if not os.path.exists(path):
+                raise FileNotFoundError(f'Path {path} does not exist!')
+            with open(path, 'rb') as f:
+                data = pickle.load(f, encoding='latin1')
+        self.device = torch.device(device)
+        self.faces = np.asarray(data['f'])
+        vt, sd = _dense_f32(data['v_template']), _dense_f32(data['shapedirs'])
+        jr, w = _dense_f32(data['J_regressor']), _dense_f32(data['weights'])
+        parents = np.asarray(data['kintree_table'])[0].astype(np.float32).astype(np.int64)      # to_np(float32).long(), smpl.py:100
+        parents[0] = -1
+        self.parents = parents
+        self.V, self.J, self.NB = vt.shape[0], jr.shape[0], sd.shape[-1]
+        self.da_smpl = da_pose(self.J)
+        self.handle = ctypes.c_void_p()
+        p32 = np.ascontiguousarray(parents.astype(np.int32))
+        _lib.check(_lib.lib().nm_smpl_create(vt.ctypes.data_as(ctypes.c_void_p), sd.ctypes.data_as(ctypes.c_void_p),
+                                             jr.ctypes.data_as(ctypes.c_void_p), p32.ctypes.data_as(ctypes.c_void_p),
+                                             w.ctypes.data_as(ctypes.c_void_p), self.da_smpl.ctypes.data_as(ctypes.c_void_p),
+                                             self.V, self.J, self.NB, ctypes.byref(self.handle)), "nm_smpl_create")
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.lib().nm_smpl_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def frames(self, poses, betas, alignments, scale=1.0, precise=True):
+        """poses [B,J*3], betas [B,NB], alignments [B,4,4] (the matrix whose transpose is applied) ->
+        T [B,V+J,4,4] f64, world [B,V+J,3] f32, static [B,V+J,3] f32, CUDA tensors (rows V.. are the joints)."""
+        dev = self.device
+        po = torch.as_tensor(np.asarray(poses, np.float32) if not isinstance(poses, torch.Tensor) else poses).to(dev, torch.float32).reshape(-1, self.J * 3).contiguous()
+        be = torch.as_tensor(np.asarray(betas, np.float32) if not isinstance(betas, torch.Tensor) else betas).to(dev, torch.float32).reshape(-1, self.NB).contiguous()
+        al = torch.as_tensor(np.asarray(alignments, np.float64) if not isinstance(alignments, torch.Tensor) else alignments).to(dev, torch.float64).reshape(-1, 16).contiguous()
+        B = po.shape[0]
+        if be.shape[0] != B or al.shape[0] != B:
+            raise _lib.NeumanHipError(f"frames: {B} poses, {be.shape[0]} betas, {al.shape[0]} alignments")
+        rows = self.V + self.J
+        T = torch.empty((B, rows, 4, 4), device=dev, dtype=torch.float64)
+        world = torch.empty((B, rows, 3), device=dev, dtype=torch.float32)
+        static = torch.empty((B, rows, 3), device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib().nm_smpl_frames(self.handle, _lib.dev_ptr(po), _lib.dev_ptr(be), _lib.dev_ptr(al, torch.float64), B, float(scale),
+                                             1 if precise else 0, _lib.dev_ptr(T, torch.float64), _lib.dev_ptr(world), _lib.dev_ptr(static),
+                                             _lib.stream_ptr()), "nm_smpl_frames")
+        return T, world, static
+
+
+def read_smpls(scene_dir, caps, scale=1, smpl_type='romp', body_model=None, model_dir=None, device='cuda'):
+    """NeuManReader.read_smpls (neuman_helper.py:258-331): same inputs on disk, same four returns -- smpls (list of per-frame
+    dicts with joints_3d / static_joints_3d added), world_verts, static_verts (lists of [6890,3] f32) and Ts (list of
+    [6914,4,4] f64) -- as numpy, all frames skinned in one batch on the device."""
+    import joblib
+    if body_model is None:
+        body_model = SMPL(model_dir if model_dir is not None else
+                          os.path.join(os.path.abspath(os.path.join(os.path.dirname(__file__), '..')), 'data/smplx/smpl'), 'neutral', device)
+    smpl_path = os.path.join(scene_dir, f'smpl_output_{smpl_type}.pkl')
+    assert os.path.isfile(smpl_path), f'{smpl_path} is missing'
+    raw_smpl = joblib.load(smpl_path)
+    assert len(raw_smpl) == 1
+    raw_smpl = raw_smpl[list(raw_smpl.keys())[0]]
+    raw_alignments = np.load(os.path.join(scene_dir, 'alignments.npy'), allow_pickle=True).item()
+    smpls, aligns = [], []
+    for cap in caps:
+        frame_id = int(os.path.basename(cap.image_path)[:-4])
+        out = {}
+        for k, v in raw_smpl.items():
+            try:
+                out[k] = v[frame_id]
+            except Exception:
+                out[k] = None
+        smpls.append(out)
+        a = np.eye(4)
+        a[:, :3] = raw_alignments[os.path.basename(cap.image_path)]
+        aligns.append(a)
+    if not smpls:
+        return [], [], [], []
+    T, world, static = body_model.frames(np.stack([s['pose'] for s in smpls]), np.stack([s['betas'] for s in smpls]), np.stack(aligns), scale, True)
+    T, world, static = T.cpu().numpy(), world.cpu().numpy(), static.cpu().numpy()
+    V = body_model.V
+    for i, s in enumerate(smpls):
+        s['joints_3d'] = world[i, V:]
+        s['static_joints_3d'] = static[i, V:]
+    return smpls, [world[i, :V] for i in range(len(smpls))], [static[i, :V] for i in range(len(smpls))], [T[i] for i in range(len(smpls))]
+
+
+def vertex_forward(body_model, pose, beta, alignment, scale):
+    """HumanNeRF.vertex_forward (human_nerf.py:92-122): pose [1,72], beta [1,10], alignment [4,4] -> world_verts [1,V,3] f32,
+    T_da2scene [1,V,4,4] f32 (CUDA tensors)."""
+    T, world, _ = body_model.frames(pose, beta, torch.as_tensor(alignment).reshape(1, 4, 4), scale, False)
+    V = body_model.V
+    return world[:, :V], T[:, :V].to(torch.float32)

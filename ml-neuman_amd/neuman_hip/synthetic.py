@@ -122,3 +122,55 @@ def twist_transforms(can_verts, twist=0.8, shift=(0.05, -0.02, 0.03)):
     T[:, :3, 3] = np.asarray(shift)
     posed = np.einsum('vij,vj->vi', T[:, :3, :3], v) + T[:, :3, 3]
     return posed.astype(np.float32), T
+
+
+SMPL_PARENTS = (-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21)   # SMPL's kinematic tree
+
+
+def smpl_like_model(seed=0, n_betas=10):
+    """A body model with SMPL's shapes and file layout (models/smpl.py:74-107 reads these keys) but synthetic content: the
+    SMPL assets are licensed and absent.  V = 6890 capsule vertices, 24 joints on SMPL's kinematic tree, dense joint
+    regressor and skinning weights (rows sum to one), small random shape directions; pose blend shapes are zero (the
+    reference computes and then ignores them, smpl.py:320-330)."""
+    rng = np.random.default_rng(seed)
+    verts, faces = capsule_mesh()
+    V, J = verts.shape[0], len(SMPL_PARENTS)
+    t = np.linspace(0.0, 1.0, J)
+    anchors = np.stack([0.18 * np.sin(2 * np.pi * t * 4.6), -0.55 + 1.1 * t, 0.1 * np.cos(2 * np.pi * t * 3.2)], 1)
+    d2 = ((verts[:, None, :].astype(np.float64) - anchors[None]) ** 2).sum(-1)                     # [V,J]
+    w = np.exp(-d2 / 0.02)
+    w /= w.sum(1, keepdims=True)
+    jr = np.exp(-d2.T / 0.005)                                                                     # [J,V]
+    jr /= jr.sum(1, keepdims=True)
+    kintree = np.stack([np.asarray(SMPL_PARENTS, np.int64), np.arange(J)], 0).astype(np.int64)
+    kintree[0, 0] = 2 ** 32 - 1                                                                    # as in the SMPL files
+    return {
+        'f': faces[:, :3].astype(np.uint32),
+        'v_template': verts.astype(np.float64),
+        'shapedirs': (rng.normal(size=(V, 3, n_betas)) * 0.004).astype(np.float64),
+        'J_regressor': jr.astype(np.float64),
+        'posedirs': np.zeros((V, 3, (J - 1) * 9), np.float64),
+        'kintree_table': kintree,
+        'weights': w.astype(np.float64),
+    }
+
+
+def smpl_like_frames(n_frames=3, seed=0, n_betas=10):
+    """Per-frame SMPL parameters and scene alignments as `smpl_output_*.pkl` / `alignments.npy` hold them
+    (neuman_helper.py:281-293): pose [n,72] f32, betas [n,10] f32, alignments {name: [4,3] f64}."""
+    rng = np.random.default_rng(seed + 99)
+    pose = (rng.normal(size=(n_frames, 72)) * 0.35).astype(np.float32)
+    pose[0, 6:9] = 0.0                                             # a joint at rest: Rodrigues at (near) zero angle
+    betas = (rng.normal(size=(n_frames, n_betas)) * 0.8).astype(np.float32)
+    align = {}
+    for i in range(n_frames):
+        a = rng.normal(size=3)
+        a /= np.linalg.norm(a)
+        ang = rng.uniform(0.2, 1.2)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        Rm = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+        M = np.eye(4)
+        M[:3, :3] = Rm * rng.uniform(0.8, 1.3)
+        M[:3, 3] = rng.normal(size=3) * 0.5
+        align[f"{i:05d}.png"] = np.ascontiguousarray(M.T[:, :3])  # stored transposed, [4,3] (neuman_helper.py:292, 316)
+    return pose, betas, align

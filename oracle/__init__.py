@@ -25,6 +25,9 @@ Pinning status
   arg-min, barycentrics of the closest point) and is anchored on the
   reference's call site utils/ray_utils.py:48-66 and on the in-repo formula of
   utils/ray_utils.py:73-88 for the barycentric ordering.
+* smpl (linear blend skinning -> per-frame verts / Ts): PINNED against the reference's own
+  ``read_smpls`` / ``verts_transformations`` / ``batch_rodrigues`` / ``vertex_forward`` run on a synthetic SMPL-layout
+  model (``tests/golden/make_golden_smpl.py`` -> ``tests/golden/smpl.npz``), to float32 tolerance.
 * frame (float -> uint8, uint8 PSNR): **parity unpinned**.  imageio and
   scikit-image (environment.yml:22, :30, no versions) are absent;
   ``oracle/frame.py`` restates their published rules.
