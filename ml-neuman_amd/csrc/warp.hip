@@ -327,8 +327,7 @@ template <bool SMALL>
 __global__ __launch_bounds__(64) NM_WARP_ATTR void search_kernel(Tree tr, int search_all_mode, const float* __restrict__ pts, int64_t N,
                                                                  const TriRec* __restrict__ rec, const int32_t* __restrict__ face_of,
                                                                  const Node* __restrict__ nodes, float* __restrict__ q_out,
-                                                                 int32_t* __restrict__ f_out
-                                                                 ) {
+                                                                 int32_t* __restrict__ f_out) {
     extern __shared__ double lds_raw[];
     const int depth = 3 * (tr.L - 1);
     // node stack entry: {distance^2, node} as float2, or -- SMALL: at most 65,536 nodes and triangles -- one dword holding the
