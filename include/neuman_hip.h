@@ -268,6 +268,40 @@ int nm_shot_rays(const int32_t* xy, int64_t n, int width, int mode, const double
 int nm_frame_to_uint8(const float* src, int64_t n, uint8_t* dst, nm_stream_t stream);
 int nm_ssd_u8(const uint8_t* a, const uint8_t* b, int64_t n, uint64_t* ssd, nm_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * SURVEY 8f-1 (first slice): device primitives of a training step of the background NeRF --
+ *   reference trainers/vanilla_nerf_trainer.py:45-96 (forward with grad) + torch autograd's backward
+ *   of models/vanilla.py:120-152 and utils/render_utils.py:69-105.  The layer loop is host code
+ *   (neuman_hip/train.py), as the reference's is Python.
+ *
+ *   nm_gemm_f32: C[M,N] = op(A) op(B) in float32 on the f32 MFMA (true f32 products and accumulation).
+ *     a_kmajor = 0: A is an [M,K] row-major array (lda);  1: A is stored [K,M] (its transpose is multiplied)
+ *     b_kmajor = 1: B is a [K,N] row-major array (ldb);   0: B is stored [N,K] (nn.Linear's weight layout)
+ *     forward      Z  = A  W^T      (0, 0)        backward-data     dA = dZ W      (0, 1)
+ *     backward-weights  dW = dZ^T A  (1, 1): split over K with a deterministic second pass when M*N is
+ *     small and K large; needs nm_gemm_workspace_floats(M,N,K) floats of workspace and allows no flag
+ *     but ACCUMULATE.
+ *     flags: ACCUMULATE  C += ...;  BIAS  + bias[col];  RELU  max(.,0);  MASK  zero where mask[row,col] <= 0
+ *     (applied in that order).  M, N, K, lda, ldb multiples of 4 (pad with zeros), A and B 16-byte aligned.
+ *   nm_pe_encode: models/vanilla.py:60-92 stand-alone: x [n,3] -> out [n,ld], 3 + 6 n_freqs features then
+ *     zeros; table = the n_freqs bands (posenc) or the [3 n_freqs, 3] projection (rotate), device f32.
+ *   nm_composite_backward: d loss / d raw [R,S,4] through raw2outputs given the gradients of rgb_map [R,3],
+ *     acc_map [R], depth_map [R], weights [R,S] (each nullable = zero); disp_map's gradient is not supported.
+ * ------------------------------------------------------------------------------------------- */
+#define NM_GEMM_ACCUMULATE 1
+#define NM_GEMM_BIAS 2
+#define NM_GEMM_RELU 4
+#define NM_GEMM_MASK 8
+int64_t nm_gemm_workspace_floats(int M, int N, int K);
+int nm_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                int ldc, const float* bias, const float* mask, int ldmask, int flags, float* workspace,
+                int64_t workspace_floats, nm_stream_t stream);
+int nm_pe_encode(const float* x, int64_t n, int kind, int n_freqs, const float* table, float* out, int ld,
+                 nm_stream_t stream);
+int nm_composite_backward(const float* raw, const float* z_vals, const float* rays_d, int64_t R, int S, int white_bkg,
+                          const float* g_rgb, const float* g_acc, const float* g_depth, const float* g_weights,
+                          float* d_raw, nm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,295 @@
+// SURVEY 8f-1, first slice: the device primitives of a training step of the background NeRF
+// (reference trainers/vanilla_nerf_trainer.py:45-96 -- forward with saved activations, torch autograd's backward).
+//   * nm_gemm_f32            C = op(A) op(B) on the f32 MFMA (v_mfma_f32_32x32x2_f32: true float32 products and accumulation,
+//                            like the reference's sgemm), with the epilogues a dense layer needs in either direction: + bias,
+//                            ReLU (forward), x (saved activation > 0) (backward-data), accumulate (the skip connection and
+//                            the two-input views layer are two GEMMs into one output).  Backward-weights (dW = dZ^T A, a
+//                            reduction over all samples into a 256 x 256 output) runs split-K with a deterministic second pass.
+//   * nm_pe_encode           models/vanilla.py:60-92 as a stand-alone kernel (the rendering path has it fused in K4)
+//   * nm_composite_backward  d loss / d raw through raw2outputs (utils/render_utils.py:69-105)
+// The layer loop lives in neuman_hip/train.py (the reference's is Python as well).  This is the correctness slice: the f32 MFMA
+// peaks at 157 TFLOP/s, a split-bf16 version on the 2.5 PFLOP/s pipe is the follow-up.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* mask;
+    float* partial;                 // split-K: raw accumulators to partial[z][M][N] instead of C
+    int M, N, K, lda, ldb, ldc, ldmask, k_per_split, flags;
+};
+
+// One 128 x 16 operand tile -> registers (two float4 per thread), zero beyond the edges.
+//   KMAJOR source: element (k, d) at S[k * ld + d]   (a [K, DIM] row-major array: direct copy)
+//   else:          element (k, d) at S[d * ld + k]   (a [DIM, K] row-major array: transposed on the way into LDS)
+template <bool KMAJOR>
+__device__ __forceinline__ void tile_load(const float* __restrict__ S, int ld, int DIM, int d0, int k0, int kend, int tid, float4 (&r)[2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        r[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (KMAJOR) {
+            const int k = k0 + (tid >> 5) + 8 * h, d = d0 + 4 * (tid & 31);
+            if (k < kend && d < DIM) r[h] = *reinterpret_cast<const float4*>(S + (int64_t)k * ld + d);
+        } else {
+            const int d = d0 + (tid & 127), k = k0 + 4 * ((tid >> 7) + 2 * h);
+            if (d < DIM && k < kend) r[h] = *reinterpret_cast<const float4*>(S + (int64_t)d * ld + k);
+        }
+    }
+}
+template <bool KMAJOR>
+__device__ __forceinline__ void tile_store(float (*T)[BM], int tid, const float4 (&r)[2]) {      // T[k][d]
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (KMAJOR) {
+            *reinterpret_cast<float4*>(&T[(tid >> 5) + 8 * h][4 * (tid & 31)]) = r[h];
+        } else {
+            const int d = tid & 127, k = 4 * ((tid >> 7) + 2 * h);
+            T[k][d] = r[h].x; T[k + 1][d] = r[h].y; T[k + 2][d] = r[h].z; T[k + 3][d] = r[h].w;
+        }
+    }
+}
+
+// 128 x 128 output tile per workgroup of four waves (64 x 64 each = 2 x 2 MFMA blocks of 32 x 32), K in steps of 16 through a
+// double-buffered LDS tile pair; the next step's global loads are in flight during the current step's MFMAs.
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+    __shared__ float As[2][BK][BM];
+    __shared__ float Bs[2][BK][BN];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    float4 ra[2], rb[2];
+    tile_load<A_KMAJOR>(g.A, g.lda, g.M, m0, kbeg, kend, tid, ra);
+    tile_load<B_KMAJOR>(g.B, g.ldb, g.N, n0, kbeg, kend, tid, rb);
+    tile_store<A_KMAJOR>(As[0], tid, ra);
+    tile_store<B_KMAJOR>(Bs[0], tid, rb);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = k0 + BK < kend;
+        if (more) {
+            tile_load<A_KMAJOR>(g.A, g.lda, g.M, m0, k0 + BK, kend, tid, ra);
+            tile_load<B_KMAJOR>(g.B, g.ldb, g.N, n0, k0 + BK, kend, tid, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int kr = kk + (lane >> 5), c = lane & 31;
+            const float a0 = As[buf][kr][wm + c], a1 = As[buf][kr][wm + 32 + c];
+            const float b0 = Bs[buf][kr][wn + c], b1 = Bs[buf][kr][wn + 32 + c];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) {
+            tile_store<A_KMAJOR>(As[buf ^ 1], tid, ra);
+            tile_store<B_KMAJOR>(Bs[buf ^ 1], tid, rb);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    // accumulator element v of a 32 x 32 block: row 8 (v / 4) + 4 (lane / 32) + v % 4, column lane % 32
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + 32 * j + (lane & 31);
+            if (col >= g.N) continue;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = m0 + wm + 32 * i + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+                if (row >= g.M) continue;
+                float x = acc[i][j][v];
+                if (g.partial) { g.partial[((int64_t)blockIdx.z * g.M + row) * g.N + col] = x; continue; }
+                float* c = g.C + (int64_t)row * g.ldc + col;
+                if (g.flags & NM_GEMM_ACCUMULATE) x += *c;
+                if (g.flags & NM_GEMM_BIAS) x += g.bias[col];
+                if (g.flags & NM_GEMM_RELU) x = fmaxf(x, 0.f);
+                if (g.flags & NM_GEMM_MASK) x = g.mask[(int64_t)row * g.ldmask + col] > 0.f ? x : 0.f;
+                *c = x;
+            }
+        }
+}
+
+// second pass of split-K: C (+)= sum over the splits, in split order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int splits, int M, int N, float* __restrict__ C, int ldc,
+                                                            int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)M * N) return;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * M * N + i];
+    float* c = C + (i / N) * ldc + (i % N);
+    *c = accumulate ? *c + s : s;
+}
+
+int pick_splits(int M, int N, int K) {
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    if (tiles >= 256 || K < 4096) return 1;
+    int s = (1024 + tiles - 1) / tiles;                      // ~4 workgroups per CU
+    const int maxs = (K + 1023) / 1024;                      // at least 1024 of K per split
+    s = s < maxs ? s : maxs;
+    return s < 1 ? 1 : s;
+}
+
+// [x, sin(f0 x), cos(f0 x), sin(f1 x), ...] (posenc, models/vanilla.py:60-79) or [x, sin(x B^T), cos(x B^T)] (rotate, :83-89),
+// then zeros up to `ld`.  One thread per output element.
+__global__ __launch_bounds__(256) void pe_encode_kernel(const float* __restrict__ x, int64_t n, int kind, int nfreq, const float* __restrict__ tab,
+                                                        float* __restrict__ out, int ld) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * ld) return;
+    const int64_t r = i / ld;
+    const int p = (int)(i % ld);
+    const float x0 = x[r * 3], x1 = x[r * 3 + 1], x2 = x[r * 3 + 2];
+    float v = 0.f;
+    if (p < 3) v = p == 0 ? x0 : (p == 1 ? x1 : x2);
+    else if (p - 3 < 6 * nfreq) {
+        const int m = p - 3;
+        if (kind == NM_PE_POSENC) {
+            const int b = m / 6, q = m - 6 * b, dim = q >= 3 ? q - 3 : q;
+            const float a = (dim == 0 ? x0 : (dim == 1 ? x1 : x2)) * tab[b];
+            v = q >= 3 ? cosf(a) : sinf(a);
+        } else {
+            const int n3 = 3 * nfreq;
+            const bool is_cos = m >= n3;
+            const float* b = tab + 3 * (is_cos ? m - n3 : m);
+            const float a = fmaf(x2, b[2], fmaf(x1, b[1], x0 * b[0]));
+            v = is_cos ? cosf(a) : sinf(a);
+        }
+    }
+    out[i] = v;
+}
+
+// d loss / d raw through raw2outputs, one thread per ray; the transmittance scan and its adjoint run in f64.
+//   w_i = a_i T_i, T_i = prod_{j<i} u_j, u_j = 1 - a_j + 1e-10, a_i = 1 - exp(-relu(sigma_i) dist_i)
+//   G_i = dL/dw_i = g_rgb . c_i + g_acc' + g_depth z_i + g_w_i      (white background: g_acc' = g_acc - sum_k g_rgb_k)
+//   dL/da_i = G_i T_i - (sum_{m>i} G_m w_m) / u_i;   da_i/dsigma_i = dist_i (1 - a_i) [sigma_i > 0]
+__global__ __launch_bounds__(64) void composite_backward_kernel(const float* __restrict__ raw, const float* __restrict__ z, const float* __restrict__ rays_d,
+                                                                int64_t R, int S, int white_bkg, const float* __restrict__ g_rgb,
+                                                                const float* __restrict__ g_acc, const float* __restrict__ g_depth,
+                                                                const float* __restrict__ g_w, float* __restrict__ d_raw) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const float dn = sqrtf(rays_d[r * 3] * rays_d[r * 3] + rays_d[r * 3 + 1] * rays_d[r * 3 + 1] + rays_d[r * 3 + 2] * rays_d[r * 3 + 2]);
+    const float gr0 = g_rgb ? g_rgb[r * 3] : 0.f, gr1 = g_rgb ? g_rgb[r * 3 + 1] : 0.f, gr2 = g_rgb ? g_rgb[r * 3 + 2] : 0.f;
+    const double ga = (double)(g_acc ? g_acc[r] : 0.f) - (white_bkg ? (double)gr0 + (double)gr1 + (double)gr2 : 0.0);
+    const double gd = g_depth ? (double)g_depth[r] : 0.0;
+    const float* rw = raw + r * S * 4;
+    const float* zz = z + r * S;
+    float* dr = d_raw + r * S * 4;
+    // forward scan: T_i, leaves T_S in `T`
+    double T = 1.0;
+    for (int i = 0; i < S; ++i) {
+        const float dist = (i + 1 < S ? zz[i + 1] - zz[i] : 1e10f) * dn;
+        const float a = 1.f - expf(-fmaxf(rw[i * 4 + 3], 0.f) * dist);
+        T *= (double)(1.f - a + 1e-10f);
+    }
+    // backward scan: peel u_i off T to get T_i, carry the suffix sum
+    double suffix = 0.0;
+    for (int i = S - 1; i >= 0; --i) {
+        const float sg = rw[i * 4 + 3];
+        const float dist = (i + 1 < S ? zz[i + 1] - zz[i] : 1e10f) * dn;
+        const float e = expf(-fmaxf(sg, 0.f) * dist);
+        const float a = 1.f - e;
+        const double u = (double)(1.f - a + 1e-10f);
+        T /= u;                                                    // T_i
+        const double wgt = (double)a * T;
+        float c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) c[k] = 1.f / (1.f + expf(-rw[i * 4 + k]));
+        const double G = (double)gr0 * c[0] + (double)gr1 * c[1] + (double)gr2 * c[2] + ga + gd * (double)zz[i] + (g_w ? (double)g_w[r * S + i] : 0.0);
+        const double da = G * T - suffix / u;
+        suffix += G * wgt;
+        dr[i * 4] = (float)(wgt * (double)gr0 * (double)(c[0] * (1.f - c[0])));
+        dr[i * 4 + 1] = (float)(wgt * (double)gr1 * (double)(c[1] * (1.f - c[1])));
+        dr[i * 4 + 2] = (float)(wgt * (double)gr2 * (double)(c[2] * (1.f - c[2])));
+        dr[i * 4 + 3] = sg > 0.f ? (float)(da * (double)dist * (double)e) : 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t nm_gemm_workspace_floats(int M, int N, int K) {
+    const int s = pick_splits(M, N, K);
+    return s > 1 ? (int64_t)s * M * N : 0;
+}
+
+int nm_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                const float* bias, const float* mask, int ldmask, int flags, float* workspace, int64_t workspace_floats, nm_stream_t stream) {
+    NM_REQUIRE(M >= 0 && N >= 0 && K >= 0, "nm_gemm_f32: negative size");
+    if (M == 0 || N == 0) return NM_OK;
+    NM_REQUIRE(A && B && C, "nm_gemm_f32: null pointer");
+    NM_REQUIRE(M % 4 == 0 && N % 4 == 0 && K % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0, "nm_gemm_f32: M, N, K, lda, ldb must be multiples of 4 "
+               "(M=%d N=%d K=%d lda=%d ldb=%d): pad with zeros", M, N, K, lda, ldb);
+    NM_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, "nm_gemm_f32: A and B must be 16-byte aligned");
+    NM_REQUIRE(lda >= (a_kmajor ? M : K) && ldb >= (b_kmajor ? N : K) && ldc >= N, "nm_gemm_f32: leading dimension too small");
+    NM_REQUIRE(!(flags & NM_GEMM_BIAS) || bias, "nm_gemm_f32: NM_GEMM_BIAS without a bias vector");
+    NM_REQUIRE(!(flags & NM_GEMM_MASK) || (mask && ldmask >= N), "nm_gemm_f32: NM_GEMM_MASK without a mask array");
+    hipStream_t st = nm::as_stream(stream);
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.mask = mask; g.partial = nullptr;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldmask = ldmask; g.flags = flags;
+    int splits = pick_splits(M, N, K);
+    if (splits > 1) {
+        NM_REQUIRE(!(flags & ~NM_GEMM_ACCUMULATE), "nm_gemm_f32: a split-K product (M=%d N=%d K=%d) takes no epilogue but ACCUMULATE", M, N, K);
+        NM_REQUIRE(workspace && workspace_floats >= (int64_t)splits * M * N, "nm_gemm_f32: needs %lld floats of workspace (nm_gemm_workspace_floats)",
+                   (long long)splits * M * N);
+        g.partial = workspace;
+    }
+    g.k_per_split = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+    if (g.k_per_split < BK) g.k_per_split = BK;
+    splits = (K + g.k_per_split - 1) / g.k_per_split;
+    if (splits < 1) splits = 1;
+    const dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits);
+    if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, g);
+    else if (a_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, g);
+    else if (b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, g);
+    if (int rc = nm::check_launch("gemm_f32_kernel")) return rc;
+    if (g.partial) {
+        const int64_t n = (int64_t)M * N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, splits, M, N, C, ldc,
+                           (flags & NM_GEMM_ACCUMULATE) ? 1 : 0);
+        return nm::check_launch("splitk_reduce_kernel");
+    }
+    return NM_OK;
+}
+
+int nm_pe_encode(const float* x, int64_t n, int kind, int n_freqs, const float* table, float* out, int ld, nm_stream_t stream) {
+    NM_REQUIRE(n >= 0 && n_freqs >= 0 && ld >= 3 + 6 * n_freqs, "nm_pe_encode: bad sizes n=%lld n_freqs=%d ld=%d", (long long)n, n_freqs, ld);
+    NM_REQUIRE(kind == NM_PE_POSENC || kind == NM_PE_ROTATE, "nm_pe_encode: mapping %d", kind);
+    if (n == 0) return NM_OK;
+    NM_REQUIRE(x && out && (table || n_freqs == 0), "nm_pe_encode: null pointer");
+    const int64_t total = n * ld;
+    hipLaunchKernelGGL(pe_encode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nm::as_stream(stream), x, n, kind, n_freqs, table, out, ld);
+    return nm::check_launch("pe_encode_kernel");
+}
+
+int nm_composite_backward(const float* raw, const float* z_vals, const float* rays_d, int64_t R, int S, int white_bkg, const float* g_rgb,
+                          const float* g_acc, const float* g_depth, const float* g_weights, float* d_raw, nm_stream_t stream) {
+    NM_REQUIRE(R >= 0 && S >= 1, "nm_composite_backward: bad sizes R=%lld S=%d", (long long)R, S);
+    if (R == 0) return NM_OK;
+    NM_REQUIRE(raw && z_vals && rays_d && d_raw, "nm_composite_backward: null pointer");
+    hipLaunchKernelGGL(composite_backward_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, nm::as_stream(stream), raw, z_vals, rays_d, R, S,
+                       white_bkg, g_rgb, g_acc, g_depth, g_weights, d_raw);
+    return nm::check_launch("composite_backward_kernel");
+}
+
+}  // extern "C"

@@ -60,6 +60,10 @@ SIGNATURES = {
     "nm_smpl_destroy": (i32, [ctypes.c_void_p]),
     "nm_smpl_frames": (i32, [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_void_p, i32, ctypes.c_double, i32, ctypes.c_void_p, c_f32p, c_f32p,
                              c_stream]),
+    "nm_gemm_workspace_floats": (i64, [i32, i32, i32]),
+    "nm_gemm_f32": (i32, [i32, i32, i32, i32, i32, c_f32p, i32, c_f32p, i32, c_f32p, i32, c_f32p, c_f32p, i32, i32, c_f32p, i64, c_stream]),
+    "nm_pe_encode": (i32, [c_f32p, i64, i32, i32, c_f32p, c_f32p, i32, c_stream]),
+    "nm_composite_backward": (i32, [c_f32p, c_f32p, c_f32p, i64, i32, i32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "nm_merge_sorted": (i32, [c_f32p, c_f32p, i32, c_f32p, c_f32p, i32, i64, c_f32p, c_f32p, c_stream]),
     "nm_gather_rows": (i32, [c_f32p, c_i32p, c_i32p, i64, i32, c_f32p, c_stream]),
     "nm_scatter_rows": (i32, [c_f32p, c_i32p, c_i32p, i64, i32, c_f32p, c_stream]),

@@ -32,14 +32,17 @@ MAX_RAYS_PER_LAUNCH = int(os.environ.get("NEUMAN_MAX_RAYS_PER_LAUNCH", 1 << 20))
 def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, white_bkg=True, want_weights=True):
     """reference render_utils.py:69-105 -> (rgb_map, disp_map, acc_map, weights, depth_map)."""
     _lib.require_gpu()
-    raw = raw.to(torch.float32).contiguous()
-    z_vals = z_vals.to(torch.float32).contiguous()
-    rays_d = rays_d.to(torch.float32).contiguous()
     R, S = z_vals.shape
     dev = raw.device
     noise = None
     if raw_noise_std > 0.:
         noise = (torch.randn((R, S), device=dev) * raw_noise_std).contiguous()          # render_utils.py:93
+    if torch.is_grad_enabled() and raw.requires_grad:                                   # a training step: autograd through `raw`
+        from . import train
+        return train.composite_train(raw, z_vals, rays_d, white_bkg, noise)
+    raw = raw.to(torch.float32).contiguous()
+    z_vals = z_vals.to(torch.float32).contiguous()
+    rays_d = rays_d.to(torch.float32).contiguous()
     rgb = torch.empty((R, 3), device=dev, dtype=torch.float32)
     disp = torch.empty(R, device=dev, dtype=torch.float32)
     acc = torch.empty(R, device=dev, dtype=torch.float32)

@@ -77,7 +77,7 @@ def make_joiner(seed, mapping='posenc', dense=True, pos_min_freq=0):
             net.nerf.alpha_linear.weight *= 40.
             net.nerf.alpha_linear.bias.fill_(0.5)
             net.nerf.rgb_linear.weight *= 8.
-    return net
+    return net.eval()                    # rendering workloads; train() + grad enabled selects the differentiable forward
 
 
 def state_numpy(joiner):

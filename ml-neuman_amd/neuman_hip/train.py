@@ -1,0 +1,223 @@
+"""SURVEY 8f-1, first slice: differentiable forward of the Joiner (PE + NeRF MLP) and of raw2outputs on the device, so that the
+reference's training loss (trainers/vanilla_nerf_trainer.py:45-96) runs through `loss.backward()` unchanged:
+
+    out = coarse_net(pts, dirs)                      # Joiner in train() mode with grad enabled -> mlp_forward_train
+    rgb_map, _, _, weights, _ = raw2outputs(out, z_vals, dirs[:, 0, :], ...)        # -> composite_train
+    F.mse_loss(rgb_map, color).backward()            # fills .grad of the 24 parameters
+
+Every matrix product is `nm_gemm_f32` (float32 MFMA, csrc/train.hip), the encodings `nm_pe_encode`, the compositing adjoint
+`nm_composite_backward`; torch supplies memory and the autograd graph.  The layer loop below is the reference's
+models/vanilla.py:120-152 with the two concatenations (skip connection :130-131, views layer :139-140) written as two
+products into one output.  Gradients reach the parameters (and flow on through `raw`); gradients with respect to the sample
+positions (pose / offset optimisation of the human trainer) are not implemented and raise.
+"""
+import torch
+
+from . import _lib
+
+ACC, BIAS, RELU, MASK = 1, 2, 4, 8                    # NM_GEMM_* (include/neuman_hip.h)
+PE_KINDS = {'posenc': 0, 'rotate': 1}                 # NM_PE_POSENC / NM_PE_ROTATE
+
+
+def _gemm(a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, bias=None, mask=None, ldmask=0, flags=0, ws=None):
+    _lib.check(_lib.lib().nm_gemm_f32(a_kmajor, b_kmajor, M, N, K, _lib.dev_ptr(A), lda, _lib.dev_ptr(B), ldb, _lib.dev_ptr(C), ldc,
+                                      _lib.dev_ptr(bias), _lib.dev_ptr(mask), ldmask, flags, _lib.dev_ptr(ws), 0 if ws is None else ws.numel(),
+                                      _lib.stream_ptr()), "nm_gemm_f32")
+
+
+def _pad_cols(w, cols):
+    """[rows, c] -> [rows, cols] zero-padded, contiguous f32"""
+    out = torch.zeros((w.shape[0], cols), device=w.device, dtype=torch.float32)
+    out[:, :w.shape[1]] = w
+    return out
+
+
+def _pad_rows(w, rows, at=0):
+    out = torch.zeros((rows, w.shape[1]), device=w.device, dtype=torch.float32)
+    out[at:at + w.shape[0]] = w
+    return out
+
+
+class _Packed:
+    """The 24 parameters in the shapes the products want (reference layout [out, in], inputs padded to multiples of 4)."""
+
+    def __init__(self, nerf, n_pos, n_dir):
+        with torch.no_grad():
+            P = [l for l in nerf.pts_linears]
+            self.n_pos, self.n_dir = n_pos, n_dir                               # 63, 27
+            self.kp, self.kd = (n_pos + 3) // 4 * 4, (n_dir + 3) // 4 * 4       # 64, 28
+            self.W, self.b = [], []
+            for i, lin in enumerate(P):
+                w = lin.weight.detach().float()
+                if i == 0:
+                    self.W.append((_pad_cols(w, self.kp),))
+                elif w.shape[1] == nerf.width + n_pos:                           # the layer after the skip: cat([x_pe, h]) (vanilla.py:130)
+                    self.W.append((_pad_cols(w[:, :n_pos], self.kp), w[:, n_pos:].contiguous()))
+                else:
+                    self.W.append((w.contiguous(),))
+                self.b.append(lin.bias.detach().float().contiguous())
+            wv = nerf.views_linears[0].weight.detach().float()                   # cat([feature, d_pe]) (vanilla.py:139)
+            self.Wv = (wv[:, :nerf.width].contiguous(), _pad_cols(wv[:, nerf.width:], self.kd))
+            self.bv = nerf.views_linears[0].bias.detach().float().contiguous()
+            self.Wf, self.bf = nerf.feature_linear.weight.detach().float().contiguous(), nerf.feature_linear.bias.detach().float().contiguous()
+            self.Wa4 = _pad_rows(nerf.alpha_linear.weight.detach().float(), 4, at=3)        # raw[:, 3] = sigma
+            self.Wr4 = _pad_rows(nerf.rgb_linear.weight.detach().float(), 4)                # raw[:, :3] = rgb
+            self.b4 = torch.cat([nerf.rgb_linear.bias.detach().float(), nerf.alpha_linear.bias.detach().float()]).contiguous()
+
+
+class _MLP(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, joiner, pts, dirs, *params):
+        nerf = joiner.nerf
+        dev = pts.device
+        n = pts.shape[0]
+        n4 = (n + 3) // 4 * 4
+        width, half = nerf.width, nerf.width // 2
+        pk = _Packed(nerf, joiner.pos_pe.out_dim, joiner.dir_pe.out_dim)
+        p4 = torch.zeros((n4, 3), device=dev, dtype=torch.float32)
+        d4 = torch.zeros((n4, 3), device=dev, dtype=torch.float32)
+        p4[:n], d4[:n] = pts, dirs
+        X0 = torch.empty((n4, pk.kp), device=dev, dtype=torch.float32)
+        D0 = torch.empty((n4, pk.kd), device=dev, dtype=torch.float32)
+        for emb, x, out in ((joiner.pos_pe, p4, X0), (joiner.dir_pe, d4, D0)):
+            tab = torch.from_numpy(emb.table()).to(dev).contiguous()
+            _lib.check(_lib.lib().nm_pe_encode(_lib.dev_ptr(x), n4, PE_KINDS[emb.mapping], emb.N_freqs, _lib.dev_ptr(tab), _lib.dev_ptr(out),
+                                               out.shape[1], _lib.stream_ptr()), "nm_pe_encode")
+        H = []
+        h, kh = X0, pk.kp
+        for i, Ws in enumerate(pk.W):
+            o = torch.empty((n4, width), device=dev, dtype=torch.float32)
+            if len(Ws) == 2:                                                     # skip layer: x_pe W_a^T, then + h W_b^T + b, ReLU
+                _gemm(0, 0, n4, width, pk.kp, X0, pk.kp, Ws[0], pk.kp, o, width)
+                _gemm(0, 0, n4, width, width, h, width, Ws[1], width, o, width, bias=pk.b[i], flags=ACC | BIAS | RELU)
+            else:
+                _gemm(0, 0, n4, width, kh, h, kh, Ws[0], kh, o, width, bias=pk.b[i], flags=BIAS | RELU)
+            H.append(o)
+            h, kh = o, width
+        raw = torch.empty((n4, 4), device=dev, dtype=torch.float32)
+        _gemm(0, 0, n4, 4, width, h, width, pk.Wa4, width, raw, 4, bias=pk.b4, flags=BIAS)             # sigma (+ all four biases)
+        feat = torch.empty((n4, width), device=dev, dtype=torch.float32)
+        _gemm(0, 0, n4, width, width, h, width, pk.Wf, width, feat, width, bias=pk.bf, flags=BIAS)
+        hv = torch.empty((n4, half), device=dev, dtype=torch.float32)
+        _gemm(0, 0, n4, half, width, feat, width, pk.Wv[0], width, hv, half)
+        _gemm(0, 0, n4, half, pk.kd, D0, pk.kd, pk.Wv[1], pk.kd, hv, half, bias=pk.bv, flags=ACC | BIAS | RELU)
+        _gemm(0, 0, n4, 4, half, hv, half, pk.Wr4, half, raw, 4, flags=ACC)                               # + rgb
+        ctx.pk, ctx.X0, ctx.D0, ctx.H, ctx.feat, ctx.hv, ctx.n, ctx.nerf = pk, X0, D0, H, feat, hv, n, nerf
+        return raw[:n]
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        pk, X0, D0, H, feat, hv, n, nerf = ctx.pk, ctx.X0, ctx.D0, ctx.H, ctx.feat, ctx.hv, ctx.n, ctx.nerf
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            raise _lib.NeumanHipError("gradients with respect to sample positions / directions are not implemented (SURVEY 8f-1, human trainer)")
+        dev = X0.device
+        n4, width, half = X0.shape[0], nerf.width, nerf.width // 2
+        d_raw = torch.zeros((n4, 4), device=dev, dtype=torch.float32)
+        d_raw[:n] = g_raw
+        ones = torch.zeros((n4, 4), device=dev, dtype=torch.float32)
+        ones[:n] = 1.0
+        ws = [torch.empty(4, device=dev, dtype=torch.float32)]
+
+        def workspace(m, k):                                                     # split-K partials, grown to the largest product
+            need = int(_lib.lib().nm_gemm_workspace_floats(m, k, n4))
+            if need > ws[0].numel():
+                ws[0] = torch.empty(need, device=dev, dtype=torch.float32)
+            return ws[0]
+
+        def wgrad(dz, m, a, k):                                                  # dW [m,k] = dz^T a, a reduction over the n4 samples
+            out = torch.empty((m, k), device=dev, dtype=torch.float32)
+            _gemm(1, 1, m, k, n4, dz, dz.shape[1], a, a.shape[1], out, k, ws=workspace(m, k))
+            return out
+
+        def bgrad(dz, m):                                                        # column sums, as ones^T dz
+            out = torch.empty((4, m), device=dev, dtype=torch.float32)
+            _gemm(1, 1, 4, m, n4, ones, 4, dz, dz.shape[1], out, m, ws=workspace(4, m))
+            return out[0]
+
+        g = {}
+        h7 = H[-1]
+        gWr4, gb4 = wgrad(d_raw, 4, hv, half), bgrad(d_raw, 4)
+        g['rgb_w'], g['rgb_b'], g['alpha_b'] = gWr4[:3], gb4[:3], gb4[3:4]
+        d_hv = torch.empty((n4, half), device=dev, dtype=torch.float32)
+        _gemm(0, 1, n4, half, 4, d_raw, 4, pk.Wr4, half, d_hv, half, mask=hv, ldmask=half, flags=MASK)
+        g['views_w'] = torch.cat([wgrad(d_hv, half, feat, width), wgrad(d_hv, half, D0, pk.kd)[:, :pk.n_dir]], 1)
+        g['views_b'] = bgrad(d_hv, half)
+        d_feat = torch.empty((n4, width), device=dev, dtype=torch.float32)
+        _gemm(0, 1, n4, width, half, d_hv, half, pk.Wv[0], width, d_feat, width)
+        g['feature_w'], g['feature_b'] = wgrad(d_feat, width, h7, width), bgrad(d_feat, width)
+        g['alpha_w'] = wgrad(d_raw, 4, h7, width)[3:4]
+        dz = torch.empty((n4, width), device=dev, dtype=torch.float32)
+        _gemm(0, 1, n4, width, width, d_feat, width, pk.Wf, width, dz, width)
+        _gemm(0, 1, n4, width, 4, d_raw, 4, pk.Wa4, width, dz, width, mask=h7, ldmask=width, flags=ACC | MASK)
+        gw, gb = [None] * len(pk.W), [None] * len(pk.W)
+        for i in range(len(pk.W) - 1, -1, -1):
+            Ws = pk.W[i]
+            gb[i] = bgrad(dz, width)
+            if i == 0:
+                gw[i] = wgrad(dz, width, X0, pk.kp)[:, :pk.n_pos]
+                break
+            prev = H[i - 1]
+            if len(Ws) == 2:
+                gw[i] = torch.cat([wgrad(dz, width, X0, pk.kp)[:, :pk.n_pos], wgrad(dz, width, prev, width)], 1)
+                Wb = Ws[1]
+            else:
+                gw[i] = wgrad(dz, width, prev, width)
+                Wb = Ws[0]
+            nz = torch.empty((n4, width), device=dev, dtype=torch.float32)
+            _gemm(0, 1, n4, width, width, dz, width, Wb, width, nz, width, mask=prev, ldmask=width, flags=MASK)
+            dz = nz
+        grads = []
+        for i in range(len(pk.W)):
+            grads += [gw[i].contiguous(), gb[i].contiguous()]
+        grads += [g['views_w'].contiguous(), g['views_b'].contiguous(), g['feature_w'], g['feature_b'].contiguous(),
+                  g['alpha_w'].contiguous(), g['alpha_b'].contiguous(), g['rgb_w'].contiguous(), g['rgb_b'].contiguous()]
+        return (None, None, None) + tuple(grads)
+
+
+def mlp_forward_train(joiner, pts, dirs):
+    """Joiner.forward with autograd: pts, dirs [..., 3] CUDA f32 -> raw [..., 4]; backward fills the parameters' .grad."""
+    _lib.require_gpu()
+    shp = pts.shape[:-1]
+    p = pts.reshape(-1, 3).to(torch.float32).contiguous()
+    d = dirs.reshape(-1, 3).to(torch.float32).contiguous()
+    return _MLP.apply(joiner, p, d, *joiner.nerf.ordered_params()).reshape(*shp, 4)
+
+
+class _Composite(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, z_vals, rays_d, white_bkg, noise):
+        R, S = z_vals.shape
+        dev = raw.device
+        rgb = torch.empty((R, 3), device=dev, dtype=torch.float32)
+        disp = torch.empty(R, device=dev, dtype=torch.float32)
+        acc = torch.empty(R, device=dev, dtype=torch.float32)
+        depth = torch.empty(R, device=dev, dtype=torch.float32)
+        weights = torch.empty((R, S), device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib().nm_composite(_lib.dev_ptr(raw), _lib.dev_ptr(z_vals), _lib.dev_ptr(rays_d), R, S, int(bool(white_bkg)),
+                                           _lib.dev_ptr(noise), _lib.dev_ptr(rgb), _lib.dev_ptr(disp), _lib.dev_ptr(acc), _lib.dev_ptr(weights),
+                                           _lib.dev_ptr(depth), _lib.stream_ptr()), "nm_composite")
+        ctx.save_for_backward(raw, z_vals, rays_d)
+        ctx.white_bkg, ctx.noise = bool(white_bkg), noise
+        ctx.set_materialize_grads(False)
+        return rgb, disp, acc, weights, depth
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_w, g_depth):
+        raw, z_vals, rays_d = ctx.saved_tensors
+        if g_disp is not None:
+            raise _lib.NeumanHipError("the gradient of disp_map is not implemented (no reference loss uses it)")
+        if ctx.noise is not None:
+            raw = (raw + torch.cat([torch.zeros_like(raw[..., :3]), ctx.noise[..., None]], -1)).contiguous()
+        R, S = z_vals.shape
+        d_raw = torch.empty_like(raw)
+        c = lambda t: None if t is None else t.to(torch.float32).contiguous()
+        _lib.check(_lib.lib().nm_composite_backward(_lib.dev_ptr(raw), _lib.dev_ptr(z_vals), _lib.dev_ptr(rays_d), R, S, int(ctx.white_bkg),
+                                                    _lib.dev_ptr(c(g_rgb)), _lib.dev_ptr(c(g_acc)), _lib.dev_ptr(c(g_depth)), _lib.dev_ptr(c(g_w)),
+                                                    _lib.dev_ptr(d_raw), _lib.stream_ptr()), "nm_composite_backward")
+        return d_raw, None, None, None, None
+
+
+def composite_train(raw, z_vals, rays_d, white_bkg=True, noise=None):
+    """raw2outputs with autograd through `raw` (utils/render_utils.py:69-105)."""
+    return _Composite.apply(raw.to(torch.float32).contiguous(), z_vals.detach().to(torch.float32).contiguous(),
+                            rays_d.detach().to(torch.float32).contiguous(), white_bkg, noise)

@@ -146,12 +146,19 @@ class Joiner(nn.Module):
     def _guard(*tensors):
         _lib.require_gpu()
         if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
-            raise _lib.NeumanHipError("the HIP MLP kernel is forward-only (training is SURVEY 8f-1); wrap in torch.no_grad()")
+            raise _lib.NeumanHipError("the rendering kernels are forward-only: wrap in torch.no_grad(), or put the Joiner in train() mode "
+                                       "for the differentiable float32 forward (neuman_hip/train.py)")
 
     def forward(self, input_pts, input_views=None, precision=None, sigma_scale=1.0, role=None):
         """input_pts [..., 3], input_views [..., 3] (CUDA f32) -> [..., 4] = (r, g, b, sigma)."""
         if input_views is None:
             raise NotImplementedError("the HIP net is the use_viewdirs=True net: input_views is required")
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # a training step (trainers/vanilla_nerf_trainer.py:66): float32 MFMA forward that keeps its activations
+            from . import train
+            if sigma_scale != 1.0:
+                raise _lib.NeumanHipError("sigma_scale is a render-time option (render_utils.py:229)")
+            return train.mlp_forward_train(self, input_pts, input_views)
         self._guard(input_pts, input_views)
         shp = input_pts.shape[:-1]
         p = input_pts.detach().reshape(-1, 3).contiguous()
