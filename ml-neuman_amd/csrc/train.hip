@@ -141,8 +141,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 int pick_splits(int M, int N, int K) {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     if (tiles >= 256 || K < 4096) return 1;
-    int s = (1024 + tiles - 1) / tiles;                      // ~4 workgroups per CU
-    const int maxs = (K + 1023) / 1024;                      // at least 1024 of K per split
+    int s = (512 + tiles - 1) / tiles;                       // ~2 workgroups per CU
+    const int maxs = (K + 2047) / 2048;                      // at least 2048 of K per split
     s = s < maxs ? s : maxs;
     return s < 1 ? 1 : s;
 }

@@ -28,6 +28,9 @@ Pinning status
 * smpl (linear blend skinning -> per-frame verts / Ts): PINNED against the reference's own
   ``read_smpls`` / ``verts_transformations`` / ``batch_rodrigues`` / ``vertex_forward`` run on a synthetic SMPL-layout
   model (``tests/golden/make_golden_smpl.py`` -> ``tests/golden/smpl.npz``), to float32 tolerance.
+* train (one training step of the background NeRF: losses and parameter gradients): PINNED against the
+  reference's own ``NeRFTrainer.loss_func`` + ``backward()`` (``tests/golden/make_golden_train.py`` ->
+  ``tests/golden/train.npz``); ``oracle/train.py`` is torch float64 + autograd.
 * frame (float -> uint8, uint8 PSNR): **parity unpinned**.  imageio and
   scikit-image (environment.yml:22, :30, no versions) are absent;
   ``oracle/frame.py`` restates their published rules.
