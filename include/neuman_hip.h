@@ -274,7 +274,8 @@ int nm_ssd_u8(const uint8_t* a, const uint8_t* b, int64_t n, uint64_t* ssd, nm_s
  *   of models/vanilla.py:120-152 and utils/render_utils.py:69-105.  The layer loop is host code
  *   (neuman_hip/train.py), as the reference's is Python.
  *
- *   nm_gemm_f32: C[M,N] = op(A) op(B) in float32 on the f32 MFMA (true f32 products and accumulation).
+ *   nm_gemm_f32: C[M,N] = op(A) op(B) in float32 on the f32 MFMA (true f32 products and accumulation);
+ *   nm_gemm_bf16x3 below is the faster, slightly less exact form (NEUMAN_TRAIN_GEMM=bf16x3).
  *     a_kmajor = 0: A is an [M,K] row-major array (lda);  1: A is stored [K,M] (its transpose is multiplied)
  *     b_kmajor = 1: B is a [K,N] row-major array (ldb);   0: B is stored [N,K] (nn.Linear's weight layout)
  *     forward      Z  = A  W^T      (0, 0)        backward-data     dA = dZ W      (0, 1)
@@ -296,6 +297,11 @@ int64_t nm_gemm_workspace_floats(int M, int N, int K);
 int nm_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                 int ldc, const float* bias, const float* mask, int ldmask, int flags, float* workspace,
                 int64_t workspace_floats, nm_stream_t stream);
+/* the same product with each float32 operand split into bf16 hi + lo and hi*hi + hi*lo + lo*hi accumulated in float32 on the
+ * bf16 MFMA (2^-17 relative per product; what the rendering kernels call bf16x3).  Same arguments, same rules. */
+int nm_gemm_bf16x3(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                   int ldc, const float* bias, const float* mask, int ldmask, int flags, float* workspace,
+                   int64_t workspace_floats, nm_stream_t stream);
 int nm_pe_encode(const float* x, int64_t n, int kind, int n_freqs, const float* table, float* out, int ld,
                  nm_stream_t stream);
 int nm_composite_backward(const float* raw, const float* z_vals, const float* rays_d, int64_t R, int S, int white_bkg,

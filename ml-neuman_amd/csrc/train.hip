@@ -16,6 +16,9 @@
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BM = 128, BN = 128, BK = 16;
 
@@ -105,6 +108,127 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         buf ^= 1;
     }
     // accumulator element v of a 32 x 32 block: row 8 (v / 4) + 4 (lane / 32) + v % 4, column lane % 32
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + 32 * j + (lane & 31);
+            if (col >= g.N) continue;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = m0 + wm + 32 * i + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
+                if (row >= g.M) continue;
+                float x = acc[i][j][v];
+                if (g.partial) { g.partial[((int64_t)blockIdx.z * g.M + row) * g.N + col] = x; continue; }
+                float* c = g.C + (int64_t)row * g.ldc + col;
+                if (g.flags & NM_GEMM_ACCUMULATE) x += *c;
+                if (g.flags & NM_GEMM_BIAS) x += g.bias[col];
+                if (g.flags & NM_GEMM_RELU) x = fmaxf(x, 0.f);
+                if (g.flags & NM_GEMM_MASK) x = g.mask[(int64_t)row * g.ldmask + col] > 0.f ? x : 0.f;
+                *c = x;
+            }
+        }
+}
+
+// ---- the same product on the bf16 MFMA, each float32 operand split into bf16 hi + lo (RNE both times; x - hi is exact in f32)
+// and hi*hi + hi*lo + lo*hi accumulated in f32: 2^-17 relative per product, 5x the f32 MFMA's rate at peak.
+// LDS holds the operand tiles already split and in MFMA fragment order: T[k-octet][row] = 8 consecutive-k bf16 (16 B), which is
+// what lane (row = l % 32, octet = l / 32) of v_mfma_f32_32x32x16_bf16 consumes -- one ds_read_b128 per fragment, conflict-free.
+constexpr int XK = 32;                  // k per tile: two MFMA k-steps
+
+__device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const f32x2 a = {v[2 * p], v[2 * p + 1]};
+        const bf16x2 hb = __builtin_convertvector(a, bf16x2);
+        const f32x2 hf = __builtin_convertvector(hb, f32x2);
+        const f32x2 r = {a.x - hf.x, a.y - hf.y};
+        const bf16x2 lb = __builtin_convertvector(r, bf16x2);
+        h[p] = __builtin_bit_cast(unsigned, hb);
+        l[p] = __builtin_bit_cast(unsigned, lb);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+// one 128 x 32 operand tile -> registers: two (row, k-octet) pairs of 8 floats per thread, zero beyond the edges
+template <bool KMAJOR>
+__device__ __forceinline__ void xtile_load(const float* __restrict__ S, int ld, int DIM, int d0, int k0, int kend, int tid, float (&r)[2][8]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int d = d0 + (tid & 127), k = k0 + 8 * ((tid >> 7) + 2 * h);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[h][j] = 0.f;
+        if (d >= DIM) continue;
+        if (KMAJOR) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k + j < kend) r[h][j] = S[(int64_t)(k + j) * ld + d];       // lanes run along d: coalesced
+        } else {
+            if (k < kend) *reinterpret_cast<float4*>(&r[h][0]) = *reinterpret_cast<const float4*>(S + (int64_t)d * ld + k);
+            if (k + 4 < kend) *reinterpret_cast<float4*>(&r[h][4]) = *reinterpret_cast<const float4*>(S + (int64_t)d * ld + k + 4);
+        }
+    }
+}
+__device__ __forceinline__ void xtile_store(uint4 (*Th)[BM], uint4 (*Tl)[BM], int tid, const float (&r)[2][8]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        uint4 hi, lo;
+        split8(r[h], hi, lo);
+        Th[(tid >> 7) + 2 * h][tid & 127] = hi;
+        Tl[(tid >> 7) + 2 * h][tid & 127] = lo;
+    }
+}
+
+template <bool A_KMAJOR, bool B_KMAJOR>
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmArgs g) {
+    __shared__ uint4 Ah[XK / 8][BM], Al[XK / 8][BM], Bh[XK / 8][BN], Bl[XK / 8][BN];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    float ra[2][8], rb[2][8];
+    xtile_load<A_KMAJOR>(g.A, g.lda, g.M, m0, kbeg, kend, tid, ra);
+    xtile_load<B_KMAJOR>(g.B, g.ldb, g.N, n0, kbeg, kend, tid, rb);
+    for (int k0 = kbeg; k0 < kend; k0 += XK) {
+        __syncthreads();                                               // the previous tile's fragments have been read
+        xtile_store(Ah, Al, tid, ra);
+        xtile_store(Bh, Bl, tid, rb);
+        __syncthreads();
+        if (k0 + XK < kend) {                                          // next tile's loads fly during this tile's MFMAs
+            xtile_load<A_KMAJOR>(g.A, g.lda, g.M, m0, k0 + XK, kend, tid, ra);
+            xtile_load<B_KMAJOR>(g.B, g.ldb, g.N, n0, k0 + XK, kend, tid, rb);
+        }
+#pragma unroll
+        for (int s = 0; s < XK / 16; ++s) {
+            const int o = 2 * s + (lane >> 5), c = lane & 31;
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = __builtin_bit_cast(bf16x8, Ah[o][wm + 32 * i + c]);
+                al[i] = __builtin_bit_cast(bf16x8, Al[o][wm + 32 * i + c]);
+                bh[i] = __builtin_bit_cast(bf16x8, Bh[o][wn + 32 * i + c]);
+                bl[i] = __builtin_bit_cast(bf16x8, Bl[o][wn + 32 * i + c]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -231,8 +355,9 @@ int64_t nm_gemm_workspace_floats(int M, int N, int K) {
     return s > 1 ? (int64_t)s * M * N : 0;
 }
 
-int nm_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                const float* bias, const float* mask, int ldmask, int flags, float* workspace, int64_t workspace_floats, nm_stream_t stream) {
+static int gemm_dispatch(int bf16x3, int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                         int ldc, const float* bias, const float* mask, int ldmask, int flags, float* workspace, int64_t workspace_floats,
+                         nm_stream_t stream) {
     NM_REQUIRE(M >= 0 && N >= 0 && K >= 0, "nm_gemm_f32: negative size");
     if (M == 0 || N == 0) return NM_OK;
     NM_REQUIRE(A && B && C, "nm_gemm_f32: null pointer");
@@ -253,16 +378,23 @@ int nm_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A,
                    (long long)splits * M * N);
         g.partial = workspace;
     }
-    g.k_per_split = ((K + splits - 1) / splits + BK - 1) / BK * BK;
-    if (g.k_per_split < BK) g.k_per_split = BK;
+    g.k_per_split = ((K + splits - 1) / splits + XK - 1) / XK * XK;
+    if (g.k_per_split < XK) g.k_per_split = XK;
     splits = (K + g.k_per_split - 1) / g.k_per_split;
     if (splits < 1) splits = 1;
     const dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits);
-    if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, g);
-    else if (a_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, g);
-    else if (b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, g);
-    if (int rc = nm::check_launch("gemm_f32_kernel")) return rc;
+    if (bf16x3) {
+        if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), grid, dim3(256), 0, st, g);
+        else if (a_kmajor) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), grid, dim3(256), 0, st, g);
+        else if (b_kmajor) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), grid, dim3(256), 0, st, g);
+    } else {
+        if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, g);
+        else if (a_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, g);
+        else if (b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, dim3(256), 0, st, g);
+    }
+    if (int rc = nm::check_launch("gemm kernel")) return rc;
     if (g.partial) {
         const int64_t n = (int64_t)M * N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, splits, M, N, C, ldc,
@@ -270,6 +402,16 @@ int nm_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A,
         return nm::check_launch("splitk_reduce_kernel");
     }
     return NM_OK;
+}
+
+int nm_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                const float* bias, const float* mask, int ldmask, int flags, float* workspace, int64_t workspace_floats, nm_stream_t stream) {
+    return gemm_dispatch(0, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, ldmask, flags, workspace, workspace_floats, stream);
+}
+
+int nm_gemm_bf16x3(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                   const float* bias, const float* mask, int ldmask, int flags, float* workspace, int64_t workspace_floats, nm_stream_t stream) {
+    return gemm_dispatch(1, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, ldmask, flags, workspace, workspace_floats, stream);
 }
 
 int nm_pe_encode(const float* x, int64_t n, int kind, int n_freqs, const float* table, float* out, int ld, nm_stream_t stream) {

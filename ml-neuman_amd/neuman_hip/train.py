@@ -11,18 +11,25 @@ models/vanilla.py:120-152 with the two concatenations (skip connection :130-131,
 products into one output.  Gradients reach the parameters (and flow on through `raw`); gradients with respect to the sample
 positions (pose / offset optimisation of the human trainer) are not implemented and raise.
 """
+import os
+
 import torch
 
 from . import _lib
 
 ACC, BIAS, RELU, MASK = 1, 2, 4, 8                    # NM_GEMM_* (include/neuman_hip.h)
 PE_KINDS = {'posenc': 0, 'rotate': 1}                 # NM_PE_POSENC / NM_PE_ROTATE
+# arithmetic of the matrix products: 'f32' (f32 MFMA: gradients within 1e-6 of the reference's) or 'bf16x3' (split-bf16 x3 on
+# the bf16 MFMA, 2^-18 per product, 1.2x faster per iteration today: its 1e-5 forward error flips a ReLU here and there, so
+# single gradient entries move by ~1e-3 of the tensor's largest -- fine for SGD, not for the parity tests)
+GEMM_PRECISION = os.environ.get('NEUMAN_TRAIN_GEMM', 'f32')
 
 
-def _gemm(a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, bias=None, mask=None, ldmask=0, flags=0, ws=None):
-    _lib.check(_lib.lib().nm_gemm_f32(a_kmajor, b_kmajor, M, N, K, _lib.dev_ptr(A), lda, _lib.dev_ptr(B), ldb, _lib.dev_ptr(C), ldc,
+def _gemm(a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, bias=None, mask=None, ldmask=0, flags=0, ws=None, precision=None):
+    fn = {'f32': _lib.lib().nm_gemm_f32, 'bf16x3': _lib.lib().nm_gemm_bf16x3}[precision or GEMM_PRECISION]
+    _lib.check(fn(a_kmajor, b_kmajor, M, N, K, _lib.dev_ptr(A), lda, _lib.dev_ptr(B), ldb, _lib.dev_ptr(C), ldc,
                                       _lib.dev_ptr(bias), _lib.dev_ptr(mask), ldmask, flags, _lib.dev_ptr(ws), 0 if ws is None else ws.numel(),
-                                      _lib.stream_ptr()), "nm_gemm_f32")
+                                      _lib.stream_ptr()), "nm_gemm")
 
 
 def _pad_cols(w, cols):

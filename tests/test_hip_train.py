@@ -31,7 +31,9 @@ def cu(x):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (4, 4, 4), (260, 132, 36), (1000, 256, 64), (256, 28, 8192), (4, 256, 20000), (512, 512, 4100)])
 @pytest.mark.parametrize("akm,bkm", [(0, 0), (0, 1), (1, 1), (1, 0)])
-def test_gemm_f32(G, M, N, K, akm, bkm):
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_gemm(G, M, N, K, akm, bkm, prec, monkeypatch):
+    monkeypatch.setattr(G.train, "GEMM_PRECISION", prec)
     rng = np.random.default_rng(M * 7 + N * 3 + K + akm * 2 + bkm)
     A = rng.normal(size=(M, K))
     B = rng.normal(size=(K, N))
@@ -45,7 +47,7 @@ def test_gemm_f32(G, M, N, K, akm, bkm):
     G.train._gemm(akm, bkm, M, N, K, a, a.shape[1], b, b.shape[1], C, N + 4, ws=ws)
     out = C.cpu().numpy().astype(np.float64)
     assert (out[:, N:] == 7.0).all()
-    scale = np.sqrt(K)
+    scale = np.sqrt(K) * (1.0 if prec == 'f32' else 10.0)          # bf16x3 drops lo*lo: 2^-18 |a||b| per product
     assert np.abs(out[:, :N] - ref).max() < 3e-6 * scale * 4, np.abs(out[:, :N] - ref).max()
     # accumulate on top
     G.train._gemm(akm, bkm, M, N, K, a, a.shape[1], b, b.shape[1], C, N + 4, flags=G.train.ACC, ws=ws)
@@ -86,7 +88,8 @@ def test_composite_backward(G, tag, white):
 
 
 @pytest.mark.parametrize("tag,white,penalty", [("white", True, 0.0), ("black_penalty", False, 0.1)])
-def test_training_step_matches_reference(G, tag, white, penalty):
+def test_training_step_matches_reference(G, tag, white, penalty, monkeypatch):
+    monkeypatch.setattr(G.train, "GEMM_PRECISION", "f32")
     """the lines of NeRFTrainer.loss_func (vanilla_nerf_trainer.py:66-95) on the HIP modules, at the reference's sample depths"""
     g = G.g
     o, d, color, depth = cu(g['origin']), cu(g['direction']), cu(g['color']), cu(g['depth'])
@@ -121,7 +124,9 @@ def test_training_step_matches_reference(G, tag, white, penalty):
         assert worst_o < 1e-4
 
 
-def test_a_few_sgd_steps_reduce_the_loss(G):
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_a_few_sgd_steps_reduce_the_loss(G, prec, monkeypatch):
+    monkeypatch.setattr(G.train, "GEMM_PRECISION", prec)
     """end to end: Adam on the HIP forward/backward drives the reference's loss down on a fixed batch"""
     g = G.g
     o, d, color = cu(g['origin']), cu(g['direction']), cu(g['color'])
