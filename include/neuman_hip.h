@@ -304,6 +304,9 @@ int nm_gemm_bf16x3(int a_kmajor, int b_kmajor, int M, int N, int K, const float*
                    int64_t workspace_floats, nm_stream_t stream);
 int nm_pe_encode(const float* x, int64_t n, int kind, int n_freqs, const float* table, float* out, int ld,
                  nm_stream_t stream);
+/* adjoint of nm_pe_encode: g [n,ld] = gradient of the encoded features -> dx [n,3] */
+int nm_pe_backward(const float* x, int64_t n, int kind, int n_freqs, const float* table, const float* g, int ld, float* dx,
+                   nm_stream_t stream);
 int nm_composite_backward(const float* raw, const float* z_vals, const float* rays_d, int64_t R, int S, int white_bkg,
                           const float* g_rgb, const float* g_acc, const float* g_depth, const float* g_weights,
                           float* d_raw, nm_stream_t stream);

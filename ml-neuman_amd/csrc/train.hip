@@ -299,6 +299,36 @@ __global__ __launch_bounds__(256) void pe_encode_kernel(const float* __restrict_
     out[i] = v;
 }
 
+// adjoint of pe_encode_kernel: dx [n,3] from the gradient g [n,ld] of the encoded features, one thread per row
+__global__ __launch_bounds__(256) void pe_backward_kernel(const float* __restrict__ x, int64_t n, int kind, int nfreq, const float* __restrict__ tab,
+                                                          const float* __restrict__ g, int ld, float* __restrict__ dx) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const float xv[3] = {x[r * 3], x[r * 3 + 1], x[r * 3 + 2]};
+    const float* gr = g + r * ld;
+    float d[3] = {gr[0], gr[1], gr[2]};
+    if (kind == NM_PE_POSENC) {
+        for (int b = 0; b < nfreq; ++b) {
+            const float f = tab[b];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float a = xv[k] * f;
+                d[k] += f * (gr[3 + 6 * b + k] * cosf(a) - gr[3 + 6 * b + 3 + k] * sinf(a));
+            }
+        }
+    } else {
+        const int n3 = 3 * nfreq;
+        for (int m = 0; m < n3; ++m) {
+            const float* b = tab + 3 * m;
+            const float a = fmaf(xv[2], b[2], fmaf(xv[1], b[1], xv[0] * b[0]));
+            const float t = gr[3 + m] * cosf(a) - gr[3 + n3 + m] * sinf(a);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) d[k] += b[k] * t;
+        }
+    }
+    dx[r * 3] = d[0]; dx[r * 3 + 1] = d[1]; dx[r * 3 + 2] = d[2];
+}
+
 // d loss / d raw through raw2outputs, one thread per ray; the transmittance scan and its adjoint run in f64.
 //   w_i = a_i T_i, T_i = prod_{j<i} u_j, u_j = 1 - a_j + 1e-10, a_i = 1 - exp(-relu(sigma_i) dist_i)
 //   G_i = dL/dw_i = g_rgb . c_i + g_acc' + g_depth z_i + g_w_i      (white background: g_acc' = g_acc - sum_k g_rgb_k)
@@ -422,6 +452,15 @@ int nm_pe_encode(const float* x, int64_t n, int kind, int n_freqs, const float* 
     const int64_t total = n * ld;
     hipLaunchKernelGGL(pe_encode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nm::as_stream(stream), x, n, kind, n_freqs, table, out, ld);
     return nm::check_launch("pe_encode_kernel");
+}
+
+int nm_pe_backward(const float* x, int64_t n, int kind, int n_freqs, const float* table, const float* g, int ld, float* dx, nm_stream_t stream) {
+    NM_REQUIRE(n >= 0 && n_freqs >= 0 && ld >= 3 + 6 * n_freqs, "nm_pe_backward: bad sizes n=%lld n_freqs=%d ld=%d", (long long)n, n_freqs, ld);
+    NM_REQUIRE(kind == NM_PE_POSENC || kind == NM_PE_ROTATE, "nm_pe_backward: mapping %d", kind);
+    if (n == 0) return NM_OK;
+    NM_REQUIRE(x && g && dx && (table || n_freqs == 0), "nm_pe_backward: null pointer");
+    hipLaunchKernelGGL(pe_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nm::as_stream(stream), x, n, kind, n_freqs, table, g, ld, dx);
+    return nm::check_launch("pe_backward_kernel");
 }
 
 int nm_composite_backward(const float* raw, const float* z_vals, const float* rays_d, int64_t R, int S, int white_bkg, const float* g_rgb,

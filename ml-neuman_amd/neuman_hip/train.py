@@ -8,8 +8,8 @@ reference's training loss (trainers/vanilla_nerf_trainer.py:45-96) runs through 
 Every matrix product is `nm_gemm_f32` (float32 MFMA, csrc/train.hip), the encodings `nm_pe_encode`, the compositing adjoint
 `nm_composite_backward`; torch supplies memory and the autograd graph.  The layer loop below is the reference's
 models/vanilla.py:120-152 with the two concatenations (skip connection :130-131, views layer :139-140) written as two
-products into one output.  Gradients reach the parameters (and flow on through `raw`); gradients with respect to the sample
-positions (pose / offset optimisation of the human trainer) are not implemented and raise.
+products into one output.  Gradients reach the parameters and, when asked for, the sample positions and view directions
+(what the human trainer's pose / offset optimisation differentiates; the warp and offset nets upstream of them are not built).
 """
 import os
 
@@ -110,13 +110,13 @@ class _MLP(torch.autograd.Function):
         _gemm(0, 0, n4, half, pk.kd, D0, pk.kd, pk.Wv[1], pk.kd, hv, half, bias=pk.bv, flags=ACC | BIAS | RELU)
         _gemm(0, 0, n4, 4, half, hv, half, pk.Wr4, half, raw, 4, flags=ACC)                               # + rgb
         ctx.pk, ctx.X0, ctx.D0, ctx.H, ctx.feat, ctx.hv, ctx.n, ctx.nerf = pk, X0, D0, H, feat, hv, n, nerf
+        ctx.p4, ctx.d4, ctx.pe = p4, d4, (joiner.pos_pe, joiner.dir_pe)
         return raw[:n]
 
     @staticmethod
     def backward(ctx, g_raw):
         pk, X0, D0, H, feat, hv, n, nerf = ctx.pk, ctx.X0, ctx.D0, ctx.H, ctx.feat, ctx.hv, ctx.n, ctx.nerf
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            raise _lib.NeumanHipError("gradients with respect to sample positions / directions are not implemented (SURVEY 8f-1, human trainer)")
+        want_in = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dev = X0.device
         n4, width, half = X0.shape[0], nerf.width, nerf.width // 2
         d_raw = torch.zeros((n4, 4), device=dev, dtype=torch.float32)
@@ -149,6 +149,10 @@ class _MLP(torch.autograd.Function):
         _gemm(0, 1, n4, half, 4, d_raw, 4, pk.Wr4, half, d_hv, half, mask=hv, ldmask=half, flags=MASK)
         g['views_w'] = torch.cat([wgrad(d_hv, half, feat, width), wgrad(d_hv, half, D0, pk.kd)[:, :pk.n_dir]], 1)
         g['views_b'] = bgrad(d_hv, half)
+        dX0 = dD0 = None
+        if want_in:                                                              # gradient of the encoded view direction
+            dD0 = torch.empty((n4, pk.kd), device=dev, dtype=torch.float32)
+            _gemm(0, 1, n4, pk.kd, half, d_hv, half, pk.Wv[1], pk.kd, dD0, pk.kd)
         d_feat = torch.empty((n4, width), device=dev, dtype=torch.float32)
         _gemm(0, 1, n4, width, half, d_hv, half, pk.Wv[0], width, d_feat, width)
         g['feature_w'], g['feature_b'] = wgrad(d_feat, width, h7, width), bgrad(d_feat, width)
@@ -160,6 +164,11 @@ class _MLP(torch.autograd.Function):
         for i in range(len(pk.W) - 1, -1, -1):
             Ws = pk.W[i]
             gb[i] = bgrad(dz, width)
+            if want_in and (i == 0 or len(Ws) == 2):                             # gradient of the encoded position: both layers it feeds
+                first = dX0 is None
+                if first:
+                    dX0 = torch.empty((n4, pk.kp), device=dev, dtype=torch.float32)
+                _gemm(0, 1, n4, pk.kp, width, dz, width, Ws[0], pk.kp, dX0, pk.kp, flags=0 if first else ACC)
             if i == 0:
                 gw[i] = wgrad(dz, width, X0, pk.kp)[:, :pk.n_pos]
                 break
@@ -178,7 +187,17 @@ class _MLP(torch.autograd.Function):
             grads += [gw[i].contiguous(), gb[i].contiguous()]
         grads += [g['views_w'].contiguous(), g['views_b'].contiguous(), g['feature_w'], g['feature_b'].contiguous(),
                   g['alpha_w'].contiguous(), g['alpha_b'].contiguous(), g['rgb_w'].contiguous(), g['rgb_b'].contiguous()]
-        return (None, None, None) + tuple(grads)
+        d_pts = d_dirs = None
+        if want_in:
+            res = []
+            for emb, x, gx in ((ctx.pe[0], ctx.p4, dX0), (ctx.pe[1], ctx.d4, dD0)):
+                tab = torch.from_numpy(emb.table()).to(dev).contiguous()
+                dx = torch.empty((n4, 3), device=dev, dtype=torch.float32)
+                _lib.check(_lib.lib().nm_pe_backward(_lib.dev_ptr(x), n4, PE_KINDS[emb.mapping], emb.N_freqs, _lib.dev_ptr(tab), _lib.dev_ptr(gx),
+                                                     gx.shape[1], _lib.dev_ptr(dx), _lib.stream_ptr()), "nm_pe_backward")
+                res.append(dx[:n])
+            d_pts, d_dirs = res
+        return (None, d_pts, d_dirs) + tuple(grads)
 
 
 def mlp_forward_train(joiner, pts, dirs):

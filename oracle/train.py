@@ -25,9 +25,18 @@ def posenc(x, n_freqs, min_freq=0, max_freq=None):
     return torch.cat(out, -1)
 
 
-def joiner_forward(W, pts, dirs, pos_freqs=10, dir_freqs=4, depth=8, skips=(4,)):
+def rotenc(x, n_freqs, min_freq=0, max_freq=None):
+    """models/vanilla.py:83-89: [x, sin(x B^T), cos(x B^T)], B from :44-55 (float32 values)"""
+    from .nerf_mlp import rotate_bvals
+    B = torch.tensor(rotate_bvals(min_freq, n_freqs - 1 if max_freq is None else max_freq, n_freqs), dtype=F64)
+    proj = x @ B.T
+    return torch.cat([x, torch.sin(proj), torch.cos(proj)], -1)
+
+
+def joiner_forward(W, pts, dirs, pos_freqs=10, dir_freqs=4, depth=8, skips=(4,), mapping='posenc'):
     """W: {state_dict name: float64 tensor requiring grad}; pts, dirs [...,3] float64 -> raw [...,4]."""
-    x_pe, d_pe = posenc(pts, pos_freqs), posenc(dirs, dir_freqs)
+    enc = rotenc if mapping == 'rotate' else posenc
+    x_pe, d_pe = enc(pts, pos_freqs), enc(dirs, dir_freqs)
     h = x_pe
     for i in range(depth):
         h = torch.relu(h @ W[f'nerf.pts_linears.{i}.weight'].T + W[f'nerf.pts_linears.{i}.bias'])
@@ -74,6 +83,16 @@ def training_pass(weights, origin, direction, z_vals, color, white_bkg=True, pen
     n = lambda t: t.detach().numpy()
     return dict(raw=n(raw), rgb_map=n(rgb_map), acc_map=n(acc), weights=n(wts), depth_map=n(dep), loss_rgb=float(loss_rgb.detach()),
                 loss_empty=float(loss_empty.detach()), d_raw=n(raw.grad), grads={k: n(v.grad) for k, v in W.items()})
+
+
+def input_gradients(weights, pts, dirs, g_out, mapping='posenc'):
+    """d (sum of g_out . net(pts, dirs)) / d pts, d dirs -> (out, d_pts, d_dirs), float64"""
+    W = {k: torch.tensor(np.asarray(v), dtype=F64) for k, v in weights.items()}
+    p = torch.tensor(np.asarray(pts), dtype=F64, requires_grad=True)
+    d = torch.tensor(np.asarray(dirs), dtype=F64, requires_grad=True)
+    out = joiner_forward(W, p, d, mapping=mapping)
+    (out * torch.tensor(np.asarray(g_out), dtype=F64)).sum().backward()
+    return out.detach().numpy(), p.grad.numpy(), d.grad.numpy()
 
 
 def composite_backward(raw, z_vals, rays_d, white_bkg, g_rgb, g_acc, g_depth, g_w):

@@ -105,6 +105,23 @@ def main():
         ((rgb * torch.from_numpy(g_rgb)).sum() + (acc * torch.from_numpy(g_acc)).sum() + (dep * torch.from_numpy(g_depth)).sum() +
          (wts * torch.from_numpy(g_w)).sum()).backward()
         out[f'c/{tag}/d_raw'] = raw.grad.numpy().copy()
+    # gradients with respect to the sample positions and view directions (what pose / offset optimisation differentiates):
+    # d (sum of g . net(pts, dirs)) / d pts, d dirs, for both encodings
+    for mapping in ('posenc', 'rotate'):
+        ours = synthetic.make_joiner(2, mapping)
+        net, _ = R_vanilla.build_nerf(synthetic.default_opt(posenc=mapping))
+        net.load_state_dict(ours.state_dict(), strict=True)
+        if mapping == 'rotate':
+            net.pos_pe.bvals = net.pos_pe.bvals.cpu()
+            net.dir_pe.bvals = net.dir_pe.bvals.cpu()
+        pts = torch.from_numpy(rng.uniform(-1.2, 1.2, size=(96, 3)).astype(np.float32)).requires_grad_(True)
+        dirs = rng.normal(size=(96, 3)).astype(np.float32)
+        dirs = torch.from_numpy(dirs / np.linalg.norm(dirs, axis=1, keepdims=True)).requires_grad_(True)
+        gout = torch.from_numpy(rng.normal(size=(96, 4)).astype(np.float32))
+        o = net(pts, dirs)
+        (o * gout).sum().backward()
+        out.update({f'in/{mapping}/pts': pts.detach().numpy(), f'in/{mapping}/dirs': dirs.detach().numpy(), f'in/{mapping}/g_out': gout.numpy(),
+                    f'in/{mapping}/out': o.detach().numpy(), f'in/{mapping}/d_pts': pts.grad.numpy(), f'in/{mapping}/d_dirs': dirs.grad.numpy()})
     np.savez_compressed(os.path.join(HERE, 'train.npz'), **out)
     print({k: out[k] for k in out if k.endswith('losses')})
     print(len(out), "arrays,", os.path.getsize(os.path.join(HERE, 'train.npz')), "bytes")

@@ -48,6 +48,15 @@ def test_training_pass_matches_reference(G, tag, white, penalty):
         print(f"[oracle train] {p}: loss {r['loss_rgb']:.6f} + {r['loss_empty']:.6f}, worst relative gradient error {worst:.2e}")
 
 
+@pytest.mark.parametrize("mapping", ["posenc", "rotate"])
+def test_input_gradients_match_reference(G, mapping):
+    w = synthetic.state_numpy(synthetic.make_joiner(2, mapping))
+    out, dp, dd = OT.input_gradients(w, G[f'in/{mapping}/pts'], G[f'in/{mapping}/dirs'], G[f'in/{mapping}/g_out'], mapping)
+    assert np.abs(out - G[f'in/{mapping}/out']).max() < 2e-4 * np.abs(G[f'in/{mapping}/out']).max()
+    for mine, ref in ((dp, G[f'in/{mapping}/d_pts']), (dd, G[f'in/{mapping}/d_dirs'])):
+        assert np.abs(mine - ref).max() < 2e-4 * np.abs(ref).max(), np.abs(mine - ref).max() / np.abs(ref).max()
+
+
 @pytest.mark.parametrize("tag,white", [("white", True), ("black", False)])
 def test_composite_backward_matches_reference(G, tag, white):
     d = OT.composite_backward(G['c/raw'], G['c/z'], G['c/d'], white, G['c/g_rgb'], G['c/g_acc'], G['c/g_depth'], G['c/g_w'])
