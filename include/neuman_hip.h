@@ -304,6 +304,9 @@ int nm_gemm_bf16x3(int a_kmajor, int b_kmajor, int M, int N, int K, const float*
                    int64_t workspace_floats, nm_stream_t stream);
 int nm_pe_encode(const float* x, int64_t n, int kind, int n_freqs, const float* table, float* out, int ld,
                  nm_stream_t stream);
+/* out[W] = column sums of X [n,W] (row stride ld): the bias gradients; bands of 256 rows summed in order (deterministic) */
+int64_t nm_colsum_workspace_floats(int64_t n, int W);
+int nm_colsum(const float* X, int64_t n, int W, int ld, float* out, float* workspace, int64_t workspace_floats, nm_stream_t stream);
 /* adjoint of nm_pe_encode: g [n,ld] = gradient of the encoded features -> dx [n,3] */
 int nm_pe_backward(const float* x, int64_t n, int kind, int n_freqs, const float* table, const float* g, int ld, float* dx,
                    nm_stream_t stream);

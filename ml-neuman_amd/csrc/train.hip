@@ -262,6 +262,33 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     *c = accumulate ? *c + s : s;
 }
 
+// column sums of X [n, W] (bias gradients): each workgroup sums a band of kColsumRows rows, one column per thread (coalesced
+// along the row); a second kernel adds the bands
+constexpr int kColsumRows = 256;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, int64_t n, int W, int ld, float* __restrict__ partial) {
+    const int64_t r0 = (int64_t)blockIdx.x * kColsumRows;
+    const int64_t r1 = r0 + kColsumRows < n ? r0 + kColsumRows : n;
+    for (int c = threadIdx.x; c < W; c += blockDim.x) {
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};          // eight loads in flight
+        int64_t r = r0;
+        for (; r + 8 <= r1; r += 8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += X[(r + j) * ld + c];
+        for (; r < r1; ++r) s[0] += X[r * ld + c];
+        partial[(int64_t)blockIdx.x * W + c] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    }
+}
+
+// second stage: one wave per column adds the bands (lane-strided partial sums in band order, then a butterfly)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int bands, int W, float* __restrict__ out) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= W) return;
+    float s = 0.f;
+    for (int b = lane; b < bands; b += 64) s += partial[(int64_t)b * W + c];
+    s = wave_sum(s);
+    if (lane == 0) out[c] = s;
+}
+
 int pick_splits(int M, int N, int K) {
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     if (tiles >= 256 || K < 4096) return 1;
@@ -442,6 +469,22 @@ int nm_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A,
 int nm_gemm_bf16x3(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                    const float* bias, const float* mask, int ldmask, int flags, float* workspace, int64_t workspace_floats, nm_stream_t stream) {
     return gemm_dispatch(1, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, ldmask, flags, workspace, workspace_floats, stream);
+}
+
+int64_t nm_colsum_workspace_floats(int64_t n, int W) { return ((n + kColsumRows - 1) / kColsumRows) * W; }
+
+int nm_colsum(const float* X, int64_t n, int W, int ld, float* out, float* workspace, int64_t workspace_floats, nm_stream_t stream) {
+    NM_REQUIRE(n >= 0 && W >= 1 && ld >= W, "nm_colsum: bad sizes n=%lld W=%d ld=%d", (long long)n, W, ld);
+    NM_REQUIRE(out && (n == 0 || X), "nm_colsum: null pointer");
+    hipStream_t st = nm::as_stream(stream);
+    if (n == 0) return nm::check_hip(hipMemsetAsync(out, 0, (size_t)W * 4, st), "nm_colsum: memset");
+    const int bands = (int)((n + kColsumRows - 1) / kColsumRows);
+    NM_REQUIRE(workspace && workspace_floats >= (int64_t)bands * W, "nm_colsum: needs %lld floats of workspace (nm_colsum_workspace_floats)",
+               (long long)bands * W);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(bands), dim3(256), 0, st, X, n, W, ld, workspace);
+    if (int rc = nm::check_launch("colsum_partial_kernel")) return rc;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((W + 3) / 4), dim3(256), 0, st, workspace, bands, W, out);
+    return nm::check_launch("colsum_final_kernel");
 }
 
 int nm_pe_encode(const float* x, int64_t n, int kind, int n_freqs, const float* table, float* out, int ld, nm_stream_t stream) {

@@ -121,8 +121,6 @@ class _MLP(torch.autograd.Function):
         n4, width, half = X0.shape[0], nerf.width, nerf.width // 2
         d_raw = torch.zeros((n4, 4), device=dev, dtype=torch.float32)
         d_raw[:n] = g_raw
-        ones = torch.zeros((n4, 4), device=dev, dtype=torch.float32)
-        ones[:n] = 1.0
         ws = [torch.empty(4, device=dev, dtype=torch.float32)]
 
         def workspace(m, k):                                                     # split-K partials, grown to the largest product
@@ -136,10 +134,14 @@ class _MLP(torch.autograd.Function):
             _gemm(1, 1, m, k, n4, dz, dz.shape[1], a, a.shape[1], out, k, ws=workspace(m, k))
             return out
 
-        def bgrad(dz, m):                                                        # column sums, as ones^T dz
-            out = torch.empty((4, m), device=dev, dtype=torch.float32)
-            _gemm(1, 1, 4, m, n4, ones, 4, dz, dz.shape[1], out, m, ws=workspace(4, m))
-            return out[0]
+        def bgrad(dz, m):                                                        # db = column sums of dz (pad rows are zero)
+            out = torch.empty(m, device=dev, dtype=torch.float32)
+            need = int(_lib.lib().nm_colsum_workspace_floats(n4, m))
+            if need > ws[0].numel():
+                ws[0] = torch.empty(need, device=dev, dtype=torch.float32)
+            _lib.check(_lib.lib().nm_colsum(_lib.dev_ptr(dz), n4, m, dz.shape[1], _lib.dev_ptr(out), _lib.dev_ptr(ws[0]), ws[0].numel(),
+                                            _lib.stream_ptr()), "nm_colsum")
+            return out
 
         g = {}
         h7 = H[-1]
