@@ -194,6 +194,12 @@ int nm_mesh_destroy(nm_mesh_t mesh);
 int nm_mesh_info(nm_mesh_t mesh, int32_t* levels, int64_t* nodes, int64_t* bytes);
 int nm_warp_to_canonical(nm_mesh_t mesh, const float* pts, int64_t R, int S, const double* T, float* can_pts,
                          float* can_dirs, float* closest, nm_stream_t stream);
+/* igl.signed_distance(P, V, F) -- reference utils/ray_utils.py:70, trainers/human_nerf_trainer.py:310, 326: for pts [N,3]
+ * the distance to the mesh signed by the angle-weighted pseudonormal of the closest feature (negative inside a closed,
+ * outward-oriented mesh), the closest face (the caller's id; lowest id on ties) and the closest point.  The pseudonormal
+ * table is built by the first call on a mesh (synchronises once). */
+int nm_signed_distance(nm_mesh_t mesh, const float* pts, int64_t N, float* sdist, int32_t* face, float* closest,
+                       nm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a12  SMPL linear blend skinning, batched over frames -- reference models/smpl.py:266-360 (lbs),

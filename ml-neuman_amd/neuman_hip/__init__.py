@@ -17,7 +17,7 @@ __all__ = ["ray_utils", "render_utils", "vanilla", "smpl", "parallel", "syntheti
 
 _RAY_FNS = ["shot_ray", "shot_rays", "shot_all_rays", "to_homogeneous", "ray_to_samples", "ray_to_importance_samples",
             "sample_pdf", "geometry_guided_near_far", "geometry_guided_near_far_torch", "geometry_guided_near_far_np",
-            "warp_samples_to_canonical",
+            "warp_samples_to_canonical", "warp_samples_to_canonical_diff",
             "shot_all_rays_dev", "shot_rays_dev"]                      # additions: a1 on the device (CUDA tensors out)
 _RENDER_FNS = ["raw2outputs", "render_vanilla", "render_smpl_nerf", "render_hybrid_nerf", "render_hybrid_nerf_multi_persons",
                "frame_to_uint8", "psnr_uint8"]                        # additions: the egress of render_test_views.py:83-92, on the device

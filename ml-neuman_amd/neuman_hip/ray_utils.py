@@ -322,3 +322,58 @@ def warp_samples_to_canonical(pts, verts, faces, T):
     if as_numpy:
         return can_pts.cpu().numpy(), can_dirs.cpu().numpy(), closest.cpu().numpy()
     return can_pts, can_dirs, closest
+
+
+# ------------------------------------------------------------------------------------------------
+# signed distance + the differentiable warp of the human trainer
+# ------------------------------------------------------------------------------------------------
+def signed_distance_dev(pts, mesh):
+    """pts [N,3] f32 CUDA, mesh = Mesh -> (signed distance [N] f32, face id [N] int32, closest point [N,3] f32), CUDA tensors."""
+    _lib.require_gpu()
+    p = _f32c(pts.reshape(-1, 3))
+    N = p.shape[0]
+    s = torch.empty(N, device=p.device, dtype=torch.float32)
+    f = torch.empty(N, device=p.device, dtype=torch.int32)
+    c = torch.empty((N, 3), device=p.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nm_signed_distance(mesh.handle, _lib.dev_ptr(p), N, _lib.dev_ptr(s), _lib.dev_ptr(f, torch.int32), _lib.dev_ptr(c),
+                                             _lib.stream_ptr()), "nm_signed_distance")
+    return s, f, c
+
+
+def signed_distance(pts, verts, faces):
+    """igl.signed_distance(P, V, F) as the reference calls it (ray_utils.py:70, human_nerf_trainer.py:310): numpy in ->
+    (S [N], I [N], C [N,3]) numpy out, pseudonormal sign (negative inside)."""
+    dev = torch.device('cuda')
+    v = torch.as_tensor(np.ascontiguousarray(verts, dtype=np.float32))
+    T = torch.zeros((v.shape[0], 16), dtype=torch.float64)                                  # the search needs no transforms
+    s, f, c = signed_distance_dev(torch.as_tensor(np.ascontiguousarray(pts, dtype=np.float32)).to(dev), Mesh(v, faces, T, dev))
+    return s.cpu().numpy(), f.cpu().numpy(), c.cpu().numpy()
+
+
+def warp_samples_to_canonical_diff(pts, verts, faces, T):
+    """reference ray_utils.py:69-93: pts [N,3] numpy (detached), verts [V,3] / T [V,4,4] torch tensors that may require grad
+    -> (T_interp_inv [N,4,4], f_id, signed_dist).  The closest-point query and its sign run in libneuman_hip; the barycentric
+    blend and the 4x4 inverse are the reference's own differentiable torch lines, on the device."""
+    dev = verts.device if isinstance(verts, torch.Tensor) and verts.is_cuda else torch.device('cuda')
+    verts = verts.to(dev)
+    T = T.to(dev)
+    f3 = torch.as_tensor(np.ascontiguousarray(np.asarray(faces)[:, :3]).astype(np.int64)).to(dev)
+    p = torch.as_tensor(np.ascontiguousarray(pts, dtype=np.float32)).to(dev)
+    mesh = Mesh(verts.detach(), f3.to(torch.int32), torch.zeros((verts.shape[0], 16), dtype=torch.float64), dev)
+    signed_dist, f_id, closest = signed_distance_dev(p, mesh)
+    f_id = f_id.long()
+    closest_tri = verts[f3[f_id]]
+    v0v1 = closest_tri[:, 1] - closest_tri[:, 0]
+    v0v2 = closest_tri[:, 2] - closest_tri[:, 0]
+    v1v2 = closest_tri[:, 2] - closest_tri[:, 1]
+    v2v0 = closest_tri[:, 0] - closest_tri[:, 2]
+    v1p = closest - closest_tri[:, 1]
+    v2p = closest - closest_tri[:, 2]
+    N = torch.cross(v0v1, v0v2, dim=1)
+    denom = (N * N).sum(1)
+    u = (N * torch.cross(v1v2, v1p, dim=1)).sum(1) / denom
+    v = (N * torch.cross(v2v0, v2p, dim=1)).sum(1) / denom
+    w = 1 - u - v
+    barycentric = torch.stack([u, v, w], dim=1)
+    T_interp = (T[f3[f_id]] * barycentric[..., None, None]).sum(axis=1)
+    return torch.inverse(T_interp), f_id.cpu().numpy(), signed_dist.cpu().numpy()

@@ -121,3 +121,80 @@ def warp_samples_to_canonical(pts, verts, faces, T):
     can_dirs = np.concatenate([can_dirs, can_dirs[:, -1:]], axis=1)
     can_dirs = can_dirs / np.linalg.norm(can_dirs, axis=2, keepdims=True)
     return can_pts, can_dirs, closest
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# signed distance (reference: igl.signed_distance at utils/ray_utils.py:70, trainers/human_nerf_trainer.py:310, 326) --
+# **parity unpinned** like the rest of this file (libigl absent).  libigl's default sign for a 3-D triangle mesh is the
+# angle-weighted pseudonormal test (Baerentzen & Aanaes 2005): the sign of (p - q) . n(q), n the face normal in the
+# triangle's interior, the sum of the two unit face normals on an edge, the incident-angle-weighted sum of unit face normals
+# at a vertex.  For a closed, consistently oriented mesh that sign is the inside / outside of the solid; `winding_number`
+# below computes the latter independently (van Oosterom & Strackee solid angles) and the tests compare the two.
+# ---------------------------------------------------------------------------------------------------------------------
+def _unit(x):
+    return x / np.maximum(np.linalg.norm(x, axis=-1, keepdims=True), 1e-300)
+
+
+def pseudonormals(verts, faces):
+    """-> face normals [F,3], vertex pseudonormals [V,3], edge pseudonormals [F,3,3] (edge e of face f joins its
+    vertices e and (e+1)%3), float64, unnormalised sums of UNIT face normals."""
+    v = verts.astype(np.float64)
+    f = faces[:, :3].astype(np.int64)
+    a, b, c = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    fn = _unit(np.cross(b - a, c - a))
+    vn = np.zeros_like(v)
+    corners = [(a, b, c), (b, c, a), (c, a, b)]
+    for k, (p0, p1, p2) in enumerate(corners):
+        e1, e2 = _unit(p1 - p0), _unit(p2 - p0)
+        ang = np.arccos(np.clip(_dot(e1, e2), -1.0, 1.0))
+        np.add.at(vn, f[:, k], fn * ang[:, None])
+    edge = {}
+    for i in range(f.shape[0]):
+        for e in range(3):
+            key = (min(f[i, e], f[i, (e + 1) % 3]), max(f[i, e], f[i, (e + 1) % 3]))
+            edge.setdefault(key, []).append(i)
+    en = np.zeros((f.shape[0], 3, 3))
+    for i in range(f.shape[0]):
+        for e in range(3):
+            key = (min(f[i, e], f[i, (e + 1) % 3]), max(f[i, e], f[i, (e + 1) % 3]))
+            en[i, e] = fn[edge[key]].sum(0)
+    return fn, vn, en
+
+
+def signed_distance(pts, verts, faces):
+    """igl.signed_distance(P, V, F) -> (S [N], face id [N], closest [N,3]) with the pseudonormal sign."""
+    sqr, fid, q = closest_point_on_mesh(pts, verts, faces)
+    v = verts.astype(np.float64)
+    f = faces[:, :3].astype(np.int64)
+    fn, vn, en = pseudonormals(verts, faces)
+    tri = v[f[fid]]                                                      # [N,3,3]
+    # which feature of the winning triangle holds q: barycentrics of q (exact up to rounding: q was built from them)
+    bary = barycentric_coordinates_tri(q, tri[:, 0], tri[:, 1], tri[:, 2])
+    on = bary > 1e-9                                                     # vertices with weight
+    n = np.empty_like(q)
+    for i in range(q.shape[0]):
+        k = np.flatnonzero(on[i])
+        if len(k) == 1:
+            n[i] = vn[f[fid[i], k[0]]]
+        elif len(k) == 2:
+            e = {(0, 1): 0, (1, 2): 1, (0, 2): 2}[tuple(k)]
+            n[i] = en[fid[i], e]
+        else:
+            n[i] = fn[fid[i]]
+    d = pts.astype(np.float64) - q
+    sign = np.where(_dot(d, n) < 0, -1.0, 1.0)
+    return sign * np.sqrt(sqr), fid, q
+
+
+def winding_number(pts, verts, faces):
+    """generalised winding number of a closed oriented mesh at each point (1 inside, 0 outside), float64"""
+    v = verts.astype(np.float64)
+    f = faces[:, :3].astype(np.int64)
+    out = np.zeros(pts.shape[0])
+    for i, p in enumerate(pts.astype(np.float64)):
+        a, b, c = v[f[:, 0]] - p, v[f[:, 1]] - p, v[f[:, 2]] - p
+        la, lb, lc = (np.linalg.norm(x, axis=1) for x in (a, b, c))
+        num = _dot(a, np.cross(b, c))
+        den = la * lb * lc + _dot(a, b) * lc + _dot(b, c) * la + _dot(c, a) * lb
+        out[i] = np.sum(2.0 * np.arctan2(num, den)) / (4.0 * np.pi)
+    return out

@@ -322,3 +322,48 @@ def test_tree_search_is_bit_identical_to_all_triangles(G, case):
     _, _, ocl = OW.closest_point_on_mesh(pts[fin][:2000], posed, faces)
     dist = np.linalg.norm(cl[:2000] - pts[fin][:2000], axis=-1)
     np.testing.assert_allclose(dist, np.linalg.norm(ocl - pts[fin][:2000], axis=-1), atol=2e-5 * (1 + np.abs(posed).max()), rtol=1e-5)
+
+
+@pytest.mark.parametrize("case", ["smpl_size", "small"])
+def test_signed_distance(G, case):
+    """nm_signed_distance vs the oracle's pseudonormal sign and, independently, the winding number of the closed mesh"""
+    rng = np.random.default_rng(3)
+    verts_c, faces = G.syn.capsule_mesh() if case == "smpl_size" else G.syn.capsule_mesh(n_rings=10, n_seg=12)
+    posed, T = G.syn.twist_transforms(np.asarray(verts_c, np.float32))
+    faces = np.ascontiguousarray(np.asarray(faces)[:, :3], np.int32)
+    n = 600 if case == "smpl_size" else 3000
+    pts = (posed[rng.integers(0, len(posed), n)] + rng.normal(size=(n, 3)) * rng.choice([0.003, 0.03, 0.2], size=(n, 1))).astype(np.float32)
+    S, I, C = G.ray.signed_distance(pts, posed, faces)
+    assert S.shape == (n,) and I.shape == (n,) and C.shape == (n, 3)
+    wn = OW.winding_number(pts, posed, faces)
+    sure = np.abs(S) > 1e-5                                            # a point within rounding of the surface has no defined side
+    assert ((S < 0) == (wn > 0.5))[sure].all(), f"{(((S < 0) != (wn > 0.5)) & sure).sum()} wrong signs"
+    print(f"[sdf] {case}: {n} queries, {(S < 0).mean():.2f} inside, signs agree with the winding number on all {sure.sum()} off-surface points")
+    m = min(n, 400)
+    oS, oI, oC = OW.signed_distance(pts[:m], posed, faces)
+    np.testing.assert_allclose(np.abs(S[:m]), np.abs(oS), atol=2e-6)
+    assert (np.sign(S[:m]) == np.sign(oS))[np.abs(oS) > 1e-5].all()
+    np.testing.assert_allclose(np.linalg.norm(C[:m] - pts[:m], axis=1), np.abs(oS), atol=2e-6)
+    # the returned face does contain the closest point
+    tri = posed[faces[I[:m]]]
+    bary = OW.barycentric_coordinates_tri(C[:m].astype(np.float64), tri[:, 0].astype(np.float64), tri[:, 1].astype(np.float64), tri[:, 2].astype(np.float64))
+    assert (bary > -1e-4).all()
+
+
+def test_warp_samples_to_canonical_diff(G):
+    """reference ray_utils.py:69-93 on the device: T_interp_inv maps a posed surface point back to canonical space, and
+    gradients reach verts and T"""
+    verts_c, faces = G.syn.capsule_mesh(n_rings=10, n_seg=12)
+    posed, T = G.syn.twist_transforms(np.asarray(verts_c, np.float32))
+    faces = np.ascontiguousarray(np.asarray(faces)[:, :3], np.int32)
+    rng = np.random.default_rng(5)
+    idx = rng.integers(0, len(posed), 64)
+    pts = posed[idx].astype(np.float32)
+    verts_t = torch.tensor(posed, device='cuda', requires_grad=True)
+    T_t = torch.tensor(T, device='cuda', dtype=torch.float32, requires_grad=True)
+    Ti, f_id, sd = G.ray.warp_samples_to_canonical_diff(pts, verts_t, faces, T_t)
+    assert Ti.shape == (64, 4, 4) and f_id.shape == (64,) and sd.shape == (64,)
+    can = (Ti @ torch.cat([torch.tensor(pts, device='cuda'), torch.ones((64, 1), device='cuda')], 1)[..., None])[:, :3, 0]
+    np.testing.assert_allclose(can.detach().cpu().numpy(), np.asarray(verts_c, np.float32)[idx], atol=2e-4)
+    can.sum().backward()
+    assert torch.isfinite(T_t.grad).all() and T_t.grad.abs().sum() > 0 and verts_t.grad is not None

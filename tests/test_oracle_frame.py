@@ -25,3 +25,21 @@ def test_psnr_known_answers():
     c = a.copy()
     c[0, 0, 0] = 200                                             # uint8 difference must not wrap
     assert abs(OF.psnr_uint8(c, a) - 10 * np.log10(255.0 ** 2 / (200.0 ** 2 / 48))) < 1e-12
+
+
+def test_signed_distance_sign_is_the_winding_number():
+    """oracle/warp.py:signed_distance (pseudonormal sign, what igl.signed_distance computes) against an independent
+    inside/outside test, the generalised winding number, on a closed mesh"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "ml-neuman_amd"))
+    from neuman_hip import synthetic
+    from oracle import warp as OW
+    verts, faces = synthetic.capsule_mesh(n_rings=8, n_seg=10)
+    posed, _ = synthetic.twist_transforms(verts)
+    rng = np.random.default_rng(1)
+    pts = (posed[rng.integers(0, len(posed), 200)] + rng.normal(size=(200, 3)) * 0.06).astype(np.float32)
+    S, I, C = OW.signed_distance(pts, posed, faces)
+    wn = OW.winding_number(pts, posed, faces)
+    assert ((S < 0) == (wn > 0.5)).all() and 0.1 < (S < 0).mean() < 0.9
+    np.testing.assert_allclose(np.abs(S), np.linalg.norm(C - pts, axis=1), atol=1e-6)
