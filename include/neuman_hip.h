@@ -290,7 +290,8 @@ int nm_ssd_u8(const uint8_t* a, const uint8_t* b, int64_t n, uint64_t* ssd, nm_s
  *     but ACCUMULATE.
  *     flags: ACCUMULATE  C += ...;  BIAS  + bias[col];  RELU  max(.,0);  MASK  zero where mask[row,col] <= 0
  *     (applied in that order).  M, N, K, lda, ldb multiples of 4 (pad with zeros), A and B 16-byte aligned.
- *   nm_pe_encode: models/vanilla.py:60-92 stand-alone: x [n,3] -> out [n,ld], 3 + 6 n_freqs features then
+ *   nm_pe_encode: models/vanilla.py:60-92 stand-alone: x [n,dims] (dims 3, or 4 = point + time for the offset net,
+ *     vanilla.py:180-188) -> out [n,ld], dims (1 + 2 n_freqs) features then
  *     zeros; table = the n_freqs bands (posenc) or the [3 n_freqs, 3] projection (rotate), device f32.
  *   nm_composite_backward: d loss / d raw [R,S,4] through raw2outputs given the gradients of rgb_map [R,3],
  *     acc_map [R], depth_map [R], weights [R,S] (each nullable = zero); disp_map's gradient is not supported.
@@ -308,14 +309,14 @@ int nm_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A,
 int nm_gemm_bf16x3(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                    int ldc, const float* bias, const float* mask, int ldmask, int flags, float* workspace,
                    int64_t workspace_floats, nm_stream_t stream);
-int nm_pe_encode(const float* x, int64_t n, int kind, int n_freqs, const float* table, float* out, int ld,
+int nm_pe_encode(const float* x, int64_t n, int dims, int kind, int n_freqs, const float* table, float* out, int ld,
                  nm_stream_t stream);
 /* out[W] = column sums of X [n,W] (row stride ld): the bias gradients; bands of 256 rows summed in order (deterministic) */
 int64_t nm_colsum_workspace_floats(int64_t n, int W);
 int nm_colsum(const float* X, int64_t n, int W, int ld, float* out, float* workspace, int64_t workspace_floats, nm_stream_t stream);
 /* adjoint of nm_pe_encode: g [n,ld] = gradient of the encoded features -> dx [n,3] */
-int nm_pe_backward(const float* x, int64_t n, int kind, int n_freqs, const float* table, const float* g, int ld, float* dx,
-                   nm_stream_t stream);
+int nm_pe_backward(const float* x, int64_t n, int dims, int kind, int n_freqs, const float* table, const float* g, int ld,
+                   float* dx, nm_stream_t stream);
 int nm_composite_backward(const float* raw, const float* z_vals, const float* rays_d, int64_t R, int S, int white_bkg,
                           const float* g_rgb, const float* g_acc, const float* g_depth, const float* g_weights,
                           float* d_raw, nm_stream_t stream);

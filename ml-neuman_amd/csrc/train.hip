@@ -300,22 +300,22 @@ int pick_splits(int M, int N, int K) {
 
 // [x, sin(f0 x), cos(f0 x), sin(f1 x), ...] (posenc, models/vanilla.py:60-79) or [x, sin(x B^T), cos(x B^T)] (rotate, :83-89),
 // then zeros up to `ld`.  One thread per output element.
-__global__ __launch_bounds__(256) void pe_encode_kernel(const float* __restrict__ x, int64_t n, int kind, int nfreq, const float* __restrict__ tab,
-                                                        float* __restrict__ out, int ld) {
+__global__ __launch_bounds__(256) void pe_encode_kernel(const float* __restrict__ x, int64_t n, int D, int kind, int nfreq,
+                                                        const float* __restrict__ tab, float* __restrict__ out, int ld) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * ld) return;
     const int64_t r = i / ld;
     const int p = (int)(i % ld);
-    const float x0 = x[r * 3], x1 = x[r * 3 + 1], x2 = x[r * 3 + 2];
     float v = 0.f;
-    if (p < 3) v = p == 0 ? x0 : (p == 1 ? x1 : x2);
-    else if (p - 3 < 6 * nfreq) {
-        const int m = p - 3;
-        if (kind == NM_PE_POSENC) {
-            const int b = m / 6, q = m - 6 * b, dim = q >= 3 ? q - 3 : q;
-            const float a = (dim == 0 ? x0 : (dim == 1 ? x1 : x2)) * tab[b];
-            v = q >= 3 ? cosf(a) : sinf(a);
+    if (p < D) v = x[r * D + p];
+    else if (p - D < 2 * D * nfreq) {
+        const int m = p - D;
+        if (kind == NM_PE_POSENC) {                                  // D = 3 (points, directions) or 4 (point + time: the offset net)
+            const int b = m / (2 * D), q = m - 2 * D * b, dim = q >= D ? q - D : q;
+            const float a = x[r * D + dim] * tab[b];
+            v = q >= D ? cosf(a) : sinf(a);
         } else {
+            const float x0 = x[r * 3], x1 = x[r * 3 + 1], x2 = x[r * 3 + 2];
             const int n3 = 3 * nfreq;
             const bool is_cos = m >= n3;
             const float* b = tab + 3 * (is_cos ? m - n3 : m);
@@ -327,20 +327,19 @@ __global__ __launch_bounds__(256) void pe_encode_kernel(const float* __restrict_
 }
 
 // adjoint of pe_encode_kernel: dx [n,3] from the gradient g [n,ld] of the encoded features, one thread per row
-__global__ __launch_bounds__(256) void pe_backward_kernel(const float* __restrict__ x, int64_t n, int kind, int nfreq, const float* __restrict__ tab,
-                                                          const float* __restrict__ g, int ld, float* __restrict__ dx) {
+__global__ __launch_bounds__(256) void pe_backward_kernel(const float* __restrict__ x, int64_t n, int D, int kind, int nfreq,
+                                                          const float* __restrict__ tab, const float* __restrict__ g, int ld, float* __restrict__ dx) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
-    const float xv[3] = {x[r * 3], x[r * 3 + 1], x[r * 3 + 2]};
+    float xv[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
     const float* gr = g + r * ld;
-    float d[3] = {gr[0], gr[1], gr[2]};
+    for (int k = 0; k < D; ++k) { xv[k] = x[r * D + k]; d[k] = gr[k]; }
     if (kind == NM_PE_POSENC) {
         for (int b = 0; b < nfreq; ++b) {
             const float f = tab[b];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
+            for (int k = 0; k < D; ++k) {
                 const float a = xv[k] * f;
-                d[k] += f * (gr[3 + 6 * b + k] * cosf(a) - gr[3 + 6 * b + 3 + k] * sinf(a));
+                d[k] += f * (gr[D + 2 * D * b + k] * cosf(a) - gr[D + 2 * D * b + D + k] * sinf(a));
             }
         }
     } else {
@@ -353,7 +352,7 @@ __global__ __launch_bounds__(256) void pe_backward_kernel(const float* __restric
             for (int k = 0; k < 3; ++k) d[k] += b[k] * t;
         }
     }
-    dx[r * 3] = d[0]; dx[r * 3 + 1] = d[1]; dx[r * 3 + 2] = d[2];
+    for (int k = 0; k < D; ++k) dx[r * D + k] = d[k];
 }
 
 // d loss / d raw through raw2outputs, one thread per ray; the transmittance scan and its adjoint run in f64.
@@ -487,22 +486,25 @@ int nm_colsum(const float* X, int64_t n, int W, int ld, float* out, float* works
     return nm::check_launch("colsum_final_kernel");
 }
 
-int nm_pe_encode(const float* x, int64_t n, int kind, int n_freqs, const float* table, float* out, int ld, nm_stream_t stream) {
-    NM_REQUIRE(n >= 0 && n_freqs >= 0 && ld >= 3 + 6 * n_freqs, "nm_pe_encode: bad sizes n=%lld n_freqs=%d ld=%d", (long long)n, n_freqs, ld);
+int nm_pe_encode(const float* x, int64_t n, int dims, int kind, int n_freqs, const float* table, float* out, int ld, nm_stream_t stream) {
+    NM_REQUIRE(dims == 3 || (dims == 4 && kind == NM_PE_POSENC), "nm_pe_encode: dims %d (3, or 4 with the posenc mapping)", dims);
+    NM_REQUIRE(n >= 0 && n_freqs >= 0 && ld >= dims + 2 * dims * n_freqs, "nm_pe_encode: bad sizes n=%lld n_freqs=%d ld=%d", (long long)n, n_freqs, ld);
     NM_REQUIRE(kind == NM_PE_POSENC || kind == NM_PE_ROTATE, "nm_pe_encode: mapping %d", kind);
     if (n == 0) return NM_OK;
     NM_REQUIRE(x && out && (table || n_freqs == 0), "nm_pe_encode: null pointer");
     const int64_t total = n * ld;
-    hipLaunchKernelGGL(pe_encode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nm::as_stream(stream), x, n, kind, n_freqs, table, out, ld);
+    hipLaunchKernelGGL(pe_encode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nm::as_stream(stream), x, n, dims, kind, n_freqs, table, out, ld);
     return nm::check_launch("pe_encode_kernel");
 }
 
-int nm_pe_backward(const float* x, int64_t n, int kind, int n_freqs, const float* table, const float* g, int ld, float* dx, nm_stream_t stream) {
-    NM_REQUIRE(n >= 0 && n_freqs >= 0 && ld >= 3 + 6 * n_freqs, "nm_pe_backward: bad sizes n=%lld n_freqs=%d ld=%d", (long long)n, n_freqs, ld);
+int nm_pe_backward(const float* x, int64_t n, int dims, int kind, int n_freqs, const float* table, const float* g, int ld, float* dx,
+                   nm_stream_t stream) {
+    NM_REQUIRE(dims == 3 || (dims == 4 && kind == NM_PE_POSENC), "nm_pe_backward: dims %d (3, or 4 with the posenc mapping)", dims);
+    NM_REQUIRE(n >= 0 && n_freqs >= 0 && ld >= dims + 2 * dims * n_freqs, "nm_pe_backward: bad sizes n=%lld n_freqs=%d ld=%d", (long long)n, n_freqs, ld);
     NM_REQUIRE(kind == NM_PE_POSENC || kind == NM_PE_ROTATE, "nm_pe_backward: mapping %d", kind);
     if (n == 0) return NM_OK;
     NM_REQUIRE(x && g && dx && (table || n_freqs == 0), "nm_pe_backward: null pointer");
-    hipLaunchKernelGGL(pe_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nm::as_stream(stream), x, n, kind, n_freqs, table, g, ld, dx);
+    hipLaunchKernelGGL(pe_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nm::as_stream(stream), x, n, dims, kind, n_freqs, table, g, ld, dx);
     return nm::check_launch("pe_backward_kernel");
 }
 

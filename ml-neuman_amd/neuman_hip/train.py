@@ -46,15 +46,14 @@ def _pad_rows(w, rows, at=0):
 
 
 class _Packed:
-    """The 24 parameters in the shapes the products want (reference layout [out, in], inputs padded to multiples of 4)."""
+    """The parameters in the shapes the products want (reference layout [out, in], inputs padded to multiples of 4)."""
 
     def __init__(self, nerf, n_pos, n_dir):
         with torch.no_grad():
-            P = [l for l in nerf.pts_linears]
-            self.n_pos, self.n_dir = n_pos, n_dir                               # 63, 27
-            self.kp, self.kd = (n_pos + 3) // 4 * 4, (n_dir + 3) // 4 * 4       # 64, 28
+            self.n_pos, self.n_dir = n_pos, n_dir                               # 63 / 84, 27
+            self.kp, self.kd = (n_pos + 3) // 4 * 4, (n_dir + 3) // 4 * 4       # 64 / 84, 28
             self.W, self.b = [], []
-            for i, lin in enumerate(P):
+            for i, lin in enumerate(nerf.pts_linears):
                 w = lin.weight.detach().float()
                 if i == 0:
                     self.W.append((_pad_cols(w, self.kp),))
@@ -63,33 +62,60 @@ class _Packed:
                 else:
                     self.W.append((w.contiguous(),))
                 self.b.append(lin.bias.detach().float().contiguous())
-            wv = nerf.views_linears[0].weight.detach().float()                   # cat([feature, d_pe]) (vanilla.py:139)
-            self.Wv = (wv[:, :nerf.width].contiguous(), _pad_cols(wv[:, nerf.width:], self.kd))
-            self.bv = nerf.views_linears[0].bias.detach().float().contiguous()
-            self.Wf, self.bf = nerf.feature_linear.weight.detach().float().contiguous(), nerf.feature_linear.bias.detach().float().contiguous()
-            self.Wa4 = _pad_rows(nerf.alpha_linear.weight.detach().float(), 4, at=3)        # raw[:, 3] = sigma
-            self.Wr4 = _pad_rows(nerf.rgb_linear.weight.detach().float(), 4)                # raw[:, :3] = rgb
-            self.b4 = torch.cat([nerf.rgb_linear.bias.detach().float(), nerf.alpha_linear.bias.detach().float()]).contiguous()
+            if nerf.use_viewdirs:
+                wv = nerf.views_linears[0].weight.detach().float()               # cat([feature, d_pe]) (vanilla.py:139)
+                self.Wv = (wv[:, :nerf.width].contiguous(), _pad_cols(wv[:, nerf.width:], self.kd))
+                self.bv = nerf.views_linears[0].bias.detach().float().contiguous()
+                self.Wf, self.bf = nerf.feature_linear.weight.detach().float().contiguous(), nerf.feature_linear.bias.detach().float().contiguous()
+                self.Wa4 = _pad_rows(nerf.alpha_linear.weight.detach().float(), 4, at=3)    # raw[:, 3] = sigma
+                self.Wr4 = _pad_rows(nerf.rgb_linear.weight.detach().float(), 4)            # raw[:, :3] = rgb
+                self.b4 = torch.cat([nerf.rgb_linear.bias.detach().float(), nerf.alpha_linear.bias.detach().float()]).contiguous()
+            else:                                                                # output_linear, <= 4 outputs (vanilla.py:117, 150)
+                self.n_out = nerf.output_linear.weight.shape[0]
+                self.Wo4 = _pad_rows(nerf.output_linear.weight.detach().float(), 4)
+                self.bo4 = torch.zeros(4, device=self.Wo4.device)
+                self.bo4[:self.n_out] = nerf.output_linear.bias.detach().float()
+
+
+def _encode(emb, x, ld):
+    dev = x.device
+    tab = torch.from_numpy(emb.table()).to(dev).contiguous()
+    out = torch.empty((x.shape[0], ld), device=dev, dtype=torch.float32)
+    _lib.check(_lib.lib().nm_pe_encode(_lib.dev_ptr(x), x.shape[0], x.shape[1], PE_KINDS[emb.mapping], emb.N_freqs, _lib.dev_ptr(tab),
+                                       _lib.dev_ptr(out), ld, _lib.stream_ptr()), "nm_pe_encode")
+    return out
+
+
+def _encode_backward(emb, x, g):
+    dev = x.device
+    tab = torch.from_numpy(emb.table()).to(dev).contiguous()
+    dx = torch.empty_like(x)
+    _lib.check(_lib.lib().nm_pe_backward(_lib.dev_ptr(x), x.shape[0], x.shape[1], PE_KINDS[emb.mapping], emb.N_freqs, _lib.dev_ptr(tab),
+                                         _lib.dev_ptr(g), g.shape[1], _lib.dev_ptr(dx), _lib.stream_ptr()), "nm_pe_backward")
+    return dx
+
+
+def _pad4(x):
+    n = x.shape[0]
+    out = torch.zeros(((n + 3) // 4 * 4, x.shape[1]), device=x.device, dtype=torch.float32)
+    out[:n] = x
+    return out
 
 
 class _MLP(torch.autograd.Function):
+    """net = Joiner (use_viewdirs: pts, dirs -> [rgb, sigma]) or OffsetNet (dirs is None: x -> output_linear)."""
+
     @staticmethod
-    def forward(ctx, joiner, pts, dirs, *params):
-        nerf = joiner.nerf
+    def forward(ctx, net, pts, dirs, *params):
+        nerf = net.nerf
         dev = pts.device
         n = pts.shape[0]
-        n4 = (n + 3) // 4 * 4
         width, half = nerf.width, nerf.width // 2
-        pk = _Packed(nerf, joiner.pos_pe.out_dim, joiner.dir_pe.out_dim)
-        p4 = torch.zeros((n4, 3), device=dev, dtype=torch.float32)
-        d4 = torch.zeros((n4, 3), device=dev, dtype=torch.float32)
-        p4[:n], d4[:n] = pts, dirs
-        X0 = torch.empty((n4, pk.kp), device=dev, dtype=torch.float32)
-        D0 = torch.empty((n4, pk.kd), device=dev, dtype=torch.float32)
-        for emb, x, out in ((joiner.pos_pe, p4, X0), (joiner.dir_pe, d4, D0)):
-            tab = torch.from_numpy(emb.table()).to(dev).contiguous()
-            _lib.check(_lib.lib().nm_pe_encode(_lib.dev_ptr(x), n4, PE_KINDS[emb.mapping], emb.N_freqs, _lib.dev_ptr(tab), _lib.dev_ptr(out),
-                                               out.shape[1], _lib.stream_ptr()), "nm_pe_encode")
+        views = nerf.use_viewdirs
+        pk = _Packed(nerf, net.pos_pe.out_dim, net.dir_pe.out_dim if views else 0)
+        p4 = _pad4(pts)
+        n4 = p4.shape[0]
+        X0 = _encode(net.pos_pe, p4, pk.kp)
         H = []
         h, kh = X0, pk.kp
         for i, Ws in enumerate(pk.W):
@@ -102,25 +128,33 @@ class _MLP(torch.autograd.Function):
             H.append(o)
             h, kh = o, width
         raw = torch.empty((n4, 4), device=dev, dtype=torch.float32)
-        _gemm(0, 0, n4, 4, width, h, width, pk.Wa4, width, raw, 4, bias=pk.b4, flags=BIAS)             # sigma (+ all four biases)
-        feat = torch.empty((n4, width), device=dev, dtype=torch.float32)
-        _gemm(0, 0, n4, width, width, h, width, pk.Wf, width, feat, width, bias=pk.bf, flags=BIAS)
-        hv = torch.empty((n4, half), device=dev, dtype=torch.float32)
-        _gemm(0, 0, n4, half, width, feat, width, pk.Wv[0], width, hv, half)
-        _gemm(0, 0, n4, half, pk.kd, D0, pk.kd, pk.Wv[1], pk.kd, hv, half, bias=pk.bv, flags=ACC | BIAS | RELU)
-        _gemm(0, 0, n4, 4, half, hv, half, pk.Wr4, half, raw, 4, flags=ACC)                               # + rgb
-        ctx.pk, ctx.X0, ctx.D0, ctx.H, ctx.feat, ctx.hv, ctx.n, ctx.nerf = pk, X0, D0, H, feat, hv, n, nerf
-        ctx.p4, ctx.d4, ctx.pe = p4, d4, (joiner.pos_pe, joiner.dir_pe)
-        return raw[:n]
+        d4 = D0 = feat = hv = None
+        if views:
+            d4 = _pad4(dirs)
+            D0 = _encode(net.dir_pe, d4, pk.kd)
+            _gemm(0, 0, n4, 4, width, h, width, pk.Wa4, width, raw, 4, bias=pk.b4, flags=BIAS)         # sigma (+ all four biases)
+            feat = torch.empty((n4, width), device=dev, dtype=torch.float32)
+            _gemm(0, 0, n4, width, width, h, width, pk.Wf, width, feat, width, bias=pk.bf, flags=BIAS)
+            hv = torch.empty((n4, half), device=dev, dtype=torch.float32)
+            _gemm(0, 0, n4, half, width, feat, width, pk.Wv[0], width, hv, half)
+            _gemm(0, 0, n4, half, pk.kd, D0, pk.kd, pk.Wv[1], pk.kd, hv, half, bias=pk.bv, flags=ACC | BIAS | RELU)
+            _gemm(0, 0, n4, 4, half, hv, half, pk.Wr4, half, raw, 4, flags=ACC)                           # + rgb
+        else:
+            _gemm(0, 0, n4, 4, width, h, width, pk.Wo4, width, raw, 4, bias=pk.bo4, flags=BIAS)
+        ctx.pk, ctx.X0, ctx.D0, ctx.H, ctx.feat, ctx.hv, ctx.n, ctx.net = pk, X0, D0, H, feat, hv, n, net
+        ctx.p4, ctx.d4 = p4, d4
+        return raw[:n] if views else raw[:n, :pk.n_out]
 
     @staticmethod
     def backward(ctx, g_raw):
-        pk, X0, D0, H, feat, hv, n, nerf = ctx.pk, ctx.X0, ctx.D0, ctx.H, ctx.feat, ctx.hv, ctx.n, ctx.nerf
-        want_in = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        pk, X0, D0, H, feat, hv, n, net = ctx.pk, ctx.X0, ctx.D0, ctx.H, ctx.feat, ctx.hv, ctx.n, ctx.net
+        nerf = net.nerf
+        views = nerf.use_viewdirs
+        want_in = ctx.needs_input_grad[1] or (views and ctx.needs_input_grad[2])
         dev = X0.device
         n4, width, half = X0.shape[0], nerf.width, nerf.width // 2
         d_raw = torch.zeros((n4, 4), device=dev, dtype=torch.float32)
-        d_raw[:n] = g_raw
+        d_raw[:n, :g_raw.shape[1]] = g_raw
         ws = [torch.empty(4, device=dev, dtype=torch.float32)]
 
         def workspace(m, k):                                                     # split-K partials, grown to the largest product
@@ -143,25 +177,31 @@ class _MLP(torch.autograd.Function):
                                             _lib.stream_ptr()), "nm_colsum")
             return out
 
-        g = {}
         h7 = H[-1]
-        gWr4, gb4 = wgrad(d_raw, 4, hv, half), bgrad(d_raw, 4)
-        g['rgb_w'], g['rgb_b'], g['alpha_b'] = gWr4[:3], gb4[:3], gb4[3:4]
-        d_hv = torch.empty((n4, half), device=dev, dtype=torch.float32)
-        _gemm(0, 1, n4, half, 4, d_raw, 4, pk.Wr4, half, d_hv, half, mask=hv, ldmask=half, flags=MASK)
-        g['views_w'] = torch.cat([wgrad(d_hv, half, feat, width), wgrad(d_hv, half, D0, pk.kd)[:, :pk.n_dir]], 1)
-        g['views_b'] = bgrad(d_hv, half)
         dX0 = dD0 = None
-        if want_in:                                                              # gradient of the encoded view direction
-            dD0 = torch.empty((n4, pk.kd), device=dev, dtype=torch.float32)
-            _gemm(0, 1, n4, pk.kd, half, d_hv, half, pk.Wv[1], pk.kd, dD0, pk.kd)
-        d_feat = torch.empty((n4, width), device=dev, dtype=torch.float32)
-        _gemm(0, 1, n4, width, half, d_hv, half, pk.Wv[0], width, d_feat, width)
-        g['feature_w'], g['feature_b'] = wgrad(d_feat, width, h7, width), bgrad(d_feat, width)
-        g['alpha_w'] = wgrad(d_raw, 4, h7, width)[3:4]
         dz = torch.empty((n4, width), device=dev, dtype=torch.float32)
-        _gemm(0, 1, n4, width, width, d_feat, width, pk.Wf, width, dz, width)
-        _gemm(0, 1, n4, width, 4, d_raw, 4, pk.Wa4, width, dz, width, mask=h7, ldmask=width, flags=ACC | MASK)
+        if views:
+            g = {}
+            gWr4, gb4 = wgrad(d_raw, 4, hv, half), bgrad(d_raw, 4)
+            g['rgb_w'], g['rgb_b'], g['alpha_b'] = gWr4[:3], gb4[:3], gb4[3:4]
+            d_hv = torch.empty((n4, half), device=dev, dtype=torch.float32)
+            _gemm(0, 1, n4, half, 4, d_raw, 4, pk.Wr4, half, d_hv, half, mask=hv, ldmask=half, flags=MASK)
+            g['views_w'] = torch.cat([wgrad(d_hv, half, feat, width), wgrad(d_hv, half, D0, pk.kd)[:, :pk.n_dir]], 1)
+            g['views_b'] = bgrad(d_hv, half)
+            if want_in:                                                          # gradient of the encoded view direction
+                dD0 = torch.empty((n4, pk.kd), device=dev, dtype=torch.float32)
+                _gemm(0, 1, n4, pk.kd, half, d_hv, half, pk.Wv[1], pk.kd, dD0, pk.kd)
+            d_feat = torch.empty((n4, width), device=dev, dtype=torch.float32)
+            _gemm(0, 1, n4, width, half, d_hv, half, pk.Wv[0], width, d_feat, width)
+            g['feature_w'], g['feature_b'] = wgrad(d_feat, width, h7, width), bgrad(d_feat, width)
+            g['alpha_w'] = wgrad(d_raw, 4, h7, width)[3:4]
+            _gemm(0, 1, n4, width, width, d_feat, width, pk.Wf, width, dz, width)
+            _gemm(0, 1, n4, width, 4, d_raw, 4, pk.Wa4, width, dz, width, mask=h7, ldmask=width, flags=ACC | MASK)
+            head = [g['views_w'].contiguous(), g['views_b'].contiguous(), g['feature_w'], g['feature_b'].contiguous(),
+                    g['alpha_w'].contiguous(), g['alpha_b'].contiguous(), g['rgb_w'].contiguous(), g['rgb_b'].contiguous()]
+        else:
+            head = [wgrad(d_raw, 4, h7, width)[:pk.n_out].contiguous(), bgrad(d_raw, 4)[:pk.n_out].contiguous()]
+            _gemm(0, 1, n4, width, 4, d_raw, 4, pk.Wo4, width, dz, width, mask=h7, ldmask=width, flags=MASK)
         gw, gb = [None] * len(pk.W), [None] * len(pk.W)
         for i in range(len(pk.W) - 1, -1, -1):
             Ws = pk.W[i]
@@ -187,19 +227,28 @@ class _MLP(torch.autograd.Function):
         grads = []
         for i in range(len(pk.W)):
             grads += [gw[i].contiguous(), gb[i].contiguous()]
-        grads += [g['views_w'].contiguous(), g['views_b'].contiguous(), g['feature_w'], g['feature_b'].contiguous(),
-                  g['alpha_w'].contiguous(), g['alpha_b'].contiguous(), g['rgb_w'].contiguous(), g['rgb_b'].contiguous()]
-        d_pts = d_dirs = None
-        if want_in:
-            res = []
-            for emb, x, gx in ((ctx.pe[0], ctx.p4, dX0), (ctx.pe[1], ctx.d4, dD0)):
-                tab = torch.from_numpy(emb.table()).to(dev).contiguous()
-                dx = torch.empty((n4, 3), device=dev, dtype=torch.float32)
-                _lib.check(_lib.lib().nm_pe_backward(_lib.dev_ptr(x), n4, PE_KINDS[emb.mapping], emb.N_freqs, _lib.dev_ptr(tab), _lib.dev_ptr(gx),
-                                                     gx.shape[1], _lib.dev_ptr(dx), _lib.stream_ptr()), "nm_pe_backward")
-                res.append(dx[:n])
-            d_pts, d_dirs = res
+        grads += head
+        d_pts = _encode_backward(net.pos_pe, ctx.p4, dX0)[:n] if want_in else None
+        d_dirs = _encode_backward(net.dir_pe, ctx.d4, dD0)[:n] if (want_in and views) else None
         return (None, d_pts, d_dirs) + tuple(grads)
+
+
+def train_params(nerf):
+    """the parameters in the order _MLP returns their gradients: pts_linears, then the heads (reference state_dict order)"""
+    lins = list(nerf.pts_linears) + ([nerf.views_linears[0], nerf.feature_linear, nerf.alpha_linear, nerf.rgb_linear] if nerf.use_viewdirs
+                                     else [nerf.output_linear])
+    out = []
+    for lin in lins:
+        out += [lin.weight, lin.bias]
+    return out
+
+
+def offset_forward_train(net, x):
+    """OffsetNet.forward (vanilla.py:169-178) with autograd: x [..., 4] (point + time) -> offset [..., 3], before the scale"""
+    _lib.require_gpu()
+    shp = x.shape[:-1]
+    xf = x.reshape(-1, x.shape[-1]).to(torch.float32).contiguous()
+    return _MLP.apply(net, xf, None, *train_params(net.nerf)).reshape(*shp, -1)
 
 
 def mlp_forward_train(joiner, pts, dirs):
@@ -208,7 +257,7 @@ def mlp_forward_train(joiner, pts, dirs):
     shp = pts.shape[:-1]
     p = pts.reshape(-1, 3).to(torch.float32).contiguous()
     d = dirs.reshape(-1, 3).to(torch.float32).contiguous()
-    return _MLP.apply(joiner, p, d, *joiner.nerf.ordered_params()).reshape(*shp, 4)
+    return _MLP.apply(joiner, p, d, *train_params(joiner.nerf)).reshape(*shp, 4)
 
 
 class _Composite(torch.autograd.Function):

@@ -195,6 +195,36 @@ class Joiner(nn.Module):
         return out
 
 
+class OffsetNet(nn.Module):
+    """reference vanilla.py:169-178: space-time encoding + a NeRF trunk without view directions, used by the human trainer only
+    (human_nerf_trainer.py:261).  Training-only here: it runs on the differentiable float32 path (neuman_hip/train.py)."""
+
+    def __init__(self, pos_pe, nerf):
+        super().__init__()
+        self.pos_pe, self.nerf = pos_pe, nerf
+
+    def forward(self, input_pts, cur_iter=None):
+        assert cur_iter is None                                      # as the reference's posenc Embedder (vanilla.py:91)
+        from . import train
+        out = train.offset_forward_train(self, input_pts)
+        if self.nerf.scale_type == 'no':                             # vanilla.py:146-152
+            return out
+        if self.nerf.scale_type == 'linear':
+            return out * self.nerf.scale
+        if self.nerf.scale_type == 'tanh':
+            return torch.tanh(out) * self.nerf.scale
+        raise ValueError(self.nerf.scale_type)
+
+
+def build_offset_net(opt):
+    """reference vanilla.py:180-205"""
+    st_pe = Embedder(opt.raw_pos_dim + 1, opt.pos_max_freq, opt.pos_N_freqs, opt.log_sampling, opt.include_input, min_freq=opt.pos_min_freq)
+    nerf = NeRF(depth=opt.nerf_depth, width=opt.nerf_width, input_ch=st_pe.out_dim, input_ch_views=0, output_ch=3, use_viewdirs=False,
+                scale=opt.offset_scale, scale_type=opt.offset_scale_type)
+    net = OffsetNet(st_pe, nerf)
+    return net.cuda() if opt.use_cuda else net
+
+
 def build_nerf(opt):
     """Same construction order as the reference (vanilla.py:208-250): coarse NeRF first, then fine."""
     mapping = opt.posenc if hasattr(opt, 'posenc') else 'posenc'

@@ -102,3 +102,20 @@ def composite_backward(raw, z_vals, rays_d, white_bkg, g_rgb, g_acc, g_depth, g_
     t = lambda a: torch.tensor(np.asarray(a), dtype=F64)
     ((rgb * t(g_rgb)).sum() + (acc * t(g_acc)).sum() + (dep * t(g_depth)).sum() + (wts * t(g_w)).sum()).backward()
     return r.grad.numpy()
+
+
+def offset_net_gradients(weights, x, g_out, scale=1.0, scale_type='linear', n_freqs=10, depth=8, skips=(4,)):
+    """The offset net (models/vanilla.py:169-205: 4-D posenc, trunk, output_linear, scale) and the adjoint of sum(g_out . out):
+    -> (out, d_x, {name: grad}) float64."""
+    W = {k: torch.tensor(np.asarray(v), dtype=F64, requires_grad=True) for k, v in weights.items()}
+    xt = torch.tensor(np.asarray(x), dtype=F64, requires_grad=True)
+    x_pe = posenc(xt, n_freqs)
+    h = x_pe
+    for i in range(depth):
+        h = torch.relu(h @ W[f'nerf.pts_linears.{i}.weight'].T + W[f'nerf.pts_linears.{i}.bias'])
+        if i in skips:
+            h = torch.cat([x_pe, h], -1)
+    out = h @ W['nerf.output_linear.weight'].T + W['nerf.output_linear.bias']
+    out = out * scale if scale_type == 'linear' else (torch.tanh(out) * scale if scale_type == 'tanh' else out)
+    (out * torch.tensor(np.asarray(g_out), dtype=F64)).sum().backward()
+    return out.detach().numpy(), xt.grad.numpy(), {k: v.grad.numpy() for k, v in W.items()}

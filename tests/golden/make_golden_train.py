@@ -122,6 +122,22 @@ def main():
         (o * gout).sum().backward()
         out.update({f'in/{mapping}/pts': pts.detach().numpy(), f'in/{mapping}/dirs': dirs.detach().numpy(), f'in/{mapping}/g_out': gout.numpy(),
                     f'in/{mapping}/out': o.detach().numpy(), f'in/{mapping}/d_pts': pts.grad.numpy(), f'in/{mapping}/d_dirs': dirs.grad.numpy()})
+    # the offset net (vanilla.py:169-205, human_nerf_trainer.py:259-261): space-time input, both scale types
+    from neuman_hip import vanilla as H_vanilla
+    for scale_type in ('linear', 'tanh'):
+        opt = synthetic.default_opt(offset_scale=0.7, offset_scale_type=scale_type)
+        torch.manual_seed(11)
+        ours = H_vanilla.build_offset_net(opt)
+        ref = R_vanilla.build_offset_net(opt)
+        ref.load_state_dict(ours.state_dict(), strict=True)
+        x = torch.from_numpy(np.concatenate([rng.uniform(-1, 1, size=(77, 3)), rng.uniform(0, 1, size=(77, 1))], 1).astype(np.float32)).requires_grad_(True)
+        gout = torch.from_numpy(rng.normal(size=(77, 3)).astype(np.float32))
+        o = ref(x)
+        (o * gout).sum().backward()
+        p = f'off/{scale_type}'
+        out.update({f'{p}/x': x.detach().numpy(), f'{p}/g_out': gout.numpy(), f'{p}/out': o.detach().numpy(), f'{p}/d_x': x.grad.numpy()})
+        for n, prm in ref.named_parameters():
+            grad_summary(n, prm.grad, out, p)
     np.savez_compressed(os.path.join(HERE, 'train.npz'), **out)
     print({k: out[k] for k in out if k.endswith('losses')})
     print(len(out), "arrays,", os.path.getsize(os.path.join(HERE, 'train.npz')), "bytes")

@@ -151,6 +151,24 @@ def test_a_few_sgd_steps_reduce_the_loss(G, prec, monkeypatch):
     assert not r.requires_grad
 
 
+@pytest.mark.parametrize("scale_type", ["linear", "tanh"])
+def test_offset_net_matches_reference(G, scale_type):
+    """the human trainer's offset net (vanilla.py:169-205, human_nerf_trainer.py:259-261): 4-D posenc, plain head, scale"""
+    from test_oracle_train import offset_weights
+    g, p = G.g, f'off/{scale_type}'
+    net, w = offset_weights(scale_type)
+    net = net.cuda().train()
+    x = cu(g[f'{p}/x']).requires_grad_(True)
+    out = net(x)
+    assert out.shape == (77, 3)
+    (out * cu(g[f'{p}/g_out'])).sum().backward()
+    assert np.abs(out.detach().cpu().numpy() - g[f'{p}/out']).max() < 1e-5
+    ref = g[f'{p}/d_x']
+    assert np.abs(x.grad.cpu().numpy() - ref).max() < 1e-4 * np.abs(ref).max()
+    worst = check_grads({n: prm.grad.cpu().numpy() for n, prm in net.named_parameters()}, g, p)
+    print(f"[train] offset net ({scale_type}): worst relative parameter-gradient error vs reference {worst:.2e}")
+
+
 @pytest.mark.parametrize("mapping", ["posenc", "rotate"])
 def test_input_gradients_match_reference(G, mapping):
     """d / d pts, d / d dirs through PE + MLP (what pose and offset optimisation differentiates), both encodings; an odd row count"""

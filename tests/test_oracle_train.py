@@ -57,6 +57,23 @@ def test_input_gradients_match_reference(G, mapping):
         assert np.abs(mine - ref).max() < 2e-4 * np.abs(ref).max(), np.abs(mine - ref).max() / np.abs(ref).max()
 
 
+def offset_weights(scale_type):
+    import torch
+    from neuman_hip import vanilla
+    torch.manual_seed(11)
+    net = vanilla.build_offset_net(synthetic.default_opt(offset_scale=0.7, offset_scale_type=scale_type))
+    return net, {k: v.detach().numpy() for k, v in net.state_dict().items()}
+
+
+@pytest.mark.parametrize("scale_type", ["linear", "tanh"])
+def test_offset_net_matches_reference(G, scale_type):
+    _, w = offset_weights(scale_type)
+    p = f'off/{scale_type}'
+    out, dx, grads = OT.offset_net_gradients(w, G[f'{p}/x'], G[f'{p}/g_out'], 0.7, scale_type)
+    assert np.abs(out - G[f'{p}/out']).max() < 1e-5 and np.abs(dx - G[f'{p}/d_x']).max() < 1e-4 * np.abs(G[f'{p}/d_x']).max()
+    check_grads(grads, G, p)
+
+
 @pytest.mark.parametrize("tag,white", [("white", True), ("black", False)])
 def test_composite_backward_matches_reference(G, tag, white):
     d = OT.composite_backward(G['c/raw'], G['c/z'], G['c/d'], white, G['c/g_rgb'], G['c/g_acc'], G['c/g_depth'], G['c/g_w'])
