@@ -187,3 +187,56 @@ def test_input_gradients_match_reference(G, mapping):
         e_ref, e_ora = np.abs(m - ref).max() / np.abs(ref).max(), np.abs(m - ora).max() / np.abs(ora).max()
         print(f"[train] {mapping} d/d{name}: vs reference {e_ref:.2e}, vs f64 oracle {e_ora:.2e} (relative to max)")
         assert e_ref < 2e-4 and e_ora < 2e-4
+
+
+def test_human_samples_iteration(G):
+    """the lines of HumanNeRFTrainer._eval_human_samples (human_nerf_trainer.py:241-278) + an rgb loss on the HIP modules: rays
+    against the skinned body, offset net, differentiable warp (device signed distance), canonical human net, raw2outputs,
+    backward; gradients reach the human net and the offset net, and a few Adam steps lower the loss"""
+    from neuman_hip import ray_utils, smpl as HS, vanilla
+    torch.manual_seed(3)
+    body = HS.SMPL(G.syn.smpl_like_model(0))
+    pose, betas, align = G.syn.smpl_like_frames(1, 0)
+    a = np.eye(4)
+    a[:, :3] = align["00000.png"]
+    world, T = HS.vertex_forward(body, pose[:1], betas[:1], a, 1.0)                   # mesh [1,V,3], raw_Ts [1,V,4,4] (f32)
+    mesh, raw_Ts = world[0], T[0]
+    faces = np.ascontiguousarray(G.syn.smpl_like_model(0)['f'].astype(np.int32))
+    human_net = G.syn.make_joiner(2, 'rotate').cuda().train()
+    offset_net = vanilla.build_offset_net(G.syn.default_opt(offset_scale=0.05, offset_scale_type='tanh')).cuda().train()
+    opt = torch.optim.Adam(list(human_net.parameters()) + list(offset_net.parameters()), lr=5e-4)
+    centre = mesh.mean(0)
+    R, S = 48, 16
+    rng = np.random.default_rng(0)
+    tgt = mesh[torch.from_numpy(rng.integers(0, mesh.shape[0], R)).cuda()]
+    o = (centre + torch.tensor([0.0, 0.0, -2.5], device='cuda')).expand(R, 3).contiguous()
+    d = torch.nn.functional.normalize(tgt - o, dim=1)
+    near, far = ray_utils.geometry_guided_near_far(o, d, mesh, 0.2)
+    assert bool((near < far).all())
+    color = torch.rand((R, 3), device='cuda')
+    losses = []
+    for it in range(6):
+        opt.zero_grad()
+        human_pts, _, z = ray_utils.sample_z(o, d, near, far, S, want_points=True)
+        cur_time = torch.ones_like(human_pts[..., 0:1]) * 0.25
+        offset = offset_net(torch.cat([human_pts, cur_time], dim=-1))
+        flat = human_pts.reshape(-1, 3)
+        Ts, _, sd = ray_utils.warp_samples_to_canonical_diff(flat.detach().cpu().numpy(), verts=mesh, faces=faces, T=raw_Ts)
+        can_pts = (Ts @ ray_utils.to_homogeneous(flat)[..., None])[:, :3, 0].reshape(R, S, 3)
+        can_pts = can_pts + offset
+        can_dirs = can_pts[:, 1:] - can_pts[:, :-1]
+        can_dirs = torch.cat([can_dirs, can_dirs[:, -1:]], dim=1)
+        can_dirs = can_dirs / torch.norm(can_dirs, dim=2, keepdim=True)
+        human_out = human_net(can_pts, can_dirs)
+        rgb_map = G.render.raw2outputs(human_out, z, d, white_bkg=True)[0]
+        loss = F.mse_loss(rgb_map, color)
+        loss.backward()
+        if it == 0:
+            for name, net in (("human", human_net), ("offset", offset_net)):
+                gs = [p.grad for p in net.parameters()]
+                assert all(g is not None and torch.isfinite(g).all() for g in gs) and sum(float(g.abs().sum()) for g in gs) > 0, name
+            assert (sd < 0).any() and (sd > 0).any()                              # samples on both sides of the surface
+        opt.step()
+        losses.append(float(loss.detach()))
+    print("[train] human-samples iteration: losses", " ".join(f"{x:.4f}" for x in losses))
+    assert losses[-1] < losses[0]
