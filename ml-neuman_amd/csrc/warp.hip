@@ -17,7 +17,7 @@
 //     What makes it fast is how the wave is scheduled, see the kernel: persistent lanes, and two wave-wide phases (expand a
 //     node / test a triangle) of which the one with more ready lanes runs.  The round's first version (a per-cell candidate
 //     grid, the exact test inside the divergent candidate loop) took 39.5 ms + 10.6 ms of build for the 7.3 M samples of a
-//     512 x 512 frame; this one takes 7.8 ms + 1.0 ms, VALU-bound (90 % busy).
+//     512 x 512 frame; this one takes 7.8 ms + 1.0 ms, VALU-bound (86–90 % of the issue slots busy, `profiles/r01_warp_pmc.json`).
 //   tail_kernel -- one workgroup per ray: the winning triangle's barycentrics, the blended 4x4 (f64, the reference's T is f64),
 //     its inverse and the canonical point in f64; the ray's canonical points are staged in LDS so the finite-difference
 //     directions (:62-64) need no second pass over HBM.
