@@ -40,31 +40,70 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ S, int ld, i
         if (KMAJOR) {
             const int k = k0 + (tid >> 5) + 8 * h, d = d0 + 4 * (tid & 31);
             if (k < kend && d < DIM) r[h] = *reinterpret_cast<const float4*>(S + (int64_t)k * ld + d);
-        } else {
-            const int d = d0 + (tid & 127), k = k0 + 4 * ((tid >> 7) + 2 * h);
+        } else {                                                       // four lanes share a row's 64 B: 16 cache lines per wave load, not 64
+            const int d = d0 + (tid >> 2) + 64 * h, k = k0 + 4 * (tid & 3);
             if (d < DIM && k < kend) r[h] = *reinterpret_cast<const float4*>(S + (int64_t)d * ld + k);
         }
     }
 }
+constexpr int LDT = BM + 4;             // LDS row stride: the transposing stores below hit every bank twice (the minimum for 64 lanes)
 template <bool KMAJOR>
-__device__ __forceinline__ void tile_store(float (*T)[BM], int tid, const float4 (&r)[2]) {      // T[k][d]
+__device__ __forceinline__ void tile_store(float (*T)[LDT], int tid, const float4 (&r)[2]) {     // T[k][d]
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         if (KMAJOR) {
             *reinterpret_cast<float4*>(&T[(tid >> 5) + 8 * h][4 * (tid & 31)]) = r[h];
         } else {
-            const int d = tid & 127, k = 4 * ((tid >> 7) + 2 * h);
+            const int d = (tid >> 2) + 64 * h, k = 4 * (tid & 3);
             T[k][d] = r[h].x; T[k + 1][d] = r[h].y; T[k + 2][d] = r[h].z; T[k + 3][d] = r[h].w;
         }
     }
+}
+
+// The epilogue both GEMM kernels share: a wave's 2 x 2 accumulator blocks -> C (or the split-K partials), with the dense-layer
+// options.  Accumulator element v of a 32 x 32 block: row 8 (v / 4) + 4 (lane / 32) + v % 4, column lane % 32.
+__device__ __forceinline__ void store_tile(const GemmArgs& g, const floatx16 (&acc)[2][2], int m0, int n0, int wm, int wn, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + 32 * j + (lane & 31);
+            if (col >= g.N) continue;
+            const int row0 = m0 + wm + 32 * i + 4 * (lane >> 5);
+            if (g.partial) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int row = row0 + 8 * (v >> 2) + (v & 3);
+                    if (row < g.M) g.partial[((int64_t)blockIdx.z * g.M + row) * g.N + col] = acc[i][j][v];
+                }
+                continue;
+            }
+            // what the epilogue reads goes to registers first: sixteen loads in flight, not sixteen round trips
+            float cv[16], mv[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = row0 + 8 * (v >> 2) + (v & 3);
+                cv[v] = ((g.flags & NM_GEMM_ACCUMULATE) && row < g.M) ? g.C[(int64_t)row * g.ldc + col] : 0.f;
+                mv[v] = ((g.flags & NM_GEMM_MASK) && row < g.M) ? g.mask[(int64_t)row * g.ldmask + col] : 1.f;
+            }
+            const float bias = (g.flags & NM_GEMM_BIAS) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = row0 + 8 * (v >> 2) + (v & 3);
+                if (row >= g.M) continue;
+                float x = acc[i][j][v] + cv[v] + bias;
+                if (g.flags & NM_GEMM_RELU) x = fmaxf(x, 0.f);
+                g.C[(int64_t)row * g.ldc + col] = mv[v] > 0.f ? x : 0.f;
+            }
+        }
 }
 
 // 128 x 128 output tile per workgroup of four waves (64 x 64 each = 2 x 2 MFMA blocks of 32 x 32), K in steps of 16 through a
 // double-buffered LDS tile pair; the next step's global loads are in flight during the current step's MFMAs.
 template <bool A_KMAJOR, bool B_KMAJOR>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
-    __shared__ float As[2][BK][BM];
-    __shared__ float Bs[2][BK][BN];
+    __shared__ float As[2][BK][LDT];
+    __shared__ float Bs[2][BK][LDT];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * g.k_per_split;
@@ -107,27 +146,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         __syncthreads();
         buf ^= 1;
     }
-    // accumulator element v of a 32 x 32 block: row 8 (v / 4) + 4 (lane / 32) + v % 4, column lane % 32
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn + 32 * j + (lane & 31);
-            if (col >= g.N) continue;
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int row = m0 + wm + 32 * i + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
-                if (row >= g.M) continue;
-                float x = acc[i][j][v];
-                if (g.partial) { g.partial[((int64_t)blockIdx.z * g.M + row) * g.N + col] = x; continue; }
-                float* c = g.C + (int64_t)row * g.ldc + col;
-                if (g.flags & NM_GEMM_ACCUMULATE) x += *c;
-                if (g.flags & NM_GEMM_BIAS) x += g.bias[col];
-                if (g.flags & NM_GEMM_RELU) x = fmaxf(x, 0.f);
-                if (g.flags & NM_GEMM_MASK) x = g.mask[(int64_t)row * g.ldmask + col] > 0.f ? x : 0.f;
-                *c = x;
-            }
-        }
+    store_tile(g, acc, m0, n0, wm, wn, lane);
 }
 
 // ---- the same product on the bf16 MFMA, each float32 operand split into bf16 hi + lo (RNE both times; x - hi is exact in f32)
@@ -229,26 +248,7 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmArgs g) {
                 }
         }
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn + 32 * j + (lane & 31);
-            if (col >= g.N) continue;
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int row = m0 + wm + 32 * i + 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3);
-                if (row >= g.M) continue;
-                float x = acc[i][j][v];
-                if (g.partial) { g.partial[((int64_t)blockIdx.z * g.M + row) * g.N + col] = x; continue; }
-                float* c = g.C + (int64_t)row * g.ldc + col;
-                if (g.flags & NM_GEMM_ACCUMULATE) x += *c;
-                if (g.flags & NM_GEMM_BIAS) x += g.bias[col];
-                if (g.flags & NM_GEMM_RELU) x = fmaxf(x, 0.f);
-                if (g.flags & NM_GEMM_MASK) x = g.mask[(int64_t)row * g.ldmask + col] > 0.f ? x : 0.f;
-                *c = x;
-            }
-        }
+    store_tile(g, acc, m0, n0, wm, wn, lane);
 }
 
 // second pass of split-K: C (+)= sum over the splits, in split order
