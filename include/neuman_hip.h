@@ -273,6 +273,11 @@ int nm_shot_rays(const int32_t* xy, int64_t n, int width, int mode, const double
  * ------------------------------------------------------------------------------------------- */
 int nm_frame_to_uint8(const float* src, int64_t n, uint8_t* dst, nm_stream_t stream);
 int nm_ssd_u8(const uint8_t* a, const uint8_t* b, int64_t n, uint64_t* ssd, nm_stream_t stream);
+/* skimage.metrics.structural_similarity(pred, gt, multichannel=True) as render_test_views.py:33 calls it, for uint8 [H,W,C]
+ * images: 7x7 uniform window, K1 0.01, K2 0.03, data range 255, sample covariance, mean over the image cropped by 3 pixels
+ * and over channels.  ssim: device double[1]; workspace: device double[NM_SSIM_WORKSPACE_DOUBLES]. */
+#define NM_SSIM_WORKSPACE_DOUBLES 4096
+int nm_ssim_u8(const uint8_t* a, const uint8_t* b, int H, int W, int C, double* ssim, double* workspace, nm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * SURVEY 8f-1 (first slice): device primitives of a training step of the background NeRF --

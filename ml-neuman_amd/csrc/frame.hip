@@ -89,6 +89,45 @@ __global__ __launch_bounds__(256) void ssd_u8_kernel(const uint8_t* __restrict__
     if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
+// skimage.metrics.structural_similarity(pred, gt, multichannel=True) for uint8 images, its defaults (render_test_views.py:33):
+// 7 x 7 uniform window, K1 = 0.01, K2 = 0.03, data range 255, sample covariance (x 49/48), the mean of the SSIM map over the image
+// cropped by 3 pixels per side, then the mean over channels.  The five window sums are exact integers; the map is f64 as skimage
+// computes it.  One thread per (pixel of the cropped region, channel); per-block partial sums, then one block adds them in order.
+constexpr int kSsimWin = 7, kSsimPad = 3;
+__global__ __launch_bounds__(256) void ssim_partial_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int H, int W, int C,
+                                                           double* __restrict__ partial) {
+    const int hh = H - 2 * kSsimPad, ww = W - 2 * kSsimPad;
+    const int64_t n = (int64_t)hh * ww * C;
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int x = (int)((i / C) % ww) + kSsimPad, y = (int)(i / ((int64_t)C * ww)) + kSsimPad;
+        int sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+        for (int dy = -kSsimPad; dy <= kSsimPad; ++dy)
+            for (int dx = -kSsimPad; dx <= kSsimPad; ++dx) {
+                const int64_t o = ((int64_t)(y + dy) * W + (x + dx)) * C + c;
+                const int p = a[o], q = b[o];
+                sx += p; sy += q; sxx += p * p; syy += q * q; sxy += p * q;
+            }
+        const double NP = kSsimWin * kSsimWin, cov = NP / (NP - 1.0);
+        const double ux = sx / NP, uy = sy / NP, uxx = sxx / NP, uyy = syy / NP, uxy = sxy / NP;
+        const double vx = cov * (uxx - ux * ux), vy = cov * (uyy - uy * uy), vxy = cov * (uxy - ux * uy);
+        const double C1 = (0.01 * 255.0) * (0.01 * 255.0), C2 = (0.03 * 255.0) * (0.03 * 255.0);
+        s += ((2.0 * ux * uy + C1) * (2.0 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+__global__ void ssim_final_kernel(const double* __restrict__ partial, int blocks, double n, double* __restrict__ out) {
+    double s = 0.0;
+    for (int i = 0; i < blocks; ++i) s += partial[i];
+    out[0] = s / n;
+}
+
 }  // namespace
 
 extern "C" {
@@ -126,6 +165,17 @@ int nm_ssd_u8(const uint8_t* a, const uint8_t* b, int64_t n, uint64_t* ssd, nm_s
     hipLaunchKernelGGL(ssd_u8_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, nm::as_stream(stream), a, b, n,
                        reinterpret_cast<unsigned long long*>(ssd));
     return nm::check_launch("ssd_u8_kernel");
+}
+
+int nm_ssim_u8(const uint8_t* a, const uint8_t* b, int H, int W, int C, double* ssim, double* workspace, nm_stream_t stream) {
+    NM_REQUIRE(H >= kSsimWin && W >= kSsimWin && C >= 1, "nm_ssim_u8: the image must be at least 7 x 7 (H=%d W=%d C=%d)", H, W, C);
+    NM_REQUIRE(a && b && ssim && workspace, "nm_ssim_u8: null pointer");
+    hipStream_t st = nm::as_stream(stream);
+    const int64_t n = (int64_t)(H - 2 * kSsimPad) * (W - 2 * kSsimPad) * C;
+    const int blocks = (int)((n + 255) / 256 < NM_SSIM_WORKSPACE_DOUBLES ? (n + 255) / 256 : NM_SSIM_WORKSPACE_DOUBLES);
+    hipLaunchKernelGGL(ssim_partial_kernel, dim3(blocks), dim3(256), 0, st, a, b, H, W, C, workspace);
+    hipLaunchKernelGGL(ssim_final_kernel, dim3(1), dim3(1), 0, st, workspace, blocks, (double)n, ssim);
+    return nm::check_launch("ssim kernels");
 }
 
 }  // extern "C"

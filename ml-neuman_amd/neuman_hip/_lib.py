@@ -69,6 +69,7 @@ SIGNATURES = {
     "nm_pe_backward": (i32, [c_f32p, i64, i32, i32, i32, c_f32p, c_f32p, i32, c_f32p, c_stream]),
     "nm_composite_backward": (i32, [c_f32p, c_f32p, c_f32p, i64, i32, i32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "nm_signed_distance": (i32, [ctypes.c_void_p, c_f32p, i64, c_f32p, c_i32p, c_f32p, c_stream]),
+    "nm_ssim_u8": (i32, [ctypes.c_void_p, ctypes.c_void_p, i32, i32, i32, ctypes.c_void_p, ctypes.c_void_p, c_stream]),
     "nm_merge_sorted": (i32, [c_f32p, c_f32p, i32, c_f32p, c_f32p, i32, i64, c_f32p, c_f32p, c_stream]),
     "nm_gather_rows": (i32, [c_f32p, c_i32p, c_i32p, i64, i32, c_f32p, c_stream]),
     "nm_scatter_rows": (i32, [c_f32p, c_i32p, c_i32p, i64, i32, c_f32p, c_stream]),

@@ -266,6 +266,20 @@ def psnr_uint8(gt, pred):
     return float('inf') if mse == 0 else 10.0 * float(np.log10(255.0 ** 2 / mse))
 
 
+def ssim_uint8(pred, gt):
+    """skimage.metrics.structural_similarity(pred, gt, multichannel=True) for uint8 [H,W,C] frames (render_test_views.py:33)."""
+    _lib.require_gpu()
+    if gt.dtype != torch.uint8 or pred.dtype != torch.uint8 or gt.shape != pred.shape or gt.dim() != 3 or not (gt.is_cuda and pred.is_cuda):
+        raise _lib.NeumanHipError("ssim_uint8 takes two CUDA uint8 tensors [H,W,C] of the same shape")
+    gt, pred = gt.contiguous(), pred.contiguous()
+    out = torch.empty(1, device=gt.device, dtype=torch.float64)
+    ws = torch.empty(4096, device=gt.device, dtype=torch.float64)
+    H, W, C = gt.shape
+    _lib.check(_lib.lib().nm_ssim_u8(ctypes.c_void_p(pred.data_ptr()), ctypes.c_void_p(gt.data_ptr()), H, W, C, ctypes.c_void_p(out.data_ptr()),
+                                     ctypes.c_void_p(ws.data_ptr()), _lib.stream_ptr()), "nm_ssim_u8")
+    return float(out.item())
+
+
 def render_vanilla(coarse_net, cap, fine_net=None, rays_per_batch=32768, samples_per_ray=64, importance_samples_per_ray=128,
                    white_bkg=True, near_far_source='bkg', return_depth=False, ablate_nerft=False):
     """reference render_utils.py:108-161."""

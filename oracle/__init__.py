@@ -31,7 +31,7 @@ Pinning status
 * train (one training step of the background NeRF: losses and parameter gradients): PINNED against the
   reference's own ``NeRFTrainer.loss_func`` + ``backward()`` (``tests/golden/make_golden_train.py`` ->
   ``tests/golden/train.npz``); ``oracle/train.py`` is torch float64 + autograd.
-* frame (float -> uint8, uint8 PSNR): **parity unpinned**.  imageio and
+* frame (float -> uint8, uint8 PSNR, SSIM): **parity unpinned**.  imageio and
   scikit-image (environment.yml:22, :30, no versions) are absent;
   ``oracle/frame.py`` restates their published rules.
 """

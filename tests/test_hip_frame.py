@@ -129,3 +129,19 @@ def test_frame_roundtrip_properties_full_size(H):
     assert H.render.psnr_uint8(u, v) == H.render.psnr_uint8(v, u)
     with pytest.raises(Exception):
         H.render.psnr_uint8(u.cpu(), v.cpu())
+
+
+@pytest.mark.parametrize("shape", [(7, 7, 1), (31, 45, 3), (200, 320, 3), (800, 800, 3)])
+def test_ssim_vs_oracle(H, shape):
+    """nm_ssim_u8 vs oracle/frame.py:ssim_uint8 (scipy uniform_filter, as scikit-image computes it)"""
+    rng = np.random.default_rng(shape[0])
+    yy, xx = np.mgrid[:shape[0], :shape[1]]
+    base = (127 + 100 * np.sin(xx / 9.0)[..., None] * np.cos(yy / 13.0)[..., None] + rng.normal(0, 6, shape)).clip(0, 255)
+    gt = base.astype(np.uint8)
+    pred = (base + rng.normal(0, 9, shape)).clip(0, 255).astype(np.uint8)
+    got = H.render.ssim_uint8(torch.as_tensor(pred, device='cuda'), torch.as_tensor(gt, device='cuda'))
+    ref = OF.ssim_uint8(pred, gt)
+    assert got == pytest.approx(ref, abs=1e-12), (got, ref)
+    assert 0.0 < got < 1.0
+    assert H.render.ssim_uint8(torch.as_tensor(gt, device='cuda'), torch.as_tensor(gt, device='cuda')) == pytest.approx(1.0, abs=1e-15)
+    assert H.render.ssim_uint8(torch.as_tensor(gt, device='cuda'), torch.as_tensor(pred, device='cuda')) == pytest.approx(got, abs=1e-15)   # symmetric

@@ -43,3 +43,18 @@ def test_signed_distance_sign_is_the_winding_number():
     wn = OW.winding_number(pts, posed, faces)
     assert ((S < 0) == (wn > 0.5)).all() and 0.1 < (S < 0).mean() < 0.9
     np.testing.assert_allclose(np.abs(S), np.linalg.norm(C - pts, axis=1), atol=1e-6)
+
+
+def test_ssim_known_properties():
+    from oracle import frame as OF
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (40, 50, 3), dtype=np.uint8)
+    assert OF.ssim_uint8(a, a) == 1.0
+    b = (a.astype(np.int32) + rng.integers(-20, 21, a.shape)).clip(0, 255).astype(np.uint8)
+    s = OF.ssim_uint8(a, b)
+    assert 0.5 < s < 1.0 and abs(s - OF.ssim_uint8(b, a)) < 1e-15
+    # a constant image against another constant: only the luminance term is left: (2 u v + C1) / (u^2 + v^2 + C1)
+    u, v = 100.0, 140.0
+    c1 = (0.01 * 255) ** 2
+    s = OF.ssim_uint8(np.full((9, 9, 1), 100, np.uint8), np.full((9, 9, 1), 140, np.uint8))
+    assert abs(s - (2 * u * v + c1) / (u * u + v * v + c1)) < 1e-12
