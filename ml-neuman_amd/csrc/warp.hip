@@ -29,10 +29,6 @@
 
 namespace {
 
-// at least five waves per SIMD for the search (it needs 38 VGPRs; the bound matters when the kernel grows)
-#ifndef NM_WARP_ATTR
-#define NM_WARP_ATTR __attribute__((amdgpu_waves_per_eu(5)))
-#endif
 constexpr int kMaxLevels = 12;           // 4^12 = 16.7 M triangles
 
 // A triangle as the exact test wants it: a corner, the two edges from it, and every quantity of the Voronoi-region test that
@@ -58,10 +54,7 @@ struct Tree {
 // written or read: the parent's record holds the empty box for them.
 __host__ __device__ inline int level_base(int l) { return (int)(((1ll << (2 * l)) - 1) / 3); }
 
-#ifndef NM_WARP_PENDING
-#define NM_WARP_PENDING 8
-#endif
-constexpr int kPending = NM_WARP_PENDING;              // a lane keeps walking until it holds this many untested triangles
+constexpr int kPending = 8;              // a lane keeps walking until it holds this many untested triangles
 constexpr int kTriSlots = kPending + 3;  // one more expansion can add four
 
 // ---- build ---------------------------------------------------------------------------------------------------------
@@ -316,15 +309,15 @@ __device__ __forceinline__ void cswap(uint32_t& a, uint32_t& b) {               
 // Lanes walk ahead of their tests ("speculative traversal"), so pending triangles are tested against a slightly stale
 // bound; that costs a few extra tests and cannot change the result (any superset of the contenders gives the same
 // minimum, ties going to the lowest face id).
-// Output: q -> q_out[i*3 ..], face -> f_out[i*3] (the caller passes can_pts / can_dirs: tail_kernel consumes and overwrites them).
+// Output: q -> q_out[i*3 ..], face -> f_out[i * f_stride] (the warp passes can_pts / can_dirs with stride 3: tail_kernel consumes
+// and overwrites them; nm_signed_distance passes its own arrays with stride 1).
+// The three constants below were swept on the posed-frame workload (pending 4 / 6 / 8 / 12: 8.2 / 8.0 / 7.8 / 7.8 ms; refill
+// threshold 3 / 8: 8.2 / 7.8 ms).
 constexpr int kChunk = 512;
-#ifndef NM_WARP_REFILL
-#define NM_WARP_REFILL 8
-#endif
-constexpr int kRefill = NM_WARP_REFILL;               // idle lanes that trigger a refill (or any, when no lane has work)
+constexpr int kRefill = 8;                            // idle lanes that trigger a refill (or any, when no lane has work)
 
 template <bool SMALL>
-__global__ __launch_bounds__(64) NM_WARP_ATTR void search_kernel(Tree tr, int search_all_mode, const float* __restrict__ pts, int64_t N,
+__global__ __launch_bounds__(64) void search_kernel(Tree tr, int search_all_mode, const float* __restrict__ pts, int64_t N,
                                                                  const TriRec* __restrict__ rec, const int32_t* __restrict__ face_of,
                                                                  const Node* __restrict__ nodes, float* __restrict__ q_out,
                                                                  int32_t* __restrict__ f_out, int f_stride) {
