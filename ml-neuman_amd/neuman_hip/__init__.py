@@ -20,7 +20,7 @@ _RAY_FNS = ["shot_ray", "shot_rays", "shot_all_rays", "to_homogeneous", "ray_to_
             "warp_samples_to_canonical", "warp_samples_to_canonical_diff",
             "shot_all_rays_dev", "shot_rays_dev"]                      # additions: a1 on the device (CUDA tensors out)
 _RENDER_FNS = ["raw2outputs", "render_vanilla", "render_smpl_nerf", "render_hybrid_nerf", "render_hybrid_nerf_multi_persons",
-               "frame_to_uint8", "psnr_uint8", "ssim_uint8"]                        # additions: the egress of render_test_views.py:83-92, on the device
+               "frame_to_uint8", "psnr_uint8", "ssim_uint8", "save_png"]                        # additions: the egress of render_test_views.py:83-92, on the device
 _MODEL_CLASSES = ["Embedder", "NeRF", "Joiner", "build_nerf", "OffsetNet", "build_offset_net"]
 
 

@@ -266,6 +266,31 @@ def psnr_uint8(gt, pred):
     return float('inf') if mse == 0 else 10.0 * float(np.log10(255.0 ** 2 / mse))
 
 
+def save_png(path, frame):
+    """imageio.imsave(path, frame) for the renderers' output (render_test_views.py:83-88, render_360.py:77-81): a float frame goes
+    through `frame_to_uint8` on the device, then an 8-bit RGB / grey PNG is written with the standard library (zlib): same
+    pixels as imageio's file, not the same bytes (deflate settings differ)."""
+    import struct
+    import zlib
+    if isinstance(frame, np.ndarray):
+        frame = torch.as_tensor(np.ascontiguousarray(frame))
+    if frame.dtype != torch.uint8:
+        frame = frame_to_uint8(frame.to('cuda', torch.float32))
+    a = frame.cpu().numpy()
+    if a.ndim == 2:
+        a = a[..., None]
+    h, w, c = a.shape
+    if c not in (1, 3, 4):
+        raise ValueError(f"save_png: {c} channels")
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), a.reshape(h, w * c)], 1).tobytes()          # filter type 0 on every row
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, {1: 0, 3: 2, 4: 6}[c], 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
 def ssim_uint8(pred, gt):
     """skimage.metrics.structural_similarity(pred, gt, multichannel=True) for uint8 [H,W,C] frames (render_test_views.py:33)."""
     _lib.require_gpu()

@@ -145,3 +145,29 @@ def test_ssim_vs_oracle(H, shape):
     assert 0.0 < got < 1.0
     assert H.render.ssim_uint8(torch.as_tensor(gt, device='cuda'), torch.as_tensor(gt, device='cuda')) == pytest.approx(1.0, abs=1e-15)
     assert H.render.ssim_uint8(torch.as_tensor(gt, device='cuda'), torch.as_tensor(pred, device='cuda')) == pytest.approx(got, abs=1e-15)   # symmetric
+
+
+def test_save_png_roundtrip(H, tmp_path):
+    """the PNG written from a float frame decodes (independent mini-decoder: zlib + filter 0) to imageio's uint8 pixels"""
+    import struct
+    import zlib
+    rng = np.random.default_rng(2)
+    x = rng.uniform(-0.02, 1.02, (37, 53, 3)).astype(np.float32)
+    p = tmp_path / "frame.png"
+    H.render.save_png(str(p), x)
+    b = p.read_bytes()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, hdr = 8, b"", None
+    while pos < len(b):
+        n, tag = struct.unpack(">I", b[pos:pos + 4])[0], b[pos + 4:pos + 8]
+        data = b[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", b[pos + 8 + n:pos + 12 + n])[0] == (zlib.crc32(tag + data) & 0xffffffff)
+        if tag == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", data)
+        if tag == b"IDAT":
+            idat += data
+        pos += 12 + n
+    assert hdr == (53, 37, 8, 2, 0, 0, 0)
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(37, 1 + 53 * 3)
+    assert (rows[:, 0] == 0).all()
+    np.testing.assert_array_equal(rows[:, 1:].reshape(37, 53, 3), OF.to_uint8(x.reshape(-1)).reshape(37, 53, 3))
