@@ -16,12 +16,24 @@ def rank_world():
     return 0, 1
 
 
+_INDEX_CACHE = {}
+
+
 def tile_ray_indices(total_rays, tile, rank, world, device='cpu'):
-    """Global ray indices owned by `rank`: tiles rank, rank+world, ... of `tile` consecutive rays each."""
+    """Global ray indices owned by `rank`: tiles rank, rank+world, ... of `tile` consecutive rays each.  Cached: the frame
+    assembly on rank 0 asks for every rank's list once per frame, and the mask below costs a host sync on a GPU."""
+    key = (int(total_rays), int(tile), int(rank), int(world), str(device))
+    hit = _INDEX_CACHE.get(key)
+    if hit is not None:
+        return hit
     n_tiles = (total_rays + tile - 1) // tile
     tiles = torch.arange(rank, n_tiles, world, device=device)
     idx = (tiles[:, None] * tile + torch.arange(tile, device=device)[None, :]).reshape(-1)
-    return idx[idx < total_rays]
+    idx = idx[idx < total_rays]
+    if len(_INDEX_CACHE) > 256:
+        _INDEX_CACHE.clear()
+    _INDEX_CACHE[key] = idx
+    return idx
 
 
 def max_local_rays(total_rays, tile, world):
