@@ -42,6 +42,9 @@ typedef void* nm_stream_t;
                             int32 accumulate), encodings on split bf16: composited colours within 2e-5 of f32 on identical
                             samples -- parity grade for passes that are only composited (the host's default policy uses it
                             there), NOT for a pass whose weights place importance samples */
+#define NM_PREC_FP16X3 4 /* split-fp16 (hi+lo, 11+11 significand bits) x3 MFMA, f32 accumulate, exact power-of-two operand
+                            scalings: float32-class results (sigma within ~2e-6 of an f64 evaluation, as an f32 sgemm is)
+                            at the bf16x3 price -- the arithmetic of a pass whose weights place importance samples      */
 
 /* positional-encoding kinds (reference models/vanilla.py:44-79) */
 #define NM_PE_POSENC 0 /* [x, sin(f0 x), cos(f0 x), sin(f1 x), ...]   vanilla.py:60-79,92 */
@@ -131,6 +134,9 @@ typedef struct nm_mlp_desc {
 int64_t nm_mlp_pack_bytes(const nm_mlp_desc* desc);
 /* host-only: write the packed weight image (what nm_mlp_create uploads) into host_out. */
 int nm_mlp_pack(const nm_mlp_desc* desc, const float* const* host_params, void* host_out);
+/* host-only: the NM_PREC_FP16X3 image -- same size and fragment layout, split fp16 of W * 2^8, biases * 2^13 (the exact
+ * power-of-two scalings that keep both parts of every operand inside fp16's normal range; csrc/mlp.hip). */
+int nm_mlp_pack_f16(const nm_mlp_desc* desc, const float* const* host_params, void* host_out);
 /* host-only: the NM_PREC_I8X3 image by stage and block (limb fragments | pad | per-feature units | biases in those
  * units | one scalar per stage); nm_mlp_create uploads its fragments re-ordered into per-wave streams. */
 int64_t nm_mlp_pack_i8_bytes(const nm_mlp_desc* desc);

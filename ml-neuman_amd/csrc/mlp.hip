@@ -26,6 +26,18 @@ using nm::kTileM;
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+// NM_PREC_FP16X3: the same three-product scheme on split fp16 (11 + 11 significand bits instead of 8 + 8: the dropped
+// wl*xl term and the representation error are ~2^-22, float32 class).  fp16's narrow exponent range is handled by exact
+// power-of-two scalings: weights are stored as W * 2^8 (a weight's lo part stays a normal number down to |W| ~ 5e-4),
+// activations and encodings as X * 2^5 (lo normal down to |X| ~ 4e-3, hi finite up to |X| = 2047); accumulators therefore
+// carry Y * 2^13 (biases are pre-scaled) and the epilogue multiplies by 2^-8 before the split.  Parts that fall below
+// fp16's normal range lose at most 2^-25 * 2^-5 (activations) / 2^-25 * 2^-8 (weights) absolutely, flushed or not.
+constexpr bool is_split(int prec) { return prec == NM_PREC_BF16X3 || prec == NM_PREC_FP16X3; }
+constexpr float kF16ActScale = 32.f, kF16WScale = 256.f;
+constexpr float kF16AccToAct = 1.f / kF16WScale, kF16AccToOut = 1.f / (kF16ActScale * kF16WScale);
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -93,13 +105,26 @@ __device__ __forceinline__ float pe_feature(int p, float x0, float x1, float x2,
     return is_cos ? cv : sv;
 }
 
-// split 8 f32 into bf16 hi and lo chunks (RNE both times; x - float(hi) is exact in f32)
-template <bool RELU>
-__device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
+// split 8 f32 into 16-bit hi and lo chunks (RNE both times; x - float(hi) is exact in f32).  F16: fp16 parts of
+// v * scale (scale a power of two: exact), clamped below fp16's overflow so that a huge activation saturates instead of
+// becoming inf - inf = NaN.
+template <bool RELU, bool F16 = false>
+__device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo, float scale = 1.f) {
     unsigned h[4], l[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         f32x2 a = {v[2 * p], v[2 * p + 1]};
+        if (F16) {
+            a.x = __builtin_amdgcn_fmed3f(a.x * scale, RELU ? 0.f : -65504.f, 65504.f);
+            a.y = __builtin_amdgcn_fmed3f(a.y * scale, RELU ? 0.f : -65504.f, 65504.f);
+            const f16x2 hb = __builtin_convertvector(a, f16x2);
+            const f32x2 hf = __builtin_convertvector(hb, f32x2);
+            const f32x2 r = {a.x - hf.x, a.y - hf.y};
+            const f16x2 lb = __builtin_convertvector(r, f16x2);
+            h[p] = __builtin_bit_cast(unsigned, hb);
+            l[p] = __builtin_bit_cast(unsigned, lb);
+            continue;
+        }
         if (RELU) {
             a.x = fmaxf(a.x, 0.f);
             a.y = fmaxf(a.y, 0.f);
@@ -139,31 +164,31 @@ __device__ __forceinline__ void w_prefetch(WPre& W, __amdgpu_buffer_rsrc_t wsrc,
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         W.h[u] = ld_w(wsrc, voff, soff + u * nm::kStepBytes);
-        if (PREC == NM_PREC_BF16X3) W.l[u] = ld_w(wsrc, voff, soff + u * nm::kStepBytes + 1024);
-#ifdef NM_L2_PROBE   // experiment: double the L2 -> CU weight traffic (second, distinct 2 KB per step) to measure headroom
-        bf16x8 d0 = ld_w(wsrc, voff, (soff + u * nm::kStepBytes + 65536) % (2 * 1024 * 1024));
-        bf16x8 d1 = ld_w(wsrc, voff, (soff + u * nm::kStepBytes + 65536 + 1024) % (2 * 1024 * 1024));
-        asm volatile("" ::"v"(d0), "v"(d1));
-#endif
+        if (is_split(PREC)) W.l[u] = ld_w(wsrc, voff, soff + u * nm::kStepBytes + 1024);
     }
 }
 
-#ifndef NM_PRIO_MODE
-#define NM_PRIO_MODE 0      // experiment knob (tools/mlp_profile.py): MFMA-pipe arbitration between the two waves of a SIMD
-#endif
-#ifndef NM_X_PIPE
-#define NM_X_PIPE 0         // 1: also software-pipeline the activation fragments of the bf16x3 k-loops (measured: -2.5 %)
-#endif
 template <int MB, int PREC>
 __device__ __forceinline__ void x_load(uint4 (&h)[MB], uint4 (&l)[MB], const uint4* ph) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) {
         h[mb] = ph[mb * 32];
-        if (PREC == NM_PREC_BF16X3) l[mb] = ph[kLoU4 + mb * 32];
+        if (is_split(PREC)) l[mb] = ph[kLoU4 + mb * 32];
     }
 }
+__device__ __forceinline__ f16x8 as_f16x8(uint4 v) { return __builtin_bit_cast(f16x8, v); }
 template <int MB, int PREC>
 __device__ __forceinline__ void mfma_step(f32x16 (&acc)[MB], bf16x8 wh, bf16x8 wl, const uint4 (&xh)[MB], const uint4 (&xl)[MB]) {
+    if (PREC == NM_PREC_FP16X3) {                       // (the fragment registers hold fp16 bit patterns in this mode)
+        const f16x8 fh = __builtin_bit_cast(f16x8, wh), fl = __builtin_bit_cast(f16x8, wl);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, as_f16x8(xl[mb]), acc[mb], 0, 0, 0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl, as_f16x8(xh[mb]), acc[mb], 0, 0, 0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, as_f16x8(xh[mb]), acc[mb], 0, 0, 0);
+        return;
+    }
     if (PREC == NM_PREC_BF16X3) {
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, as_bf16x8(xl[mb]), acc[mb], 0, 0, 0);
@@ -175,11 +200,11 @@ __device__ __forceinline__ void mfma_step(f32x16 (&acc)[MB], bf16x8 wh, bf16x8 w
 }
 template <int MB, int PREC>
 __device__ __forceinline__ void k_run(f32x16 (&acc)[MB], WPre& W, __amdgpu_buffer_rsrc_t wsrc, int voff, int soff, int next_soff,
-                                      const uint4* xh, int nsteps, bool prio_phase = false) {
+                                      const uint4* xh, int nsteps) {
     // Activation fragments of step t + 1 requested before the MFMAs of step t (two register sets): pays for the single-MFMA
     // NM_PREC_BF16 steps (+6 %), where an LDS round trip per step is exposed; with three MFMAs per step (bf16x3) the partner
     // wave of the SIMD already covers it and the extra registers cost more than they buy (-2.5 %, same GPU, A/B).
-    if (NM_X_PIPE || PREC == NM_PREC_BF16) {
+    if (PREC == NM_PREC_BF16) {
     uint4 xah[MB], xal[MB];
     x_load<MB, PREC>(xah, xal, xh);
 #pragma unroll 1
@@ -210,11 +235,6 @@ __device__ __forceinline__ void k_run(f32x16 (&acc)[MB], WPre& W, __amdgpu_buffe
         for (int u = 0; u < 2; ++u) {
             uint4 bh[MB], bl[MB];
             x_load<MB, PREC>(bh, bl, xh + (t + u) * (2 * kChunkU4));
-#if NM_PRIO_MODE == 2
-            __builtin_amdgcn_s_setprio(u == 0 ? 1 : 0);
-#elif NM_PRIO_MODE == 3
-            __builtin_amdgcn_s_setprio((u == 0) != prio_phase ? 1 : 0);
-#endif
             mfma_step<MB, PREC>(acc, W.h[u], W.l[u], bh, bl);
         }
         W = N;
@@ -245,18 +265,11 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[MB], const BiasRegs& B) 
 // The epilogue is split around the "all reads of H done" barrier: the VALU half (ReLU + hi/lo split) runs BEFORE it --
 // the wave that finishes its k-loop first (the older wave of each SIMD wins MFMA arbitration) converts while its partner
 // is still issuing MFMAs, on the otherwise idle VALU -- and only the ds_write_b128s remain after the barrier.
-#ifdef NM_EPI_LATE      // experiment knob: convert after the barrier (the pre-split behaviour)
-#define NM_BAR_A __syncthreads();
-#define NM_BAR_B
-#else
-#define NM_BAR_A
-#define NM_BAR_B __syncthreads();
-#endif
 template <int MB>
 struct ActRegs {
     uint4 hi[MB][2], lo[MB][2];
 };
-template <int MB, bool RELU>
+template <int MB, bool RELU, int PREC>
 __device__ __forceinline__ void convert_act(const f32x16 (&acc)[MB], ActRegs<MB>& r) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
@@ -265,7 +278,7 @@ __device__ __forceinline__ void convert_act(const f32x16 (&acc)[MB], ActRegs<MB>
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = acc[mb][8 * qp + e];
-            split8<RELU>(v, r.hi[mb][qp], r.lo[mb][qp]);
+            split8<RELU, PREC == NM_PREC_FP16X3>(v, r.hi[mb][qp], r.lo[mb][qp], kF16AccToAct);
         }
 }
 template <int MB, int PREC>
@@ -276,12 +289,13 @@ __device__ __forceinline__ void write_act(const ActRegs<MB>& r, uint4* lds, int 
         for (int qp = 0; qp < 2; ++qp) {
             const int idx = H_BASE + (4 * blk + 2 * qp + g) * kChunkU4 + row0 + 32 * mb + s;
             lds[idx] = r.hi[mb][qp];
-            if (PREC == NM_PREC_BF16X3) lds[idx + kLoU4] = r.lo[mb][qp];
+            if (is_split(PREC)) lds[idx + kLoU4] = r.lo[mb][qp];
         }
 }
 
 // fill `nchunks` PE chunks for the tile: work item = (chunk, sample); 8 features -> one b128 write per array
 // (`nthreads` threads numbered by tid cover rows row0 .. row0 + 2^rshift - 1: the whole tile, or one wave group's half)
+template <bool F16 = false>
 __device__ __forceinline__ void fill_pe(uint4* lds, int nchunks, bool is_dir, const MlpArgs& a, int64_t base, int tid,
                                         int nthreads = kThreads, int row0 = 0, int rshift = 7) {
     const PeSpec spec = is_dir ? a.dir : a.pos;
@@ -311,7 +325,7 @@ __device__ __forceinline__ void fill_pe(uint4* lds, int nchunks, bool is_dir, co
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = pe_feature(8 * c + e, x0, x1, x2, spec, tab);
         uint4 hi, lo;
-        split8<false>(v, hi, lo);
+        split8<false, F16>(v, hi, lo, kF16ActScale);
         lds[P_BASE + c * kChunkU4 + row] = hi;
         lds[P_BASE + c * kChunkU4 + kLoU4 + row] = lo;
     }
@@ -345,6 +359,7 @@ __device__ __forceinline__ void sincos_f64(double a, double& sn, double& cs) {
     if (q >= 2) sn = -sn;
 }
 
+template <bool F16 = false>
 __device__ __forceinline__ void fill_pe_fast(uint4* lds, bool is_dir, const MlpArgs& a, int64_t base, int tid, int row0 = 0,
                                              int rshift = 7) {
     const PeSpec spec = is_dir ? a.dir : a.pos;
@@ -375,10 +390,18 @@ __device__ __forceinline__ void fill_pe_fast(uint4* lds, bool is_dir, const MlpA
     unsigned short* hi = reinterpret_cast<unsigned short*>(lds + P_BASE);
     unsigned short* lo = hi + kLoU4 * 8;
     auto put = [&](int p, float v) {                          // feature slot p of this row: chunk p>>3, element p&7
+        const int off = ((p >> 3) * kChunkU4 + row) * 8 + (p & 7);
+        if (F16) {
+            const float sv = v * kF16ActScale;                    // |v| <= max(1, |x|): far below fp16's range after scaling
+            const _Float16 hb = (_Float16)sv;
+            const _Float16 lb = (_Float16)(sv - (float)hb);
+            hi[off] = __builtin_bit_cast(unsigned short, hb);
+            lo[off] = __builtin_bit_cast(unsigned short, lb);
+            return;
+        }
         const bf16x2 hb = __builtin_convertvector((f32x2){v, 0.f}, bf16x2);
         const f32x2 hf = __builtin_convertvector(hb, f32x2);
         const bf16x2 lb = __builtin_convertvector((f32x2){v - hf.x, 0.f}, bf16x2);
-        const int off = ((p >> 3) * kChunkU4 + row) * 8 + (p & 7);
         hi[off] = (unsigned short)(__builtin_bit_cast(unsigned, hb) & 0xffffu);
         lo[off] = (unsigned short)(__builtin_bit_cast(unsigned, lb) & 0xffffu);
     };
@@ -400,13 +423,15 @@ __device__ __forceinline__ void fill_pe_fast(uint4* lds, bool is_dir, const MlpA
     }
 }
 
+template <bool F16 = false>
 __device__ __forceinline__ void fill_pe_any(uint4* lds, bool is_dir, const MlpArgs& a, int64_t base, int tid,
                                             int nthreads = kThreads, int row0 = 0, int rshift = 7) {
-    if ((is_dir ? a.dir : a.pos).octaves) fill_pe_fast(lds, is_dir, a, base, tid, row0, rshift);
-    else fill_pe(lds, is_dir ? 4 : nm::kPeChunks, is_dir, a, base, tid, nthreads, row0, rshift);
+    if ((is_dir ? a.dir : a.pos).octaves) fill_pe_fast<F16>(lds, is_dir, a, base, tid, row0, rshift);
+    else fill_pe<F16>(lds, is_dir ? 4 : nm::kPeChunks, is_dir, a, base, tid, nthreads, row0, rshift);
 }
 
 // debug: dump `width` features of the tile from the H (or P) arrays as f32 [n, width] in natural order
+template <bool F16 = false>
 __device__ __forceinline__ void dump_act(const uint4* lds, bool from_pe, int width, const MlpArgs& a, int64_t base, int tid,
                                          int nthreads = kThreads, int row0 = 0, int nrows = kTileM) {
     const unsigned short* hi = reinterpret_cast<const unsigned short*>(lds + (from_pe ? P_BASE : H_BASE));
@@ -417,6 +442,11 @@ __device__ __forceinline__ void dump_act(const uint4* lds, bool from_pe, int wid
         const int c = from_pe ? (n >> 3) : nm::feature_chunk(n);
         const int e = from_pe ? (n & 7) : nm::feature_elem(n);
         const int off = (c * kChunkU4 + row) * 8 + e;
+        if (F16) {
+            a.dbg[(base + row) * width + n] = ((float)__builtin_bit_cast(_Float16, hi[off]) + (float)__builtin_bit_cast(_Float16, lo[off])) *
+                                              (1.f / kF16ActScale);
+            continue;
+        }
         const float h = __uint_as_float((unsigned)hi[off] << 16);
         const float l = __uint_as_float((unsigned)lo[off] << 16);
         a.dbg[(base + row) * width + n] = h + l;
@@ -436,6 +466,8 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
         t_prev = t_now;                                              \
     }
     __shared__ uint4 lds[LDS_U4];
+    constexpr bool F16 = PREC == NM_PREC_FP16X3;
+    constexpr float oscale = F16 ? kF16AccToOut : 1.f;            // accumulators of the fp16 mode carry Y * 2^13 (exact to undo)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -449,11 +481,6 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
     auto wo = [](int st, int blk) { return (int)nm::stage_w_off(st) + blk * nm::stage_shape(st).steps * nm::kStepBytes; };
     const int so_s0 = wo(0, w);
     const int so_s8a = wo(8, 8), so_s9 = wo(9, w & 3), so_s10 = wo(10, 0);
-#if NM_PRIO_MODE == 1
-    if (w >= 4) __builtin_amdgcn_s_setprio(1);
-#elif NM_PRIO_MODE == 4
-    if (w < 4) __builtin_amdgcn_s_setprio(1);
-#endif
     // pad slots of the encodings (63; 27..31) are never written by the octave path: give them a finite value once
     for (int i = tid; i < nm::kPeChunks * kChunkU4; i += kThreads) lds[P_BASE + i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -466,10 +493,10 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t base = tile * kTileM;
         // ---------------- position PE -> P
-        fill_pe_any(lds, false, a, base, tid);
+        fill_pe_any<F16>(lds, false, a, base, tid);
         __syncthreads();
         NM_TICK(0)
-        if (a.stop_stage == -1) { dump_act(lds, true, 64, a, base, tid); __syncthreads(); continue; }
+        if (a.stop_stage == -1) { dump_act<F16>(lds, true, 64, a, base, tid); __syncthreads(); continue; }
 
         // ---------------- stages 0..7: 256-wide ReLU layers (wave w = output block w, all 4 sample blocks)
         f32x16 acc[4];
@@ -482,24 +509,23 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
             const int next = (st == 7 && a.sigma_only) ? (w < 4 ? so_s8a : so_s0) : wo(st + 1, w);
             if (sh.pe_steps)
                 k_run<4, PREC>(acc, W, wsrc, voff, soff, sh.steps > sh.pe_steps ? soff + sh.pe_steps * nm::kStepBytes : next,
-                               lds + P_BASE + g * kChunkU4 + s, sh.pe_steps, w >= 4);
+                               lds + P_BASE + g * kChunkU4 + s, sh.pe_steps);
             if (sh.steps > sh.pe_steps)
                 k_run<4, PREC>(acc, W, wsrc, voff, soff + sh.pe_steps * nm::kStepBytes, next, lds + H_BASE + g * kChunkU4 + s,
-                               sh.steps - sh.pe_steps, w >= 4);
+                               sh.steps - sh.pe_steps);
             bias_prefetch(B, a.bias + nm::stage_b_off(st + 1) + 32 * w, g);     // next stage (st + 1 <= 8), block w
             NM_TICK(1)
-            NM_BAR_A
             ActRegs<4> ar;
-            convert_act<4, true>(acc, ar);
+            convert_act<4, true, PREC>(acc, ar);
             NM_TICK(3)
-            NM_BAR_B                                              // every wave has finished reading H (and P)
+            __syncthreads();                                              // every wave has finished reading H (and P)
             NM_TICK(2)
             write_act<4, PREC>(ar, lds, w, 0, g, s);
-            if (st == 5 && !a.sigma_only) fill_pe_any(lds, true, a, base, tid);   // P is free after the skip layer: direction PE -> P[0..3]
+            if (st == 5 && !a.sigma_only) fill_pe_any<F16>(lds, true, a, base, tid);   // P is free after the skip layer: direction PE -> P[0..3]
             NM_TICK(3)
             __syncthreads();
             NM_TICK(4)
-            if (a.stop_stage == st) { dump_act(lds, false, 256, a, base, tid); stopped = true; break; }
+            if (a.stop_stage == st) { dump_act<F16>(lds, false, 256, a, base, tid); stopped = true; break; }
         }
         if (stopped) {                                            // debug exit: restart the weight / bias pipelines
             __syncthreads();
@@ -519,7 +545,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
                 init_bias<1>(aacc, B);
                 k_run<1, PREC>(aacc, W, wsrc, voff, so_s8a, so_s0, lds + H_BASE + g * kChunkU4 + 32 * w + s, sh.steps);
                 const int64_t i = base + 32 * w + s;
-                if (g == 0 && i < a.n) reinterpret_cast<float4*>(a.out)[i] = make_float4(0.f, 0.f, 0.f, aacc[0][0] * a.sigma_scale);
+                if (g == 0 && i < a.n) reinterpret_cast<float4*>(a.out)[i] = make_float4(0.f, 0.f, 0.f, aacc[0][0] * oscale * a.sigma_scale);
             }
             bias_prefetch(B, a.bias + nm::stage_b_off(0) + 32 * w, g);
             NM_TICK(1)
@@ -539,22 +565,21 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
                 bias_prefetch(B, a.bias + nm::stage_b_off(8) + 32 * 8, g);
                 init_bias<1>(aacc, B);
                 k_run<1, PREC>(aacc, W, wsrc, voff, so_s8a, so_s9, lds + H_BASE + g * kChunkU4 + 32 * w + s, sh.steps);
-                sigma = aacc[0][0];                               // feature row 0 of the block: lanes 0..31 (g == 0)
+                sigma = aacc[0][0] * oscale;                      // feature row 0 of the block: lanes 0..31 (g == 0)
             }
             bias_prefetch(B, a.bias + nm::stage_b_off(9) + 32 * (w & 3), g);
             NM_TICK(1)
-            NM_BAR_A
             ActRegs<4> ar;
-            convert_act<4, false>(acc, ar);
+            convert_act<4, false, PREC>(acc, ar);
             NM_TICK(3)
-            NM_BAR_B
+            __syncthreads();
             NM_TICK(2)
             write_act<4, PREC>(ar, lds, w, 0, g, s);
             NM_TICK(3)
             __syncthreads();
             NM_TICK(4)
             if (a.stop_stage == 8) {
-                dump_act(lds, false, 256, a, base, tid);
+                dump_act<F16>(lds, false, 256, a, base, tid);
                 __syncthreads();
                 w_prefetch<PREC>(W, wsrc, voff, so_s0);
                 bias_prefetch(B, a.bias + nm::stage_b_off(0) + 32 * w, g);
@@ -574,18 +599,17 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
                            lds + P_BASE + g * kChunkU4 + row0 + s, sh.pe_steps);
             bias_prefetch(B, w < 4 ? a.bias + nm::stage_b_off(10) : a.bias + nm::stage_b_off(0) + 32 * w, g);
             NM_TICK(1)
-            NM_BAR_A
             ActRegs<2> ar;
-            convert_act<2, true>(vacc, ar);
+            convert_act<2, true, PREC>(vacc, ar);
             NM_TICK(3)
-            NM_BAR_B
+            __syncthreads();
             NM_TICK(2)
             write_act<2, PREC>(ar, lds, nb, row0, g, s);
             NM_TICK(3)
             __syncthreads();
             NM_TICK(4)
             if (a.stop_stage == 9) {
-                dump_act(lds, false, 128, a, base, tid);
+                dump_act<F16>(lds, false, 128, a, base, tid);
                 __syncthreads();
                 w_prefetch<PREC>(W, wsrc, voff, so_s0);
                 bias_prefetch(B, a.bias + nm::stage_b_off(0) + 32 * w, g);
@@ -602,7 +626,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
             bias_prefetch(B, a.bias + nm::stage_b_off(0) + 32 * w, g);
             const int64_t i = base + 32 * w + s;
             if (g == 0 && i < a.n)                                // rows 0,1,2 = regs 0,1,2 of the g == 0 half
-                reinterpret_cast<float4*>(a.out)[i] = make_float4(racc[0][0], racc[0][1], racc[0][2], sigma * a.sigma_scale);
+                reinterpret_cast<float4*>(a.out)[i] = make_float4(racc[0][0] * oscale, racc[0][1] * oscale, racc[0][2] * oscale, sigma * a.sigma_scale);
         }
         NM_TICK(1)
         __syncthreads();                                          // H / P are rewritten by the next tile
@@ -698,21 +722,10 @@ __device__ __forceinline__ void dump_act8(const uint4* lds, int width, const flo
 //     so at most 96 accumulator registers are live and nothing spills (scratch would evict the weights from L2).
 // Cost: both groups stream the whole weight image (2 x 1.2 MB per 128-sample tile = what bf16x3 streams).
 // =====================================================================================================================
-#ifndef NM_W_PRIO
-#define NM_W_PRIO 2          // issue priority of a wave inside its k-loop (its SIMD partner is in an epilogue)
-#endif
-#ifndef NM_E_PRIO
-#define NM_E_PRIO 0          // ... and outside it (epilogues, fills)
-#endif
-#ifndef NM_W_RING
-#define NM_W_RING 4          // k-steps of weights in flight per wave (8 VGPRs each)
-#endif
-#ifndef NM_W_XD
-#define NM_W_XD 1            // k-steps of activation fragments in flight
-#endif
-constexpr int kXD = NM_W_XD;
-constexpr int kRing = NM_W_RING;
-static_assert(kRing == 4 || kRing == 8, "runs are multiples of 4 steps");
+constexpr int kWPrio = 2;    // issue priority of a wave inside its k-loop (its SIMD partner is in an epilogue) ...
+constexpr int kEPrio = 0;    // ... and outside it (epilogues, fills)
+constexpr int kXD = 1;       // k-steps of activation fragments in flight
+constexpr int kRing = 4;     // k-steps of weights in flight per wave (8 VGPRs each); runs are multiples of 4 steps
 static_assert(kRing <= nm::kW8Pad, "the stream is padded for the ring's overrun");
 
 struct WStep {
@@ -753,7 +766,7 @@ __device__ __forceinline__ void w_run(i32x16 (&ah)[MB], i32x16 (&ac)[MB], f32x16
                 xq[d][1][m] = xh[d * (2 * kChunkU4) + kLoU4 + m * 32];
             }
         }
-    __builtin_amdgcn_s_setprio(NM_W_PRIO);
+    __builtin_amdgcn_s_setprio(kWPrio);
 #pragma unroll
     for (int t = 0; t < NSTEPS; ++t) {
         const int slot = (PH + t) % kRing;
@@ -771,16 +784,6 @@ __device__ __forceinline__ void w_run(i32x16 (&ah)[MB], i32x16 (&ac)[MB], f32x16
         }
         const v4u wh = R.s[slot].h, wl = R.s[slot].l;
         __builtin_amdgcn_sched_barrier(0);
-#ifdef NM_W_NO_MFMA     // experiment: everything but the matrix work (results are garbage)
-        if (I8) {
-#pragma unroll
-            for (int m = 0; m < MB; ++m) { ac[m][0] += (int)(wh[0] + wl[0] + xlc[m].x + xhc[m].x); ah[m][0] += 1; }
-        } else {
-#pragma unroll
-            for (int m = 0; m < MB; ++m) ff[m][0] += (float)(wh[0] + wl[0] + xlc[m].x + xhc[m].x);
-        }
-        if (false)
-#endif
         if (I8) {
 #pragma unroll
             for (int m = 0; m < MB; ++m)
@@ -800,14 +803,10 @@ __device__ __forceinline__ void w_run(i32x16 (&ah)[MB], i32x16 (&ac)[MB], f32x16
             for (int m = 0; m < MB; ++m) ff[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wh), as_bf16x8(xhc[m]), ff[m], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-#if defined(NM_W_HALF_WLOAD)   // (experiment: every other step reloaded -- half the weight stream; results garbage)
-        if (((PH + t) & 1) == 0) w_step_load(R.s[slot], wsrc, voff, pos);
-#elif !defined(NM_W_NO_WLOAD)  // (experiment: weights never reloaded -- the ceiling if the weight stream were free; results garbage)
         w_step_load(R.s[slot], wsrc, voff, pos);       // the slot just consumed <- the step kRing ahead
-#endif
         pos += nm::kStepBytes;
     }
-    __builtin_amdgcn_s_setprio(NM_E_PRIO);
+    __builtin_amdgcn_s_setprio(kEPrio);
 }
 template <int MB, int NSTEPS, int PH>
 __device__ __forceinline__ void w_run8(i32x16 (&ah)[MB], i32x16 (&ac)[MB], WRing& R, __amdgpu_buffer_rsrc_t wsrc, int voff, int& pos,
@@ -1202,8 +1201,8 @@ int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, con
                     const float* z, int64_t n, int S, int in_mode, int precision, int stop_stage, float sigma_scale, float* out,
                     float* dbg, void* prof, hipStream_t stream, int sigma_only) {
     MlpArgs a;
-    a.wpack = reinterpret_cast<const uint4*>(L.wpack);
-    a.bias = L.bias;
+    a.wpack = reinterpret_cast<const uint4*>(precision == NM_PREC_FP16X3 ? L.wpack16 : L.wpack);
+    a.bias = precision == NM_PREC_FP16X3 ? L.bias16 : L.bias;
     a.petab = L.petab;
     a.pts = pts; a.dirs = dirs; a.origin = origin; a.direction = direction; a.z = z;
     a.out = out; a.dbg = dbg; a.prof = reinterpret_cast<unsigned long long*>(prof); a.n = n; a.S = S; a.in_mode = in_mode; a.stop_stage = stop_stage; a.sigma_scale = sigma_scale;
@@ -1226,10 +1225,14 @@ int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, con
         else hipLaunchKernelGGL(nerf_mlp_i8w_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, a8);
         return check_launch("nerf_mlp_i8w_kernel");
     }
-    if (prof)
+    if (prof && precision == NM_PREC_FP16X3)
+        hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_FP16X3, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+    else if (prof)
         hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_BF16X3, true>), dim3(grid), dim3(kThreads), 0, stream, a);
     else if (precision == NM_PREC_BF16X3)
         hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_BF16X3, false>), dim3(grid), dim3(kThreads), 0, stream, a);
+    else if (precision == NM_PREC_FP16X3)
+        hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_FP16X3, false>), dim3(grid), dim3(kThreads), 0, stream, a);
     else
         hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_BF16, false>), dim3(grid), dim3(kThreads), 0, stream, a);
     return check_launch("nerf_mlp_kernel");

@@ -43,6 +43,47 @@ static inline float bf16_to_f32(uint16_t h) {
     return f;
 }
 
+// ---- fp16 helpers (round to nearest even, subnormals kept, overflow saturates to the largest finite value) -----------------
+static inline uint16_t f32_to_f16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    u &= 0x7FFFFFFFu;
+    if (u >= 0x7F800000u) return (uint16_t)(sign | 0x7BFFu);            // inf / nan never occur in a weight image: saturate
+    if (u >= 0x477FF000u) return (uint16_t)(sign | 0x7BFFu);            // >= 65520 rounds past the largest fp16: saturate
+    if (u < 0x38800000u) {                                              // below 2^-14: subnormal fp16 (or zero)
+        if (u < 0x33000000u) return (uint16_t)sign;                     // < 2^-25: rounds to zero
+        const int e = (int)(u >> 23);                                   // biased f32 exponent, 102..112
+        uint32_t m = (u & 0x7FFFFFu) | 0x800000u;                       // 24-bit significand
+        const int shift = 126 - e;                                      // 14..24: value = m * 2^(e-150); fp16 subnormal unit 2^-24
+        const uint32_t q = m >> shift, rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+        uint32_t r = q + ((rem > half || (rem == half && (q & 1))) ? 1u : 0u);
+        return (uint16_t)(sign | r);
+    }
+    uint32_t v = u - 0x38000000u;                                       // rebias 127 -> 15
+    const uint32_t rem = v & 0x1FFFu;
+    v >>= 13;
+    if (rem > 0x1000u || (rem == 0x1000u && (v & 1))) ++v;
+    return (uint16_t)(sign | v);
+}
+static inline float f16_to_f32(uint16_t h) {
+    const uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    const int e = (h >> 10) & 31;
+    const uint32_t m = h & 0x3FFu;
+    float f;
+    if (e == 0) {
+        f = (float)m * 5.9604644775390625e-08f;                         // m * 2^-24
+    } else {
+        const uint32_t u = ((uint32_t)(e + 112) << 23) | (m << 13);
+        memcpy(&f, &u, 4);
+    }
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u |= sign;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
 // indices into host_params (reference state_dict order, include/neuman_hip.h)
 enum { P_PTS_W = 0, P_VIEWS_W = 16, P_VIEWS_B = 17, P_FEAT_W = 18, P_FEAT_B = 19, P_ALPHA_W = 20, P_ALPHA_B = 21, P_RGB_W = 22, P_RGB_B = 23 };
 
@@ -89,7 +130,9 @@ static float stage_weight(const nm_mlp_desc* d, const float* const* P, int st, i
     }
 }
 
-static void pack_image(const nm_mlp_desc* d, const float* const* P, uint8_t* img) {
+// f16 = false: split bf16 of W (NM_PREC_BF16X3 / NM_PREC_BF16); true: split fp16 of W * 2^8 and biases * 2^13 (NM_PREC_FP16X3,
+// scalings of mlp.hip kF16WScale / kF16ActScale).  Same fragment layout.
+static void pack_image(const nm_mlp_desc* d, const float* const* P, uint8_t* img, bool f16 = false) {
     memset(img, 0, (size_t)(kWeightBytes + kWeightPadBytes + (int64_t)kBiasFloats * 4));
     for (int st = 0; st < kStages; ++st) {
         const StageShape sh = stage_shape(st);
@@ -100,6 +143,13 @@ static void pack_image(const nm_mlp_desc* d, const float* const* P, uint8_t* img
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j) {
                         const float wv = stage_weight(d, P, st, 32 * nb + (lane & 31), 2 * t + (lane >> 5), j);
+                        if (f16) {
+                            const float ws = wv * 256.f;
+                            const uint16_t h = f32_to_f16(ws);
+                            hi[lane * 8 + j] = h;
+                            lo[lane * 8 + j] = f32_to_f16(ws - f16_to_f32(h));
+                            continue;
+                        }
                         const uint16_t h = f32_to_bf16(wv);
                         hi[lane * 8 + j] = h;
                         lo[lane * 8 + j] = f32_to_bf16(wv - bf16_to_f32(h));
@@ -114,6 +164,8 @@ static void pack_image(const nm_mlp_desc* d, const float* const* P, uint8_t* img
         else if (st == 9) memcpy(b, P[P_VIEWS_B], 128 * 4);
         else memcpy(b, P[P_RGB_B], 3 * 4);
     }
+    if (f16)
+        for (int i = 0; i < kBiasFloats; ++i) bias[i] *= 8192.f;        // accumulators carry Y * 2^(8+5)
 }
 
 // ---- NM_PREC_I8X3 image: [fragments (i8 limb steps, then bf16 PE steps) | pad | units | biases | kappa] ----------------
@@ -250,6 +302,7 @@ static void pack_stream8(const uint8_t* img8, uint8_t* out) {
 struct nm_mlp_s {
     nm_mlp_desc desc;
     uint8_t* d_image;      // weight fragments | pad | bias
+    uint8_t* d_image16;    // NM_PREC_FP16X3: the same layout, split fp16 of W * 2^8 | pad | bias * 2^13
     float* d_consts8;      // NM_PREC_I8X3: units | biases | kappa (the tail of the nm_mlp_pack_i8 image)
     uint8_t* d_stream8;    // NM_PREC_I8X3: the image's fragments as per-wave streams (nerf_mlp_i8w_kernel)
     float* d_petab;        // 192 floats
@@ -281,6 +334,14 @@ int nm_mlp_pack(const nm_mlp_desc* desc, const float* const* host_params, void* 
     return NM_OK;
 }
 
+int nm_mlp_pack_f16(const nm_mlp_desc* desc, const float* const* host_params, void* host_out) {
+    if (int e = nm::validate_desc(desc)) return e;
+    NM_REQUIRE(host_params && host_out, "nm_mlp_pack_f16: null pointer");
+    for (int i = 0; i < 24; ++i) NM_REQUIRE(host_params[i], "nm_mlp_pack_f16: host_params[%d] is null", i);
+    nm::pack_image(desc, host_params, static_cast<uint8_t*>(host_out), true);
+    return NM_OK;
+}
+
 int64_t nm_mlp_pack_i8_bytes(const nm_mlp_desc* desc) {
     if (nm::validate_desc(desc) != NM_OK) return -1;
     return nm::image8_bytes();
@@ -302,6 +363,8 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     const int64_t bytes = nm_mlp_pack_bytes(desc);
     std::vector<uint8_t> img((size_t)bytes);
     nm::pack_image(desc, host_params, img.data());
+    std::vector<uint8_t> img16((size_t)bytes);
+    nm::pack_image(desc, host_params, img16.data(), true);
     std::vector<uint8_t> img8((size_t)nm::image8_bytes());
     nm::pack_image8(desc, host_params, img8.data());
     std::vector<uint8_t> str8((size_t)nm::kWeightBytes8w);
@@ -342,7 +405,7 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     m->pos_octaves = octaves(tab, desc->pos_n_freqs);
     m->dir_octaves = octaves(tab + 96, desc->dir_n_freqs);
 
-    m->d_image = nullptr; m->d_consts8 = nullptr; m->d_stream8 = nullptr; m->d_petab = nullptr; m->d_ref = nullptr;
+    m->d_image = nullptr; m->d_image16 = nullptr; m->d_consts8 = nullptr; m->d_stream8 = nullptr; m->d_petab = nullptr; m->d_ref = nullptr;
     int rc = nm::check_hip(hipMalloc(&m->d_image, (size_t)bytes), "nm_mlp_create: hipMalloc(image)");
     const size_t consts_off = (size_t)(nm::kWeightBytes8 + nm::kWeightPadBytes), consts_bytes = img8.size() - consts_off;
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_consts8, consts_bytes), "nm_mlp_create: hipMalloc(consts8)");
@@ -352,6 +415,8 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_petab, sizeof(tab)), "nm_mlp_create: hipMalloc(petab)");
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_ref, ref.size() * 4), "nm_mlp_create: hipMalloc(ref)");
     if (!rc) rc = nm::check_hip(hipMemcpy(m->d_image, img.data(), (size_t)bytes, hipMemcpyHostToDevice), "nm_mlp_create: upload image");
+    if (!rc) rc = nm::check_hip(hipMalloc(&m->d_image16, (size_t)bytes), "nm_mlp_create: hipMalloc(image16)");
+    if (!rc) rc = nm::check_hip(hipMemcpy(m->d_image16, img16.data(), (size_t)bytes, hipMemcpyHostToDevice), "nm_mlp_create: upload image16");
     if (!rc) rc = nm::check_hip(hipMemcpy(m->d_petab, tab, sizeof(tab), hipMemcpyHostToDevice), "nm_mlp_create: upload petab");
     if (!rc) rc = nm::check_hip(hipMemcpy(m->d_ref, ref.data(), ref.size() * 4, hipMemcpyHostToDevice), "nm_mlp_create: upload ref");
     if (rc) { nm_mlp_destroy(m); return rc; }
@@ -362,6 +427,7 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
 int nm_mlp_destroy(nm_mlp_t m) {
     if (!m) return NM_OK;
     if (m->d_image) (void)hipFree(m->d_image);
+    if (m->d_image16) (void)hipFree(m->d_image16);
     if (m->d_consts8) (void)hipFree(m->d_consts8);
     if (m->d_stream8) (void)hipFree(m->d_stream8);
     if (m->d_petab) (void)hipFree(m->d_petab);
@@ -375,7 +441,8 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
                         float* out, float* dbg, nm_stream_t stream, void* prof = nullptr, int sigma_only = 0) {
     NM_REQUIRE(m, "nm_mlp_forward: null handle");
     NM_REQUIRE(n >= 0, "nm_mlp_forward: negative n");
-    NM_REQUIRE(precision == NM_PREC_FP32 || precision == NM_PREC_BF16X3 || precision == NM_PREC_BF16 || precision == NM_PREC_I8X3,
+    NM_REQUIRE(precision == NM_PREC_FP32 || precision == NM_PREC_BF16X3 || precision == NM_PREC_BF16 || precision == NM_PREC_I8X3 ||
+                   precision == NM_PREC_FP16X3,
                "nm_mlp_forward: bad precision %d", precision);
     if (n == 0) return NM_OK;
     if (precision == NM_PREC_FP32) {
@@ -389,6 +456,8 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
     nm::MlpLaunch L;
     L.wpack = m->d_image;
     L.bias = reinterpret_cast<const float*>(m->d_image + nm::kWeightBytes + nm::kWeightPadBytes);
+    L.wpack16 = m->d_image16;
+    L.bias16 = reinterpret_cast<const float*>(m->d_image16 + nm::kWeightBytes + nm::kWeightPadBytes);
     L.petab = m->d_petab;
     L.pe_kind = m->desc.pe_kind; L.pos_nfreq = m->desc.pos_n_freqs; L.dir_nfreq = m->desc.dir_n_freqs;
     L.pos_octaves = m->pos_octaves; L.dir_octaves = m->dir_octaves;
@@ -426,7 +495,8 @@ int nm_mlp_sigma_rays(nm_mlp_t mlp, const float* origin, const float* direction,
 int nm_mlp_forward_profile(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision, float* out,
                            uint64_t* cycles, nm_stream_t stream) {
     NM_REQUIRE(n == 0 || (pts && dirs && out && cycles), "nm_mlp_forward_profile: null pointer");
-    NM_REQUIRE(precision == NM_PREC_BF16X3 || precision == NM_PREC_I8X3, "nm_mlp_forward_profile: precision %d has no profiling build",
+    NM_REQUIRE(precision == NM_PREC_BF16X3 || precision == NM_PREC_I8X3 || precision == NM_PREC_FP16X3,
+               "nm_mlp_forward_profile: precision %d has no profiling build",
                precision);
     return mlp_dispatch(mlp, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, precision, -2, 1.f, out, nullptr, stream, cycles);
 }

@@ -8,6 +8,7 @@ struct MlpLaunch {
     const void* wpack; const float* bias; const float* petab;
     int pe_kind, pos_nfreq, dir_nfreq;
     int pos_octaves, dir_octaves;   // encodings whose bands are consecutive powers of two (octave recurrence allowed)
+    const void* wpack16; const float* bias16;     // NM_PREC_FP16X3: the same fragment image as split fp16 of W * 2^8, biases * 2^13
     const void* wstream8; const float* consts8;   // NM_PREC_I8X3: per-wave fragment streams; units | biases | kappa (mlp_layout.h)
 };
 struct RefLaunch {

@@ -162,6 +162,7 @@ __device__ __forceinline__ int lower_bound_lds(const float* a, int n, float v) {
     return lo;
 }
 
+constexpr int kMaxImportanceChunks = 8;     // importance samples per ray <= 512 when merged with the old samples
 // MODE 0: bins/weights given (sample_pdf).  MODE 1: derive from z/w (importance), optionally merge.
 template <int MODE>
 __global__ __launch_bounds__(64 * kRayWavesPerBlock) void sample_pdf_kernel(
@@ -220,10 +221,11 @@ __global__ __launch_bounds__(64 * kRayWavesPerBlock) void sample_pdf_kernel(
         }
         __syncthreads();
         // ---- invert the cdf at u                                                      // ray_utils.py:180-192
-        float run_max = -INFINITY;
+        bool inverted = false;                                   // MODE 1: some sample is smaller than its predecessor
+        float prev_last = -INFINITY;
         for (int c0 = 0; c0 < N; c0 += 64) {
             const int j = c0 + lane;
-            float smp = -INFINITY;
+            float smp = INFINITY;
             if (j < N) {
                 const float uj = u[j];
                 const int inds = upper_bound_lds(cdf, B, uj);                            // searchsorted(right=True)
@@ -237,15 +239,38 @@ __global__ __launch_bounds__(64 * kRayWavesPerBlock) void sample_pdf_kernel(
                 smp = b0 + t * (b1 - b0);
             }
             if (MODE == 1 && including_old) {
-                // torch.sort fixes the (1-ulp, rare) inversions of the inverse-CDF output; a running
-                // max does the same to the values the rank merge below relies on.
-                float m = wave_scan_max(smp, lane);
-                m = fmaxf(m, run_max);
-                run_max = __shfl(m, 63, 64);
-                if (j < N) zs[j] = m;
+                float prev = __shfl_up(smp, 1, 64);
+                if (lane == 0) prev = prev_last;
+                inverted |= j < N && smp < prev;
+                prev_last = __shfl(smp, 63, 64);
+                if (j < N) zs[j] = smp;
             } else if (j < N && live) {
                 out[r * N + j] = smp;
             }
+        }
+        if (MODE == 1 && including_old && __any(inverted)) {
+            // The inverse-CDF output is monotone up to f32 rounding; the reference's torch.sort (ray_utils.py:151) puts the
+            // rare inversions in order, and so does this exact, stable rank sort (a wave-uniform branch taken only by rays
+            // that have one; N <= 64 * kMaxImportanceChunks is checked on the host).  Values and ranks of every chunk are
+            // held in registers until all ranks are known; a wave's DS operations execute in program order, so the loads
+            // are done before the first store.
+            float v[kMaxImportanceChunks];
+            int rk[kMaxImportanceChunks];
+#pragma unroll
+            for (int c = 0; c < kMaxImportanceChunks; ++c) {
+                const int j = c * 64 + lane;
+                v[c] = j < N ? zs[j] : INFINITY;
+                rk[c] = 0;
+            }
+            for (int k = 0; k < N; ++k) {
+                const float x = zs[k];
+#pragma unroll
+                for (int c = 0; c < kMaxImportanceChunks; ++c) rk[c] += (x < v[c] || (x == v[c] && k < c * 64 + lane)) ? 1 : 0;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < kMaxImportanceChunks; ++c)
+                if (c * 64 + lane < N) zs[rk[c]] = v[c];
         }
         __syncthreads();
         if (MODE == 1 && including_old && live) {
@@ -380,6 +405,8 @@ int nm_importance_z(const float* z_vals, const float* weights, int64_t R, int S,
     const int B = S - 1;
     const size_t lds = (size_t)kRayWavesPerBlock * (2 * B + N + S) * sizeof(float);
     NM_REQUIRE(lds <= 64 * 1024, "nm_importance_z: S=%d N=%d exceed the per-wave LDS budget", S, N);
+    NM_REQUIRE(!including_old || N <= 64 * kMaxImportanceChunks, "nm_importance_z: N=%d importance samples exceed %d when merged with the old ones", N,
+               64 * kMaxImportanceChunks);
     if (R == 0) return NM_OK;
     hipLaunchKernelGGL(sample_pdf_kernel<1>, dim3(grid_for(R, kRayWavesPerBlock)), dim3(64 * kRayWavesPerBlock), lds,
                        nm::as_stream(stream), z_vals, weights, R, B, u, N, including_old, z_out);

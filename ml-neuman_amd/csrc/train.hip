@@ -372,14 +372,20 @@ __global__ __launch_bounds__(64) void composite_backward_kernel(const float* __r
     const float* rw = raw + r * S * 4;
     const float* zz = z + r * S;
     float* dr = d_raw + r * S * 4;
-    // forward scan: T_i, leaves T_S in `T`
-    double T = 1.0;
-    for (int i = 0; i < S; ++i) {
-        const float dist = (i + 1 < S ? zz[i + 1] - zz[i] : 1e10f) * dn;
-        const float a = 1.f - expf(-fmaxf(rw[i * 4 + 3], 0.f) * dist);
-        T *= (double)(1.f - a + 1e-10f);
+    // forward scan: T_i = prod_{j<i} u_j is kept per sample (as a double in the first 8 bytes of the sample's own d_raw
+    // record, which the backward scan overwrites after reading it).  Recovering T_i by dividing T_S back would give 0 / u = 0
+    // for every sample in front of a run of saturated ones (u = 1e-10 each: T_S underflows after ~31 of them, or beyond ~709
+    // nats of optical depth) -- exactly the rays late training produces.
+    {
+        double T = 1.0;
+        for (int i = 0; i < S; ++i) {
+            const float dist = (i + 1 < S ? zz[i + 1] - zz[i] : 1e10f) * dn;
+            const float a = 1.f - expf(-fmaxf(rw[i * 4 + 3], 0.f) * dist);
+            *reinterpret_cast<double*>(dr + i * 4) = T;
+            T *= (double)(1.f - a + 1e-10f);
+        }
     }
-    // backward scan: peel u_i off T to get T_i, carry the suffix sum
+    // backward scan: carry the suffix sum  sum_{m>i} G_m w_m
     double suffix = 0.0;
     for (int i = S - 1; i >= 0; --i) {
         const float sg = rw[i * 4 + 3];
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(64) void composite_backward_kernel(const float* __r
         const float e = expf(-fmaxf(sg, 0.f) * dist);
         const float a = 1.f - e;
         const double u = (double)(1.f - a + 1e-10f);
-        T /= u;                                                    // T_i
+        const double T = *reinterpret_cast<const double*>(dr + i * 4);   // T_i
         const double wgt = (double)a * T;
         float c[3];
 #pragma unroll

@@ -17,9 +17,9 @@ c_stream = ctypes.c_void_p
 i64 = ctypes.c_int64
 i32 = ctypes.c_int
 
-NM_PREC_FP32, NM_PREC_BF16X3, NM_PREC_BF16, NM_PREC_I8X3 = 0, 1, 2, 3
+NM_PREC_FP32, NM_PREC_BF16X3, NM_PREC_BF16, NM_PREC_I8X3, NM_PREC_FP16X3 = 0, 1, 2, 3, 4
 NM_PE_POSENC, NM_PE_ROTATE = 0, 1
-PRECISIONS = {"fp32": NM_PREC_FP32, "bf16x3": NM_PREC_BF16X3, "bf16": NM_PREC_BF16, "i8x3": NM_PREC_I8X3}
+PRECISIONS = {"fp32": NM_PREC_FP32, "bf16x3": NM_PREC_BF16X3, "bf16": NM_PREC_BF16, "i8x3": NM_PREC_I8X3, "fp16x3": NM_PREC_FP16X3}
 
 
 class MlpDesc(ctypes.Structure):
@@ -42,6 +42,7 @@ SIGNATURES = {
     "nm_compact_hits": (i32, [c_f32p, c_f32p, i64, c_i32p, c_i32p, c_i32p, c_i32p, c_stream]),
     "nm_mlp_pack_bytes": (i64, [ctypes.POINTER(MlpDesc)]),
     "nm_mlp_pack": (i32, [ctypes.POINTER(MlpDesc), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
+    "nm_mlp_pack_f16": (i32, [ctypes.POINTER(MlpDesc), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     "nm_mlp_pack_i8_bytes": (i64, [ctypes.POINTER(MlpDesc)]),
     "nm_mlp_pack_i8": (i32, [ctypes.POINTER(MlpDesc), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     "nm_mlp_create": (i32, [ctypes.POINTER(MlpDesc), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p,

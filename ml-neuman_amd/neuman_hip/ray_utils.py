@@ -269,6 +269,15 @@ class Mesh:
         self.verts = v.to(device, torch.float32).contiguous()
         self.faces = f.to(device, torch.int32).contiguous()          # cols 3-5 of scene.faces are UV ids (utils/utils.py:213-221)
         self.T = t.to(device, torch.float64).reshape(-1, 16).contiguous()
+        # the kernels index verts and T by face entries without bounds checks: refuse UV ids, 1-based or out-of-range indices
+        # and a transform table shorter than the vertex list here, once per mesh (the check is a reduction on the device;
+        # nm_mesh_create syncs for the bounding box anyway)
+        V = self.verts.shape[0]
+        if self.faces.numel() and (int(self.faces.min()) < 0 or int(self.faces.max()) >= V):
+            raise _lib.NeumanHipError(f"Mesh: face indices must lie in [0, {V}) (got {int(self.faces.min())}..{int(self.faces.max())}): "
+                                      "pass the vertex-id columns of a 0-based face array")
+        if self.T.shape[0] < V:
+            raise _lib.NeumanHipError(f"Mesh: T has {self.T.shape[0]} rows for {V} vertices (one 4x4 per vertex is required)")
         self.handle = ctypes.c_void_p()
         _lib.check(_lib.lib().nm_mesh_create(_lib.dev_ptr(self.verts), self.verts.shape[0], _lib.dev_ptr(self.faces, torch.int32),
                                              self.faces.shape[0], self.SEARCH[search], ctypes.byref(self.handle), _lib.stream_ptr()),

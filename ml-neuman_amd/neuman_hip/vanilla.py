@@ -15,9 +15,9 @@ import torch.nn as nn
 
 from . import _lib
 
-# "mixed" (Joiner._prec): bf16x3 everywhere except the passes the renderers tag as shading, which run i8x3 -- sample
-# positions identical to all-bf16x3, every pixel within 1e-4 of the oracle on identical samples (measured <= 2.3e-5).
-# "bf16x3" | "i8x3" | "bf16" | "fp32" force one arithmetic for every call.
+# "mixed" (Joiner._prec): split-fp16 x3 (float32-class results) everywhere except the passes the renderers tag as shading,
+# which run i8x3 -- sample positions identical to all-fp16x3, every pixel within 1e-4 of the oracle on identical samples
+# (measured <= 2.3e-5).  "fp16x3" | "bf16x3" | "i8x3" | "bf16" | "fp32" force one arithmetic for every call.
 DEFAULT_PRECISION = os.environ.get("NEUMAN_PRECISION", "mixed")
 
 
@@ -111,6 +111,22 @@ class Joiner(nn.Module):
         except Exception:
             pass
 
+    # the packed-weight handle is a cache owned by this object: copies and pickles (copy.deepcopy, torch.save(model),
+    # DataLoader workers) drop it and rebuild their own lazily, like the reference's plain nn.Module
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state['_handle'] = None
+        state['_handle_key'] = None
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k in ('_handle', '_handle_key') else copy.deepcopy(v, memo)
+        return new
+
     def handle(self):
         key = self._key()
         if self._handle is None or key != self._handle_key:
@@ -135,11 +151,12 @@ class Joiner(nn.Module):
     def _prec(self, precision, role=None):
         """'mixed': a pass the caller tags role='shading' -- its output is composited into the frame and nothing else --
         runs in i8x3; every other call (the coarse pass whose compositing weights place the importance samples, and any
-        direct call) runs in bf16x3.  Sample positions are then bit-identical to the all-bf16x3 path and the colours differ
-        from it by the i8x3 compositing error (<= 2e-5, tests/test_hip_mlp.py) on every pixel."""
+        direct call) runs in fp16x3, whose sigma is float32 class (the inverse CDF amplifies a coarse-pass error by 1 / pdf:
+        DESIGN.md section 5).  Sample positions are then bit-identical to the all-fp16x3 path and the colours differ from it
+        by the i8x3 compositing error (<= 2e-5, tests/test_hip_mlp.py) on every pixel."""
         p = precision or self.precision
         if p == 'mixed':
-            p = 'i8x3' if role == 'shading' else 'bf16x3'
+            p = 'i8x3' if role == 'shading' else 'fp16x3'
         return _lib.PRECISIONS[p]
 
     @staticmethod

@@ -141,6 +141,31 @@ def test_importance_z_vs_oracle(H, R, S, N):
     np.testing.assert_array_equal(p.cpu().numpy(), (o[:, None, :] + d[:, None, :] * hz.cpu().numpy()[..., None]).astype(np.float32))
 
 
+@pytest.mark.parametrize("S,N", [(128, 128), (32, 32), (192, 320), (65, 130)])
+def test_importance_merge_is_exactly_torch_sort(H, S, N):
+    """including_old=True must be sort(cat(z, z_samples)) of the kernel's OWN inverse-CDF samples, bit for bit --
+    also where those samples come out with f32 inversions (flat, near-zero and spiky PDFs: the adversarial cases)."""
+    rng = np.random.default_rng(S * 1000 + N)
+    R = 600
+    z = np.sort(rng.uniform(0.0, 3.14, size=(R, S)).astype(np.float32), axis=1)
+    z[: R // 6] = np.linspace(0.0, 3.14, S, dtype=np.float32)[None]                          # the renderers' own spacing
+    w = np.zeros((R, S), np.float32)
+    k = R // 6
+    w[:k] = 0.0                                                                               # flat: every bin at the 1e-5 floor
+    w[k:2 * k] = rng.uniform(0, 1e-7, size=(k, S))                                            # near zero
+    w[2 * k:3 * k] = rng.uniform(0, 1, size=(k, S)) ** 8                                      # spiky
+    w[3 * k:4 * k, S // 2] = 1.0                                                              # one opaque sample
+    w[4 * k:5 * k] = rng.uniform(0, 1 / S, size=(k, S))                                       # diffuse
+    w[5 * k:] = np.where(rng.uniform(size=(R - 5 * k, S)) < 0.1, rng.uniform(0, 0.2, size=(R - 5 * k, S)), 0).astype(np.float32)
+    zt, wt = cu(z), cu(w)
+    merged = H.ray.importance_z(zt, wt, N, including_old=True)
+    alone = H.ray.importance_z(zt, wt, N, including_old=False)
+    inv = (alone[:, 1:] < alone[:, :-1]).any(1)
+    ref = torch.sort(torch.cat([zt, alone], dim=1), dim=1).values
+    print(f"[importance] S={S} N={N}: rays whose inverse-CDF samples carry an f32 inversion: {int(inv.sum())} / {R}")
+    assert torch.equal(merged, ref)
+
+
 def test_importance_golden(H, golden):
     g = golden['ray_ops']
     hz = H.ray.importance_z(cu(g['rs_lin_z']), cu(g['imp_w']), 24).cpu().numpy()

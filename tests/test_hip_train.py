@@ -87,6 +87,39 @@ def test_composite_backward(G, tag, white):
     assert torch.isfinite(raw.grad).all()
 
 
+def saturated_rays(R=96, S=64, seed=11):
+    """Rays that run into a thick opaque region: sigma = 2000 from a random sample on (alpha saturates to exactly 1, u = 1e-10),
+    40+ such samples per ray (the product of all u underflows even in f64), visible samples in front."""
+    rng = np.random.default_rng(seed)
+    raw = rng.normal(size=(R, S, 4)).astype(np.float32) * np.array([1, 1, 1, 3], np.float32)
+    start = rng.integers(4, 20, size=R)
+    raw[..., 3] = np.where(np.arange(S)[None] >= start[:, None], 2000.0, raw[..., 3])
+    z = np.sort(rng.uniform(0.5, 4.0, size=(R, S)).astype(np.float32), -1)
+    d = rng.normal(size=(R, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    g = [rng.normal(size=(R, 3)).astype(np.float32), rng.normal(size=R).astype(np.float32), rng.normal(size=R).astype(np.float32),
+         (rng.normal(size=(R, S)) * 0.1).astype(np.float32)]
+    return raw, z, d, g, start
+
+
+@pytest.mark.parametrize("white", [True, False])
+def test_composite_backward_saturated_rays(G, white):
+    """gradients of the visible samples in front of a run of saturated ones (T_i must not be recovered by dividing
+    the underflowed full product back)."""
+    raw_np, z, d, g, start = saturated_rays()
+    raw = cu(raw_np).requires_grad_(True)
+    rgb, disp, acc, w, depth = G.render.raw2outputs(raw, cu(z), cu(d), white_bkg=white)
+    ((rgb * cu(g[0])).sum() + (acc * cu(g[1])).sum() + (depth * cu(g[2])).sum() + (w * cu(g[3])).sum()).backward()
+    got = raw.grad.cpu().numpy()
+    ora = OT.composite_backward(raw_np, z, d, white, *g)
+    s = np.abs(ora).max()
+    front = np.arange(raw_np.shape[1])[None] <= start[:, None]
+    print(f"[train] composite backward, saturated rays (white={white}): max |grad| {s:.3e}, front-sample |grad| mean "
+          f"{np.abs(ora[front]).mean():.3e}, device vs f64 autograd {np.abs(got - ora).max() / s:.2e} (relative to max)")
+    assert np.abs(ora[front]).mean() > 1e-3                               # the case is not vacuous
+    assert np.isfinite(got).all() and np.abs(got - ora).max() < 2e-5 * s
+
+
 @pytest.mark.parametrize("tag,white,penalty", [("white", True, 0.0), ("black_penalty", False, 0.1)])
 def test_training_step_matches_reference(G, tag, white, penalty, monkeypatch):
     monkeypatch.setattr(G.train, "GEMM_PRECISION", "f32")

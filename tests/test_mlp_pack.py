@@ -105,6 +105,94 @@ def test_pack_matches_oracle(nets, seed):
     assert np.abs(got[:, 3] - ref[:, 3]).max() < 2e-3 * max(1.0, np.abs(ref[:, 3]).max())
 
 
+def emulate_f16(img, pts, dirs, spec):
+    """The NM_PREC_FP16X3 data flow (csrc/mlp.hip): fp16 hi/lo parts of W * 2^8 from the image, activations and encodings
+    split into fp16 parts of X * 2^5, the three kept products wh.xh + wh.xl + wl.xh accumulated wide, biases * 2^13,
+    the epilogue's exact * 2^-8 and the outputs' exact * 2^-13."""
+    total_w = w_off(11)
+    bias = np.frombuffer(img, dtype=np.float32, offset=total_w + 4 * 2048)
+
+    def parts(s):
+        nblk, steps, _ = shape(s)
+        frag = np.frombuffer(img, dtype=np.float16, count=nblk * steps * 1024, offset=w_off(s)).reshape(nblk, steps, 2, 2, 32, 8)
+        f = frag.astype(np.float64).transpose(2, 0, 4, 1, 3, 5).reshape(2, nblk * 32, steps * 16)     # [hi|lo][n][(t, g, j)]
+        return f[0], f[1]
+
+    def split(x):                                                                                       # X * 32 -> fp16 hi, lo
+        xs = np.clip((x * np.float32(32.0)).astype(np.float32), -65504, 65504)
+        hi = xs.astype(np.float16)
+        lo = (xs - hi.astype(np.float32)).astype(np.float16)
+        return hi.astype(np.float64), lo.astype(np.float64)
+
+    def run(s, act_slots, n_out):
+        wh, wl = parts(s)
+        xh, xl = split(act_slots)
+        b = bias[b_off(s):b_off(s) + wh.shape[0]].astype(np.float64)
+        return ((xh @ wh.T + xl @ wh.T + xh @ wl.T) + b)[:, :n_out].astype(np.float32)                  # Y * 2^13
+
+    x_pe = nerf_mlp.embed(pts, spec.mapping, *spec.pos)
+    d_pe = nerf_mlp.embed(dirs, spec.mapping, *spec.dir)
+    P = np.zeros((pts.shape[0], 64), np.float32)
+    P[:, :x_pe.shape[1]] = x_pe
+    Pd = np.zeros((pts.shape[0], 32), np.float32)
+    Pd[:, :d_pe.shape[1]] = d_pe
+    act = np.float32(1.0 / 8192)                                   # (2^-8 in the kernel, then the stored X * 2^5; here X itself)
+    h = np.maximum(run(0, P, 256), 0) * act
+    for s in range(1, 8):
+        a = slots_from_features(h, 32)
+        if s == 5:
+            a = np.concatenate([P, a], 1)
+        h = np.maximum(run(s, a, 256), 0) * act
+    o8 = run(8, slots_from_features(h, 32), 288) * act
+    feature, sigma = o8[:, :256], o8[:, 256]
+    v = np.maximum(run(9, np.concatenate([slots_from_features(feature, 32), Pd], 1), 128), 0) * act
+    o10 = run(10, slots_from_features(v, 16), 32) * act
+    return np.concatenate([o10[:, :3], sigma[:, None]], 1)
+
+
+@pytest.mark.parametrize("seed", [0, 2])
+def test_pack_f16_is_float32_class(nets, seed):
+    """The split-fp16 image and data flow reproduce an f64 evaluation of the network ~10x closer than split bf16 does:
+    float32-sgemm class (the oracle's own f32 evaluation is ~1e-6 from f64 on sigma)."""
+    joiner, sd, spec = nets[seed]
+    lib = _lib.lib()
+    desc = _lib.MlpDesc(8, 256, 4, _lib.NM_PE_ROTATE if spec.mapping == 'rotate' else _lib.NM_PE_POSENC, 10, 4)
+    nbytes = lib.nm_mlp_pack_bytes(ctypes.byref(desc))
+    host = [p.detach().contiguous() for p in joiner.nerf.ordered_params()]
+    arr = (ctypes.c_void_p * 24)(*[t.data_ptr() for t in host])
+    img = ctypes.create_string_buffer(nbytes)
+    _lib.check(lib.nm_mlp_pack_f16(ctypes.byref(desc), arr, img), "nm_mlp_pack_f16")
+    # the packer's own fp16 rounding is IEEE round-to-nearest-even (checked against numpy's)
+    w0 = sd['nerf.pts_linears.1.weight']
+    frag = np.frombuffer(img.raw, dtype=np.float16, count=1024, offset=w_off(1)).reshape(2, 2, 32, 8)   # block 0, step 0
+    for g in range(2):
+        for j in range(8):
+            col = slot_feature(g, j)
+            ws = (w0[:32, col] * np.float32(256)).astype(np.float32)
+            hi = ws.astype(np.float16)
+            np.testing.assert_array_equal(frag[0, g, :, j], hi)
+            np.testing.assert_array_equal(frag[1, g, :, j], (ws - hi.astype(np.float32)).astype(np.float16))
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(-1.5, 1.5, size=(64, 3)).astype(np.float32)
+    dirs = rng.normal(size=(64, 3)).astype(np.float32)
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    got = emulate_f16(img.raw, pts, dirs, spec)
+    sd64 = {k: v.astype(np.float64) for k, v in sd.items()}
+    x_pe = nerf_mlp.embed(pts, spec.mapping, *spec.pos).astype(np.float64)
+    d_pe = nerf_mlp.embed(dirs, spec.mapping, *spec.dir).astype(np.float64)
+    lin = lambda h, n: h @ sd64[f'nerf.{n}.weight'].T + sd64[f'nerf.{n}.bias']
+    h = x_pe
+    for i in range(8):
+        h = np.maximum(lin(h, f'pts_linears.{i}'), 0)
+        if i == 4:
+            h = np.concatenate([x_pe, h], -1)
+    sigma = lin(h, 'alpha_linear')[:, 0]
+    rgb = lin(np.maximum(lin(np.concatenate([lin(h, 'feature_linear'), d_pe], -1), 'views_linears.0'), 0), 'rgb_linear')
+    e_rgb, e_sig = np.abs(got[:, :3] - rgb).max(), np.abs(got[:, 3] - sigma).max()
+    print(f"[pack f16] seed {seed}: vs f64 network  rgb {e_rgb:.2e}  sigma {e_sig:.2e}  (|sigma| max {np.abs(sigma).max():.2f})")
+    assert e_rgb < 3e-6 and e_sig < 1e-5 * max(1.0, np.abs(sigma).max())
+
+
 def test_pack_rejects_unsupported_nets():
     lib = _lib.lib()
     for bad in [(6, 256, 4, 0, 10, 4), (8, 128, 4, 0, 10, 4), (8, 256, 4, 0, 11, 4), (8, 256, 4, 3, 10, 4)]:
