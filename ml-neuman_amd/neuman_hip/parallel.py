@@ -41,32 +41,47 @@ def max_local_rays(total_rays, tile, world):
     return ((n_tiles + world - 1) // world) * tile
 
 
-def gather_frame(local, local_idx, total_rays, tile, dst=0):
+def frame_source_rows(total_rays, tile, world, device='cpu'):
+    """For every global ray, its row in the concatenation of the ranks' padded shards ([world * cap, C], cap =
+    max_local_rays): the whole frame assembly on the destination rank is ONE index_select with this list.  Cached."""
+    key = ("rows", int(total_rays), int(tile), int(world), str(device))
+    hit = _INDEX_CACHE.get(key)
+    if hit is not None:
+        return hit
+    cap = max_local_rays(total_rays, tile, world)
+    rows = torch.empty(total_rays, dtype=torch.int64, device=device)
+    for r in range(world):
+        idx = tile_ray_indices(total_rays, tile, r, world, device=device)
+        rows[idx] = r * cap + torch.arange(idx.shape[0], device=device)
+    _INDEX_CACHE[key] = rows
+    return rows
+
+
+def gather_frame(local, local_idx, total_rays, tile, dst=0, force_collective=False):
     """Assemble [total_rays, C] on rank `dst` from every rank's (local values, global indices).
 
     local [n_local, C] float32; returns the frame on `dst`, None elsewhere.  One collective per frame; the payload
-    is padded to the largest shard so all ranks send equal sizes (a requirement of gather on RCCL).
+    is padded to the largest shard so all ranks send equal sizes (a requirement of gather on RCCL); the receive buffers
+    are slices of one [world * cap, C] tensor, which one index_select turns into the frame.  `force_collective` runs the
+    collective path at world size 1 too (an initialised process group of one rank: what the single-GPU test box can execute).
     """
     rank, world = rank_world()
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_available() and dist.is_initialized()):
         out = torch.empty((total_rays, local.shape[1]), device=local.device, dtype=local.dtype)
         out[local_idx] = local
         return out
     cap = max_local_rays(total_rays, tile, world)
     send = torch.zeros((cap, local.shape[1]), device=local.device, dtype=local.dtype)
     send[:local.shape[0]] = local
-    bufs = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, gather_list=bufs, dst=dst)
+    big = torch.empty((world, cap, local.shape[1]), device=local.device, dtype=local.dtype) if rank == dst else None
+    dist.gather(send, gather_list=list(big.unbind(0)) if rank == dst else None, dst=dst)
     if rank != dst:
         return None
-    out = torch.empty((total_rays, local.shape[1]), device=local.device, dtype=local.dtype)
-    for r in range(world):
-        idx = tile_ray_indices(total_rays, tile, r, world, device=local.device)
-        out[idx] = bufs[r][:idx.shape[0]]
-    return out
+    rows = frame_source_rows(total_rays, tile, world, device=local.device)
+    return big.reshape(world * cap, local.shape[1]).index_select(0, rows)
 
 
-def render_sharded(render_rays_fn, origins, dirs, tile=8192, dst=0):
+def render_sharded(render_rays_fn, origins, dirs, tile=8192, dst=0, force_collective=False):
     """Render a frame's rays across all ranks.
 
     render_rays_fn(o [n,3], d [n,3]) -> [n, C] on the same device.  `origins`/`dirs` are the full frame's rays
@@ -76,4 +91,4 @@ def render_sharded(render_rays_fn, origins, dirs, tile=8192, dst=0):
     total = origins.shape[0]
     idx = tile_ray_indices(total, tile, rank, world, device=origins.device)
     local = render_rays_fn(origins[idx].contiguous(), dirs[idx].contiguous())
-    return gather_frame(local, idx, total, tile, dst)
+    return gather_frame(local, idx, total, tile, dst, force_collective)

@@ -197,7 +197,7 @@ def _near_far_dev(orig, direction, vert, geo_threshold):
     return near, far
 
 
-def geometry_guided_near_far(orig, dir, vert, geo_threshold=DEFAULT_GEO_THRESH):
+def geometry_guided_near_far(orig, dir, vert, geo_threshold):
     """reference ray_utils.py:197-233.  Dispatches on the type of `orig` like the reference: CUDA tensors in ->
     tensors out; numpy in -> numpy out (the arrays make one round trip to the device, the arithmetic is the kernel's)."""
     _lib.require_gpu()
@@ -210,8 +210,14 @@ def geometry_guided_near_far(orig, dir, vert, geo_threshold=DEFAULT_GEO_THRESH):
     return n.cpu().numpy(), f.cpu().numpy()
 
 
-geometry_guided_near_far_torch = geometry_guided_near_far
-geometry_guided_near_far_np = geometry_guided_near_far
+def geometry_guided_near_far_torch(orig, dir, vert, geo_threshold=DEFAULT_GEO_THRESH):
+    """reference ray_utils.py:204-219 (the variant with a default threshold)."""
+    return geometry_guided_near_far(orig, dir, vert, geo_threshold)
+
+
+def geometry_guided_near_far_np(orig, dir, vert, geo_threshold=DEFAULT_GEO_THRESH):
+    """reference ray_utils.py:222-233."""
+    return geometry_guided_near_far(orig, dir, vert, geo_threshold)
 
 
 def compact_hits(near, far):

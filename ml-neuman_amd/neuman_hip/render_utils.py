@@ -76,8 +76,16 @@ def _chunks(n):
         yield i, min(i + MAX_RAYS_PER_LAUNCH, n)
 
 
+def _note(trace, **kw):
+    """`trace` (a dict, or None) collects a renderer's intermediates -- sample positions, hit lists, warped points -- so that
+    tests can hand exactly those to the CPU oracle (conditional parity) while running the product code path itself."""
+    if trace is not None:
+        for k, v in kw.items():
+            trace.setdefault(k, []).append(v)
+
+
 def bkg_pass_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, importance_samples_per_ray, white_bkg,
-                  precision=None):
+                  precision=None, trace=None):
     """Coarse (+ fine) background evaluation of R rays -> (raw [R,S',4], z [R,S'])  (render_utils.py:131-151, 287-297)."""
     _, _, z = ray_utils.sample_z(o, d, near, far, samples_per_ray)
     # with a fine net the coarse pass only places the importance samples; otherwise it is the pass that is composited
@@ -89,11 +97,12 @@ def bkg_pass_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, import
         _, _, _, w, _ = raw2outputs(raw, z, d, white_bkg=white_bkg)
         z = ray_utils.importance_z(z, w, importance_samples_per_ray)
         raw = fine_net.forward_rays(o, d, z, precision=precision, role='shading')
+    _note(trace, bkg_z=z)
     return raw, z
 
 
 def render_vanilla_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, importance_samples_per_ray, white_bkg=True,
-                        precision=None):
+                        precision=None, trace=None):
     """Device core of render_vanilla: o, d [R,3] CUDA f32, scalar near/far -> (rgb [R,3], depth [R]) CUDA."""
     R = o.shape[0]
     rgb = torch.empty((R, 3), device=o.device, dtype=torch.float32)
@@ -103,23 +112,26 @@ def render_vanilla_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, 
         n = torch.full((j - i,), float(near), device=o.device, dtype=torch.float32)
         f = torch.full((j - i,), float(far), device=o.device, dtype=torch.float32)
         raw, z = bkg_pass_rays(coarse_net, fine_net, oc, dc, n, f, samples_per_ray, importance_samples_per_ray, white_bkg,
-                               precision)
+                               precision, trace)
         rgb[i:j], _, _, _, depth[i:j] = raw2outputs(raw, z, dc, white_bkg=white_bkg, want_weights=False)
     return rgb, depth
 
 
-def human_pass_rays(human_net, o, d, near, far, samples_per_ray, mesh=None, render_can=False, sigma_scale=1.0, precision=None):
+def human_pass_rays(human_net, o, d, near, far, samples_per_ray, mesh=None, render_can=False, sigma_scale=1.0, precision=None,
+                    trace=None):
     """Human-net evaluation of (already compacted) hit rays -> (raw [R,S,4], z [R,S])  (render_utils.py:213-229, 320-329)."""
     if render_can:
         _, _, z = ray_utils.sample_z(o, d, near, far, samples_per_ray)
+        _note(trace, human_z=z)
         return human_net.forward_rays(o, d, z, precision=precision, sigma_scale=sigma_scale, role='shading'), z
     pts, _, z = ray_utils.sample_z(o, d, near, far, samples_per_ray, want_points=True)
     can_pts, can_dirs, _ = ray_utils.warp_to_canonical_dev(pts, mesh)
+    _note(trace, human_z=z, can_pts=can_pts, can_dirs=can_dirs)
     return human_net(can_pts, can_dirs, precision=precision, sigma_scale=sigma_scale, role='shading'), z
 
 
 def render_smpl_nerf_rays(human_net, o, d, posed_verts, mesh, samples_per_ray, white_bkg=True, render_can=False,
-                          geo_threshold=DEFAULT_GEO_THRESH, interval_comp=1.0, precision=None):
+                          geo_threshold=DEFAULT_GEO_THRESH, interval_comp=1.0, precision=None, trace=None):
     """Device core of render_smpl_nerf -> (rgb [R,3], depth [R], acc [R]) CUDA."""
     R = o.shape[0]
     rgb = torch.full((R, 3), 1.0 if white_bkg else 0.0, device=o.device, dtype=torch.float32)    # misses, :199-205
@@ -133,7 +145,8 @@ def render_smpl_nerf_rays(human_net, o, d, posed_verts, mesh, samples_per_ray, w
             continue
         ho, hd = ray_utils.gather_rows(oc, hit), ray_utils.gather_rows(dc, hit)
         hn, hf = ray_utils.gather_rows(near, hit), ray_utils.gather_rows(far, hit)
-        raw, z = human_pass_rays(human_net, ho, hd, hn, hf, samples_per_ray, mesh, render_can, interval_comp, precision)
+        _note(trace, hit=hit + i)
+        raw, z = human_pass_rays(human_net, ho, hd, hn, hf, samples_per_ray, mesh, render_can, interval_comp, precision, trace)
         _rgb, _, _acc, _, _depth = raw2outputs(raw, z, hd, white_bkg=white_bkg, want_weights=False)
         ray_utils.scatter_rows(rgb[i:j], hit, _rgb)
         ray_utils.scatter_rows(depth[i:j], hit, _depth)
@@ -142,7 +155,7 @@ def render_smpl_nerf_rays(human_net, o, d, posed_verts, mesh, samples_per_ray, w
 
 
 def render_hybrid_rays(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far, posed_verts, mesh, samples_per_ray,
-                       importance_samples_per_ray, white_bkg=True, geo_threshold=DEFAULT_GEO_THRESH, precision=None):
+                       importance_samples_per_ray, white_bkg=True, geo_threshold=DEFAULT_GEO_THRESH, precision=None, trace=None):
     """Device core of render_hybrid_nerf -> (rgb [R,3], depth [R], acc [R]) CUDA  (render_utils.py:276-356)."""
     R = o.shape[0]
     rgb = torch.empty((R, 3), device=o.device, dtype=torch.float32)
@@ -153,7 +166,7 @@ def render_hybrid_rays(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far,
         n = torch.full((j - i,), float(bkg_near), device=o.device, dtype=torch.float32)
         f = torch.full((j - i,), float(bkg_far), device=o.device, dtype=torch.float32)
         bkg_raw, bkg_z = bkg_pass_rays(coarse_bkg, fine_bkg, oc, dc, n, f, samples_per_ray, importance_samples_per_ray,
-                                       white_bkg, precision)
+                                       white_bkg, precision, trace)
         # every ray first gets the background-only composite (what the reference does for misses, :303-311) ...
         rgb[i:j], _, _, _, depth[i:j] = raw2outputs(bkg_raw, bkg_z, dc, white_bkg=white_bkg, want_weights=False)
         near, far = ray_utils.geometry_guided_near_far(oc, dc, posed_verts, geo_threshold)
@@ -163,7 +176,8 @@ def render_hybrid_rays(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far,
         # ... and hit rays are overwritten by the merged human + background composite (:313-353)
         ho, hd = ray_utils.gather_rows(oc, hit), ray_utils.gather_rows(dc, hit)
         hn, hf = ray_utils.gather_rows(near, hit), ray_utils.gather_rows(far, hit)
-        h_raw, h_z = human_pass_rays(human_net, ho, hd, hn, hf, samples_per_ray, mesh, False, 1.0, precision)
+        _note(trace, hit=hit + i)
+        h_raw, h_z = human_pass_rays(human_net, ho, hd, hn, hf, samples_per_ray, mesh, False, 1.0, precision, trace)
         S_b = bkg_z.shape[1]
         z_all, raw_all = merge_sorted(ray_utils.gather_rows(bkg_z, hit), ray_utils.gather_rows(bkg_raw.reshape(j - i, -1), hit).reshape(-1, S_b, 4),
                                       h_z, h_raw)
@@ -176,7 +190,7 @@ def render_hybrid_rays(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far,
 
 
 def render_multi_rays(coarse_bkg, fine_bkg, human_nets, o, d, bkg_near, bkg_far, posed_verts, meshes, samples_per_ray,
-                      importance_samples_per_ray, white_bkg=True, geo_threshold=DEFAULT_GEO_THRESH, precision=None):
+                      importance_samples_per_ray, white_bkg=True, geo_threshold=DEFAULT_GEO_THRESH, precision=None, trace=None):
     """Device core of render_hybrid_nerf_multi_persons -> (rgb [R,3], depth [R]) CUDA  (render_utils.py:390-456)."""
     R = o.shape[0]
     rgb = torch.empty((R, 3), device=o.device, dtype=torch.float32)
@@ -187,19 +201,22 @@ def render_multi_rays(coarse_bkg, fine_bkg, human_nets, o, d, bkg_near, bkg_far,
         n = torch.full((nr,), float(bkg_near), device=o.device, dtype=torch.float32)
         f = torch.full((nr,), float(bkg_far), device=o.device, dtype=torch.float32)
         raw_all, z_all = bkg_pass_rays(coarse_bkg, fine_bkg, oc, dc, n, f, samples_per_ray, importance_samples_per_ray,
-                                       white_bkg, precision)
+                                       white_bkg, precision, trace)
         far_z = torch.linspace(float(bkg_far) * 2, float(bkg_far) * 3, samples_per_ray, device=o.device)   # :418-419
         for net, verts, mesh in zip(human_nets, posed_verts, meshes):
             near, far = ray_utils.geometry_guided_near_far(oc, dc, verts, geo_threshold)
             h_raw = torch.zeros((nr, samples_per_ray, 4), device=o.device, dtype=torch.float32)
             h_z = far_z[None].repeat(nr, 1).contiguous()
             hit, _ = ray_utils.compact_hits(near, far)
+            _note(trace, hit=hit + i)
             if hit.numel() > 0:
                 ho, hd = ray_utils.gather_rows(oc, hit), ray_utils.gather_rows(dc, hit)
                 hn, hf = ray_utils.gather_rows(near, hit), ray_utils.gather_rows(far, hit)
-                r_, z_ = human_pass_rays(net, ho, hd, hn, hf, samples_per_ray, mesh, False, 1.0, precision)
+                r_, z_ = human_pass_rays(net, ho, hd, hn, hf, samples_per_ray, mesh, False, 1.0, precision, trace)
                 ray_utils.scatter_rows(h_raw.reshape(nr, -1), hit, r_.reshape(hit.shape[0], -1))
                 ray_utils.scatter_rows(h_z, hit, z_)
+            else:
+                _note(trace, human_z=None, can_pts=None, can_dirs=None)
             z_all, raw_all = merge_sorted(z_all, raw_all, h_z, h_raw)                                   # :441-448, list by list
         rgb[i:j], _, _, _, depth[i:j] = raw2outputs(raw_all, z_all, dc, white_bkg=white_bkg, want_weights=False)
     return rgb, depth

@@ -1,14 +1,21 @@
 """Oracle: positional encodings and the 8x256 NeRF MLP.
 
-numpy float32 restatement of reference models/vanilla.py (Embedder :17-92,
-NeRF :95-152, Joiner :155-166).  Test infrastructure only.
+float32 restatement of reference models/vanilla.py (Embedder :17-92, NeRF :95-152, Joiner :155-166): the
+encodings in numpy, the dense layers through torch's CPU `linear` -- the BLAS call the reference itself makes.
+Test infrastructure only.
 
 Weights are a dict keyed by the reference Joiner's state_dict names
 (``nerf.pts_linears.0.weight`` ... ``nerf.rgb_linear.bias``), values numpy f32.
 """
 import numpy as np
+import torch
+import torch.nn.functional as TF
 
 F32 = np.float32
+
+
+def _t(a):
+    return a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=F32))
 
 
 def rotate_bvals(min_freq, max_freq, n_freqs):
@@ -28,24 +35,25 @@ def posenc_bands(min_freq, max_freq, n_freqs):
 
 
 def embed_posenc(x, min_freq, max_freq, n_freqs, include_input=True):
-    """reference models/vanilla.py:60-79, 92: [x, sin(f0 x), cos(f0 x), sin(f1 x), ...]."""
-    x = x.astype(F32)
-    out = [x] if include_input else []
-    for f in posenc_bands(min_freq, max_freq, n_freqs):
-        xf = (x * f).astype(F32)
-        out.append(np.sin(xf, dtype=F32))
-        out.append(np.cos(xf, dtype=F32))
-    return np.concatenate(out, -1)
+    """reference models/vanilla.py:60-79, 92: [x, sin(f0 x), cos(f0 x), sin(f1 x), ...] -- with torch's CPU sin / cos, the
+    functions the reference calls (numpy's differ from them by an ulp here and there)."""
+    xt = _t(x)
+    out = [xt] if include_input else []
+    for f in torch.from_numpy(posenc_bands(min_freq, max_freq, n_freqs)):
+        xf = xt * f
+        out.append(torch.sin(xf))
+        out.append(torch.cos(xf))
+    return torch.cat(out, -1).numpy()
 
 
 def embed_rotate(x, min_freq, max_freq, n_freqs, include_input=True):
     """reference models/vanilla.py:83-89: [x, sin(x B^T), cos(x B^T)]."""
-    x = x.astype(F32)
-    proj = (x @ rotate_bvals(min_freq, max_freq, n_freqs).T).astype(F32)
-    out = np.concatenate([np.sin(proj, dtype=F32), np.cos(proj, dtype=F32)], -1)
+    xt = _t(x)
+    proj = xt @ torch.from_numpy(rotate_bvals(min_freq, max_freq, n_freqs)).T
+    out = torch.cat([torch.sin(proj), torch.cos(proj)], -1)
     if include_input:
-        out = np.concatenate([x, out], -1)
-    return out
+        out = torch.cat([xt, out], -1)
+    return out.numpy()
 
 
 def embed(x, mapping, min_freq, max_freq, n_freqs):
@@ -53,7 +61,9 @@ def embed(x, mapping, min_freq, max_freq, n_freqs):
 
 
 def _linear(h, w, b):
-    return (h @ w.T + b).astype(F32)
+    """nn.Linear on CPU tensors: the very sgemm call (torch's CPU BLAS, float32, bias added by addmm) the reference's
+    `self.pts_linears[i](h)` makes, so the restatement runs at the reference's speed and rounds like it."""
+    return TF.linear(h, w, b)
 
 
 def nerf_forward(weights, x_pe, d_pe, depth=8, skips=(4,), return_hidden=False):
@@ -61,24 +71,27 @@ def nerf_forward(weights, x_pe, d_pe, depth=8, skips=(4,), return_hidden=False):
 
     x_pe [N,63], d_pe [N,27] -> [N,4] = (r,g,b,sigma).  With return_hidden the
     post-activation output of every layer is returned too (for layer-by-layer
-    kernel debugging).
+    kernel debugging).  numpy in, numpy out; the dense layers run as torch CPU ops (see _linear).
     """
+    W = {k: _t(v) for k, v in weights.items()}
     hidden = []
+    x_pe, d_pe = _t(x_pe), _t(d_pe)
     h = x_pe
-    for i in range(depth):
-        h = np.maximum(_linear(h, weights[f'nerf.pts_linears.{i}.weight'], weights[f'nerf.pts_linears.{i}.bias']), F32(0.))
+    with torch.no_grad():
+        for i in range(depth):
+            h = torch.relu(_linear(h, W[f'nerf.pts_linears.{i}.weight'], W[f'nerf.pts_linears.{i}.bias']))
+            hidden.append(h)
+            if i in skips:
+                h = torch.cat([x_pe, h], -1)
+        alpha = _linear(h, W['nerf.alpha_linear.weight'], W['nerf.alpha_linear.bias'])
+        feature = _linear(h, W['nerf.feature_linear.weight'], W['nerf.feature_linear.bias'])
+        hidden.append(feature)
+        h = torch.cat([feature, d_pe], -1)
+        h = torch.relu(_linear(h, W['nerf.views_linears.0.weight'], W['nerf.views_linears.0.bias']))
         hidden.append(h)
-        if i in skips:
-            h = np.concatenate([x_pe, h], -1)
-    alpha = _linear(h, weights['nerf.alpha_linear.weight'], weights['nerf.alpha_linear.bias'])
-    feature = _linear(h, weights['nerf.feature_linear.weight'], weights['nerf.feature_linear.bias'])
-    hidden.append(feature)
-    h = np.concatenate([feature, d_pe], -1)
-    h = np.maximum(_linear(h, weights['nerf.views_linears.0.weight'], weights['nerf.views_linears.0.bias']), F32(0.))
-    hidden.append(h)
-    rgb = _linear(h, weights['nerf.rgb_linear.weight'], weights['nerf.rgb_linear.bias'])
-    out = np.concatenate([rgb, alpha], -1)
-    return (out, hidden) if return_hidden else out
+        rgb = _linear(h, W['nerf.rgb_linear.weight'], W['nerf.rgb_linear.bias'])
+        out = torch.cat([rgb, alpha], -1).numpy()
+    return (out, [x.numpy() for x in hidden]) if return_hidden else out
 
 
 class JoinerSpec:

@@ -1,0 +1,227 @@
+"""-m gpu: one oracle-checked slice per BASELINE.json configuration at its REAL sample counts.
+
+    C2  800x800 background, 128 coarse + 128 importance (merged 256)            2048 rays of the frame
+    C3  512x512 canonical human, 128 samples                                     >= 1024 hit rays
+    C4  hybrid: background 128 + 128 and human 128, merged 384                   hit and miss rays
+    C5  three actors: background 192 + 128 and 3 x 192, merged 896
+
+Two kinds of statement are made:
+
+* end to end against the oracle's own rendering, with every ray that is off by more than 1e-4 EXPLAINED: it has an
+  importance sample that sits somewhere else than the oracle's (the inverse CDF of ray_utils.py:164-194 amplifies a
+  coarse-weight difference by 1 / pdf), and every ray whose samples did not move is within 1e-4;
+* conditional parity at 1e-4 on EVERY pixel: the oracle evaluates its networks, merge and compositing on the device's own
+  sample positions and (for posed humans) the device's own warped points -- the renderer's product code path is what
+  runs on the device (the `trace` hook records its intermediates), the warp itself is checked against the oracle in
+  tests/test_hip_render.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import compositing, nerf_mlp, ray_ops as O
+
+pytestmark = pytest.mark.gpu
+MOVED = 5e-6          # a fine sample "moved": further than this from the oracle's (f32 ulp of z: 2.4e-7; a 128-sample coarse bin: 2.5e-2;
+                      # displacing EVERY sample of a ray by up to 1e-5 changes its colour by < 6e-5 on this workload)
+
+
+@pytest.fixture(scope="module")
+def G(nets):
+    import types
+    from neuman_hip import ray_utils, render_utils, synthetic
+    gn = {k: (j.cuda(), (sd, spec)) for k, (j, sd, spec) in nets.items()}
+    return types.SimpleNamespace(ray=ray_utils, render=render_utils, syn=synthetic, nets=gn)
+
+
+def cu(x):
+    return torch.as_tensor(np.ascontiguousarray(x)).to('cuda', torch.float32).contiguous()
+
+
+def psnr(a, b):
+    return 10 * np.log10(1.0 / max(np.mean((a.astype(np.float64) - b) ** 2), 1e-30))
+
+
+def oracle_two_pass(nets, o, d, near, far, S, NI):
+    """reference render_utils.py:131-151 on the CPU oracle -> rgb, z_fine"""
+    R = o.shape[0]
+    pts, dd, z = O.ray_to_samples(o, d, np.full((R, 1), near, np.float32), np.full((R, 1), far, np.float32), S)
+    out = nerf_mlp.joiner_forward(*nets[0], pts, dd)
+    _, _, _, w, _ = compositing.raw2outputs(out, z, d)
+    pts, dd, zf = O.ray_to_importance_samples(o, d, z, w, NI)
+    out = nerf_mlp.joiner_forward(*nets[1], pts, dd)
+    return compositing.raw2outputs(out, zf, d)[0], zf
+
+
+def explained(err, z_dev, z_ora, tag, max_bad):
+    """every ray off by more than 1e-4 has a moved sample; every ray with unmoved samples is within 1e-4"""
+    moved = (np.abs(z_dev - z_ora) > MOVED).any(-1)
+    bad = err > 1e-4
+    unmoved_max = err[~moved].max() if (~moved).any() else 0.0
+    print(f"[{tag}] rays > 1e-4: {bad.sum()} / {err.size} (all with a moved sample: {bool((bad & ~moved).sum() == 0)}), rays with a moved "
+          f"sample {moved.sum()}, Linf over rays with unmoved samples {unmoved_max:.2e}, Linf overall {err.max():.2e}")
+    assert (bad & ~moved).sum() == 0, f"{(bad & ~moved).sum()} rays are off by > 1e-4 although every sample sits where the oracle's does"
+    assert unmoved_max <= 1e-4
+    assert bad.sum() <= max_bad, f"{bad.sum()} rays off by more than 1e-4 (allowed {max_bad})"
+    return moved
+
+
+@pytest.mark.parametrize("precision", ["mixed", "fp16x3", "bf16x3"])
+def test_c2_slice_vs_oracle(G, precision):
+    """2048 rays from the middle of the 800x800 frame, 128 + 128 samples, against the oracle end to end"""
+    coarse, fine = G.syn.make_joiner(0).cuda(), G.syn.make_joiner(1).cuda()
+    coarse.precision = fine.precision = precision
+    cap = G.syn.SimpleCapture(800, 800)
+    o, d = O.shot_all_rays(cap.intrinsic_matrix, cap.cam_pose.camera_to_world, cap.shape)
+    sl = slice(400 * 800 + 100, 400 * 800 + 100 + 2048)
+    o, d = o[sl].astype(np.float32), d[sl].astype(np.float32)
+    o_rgb, o_z = oracle_two_pass([G.nets[0][1], G.nets[1][1]], o, d, 0.0, 3.14, 128, 128)
+    trace = {}
+    rgb, _ = G.render.render_vanilla_rays(coarse, fine, cu(o), cu(d), 0.0, 3.14, 128, 128, trace=trace)
+    rgb, z = rgb.cpu().numpy(), trace['bkg_z'][0].cpu().numpy()
+    err = np.abs(rgb - o_rgb).max(-1)
+    print(f"[C2 {precision}] PSNR vs oracle {psnr(rgb, o_rgb):.1f} dB")
+    # measured (r02, MI355X): mixed / fp16x3 N rays, bf16x3 ~3x as many -- the float32-class coarse pass is what keeps this at
+    # the level two float32 CPU evaluations of the reference differ at (14 of 4800 rays, tools/port_vs_reference.py)
+    explained(err, z, o_z, f"C2 {precision}", {"mixed": 16, "fp16x3": 16, "bf16x3": 60}[precision])
+    assert psnr(rgb, o_rgb) > (80.0 if precision != "bf16x3" else 70.0)
+    # conditional parity on every pixel: the oracle's fine pass on the device's sample positions
+    pts = (o[:, None, :] + d[:, None, :] * z[..., None]).astype(np.float32)
+    c_raw = nerf_mlp.joiner_forward(*G.nets[1][1], pts, np.broadcast_to(d[:, None, :], pts.shape))
+    c_rgb = compositing.raw2outputs(c_raw, z, d)[0]
+    e = np.abs(rgb - c_rgb).max()
+    print(f"[C2 {precision}] oracle fine pass on the device's samples: Linf {e:.2e}")
+    assert e < 1e-4
+
+
+def test_c3_canonical_slice_at_128_samples(G):
+    """>= 1024 hit rays of the 512x512 canonical-human frame at 128 samples (rotate encoding, interval_comp): single pass, so
+    the 1e-4 contract holds on every pixel against the oracle's own rendering"""
+    human = G.nets[2]
+    verts = G.syn.human_vertex_cloud(0)
+    cap = G.syn.SimpleCapture(512, 512, c2w=G.syn.spherical_c2w(40., 0., 3.0))
+    coords = O.all_pixel_coords(cap.shape)
+    band = coords[(coords[:, 1] >= 250) & (coords[:, 1] < 256)]                    # six rows through the body
+    o, d = O.shot_rays(cap.intrinsic_matrix, cap.cam_pose.camera_to_world, band)
+    o, d = o.astype(np.float32), d.astype(np.float32)
+    trace = {}
+    rgb, depth, acc = G.render.render_smpl_nerf_rays(human[0], cu(o), cu(d), cu(verts), None, 128, True, True, 0.2, 0.7, trace=trace)
+    hit = trace['hit'][0].cpu().numpy()
+    assert hit.size >= 1024, hit.size
+    near, far = O.geometry_guided_near_far(o, d, verts, 0.2)
+    o_hit = np.nonzero(near < far)[0]
+    both = np.intersect1d(hit, o_hit)
+    assert both.size >= 0.995 * max(hit.size, o_hit.size)                          # silhouette rays may flip on an ulp
+    pts, dd, z = O.ray_to_samples(o[both], d[both], near[both][:, None], far[both][:, None], 128)
+    out = nerf_mlp.joiner_forward(*human[1], pts, dd).copy()
+    out[..., -1] *= np.float32(0.7)
+    o_rgb, _, o_acc, _, o_depth = compositing.raw2outputs(out, z, d[both])
+    e = np.abs(rgb.cpu().numpy()[both] - o_rgb).max()
+    print(f"[C3] {both.size} hit rays at 128 samples vs oracle: rgb Linf {e:.2e}, acc Linf {np.abs(acc.cpu().numpy()[both] - o_acc).max():.2e}")
+    # the rotate encoding evaluates sin / cos at arguments up to ~1e3 rad, where one float32 ulp of the argument is 6e-5: the
+    # oracle itself sits ~5e-5 from the reference's output there (tests/test_oracle_golden.py); 1e-4 is the contract
+    assert e < 1e-4
+    assert np.abs(acc.cpu().numpy()[both] - o_acc).max() < 1e-4
+    miss = np.setdiff1d(np.arange(o.shape[0]), hit)
+    assert (rgb.cpu().numpy()[miss] == 1).all() and (depth.cpu().numpy()[miss] == 0).all()
+
+
+def small_body(G):
+    verts_c, faces = G.syn.capsule_mesh(n_rings=20, n_seg=24)
+    posed, T = G.syn.twist_transforms(verts_c)
+    return posed, np.ascontiguousarray(faces[:, :3], np.int32), T
+
+
+def conditional_hybrid(G, nets_o, o, d, trace, n_actors, S_h, white=True, far=3.14):
+    """The oracle's fine background net, human nets, merge and compositing on the device's sample positions / warped points
+    (reference render_utils.py:313-353 for one actor, :390-456 for several) -> rgb per ray for the rays it covers, index list."""
+    bkg_z = trace['bkg_z'][0].cpu().numpy()
+    R = o.shape[0]
+    pts = (o[:, None, :] + d[:, None, :] * bkg_z[..., None]).astype(np.float32)
+    bkg_raw = nerf_mlp.joiner_forward(*nets_o['fine'], pts, np.broadcast_to(d[:, None, :], pts.shape))
+    zs, raws = [bkg_z], [bkg_raw]
+    hits = []
+    for a in range(n_actors):
+        hit = trace['hit'][a].cpu().numpy()
+        hits.append(hit)
+        h_raw = np.zeros((R, S_h, 4), np.float32)
+        h_z = np.stack([O.linspace_f32(far * 2, far * 3, S_h)] * R) if n_actors > 1 else None
+        if hit.size:
+            cp, cdirs = trace['can_pts'][a].cpu().numpy(), trace['can_dirs'][a].cpu().numpy()
+            raw = nerf_mlp.joiner_forward(*nets_o['human'], cp, cdirs)
+            if n_actors > 1:
+                h_raw[hit] = raw
+                h_z[hit] = trace['human_z'][a].cpu().numpy()
+            else:
+                h_raw, h_z = raw, trace['human_z'][a].cpu().numpy()
+        zs.append(h_z)
+        raws.append(h_raw)
+    if n_actors == 1:                                                              # hit rays merged, misses background only
+        hit = hits[0]
+        rgb = compositing.raw2outputs(bkg_raw, bkg_z, d, white_bkg=white)[0]
+        if hit.size:
+            z_all, raw_all = compositing.merge_sorted([bkg_z[hit], zs[1]], [bkg_raw[hit], raws[1]])
+            rgb[hit] = compositing.raw2outputs(raw_all, z_all, d[hit], white_bkg=white)[0]
+        return rgb, hits
+    z_all, raw_all = compositing.merge_sorted(zs, raws)
+    return compositing.raw2outputs(raw_all, z_all, d, white_bkg=white)[0], hits
+
+
+def test_c4_hybrid_slice_128_128_128(G):
+    """hybrid render (background 128 + 128, human 128 -> 384 merged samples on hit rays) on 1536 rays through a posed body"""
+    posed, faces, T = small_body(G)
+    cap = G.syn.SimpleCapture(96, 96, fx=190., c2w=G.syn.spherical_c2w(20., -10., 3.0), near=0.5, far=4.0)
+    coords = O.all_pixel_coords(cap.shape)
+    coords = coords[(coords[:, 1] >= 40) & (coords[:, 1] < 56)]
+    o, d = O.shot_rays(cap.intrinsic_matrix, cap.cam_pose.camera_to_world, coords)
+    o, d = o.astype(np.float32), d.astype(np.float32)
+    coarse, fine, human = G.nets[0], G.nets[1], G.nets[2]
+    mesh = G.ray.mesh_to_device(posed, faces, T, 'cuda')
+    trace = {}
+    rgb, depth, acc = G.render.render_hybrid_rays(coarse[0], fine[0], human[0], cu(o), cu(d), cap.near['bkg'], cap.far['bkg'], cu(posed), mesh,
+                                                  128, 128, trace=trace)
+    assert trace['bkg_z'][0].shape[1] == 256 and trace['human_z'][0].shape[1] == 128
+    c_rgb, hits = conditional_hybrid(G, {'fine': fine[1], 'human': human[1]}, o, d, trace, 1, 128)
+    assert 200 < hits[0].size < o.shape[0] - 200, hits[0].size                     # hit and miss rays both well represented
+    e = np.abs(rgb.cpu().numpy() - c_rgb).max(-1)
+    print(f"[C4] {o.shape[0]} rays ({hits[0].size} hit, merged 384 samples): oracle nets + merge + compositing on the device's samples and "
+          f"warped points: Linf {e.max():.2e} (hit rays {e[hits[0]].max():.2e})")
+    assert e.max() < 1e-4
+    # hit list and the human samples are what the oracle derives from the same rays
+    near, far = O.geometry_guided_near_far(o, d, posed, 0.2)
+    o_hit = np.nonzero(near < far)[0]
+    assert np.intersect1d(o_hit, hits[0]).size >= 0.99 * max(o_hit.size, hits[0].size)
+    common = np.intersect1d(o_hit, hits[0])
+    _, _, hz = O.ray_to_samples(o[common], d[common], near[common][:, None], far[common][:, None], 128)
+    dev_hz = trace['human_z'][0].cpu().numpy()[np.searchsorted(hits[0], common)]
+    assert np.abs(dev_hz - hz).max() < 3e-5                                        # near / far carry ~1e-5 of sqrt rounding
+
+
+def test_c5_three_actor_slice_192_128_3x192(G):
+    """three actors (background 192 + 128 and 3 x 192 -> 896 merged samples, zero-raw placeholders at z in [2 far, 3 far] for
+    actors a ray misses, render_utils.py:418-419) on 768 rays"""
+    posed, faces, T = small_body(G)
+    shifts = [np.zeros(3), np.array([0.35, 0.0, 0.2]), np.array([-0.3, 0.05, -0.15])]
+    posed_l = [(posed + s).astype(np.float32) for s in shifts]
+    T_l = []
+    for s in shifts:
+        t = T.copy()
+        t[:, :3, 3] += s
+        T_l.append(t)
+    cap = G.syn.SimpleCapture(96, 96, fx=150., c2w=G.syn.spherical_c2w(20., -10., 3.0), near=0.5, far=3.14)
+    coords = O.all_pixel_coords(cap.shape)
+    coords = coords[(coords[:, 1] >= 44) & (coords[:, 1] < 52)]
+    o, d = O.shot_rays(cap.intrinsic_matrix, cap.cam_pose.camera_to_world, coords)
+    o, d = o.astype(np.float32), d.astype(np.float32)
+    coarse, fine, human = G.nets[0], G.nets[1], G.nets[2]
+    meshes = [G.ray.mesh_to_device(p, faces, t, 'cuda') for p, t in zip(posed_l, T_l)]
+    trace = {}
+    rgb, depth = G.render.render_multi_rays(coarse[0], fine[0], [human[0]] * 3, cu(o), cu(d), cap.near['bkg'], cap.far['bkg'],
+                                            [cu(p) for p in posed_l], meshes, 192, 128, trace=trace)
+    assert trace['bkg_z'][0].shape[1] == 320
+    c_rgb, hits = conditional_hybrid(G, {'fine': fine[1], 'human': human[1]}, o, d, trace, 3, 192)
+    n_hit = [h.size for h in hits]
+    assert all(n > 50 for n in n_hit), n_hit
+    e = np.abs(rgb.cpu().numpy() - c_rgb).max(-1)
+    print(f"[C5] {o.shape[0]} rays, hits per actor {n_hit}, merged 896 samples: conditional Linf {e.max():.2e}")
+    assert e.max() < 1e-4
