@@ -344,6 +344,38 @@ def main():
                               "difference d into a position difference d / pdf, and the synthetic workload's fine net (an independent random field) "
                               "turns that into colour; the oracle itself differs from the reference's own output on ~0.5 % of the rays of "
                               "configuration 1 for the same reason (tests/test_oracle_golden.py)")
+        workloads = None
+        if extras and world == 1 and not args.no_other_precisions:
+            # early ray termination (north star) on the workload that can show it: the 'opaque' preset (surface-like sigma; the
+            # same field for the coarse and the fine net, as a trained pair agrees on where the surfaces are).  Same frame, same
+            # sample counts; eps = 0 is the reference's semantics (every sample evaluated), eps = 1e-4 drops rays whose
+            # transmittance fell below it at a 32-sample chunk boundary.  Never `value`.
+            net = synthetic.make_joiner(1, preset='opaque').to(dev)
+            net.precision = args.precision
+            res = {}
+            with torch.no_grad():
+                for eps in (0.0, 1e-4):
+                    render_utils.TERMINATION_EPS = eps
+                    try:
+                        tr = {}
+                        rgb_e, _ = render_utils.render_vanilla_rays(net, net, origins, dirs, 0.0, 3.14, S, NI, True, trace=tr)
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        for _ in range(args.steps):
+                            render_utils.render_vanilla_rays(net, net, origins, dirs, 0.0, 3.14, S, NI, True)
+                        torch.cuda.synchronize()
+                        dte = (time.perf_counter() - t1) / args.steps
+                    finally:
+                        render_utils.TERMINATION_EPS = 0.0
+                    res[eps] = (rgb_e, dte, tr.get('march', [None])[0])
+            st = res[1e-4][2]
+            workloads = {"opaque_preset_early_termination": {
+                "what": "800x800, 128 + 128 samples, synthetic.make_joiner(1, preset='opaque') as coarse and fine net; fine pass marched front to "
+                        "back in 32-sample chunks with ballot / prefix-sum compaction of the live rays between chunks (nm_mlp_forward_ray_chunk, "
+                        "nm_transmittance_chunk, nm_compact_hits), no host synchronisation between chunks",
+                "eps": 1e-4, "rays_per_s_every_sample": total / res[0.0][1], "rays_per_s_terminated": total / res[1e-4][1],
+                "speedup": res[0.0][1] / res[1e-4][1], "fine_evaluations_done": st['evaluated'] / st['total'] if st else None,
+                "rgb_linf_vs_every_sample": float((res[0.0][0] - res[1e-4][0]).abs().max())}}
         line = {
             "metric": "rays_per_sec (800x800 frame, 128 samples/ray coarse + 128 importance, NeuMan background NeRF)",
             "value": total * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -355,6 +387,7 @@ def main():
                        "parallelism": f"ray-tile sharding x{world}, 1 gather/frame", "tile_rays": TILE, "precision": args.precision},
             "parity_vs_oracle": parity,
             "other_precisions": others,
+            "other_workloads": workloads,
             "roofline": rl_fine,
             "roofline_coarse": rl_coarse,
         }

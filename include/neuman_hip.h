@@ -161,6 +161,21 @@ int nm_mlp_forward_rays(nm_mlp_t mlp, const float* origin, const float* directio
  * precisions evaluate everything and return the colours too. */
 int nm_mlp_sigma_rays(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals,
                       int64_t R, int S, int precision, float sigma_scale, float* out, nm_stream_t stream);
+/* Front-to-back marching with early ray termination (the north star's "wavefront ballot / prefix-sum for early termination
+ * and sample compaction ... MLP over the compacted (rays x samples) batch"; the reference evaluates every sample,
+ * utils/render_utils.py:139-151).  One chunk of the pass: samples s0 .. s0+S-1 of the rays listed in ray_idx [n_rays]
+ * (int32, compacted list of live rays; when n_rays_dev is non-null the list's length is read from the device and n_rays
+ * is only its upper bound, so no host synchronisation separates the chunks).  origin / direction [R,3], z_vals
+ * [R,S_total], out [R,S_total,4]: only the listed rays' records of this chunk are written (pre-zeroed records of samples
+ * never evaluated composite with weight exactly 0).  NM_PREC_FP32 is not available in this form. */
+int nm_mlp_forward_ray_chunk(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals, int S_total,
+                             const int32_t* ray_idx, const int32_t* n_rays_dev, int64_t n_rays, int s0, int S, int precision,
+                             float sigma_scale, float* out, nm_stream_t stream);
+/* T[r] *= prod_{i in chunk} (1 - alpha_i + 1e-10) for the listed rays (ray_idx nullable = rays 0..n_rays-1): the
+ * transmittance factors of raw2outputs (render_utils.py:85-95) over samples s0 .. s0+S-1 of raw [R,S_total,4]; rays whose T
+ * falls below the caller's epsilon are dropped by nm_compact_hits(eps, T). */
+int nm_transmittance_chunk(const float* raw, const float* z_vals, const float* rays_d, const int32_t* ray_idx, const int32_t* n_rays_dev,
+                           int64_t n_rays, int s0, int S, int S_total, float* T, nm_stream_t stream);
 /* Debug: stop after `stage` and write that stage's activations as f32 [n, width_of_stage]:
  *   -1 -> position PE (64 wide, col 63 = 0);  0..7 -> relu(pts_linears[i]) (256);
  *    8 -> feature_linear output (256);  9 -> relu(views_linears[0]) (128). */

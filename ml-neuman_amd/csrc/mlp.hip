@@ -31,13 +31,14 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 
 // NM_PREC_FP16X3: the same three-product scheme on split fp16 (11 + 11 significand bits instead of 8 + 8: the dropped
 // wl*xl term and the representation error are ~2^-22, float32 class).  fp16's narrow exponent range is handled by exact
-// power-of-two scalings: weights are stored as W * 2^8 (a weight's lo part stays a normal number down to |W| ~ 5e-4),
-// activations and encodings as X * 2^5 (lo normal down to |X| ~ 4e-3, hi finite up to |X| = 2047); accumulators therefore
-// carry Y * 2^13 (biases are pre-scaled) and the epilogue multiplies by 2^-8 before the split.  Parts that fall below
-// fp16's normal range lose at most 2^-25 * 2^-5 (activations) / 2^-25 * 2^-8 (weights) absolutely, flushed or not.
+// power-of-two scalings: the weights of stage s are stored as W * 2^k_s, k_s = 8 unless the stage's largest weight needs
+// less (mlp_host.hip pack_image: |W| * 2^k_s <= 32000, so a weight's lo part stays a normal number down to |W| ~ 5e-4 for
+// ordinary layers), activations and encodings as X * 2^5 (lo normal down to |X| ~ 4e-3, hi clamped at |X| = 2047);
+// accumulators therefore carry Y * 2^(k_s + 5) (biases are pre-scaled) and the epilogue multiplies by 2^-k_s before the
+// split (the per-stage factors sit behind the bias table).  Parts that fall below fp16's normal range lose at most
+// 2^-25 * 2^-5 (activations) / 2^-25 * 2^-k_s (weights) absolutely, flushed or not.
 constexpr bool is_split(int prec) { return prec == NM_PREC_BF16X3 || prec == NM_PREC_FP16X3; }
-constexpr float kF16ActScale = 32.f, kF16WScale = 256.f;
-constexpr float kF16AccToAct = 1.f / kF16WScale, kF16AccToOut = 1.f / (kF16ActScale * kF16WScale);
+constexpr float kF16ActScale = 32.f;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -71,7 +72,10 @@ struct MlpArgs {
     unsigned long long* prof;  // PROF instantiation only: [grid*8 waves][8] cycle buckets
     int64_t n;
     int S;
-    int in_mode;
+    int in_mode;             // 0: points / directions given; 1: rays + z [R,S]; 2: a chunk of S samples starting at s0 of the listed rays
+    const int* ray_idx;      // in_mode 2: [n / S] global ray numbers (compacted list of live rays)
+    const int* n_rays_dev;   // in_mode 2: the list's length lives on the device (no host sync between chunks); n = *n_rays_dev * S
+    int s0, S_total;         // in_mode 2: z and out are [R, S_total] (x4); this launch covers samples s0 .. s0 + S - 1
     int stop_stage;          // -2 = run everything
     float sigma_scale;
     int sigma_only;          // 1: only the density head is wanted (a pass whose colours the renderer discards): skip the
@@ -103,6 +107,39 @@ __device__ __forceinline__ float pe_feature(int p, float x0, float x1, float x2,
     if (p < 3) return p == 0 ? x0 : (p == 1 ? x1 : x2);
     if (m >= 6 * spec.nfreq) return 0.f;                      // zero padding slots
     return is_cos ? cv : sv;
+}
+
+// sample i of the launch -> the 3-vector to encode (position or direction) and, for the stores, its record in `out`
+__device__ __forceinline__ int64_t sample_record(const MlpArgs& a, int64_t i) {
+    if (a.in_mode != 2) return i;
+    const int64_t j = i / a.S;
+    return (int64_t)a.ray_idx[j] * a.S_total + a.s0 + (i - j * a.S);
+}
+__device__ __forceinline__ void sample_input(const MlpArgs& a, int64_t i, bool is_dir, float& x0, float& x1, float& x2) {
+    if (a.in_mode == 0) {
+        const float* src = (is_dir ? a.dirs : a.pts) + i * 3;
+        x0 = src[0]; x1 = src[1]; x2 = src[2];
+        return;
+    }
+    int64_t r, zi;
+    if (a.in_mode == 1) {
+        r = i / a.S;
+        zi = i;
+    } else {
+        const int64_t j = i / a.S;
+        r = a.ray_idx[j];
+        zi = r * a.S_total + a.s0 + (i - j * a.S);
+    }
+    const float* d = a.direction + r * 3;
+    if (is_dir) {
+        x0 = d[0]; x1 = d[1]; x2 = d[2];                        // ray_utils.py:132
+    } else {
+        const float zz = a.z[zi];
+        const float* o = a.origin + r * 3;
+        x0 = o[0] + d[0] * zz;                                  // ray_utils.py:131 (two roundings: built with -ffp-contract=off)
+        x1 = o[1] + d[1] * zz;
+        x2 = o[2] + d[2] * zz;
+    }
 }
 
 // split 8 f32 into 16-bit hi and lo chunks (RNE both times; x - float(hi) is exact in f32).  F16: fp16 parts of
@@ -270,7 +307,7 @@ struct ActRegs {
     uint4 hi[MB][2], lo[MB][2];
 };
 template <int MB, bool RELU, int PREC>
-__device__ __forceinline__ void convert_act(const f32x16 (&acc)[MB], ActRegs<MB>& r) {
+__device__ __forceinline__ void convert_act(const f32x16 (&acc)[MB], ActRegs<MB>& r, float acc2act = 1.f) {
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -278,7 +315,7 @@ __device__ __forceinline__ void convert_act(const f32x16 (&acc)[MB], ActRegs<MB>
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = acc[mb][8 * qp + e];
-            split8<RELU, PREC == NM_PREC_FP16X3>(v, r.hi[mb][qp], r.lo[mb][qp], kF16AccToAct);
+            split8<RELU, PREC == NM_PREC_FP16X3>(v, r.hi[mb][qp], r.lo[mb][qp], acc2act);
         }
 }
 template <int MB, int PREC>
@@ -305,22 +342,7 @@ __device__ __forceinline__ void fill_pe(uint4* lds, int nchunks, bool is_dir, co
         int64_t i = base + row;
         if (i >= a.n) i = a.n - 1;                              // tail rows recompute the last sample (never stored)
         float x0, x1, x2;
-        if (a.in_mode == 0) {
-            const float* src = (is_dir ? a.dirs : a.pts) + i * 3;
-            x0 = src[0]; x1 = src[1]; x2 = src[2];
-        } else {
-            const int64_t r = i / a.S;
-            const float* d = a.direction + r * 3;
-            if (is_dir) {
-                x0 = d[0]; x1 = d[1]; x2 = d[2];                // ray_utils.py:132
-            } else {
-                const float zz = a.z[i];
-                const float* o = a.origin + r * 3;
-                x0 = o[0] + d[0] * zz;                          // ray_utils.py:131 (two roundings: built with -ffp-contract=off)
-                x1 = o[1] + d[1] * zz;
-                x2 = o[2] + d[2] * zz;
-            }
-        }
+        sample_input(a, i, is_dir, x0, x1, x2);
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = pe_feature(8 * c + e, x0, x1, x2, spec, tab);
@@ -369,20 +391,7 @@ __device__ __forceinline__ void fill_pe_fast(uint4* lds, bool is_dir, const MlpA
     int64_t i = base + row;
     if (i >= a.n) i = a.n - 1;
     float x0, x1, x2;
-    if (a.in_mode == 0) {
-        const float* src = (is_dir ? a.dirs : a.pts) + i * 3;
-        x0 = src[0]; x1 = src[1]; x2 = src[2];
-    } else {
-        const int64_t r = i / a.S;
-        const float* d = a.direction + r * 3;
-        if (is_dir) {
-            x0 = d[0]; x1 = d[1]; x2 = d[2];
-        } else {
-            const float zz = a.z[i];
-            const float* o = a.origin + r * 3;
-            x0 = o[0] + d[0] * zz; x1 = o[1] + d[1] * zz; x2 = o[2] + d[2] * zz;     // ray_utils.py:131
-        }
-    }
+    sample_input(a, i, is_dir, x0, x1, x2);
     const float xj = j == 0 ? x0 : (j == 1 ? x1 : x2);
     float a0;
     if (spec.kind == NM_PE_POSENC) a0 = xj * tab[0];
@@ -455,8 +464,15 @@ __device__ __forceinline__ void dump_act(const uint4* lds, bool from_pe, int wid
 
 // PROF: accumulate s_memtime deltas per wave into 6 buckets {pe, k-loops, wait before epilogue, epilogue, wait after
 // epilogue, tail} (a.prof[(block*8 + wave)*8 + bucket]); a separate instantiation so the production kernel is untouched.
+// in_mode 2 launches size themselves on the device: the live-ray count is the output of the compaction that ran just before
+__device__ __forceinline__ MlpArgs resolve_args(MlpArgs a) {
+    if (a.in_mode == 2 && a.n_rays_dev) a.n = (int64_t)(*a.n_rays_dev) * a.S;
+    return a;
+}
+
 template <int PREC, bool PROF>
-__global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) {
+__global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_in) {
+    const MlpArgs a = resolve_args(a_in);
     unsigned long long pr[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = PROF ? __builtin_readcyclecounter() : 0;
 #define NM_TICK(b)                                                   \
@@ -467,7 +483,11 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
     }
     __shared__ uint4 lds[LDS_U4];
     constexpr bool F16 = PREC == NM_PREC_FP16X3;
-    constexpr float oscale = F16 ? kF16AccToOut : 1.f;            // accumulators of the fp16 mode carry Y * 2^13 (exact to undo)
+    // accumulators of the fp16 mode carry Y * 2^(k_stage + 5): per-stage factors 2^-k (-> stored activations) and 2^-(k+5)
+    // (-> outputs) follow the bias table of that mode's image (exact to undo; wave-uniform scalar loads)
+    const float* f16tab = a.bias + nm::kBiasFloats;
+    auto acc2act = [&](int st) { return F16 ? f16tab[st] : 1.f; };
+    auto acc2out = [&](int st) { return F16 ? f16tab[nm::kStages + st] : 1.f; };
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -516,7 +536,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
             bias_prefetch(B, a.bias + nm::stage_b_off(st + 1) + 32 * w, g);     // next stage (st + 1 <= 8), block w
             NM_TICK(1)
             ActRegs<4> ar;
-            convert_act<4, true, PREC>(acc, ar);
+            convert_act<4, true, PREC>(acc, ar, acc2act(st));
             NM_TICK(3)
             __syncthreads();                                              // every wave has finished reading H (and P)
             NM_TICK(2)
@@ -545,7 +565,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
                 init_bias<1>(aacc, B);
                 k_run<1, PREC>(aacc, W, wsrc, voff, so_s8a, so_s0, lds + H_BASE + g * kChunkU4 + 32 * w + s, sh.steps);
                 const int64_t i = base + 32 * w + s;
-                if (g == 0 && i < a.n) reinterpret_cast<float4*>(a.out)[i] = make_float4(0.f, 0.f, 0.f, aacc[0][0] * oscale * a.sigma_scale);
+                if (g == 0 && i < a.n) reinterpret_cast<float4*>(a.out)[sample_record(a, i)] = make_float4(0.f, 0.f, 0.f, aacc[0][0] * acc2out(8) * a.sigma_scale);
             }
             bias_prefetch(B, a.bias + nm::stage_b_off(0) + 32 * w, g);
             NM_TICK(1)
@@ -565,12 +585,12 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
                 bias_prefetch(B, a.bias + nm::stage_b_off(8) + 32 * 8, g);
                 init_bias<1>(aacc, B);
                 k_run<1, PREC>(aacc, W, wsrc, voff, so_s8a, so_s9, lds + H_BASE + g * kChunkU4 + 32 * w + s, sh.steps);
-                sigma = aacc[0][0] * oscale;                      // feature row 0 of the block: lanes 0..31 (g == 0)
+                sigma = aacc[0][0] * acc2out(8);                     // feature row 0 of the block: lanes 0..31 (g == 0)
             }
             bias_prefetch(B, a.bias + nm::stage_b_off(9) + 32 * (w & 3), g);
             NM_TICK(1)
             ActRegs<4> ar;
-            convert_act<4, false, PREC>(acc, ar);
+            convert_act<4, false, PREC>(acc, ar, acc2act(8));
             NM_TICK(3)
             __syncthreads();
             NM_TICK(2)
@@ -600,7 +620,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
             bias_prefetch(B, w < 4 ? a.bias + nm::stage_b_off(10) : a.bias + nm::stage_b_off(0) + 32 * w, g);
             NM_TICK(1)
             ActRegs<2> ar;
-            convert_act<2, true, PREC>(vacc, ar);
+            convert_act<2, true, PREC>(vacc, ar, acc2act(9));
             NM_TICK(3)
             __syncthreads();
             NM_TICK(2)
@@ -626,7 +646,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a) 
             bias_prefetch(B, a.bias + nm::stage_b_off(0) + 32 * w, g);
             const int64_t i = base + 32 * w + s;
             if (g == 0 && i < a.n)                                // rows 0,1,2 = regs 0,1,2 of the g == 0 half
-                reinterpret_cast<float4*>(a.out)[i] = make_float4(racc[0][0] * oscale, racc[0][1] * oscale, racc[0][2] * oscale, sigma * a.sigma_scale);
+                reinterpret_cast<float4*>(a.out)[sample_record(a, i)] = make_float4(racc[0][0] * acc2out(10), racc[0][1] * acc2out(10), racc[0][2] * acc2out(10), sigma * a.sigma_scale);
         }
         NM_TICK(1)
         __syncthreads();                                          // H / P are rewritten by the next tile
@@ -940,7 +960,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_i8w_kernel(const MlpArgs
         t_prev = t_now;                                              \
     }
     __shared__ uint4 lds[LDS_U4];
-    const MlpArgs& a = A.a;
+    const MlpArgs a = resolve_args(A.a);
     const int tid0 = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int G = w >> 2, wq = w & 3;                          // wave group (tile half) and this wave's feature quarter
@@ -1180,7 +1200,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_i8w_kernel(const MlpArgs
             asm volatile("" : "+v"(ls));
             const int64_t i = base + row0 + 32 * wq + ls;
             if (g == 0 && i < a.n)
-                reinterpret_cast<float4*>(a.out)[i] = make_float4(fr[0][0] * cst[nm::stage_b_off(10)], fr[0][1] * cst[nm::stage_b_off(10) + 1],
+                reinterpret_cast<float4*>(a.out)[sample_record(a, i)] = make_float4(fr[0][0] * cst[nm::stage_b_off(10)], fr[0][1] * cst[nm::stage_b_off(10) + 1],
                                                                   fr[0][2] * cst[nm::stage_b_off(10) + 2], sigma * a.sigma_scale);
         }
     }
@@ -1199,8 +1219,12 @@ namespace nm {
 
 int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
                     const float* z, int64_t n, int S, int in_mode, int precision, int stop_stage, float sigma_scale, float* out,
-                    float* dbg, void* prof, hipStream_t stream, int sigma_only) {
+                    float* dbg, void* prof, hipStream_t stream, int sigma_only, const MlpChunk* chunk) {
     MlpArgs a;
+    a.ray_idx = chunk ? chunk->ray_idx : nullptr;
+    a.n_rays_dev = chunk ? chunk->n_rays_dev : nullptr;
+    a.s0 = chunk ? chunk->s0 : 0;
+    a.S_total = chunk ? chunk->S_total : S;
     a.wpack = reinterpret_cast<const uint4*>(precision == NM_PREC_FP16X3 ? L.wpack16 : L.wpack);
     a.bias = precision == NM_PREC_FP16X3 ? L.bias16 : L.bias;
     a.petab = L.petab;

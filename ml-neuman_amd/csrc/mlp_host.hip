@@ -130,10 +130,26 @@ static float stage_weight(const nm_mlp_desc* d, const float* const* P, int st, i
     }
 }
 
-// f16 = false: split bf16 of W (NM_PREC_BF16X3 / NM_PREC_BF16); true: split fp16 of W * 2^8 and biases * 2^13 (NM_PREC_FP16X3,
-// scalings of mlp.hip kF16WScale / kF16ActScale).  Same fragment layout.
+// f16 = false: split bf16 of W (NM_PREC_BF16X3 / NM_PREC_BF16); true (NM_PREC_FP16X3): split fp16 of W * 2^k_s per stage,
+// k_s = min(8, floor(log2(32000 / max|W_s|))), biases * 2^(k_s + 5), and behind the bias table the per-stage factors
+// [2^-k_s (11)] [2^-(k_s+5) (11)] the kernel undoes the scalings with (csrc/mlp.hip).  Same fragment layout.
+constexpr int kF16TabFloats = 2 * kStages + 2;
+static inline int64_t image_bytes() { return kWeightBytes + kWeightPadBytes + ((int64_t)kBiasFloats + kF16TabFloats) * 4; }
 static void pack_image(const nm_mlp_desc* d, const float* const* P, uint8_t* img, bool f16 = false) {
-    memset(img, 0, (size_t)(kWeightBytes + kWeightPadBytes + (int64_t)kBiasFloats * 4));
+    memset(img, 0, (size_t)image_bytes());
+    float wscale[kStages];
+    for (int st = 0; st < kStages; ++st) {
+        wscale[st] = 1.f;
+        if (!f16) continue;
+        const StageShape sh = stage_shape(st);
+        float mx = 0.f;
+        for (int n = 0; n < sh.nblk * 32; ++n)
+            for (int cc = 0; cc < 2 * sh.steps; ++cc)
+                for (int e = 0; e < 8; ++e) mx = fmaxf(mx, fabsf(stage_weight(d, P, st, n, cc, e)));
+        int k = 8;
+        while (k > -40 && mx * ldexpf(1.f, k) > 32000.f) --k;
+        wscale[st] = ldexpf(1.f, k);
+    }
     for (int st = 0; st < kStages; ++st) {
         const StageShape sh = stage_shape(st);
         for (int nb = 0; nb < sh.nblk; ++nb)
@@ -144,7 +160,7 @@ static void pack_image(const nm_mlp_desc* d, const float* const* P, uint8_t* img
                     for (int j = 0; j < 8; ++j) {
                         const float wv = stage_weight(d, P, st, 32 * nb + (lane & 31), 2 * t + (lane >> 5), j);
                         if (f16) {
-                            const float ws = wv * 256.f;
+                            const float ws = wv * wscale[st];
                             const uint16_t h = f32_to_f16(ws);
                             hi[lane * 8 + j] = h;
                             lo[lane * 8 + j] = f32_to_f16(ws - f16_to_f32(h));
@@ -164,8 +180,14 @@ static void pack_image(const nm_mlp_desc* d, const float* const* P, uint8_t* img
         else if (st == 9) memcpy(b, P[P_VIEWS_B], 128 * 4);
         else memcpy(b, P[P_RGB_B], 3 * 4);
     }
-    if (f16)
-        for (int i = 0; i < kBiasFloats; ++i) bias[i] *= 8192.f;        // accumulators carry Y * 2^(8+5)
+    if (f16) {
+        for (int st = 0; st < kStages; ++st) {
+            const StageShape sh = stage_shape(st);
+            for (int i = 0; i < sh.nblk * 32; ++i) bias[stage_b_off(st) + i] *= wscale[st] * 32.f;   // accumulators carry Y * 2^(k_s + 5)
+            bias[kBiasFloats + st] = 1.f / wscale[st];
+            bias[kBiasFloats + kStages + st] = 1.f / (wscale[st] * 32.f);
+        }
+    }
 }
 
 // ---- NM_PREC_I8X3 image: [fragments (i8 limb steps, then bf16 PE steps) | pad | units | biases | kappa] ----------------
@@ -323,7 +345,7 @@ int nm_device_count(void) {
 
 int64_t nm_mlp_pack_bytes(const nm_mlp_desc* desc) {
     if (nm::validate_desc(desc) != NM_OK) return -1;
-    return nm::kWeightBytes + nm::kWeightPadBytes + (int64_t)nm::kBiasFloats * 4;
+    return nm::image_bytes();
 }
 
 int nm_mlp_pack(const nm_mlp_desc* desc, const float* const* host_params, void* host_out) {
@@ -438,13 +460,15 @@ int nm_mlp_destroy(nm_mlp_t m) {
 
 static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const float* origin, const float* direction,
                         const float* z, int64_t n, int S, int in_mode, int precision, int stop_stage, float sigma_scale,
-                        float* out, float* dbg, nm_stream_t stream, void* prof = nullptr, int sigma_only = 0) {
+                        float* out, float* dbg, nm_stream_t stream, void* prof = nullptr, int sigma_only = 0,
+                        const nm::MlpChunk* chunk = nullptr) {
     NM_REQUIRE(m, "nm_mlp_forward: null handle");
     NM_REQUIRE(n >= 0, "nm_mlp_forward: negative n");
     NM_REQUIRE(precision == NM_PREC_FP32 || precision == NM_PREC_BF16X3 || precision == NM_PREC_BF16 || precision == NM_PREC_I8X3 ||
                    precision == NM_PREC_FP16X3,
                "nm_mlp_forward: bad precision %d", precision);
     if (n == 0) return NM_OK;
+    NM_REQUIRE(!(chunk && precision == NM_PREC_FP32), "nm_mlp_forward_ray_chunk: the exact-f32 validation kernel has no chunked form");
     if (precision == NM_PREC_FP32) {
         nm::RefLaunch L;
         L.wt = m->d_ref; L.bias = m->d_ref; L.petab = m->d_petab;
@@ -464,7 +488,7 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
     L.wstream8 = m->d_stream8;
     L.consts8 = m->d_consts8;
     return nm::launch_mlp_mfma(L, pts, dirs, origin, direction, z, n, S, in_mode, precision, stop_stage, sigma_scale, out, dbg,
-                               prof, nm::as_stream(stream), sigma_only);
+                               prof, nm::as_stream(stream), sigma_only, chunk);
 }
 
 int nm_mlp_forward(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision, float sigma_scale,
@@ -490,6 +514,17 @@ int nm_mlp_sigma_rays(nm_mlp_t mlp, const float* origin, const float* direction,
     NM_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "nm_mlp_sigma_rays: out must be 16-byte aligned");
     return mlp_dispatch(mlp, nullptr, nullptr, origin, direction, z_vals, R * (int64_t)S, S, 1, precision, -2, sigma_scale, out,
                         nullptr, stream, nullptr, 1);
+}
+
+int nm_mlp_forward_ray_chunk(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals, int S_total,
+                             const int32_t* ray_idx, const int32_t* n_rays_dev, int64_t n_rays, int s0, int S, int precision,
+                             float sigma_scale, float* out, nm_stream_t stream) {
+    NM_REQUIRE(n_rays == 0 || (origin && direction && z_vals && ray_idx && out), "nm_mlp_forward_ray_chunk: null pointer");
+    NM_REQUIRE(n_rays >= 0 && S >= 1 && s0 >= 0 && s0 + S <= S_total, "nm_mlp_forward_ray_chunk: bad sizes (s0=%d S=%d S_total=%d)", s0, S, S_total);
+    NM_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "nm_mlp_forward_ray_chunk: out must be 16-byte aligned");
+    nm::MlpChunk c{ray_idx, n_rays_dev, s0, S_total};
+    return mlp_dispatch(mlp, nullptr, nullptr, origin, direction, z_vals, n_rays * (int64_t)S, S, 2, precision, -2, sigma_scale, out,
+                        nullptr, stream, nullptr, 0, &c);
 }
 
 int nm_mlp_forward_profile(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision, float* out,

@@ -16,9 +16,15 @@ struct RefLaunch {
     int pe_kind, pos_nfreq, dir_nfreq;
 };
 
+// in_mode 2: the launch covers samples s0 .. s0 + S - 1 of the rays listed in ray_idx (n = upper bound of listed rays * S; the
+// actual list length is read from *n_rays_dev on the device when that is non-null); z and out are [R, S_total] (x4)
+struct MlpChunk {
+    const int* ray_idx; const int* n_rays_dev; int s0, S_total;
+};
+
 int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
                     const float* z, int64_t n, int S, int in_mode, int precision, int stop_stage, float sigma_scale, float* out,
-                    float* dbg, void* prof, hipStream_t stream, int sigma_only = 0);
+                    float* dbg, void* prof, hipStream_t stream, int sigma_only = 0, const MlpChunk* chunk = nullptr);
 int launch_mlp_ref(const RefLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
                    const float* z, int64_t n, int S, int in_mode, int stop_stage, float sigma_scale, float* out, float* dbg,
                    hipStream_t stream);

@@ -24,6 +24,11 @@ from . import _lib, ray_utils
 from .ray_utils import DEFAULT_GEO_THRESH
 
 MAX_RAYS_PER_LAUNCH = int(os.environ.get("NEUMAN_MAX_RAYS_PER_LAUNCH", 1 << 20))
+# Early ray termination in the shading pass of the background renderers (march_pass_rays): rays whose transmittance has fallen
+# below this are not evaluated any further.  0 = off: every sample is evaluated, as the reference does (render_utils.py:139-151),
+# and the frame is bit-identical to the unchunked path.  eps > 0 changes a pixel by at most eps per channel.
+TERMINATION_EPS = float(os.environ.get("NEUMAN_TERMINATION_EPS", "0"))
+TERMINATION_CHUNK = int(os.environ.get("NEUMAN_TERMINATION_CHUNK", "32"))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -84,6 +89,47 @@ def _note(trace, **kw):
             trace.setdefault(k, []).append(v)
 
 
+def march_pass_rays(net, o, d, z, eps, chunk=None, precision=None, role='shading', stats=None):
+    """Shading pass with early ray termination: the S sorted samples of every ray are evaluated front to back in chunks of
+    `chunk`; after each chunk the rays whose transmittance (the running product of raw2outputs' factors, nm_transmittance_chunk)
+    is below `eps` leave the list (ballot / prefix-sum compaction on the device, nm_compact_hits) and the next MLP launch covers
+    the compacted live rays only (nm_mlp_forward_ray_chunk).  Samples never evaluated keep sigma = 0, i.e. weight exactly 0 in
+    raw2outputs; what they would have contributed is bounded by the transmittance at the cut: < eps per channel.  No host
+    synchronisation between chunks.  -> raw [R,S,4]; `stats` (a dict) receives the evaluation counts (one host sync, at the end)."""
+    _lib.require_gpu()
+    chunk = chunk or TERMINATION_CHUNK
+    R, S = z.shape
+    dev = z.device
+    raw = torch.zeros((R, S, 4), device=dev, dtype=torch.float32)
+    T = torch.ones(R, device=dev, dtype=torch.float32)
+    thr = torch.full((R,), float(eps), device=dev, dtype=torch.float32)
+    live = torch.arange(R, device=dev, dtype=torch.int32)
+    counts = torch.tensor([R, 0], device=dev, dtype=torch.int32)
+    ws = torch.empty(int(_lib.lib().nm_compact_workspace_ints(R)), device=dev, dtype=torch.int32)
+    evaluated = torch.zeros(1, device=dev, dtype=torch.int64) if stats is not None else None
+    o, d, z = o.contiguous(), d.contiguous(), z.contiguous()
+    for s0 in range(0, S, chunk):
+        c = min(chunk, S - s0)
+        if evaluated is not None:
+            evaluated += counts[0].to(torch.int64) * c
+        net.forward_ray_chunk(o, d, z, live, counts, s0, c, raw, precision=precision, role=role)
+        if s0 + c >= S or eps <= 0:                               # (eps = 0: nothing is ever dropped, not even rays whose T underflowed to 0)
+            continue
+        _lib.check(_lib.lib().nm_transmittance_chunk(_lib.dev_ptr(raw), _lib.dev_ptr(z), _lib.dev_ptr(d), _lib.dev_ptr(live, torch.int32),
+                                                     _lib.dev_ptr(counts, torch.int32), R, s0, c, S, _lib.dev_ptr(T), _lib.stream_ptr()),
+                   "nm_transmittance_chunk")
+        nxt = torch.empty(R, device=dev, dtype=torch.int32)
+        counts = torch.zeros(2, device=dev, dtype=torch.int32)
+        _lib.check(_lib.lib().nm_compact_hits(_lib.dev_ptr(thr), _lib.dev_ptr(T), R, _lib.dev_ptr(nxt, torch.int32), None,
+                                              _lib.dev_ptr(counts, torch.int32), _lib.dev_ptr(ws, torch.int32), _lib.stream_ptr()), "nm_compact_hits")
+        live = nxt
+    if stats is not None:
+        n = int(evaluated.item())
+        stats['evaluated'] = stats.get('evaluated', 0) + n
+        stats['total'] = stats.get('total', 0) + R * S
+    return raw
+
+
 def bkg_pass_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, importance_samples_per_ray, white_bkg,
                   precision=None, trace=None):
     """Coarse (+ fine) background evaluation of R rays -> (raw [R,S',4], z [R,S'])  (render_utils.py:131-151, 287-297)."""
@@ -96,7 +142,12 @@ def bkg_pass_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, import
     if fine_net is not None:
         _, _, _, w, _ = raw2outputs(raw, z, d, white_bkg=white_bkg)
         z = ray_utils.importance_z(z, w, importance_samples_per_ray)
-        raw = fine_net.forward_rays(o, d, z, precision=precision, role='shading')
+        if TERMINATION_EPS > 0:
+            stats = {} if trace is not None else None
+            raw = march_pass_rays(fine_net, o, d, z, TERMINATION_EPS, precision=precision, stats=stats)
+            _note(trace, march=stats)
+        else:
+            raw = fine_net.forward_rays(o, d, z, precision=precision, role='shading')
     _note(trace, bkg_z=z)
     return raw, z
 
@@ -202,6 +253,13 @@ def render_multi_rays(coarse_bkg, fine_bkg, human_nets, o, d, bkg_near, bkg_far,
         f = torch.full((nr,), float(bkg_far), device=o.device, dtype=torch.float32)
         raw_all, z_all = bkg_pass_rays(coarse_bkg, fine_bkg, oc, dc, n, f, samples_per_ray, importance_samples_per_ray,
                                        white_bkg, precision, trace)
+        # In this renderer the terminal 1e10 interval sits on an actor's zero-density placeholder whenever a ray misses one
+        # (render_utils.py:418-419), so the LAST background sample is followed by a finite interval of ~far..2 far instead:
+        # alpha = 1 - exp(-sigma * 3.14..) is then ~300x as sensitive to that one sigma as a sample inside the ray is.  Under the
+        # mixed policy (i8x3 shading passes) that single sample per ray is re-evaluated in the float32-class arithmetic.
+        last_net = fine_bkg if fine_bkg is not None else coarse_bkg
+        if last_net._prec(precision, 'shading') == _lib.NM_PREC_I8X3 and (precision or last_net.precision) == 'mixed':
+            raw_all[:, -1, :] = last_net.forward_rays(oc, dc, z_all[:, -1:].contiguous(), precision='fp16x3')[:, 0, :]
         far_z = torch.linspace(float(bkg_far) * 2, float(bkg_far) * 3, samples_per_ray, device=o.device)   # :418-419
         for net, verts, mesh in zip(human_nets, posed_verts, meshes):
             near, far = ray_utils.geometry_guided_near_far(oc, dc, verts, geo_threshold)

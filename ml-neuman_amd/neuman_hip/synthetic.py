@@ -65,14 +65,27 @@ def spherical_c2w(theta_deg, phi_deg, radius):
     return c2w @ np.diag([1., -1., -1., 1.])
 
 
-def make_joiner(seed, mapping='posenc', dense=True, pos_min_freq=0):
+def make_joiner(seed, mapping='posenc', dense=True, pos_min_freq=0, preset=None):
     """One Joiner with torch.manual_seed(seed) default nn.Linear init; `dense` applies the synthetic-dense
     preset of SURVEY 8d (alpha_linear.weight *= 40, alpha_linear.bias = 0.5, rgb_linear.weight *= 8) that keeps
-    sigma away from the 1e10-interval step at 0 and gives non-trivial transmittance."""
+    sigma away from the 1e10-interval step at 0 and gives non-trivial transmittance.
+
+    preset='opaque': the same random field read as SURFACES -- alpha_linear.weight *= 40000, bias = 400: sigma is zero in two
+    thirds of the volume and in the hundreds elsewhere, so a ray crosses empty space and is absorbed within a couple of samples
+    of the first blob it meets (what trained scenes look like to a renderer: the workload early ray termination is for,
+    which the dense preset -- every sample of every ray still visible -- cannot show).  Use the SAME seed for the coarse and the
+    fine net, as a trained pair agrees about where the surfaces are."""
     opt = default_opt(posenc=mapping, pos_min_freq=pos_min_freq)
     torch.manual_seed(seed)
     net, _ = vanilla.build_nerf(opt)
-    if dense:
+    if preset == 'opaque':
+        with torch.no_grad():
+            net.nerf.alpha_linear.weight *= 40000.
+            net.nerf.alpha_linear.bias.fill_(400.)
+            net.nerf.rgb_linear.weight *= 8.
+    elif preset is not None:
+        raise ValueError(preset)
+    elif dense:
         with torch.no_grad():
             net.nerf.alpha_linear.weight *= 40.
             net.nerf.alpha_linear.bias.fill_(0.5)
