@@ -129,6 +129,11 @@ typedef struct nm_mlp_desc {
     int32_t pe_kind;      /* NM_PE_POSENC / NM_PE_ROTATE, used for both inputs (vanilla.py:216,225) */
     int32_t pos_n_freqs;  /* 10 */
     int32_t dir_n_freqs;  /* 4 */
+    int32_t plain_head;   /* 0: the use_viewdirs=True net (alpha / feature / views / rgb heads, vanilla.py:112-115, 133-144);
+                             1: use_viewdirs=False (`--specular_can no`, models/human_nerf.py:28): one output_linear 256 -> 4 =
+                             (r, g, b, sigma) on the eighth layer (vanilla.py:116-117, 145), view directions ignored.  host_params
+                             then holds the 16 pts_linears tensors followed by output_linear.weight [4,256] and .bias [4] (the other
+                             entries are not read).  NM_PREC_I8X3 is not available for this net. */
 } nm_mlp_desc;
 
 int64_t nm_mlp_pack_bytes(const nm_mlp_desc* desc);

@@ -78,7 +78,8 @@ struct MlpArgs {
     int s0, S_total;         // in_mode 2: z and out are [R, S_total] (x4); this launch covers samples s0 .. s0 + S - 1
     int stop_stage;          // -2 = run everything
     float sigma_scale;
-    int sigma_only;          // 1: only the density head is wanted (a pass whose colours the renderer discards): skip the
+    int sigma_only;          // 2: plain-head net (use_viewdirs=False): the 32-row block after layer 7 holds output_linear's 4 rows = the output;
+                             // 1: only the density head is wanted (a pass whose colours the renderer discards): skip the
                              //    feature / views / rgb layers and write (0, 0, 0, sigma)
     PeSpec pos, dir;
 };
@@ -565,7 +566,12 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
                 init_bias<1>(aacc, B);
                 k_run<1, PREC>(aacc, W, wsrc, voff, so_s8a, so_s0, lds + H_BASE + g * kChunkU4 + 32 * w + s, sh.steps);
                 const int64_t i = base + 32 * w + s;
-                if (g == 0 && i < a.n) reinterpret_cast<float4*>(a.out)[sample_record(a, i)] = make_float4(0.f, 0.f, 0.f, aacc[0][0] * acc2out(8) * a.sigma_scale);
+                if (g == 0 && i < a.n) {
+                    const float os = acc2out(8);
+                    reinterpret_cast<float4*>(a.out)[sample_record(a, i)] =
+                        a.sigma_only == 2 ? make_float4(aacc[0][0] * os, aacc[0][1] * os, aacc[0][2] * os, aacc[0][3] * os * a.sigma_scale)   // vanilla.py:145
+                                          : make_float4(0.f, 0.f, 0.f, aacc[0][0] * os * a.sigma_scale);
+                }
             }
             bias_prefetch(B, a.bias + nm::stage_b_off(0) + 32 * w, g);
             NM_TICK(1)
@@ -1230,7 +1236,7 @@ int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, con
     a.petab = L.petab;
     a.pts = pts; a.dirs = dirs; a.origin = origin; a.direction = direction; a.z = z;
     a.out = out; a.dbg = dbg; a.prof = reinterpret_cast<unsigned long long*>(prof); a.n = n; a.S = S; a.in_mode = in_mode; a.stop_stage = stop_stage; a.sigma_scale = sigma_scale;
-    a.sigma_only = (sigma_only && precision != NM_PREC_I8X3) ? 1 : 0;   // (the i8x3 kernel always evaluates the colour head)
+    a.sigma_only = L.plain_head ? 2 : ((sigma_only && precision != NM_PREC_I8X3) ? 1 : 0);   // (the i8x3 kernel always evaluates the colour head)
     a.pos = PeSpec{L.pe_kind, L.pos_nfreq, L.pos_octaves};
     a.dir = PeSpec{L.pe_kind, L.dir_nfreq, L.dir_octaves};
     const int64_t ntiles = (n + kTileM - 1) / kTileM;

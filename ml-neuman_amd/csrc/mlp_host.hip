@@ -85,6 +85,7 @@ static inline float f16_to_f32(uint16_t h) {
 }
 
 // indices into host_params (reference state_dict order, include/neuman_hip.h)
+enum { P_OUT_W = 16, P_OUT_B = 17 };      // plain head (use_viewdirs=False): output_linear follows the 16 pts_linears tensors
 enum { P_PTS_W = 0, P_VIEWS_W = 16, P_VIEWS_B = 17, P_FEAT_W = 18, P_FEAT_B = 19, P_ALPHA_W = 20, P_ALPHA_B = 21, P_RGB_W = 22, P_RGB_B = 23 };
 
 static int validate_desc(const nm_mlp_desc* d) {
@@ -95,6 +96,7 @@ static int validate_desc(const nm_mlp_desc* d) {
     NM_REQUIRE(d->pe_kind == NM_PE_POSENC || d->pe_kind == NM_PE_ROTATE, "nm_mlp: bad pe_kind %d", d->pe_kind);
     NM_REQUIRE(d->pos_n_freqs >= 1 && d->pos_n_freqs <= 10, "nm_mlp: pos_n_freqs %d outside 1..10", d->pos_n_freqs);
     NM_REQUIRE(d->dir_n_freqs >= 1 && d->dir_n_freqs <= 4, "nm_mlp: dir_n_freqs %d outside 1..4", d->dir_n_freqs);
+    NM_REQUIRE(d->plain_head == 0 || d->plain_head == 1, "nm_mlp: plain_head must be 0 or 1, got %d", d->plain_head);
     return NM_OK;
 }
 
@@ -115,15 +117,18 @@ static float stage_weight(const nm_mlp_desc* d, const float* const* P, int st, i
             return P[P_PTS_W + 10][(int64_t)n * K + kpe + slot_feature(cc - 8, e)];
         }
         case 8:
+            if (d->plain_head) return (n >= 256 && n < 260) ? P[P_OUT_W][(int64_t)(n - 256) * 256 + slot_feature(cc, e)] : 0.f;
             if (n < 256) return P[P_FEAT_W][(int64_t)n * 256 + slot_feature(cc, e)];
             return n == 256 ? P[P_ALPHA_W][slot_feature(cc, e)] : 0.f;
         case 9: {
+            if (d->plain_head) return 0.f;
             const int K = 256 + kdpe;
             if (cc < 32) return P[P_VIEWS_W][(int64_t)n * K + slot_feature(cc, e)];
             const int p = 8 * (cc - 32) + e;
             return p < kdpe ? P[P_VIEWS_W][(int64_t)n * K + 256 + p] : 0.f;
         }
         case 10:
+            if (d->plain_head) return 0.f;
             return n < 3 ? P[P_RGB_W][(int64_t)n * 128 + slot_feature(cc, e)] : 0.f;
         default:
             return P[P_PTS_W + 2 * st][(int64_t)n * 256 + slot_feature(cc, e)];
@@ -176,6 +181,7 @@ static void pack_image(const nm_mlp_desc* d, const float* const* P, uint8_t* img
     for (int st = 0; st < kStages; ++st) {
         float* b = bias + stage_b_off(st);
         if (st <= 7) memcpy(b, P[P_PTS_W + 2 * st + 1], 256 * 4);
+        else if (d->plain_head) { if (st == 8) memcpy(b + 256, P[P_OUT_B], 4 * 4); }
         else if (st == 8) { memcpy(b, P[P_FEAT_B], 256 * 4); b[256] = P[P_ALPHA_B][0]; }
         else if (st == 9) memcpy(b, P[P_VIEWS_B], 128 * 4);
         else memcpy(b, P[P_RGB_B], 3 * 4);
@@ -351,7 +357,7 @@ int64_t nm_mlp_pack_bytes(const nm_mlp_desc* desc) {
 int nm_mlp_pack(const nm_mlp_desc* desc, const float* const* host_params, void* host_out) {
     if (int e = nm::validate_desc(desc)) return e;
     NM_REQUIRE(host_params && host_out, "nm_mlp_pack: null pointer");
-    for (int i = 0; i < 24; ++i) NM_REQUIRE(host_params[i], "nm_mlp_pack: host_params[%d] is null", i);
+    for (int i = 0; i < (desc->plain_head ? 18 : 24); ++i) NM_REQUIRE(host_params[i], "nm_mlp_pack: host_params[%d] is null", i);
     nm::pack_image(desc, host_params, static_cast<uint8_t*>(host_out));
     return NM_OK;
 }
@@ -359,7 +365,7 @@ int nm_mlp_pack(const nm_mlp_desc* desc, const float* const* host_params, void* 
 int nm_mlp_pack_f16(const nm_mlp_desc* desc, const float* const* host_params, void* host_out) {
     if (int e = nm::validate_desc(desc)) return e;
     NM_REQUIRE(host_params && host_out, "nm_mlp_pack_f16: null pointer");
-    for (int i = 0; i < 24; ++i) NM_REQUIRE(host_params[i], "nm_mlp_pack_f16: host_params[%d] is null", i);
+    for (int i = 0; i < (desc->plain_head ? 18 : 24); ++i) NM_REQUIRE(host_params[i], "nm_mlp_pack_f16: host_params[%d] is null", i);
     nm::pack_image(desc, host_params, static_cast<uint8_t*>(host_out), true);
     return NM_OK;
 }
@@ -372,6 +378,7 @@ int64_t nm_mlp_pack_i8_bytes(const nm_mlp_desc* desc) {
 int nm_mlp_pack_i8(const nm_mlp_desc* desc, const float* const* host_params, void* host_out) {
     if (int e = nm::validate_desc(desc)) return e;
     NM_REQUIRE(host_params && host_out, "nm_mlp_pack_i8: null pointer");
+    NM_REQUIRE(!desc->plain_head, "nm_mlp_pack_i8: the plain-head (use_viewdirs=False) net has no i8x3 image");
     for (int i = 0; i < 24; ++i) NM_REQUIRE(host_params[i], "nm_mlp_pack_i8: host_params[%d] is null", i);
     nm::pack_image8(desc, host_params, static_cast<uint8_t*>(host_out));
     return NM_OK;
@@ -381,21 +388,26 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
                   const float* host_dir_tab, nm_mlp_t* out) {
     if (int e = nm::validate_desc(desc)) return e;
     NM_REQUIRE(host_params && host_pos_tab && host_dir_tab && out, "nm_mlp_create: null pointer");
-    for (int i = 0; i < 24; ++i) NM_REQUIRE(host_params[i], "nm_mlp_create: host_params[%d] is null", i);
+    const int plain = desc->plain_head;
+    for (int i = 0; i < (plain ? 18 : 24); ++i) NM_REQUIRE(host_params[i], "nm_mlp_create: host_params[%d] is null", i);
     const int64_t bytes = nm_mlp_pack_bytes(desc);
     std::vector<uint8_t> img((size_t)bytes);
     nm::pack_image(desc, host_params, img.data());
     std::vector<uint8_t> img16((size_t)bytes);
     nm::pack_image(desc, host_params, img16.data(), true);
     std::vector<uint8_t> img8((size_t)nm::image8_bytes());
-    nm::pack_image8(desc, host_params, img8.data());
     std::vector<uint8_t> str8((size_t)nm::kWeightBytes8w);
-    nm::pack_stream8(img8.data(), str8.data());
+    if (!plain) {                                               // (no i8x3 form of the plain-head net: those buffers stay zero)
+        nm::pack_image8(desc, host_params, img8.data());
+        nm::pack_stream8(img8.data(), str8.data());
+    }
 
     // reference-layout image for the exact-f32 kernel
     const int kpe = 3 + 6 * desc->pos_n_freqs, kdpe = 3 + 6 * desc->dir_n_freqs;
-    const int K[12] = {kpe, 256, 256, 256, 256, kpe + 256, 256, 256, 256 + kdpe, 256, 256, 128};
-    const int N[12] = {256, 256, 256, 256, 256, 256, 256, 256, 128, 256, 1, 3};
+    // (plain head: layer 10 is output_linear [4,256]; layers 8, 9, 11 are empty)
+    const int K[12] = {kpe, 256, 256, 256, 256, kpe + 256, 256, 256, plain ? 0 : 256 + kdpe, plain ? 0 : 256, 256, plain ? 0 : 128};
+    const int N[12] = {256, 256, 256, 256, 256, 256, 256, 256, plain ? 0 : 128, plain ? 0 : 256, plain ? 4 : 1, plain ? 0 : 3};
+    const int src[12] = {0, 2, 4, 6, 8, 10, 12, 14, 16, 18, plain ? (int)nm::P_OUT_W : 20, 22};
     nm_mlp_s* m = new nm_mlp_s();
     m->desc = *desc;
     int woff = 0;
@@ -404,10 +416,11 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     for (int l = 0; l < 12; ++l) { m->ref_boff[l] = boff; boff += N[l]; }
     std::vector<float> ref((size_t)boff);
     for (int l = 0; l < 12; ++l) {
-        const float* W = host_params[2 * l];
+        if (!K[l]) continue;
+        const float* W = host_params[src[l]];
         for (int k = 0; k < K[l]; ++k)
             for (int n = 0; n < N[l]; ++n) ref[m->ref_off[l] + (size_t)k * N[l] + n] = W[(size_t)n * K[l] + k];
-        memcpy(&ref[m->ref_boff[l]], host_params[2 * l + 1], (size_t)N[l] * 4);
+        memcpy(&ref[m->ref_boff[l]], host_params[src[l] + 1], (size_t)N[l] * 4);
     }
     float tab[192];
     memset(tab, 0, sizeof(tab));
@@ -469,8 +482,11 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
                "nm_mlp_forward: bad precision %d", precision);
     if (n == 0) return NM_OK;
     NM_REQUIRE(!(chunk && precision == NM_PREC_FP32), "nm_mlp_forward_ray_chunk: the exact-f32 validation kernel has no chunked form");
+    NM_REQUIRE(!(m->desc.plain_head && precision == NM_PREC_I8X3), "nm_mlp_forward: the plain-head (use_viewdirs=False) net has no i8x3 form");
+    NM_REQUIRE(!(m->desc.plain_head && stop_stage > 7), "nm_mlp_forward_debug: the plain-head net has stages -1..7 only");
     if (precision == NM_PREC_FP32) {
         nm::RefLaunch L;
+        L.plain_head = m->desc.plain_head;
         L.wt = m->d_ref; L.bias = m->d_ref; L.petab = m->d_petab;
         for (int i = 0; i < 12; ++i) { L.off[i] = m->ref_off[i]; L.boff[i] = m->ref_boff[i]; }
         L.pe_kind = m->desc.pe_kind; L.pos_nfreq = m->desc.pos_n_freqs; L.dir_nfreq = m->desc.dir_n_freqs;
@@ -485,6 +501,7 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
     L.petab = m->d_petab;
     L.pe_kind = m->desc.pe_kind; L.pos_nfreq = m->desc.pos_n_freqs; L.dir_nfreq = m->desc.dir_n_freqs;
     L.pos_octaves = m->pos_octaves; L.dir_octaves = m->dir_octaves;
+    L.plain_head = m->desc.plain_head;
     L.wstream8 = m->d_stream8;
     L.consts8 = m->d_consts8;
     return nm::launch_mlp_mfma(L, pts, dirs, origin, direction, z, n, S, in_mode, precision, stop_stage, sigma_scale, out, dbg,

@@ -8,12 +8,14 @@ struct MlpLaunch {
     const void* wpack; const float* bias; const float* petab;
     int pe_kind, pos_nfreq, dir_nfreq;
     int pos_octaves, dir_octaves;   // encodings whose bands are consecutive powers of two (octave recurrence allowed)
+    int plain_head;                 // use_viewdirs=False net: output_linear instead of the alpha / feature / views / rgb heads
     const void* wpack16; const float* bias16;     // NM_PREC_FP16X3: the same fragment image as split fp16 of W * 2^8, biases * 2^13
     const void* wstream8; const float* consts8;   // NM_PREC_I8X3: per-wave fragment streams; units | biases | kappa (mlp_layout.h)
 };
 struct RefLaunch {
     const float* wt; const float* bias; int off[12]; int boff[12]; const float* petab;
     int pe_kind, pos_nfreq, dir_nfreq;
+    int plain_head;
 };
 
 // in_mode 2: the launch covers samples s0 .. s0 + S - 1 of the rays listed in ray_idx (n = upper bound of listed rays * S; the

@@ -21,6 +21,7 @@ struct RefArgs {
     float* out; float* dbg;
     int64_t n; int S; int in_mode; int stop_stage; float sigma_scale;
     int pe_kind, pos_nfreq, dir_nfreq;
+    int plain_head;           // use_viewdirs=False: layer 10 is output_linear (256 -> 4), layers 8, 9, 11 do not exist
 };
 // layer ids: 0..7 pts_linears, 8 views, 9 feature, 10 alpha, 11 rgb   (reference state_dict order)
 
@@ -107,6 +108,15 @@ __global__ __launch_bounds__(kRefThreads) void nerf_mlp_ref_kernel(const RefArgs
             }
         }
         if (stopped) { __syncthreads(); continue; }
+        if (a.plain_head) {                                                 // outputs = output_linear(h), vanilla.py:145
+            if (grp == 0) {
+                float c[4] = {a.bias[a.boff[10]], a.bias[a.boff[10] + 1], a.bias[a.boff[10] + 2], a.bias[a.boff[10] + 3]};
+                dense<4>(c, a.wt + a.off[10], 4, 0, h, 256, s);
+                if (live) reinterpret_cast<float4*>(a.out)[i] = make_float4(c[0], c[1], c[2], c[3] * a.sigma_scale);
+            }
+            __syncthreads();
+            continue;
+        }
         // alpha (vanilla.py:135) then feature (:136)
         float sigma = 0.f;
         if (grp == 0) {
@@ -169,6 +179,7 @@ int launch_mlp_ref(const RefLaunch& L, const float* pts, const float* dirs, cons
     a.pts = pts; a.dirs = dirs; a.origin = origin; a.direction = direction; a.z = z;
     a.out = out; a.dbg = dbg; a.n = n; a.S = S; a.in_mode = in_mode; a.stop_stage = stop_stage; a.sigma_scale = sigma_scale;
     a.pe_kind = L.pe_kind; a.pos_nfreq = L.pos_nfreq; a.dir_nfreq = L.dir_nfreq;
+    a.plain_head = L.plain_head;
     const int64_t ntiles = (n + kRefTile - 1) / kRefTile;
     const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
     hipLaunchKernelGGL(nerf_mlp_ref_kernel, dim3(grid), dim3(kRefThreads), 0, stream, a);

@@ -24,7 +24,8 @@ PRECISIONS = {"fp32": NM_PREC_FP32, "bf16x3": NM_PREC_BF16X3, "bf16": NM_PREC_BF
 
 class MlpDesc(ctypes.Structure):
     _fields_ = [("depth", ctypes.c_int32), ("width", ctypes.c_int32), ("skip", ctypes.c_int32),
-                ("pe_kind", ctypes.c_int32), ("pos_n_freqs", ctypes.c_int32), ("dir_n_freqs", ctypes.c_int32)]
+                ("pe_kind", ctypes.c_int32), ("pos_n_freqs", ctypes.c_int32), ("dir_n_freqs", ctypes.c_int32),
+                ("plain_head", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/neuman_hip.h one to one (tests/test_abi.py checks the set)

@@ -383,13 +383,47 @@ def ssim_uint8(pred, gt):
 def render_vanilla(coarse_net, cap, fine_net=None, rays_per_batch=32768, samples_per_ray=64, importance_samples_per_ray=128,
                    white_bkg=True, near_far_source='bkg', return_depth=False, ablate_nerft=False):
     """reference render_utils.py:108-161."""
-    if ablate_nerft:
-        raise NotImplementedError("ablate_nerft (time-conditioned ablation net) is outside the HIP path")
     device = _device_of(coarse_net)
+    if ablate_nerft:
+        return _render_vanilla_with_time(coarse_net, cap, fine_net, samples_per_ray, importance_samples_per_ray, white_bkg, near_far_source,
+                                         return_depth, device)
     with torch.no_grad():
         o, d = _all_rays(cap, device)
         rgb, depth = render_vanilla_rays(coarse_net, fine_net, o, d, cap.near[near_far_source], cap.far[near_far_source],
                                          samples_per_ray, importance_samples_per_ray, white_bkg)
+        rgb = rgb.reshape(*cap.shape, -1).cpu().numpy()
+        depth = depth.reshape(*cap.shape).cpu().numpy()
+    return (rgb, depth) if return_depth else rgb
+
+
+def _render_vanilla_with_time(coarse_net, cap, fine_net, samples_per_ray, importance_samples_per_ray, white_bkg, near_far_source, return_depth,
+                              device, rays_per_chunk=8192):
+    """render_vanilla(ablate_nerft=True), reference render_utils.py:134-151: every sample point carries the frame's time
+    `frame_id / total_frames` as a fourth coordinate (ray_utils.py:133-134, 158-159) and the nets encode 4-vectors.  Spelled with
+    the reference-named functions; the nets run on the float32 GEMM chain (Joiner.forward), the sampling and compositing on the
+    usual kernels.  Chunked: that forward keeps its layer outputs while it runs (8 KB per sample)."""
+    with torch.no_grad():
+        o, d = _all_rays(cap, device)
+        R = o.shape[0]
+        cur_time = cap.frame_id['frame_id'] / cap.frame_id['total_frames']
+        rgb = torch.empty((R, 3), device=device, dtype=torch.float32)
+        depth = torch.empty(R, device=device, dtype=torch.float32)
+        for i in range(0, R, rays_per_chunk):
+            j = min(i + rays_per_chunk, R)
+            n = j - i
+            batch = {'origin': o[i:j], 'direction': d[i:j],
+                     'near': torch.full((n, 1), float(cap.near[near_far_source]), device=device),
+                     'far': torch.full((n, 1), float(cap.far[near_far_source]), device=device)}
+            coarse_time = torch.ones((n, samples_per_ray, 1), device=device) * cur_time
+            pts, dirs, z = ray_utils.ray_to_samples(batch, samples_per_ray, device=device, append_t=coarse_time)
+            out = coarse_net(pts, dirs)
+            rgb_c, _, _, w, depth_c = raw2outputs(out, z, dirs[:, 0, :].contiguous(), white_bkg=white_bkg)
+            if fine_net is not None:
+                fine_time = torch.ones((n, samples_per_ray + importance_samples_per_ray, 1), device=device) * cur_time
+                pts, dirs, z = ray_utils.ray_to_importance_samples(batch, z, w, importance_samples_per_ray, device=device, append_t=fine_time)
+                out = fine_net(pts, dirs)
+                rgb_c, _, _, _, depth_c = raw2outputs(out, z, dirs[:, 0, :].contiguous(), white_bkg=white_bkg, want_weights=False)
+            rgb[i:j], depth[i:j] = rgb_c, depth_c
         rgb = rgb.reshape(*cap.shape, -1).cpu().numpy()
         depth = depth.reshape(*cap.shape).cpu().numpy()
     return (rgb, depth) if return_depth else rgb

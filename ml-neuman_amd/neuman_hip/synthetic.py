@@ -93,6 +93,31 @@ def make_joiner(seed, mapping='posenc', dense=True, pos_min_freq=0, preset=None)
     return net.eval()                    # rendering workloads; train() + grad enabled selects the differentiable forward
 
 
+def densify(net):
+    """The synthetic-dense preset on whichever head a Joiner has (ours or the reference's): sigma away from the 1e10-interval
+    step at 0 and non-trivial transmittance."""
+    with torch.no_grad():
+        if net.nerf.use_viewdirs:
+            net.nerf.alpha_linear.weight *= 40.
+            net.nerf.alpha_linear.bias.fill_(0.5)
+            net.nerf.rgb_linear.weight *= 8.
+        else:                                            # plain head: output_linear rows (r, g, b, sigma)
+            net.nerf.output_linear.weight[:3] *= 8.
+            net.nerf.output_linear.weight[3] *= 40.
+            net.nerf.output_linear.bias[3] = 0.5
+    return net
+
+
+def make_variant_joiner(seed, **opt_over):
+    """A dense Joiner of one of the variants beside the default net: use_viewdirs=False (the plain head of `--specular_can no`),
+    raw_pos_dim=4 (the time-conditioned net of `--ablate_nerft`), posenc='rotate' ...  Same seed and construction order as the
+    reference's build_nerf, so the weights equal the ones tests/golden/make_golden_heads.py gave the reference."""
+    opt = default_opt(**opt_over)
+    torch.manual_seed(seed)
+    net, _ = vanilla.build_nerf(opt)
+    return densify(net).eval()
+
+
 def state_numpy(joiner):
     """Joiner weights as {reference state_dict name: f32 numpy} (what oracle/nerf_mlp.py consumes)."""
     return {k: v.detach().cpu().numpy().astype(np.float32) for k, v in joiner.state_dict().items()}

@@ -255,7 +255,7 @@ def mlp_forward_train(joiner, pts, dirs):
     """Joiner.forward with autograd: pts, dirs [..., 3] CUDA f32 -> raw [..., 4]; backward fills the parameters' .grad."""
     _lib.require_gpu()
     shp = pts.shape[:-1]
-    p = pts.reshape(-1, 3).to(torch.float32).contiguous()
+    p = pts.reshape(-1, pts.shape[-1]).to(torch.float32).contiguous()             # (3, or 4 with the time channel of ray_utils.py:133-134)
     d = dirs.reshape(-1, 3).to(torch.float32).contiguous()
     return _MLP.apply(joiner, p, d, *train_params(joiner.nerf)).reshape(*shp, 4)
 

@@ -74,11 +74,14 @@ class NeRF(nn.Module):
             self.output_linear = nn.Linear(width, output_ch)
 
     def ordered_params(self):
-        """The 24 tensors nm_mlp_create expects (include/neuman_hip.h), reference state_dict order."""
-        if not self.use_viewdirs:
-            raise NotImplementedError("HIP path implements the use_viewdirs=True net (options/options.py:54)")
+        """The tensors nm_mlp_create expects (include/neuman_hip.h), reference state_dict order: 24 for the use_viewdirs=True net;
+        the 16 pts_linears tensors + output_linear's two for the plain head (use_viewdirs=False, vanilla.py:116-117)."""
+        heads = [self.views_linears[0], self.feature_linear, self.alpha_linear, self.rgb_linear] if self.use_viewdirs else [self.output_linear]
+        if not self.use_viewdirs and self.output_linear.out_features != 4:
+            raise NotImplementedError("the rendering kernels take the 4-output (r, g, b, sigma) plain head; other widths (the offset "
+                                      "net's 3) run on the differentiable float32 path (neuman_hip/train.py)")
         out = []
-        for lin in list(self.pts_linears) + [self.views_linears[0], self.feature_linear, self.alpha_linear, self.rgb_linear]:
+        for lin in list(self.pts_linears) + heads:
             out += [lin.weight, lin.bias]
         return out
 
@@ -138,9 +141,9 @@ class Joiner(nn.Module):
                 raise NotImplementedError("mixed PE kinds")
             desc = _lib.MlpDesc(n.depth, n.width, n.skips[0] if len(n.skips) == 1 else -1,
                                 _lib.NM_PE_ROTATE if self.pos_pe.mapping == 'rotate' else _lib.NM_PE_POSENC,
-                                self.pos_pe.N_freqs, self.dir_pe.N_freqs)
+                                self.pos_pe.N_freqs, self.dir_pe.N_freqs, 0 if n.use_viewdirs else 1)
             host = [p.detach().to('cpu', torch.float32).contiguous() for p in n.ordered_params()]
-            arr = (ctypes.c_void_p * 24)(*[t.data_ptr() for t in host])
+            arr = (ctypes.c_void_p * 24)(*([t.data_ptr() for t in host] + [None] * (24 - len(host))))
             pos_tab, dir_tab = self.pos_pe.table(), self.dir_pe.table()
             out = ctypes.c_void_p()
             _lib.check(_lib.lib().nm_mlp_create(ctypes.byref(desc), arr, pos_tab.ctypes.data, dir_tab.ctypes.data,
@@ -157,6 +160,8 @@ class Joiner(nn.Module):
         p = precision or self.precision
         if p == 'mixed':
             p = 'i8x3' if role == 'shading' else 'fp16x3'
+        if p == 'i8x3' and not self.nerf.use_viewdirs and (precision or self.precision) == 'mixed':
+            p = 'fp16x3'                                     # the plain-head net has no i8x3 kernel: its shading passes stay float32 class
         return _lib.PRECISIONS[p]
 
     @staticmethod
@@ -167,9 +172,22 @@ class Joiner(nn.Module):
                                        "for the differentiable float32 forward (neuman_hip/train.py)")
 
     def forward(self, input_pts, input_views=None, precision=None, sigma_scale=1.0, role=None):
-        """input_pts [..., 3], input_views [..., 3] (CUDA f32) -> [..., 4] = (r, g, b, sigma)."""
+        """input_pts [..., 3], input_views [..., 3] (CUDA f32) -> [..., 4] = (r, g, b, sigma).  The plain-head net
+        (use_viewdirs=False) ignores the views like the reference (vanilla.py:122-123) and accepts None."""
         if input_views is None:
-            raise NotImplementedError("the HIP net is the use_viewdirs=True net: input_views is required")
+            if self.nerf.use_viewdirs:
+                raise _lib.NeumanHipError("input_views is required by the use_viewdirs=True net (vanilla.py:133-134)")
+            input_views = torch.zeros_like(input_pts)
+        if self.pos_pe.input_dims != 3:
+            # the time-conditioned ablation net (`--ablate_nerft`, raw_pos_dim = 4: points carry the frame time, ray_utils.py:133-134,
+            # render_utils.py:134-148): the fused kernels encode 3-vectors only, so this net runs on the float32 MFMA GEMM chain of
+            # the training slice (exact float32 products; with or without autograd) -- correct, not the tuned path
+            from . import train
+            if sigma_scale != 1.0:
+                raise _lib.NeumanHipError("sigma_scale is a canonical-render option (render_utils.py:229)")
+            if input_pts.shape[-1] != self.pos_pe.input_dims:
+                raise _lib.NeumanHipError(f"input_pts has {input_pts.shape[-1]} components, the position encoding takes {self.pos_pe.input_dims}")
+            return train.mlp_forward_train(self, input_pts, input_views)
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # a training step (trainers/vanilla_nerf_trainer.py:66): float32 MFMA forward that keeps its activations
             from . import train

@@ -83,6 +83,9 @@ def nerf_forward(weights, x_pe, d_pe, depth=8, skips=(4,), return_hidden=False):
             hidden.append(h)
             if i in skips:
                 h = torch.cat([x_pe, h], -1)
+        if 'nerf.output_linear.weight' in W:                      # use_viewdirs=False: outputs = output_linear(h), vanilla.py:145
+            out = _linear(h, W['nerf.output_linear.weight'], W['nerf.output_linear.bias']).numpy()
+            return (out, [x.numpy() for x in hidden]) if return_hidden else out
         alpha = _linear(h, W['nerf.alpha_linear.weight'], W['nerf.alpha_linear.bias'])
         feature = _linear(h, W['nerf.feature_linear.weight'], W['nerf.feature_linear.bias'])
         hidden.append(feature)
@@ -108,7 +111,7 @@ class JoinerSpec:
 def joiner_forward(weights, spec, pts, dirs, chunk=65536, return_hidden=False):
     """reference models/vanilla.py:162-166: PE both inputs then NeRF.forward.  pts/dirs [...,3] -> [...,4]."""
     shp = pts.shape[:-1]
-    p = pts.reshape(-1, 3).astype(F32)
+    p = pts.reshape(-1, pts.shape[-1]).astype(F32)             # 3, or 4 with the time channel (ray_utils.py:133-134)
     d = dirs.reshape(-1, 3).astype(F32)
     outs, hid = [], None
     for s in range(0, p.shape[0], chunk):

@@ -88,7 +88,7 @@ def to_homogeneous(pts):
 # ----------------------------------------------------------------------------
 # sampling
 # ----------------------------------------------------------------------------
-def ray_to_samples(origin, direction, near, far, samples_per_ray, lindisp=False, t_rand=None, t_vals=None):
+def ray_to_samples(origin, direction, near, far, samples_per_ray, lindisp=False, t_rand=None, t_vals=None, append_t=None):
     """reference utils/ray_utils.py:96-135.
 
     origin/direction [R,3] f32, near/far [R,1] f32.  ``t_rand`` (already clipped
@@ -110,6 +110,8 @@ def ray_to_samples(origin, direction, near, far, samples_per_ray, lindisp=False,
         z = (lower + (upper - lower) * t_rand.astype(F32)).astype(F32)
     pts = (o[..., None, :] + d[..., None, :] * z[..., :, None]).astype(F32)
     dirs = np.stack([d] * samples_per_ray, axis=1)
+    if append_t is not None:                                    # ray_utils.py:133-134
+        pts = np.concatenate([pts, append_t.astype(F32)], -1)
     return pts, dirs, z
 
 
@@ -150,7 +152,7 @@ def sample_pdf(bins, weights, n_samples, u=None, cdf_ulps=0):
     return (bins_g0 + t * (bins_g1 - bins_g0)).astype(F32)
 
 
-def ray_to_importance_samples(origin, direction, z_vals, weights, n_importance, including_old=True, cdf_ulps=0):
+def ray_to_importance_samples(origin, direction, z_vals, weights, n_importance, including_old=True, cdf_ulps=0, append_t=None):
     """reference utils/ray_utils.py:138-160."""
     o, d = origin.astype(F32), direction.astype(F32)
     z_mid = (F32(.5) * (z_vals[..., 1:] + z_vals[..., :-1])).astype(F32)
@@ -161,6 +163,8 @@ def ray_to_importance_samples(origin, direction, z_vals, weights, n_importance, 
         z = z_samples
     pts = (o[..., None, :] + d[..., None, :] * z[..., :, None]).astype(F32)
     dirs = np.stack([d] * pts.shape[1], axis=1)
+    if append_t is not None:                                    # ray_utils.py:158-159
+        pts = np.concatenate([pts, append_t.astype(F32)], -1)
     return pts, dirs, z.astype(F32)
 
 

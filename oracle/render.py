@@ -20,9 +20,10 @@ def _net(net, pts, dirs):
 
 def render_vanilla(coarse_net, cap, fine_net=None, rays_per_batch=32768, samples_per_ray=64,
                    importance_samples_per_ray=128, white_bkg=True, near_far_source='bkg', return_depth=False,
-                   max_rays=None, cdf_ulps=0):
+                   max_rays=None, cdf_ulps=0, ablate_nerft=False):
     """reference utils/render_utils.py:108-161.  ``max_rays`` renders only a prefix of the frame (bounded CPU baseline);
-    ``cdf_ulps`` is the conditioning probe of ray_ops.sample_pdf."""
+    ``cdf_ulps`` is the conditioning probe of ray_ops.sample_pdf; ``ablate_nerft`` appends the frame time
+    cap.frame_id['frame_id'] / cap.frame_id['total_frames'] to every sample point (:134-148)."""
     origins, dirs = ray_ops.shot_all_rays(cap.intrinsic_matrix, cap.cam_pose.camera_to_world, cap.shape)
     total = origins.shape[0] if max_rays is None else min(max_rays, origins.shape[0])
     rgbs, depths = [], []
@@ -31,11 +32,16 @@ def render_vanilla(coarse_net, cap, fine_net=None, rays_per_batch=32768, samples
         o, d = origins[i:j].astype(F32), dirs[i:j].astype(F32)
         near = np.full((j - i, 1), cap.near[near_far_source], F32)
         far = np.full((j - i, 1), cap.far[near_far_source], F32)
-        pts, dd, z = ray_ops.ray_to_samples(o, d, near, far, samples_per_ray)
+        ct = ft = None
+        if ablate_nerft:
+            cur_time = cap.frame_id['frame_id'] / cap.frame_id['total_frames']
+            ct = np.ones((j - i, samples_per_ray, 1), F32) * F32(cur_time)
+            ft = np.ones((j - i, samples_per_ray + importance_samples_per_ray, 1), F32) * F32(cur_time)
+        pts, dd, z = ray_ops.ray_to_samples(o, d, near, far, samples_per_ray, append_t=ct)
         out = _net(coarse_net, pts, dd)
         rgb, _, _, w, depth = raw2outputs(out, z, dd[:, 0, :], white_bkg=white_bkg)
         if fine_net is not None:
-            pts, dd, z = ray_ops.ray_to_importance_samples(o, d, z, w, importance_samples_per_ray, cdf_ulps=cdf_ulps)
+            pts, dd, z = ray_ops.ray_to_importance_samples(o, d, z, w, importance_samples_per_ray, cdf_ulps=cdf_ulps, append_t=ft)
             out = _net(fine_net, pts, dd)
             rgb, _, _, w, depth = raw2outputs(out, z, dd[:, 0, :], white_bkg=white_bkg)
         rgbs.append(rgb)

@@ -1,0 +1,111 @@
+"""-m gpu: the two network variants beside the default one, against the reference's own outputs (tests/golden/heads.npz) and the oracle:
+the plain head of `--specular_can no` (use_viewdirs=False: output_linear, models/vanilla.py:116-117, 145) and the time-conditioned net
+of `--ablate_nerft` (4-D position encoding, ray_utils.py:133-134, render_utils.py:134-148)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_mlp, render as OR
+from oracle.nerf_mlp import JoinerSpec
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def H():
+    return dict(np.load(os.path.join(HERE, "golden", "heads.npz")))
+
+
+def cu(x):
+    return torch.as_tensor(np.ascontiguousarray(x)).to('cuda', torch.float32).contiguous()
+
+
+@pytest.mark.parametrize("mapping", ["posenc", "rotate"])
+def test_plain_head_forward(H, mapping):
+    from neuman_hip import _lib, synthetic
+    j = synthetic.make_variant_joiner(5, posenc=mapping, use_viewdirs=False).cuda()
+    sd = synthetic.state_numpy(j)
+    ora = nerf_mlp.joiner_forward(sd, JoinerSpec(mapping=mapping), H['pts'], H['dirs'])
+    s = 30 if mapping == 'rotate' else 1
+    for prec, tol in (("fp32", 2e-5), ("fp16x3", 2e-5), ("bf16x3", 1e-4), (None, 2e-5)):
+        got = j(cu(H['pts']), cu(H['dirs']), precision=prec).cpu().numpy()
+        e_g, e_o = np.abs(got - H[f'plain_{mapping}_out']).max(), np.abs(got - ora).max()
+        print(f"[heads] plain head {mapping} {prec}: vs reference golden {e_g:.2e}, vs oracle {e_o:.2e}")
+        assert e_g < tol * s * 2 and e_o < tol * s
+    # views are ignored (vanilla.py:122-123) and may be omitted; the shading role stays float32 class; i8x3 does not exist for this net
+    a = j(cu(H['pts']), cu(H['dirs']))
+    assert torch.equal(a, j(cu(H['pts']), None)) and torch.equal(a, j(cu(H['pts']), cu(H['dirs'][::-1].copy())))
+    assert torch.equal(a, j(cu(H['pts']), cu(H['dirs']), role='shading'))
+    with pytest.raises(_lib.NeumanHipError):
+        j(cu(H['pts']), cu(H['dirs']), precision="i8x3")
+    # fused ray form and sigma_scale
+    R, S = 16, 16
+    o = cu(H['pts'][:R] * 0.2)
+    d = cu(H['dirs'][:R])
+    z = torch.linspace(0.5, 2.0, S, device='cuda')[None].repeat(R, 1).contiguous()
+    pts = o[:, None, :] + d[:, None, :] * z[..., None]
+    full = j.forward_rays(o, d, z, sigma_scale=0.7)
+    ref = j(pts, d[:, None, :].expand(R, S, 3))
+    assert (full[..., :3] - ref[..., :3]).abs().max() < 2e-5 and (full[..., 3] - ref[..., 3] * 0.7).abs().max() < 2e-5 * max(1.0, ref[..., 3].abs().max().item())
+
+
+def test_plain_head_canonical_frame(H):
+    """render_smpl_nerf(render_can=True) with the plain-head human net: what render_360.py --specular_can no renders"""
+    from neuman_hip import render_utils, synthetic
+    j = synthetic.make_variant_joiner(5, posenc='rotate', use_viewdirs=False).cuda()
+    net = types.SimpleNamespace(coarse_human_net=j, parameters=j.parameters)
+    cap = synthetic.SimpleCapture(40, 40, fx=50., c2w=H['plain_c3_c2w'])
+    verts = synthetic.human_vertex_cloud(0)
+    rgb, depth, acc = render_utils.render_smpl_nerf(net, cap, verts, None, None, rays_per_batch=4096, samples_per_ray=24, render_can=True,
+                                                    geo_threshold=0.2, return_depth=True, return_mask=True, interval_comp=0.8)
+    ok = (acc > 0) == (H['plain_c3_acc'] > 0)
+    e = np.abs(rgb - H['plain_c3_rgb'])[ok].max()
+    print(f"[heads] plain-head canonical frame vs reference golden: hit/miss flips {(~ok).sum()}, rgb Linf {e:.2e}, acc Linf {np.abs(acc - H['plain_c3_acc'])[ok].max():.2e}")
+    assert ok.mean() > 0.998 and e < 1e-4 and np.abs(acc - H['plain_c3_acc'])[ok].max() < 1e-4
+    assert np.abs(depth - H['plain_c3_depth'])[ok].max() < 5e-4
+
+
+def test_time_conditioned_net_and_frame(H):
+    from neuman_hip import render_utils, synthetic
+    coarse = synthetic.make_variant_joiner(6, raw_pos_dim=4).cuda()
+    fine = synthetic.make_variant_joiner(7, raw_pos_dim=4).cuda()
+    got = coarse(cu(H['nerft_pts4']), cu(H['dirs'])).cpu().numpy()
+    e = np.abs(got - H['nerft_out']).max()
+    print(f"[heads] time-conditioned net on 4-D points vs reference golden: {e:.2e}")
+    assert e < 2e-5
+    cap = synthetic.SimpleCapture(24, 18, fx=30.)
+    cap.frame_id = {'frame_id': 7, 'total_frames': 20}
+    rgb1 = render_utils.render_vanilla(coarse, cap, None, rays_per_batch=256, samples_per_ray=16, ablate_nerft=True)
+    e1 = np.abs(rgb1 - H['nerft_coarse_only_rgb']).max()
+    rgb, depth = render_utils.render_vanilla(coarse, cap, fine, rays_per_batch=256, samples_per_ray=16, importance_samples_per_ray=16,
+                                             return_depth=True, ablate_nerft=True)
+    err = np.abs(rgb - H['nerft_rgb']).max(-1)
+    print(f"[heads] ablate_nerft frames vs reference golden: coarse-only Linf {e1:.2e}; two-pass rays > 1e-4: {(err > 1e-4).sum()} / {err.size}, Linf {err.max():.2e}")
+    assert e1 < 1e-4
+    assert (err > 1e-4).mean() < 0.02 and err.max() < 2e-2
+    sdc, sdf = synthetic.state_numpy(coarse), synthetic.state_numpy(fine)
+    o_rgb = OR.render_vanilla((sdc, JoinerSpec()), cap, (sdf, JoinerSpec()), rays_per_batch=256, samples_per_ray=16, importance_samples_per_ray=16,
+                              ablate_nerft=True)
+    eo = np.abs(rgb - o_rgb).max(-1)
+    assert (eo > 1e-4).mean() < 0.02
+
+
+def test_plain_head_trains(H):
+    """a Joiner with the plain head in train() mode: the differentiable float32 forward equals the rendering kernels' output and
+    gradients reach output_linear"""
+    from neuman_hip import synthetic
+    j = synthetic.make_variant_joiner(5, posenc='posenc', use_viewdirs=False).cuda()
+    pts, dirs = cu(H['pts']), cu(H['dirs'])
+    with torch.no_grad():
+        ref = j(pts, dirs, precision="fp32")
+    j.train()
+    out = j(pts, dirs)
+    assert out.requires_grad and (out - ref).abs().max().item() < 2e-5
+    out.square().sum().backward()
+    g = j.nerf.output_linear.weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().sum().item() > 0
+    assert j.nerf.pts_linears[0].weight.grad.abs().sum().item() > 0
