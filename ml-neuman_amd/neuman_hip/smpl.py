@@ -131,3 +131,78 @@ def vertex_forward(body_model, pose, beta, alignment, scale):
     T, world, _ = body_model.frames(pose, beta, torch.as_tensor(alignment).reshape(1, 4, 4), scale, False)
     V = body_model.V
     return world[:, :V], T[:, :V].to(torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# differentiable skinning for training: gradients to poses / betas / alignments
+# ------------------------------------------------------------------------------------------------
+class SMPLDiff(torch.nn.Module):
+    """HumanNeRF.vertex_forward (models/human_nerf.py:92-122) with autograd, for the trainer's pose refinement: the skinning
+    chain of models/smpl.py:266-360 (shape blend, joint regression, Rodrigues, 24-joint kinematic chain, blend of the joint
+    transforms; pose blend shapes are computed and ignored by the reference, :320-334) written as batched tensor algebra so that
+    torch differentiates it.  A few small matrix products per training iteration on whatever device the parameters live on
+    (the forward-only, all-frames-at-once form used by the renderers is the HIP kernel behind `SMPL.frames`)."""
+
+    def __init__(self, model, device='cuda'):
+        super().__init__()
+        if not isinstance(model, dict):
+            with open(model, 'rb') as f:
+                model = pickle.load(f, encoding='latin1')
+        dev = torch.device(device)
+        t = lambda x: torch.from_numpy(_dense_f32(x)).to(dev)                      # noqa: E731
+        self.register_buffer('v_template', t(model['v_template']))                # [V,3]
+        self.register_buffer('shapedirs', t(model['shapedirs']))                  # [V,3,NB]
+        self.register_buffer('J_regressor', t(model['J_regressor']))              # [J,V]
+        self.register_buffer('lbs_weights', t(model['weights']))                  # [V,J]
+        parents = np.asarray(model['kintree_table'])[0].astype(np.float32).astype(np.int64)
+        parents[0] = -1
+        self.parents = [int(p) for p in parents]
+        self.register_buffer('da_smpl', torch.from_numpy(da_pose(len(self.parents))).to(dev)[None])
+
+    @staticmethod
+    def rodrigues(rot_vecs):
+        """axis-angle [N,3] -> rotation matrices [N,3,3]  (models/smpl.py:407-438: angle = |v + 1e-8|, R = I + sin K + (1 - cos) K^2)"""
+        angle = torch.norm(rot_vecs + 1e-8, dim=1, keepdim=True)
+        axis = rot_vecs / angle
+        x, y, z = axis[:, 0], axis[:, 1], axis[:, 2]
+        zero = torch.zeros_like(x)
+        K = torch.stack([zero, -z, y, z, zero, -x, -y, x, zero], dim=1).reshape(-1, 3, 3)
+        s, c = torch.sin(angle)[:, :, None], torch.cos(angle)[:, :, None]
+        eye = torch.eye(3, dtype=rot_vecs.dtype, device=rot_vecs.device)[None]
+        return eye + s * K + (1 - c) * torch.bmm(K, K)
+
+    def transformations(self, pose, beta):
+        """pose [1,J*3], beta [1,NB] -> (vertex transforms T [V,4,4] from the shaped template to the posed body, v_shaped [V,3])"""
+        J = len(self.parents)
+        v_shaped = self.v_template + torch.einsum('vkl,l->vk', self.shapedirs, beta[0])            # smpl.py:312
+        joints = self.J_regressor @ v_shaped                                                       # :315
+        R = self.rodrigues(pose.reshape(J, 3))                                                      # :319-320
+        rel = joints.clone()
+        rel[1:] = joints[1:] - joints[[p for p in self.parents[1:]]]                               # :474-476
+        local = torch.cat([torch.cat([R, rel[:, :, None]], 2),
+                           torch.tensor([0., 0., 0., 1.], dtype=R.dtype, device=R.device).expand(J, 1, 4)], 1)    # [J,4,4]
+        chain = [local[0]]
+        for j in range(1, J):                                                                       # :487-493
+            chain.append(chain[self.parents[j]] @ local[j])
+        G = torch.stack(chain)
+        # remove the rest pose: A_j = G_j - [0 | G_j[:3,:3] J_j]                                    # :499-503
+        shift = torch.einsum('jab,jb->ja', G[:, :3, :3], joints)
+        A = G.clone()
+        A[:, :3, 3] = G[:, :3, 3] - shift
+        T = torch.einsum('vj,jab->vab', self.lbs_weights, A)                                        # :338-341
+        return T, v_shaped
+
+    def vertex_forward(self, pose, beta, alignment, scale):
+        """pose [1,J*3], beta [1,NB], alignment [4,4] (human_nerf.py's self.alignments[idx]: its TRANSPOSE is applied), scale ->
+        world_verts [1,V,3], T_da2scene [1,V,4,4]; differentiable in pose, beta and alignment."""
+        T_pose, v_shaped = self.transformations(pose, beta)
+        T_da, _ = self.transformations(self.da_smpl.to(pose.dtype), beta)
+        T_da2pose = T_pose @ torch.inverse(T_da)                                                    # human_nerf.py:109
+        T = alignment.T @ T_da2pose                                                                 # :110
+        s = torch.eye(4, dtype=T.dtype, device=T.device)
+        s[:3, :3] *= scale                                                                          # :111-113
+        T = s @ T
+        hom = torch.cat([v_shaped, torch.ones_like(v_shaped[:, :1])], 1)
+        da_verts = torch.einsum('vab,vb->va', T_da, hom)                                            # the body in the da pose, :114-120
+        world = torch.einsum('vab,vb->va', T, da_verts)[:, :3]                                      # :121
+        return world[None], T[None]
