@@ -1,0 +1,200 @@
+"""The human trainer's loss on the device pieces: reference trainers/human_nerf_trainer.py:180-446.
+
+One training iteration of the NeuMan human model is, per batch of rays of one frame:
+
+    background samples   coarse pass -> importance samples -> fine pass, both nets frozen (:180-239)   the RENDERING kernels
+                                                                                                        (fp16x3 / i8x3, no autograd)
+    human samples        ray_to_samples, offset net, differentiable skinning (pose refinement),         nm_ray_to_samples, f32 MFMA GEMMs
+                         warp to canonical space with T^-1 of the closest surface point, human net      (neuman_hip/train.py), tree search
+                                                                                          (:241-278)    (nm_signed_distance), SMPLDiff
+    seven loss terms     rgb, lpips, colour range, symmetry, smpl shape, mask, sparsity (:382-446)       differentiable compositing
+                                                                                                        (nm_composite / nm_composite_backward)
+
+`HumanNeRFLoss.loss_func(batch)` returns the reference's `loss_dict` (same seven names, LOSS_NAMES); `train_step` adds the backward
+pass and the optimiser step of `train_batch` (:470-494 of the reference).  The elementwise algebra between kernels (mse, tanh, exp,
+clip: a few thousand values per iteration) is torch on the device, as in the reference.  Random draws (offset net choice, dummy
+directions / points, the canonical camera and its pixels) come from `self.rng` / the device generator so that a test can replay them.
+"""
+import random
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ray_utils, render_utils
+
+LOSS_NAMES = ['fine_rgb_loss', 'lpips_loss', 'color_range_reg', 'smpl_sym_reg', 'smpl_shape_reg', 'mask_loss', 'sparsity_reg']   # :31-39
+HARD_SURFACE_OFFSET = 0.31326165795326233          # utils/constant.py:7
+PATCH_SIZE = 32                                    # :8
+CANONICAL_CAMERA_DIST = 3.0                        # :13
+
+
+class HumanNeRFLoss:
+    """opt carries the reference's option names (samples_per_ray, importance_samples_per_ray, perturb, white_bkg, penalize_*,
+    penalize_outside_factor, dist_exponent).  `net` is a HumanNeRF-like holder: coarse_bkg_net, fine_bkg_net, coarse_human_net
+    (Joiners), offset_nets (list), and vertex_forward(cap_id) -> (world_verts [1,V,3], T [1,V,4,4]) with autograd (SMPLDiff).
+    `faces` [F,3] are the body's triangles, `can_mesh` = (verts [V,3], faces) the canonical (da-pose) body for the shape
+    regulariser, `can_caps` the canonical cameras of the sparsity regulariser (:157-172)."""
+
+    def __init__(self, opt, net, faces, can_mesh, can_caps, interval_comp=1.0, lpips_loss_fn=None, seed=0):
+        self.opt, self.net, self.faces, self.can_mesh, self.can_caps = opt, net, np.ascontiguousarray(np.asarray(faces)[:, :3], np.int32), can_mesh, can_caps
+        self.interval_comp, self.lpips_loss_fn = interval_comp, lpips_loss_fn
+        for k in ('penalize_smpl_alpha', 'penalize_symmetric_alpha', 'penalize_dummy', 'penalize_hard_surface', 'penalize_color_range',
+                  'penalize_mask', 'penalize_lpips', 'penalize_sharp_edge'):
+            setattr(self, k, getattr(opt, k))                                            # :143-152
+        self.rng = random.Random(seed)
+        self.np_rng = np.random.default_rng(seed)
+        self.last = {}                                                                   # intermediates of the last call (tests, logging)
+        self._can_tree = None
+
+    # ---- :180-239: frozen background, rendering kernels, nothing kept for autograd
+    def _eval_bkg_samples(self, batch, device):
+        o, d = batch['origin'].to(device, torch.float32).contiguous(), batch['direction'].to(device, torch.float32).contiguous()
+        near, far = batch['bkg_near'].to(device, torch.float32).reshape(-1).contiguous(), batch['bkg_far'].to(device, torch.float32).reshape(-1).contiguous()
+        with torch.no_grad():
+            raw, z = render_utils.bkg_pass_rays(self.net.coarse_bkg_net, self.net.fine_bkg_net, o, d, near, far, self.opt.samples_per_ray,
+                                                self.opt.importance_samples_per_ray, self.opt.white_bkg)
+        return d, z, raw
+
+    # ---- :241-278
+    def _eval_human_samples(self, batch, device):
+        human_batch = {'origin': batch['origin'].clone().to(device), 'direction': batch['direction'].clone().to(device),
+                       'near': batch['human_near'].clone().to(device), 'far': batch['human_far'].clone().to(device)}
+        human_pts, human_dirs, human_z_vals = ray_utils.ray_to_samples(human_batch, self.opt.samples_per_ray, device=device, perturb=self.opt.perturb)
+        b, n, _ = human_pts.shape
+        cur_time = torch.ones_like(human_pts[..., 0:1]) * float(batch['cur_view_f'])
+        offset = self.rng.choice(list(self.net.offset_nets))(torch.cat([human_pts, cur_time], dim=-1))
+        mesh, raw_Ts = self.net.vertex_forward(int(batch['cap_id']))                      # autograd: pose / shape / alignment refinement
+        flat = human_pts.reshape(-1, 3)
+        Ts, _, _ = ray_utils.warp_samples_to_canonical_diff(flat.detach(), verts=mesh[0], faces=self.faces, T=raw_Ts[0])
+        can_pts = (Ts @ ray_utils.to_homogeneous(flat)[..., None])[:, :3, 0].reshape(b, n, 3)
+        can_pts = can_pts + offset
+        can_dirs = can_pts[:, 1:] - can_pts[:, :-1]
+        can_dirs = torch.cat([can_dirs, can_dirs[:, -1:]], dim=1)
+        can_dirs = can_dirs / torch.norm(can_dirs, dim=2, keepdim=True)
+        human_out = self.net.coarse_human_net(can_pts, can_dirs)
+        return human_pts, human_dirs, human_z_vals, can_pts, can_dirs, human_out
+
+    # ---- :280-290
+    def _color_range_regularization(self, pts, dirs, tgts):
+        dummy_dirs = torch.randn(dirs.shape, dtype=dirs.dtype, device=pts.device)
+        dummy_dirs = dummy_dirs / torch.norm(dummy_dirs, dim=-1, keepdim=True)
+        dummy_out = self.net.coarse_human_net(pts, dummy_dirs)
+        return F.mse_loss(torch.sigmoid(dummy_out.reshape(-1, 4))[:, :3], torch.sigmoid(tgts.reshape(-1, 4))[:, :3]) * self.penalize_color_range
+
+    # ---- :292-304
+    def _smpl_symmetry_regularization(self, pts, dirs, tgts):
+        pts_flip = pts.clone().detach()
+        pts_flip[..., 0] *= -1
+        out_flip = self.net.coarse_human_net(pts_flip, dirs.clone().detach())
+        return F.mse_loss(torch.tanh(torch.relu(tgts[..., 3])), torch.tanh(torch.relu(out_flip[..., 3]))) * self.penalize_symmetric_alpha
+
+    def _signed_distance(self, pts):
+        """igl.signed_distance of the reference (:310, :326) on the device: negative inside the canonical body (the search tree of
+        the canonical mesh is built once)"""
+        if self._can_tree is None:
+            verts, faces = self.can_mesh
+            v = torch.as_tensor(np.ascontiguousarray(verts, dtype=np.float32))
+            self._can_tree = ray_utils.Mesh(v, np.ascontiguousarray(np.asarray(faces)[:, :3], np.int32), torch.zeros((v.shape[0], 16), dtype=torch.float64),
+                                            pts.device)
+        return ray_utils.signed_distance_dev(pts.reshape(-1, 3).detach(), self._can_tree)[0]
+
+    # ---- :305-343
+    def _smpl_shape_regularization(self, batch, pts, dirs, pred):
+        device = pts.device
+        smpl_reg = torch.zeros((), device=device)
+        dist_human = self._signed_distance(pts)
+        inside = dist_human < 0
+        if inside.sum() > 0:
+            sig = pred.reshape(-1, 4)[inside][:, 3]
+            smpl_reg = smpl_reg + F.mse_loss(1 - torch.exp(-torch.relu(sig)), torch.ones_like(sig)) * self.penalize_smpl_alpha
+        if self.penalize_dummy > 0:
+            dummy_pts = (torch.rand(pts.shape, dtype=pts.dtype, device=device) - 0.5) * 3
+            dummy_out = self.net.coarse_human_net(dummy_pts, dirs)
+            dist_dummy = self._signed_distance(dummy_pts)
+            d_in, d_out = dist_dummy < 0, dist_dummy > 0
+            if d_in.sum() > 0:
+                sig = dummy_out.reshape(-1, 4)[d_in][:, 3]
+                smpl_reg = smpl_reg + F.mse_loss(1 - torch.exp(-torch.relu(sig)), torch.ones_like(sig)) * self.penalize_dummy
+            if d_out.sum() > 0:
+                sig = dummy_out.reshape(-1, 4)[d_out][:, 3]
+                w = torch.pow(torch.abs(dist_dummy[d_out]) * self.opt.penalize_outside_factor, self.opt.dist_exponent)
+                smpl_reg = smpl_reg + F.l1_loss((1 - torch.exp(-torch.relu(sig))) * w, torch.zeros_like(sig)) * self.penalize_dummy
+            self.last.update(dummy_pts=dummy_pts, dist_dummy=dist_dummy, dummy_out=dummy_out)
+        self.last.update(dist_human=dist_human)
+        return smpl_reg
+
+    # ---- :345-380
+    def _sparsity_regularization(self, device):
+        sparsity_reg = torch.zeros((), device=device)
+        num_can_rays = 128
+        can_cap = self.rng.choice(self.can_caps)
+        coords = np.argwhere(np.ones(can_cap.shape))
+        coords = coords[self.np_rng.integers(0, len(coords), num_can_rays)][:, ::-1]
+        can_orig, can_dir = ray_utils.shot_rays(can_cap, coords)
+        can_pts, can_dirs, can_z_vals = ray_utils.ray_to_samples(
+            {'origin': torch.from_numpy(can_orig).float().to(device), 'direction': torch.from_numpy(can_dir).float().to(device),
+             'near': torch.zeros(num_can_rays, 1).float().to(device), 'far': torch.ones(num_can_rays, 1).float().to(device) * CANONICAL_CAMERA_DIST * 1.667},
+            samples_per_ray=self.opt.samples_per_ray, device=device, perturb=self.opt.perturb)
+        can_out = self.net.coarse_human_net(can_pts, can_dirs)
+        can_out = torch.cat([can_out[..., :3], can_out[..., 3:] * self.interval_comp], -1)            # `can_out[..., -1] *= interval_comp`, out of place
+        _, _, can_mask, can_weights, _ = render_utils.raw2outputs(can_out, can_z_vals.clone(), can_dirs[:, 0, :].clone(), white_bkg=True)
+        can_weights = torch.clip(can_weights, 0.0, 1.0)
+        can_mask = torch.clip(can_mask, 0.0, 1.0)
+        if self.penalize_sharp_edge > 0:
+            sparsity_reg = sparsity_reg + torch.mean(-torch.log(torch.exp(-torch.abs(can_mask)) + torch.exp(-torch.abs(1 - can_mask)))
+                                                     + HARD_SURFACE_OFFSET) * self.penalize_sharp_edge
+        if self.penalize_hard_surface > 0:
+            sparsity_reg = sparsity_reg + torch.mean(-torch.log(torch.exp(-torch.abs(can_weights)) + torch.exp(-torch.abs(1 - can_weights)))
+                                                     + HARD_SURFACE_OFFSET) * self.penalize_hard_surface
+        self.last.update(can_mask=can_mask, can_weights=can_weights)
+        return sparsity_reg
+
+    # ---- :382-446
+    def loss_func(self, batch, return_rgb=False):
+        device = next(self.net.coarse_human_net.parameters()).device
+        loss_dict = {name: torch.zeros((), device=device) for name in LOSS_NAMES}
+        self.last = {}
+        hit_index = torch.nonzero(batch['is_hit'].to(device))[:, 0]
+        fine_bkg_dir, fine_bkg_z_vals, fine_bkg_out = self._eval_bkg_samples(batch, device)
+        _, human_dirs, human_z_vals, can_pts, can_dirs, human_out = self._eval_human_samples(batch, device)
+        if self.penalize_symmetric_alpha > 0:
+            loss_dict['smpl_sym_reg'] = loss_dict['smpl_sym_reg'] + self._smpl_symmetry_regularization(can_pts, can_dirs, human_out)
+        if self.penalize_color_range > 0:
+            loss_dict['color_range_reg'] = loss_dict['color_range_reg'] + self._color_range_regularization(can_pts, can_dirs, human_out)
+        if self.penalize_mask > 0:
+            _, _, human_mask, _, _ = render_utils.raw2outputs(human_out, human_z_vals, human_dirs[:, 0, :].contiguous(), white_bkg=self.opt.white_bkg)
+            loss_dict['mask_loss'] = loss_dict['mask_loss'] + F.mse_loss(torch.clamp(human_mask, min=0.0, max=1.0),
+                                                                         (1 - batch['is_bkg'].to(device)).float()) * self.penalize_mask
+        if self.penalize_smpl_alpha > 0:
+            loss_dict['smpl_shape_reg'] = loss_dict['smpl_shape_reg'] + self._smpl_shape_regularization(batch, can_pts, can_dirs, human_out)
+        if self.penalize_sharp_edge > 0 or self.penalize_hard_surface > 0:
+            loss_dict['sparsity_reg'] = loss_dict['sparsity_reg'] + self._sparsity_regularization(device)
+        # RGB loss: the two sample lists merged by depth (:415-422), composited once (:423-428)
+        fine_total_zvals, fine_order = torch.sort(torch.cat([fine_bkg_z_vals, human_z_vals], -1), -1)
+        fine_total_out = torch.gather(torch.cat([fine_bkg_out, human_out], 1), 1, fine_order[..., None].expand(-1, -1, 4))
+        fine_rgb_map, _, _, _, _ = render_utils.raw2outputs(fine_total_out, fine_total_zvals, fine_bkg_dir, white_bkg=self.opt.white_bkg)
+        color = batch['color'].to(device)
+        loss_dict['fine_rgb_loss'] = loss_dict['fine_rgb_loss'] + F.mse_loss(fine_rgb_map[hit_index], color[hit_index])
+        if self.penalize_lpips > 0 and int(batch.get('patch_counter', 0)) == 1 and self.lpips_loss_fn is not None:   # :431-435
+            n = PATCH_SIZE * PATCH_SIZE
+            a = fine_rgb_map[:n].reshape(PATCH_SIZE, PATCH_SIZE, -1).permute(2, 0, 1) * 2 - 1
+            b = color[:n].reshape(PATCH_SIZE, PATCH_SIZE, -1).permute(2, 0, 1) * 2 - 1
+            loss_dict['lpips_loss'] = loss_dict['lpips_loss'] + (self.lpips_loss_fn(a, b) * self.penalize_lpips).flatten()[0]
+        self.last.update(human_out=human_out, can_pts=can_pts, can_dirs=can_dirs, human_z_vals=human_z_vals, fine_bkg_out=fine_bkg_out,
+                         fine_bkg_z_vals=fine_bkg_z_vals, fine_rgb_map=fine_rgb_map, hit_index=hit_index)
+        if float(human_out[..., 3].max()) <= 0.0:                                         # :437-442: a dead network is re-initialised
+            from .vanilla import weight_reset
+            for m in list(self.net.offset_nets) + [self.net.coarse_human_net]:
+                m.apply(weight_reset)
+            loss_dict = {name: torch.zeros((), device=device, requires_grad=True) for name in LOSS_NAMES}
+        return (loss_dict, fine_rgb_map) if return_rgb else loss_dict
+
+    def train_step(self, batch, optimizer):
+        """train_batch (:470-494): zero_grad, loss, backward, step -> {name: float}, total"""
+        optimizer.zero_grad()
+        loss_dict = self.loss_func(batch)
+        total = sum(loss_dict.values())
+        total.backward()
+        optimizer.step()
+        return {k: float(v.detach()) for k, v in loss_dict.items()}, float(total.detach())

@@ -373,7 +373,7 @@ def warp_samples_to_canonical_diff(pts, verts, faces, T):
     verts = verts.to(dev)
     T = T.to(dev)
     f3 = torch.as_tensor(np.ascontiguousarray(np.asarray(faces)[:, :3]).astype(np.int64)).to(dev)
-    p = torch.as_tensor(np.ascontiguousarray(pts, dtype=np.float32)).to(dev)
+    p = pts.detach().to(dev, torch.float32) if isinstance(pts, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(pts, dtype=np.float32)).to(dev)
     mesh = Mesh(verts.detach(), f3.to(torch.int32), torch.zeros((verts.shape[0], 16), dtype=torch.float64), dev)
     signed_dist, f_id, closest = signed_distance_dev(p, mesh)
     f_id = f_id.long()

@@ -21,6 +21,12 @@ from . import _lib
 DEFAULT_PRECISION = os.environ.get("NEUMAN_PRECISION", "mixed")
 
 
+def weight_reset(m):
+    """reference models/vanilla.py:11-14: re-draw a Linear layer's parameters (the trainer's restart of a dead network)"""
+    if isinstance(m, nn.Linear):
+        m.reset_parameters()
+
+
 class Embedder(nn.Module):
     """Positional-encoding *specification* (the encoding itself is computed inside the MLP kernel)."""
 
