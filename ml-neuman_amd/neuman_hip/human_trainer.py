@@ -183,7 +183,7 @@ class HumanNeRFLoss:
             loss_dict['lpips_loss'] = loss_dict['lpips_loss'] + (self.lpips_loss_fn(a, b) * self.penalize_lpips).flatten()[0]
         self.last.update(human_out=human_out, can_pts=can_pts, can_dirs=can_dirs, human_z_vals=human_z_vals, fine_bkg_out=fine_bkg_out,
                          fine_bkg_z_vals=fine_bkg_z_vals, fine_rgb_map=fine_rgb_map, hit_index=hit_index)
-        if float(human_out[..., 3].max()) <= 0.0:                                         # :437-442: a dead network is re-initialised
+        if float(human_out[..., 3].detach().max()) <= 0.0:                                       # :437-442: a dead network is re-initialised
             from .vanilla import weight_reset
             for m in list(self.net.offset_nets) + [self.net.coarse_human_net]:
                 m.apply(weight_reset)
