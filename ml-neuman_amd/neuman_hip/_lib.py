@@ -9,7 +9,7 @@ import os
 import torch  # imported first so that torch's bundled libamdhip64.so.7 is the HIP runtime the library binds to
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "..", "lib", "libneuman_hip.so")
+LIB_PATH = os.environ.get("NEUMAN_HIP_LIB") or os.path.join(_HERE, "..", "lib", "libneuman_hip.so")   # (the override serves tools/ A/B builds)
 
 c_f32p = ctypes.c_void_p
 c_i32p = ctypes.c_void_p
