@@ -3,7 +3,8 @@
 #   tools/profile_round.sh r01      -> gpurun_out/<tag>/{bench_kernel_stats.csv, bench_pmc_summary.json, bench_line.json, ...}
 # Counters are collected in their own passes, with --kernel-trace only (no sys/hip/hsa trace domains).
 # The profiled command is `bench.py --timed-only` in the default (mixed) precision: every MLP launch rocprofv3 sees is a
-# timed one -- nerf_mlp_kernel<1,false> = the coarse (bf16x3) launch, nerf_mlp_i8w_kernel<false> = the fine (i8x3) launch.
+# timed one -- nerf_mlp_kernel<4,false> = the coarse (fp16x3) launch, nerf_mlp_i8w_kernel<false> = the fine (i8x3) launch.
+# FULL=1 also collects the in-kernel cycle buckets, the clock / power samples and the zero-weight probe (minutes of GPU time).
 set -u
 TAG=${1:-r00}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -38,7 +39,7 @@ for a, b in zip([x for x in out['sq'] if 'nerf_mlp' in x['kernel']], [x for x in
                            'cycles_per_xcd': b['GRBM_GUI_ACTIVE'] / 8})
 out['note'] = ("bench.py --steps 1 --warmup 0 --timed-only (default precision: mixed) under rocprofv3 --pmc <one group per pass> "
                "--kernel-trace; FETCH_SIZE/WRITE_SIZE in KiB (FETCH_SIZE under-reports wide streaming reads by 2x on gfx950, "
-               "MI355X_MICROARCH.md); one coarse launch (nerf_mlp_kernel<1, false>, 81.92 M evaluations) and one fine launch "
+               "MI355X_MICROARCH.md); one coarse launch (nerf_mlp_kernel<4, false>, 81.92 M evaluations) and one fine launch "
                "(nerf_mlp_i8w_kernel<false>, 163.84 M evaluations)")
 json.dump(out, open('$OUT/bench_pmc_summary.json', 'w'), indent=1)
 print(json.dumps(out['derived']))
@@ -47,7 +48,11 @@ cd $R
 cp $OUT/bench_pmc_summary.json profiles/${TAG}_bench_pmc_summary.json 2>/dev/null     # bench.py reads `traffic` from here
 python bench.py --steps 5 --warmup 1 > $OUT/bench_line.json 2> $OUT/bench_stderr.log
 tail -c 1500 $OUT/bench_line.json
-# the in-kernel cycle buckets and the clock / power samples quoted in DESIGN.md section 6
-(python tools/mlp_profile.py; python tools/mlp_profile_i8.py) > $OUT/mlp_profile.log 2>&1
-for p in bf16x3 i8x3 bf16; do tools/clock_watch.sh $p; done > $OUT/clock_watch.log 2>&1
-python tools/mlp_power_probe.py > $OUT/mlp_power_probe.log 2>&1
+cp $OUT/bench_kernel_stats.csv profiles/${TAG}_bench_kernel_stats.csv 2>/dev/null
+cp $OUT/bench_line.json profiles/${TAG}_bench_line.json 2>/dev/null
+if [ "${FULL:-0}" = "1" ]; then
+  # the in-kernel cycle buckets and the clock / power samples quoted in DESIGN.md section 6
+  (python tools/mlp_profile.py; python tools/mlp_profile_i8.py) > $OUT/mlp_profile.log 2>&1
+  for p in fp16x3 i8x3 bf16; do tools/clock_watch.sh $p; done > $OUT/clock_watch.log 2>&1
+  python tools/mlp_power_probe.py > $OUT/mlp_power_probe.log 2>&1
+fi
