@@ -29,6 +29,21 @@ PATCH_SIZE = 32                                    # :8
 CANONICAL_CAMERA_DIST = 3.0                        # :13
 
 
+def _occupancy(raw):
+    """1 - exp(-relu(sigma)) of a raw network output [..., 4]: the opacity of a unit interval"""
+    return 1 - torch.exp(-torch.relu(raw.reshape(-1, 4)[:, 3]))
+
+
+def _bimodal_prior(x):
+    """mean(-log(e^-|x| + e^-|1-x|)) + HARD_SURFACE_OFFSET: zero-mean pull of x towards 0 or 1 (the trainer's sharp-edge and
+    hard-surface terms, human_nerf_trainer.py:368-379)"""
+    return torch.mean(-torch.log(torch.exp(-x.abs()) + torch.exp(-(1 - x).abs())) + HARD_SURFACE_OFFSET)
+
+
+def _unit(v):
+    return v / torch.norm(v, dim=-1, keepdim=True)
+
+
 class HumanNeRFLoss:
     """opt carries the reference's option names (samples_per_ray, importance_samples_per_ray, perturb, white_bkg, penalize_*,
     penalize_outside_factor, dist_exponent).  `net` is a HumanNeRF-like holder: coarse_bkg_net, fine_bkg_net, coarse_human_net
@@ -69,25 +84,23 @@ class HumanNeRFLoss:
         Ts, _, _ = ray_utils.warp_samples_to_canonical_diff(flat.detach(), verts=mesh[0], faces=self.faces, T=raw_Ts[0])
         can_pts = (Ts @ ray_utils.to_homogeneous(flat)[..., None])[:, :3, 0].reshape(b, n, 3)
         can_pts = can_pts + offset
-        can_dirs = can_pts[:, 1:] - can_pts[:, :-1]
-        can_dirs = torch.cat([can_dirs, can_dirs[:, -1:]], dim=1)
-        can_dirs = can_dirs / torch.norm(can_dirs, dim=2, keepdim=True)
+        step = can_pts[:, 1:] - can_pts[:, :-1]                                          # view direction of a warped sample: towards the next one
+        can_dirs = _unit(torch.cat([step, step[:, -1:]], dim=1))
         human_out = self.net.coarse_human_net(can_pts, can_dirs)
         return human_pts, human_dirs, human_z_vals, can_pts, can_dirs, human_out
 
     # ---- :280-290
     def _color_range_regularization(self, pts, dirs, tgts):
-        dummy_dirs = torch.randn(dirs.shape, dtype=dirs.dtype, device=pts.device)
-        dummy_dirs = dummy_dirs / torch.norm(dummy_dirs, dim=-1, keepdim=True)
-        dummy_out = self.net.coarse_human_net(pts, dummy_dirs)
-        return F.mse_loss(torch.sigmoid(dummy_out.reshape(-1, 4))[:, :3], torch.sigmoid(tgts.reshape(-1, 4))[:, :3]) * self.penalize_color_range
+        other_view = self.net.coarse_human_net(pts, _unit(torch.randn_like(dirs)))       # the same points seen from random directions
+        rgb = lambda raw: torch.sigmoid(raw.reshape(-1, 4)[:, :3])                       # noqa: E731
+        return self.penalize_color_range * F.mse_loss(rgb(other_view), rgb(tgts))
 
     # ---- :292-304
     def _smpl_symmetry_regularization(self, pts, dirs, tgts):
-        pts_flip = pts.clone().detach()
-        pts_flip[..., 0] *= -1
-        out_flip = self.net.coarse_human_net(pts_flip, dirs.clone().detach())
-        return F.mse_loss(torch.tanh(torch.relu(tgts[..., 3])), torch.tanh(torch.relu(out_flip[..., 3]))) * self.penalize_symmetric_alpha
+        mirror = torch.tensor([-1.0, 1.0, 1.0], device=pts.device)                      # the canonical body is left-right symmetric in x
+        mirrored = self.net.coarse_human_net(pts.detach() * mirror, dirs.detach())      # (dummy directions: only the occupancy is compared)
+        squash = lambda raw: torch.tanh(torch.relu(raw[..., 3]))                        # noqa: E731
+        return self.penalize_symmetric_alpha * F.mse_loss(squash(tgts), squash(mirrored))
 
     def _signed_distance(self, pts):
         """igl.signed_distance of the reference (:310, :326) on the device: negative inside the canonical body (the search tree of
@@ -103,23 +116,21 @@ class HumanNeRFLoss:
     def _smpl_shape_regularization(self, batch, pts, dirs, pred):
         device = pts.device
         smpl_reg = torch.zeros((), device=device)
+
+        def filled(raw, mask, weight):                                                   # occupancy 1 where the body is
+            return weight * ((1 - _occupancy(raw)[mask]) ** 2).mean() if bool(mask.any()) else 0.0
+
         dist_human = self._signed_distance(pts)
-        inside = dist_human < 0
-        if inside.sum() > 0:
-            sig = pred.reshape(-1, 4)[inside][:, 3]
-            smpl_reg = smpl_reg + F.mse_loss(1 - torch.exp(-torch.relu(sig)), torch.ones_like(sig)) * self.penalize_smpl_alpha
-        if self.penalize_dummy > 0:
-            dummy_pts = (torch.rand(pts.shape, dtype=pts.dtype, device=device) - 0.5) * 3
+        smpl_reg = smpl_reg + filled(pred, dist_human < 0, self.penalize_smpl_alpha)
+        if self.penalize_dummy > 0:                                                      # random points of a 3-unit box around the canonical body
+            dummy_pts = (torch.rand_like(pts) - 0.5) * 3
             dummy_out = self.net.coarse_human_net(dummy_pts, dirs)
             dist_dummy = self._signed_distance(dummy_pts)
-            d_in, d_out = dist_dummy < 0, dist_dummy > 0
-            if d_in.sum() > 0:
-                sig = dummy_out.reshape(-1, 4)[d_in][:, 3]
-                smpl_reg = smpl_reg + F.mse_loss(1 - torch.exp(-torch.relu(sig)), torch.ones_like(sig)) * self.penalize_dummy
-            if d_out.sum() > 0:
-                sig = dummy_out.reshape(-1, 4)[d_out][:, 3]
-                w = torch.pow(torch.abs(dist_dummy[d_out]) * self.opt.penalize_outside_factor, self.opt.dist_exponent)
-                smpl_reg = smpl_reg + F.l1_loss((1 - torch.exp(-torch.relu(sig))) * w, torch.zeros_like(sig)) * self.penalize_dummy
+            smpl_reg = smpl_reg + filled(dummy_out, dist_dummy < 0, self.penalize_dummy)
+            outside = dist_dummy > 0
+            if bool(outside.any()):                                                      # occupancy 0 outside, weighted by the distance from the surface
+                falloff = (dist_dummy[outside].abs() * self.opt.penalize_outside_factor) ** self.opt.dist_exponent
+                smpl_reg = smpl_reg + self.penalize_dummy * (_occupancy(dummy_out)[outside] * falloff).abs().mean()
             self.last.update(dummy_pts=dummy_pts, dist_dummy=dist_dummy, dummy_out=dummy_out)
         self.last.update(dist_human=dist_human)
         return smpl_reg
@@ -139,14 +150,11 @@ class HumanNeRFLoss:
         can_out = self.net.coarse_human_net(can_pts, can_dirs)
         can_out = torch.cat([can_out[..., :3], can_out[..., 3:] * self.interval_comp], -1)            # `can_out[..., -1] *= interval_comp`, out of place
         _, _, can_mask, can_weights, _ = render_utils.raw2outputs(can_out, can_z_vals.clone(), can_dirs[:, 0, :].clone(), white_bkg=True)
-        can_weights = torch.clip(can_weights, 0.0, 1.0)
-        can_mask = torch.clip(can_mask, 0.0, 1.0)
-        if self.penalize_sharp_edge > 0:
-            sparsity_reg = sparsity_reg + torch.mean(-torch.log(torch.exp(-torch.abs(can_mask)) + torch.exp(-torch.abs(1 - can_mask)))
-                                                     + HARD_SURFACE_OFFSET) * self.penalize_sharp_edge
-        if self.penalize_hard_surface > 0:
-            sparsity_reg = sparsity_reg + torch.mean(-torch.log(torch.exp(-torch.abs(can_weights)) + torch.exp(-torch.abs(1 - can_weights)))
-                                                     + HARD_SURFACE_OFFSET) * self.penalize_hard_surface
+        can_weights, can_mask = can_weights.clamp(0.0, 1.0), can_mask.clamp(0.0, 1.0)
+        if self.penalize_sharp_edge > 0:                                                 # silhouettes: a ray is inside or outside
+            sparsity_reg = sparsity_reg + self.penalize_sharp_edge * _bimodal_prior(can_mask)
+        if self.penalize_hard_surface > 0:                                               # surfaces: a sample carries all of the weight or none
+            sparsity_reg = sparsity_reg + self.penalize_hard_surface * _bimodal_prior(can_weights)
         self.last.update(can_mask=can_mask, can_weights=can_weights)
         return sparsity_reg
 
