@@ -50,7 +50,7 @@ FLOP_PER_EVAL = 1186816            # 593,408 MAC per sample evaluation (SURVEY 8
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA, MI355X_MICROARCH.md
 W, H, S, NI = 800, 800, 128, 128
 EVALS_PER_RAY = S + (S + NI)
-TILE = 8192
+MAX_TILE = 8192           # rays per sharding tile at most; parallel.balanced_tile picks the size that gives every rank equally many
 DTYPES = {
     "mixed": "coarse (sampling) pass: split-fp16 hi+lo MFMA x3, f32 accumulate; fine (shading) pass: per-row-scaled int16 as two "
              "int8 limbs on the i8 MFMA x3, exact int32 accumulate, encodings on split bf16",
@@ -228,6 +228,7 @@ def main():
     cap = synthetic.SimpleCapture(W, H)
     origins, dirs = ray_utils.shot_all_rays_dev(cap, dev)                  # a1 on the device
     total = origins.shape[0]
+    TILE = parallel.balanced_tile(total, world, MAX_TILE)
     idx = parallel.tile_ray_indices(total, TILE, rank, world, device=dev)
     o_loc, d_loc = origins[idx].contiguous(), dirs[idx].contiguous()       # this rank's rays, resident in HBM
 

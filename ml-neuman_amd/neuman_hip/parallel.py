@@ -36,6 +36,18 @@ def tile_ray_indices(total_rays, tile, rank, world, device='cpu'):
     return idx
 
 
+def balanced_tile(total_rays, world, max_tile=8192):
+    """Largest tile <= max_tile that gives every rank the same number of tiles (n_tiles a multiple of `world`): with a fixed
+    8192 an 800x800 frame is 79 tiles, 10 / 9 per rank at world 8 -- 2.4 % of the frame time spent waiting for the ranks that
+    got 10; 80 tiles of 8000 are 10 each.  Only the last tile can be short, by less than n_tiles rays."""
+    per_round = world * max_tile
+    n_tiles = world * ((total_rays + per_round - 1) // per_round)
+    tile = max(1, (total_rays + n_tiles - 1) // n_tiles)
+    while tile > 1 and ((total_rays + tile - 1) // tile) % world:      # (rounding up can lose a tile on tiny frames)
+        tile -= 1
+    return tile
+
+
 def max_local_rays(total_rays, tile, world):
     n_tiles = (total_rays + tile - 1) // tile
     return ((n_tiles + world - 1) // world) * tile

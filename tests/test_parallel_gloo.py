@@ -20,6 +20,20 @@ def test_tile_assignment_is_a_partition():
         assert max(sizes) - min(sizes) <= tile
 
 
+def test_balanced_tile_gives_every_rank_the_same_tile_count():
+    for total, world, cap in [(640000, 8, 8192), (640000, 4, 8192), (640000, 2, 8192), (640000, 1, 8192), (262144, 8, 8192),
+                              (2073600, 8, 8192), (1000, 4, 64), (7, 8, 8192)]:
+        tile = parallel.balanced_tile(total, world, cap)
+        assert 1 <= tile <= cap
+        n_tiles = (total + tile - 1) // tile
+        sizes = [parallel.tile_ray_indices(total, tile, r, world).numel() for r in range(world)]
+        assert sum(sizes) == total
+        if total >= world * world:
+            assert n_tiles % world == 0, (total, world, tile, n_tiles)
+            assert max(sizes) - min(sizes) < n_tiles          # only the last tile is short
+    assert parallel.balanced_tile(640000, 8, 8192) == 8000
+
+
 def _fake_render(o, d):
     # deterministic per-ray "pixel": depends only on the ray, like the real renderer
     return torch.stack([o[:, 0] + d[:, 1], o[:, 1] * d[:, 2], d[:, 0], (o * d).sum(-1)], 1)
