@@ -288,6 +288,15 @@ int nm_scatter_rows(const float* src, const int32_t* idx, const int32_t* n_dev, 
 int nm_shot_rays(const int32_t* xy, int64_t n, int width, int mode, const double* inv_intrinsic,
                  const double* cam2world, float* origin, float* direction, nm_stream_t stream);
 
+/* The same for a training batch whose rays come from many captures at once -- reference
+ *   datasets/background_rays.py:47-101 and datasets/human_rays.py:133-209 call shot_rays once per
+ *   capture inside a host loop; here ray i uses camera cam_id[i] of a DEVICE table cams [n_cams][25]
+ *   of f64 (K^-1 row-major, then cam2world row-major), so a batch is one launch whatever the number
+ *   of captures it touches.  mode 1 / 2 as above (there is no full-grid form).  cam_id out of range
+ *   is clamped.  xy device int32 [n,2]; origin, direction [n,3].                                  */
+int nm_shot_rays_cams(const int32_t* xy, const int32_t* cam_id, int64_t n, int mode, const double* cams,
+                      int n_cams, float* origin, float* direction, nm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * frame egress -- reference render_test_views.py:83-88, render_360.py:77-81 (imageio.imsave of the
  *   renderer's f32 [H,W,3] frame) and render_test_views.py:35 (PSNR of the uint8 frames).

@@ -20,6 +20,40 @@ struct CamParams {
 // The products are summed left to right without contraction (the library is built with -ffp-contract=off); BLAS may
 // contract differently inside its dgemm, which moves a result by at most one f64 ulp -- invisible after the f32 cast
 // except on a rounding tie.
+__device__ __forceinline__ void shoot(double x, double y, const double* kinv, const double* c2w, int mode, float* __restrict__ origin,
+                                      float* __restrict__ direction) {
+    double cam[3], w4[4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) cam[r] = kinv[3 * r] * x + kinv[3 * r + 1] * y + kinv[3 * r + 2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w4[r] = c2w[4 * r] * cam[0] + c2w[4 * r + 1] * cam[1] + c2w[4 * r + 2] * cam[2] + c2w[4 * r + 3];
+    if (mode == 2) {
+        float f[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) f[r] = (float)(w4[r] / w4[3]) - (float)c2w[4 * r + 3];
+        const float norm = sqrtf((f[0] * f[0] + f[1] * f[1]) + f[2] * f[2]);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            direction[r] = f[r] / norm;
+            origin[r] = (float)c2w[4 * r + 3];
+        }
+        return;
+    }
+    double d[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double p = w4[r] / w4[3];
+        if (mode == 1) p = (double)(float)p;
+        d[r] = p - c2w[4 * r + 3];
+    }
+    const double norm = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        direction[r] = (float)(d[r] / norm);                  // numpy divides by the norm, it does not multiply by a reciprocal
+        origin[r] = (float)c2w[4 * r + 3];
+    }
+}
+
 __global__ __launch_bounds__(256) void shot_rays_kernel(const int32_t* __restrict__ xy, int64_t n, int width, int mode, CamParams P,
                                                         float* __restrict__ origin, float* __restrict__ direction) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -32,36 +66,22 @@ __global__ __launch_bounds__(256) void shot_rays_kernel(const int32_t* __restric
         y = (double)(i / width);
         x = (double)(i - (i / width) * width);
     }
-    double cam[3], w4[4];
+    shoot(x, y, P.kinv, P.c2w, mode, origin + 3 * i, direction + 3 * i);
+}
+
+// The same per ray with the camera picked by cam_id[i] from a device table of [n_cams][25] doubles (Kinv 3x3, then cam2world 4x4):
+// a training batch draws its rays from many captures at once (datasets/background_rays.py:47-101 loops over them on the host)
+__global__ __launch_bounds__(256) void shot_rays_cams_kernel(const int32_t* __restrict__ xy, const int32_t* __restrict__ cam_id, int64_t n,
+                                                             int mode, const double* __restrict__ cams, int n_cams,
+                                                             float* __restrict__ origin, float* __restrict__ direction) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = cam_id[i];
+    c = c < 0 ? 0 : (c >= n_cams ? n_cams - 1 : c);
+    double P[25];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) cam[r] = P.kinv[3 * r] * x + P.kinv[3 * r + 1] * y + P.kinv[3 * r + 2];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) w4[r] = P.c2w[4 * r] * cam[0] + P.c2w[4 * r + 1] * cam[1] + P.c2w[4 * r + 2] * cam[2] + P.c2w[4 * r + 3];
-    if (mode == 2) {
-        float f[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) f[r] = (float)(w4[r] / w4[3]) - (float)P.c2w[4 * r + 3];
-        const float norm = sqrtf((f[0] * f[0] + f[1] * f[1]) + f[2] * f[2]);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            direction[3 * i + r] = f[r] / norm;
-            origin[3 * i + r] = (float)P.c2w[4 * r + 3];
-        }
-        return;
-    }
-    double d[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        double p = w4[r] / w4[3];
-        if (mode == 1) p = (double)(float)p;
-        d[r] = p - P.c2w[4 * r + 3];
-    }
-    const double norm = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        direction[3 * i + r] = (float)(d[r] / norm);          // numpy divides by the norm, it does not multiply by a reciprocal
-        origin[3 * i + r] = (float)P.c2w[4 * r + 3];
-    }
+    for (int k = 0; k < 25; ++k) P[k] = cams[(int64_t)c * 25 + k];
+    shoot((double)xy[2 * i], (double)xy[2 * i + 1], P, P + 9, mode, origin + 3 * i, direction + 3 * i);
 }
 
 // imageio (v2 `image_as_uint`, bitdepth 8) on a float image: clip to [0, 1], then uint8(x * 255 + 0.499999999) in f64
@@ -146,6 +166,18 @@ int nm_shot_rays(const int32_t* xy, int64_t n, int width, int mode, const double
     hipLaunchKernelGGL(shot_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nm::as_stream(stream), xy, n, width, mode, P,
                        origin, direction);
     return nm::check_launch("shot_rays_kernel");
+}
+
+int nm_shot_rays_cams(const int32_t* xy, const int32_t* cam_id, int64_t n, int mode, const double* cams, int n_cams, float* origin,
+                      float* direction, nm_stream_t stream) {
+    NM_REQUIRE(n >= 0, "nm_shot_rays_cams: negative n");
+    NM_REQUIRE(mode == 1 || mode == 2, "nm_shot_rays_cams: mode %d (1 / 2 = shot_rays with an f64 / f32 pose)", mode);
+    NM_REQUIRE(cams && n_cams >= 1, "nm_shot_rays_cams: no camera table");
+    NM_REQUIRE(n == 0 || (xy && cam_id && origin && direction), "nm_shot_rays_cams: null pointer");
+    if (n == 0) return NM_OK;
+    hipLaunchKernelGGL(shot_rays_cams_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nm::as_stream(stream), xy, cam_id, n, mode,
+                       cams, n_cams, origin, direction);
+    return nm::check_launch("shot_rays_cams_kernel");
 }
 
 int nm_frame_to_uint8(const float* src, int64_t n, uint8_t* dst, nm_stream_t stream) {

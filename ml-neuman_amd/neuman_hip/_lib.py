@@ -80,6 +80,7 @@ SIGNATURES = {
     "nm_scatter_rows": (i32, [c_f32p, c_i32p, c_i32p, i64, i32, c_f32p, c_stream]),
     "nm_shot_rays": (i32, [c_i32p, i64, i32, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_f32p, c_f32p,
                            c_stream]),
+    "nm_shot_rays_cams": (i32, [c_i32p, c_i32p, i64, i32, ctypes.c_void_p, i32, c_f32p, c_f32p, c_stream]),
     "nm_frame_to_uint8": (i32, [c_f32p, i64, ctypes.c_void_p, c_stream]),
     "nm_ssd_u8": (i32, [ctypes.c_void_p, ctypes.c_void_p, i64, ctypes.c_void_p, c_stream]),
 }

@@ -15,6 +15,8 @@ pass and the optimiser step of `train_batch` (:470-494 of the reference).  The e
 clip: a few thousand values per iteration) is torch on the device, as in the reference.  Random draws (offset net choice, dummy
 directions / points, the canonical camera and its pixels) come from `self.rng` / the device generator so that a test can replay them.
 """
+import math
+import os
 import random
 
 import numpy as np
@@ -206,3 +208,121 @@ class HumanNeRFLoss:
         total.backward()
         optimizer.step()
         return {k: float(v.detach()) for k, v in loss_dict.items()}, float(total.detach())
+
+
+class HumanNeRFTrainer(HumanNeRFLoss):
+    """The loop around the loss (human_nerf_trainer.py:447-494, 540-601, 636-680 + base_trainer.py:66-108): loss grouping and the
+    photometric delay, NaN guard, optimiser step, the schedules of the learning rates (parameter group 0 = the SMPL parameters at
+    smpl_lr, groups 1-2 = the networks at learning_rate), of the prior penalties and of the offset nets' scale, and checkpoints with
+    the reference's keys.  `batches` / `val_batches` are callables returning a batch (ray_batches.HumanRayBatcher).
+    `pose_grad_mask(cap_id)` -> [24,3] or None stands in for the DensePose visibility mask of :560-573 (external data)."""
+
+    def __init__(self, opt, net, optimizer, faces, can_mesh, can_caps, batches=None, val_batches=None, pose_grad_mask=None, **kw):
+        super().__init__(opt, net, faces, can_mesh, can_caps, **kw)
+        self.optim, self.batches, self.val_batches, self.pose_grad_mask = optimizer, batches, val_batches, pose_grad_mask
+        self.epoch, self.iteration = 0, 0
+        self.out = getattr(opt, 'out', None)
+        if self.out:
+            os.makedirs(self.out, exist_ok=True)
+        if getattr(opt, 'resume', False):
+            self.resume()
+        if getattr(opt, 'load_weights', False):
+            self.load_pretrained_weights()
+
+    @staticmethod
+    def _grouped(loss_dict, photometric=True):
+        g = dict(loss_dict)
+        g['rgb_loss'] = g['fine_rgb_loss'] + g['color_range_reg'] + g['lpips_loss']
+        g['can_loss'] = g['smpl_sym_reg'] + g['smpl_shape_reg']
+        g['total_loss'] = g['can_loss'] + g['mask_loss'] + g['sparsity_reg'] + (g['rgb_loss'] if photometric else 0.0)
+        return g
+
+    def train_batch(self, batch):
+        opt, it = self.opt, self.iteration
+        self.optim.zero_grad()
+        g = self._grouped(self.loss_func(batch), photometric=it >= opt.delay_iters)
+        report = {k: float(v.detach()) for k, v in g.items()}
+        report['lr'] = self.optim.param_groups[0]['lr']
+        if math.isnan(report['total_loss']):
+            print('loss is nan during training', report)
+            self.optim.zero_grad()
+        else:
+            g['total_loss'].backward()
+            mask = self.pose_grad_mask(int(batch['cap_id'])) if self.pose_grad_mask is not None else None
+            if mask is not None and getattr(self.net, 'poses', None) is not None and self.net.poses.grad is not None:
+                cap = int(batch['cap_id'])
+                self.net.poses.grad[cap] *= torch.as_tensor(mask, dtype=torch.float32, device=self.net.poses.device).reshape(self.net.poses.grad[cap].shape)
+        self.optim.step()
+        if opt.lrate_decay is not None:
+            k = 0.1 ** (it / (opt.lrate_decay * 1000))
+            for group in self.optim.param_groups[:1]:
+                group['lr'] = opt.smpl_lr * k
+            for group in self.optim.param_groups[1:3]:
+                group['lr'] = opt.learning_rate * k
+            keep = max(0, 1 - it / 60000)                                                # the priors fade out over 60k iterations
+            self.penalize_mask = opt.penalize_mask * keep
+            if opt.prior_knowledge_decay:
+                self.penalize_symmetric_alpha = opt.penalize_symmetric_alpha * keep
+                self.penalize_dummy = opt.penalize_dummy * keep
+                self.penalize_smpl_alpha = opt.penalize_smpl_alpha * keep
+            assert opt.offset_lim >= opt.offset_scale >= 0
+            grown = (opt.offset_lim - opt.offset_scale) * max(0, (it - opt.offset_delay) / 60000) + opt.offset_scale
+            for off in self.net.offset_nets:                                             # the offsets switch on at offset_delay and grow to offset_lim
+                off.nerf.scale = min(grown, opt.offset_lim) if it >= opt.offset_delay else 0
+        return report
+
+    def validate_batch(self, batch):
+        self.optim.zero_grad()
+        with torch.no_grad():
+            g = self._grouped(self.loss_func(batch))
+        return {k: float(v) for k, v in g.items()}
+
+    def _modules(self):
+        return [m for m in [self.net.coarse_human_net, *list(self.net.offset_nets)] if hasattr(m, 'train')]
+
+    def validate(self, n_batches=10, save=True):
+        was_training = self.net.coarse_human_net.training
+        for m in self._modules():
+            m.eval()
+        source = self.val_batches or self.batches
+        reports = [self.validate_batch(source()) for _ in range(n_batches)]
+        if save and self.out:
+            self.save_model()
+        if was_training:
+            for m in self._modules():
+                m.train()
+        return {k: sum(r[k] for r in reports) / len(reports) for k in reports[0]}
+
+    def train(self, max_iter=None, on_step=None):
+        max_iter = self.opt.max_iter if max_iter is None else max_iter
+        for m in self._modules():
+            m.train()
+        while True:
+            if getattr(self.opt, 'valid_iter', 0) and self.iteration % self.opt.valid_iter == 0:
+                self.validate()
+            report = self.train_batch(self.batches())
+            if on_step is not None:
+                on_step(self.iteration, report)
+            if self.iteration >= max_iter:
+                break
+            self.iteration += 1
+        return report
+
+    def save_model(self, path=None):
+        torch.save({'epoch': self.epoch, 'iteration': self.iteration, 'optim_state_dict': self.optim.state_dict(),
+                    'hybrid_model_state_dict': self.net.state_dict()}, path or os.path.join(self.out, 'checkpoint.pth.tar'))
+
+    def resume(self):
+        path = os.path.join(self.opt.out, 'checkpoint.pth.tar')
+        if not os.path.isfile(path):
+            raise FileNotFoundError(f'model check point cannot found: {path}')
+        ckpt = torch.load(path, map_location='cpu', weights_only=False)
+        self.epoch, self.iteration = ckpt['epoch'], ckpt['iteration']
+        self.load_pretrained_weights()
+        self.optim.load_state_dict(ckpt['optim_state_dict'])
+
+    def load_pretrained_weights(self):
+        from .data_io import safe_load_weights
+        path = self.opt.load_weights_path
+        assert os.path.isfile(path), path
+        safe_load_weights(self.net, torch.load(path, map_location='cpu', weights_only=False)['hybrid_model_state_dict'])

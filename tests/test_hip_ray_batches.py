@@ -1,0 +1,184 @@
+"""Training ray batches assembled on the device (neuman_hip/ray_batches.py) against the batches the REFERENCE's datasets produced
+for the same synthetic scene under the same random seeds (tests/golden/ray_batches.npz, made by make_golden_ray_batches.py):
+BackgroundRayDataset / HumanRayDataset.__getitem__, add_border_mask and the near/far cache export."""
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "helpers"))
+import batch_scene  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    from neuman_hip import data_io, ray_batches
+    g = dict(np.load(os.path.join(HERE, "golden", "ray_batches.npz")))
+    spec = batch_scene.make(seed=11)
+    caps = []
+    for i, c in enumerate(spec['captures']):
+        cam = data_io.PinholeCamera(spec['w'], spec['h'], *c['intrinsics'])
+        pose = data_io.CameraPose(c['t'].astype(np.float32), c['q'].astype(np.float32))
+        cap = data_io.Capture(os.path.join('/nowhere/images', c['name']), cam, pose, frame_id={'frame_id': i, 'total_frames': c['total_frames']})
+        cap.image, cap.mask, cap.depth_map = c['image'], c['mask'], c['depth']
+        cap.near, cap.far = dict(c['near']), dict(c['far'])
+        caps.append(cap)
+        assert np.array_equal(np.asarray(cap.intrinsic_matrix), g[f'cam/{i}/intrinsic'])
+        c2w = np.asarray(cap.cam_pose.camera_to_world)
+        assert c2w.dtype == g[f'cam/{i}/c2w'].dtype and np.array_equal(c2w, g[f'cam/{i}/c2w'])
+    verts = [c['verts'] for c in spec['captures']]
+    opt = types.SimpleNamespace(rays_per_batch=512, ablate_nerft=False, use_fused_depth=False, white_bkg=True, geo_threshold=0.2,
+                                normalize=True, penalize_lpips=0.0, body_rays_ratio=0.6, border_rays_ratio=0.15, bkg_rays_ratio=0.25,
+                                dilation=spec['dilation'])
+    return types.SimpleNamespace(rb=ray_batches, g=g, caps=caps, verts=verts, opt=opt, spec=spec, dev=torch.device('cuda'))
+
+
+def np_(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def check_batch(got, g, prefix, ray_tol=2e-6, bound_tol=0.0, skip=()):
+    keys = [k[len(prefix) + 1:] for k in g if k.startswith(prefix + '/') and k != f'{prefix}/seed']
+    assert keys
+    for k in keys:
+        if k in skip:
+            continue
+        want, have = g[f'{prefix}/{k}'], np_(got[k])
+        assert have.shape == want.shape, (k, have.shape, want.shape)
+        assert have.dtype == want.dtype, (k, have.dtype, want.dtype)
+        if k in ('origin', 'direction'):
+            assert np.abs(have - want).max() <= ray_tol, (k, np.abs(have - want).max())
+        elif k in ('human_near', 'human_far') and bound_tol:
+            assert np.abs(have - want).max() <= bound_tol, (k, np.abs(have - want).max())
+        else:
+            assert np.array_equal(have, want), k
+    return keys
+
+
+@pytest.mark.parametrize("it,key", [(4, 'border'), (3, 'border_it3'), (0, 'border_it0')])
+def test_border_mask_equals_scipy_dilation(G, it, key):
+    binary = torch.from_numpy(np.stack([(c.mask > 0).astype(np.uint8) for c in G.caps])).cuda()
+    got = G.rb.border_mask(binary, it)
+    assert got.dtype == torch.uint8 and np.array_equal(got.cpu().numpy(), G.g[key])
+
+
+def test_near_far_cache_matches_the_reference_export(G):
+    """data_io/cache_helper.py:16-36 for every pixel of every capture: the same hit set and bounds within float32 rounding"""
+    st = G.rb.FrameStore(G.caps, G.dev, verts=G.verts, geo_threshold=0.2)
+    got, want = st.near_far.cpu().numpy(), G.g['cache']
+    assert got.shape == want[..., :2].shape
+    hit_w, hit_g = want[..., 0] < want[..., 1], got[..., 0] < got[..., 1]
+    assert np.array_equal(hit_w, hit_g) and hit_w.sum() > 2000
+    err = np.abs(got[hit_w] - want[..., :2][hit_w]).max(axis=-1)
+    print(f"[batches] near/far cache: {int(hit_w.sum())} hit pixels of {hit_w.size}, |near/far - reference| median {np.median(err):.2e}, "
+          f"90 % {np.quantile(err, 0.9):.2e}, 99 % {np.quantile(err, 0.99):.2e}, worst {err.max():.2e}")
+    # sqrt(tau^2 - r^2) of a ray grazing a vertex sphere amplifies float32 rounding (the reference's own f32 evaluation is as noisy
+    # there): a tight bound on the bulk, a conditioning bound on the grazing rays
+    assert np.median(err) < 1e-6 and np.quantile(err, 0.9) < 5e-6 and err.max() < 3e-4
+    assert np.all(np.isinf(got[~hit_w][:, 0]) | (got[~hit_w][:, 0] >= got[~hit_w][:, 1]))
+
+
+def test_background_batches_replay_the_reference_draws(G):
+    g = G.g
+    for prefix, seed, dilation, ablate in [('bkg/plain', 101, None, False), ('bkg/border', 102, G.spec['dilation'], False), ('bkg/nerft', 103, G.spec['dilation'], True)]:
+        st = G.rb.FrameStore(G.caps, G.dev, dilation=dilation)
+        opt = types.SimpleNamespace(**{**vars(G.opt), 'ablate_nerft': ablate})
+        b = G.rb.BackgroundRayBatcher(opt, st, inclusions=[c['name'] for c in G.spec['captures']], draws='numpy')
+        np.random.seed(seed)
+        keys = check_batch(b.next_batch(), g, prefix)
+        assert set(keys) == {'color', 'depth', 'origin', 'direction', 'near', 'far', 'is_bkg', 'viewf_list'}
+        print(f"[batches] {prefix}: {len(keys)} tensors equal the reference dataset's (rays within 2e-6)")
+
+
+def test_human_batches_replay_the_reference_draws(G):
+    g = G.g
+    cache = {c['name']: g['cache'][i] for i, c in enumerate(G.spec['captures'])}
+    st = G.rb.FrameStore(G.caps, G.dev, dilation=G.spec['dilation'], near_far_cache=cache)     # the reference's cache files, as a trainer would load them
+    names = [c['name'] for c in G.spec['captures']]
+    b = G.rb.HumanRayBatcher(G.opt, st, inclusions=names, draws='numpy')
+    random.seed(201)
+    np.random.seed(201)
+    keys = check_batch(b.next_batch(), g, 'human/plain')
+    assert {'color', 'origin', 'direction', 'human_near', 'human_far', 'bkg_near', 'bkg_far', 'is_bkg', 'is_hit', 'cur_view_f', 'cur_view', 'cap_id',
+            'patch_counter'} == set(keys)
+    opt_p = types.SimpleNamespace(**{**vars(G.opt), 'penalize_lpips': 0.01, 'rays_per_batch': 1024 + 300})
+    bp = G.rb.HumanRayBatcher(opt_p, st, inclusions=names, draws='numpy')
+    for kind in (0, 1):
+        seed = int(g[f'human/patch{kind}/seed'])
+        random.seed(seed)
+        np.random.seed(seed)
+        got = bp.next_batch()
+        assert int(got['patch_counter']) == kind
+        check_batch(got, g, f'human/patch{kind}')
+    bp.cap_id = 1
+    random.seed(401)
+    np.random.seed(401)
+    got = bp.next_batch()
+    assert got['cap_id'] == 1
+    check_batch(got, g, 'human/fixed')
+    # the same batches from the device-built cache: bounds within float32 rounding, hit flags equal
+    st2 = G.rb.FrameStore(G.caps, G.dev, dilation=G.spec['dilation'], verts=G.verts, geo_threshold=0.2)
+    b2 = G.rb.HumanRayBatcher(G.opt, st2, inclusions=names, draws='numpy')
+    random.seed(201)
+    np.random.seed(201)
+    check_batch(b2.next_batch(), g, 'human/plain', bound_tol=3e-4)
+
+
+def test_device_draws_have_the_reference_distribution(G):
+    """draws='device': no host traffic; the classes, counts and per-capture spread of the reference's sampling"""
+    st = G.rb.FrameStore(G.caps, G.dev, dilation=G.spec['dilation'], verts=G.verts, geo_threshold=0.2)
+    opt = types.SimpleNamespace(**{**vars(G.opt), 'rays_per_batch': 6000})
+    b = G.rb.BackgroundRayBatcher(opt, st, draws='device', seed=5)
+    out = b.next_batch()
+    assert out['color'].shape == (6000, 3) and out['origin'].is_cuda
+    # every ray is a background pixel outside the border of its capture, and its colour / depth are that pixel's
+    d = out['direction'].cpu().numpy().astype(np.float64)
+    per_cap = np.bincount(np.round(out['viewf_list'].cpu().numpy()[:, 0] * 3).astype(int), minlength=3)
+    assert per_cap.sum() == 6000 and per_cap.min() > 1700                       # multinomial(6000, 1/3): sigma = 36
+    assert np.allclose(np.linalg.norm(d, axis=1), 1.0, atol=1e-6)
+    allowed = [(G.g['border'][i] | G.caps[i].mask) == 0 for i in range(3)]
+    lut = {}
+    for i in range(3):
+        ys, xs = np.nonzero(allowed[i])
+        for y, x in zip(ys, xs):
+            lut.setdefault((i,) + tuple(G.caps[i].image[y, x]), []).append(G.caps[i].depth_map[y, x])
+    cols = np.round(out['color'].cpu().numpy() * 255).astype(np.uint8)
+    caps_of = np.round(out['viewf_list'].cpu().numpy()[:, 0] * 3).astype(int)
+    dep = out['depth'].cpu().numpy()
+    for k in range(0, 6000, 7):
+        cands = lut.get((caps_of[k],) + tuple(cols[k]))
+        assert cands is not None and any(c == dep[k] for c in cands)
+    hb = G.rb.HumanRayBatcher(G.opt, st, draws='device', seed=3)
+    hout = hb.next_batch()
+    cap = hout['cap_id']
+    n = G.rb.num_rays_per_class(G.opt, 512)
+    is_bkg = hout['is_bkg'].cpu().numpy()
+    assert (is_bkg == 0).sum() == n['num_body_rays'] and (is_bkg == 1).sum() == n['num_border_rays'] + n['num_bkg_rays']
+    assert hout['is_hit'].sum() > 0 and bool((hout['human_near'] <= hout['human_far']).all())
+    assert float(hout['bkg_far'][0]) == np.float32(G.caps[cap].far['bkg'])
+
+
+def test_cache_files_round_trip(G, tmp_path):
+    """export_near_far_cache writes the reference's file names and [H,W,3] float64 layout; load_near_far_cache reads them back"""
+    caps = []
+    for c in G.caps:
+        k = types.SimpleNamespace(**{a: getattr(c, a) for a in ('image', 'mask', 'depth_map', 'near', 'far', 'frame_id', 'cam_pose', 'intrinsic_matrix', 'shape')})
+        k.image_path = str(tmp_path / 'images' / os.path.basename(c.image_path))
+        k.size = c.shape
+        caps.append(k)
+    scene = types.SimpleNamespace(captures=caps, verts=G.verts, image_path_to_index={c.image_path: i for i, c in enumerate(caps)})
+    G.rb.export_near_far_cache(G.opt, scene, 0.2, device=G.dev)
+    path = tmp_path / 'cache' / 'near_far_cache_00001.png_40_56_0.2_True.npy'
+    assert path.is_file()
+    book = G.rb.load_near_far_cache(G.opt, scene, 0.2)
+    arr = book['00001.png']
+    assert arr.shape == (40, 56, 3) and arr.dtype == np.float64 and np.all(arr[..., 2] == 1)
+    hit = G.g['cache'][1][..., 0] < G.g['cache'][1][..., 1]
+    assert np.abs(arr[..., :2][hit] - G.g['cache'][1][..., :2][hit]).max() < 3e-4
