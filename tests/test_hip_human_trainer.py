@@ -133,3 +133,46 @@ def test_training_steps_lower_the_loss(setup):
         totals.append(total)
     print("[trainer] totals", " ".join(f"{t:.4f}" for t in totals))
     assert np.isfinite(totals).all() and min(totals[4:]) < totals[0]
+
+
+def test_trainer_loop_schedules_and_checkpoint(setup, tmp_path):
+    """HumanNeRFTrainer: train_batch's grouping / delay / schedules (human_nerf_trainer.py:540-601) and the checkpoint round trip"""
+    S = setup
+    opt = types.SimpleNamespace(**{**vars(S.opt), 'delay_iters': 2, 'lrate_decay': 1, 'learning_rate': 5e-4, 'smpl_lr': 3e-4, 'prior_knowledge_decay': True,
+                                   'offset_lim': 1.0, 'offset_scale': 0.05, 'offset_delay': 3, 'max_iter': 5, 'valid_iter': 0, 'out': str(tmp_path / 'human'),
+                                   'resume': False, 'load_weights': False})
+    optim = torch.optim.Adam([{"params": [S.net.poses], "lr": opt.smpl_lr}, {"params": S.net.coarse_human_net.parameters(), "lr": opt.learning_rate},
+                              {"params": S.net.offset_nets.parameters(), "lr": opt.learning_rate}])
+    masked = []
+
+    def mask(cap_id):                                             # stands in for the DensePose visibility mask: freeze every joint but the root
+        masked.append(cap_id)
+        m = np.zeros((24, 3), np.float32)
+        m[0] = 1
+        return m
+    tr = S.ht.HumanNeRFTrainer(opt, S.net, optim, S.loss.faces, S.loss.can_mesh, S.loss.can_caps, batches=lambda: S.batch, pose_grad_mask=mask,
+                               interval_comp=0.8, seed=4)
+    pose_before = S.net.poses.detach().clone()
+    log = []
+    torch.manual_seed(13)
+    tr.train(on_step=lambda it, rep: log.append((it, rep, S.net.offset_nets[0].nerf.scale)))
+    assert [it for it, _, _ in log] == [0, 1, 2, 3, 4, 5] and masked == [1] * 6
+    for it, rep, _ in log:
+        can = rep['smpl_sym_reg'] + rep['smpl_shape_reg']
+        rgb = rep['fine_rgb_loss'] + rep['color_range_reg'] + rep['lpips_loss']
+        want = can + rep['mask_loss'] + rep['sparsity_reg'] + (rgb if it >= 2 else 0.0)          # photometric terms join at delay_iters
+        assert rep['total_loss'] == pytest.approx(want, rel=1e-5) and rep['rgb_loss'] == pytest.approx(rgb, rel=1e-6)
+    k = 0.1 ** (5 / 1000)
+    assert optim.param_groups[0]['lr'] == pytest.approx(3e-4 * k, rel=1e-12) and optim.param_groups[2]['lr'] == pytest.approx(5e-4 * k, rel=1e-12)
+    keep = 1 - 5 / 60000
+    assert tr.penalize_mask == pytest.approx(S.opt.penalize_mask * keep) and tr.penalize_dummy == pytest.approx(S.opt.penalize_dummy * keep)
+    scales = [s for _, _, s in log]                                # set AFTER each step: 0 until offset_delay, then growing from offset_scale
+    assert scales[:3] == [0, 0, 0] and scales[3] == pytest.approx(0.05) and scales[5] == pytest.approx(0.05 + 0.95 * 2 / 60000)
+    moved = (S.net.poses.detach() - pose_before)[1].reshape(24, 3).abs().sum(1)
+    assert float(moved[0]) > 0 and float(moved[1:].sum()) == 0     # the mask froze the other joints; other frames got no gradient at all
+    assert float((S.net.poses.detach() - pose_before)[0].abs().sum()) == 0
+    rep = tr.validate(n_batches=1)
+    assert S.net.coarse_human_net.training and np.isfinite(rep['total_loss'])
+    ckpt = torch.load(tmp_path / 'human' / 'checkpoint.pth.tar', map_location='cpu', weights_only=False)
+    assert set(ckpt) == {'epoch', 'iteration', 'optim_state_dict', 'hybrid_model_state_dict'} and ckpt['iteration'] == 5
+    assert any(k.startswith('coarse_human_net.') for k in ckpt['hybrid_model_state_dict']) and 'poses' in ckpt['hybrid_model_state_dict']
