@@ -21,6 +21,7 @@ import random
 import numpy as np
 import torch
 import torch.nn.functional as F
+import torch.utils.data
 
 from . import _lib, ray_utils
 
@@ -418,3 +419,55 @@ def load_near_far_cache(opt, scene, geo_threshold):
         assert os.path.isfile(path), f'{path} not exist'
         book[os.path.basename(cap.image_path)] = np.load(path)
     return book
+
+
+# ------------------------------------------------------------------------------------------------
+# the reference's dataset classes by name and constructor, for its train.py (train.py:40-52, 108-119): a torch Dataset whose items are
+# device batches.  Use with DataLoader(num_workers=0) -- the default collate adds the leading axis of 1 the reference's trainers strip
+# (utils/utils.py:89-93), and nothing has to cross from worker processes because nothing is built on the host.
+# ------------------------------------------------------------------------------------------------
+class BackgroundRayDataset(torch.utils.data.Dataset):
+    """datasets/background_rays.py:15-41 (opt, scene, dset_type, split) over a FrameStore built from scene.captures"""
+
+    def __init__(self, opt, scene, dset_type, split, device='cuda', store=None, draws='device'):
+        from .data_io import read_text
+        self.opt, self.scene, self.dset_type, self.split = opt, scene, dset_type, split
+        self.inclusions = read_text(split)
+        has_border = all(hasattr(c, 'border_mask') for c in scene.captures)
+        self.store = store or FrameStore(scene.captures, device, dilation=(opt.dilation if has_border else None),
+                                         use_fused_depth=bool(getattr(opt, 'use_fused_depth', False)))
+        self.batcher = BackgroundRayBatcher(opt, self.store, self.inclusions, dset_type, draws=draws)
+
+    def __len__(self):
+        return len(self.batcher)
+
+    def __getitem__(self, index):
+        return self.batcher.next_batch()
+
+
+class HumanRayDataset(torch.utils.data.Dataset):
+    """datasets/human_rays.py:36-79 (opt, scene, dset_type, split, near_far_cache=None); the cache is computed on the device from
+    scene.verts when none is passed (the reference exports and reloads .npy files at this point, :62-64)"""
+
+    def __init__(self, opt, scene, dset_type, split, near_far_cache=None, device='cuda', store=None, draws='device'):
+        from .data_io import read_text
+        self.opt, self.scene, self.dset_type, self.split = opt, scene, dset_type, split
+        self.inclusions = read_text(split)
+        self.store = store or FrameStore(scene.captures, device, dilation=opt.dilation, near_far_cache=near_far_cache,
+                                         verts=None if near_far_cache is not None else scene.verts, geo_threshold=opt.geo_threshold)
+        self.batcher = HumanRayBatcher(opt, self.store, self.inclusions, dset_type, draws=draws)
+        self.near_far_cache = near_far_cache
+
+    @property
+    def cap_id(self):
+        return self.batcher.cap_id
+
+    @cap_id.setter
+    def cap_id(self, value):
+        self.batcher.cap_id = value
+
+    def __len__(self):
+        return len(self.batcher)
+
+    def __getitem__(self, index):
+        return self.batcher.next_batch()

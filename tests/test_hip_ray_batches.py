@@ -182,3 +182,20 @@ def test_cache_files_round_trip(G, tmp_path):
     assert arr.shape == (40, 56, 3) and arr.dtype == np.float64 and np.all(arr[..., 2] == 1)
     hit = G.g['cache'][1][..., 0] < G.g['cache'][1][..., 1]
     assert np.abs(arr[..., :2][hit] - G.g['cache'][1][..., :2][hit]).max() < 3e-4
+
+
+def test_reference_named_datasets_under_a_dataloader(G, tmp_path):
+    """train.py:40-52: BackgroundRayDataset(opt, scene, 'train', split) behind a DataLoader -> [1, N, ...] batches, on the device"""
+    split = tmp_path / 'train_split.txt'
+    split.write_text('\n'.join(c['name'] for c in G.spec['captures'][:2]))
+    scene = types.SimpleNamespace(captures=G.caps, verts=G.verts)
+    ds = G.rb.BackgroundRayDataset(G.opt, scene, 'train', str(split))
+    assert len(ds) == 1000000 and len(G.rb.BackgroundRayDataset(G.opt, scene, 'val', str(split), store=ds.store)) == 10
+    loader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False, num_workers=0)
+    batch = next(iter(loader))
+    assert batch['color'].shape == (1, 512, 3) and batch['origin'].is_cuda and batch['is_bkg'].dtype == torch.int64
+    assert set(np.round(batch['viewf_list'][0, :, 0].cpu().numpy() * 3).astype(int)) <= {0, 1}          # only the split's captures
+    hs = G.rb.HumanRayDataset(G.opt, scene, 'train', str(split))
+    hs.cap_id = 0
+    hb = next(iter(torch.utils.data.DataLoader(hs, batch_size=1, num_workers=0)))
+    assert hb['human_near'].shape == (1, 512, 1) and int(hb['cap_id']) == 0 and hb['is_hit'].sum() > 0
