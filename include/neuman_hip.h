@@ -349,6 +349,13 @@ int nm_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A,
 int nm_gemm_bf16x3(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                    int ldc, const float* bias, const float* mask, int ldmask, int flags, float* workspace,
                    int64_t workspace_floats, nm_stream_t stream);
+/* and split into fp16 hi + lo on the fp16 MFMA (11 + 11 significand bits: float32 class, what the rendering kernels call fp16x3).
+ * Operands are taken as they are (no scaling): parts below fp16's normal range lose at most 2^-25 absolutely, magnitudes beyond
+ * 65504 saturate -- meant for the forward products (activations and weights of O(1)); gradients, whose magnitudes are unbounded
+ * below, belong on nm_gemm_bf16x3 or nm_gemm_f32.  Same arguments, same rules. */
+int nm_gemm_fp16x3(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+                   int ldc, const float* bias, const float* mask, int ldmask, int flags, float* workspace,
+                   int64_t workspace_floats, nm_stream_t stream);
 int nm_pe_encode(const float* x, int64_t n, int dims, int kind, int n_freqs, const float* table, float* out, int ld,
                  nm_stream_t stream);
 /* out[W] = column sums of X [n,W] (row stride ld): the bias gradients; bands of 256 rows summed in order (deterministic) */

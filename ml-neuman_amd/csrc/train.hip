@@ -155,11 +155,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
 // what lane (row = l % 32, octet = l / 32) of v_mfma_f32_32x32x16_bf16 consumes -- one ds_read_b128 per fragment, conflict-free.
 constexpr int XK = 32;                  // k per tile: two MFMA k-steps
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool HALF>
 __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
     unsigned h[4], l[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const f32x2 a = {v[2 * p], v[2 * p + 1]};
+        f32x2 a = {v[2 * p], v[2 * p + 1]};
+        if (HALF) {                                                  // fp16 parts (11 + 11 significand bits); saturate instead of inf - inf
+            a.x = __builtin_amdgcn_fmed3f(a.x, -65504.f, 65504.f);
+            a.y = __builtin_amdgcn_fmed3f(a.y, -65504.f, 65504.f);
+            const f16x2 hb = __builtin_convertvector(a, f16x2);
+            const f32x2 hf = __builtin_convertvector(hb, f32x2);
+            const f32x2 r = {a.x - hf.x, a.y - hf.y};
+            const f16x2 lb = __builtin_convertvector(r, f16x2);
+            h[p] = __builtin_bit_cast(unsigned, hb);
+            l[p] = __builtin_bit_cast(unsigned, lb);
+            continue;
+        }
         const bf16x2 hb = __builtin_convertvector(a, bf16x2);
         const f32x2 hf = __builtin_convertvector(hb, f32x2);
         const f32x2 r = {a.x - hf.x, a.y - hf.y};
@@ -171,37 +185,50 @@ __device__ __forceinline__ void split8(const float* v, uint4& hi, uint4& lo) {
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-// one 128 x 32 operand tile -> registers: two (row, k-octet) pairs of 8 floats per thread, zero beyond the edges
+// one 128 x 32 operand tile -> registers: two (row, k-octet) pairs of 8 floats per thread, zero beyond the edges.
+//   KMAJOR (element (k, d) at S[k * ld + d]): lanes run along d, eight strided 4-byte loads each -- 256 B contiguous per instruction
+//   else   (element (k, d) at S[d * ld + k]): four lanes share a row's 128 B (one cache line), so a wave instruction touches 16
+//          lines; one lane per row (64 lines per instruction) left the kernel bound by the texture path, not by its MFMAs
+template <bool KMAJOR>
+__device__ __forceinline__ void xtile_item(int tid, int h, int& row, int& octet) {
+    if (KMAJOR) { row = tid & 127; octet = (tid >> 7) + 2 * h; }
+    else { const int item = tid + 256 * h; row = item >> 2; octet = item & 3; }
+}
 template <bool KMAJOR>
 __device__ __forceinline__ void xtile_load(const float* __restrict__ S, int ld, int DIM, int d0, int k0, int kend, int tid, float (&r)[2][8]) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int d = d0 + (tid & 127), k = k0 + 8 * ((tid >> 7) + 2 * h);
+        int row, octet;
+        xtile_item<KMAJOR>(tid, h, row, octet);
+        const int d = d0 + row, k = k0 + 8 * octet;
 #pragma unroll
         for (int j = 0; j < 8; ++j) r[h][j] = 0.f;
         if (d >= DIM) continue;
         if (KMAJOR) {
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if (k + j < kend) r[h][j] = S[(int64_t)(k + j) * ld + d];       // lanes run along d: coalesced
+                if (k + j < kend) r[h][j] = S[(int64_t)(k + j) * ld + d];
         } else {
             if (k < kend) *reinterpret_cast<float4*>(&r[h][0]) = *reinterpret_cast<const float4*>(S + (int64_t)d * ld + k);
             if (k + 4 < kend) *reinterpret_cast<float4*>(&r[h][4]) = *reinterpret_cast<const float4*>(S + (int64_t)d * ld + k + 4);
         }
     }
 }
+template <bool KMAJOR, bool HALF>
 __device__ __forceinline__ void xtile_store(uint4 (*Th)[BM], uint4 (*Tl)[BM], int tid, const float (&r)[2][8]) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
+        int row, octet;
+        xtile_item<KMAJOR>(tid, h, row, octet);
         uint4 hi, lo;
-        split8(r[h], hi, lo);
-        Th[(tid >> 7) + 2 * h][tid & 127] = hi;
-        Tl[(tid >> 7) + 2 * h][tid & 127] = lo;
+        split8<HALF>(r[h], hi, lo);
+        Th[octet][row] = hi;
+        Tl[octet][row] = lo;
     }
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR>
-__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmArgs g) {
+template <bool A_KMAJOR, bool B_KMAJOR, bool HALF>
+__global__ __launch_bounds__(256) void gemm_split_kernel(const GemmArgs g) {
     __shared__ uint4 Ah[XK / 8][BM], Al[XK / 8][BM], Bh[XK / 8][BN], Bl[XK / 8][BN];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -220,8 +247,8 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmArgs g) {
     xtile_load<B_KMAJOR>(g.B, g.ldb, g.N, n0, kbeg, kend, tid, rb);
     for (int k0 = kbeg; k0 < kend; k0 += XK) {
         __syncthreads();                                               // the previous tile's fragments have been read
-        xtile_store(Ah, Al, tid, ra);
-        xtile_store(Bh, Bl, tid, rb);
+        xtile_store<A_KMAJOR, HALF>(Ah, Al, tid, ra);
+        xtile_store<B_KMAJOR, HALF>(Bh, Bl, tid, rb);
         __syncthreads();
         if (k0 + XK < kend) {                                          // next tile's loads fly during this tile's MFMAs
             xtile_load<A_KMAJOR>(g.A, g.lda, g.M, m0, k0 + XK, kend, tid, ra);
@@ -238,14 +265,23 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(const GemmArgs g) {
                 bh[i] = __builtin_bit_cast(bf16x8, Bh[o][wn + 32 * i + c]);
                 bl[i] = __builtin_bit_cast(bf16x8, Bl[o][wn + 32 * i + c]);
             }
+            auto mm = [](bf16x8 x, bf16x8 y, floatx16 c) {          // (the registers hold fp16 bit patterns when HALF)
+                if (HALF) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+                return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+            };
+            // the three products of one k-step, each over the four accumulator blocks: a block's next MFMA never waits for its last
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < 2; ++j) acc[i][j] = mm(al[i], bh[j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mm(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mm(ah[i], bh[j], acc[i][j]);
         }
     }
     store_tile(g, acc, m0, n0, wm, wn, lane);
@@ -417,7 +453,7 @@ int64_t nm_gemm_workspace_floats(int M, int N, int K) {
     return s > 1 ? (int64_t)s * M * N : 0;
 }
 
-static int gemm_dispatch(int bf16x3, int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
+static int gemm_dispatch(int mode, int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                          int ldc, const float* bias, const float* mask, int ldmask, int flags, float* workspace, int64_t workspace_floats,
                          nm_stream_t stream) {
     NM_REQUIRE(M >= 0 && N >= 0 && K >= 0, "nm_gemm_f32: negative size");
@@ -445,11 +481,16 @@ static int gemm_dispatch(int bf16x3, int a_kmajor, int b_kmajor, int M, int N, i
     splits = (K + g.k_per_split - 1) / g.k_per_split;
     if (splits < 1) splits = 1;
     const dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, splits);
-    if (bf16x3) {
-        if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), grid, dim3(256), 0, st, g);
-        else if (a_kmajor) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), grid, dim3(256), 0, st, g);
-        else if (b_kmajor) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true>), grid, dim3(256), 0, st, g);
-        else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), grid, dim3(256), 0, st, g);
+    if (mode == 1) {
+        if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_split_kernel<true, true, false>), grid, dim3(256), 0, st, g);
+        else if (a_kmajor) hipLaunchKernelGGL((gemm_split_kernel<true, false, false>), grid, dim3(256), 0, st, g);
+        else if (b_kmajor) hipLaunchKernelGGL((gemm_split_kernel<false, true, false>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_split_kernel<false, false, false>), grid, dim3(256), 0, st, g);
+    } else if (mode == 2) {
+        if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_split_kernel<true, true, true>), grid, dim3(256), 0, st, g);
+        else if (a_kmajor) hipLaunchKernelGGL((gemm_split_kernel<true, false, true>), grid, dim3(256), 0, st, g);
+        else if (b_kmajor) hipLaunchKernelGGL((gemm_split_kernel<false, true, true>), grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL((gemm_split_kernel<false, false, true>), grid, dim3(256), 0, st, g);
     } else {
         if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, dim3(256), 0, st, g);
         else if (a_kmajor) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, dim3(256), 0, st, g);
@@ -474,6 +515,11 @@ int nm_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A,
 int nm_gemm_bf16x3(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                    const float* bias, const float* mask, int ldmask, int flags, float* workspace, int64_t workspace_floats, nm_stream_t stream) {
     return gemm_dispatch(1, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, ldmask, flags, workspace, workspace_floats, stream);
+}
+
+int nm_gemm_fp16x3(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                   const float* bias, const float* mask, int ldmask, int flags, float* workspace, int64_t workspace_floats, nm_stream_t stream) {
+    return gemm_dispatch(2, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, ldmask, flags, workspace, workspace_floats, stream);
 }
 
 int64_t nm_colsum_workspace_floats(int64_t n, int W) { return ((n + kColsumRows - 1) / kColsumRows) * W; }

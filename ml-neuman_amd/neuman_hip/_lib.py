@@ -68,6 +68,7 @@ SIGNATURES = {
     "nm_gemm_workspace_floats": (i64, [i32, i32, i32]),
     "nm_gemm_f32": (i32, [i32, i32, i32, i32, i32, c_f32p, i32, c_f32p, i32, c_f32p, i32, c_f32p, c_f32p, i32, i32, c_f32p, i64, c_stream]),
     "nm_gemm_bf16x3": (i32, [i32, i32, i32, i32, i32, c_f32p, i32, c_f32p, i32, c_f32p, i32, c_f32p, c_f32p, i32, i32, c_f32p, i64, c_stream]),
+    "nm_gemm_fp16x3": (i32, [i32, i32, i32, i32, i32, c_f32p, i32, c_f32p, i32, c_f32p, i32, c_f32p, c_f32p, i32, i32, c_f32p, i64, c_stream]),
     "nm_pe_encode": (i32, [c_f32p, i64, i32, i32, i32, c_f32p, c_f32p, i32, c_stream]),
     "nm_colsum_workspace_floats": (i64, [i64, i32]),
     "nm_colsum": (i32, [c_f32p, i64, i32, i32, c_f32p, c_f32p, i64, c_stream]),

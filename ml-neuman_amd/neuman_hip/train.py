@@ -19,14 +19,21 @@ from . import _lib
 
 ACC, BIAS, RELU, MASK = 1, 2, 4, 8                    # NM_GEMM_* (include/neuman_hip.h)
 PE_KINDS = {'posenc': 0, 'rotate': 1}                 # NM_PE_POSENC / NM_PE_ROTATE
-# arithmetic of the matrix products: 'f32' (f32 MFMA: gradients within 1e-6 of the reference's) or 'bf16x3' (split-bf16 x3 on
-# the bf16 MFMA, 2^-18 per product, 1.2x faster per iteration today: its 1e-5 forward error flips a ReLU here and there, so
-# single gradient entries move by ~1e-3 of the tensor's largest -- fine for SGD, not for the parity tests)
+# arithmetic of the matrix products:
+#   'f32'     f32 MFMA everywhere: gradients within 1e-6 of the reference's (the parity mode and the default)
+#   'mixed16' forward products split-fp16 x3 on the fp16 MFMA (float32 class: no ReLU decided differently from the f32 forward beyond
+#             what float32 reordering already does), backward products split-bf16 x3 on the bf16 MFMA (range-safe for gradients of any
+#             magnitude; 2^-17 per product, a smooth error)
+#   'bf16x3'  split-bf16 x3 everywhere (its 1e-5 forward error flips a ReLU here and there: single gradient entries move by ~1e-3 of
+#             the tensor's largest -- fine for SGD, not for the parity tests);  'fp16x3': split-fp16 x3 everywhere (forward-safe only)
 GEMM_PRECISION = os.environ.get('NEUMAN_TRAIN_GEMM', 'f32')
 
 
 def _gemm(a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, bias=None, mask=None, ldmask=0, flags=0, ws=None, precision=None):
-    fn = {'f32': _lib.lib().nm_gemm_f32, 'bf16x3': _lib.lib().nm_gemm_bf16x3}[precision or GEMM_PRECISION]
+    prec = precision or GEMM_PRECISION
+    if prec == 'mixed16':
+        prec = 'fp16x3' if (a_kmajor, b_kmajor) == (0, 0) else 'bf16x3'        # (0, 0) = the forward products Z = A W^T
+    fn = {'f32': _lib.lib().nm_gemm_f32, 'bf16x3': _lib.lib().nm_gemm_bf16x3, 'fp16x3': _lib.lib().nm_gemm_fp16x3}[prec]
     _lib.check(fn(a_kmajor, b_kmajor, M, N, K, _lib.dev_ptr(A), lda, _lib.dev_ptr(B), ldb, _lib.dev_ptr(C), ldc,
                                       _lib.dev_ptr(bias), _lib.dev_ptr(mask), ldmask, flags, _lib.dev_ptr(ws), 0 if ws is None else ws.numel(),
                                       _lib.stream_ptr()), "nm_gemm")

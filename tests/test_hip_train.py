@@ -31,7 +31,7 @@ def cu(x):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 16), (4, 4, 4), (260, 132, 36), (1000, 256, 64), (256, 28, 8192), (4, 256, 20000), (512, 512, 4100)])
 @pytest.mark.parametrize("akm,bkm", [(0, 0), (0, 1), (1, 1), (1, 0)])
-@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "fp16x3"])
 def test_gemm(G, M, N, K, akm, bkm, prec, monkeypatch):
     monkeypatch.setattr(G.train, "GEMM_PRECISION", prec)
     rng = np.random.default_rng(M * 7 + N * 3 + K + akm * 2 + bkm)
@@ -47,7 +47,7 @@ def test_gemm(G, M, N, K, akm, bkm, prec, monkeypatch):
     G.train._gemm(akm, bkm, M, N, K, a, a.shape[1], b, b.shape[1], C, N + 4, ws=ws)
     out = C.cpu().numpy().astype(np.float64)
     assert (out[:, N:] == 7.0).all()
-    scale = np.sqrt(K) * (1.0 if prec == 'f32' else 10.0)          # bf16x3 drops lo*lo: 2^-18 |a||b| per product
+    scale = np.sqrt(K) * {'f32': 1.0, 'fp16x3': 2.0, 'bf16x3': 10.0}[prec]   # bf16x3 drops lo*lo: 2^-18 |a||b| per product; fp16x3: 2^-22
     assert np.abs(out[:, :N] - ref).max() < 3e-6 * scale * 4, np.abs(out[:, :N] - ref).max()
     # accumulate on top
     G.train._gemm(akm, bkm, M, N, K, a, a.shape[1], b, b.shape[1], C, N + 4, flags=G.train.ACC, ws=ws)
@@ -120,9 +120,10 @@ def test_composite_backward_saturated_rays(G, white):
     assert np.isfinite(got).all() and np.abs(got - ora).max() < 2e-5 * s
 
 
+@pytest.mark.parametrize("prec", ["f32", "mixed16"])
 @pytest.mark.parametrize("tag,white,penalty", [("white", True, 0.0), ("black_penalty", False, 0.1)])
-def test_training_step_matches_reference(G, tag, white, penalty, monkeypatch):
-    monkeypatch.setattr(G.train, "GEMM_PRECISION", "f32")
+def test_training_step_matches_reference(G, tag, white, penalty, prec, monkeypatch):
+    monkeypatch.setattr(G.train, "GEMM_PRECISION", prec)
     """the lines of NeRFTrainer.loss_func (vanilla_nerf_trainer.py:66-95) on the HIP modules, at the reference's sample depths"""
     g = G.g
     o, d, color, depth = cu(g['origin']), cu(g['direction']), cu(g['color']), cu(g['depth'])
@@ -152,12 +153,12 @@ def test_training_step_matches_reference(G, tag, white, penalty, monkeypatch):
         worst = check_grads(grads, g, p)
         ora = OT.training_pass(G.syn.state_numpy(net), g['origin'], g['direction'], g[f'{p}/z'], g['color'], white, penalty, g['depth'])
         worst_o = max(np.abs(grads[n] - ora['grads'][n]).max() / max(np.abs(ora['grads'][n]).max(), 1e-12) for n in grads)
-        print(f"[train] {p}: loss {float(loss_rgb.detach()):.6f} + {float(loss_empty.detach()):.6f}; parameter gradients: worst relative error vs reference {worst:.2e}, "
+        print(f"[train] {prec} {p}: loss {float(loss_rgb.detach()):.6f} + {float(loss_empty.detach()):.6f}; parameter gradients: worst relative error vs reference {worst:.2e}, "
               f"vs f64 oracle {worst_o:.2e}")
         assert worst_o < 1e-4
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "mixed16"])
 def test_a_few_sgd_steps_reduce_the_loss(G, prec, monkeypatch):
     monkeypatch.setattr(G.train, "GEMM_PRECISION", prec)
     """end to end: Adam on the HIP forward/backward drives the reference's loss down on a fixed batch"""
