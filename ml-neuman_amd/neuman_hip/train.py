@@ -9,7 +9,8 @@ Every matrix product is `nm_gemm_f32` (float32 MFMA, csrc/train.hip), the encodi
 `nm_composite_backward`; torch supplies memory and the autograd graph.  The layer loop below is the reference's
 models/vanilla.py:120-152 with the two concatenations (skip connection :130-131, views layer :139-140) written as two
 products into one output.  Gradients reach the parameters and, when asked for, the sample positions and view directions
-(what the human trainer's pose / offset optimisation differentiates; the warp and offset nets upstream of them are not built).
+(what the human trainer's pose / offset optimisation differentiates: the differentiable warp, the offset nets and the skinning
+upstream of them are neuman_hip.ray_utils.warp_samples_to_canonical_diff, OffsetNet and smpl.SMPLDiff).
 """
 import os
 
