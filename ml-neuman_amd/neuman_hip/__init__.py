@@ -7,8 +7,10 @@
 
 Sub-modules mirror the reference's: ``ray_utils`` (utils/ray_utils.py), ``render_utils`` (utils/render_utils.py:69-461),
 ``vanilla`` (models/vanilla.py), ``smpl`` (models/smpl.py skinning + data_io/neuman_helper.py:read_smpls, batched on the
-device); ``parallel`` adds the ray-tile sharding for 1/2/4/8 GPUs; ``synthetic`` the
-asset-free workloads.  Nothing in this package evaluates the hot path on the CPU.
+device); ``parallel`` adds the ray-tile sharding for 1/2/4/8 GPUs; ``synthetic`` the asset-free workloads.  Around the path
+(imported on demand): ``data_io`` + ``scene_content`` (COLMAP / split / checkpoint / per-frame file readers), ``ray_batches``
+(datasets/*.py: training batches drawn on the device), ``train`` + ``bkg_trainer`` + ``human_trainer`` (trainers/*.py),
+``lpips``.  Nothing in this package evaluates the hot path on the CPU.
 """
 from . import _lib, parallel, ray_utils, render_utils, smpl, synthetic, vanilla  # noqa: F401
 from ._lib import NeumanHipError  # noqa: F401
