@@ -210,16 +210,49 @@ class HumanNeRFLoss:
         return {k: float(v.detach()) for k, v in loss_dict.items()}, float(total.detach())
 
 
+# DensePose body-part labels (1..24) that show a limb, and the SMPL joints whose pose gradient is zeroed when none of them is in
+# the frame's DensePose map (human_nerf_trainer.py:40-105: an occluded limb's rotation is not refined from that frame)
+_LIMB_LABELS_TO_JOINTS = (
+    ((8, 10), (1,)), ((7, 9), (2,)),            # upper leg left / right -> hips
+    ((12, 14), (4,)), ((11, 13), (5,)),         # lower leg left / right -> knees
+    ((5,), (7, 10)), ((6,), (8, 11)),           # foot left / right -> ankle, toes
+    ((15, 17), (16,)), ((16, 18), (17,)),       # upper arm left / right -> shoulders
+    ((19, 21), (18,)), ((20, 22), (19,)),       # lower arm left / right -> elbows
+    ((4,), (20, 22)), ((3,), (21, 23)),         # hand left / right -> wrist, fingers
+    ((23, 24), (12, 15)),                       # head -> neck, head
+)
+
+
+def densepose_pose_mask(dp_mask):
+    """turn_smpl_gradient_off (human_nerf_trainer.py:70-105): [72] multipliers for one frame's pose gradient, 0 for the three
+    axis-angle components of every joint whose limb has no pixel in the DensePose label map `dp_mask`."""
+    assert dp_mask is not None
+    seen = set(int(v) for v in np.unique(dp_mask))
+    mask = np.ones((24, 3))
+    for labels, joints in _LIMB_LABELS_TO_JOINTS:
+        if not any(l in seen for l in labels):
+            mask[list(joints)] = 0
+    return mask.reshape(-1)
+
+
 class HumanNeRFTrainer(HumanNeRFLoss):
     """The loop around the loss (human_nerf_trainer.py:447-494, 540-601, 636-680 + base_trainer.py:66-108): loss grouping and the
     photometric delay, NaN guard, optimiser step, the schedules of the learning rates (parameter group 0 = the SMPL parameters at
     smpl_lr, groups 1-2 = the networks at learning_rate), of the prior penalties and of the offset nets' scale, and checkpoints with
     the reference's keys.  `batches` / `val_batches` are callables returning a batch (ray_batches.HumanRayBatcher).
-    `pose_grad_mask(cap_id)` -> [24,3] or None stands in for the DensePose visibility mask of :560-573 (external data)."""
+    `pose_grad_mask(cap_id)` -> [72] multipliers or None; with opt.block_grad and `captures` carrying `.densepose` label maps it is
+    densepose_pose_mask of the batch's frame (:560-573)."""
 
-    def __init__(self, opt, net, optimizer, faces, can_mesh, can_caps, batches=None, val_batches=None, pose_grad_mask=None, **kw):
+    def __init__(self, opt, net, optimizer, faces, can_mesh, can_caps, batches=None, val_batches=None, pose_grad_mask=None, captures=None, **kw):
         super().__init__(opt, net, faces, can_mesh, can_caps, **kw)
+        kw_captures = captures
         self.optim, self.batches, self.val_batches, self.pose_grad_mask = optimizer, batches, val_batches, pose_grad_mask
+        captures = kw_captures
+        if pose_grad_mask is None and getattr(opt, 'block_grad', False) and captures is not None:      # :560-573
+            def from_densepose(cap_id):
+                dp = getattr(captures[cap_id], 'densepose', None)
+                return None if dp is None else densepose_pose_mask(dp)
+            self.pose_grad_mask = from_densepose
         self.epoch, self.iteration = 0, 0
         self.out = getattr(opt, 'out', None)
         if self.out:
