@@ -225,3 +225,61 @@ def test_c5_three_actor_slice_192_128_3x192(G):
     e = np.abs(rgb.cpu().numpy() - c_rgb).max(-1)
     print(f"[C5] {o.shape[0]} rays, hits per actor {n_hit}, merged 896 samples: conditional Linf {e.max():.2e}")
     assert e.max() < 1e-4
+
+
+def test_c4_c5_full_size_frame_properties(G):
+    """BASELINE configs 4 and 5 at their full frame sizes (1280x720 hybrid, merged 384; 1920x1080 three actors, merged 896) through the
+    size-independent properties the domain offers: rays are independent (a frame equals its slices, however it is cut into launches),
+    rays that miss every body are the background render, colours / depths stay in range."""
+    posed, T = G.syn.twist_transforms(G.syn.capsule_mesh()[0])
+    faces = np.ascontiguousarray(G.syn.capsule_mesh()[1][:, :3], np.int32)
+    coarse, fine, human = G.nets[0][0], G.nets[1][0], G.nets[2][0]
+    # ---- C4
+    cap = G.syn.SimpleCapture(1280, 720, fx=1.25 * 1280, c2w=G.syn.spherical_c2w(20., -10., 3.0), near=0.5, far=4.0)
+    o, d = G.ray.shot_all_rays_dev(cap, 'cuda')
+    mesh = G.ray.mesh_to_device(posed, faces, T, 'cuda')
+    verts = cu(posed)
+    trace = {}
+    rgb, depth, acc = G.render.render_hybrid_rays(coarse, fine, human, o, d, cap.near['bkg'], cap.far['bkg'], verts, mesh, 128, 128, trace=trace)
+    hit = trace['hit'][0]
+    R = o.shape[0]
+    assert 0.02 * R < hit.numel() < 0.6 * R, hit.numel()
+    assert torch.isfinite(rgb).all() and rgb.min() >= -1e-5 and rgb.max() <= 1 + 1e-5 and depth.min() >= 0
+    rows = slice(1280 * 330, 1280 * 390)                                           # 60 rows through the body
+    old = G.render.MAX_RAYS_PER_LAUNCH
+    try:
+        G.render.MAX_RAYS_PER_LAUNCH = 7001
+        s_rgb, s_depth, s_acc = G.render.render_hybrid_rays(coarse, fine, human, o[rows].contiguous(), d[rows].contiguous(), cap.near['bkg'],
+                                                            cap.far['bkg'], verts, mesh, 128, 128)
+    finally:
+        G.render.MAX_RAYS_PER_LAUNCH = old
+    assert torch.equal(s_rgb, rgb[rows]) and torch.equal(s_depth, depth[rows]) and torch.equal(s_acc, acc[rows])
+    miss = torch.ones(R, dtype=torch.bool, device='cuda')
+    miss[hit.long()] = False
+    idx = torch.nonzero(miss)[:, 0][:: max(1, int(miss.sum()) // 20000)]          # ~20 000 miss rays across the frame
+    b_rgb, b_depth = G.render.render_vanilla_rays(coarse, fine, o[idx].contiguous(), d[idx].contiguous(), cap.near['bkg'], cap.far['bkg'], 128, 128)
+    assert torch.equal(b_rgb, rgb[idx]) and torch.equal(b_depth, depth[idx])      # render_utils.py:300-319: misses are the background pass
+    print(f"[C4 full] 1280x720: {hit.numel()} of {R} rays hit the body; frame = slices bit for bit, {idx.numel()} miss rays = background render")
+    # ---- C5
+    cap = G.syn.SimpleCapture(1920, 1080, fx=1.25 * 1920, c2w=G.syn.spherical_c2w(20., -10., 3.0), near=0.5, far=3.14)
+    o, d = G.ray.shot_all_rays_dev(cap, 'cuda')
+    shifts = [np.zeros(3), np.array([0.35, 0.0, 0.2]), np.array([-0.3, 0.05, -0.15])]
+    posed_l, meshes = [], []
+    for s in shifts:
+        t = T.copy()
+        t[:, :3, 3] += s
+        posed_l.append(cu((posed + s).astype(np.float32)))
+        meshes.append(G.ray.mesh_to_device((posed + s).astype(np.float32), faces, t, 'cuda'))
+    trace = {}
+    rgb, depth = G.render.render_multi_rays(coarse, fine, [human] * 3, o, d, cap.near['bkg'], cap.far['bkg'], posed_l, meshes, 192, 128, trace=trace)
+    assert torch.isfinite(rgb).all() and rgb.min() >= -1e-5 and rgb.max() <= 1 + 1e-5 and depth.min() >= 0
+    assert all(h.numel() > 1000 for h in trace['hit'])
+    rows = slice(1920 * 520, 1920 * 550)
+    try:
+        G.render.MAX_RAYS_PER_LAUNCH = 9973
+        s_rgb, s_depth = G.render.render_multi_rays(coarse, fine, [human] * 3, o[rows].contiguous(), d[rows].contiguous(), cap.near['bkg'],
+                                                    cap.far['bkg'], posed_l, meshes, 192, 128)
+    finally:
+        G.render.MAX_RAYS_PER_LAUNCH = old
+    assert torch.equal(s_rgb, rgb[rows]) and torch.equal(s_depth, depth[rows])
+    print(f"[C5 full] 1920x1080, hits per (launch, actor) {[h.numel() for h in trace['hit']]}: frame = slices bit for bit")
