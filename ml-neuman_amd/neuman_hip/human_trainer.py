@@ -4,7 +4,7 @@ One training iteration of the NeuMan human model is, per batch of rays of one fr
 
     background samples   coarse pass -> importance samples -> fine pass, both nets frozen (:180-239)   the RENDERING kernels
                                                                                                         (fp16x3 / i8x3, no autograd)
-    human samples        ray_to_samples, offset net, differentiable skinning (pose refinement),         nm_ray_to_samples, f32 MFMA GEMMs
+    human samples        ray_to_samples, offset net, differentiable skinning (pose refinement),         nm_ray_to_samples, MFMA GEMMs      
                          warp to canonical space with T^-1 of the closest surface point, human net      (neuman_hip/train.py), tree search
                                                                                           (:241-278)    (nm_signed_distance), SMPLDiff
     seven loss terms     rgb, lpips, colour range, symmetry, smpl shape, mask, sparsity (:382-446)       differentiable compositing

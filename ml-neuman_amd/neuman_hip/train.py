@@ -5,7 +5,7 @@ reference's training loss (trainers/vanilla_nerf_trainer.py:45-96) runs through 
     rgb_map, _, _, weights, _ = raw2outputs(out, z_vals, dirs[:, 0, :], ...)        # -> composite_train
     F.mse_loss(rgb_map, color).backward()            # fills .grad of the 24 parameters
 
-Every matrix product is `nm_gemm_f32` (float32 MFMA, csrc/train.hip), the encodings `nm_pe_encode`, the compositing adjoint
+Every matrix product is one of `nm_gemm_fp16x3 / nm_gemm_bf16x3 / nm_gemm_f32` (csrc/train.hip; GEMM_PRECISION below), the encodings `nm_pe_encode`, the compositing adjoint
 `nm_composite_backward`; torch supplies memory and the autograd graph.  The layer loop below is the reference's
 models/vanilla.py:120-152 with the two concatenations (skip connection :130-131, views layer :139-140) written as two
 products into one output.  Gradients reach the parameters and, when asked for, the sample positions and view directions
@@ -21,13 +21,14 @@ from . import _lib
 ACC, BIAS, RELU, MASK = 1, 2, 4, 8                    # NM_GEMM_* (include/neuman_hip.h)
 PE_KINDS = {'posenc': 0, 'rotate': 1}                 # NM_PE_POSENC / NM_PE_ROTATE
 # arithmetic of the matrix products:
-#   'f32'     f32 MFMA everywhere: gradients within 1e-6 of the reference's (the parity mode and the default)
-#   'mixed16' forward products split-fp16 x3 on the fp16 MFMA (float32 class: no ReLU decided differently from the f32 forward beyond
+#   'f32'     f32 MFMA everywhere: gradients within 1e-6 of the reference's float32 autograd (NEUMAN_TRAIN_GEMM=f32)
+#   'mixed16' (default) forward products split-fp16 x3 on the fp16 MFMA (float32 class: no ReLU decided differently from the f32 forward beyond
 #             what float32 reordering already does), backward products split-bf16 x3 on the bf16 MFMA (range-safe for gradients of any
-#             magnitude; 2^-17 per product, a smooth error)
+#             magnitude; 2^-17 per product, a smooth error): parameter gradients 6e-6 from the reference's float32 autograd, 1.25x faster
+#             per iteration (the reference itself runs TF32 products on the GPUs it was written for: torch 1.8's default)
 #   'bf16x3'  split-bf16 x3 everywhere (its 1e-5 forward error flips a ReLU here and there: single gradient entries move by ~1e-3 of
 #             the tensor's largest -- fine for SGD, not for the parity tests);  'fp16x3': split-fp16 x3 everywhere (forward-safe only)
-GEMM_PRECISION = os.environ.get('NEUMAN_TRAIN_GEMM', 'f32')
+GEMM_PRECISION = os.environ.get('NEUMAN_TRAIN_GEMM', 'mixed16')
 
 
 def _gemm(a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, bias=None, mask=None, ldmask=0, flags=0, ws=None, precision=None):
