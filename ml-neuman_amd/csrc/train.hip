@@ -98,12 +98,74 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, const floatx16 (&a
         }
 }
 
+// The same epilogue with 16-byte accesses: each wave passes its 64 x 64 accumulator tile through LDS (free once the k-loop is
+// over), half of it at a time -- 32 rows x 64 columns = 8 KB per wave --, and reads it back row-wise, so that a lane holds four
+// consecutive columns of one row: the mask / C loads and the stores become b128 accesses of 256 contiguous bytes per row (a
+// quarter of the instructions of the column-per-lane layout, whole cache lines).  Needs 16-byte aligned C / mask / partial rows
+// (ldc, ldmask multiples of 4; N is one already); `scratch` = 8192 floats of LDS no wave reads any more (caller synchronised).
+__device__ __forceinline__ bool wide_ok(const GemmArgs& g) {
+    const bool c_ok = g.partial ? (((uintptr_t)g.partial & 15) == 0) : ((((uintptr_t)g.C & 15) == 0) && (g.ldc & 3) == 0);
+    const bool m_ok = !(g.flags & NM_GEMM_MASK) || ((((uintptr_t)g.mask & 15) == 0) && (g.ldmask & 3) == 0);
+    const bool b_ok = !(g.flags & NM_GEMM_BIAS) || (((uintptr_t)g.bias & 15) == 0);
+    return c_ok && m_ok && b_ok;
+}
+__device__ __forceinline__ void store_tile_wide(const GemmArgs& g, const floatx16 (&acc)[2][2], int m0, int n0, int wm, int wn, int w, int lane,
+                                                float* scratch) {
+    float* T = scratch + w * 2048;                                  // this wave's [32][64] window
+    const int c4 = 4 * (lane & 15), rsub = lane >> 4;               // read-back: columns c4..c4+3 of rows rsub + 4 k
+    const int col = n0 + wn + c4;
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((g.flags & NM_GEMM_BIAS) && col < g.N) bias = *reinterpret_cast<const float4*>(g.bias + col);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) T[(8 * (v >> 2) + 4 * (lane >> 5) + (v & 3)) * 64 + 32 * j + (lane & 31)] = acc[i][j][v];
+        // (a wave reads only what it wrote itself: LDS operations of one wave complete in order, no barrier)
+        const int row_base = m0 + wm + 32 * i + rsub;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                      // four rows' worth of loads in flight at a time
+            float4 cv[4], mv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = row_base + 4 * (4 * half + k);
+                const bool in = row < g.M && col < g.N;
+                cv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                mv[k] = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (!g.partial && (g.flags & NM_GEMM_ACCUMULATE) && in) cv[k] = *reinterpret_cast<const float4*>(g.C + (int64_t)row * g.ldc + col);
+                if (!g.partial && (g.flags & NM_GEMM_MASK) && in) mv[k] = *reinterpret_cast<const float4*>(g.mask + (int64_t)row * g.ldmask + col);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int rr = rsub + 4 * (4 * half + k), row = row_base + 4 * (4 * half + k);
+                if (row >= g.M || col >= g.N) continue;
+                const float4 a = *reinterpret_cast<const float4*>(T + rr * 64 + c4);
+                if (g.partial) {
+                    *reinterpret_cast<float4*>(g.partial + ((int64_t)blockIdx.z * g.M + row) * g.N + col) = a;
+                    continue;
+                }
+                float x[4] = {a.x + cv[k].x + bias.x, a.y + cv[k].y + bias.y, a.z + cv[k].z + bias.z, a.w + cv[k].w + bias.w};
+                const float m[4] = {mv[k].x, mv[k].y, mv[k].z, mv[k].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (g.flags & NM_GEMM_RELU) x[e] = fmaxf(x[e], 0.f);
+                    x[e] = m[e] > 0.f ? x[e] : 0.f;
+                }
+                *reinterpret_cast<float4*>(g.C + (int64_t)row * g.ldc + col) = make_float4(x[0], x[1], x[2], x[3]);
+            }
+        }
+    }
+}
+
 // 128 x 128 output tile per workgroup of four waves (64 x 64 each = 2 x 2 MFMA blocks of 32 x 32), K in steps of 16 through a
 // double-buffered LDS tile pair; the next step's global loads are in flight during the current step's MFMAs.
 template <bool A_KMAJOR, bool B_KMAJOR>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
-    __shared__ float As[2][BK][LDT];
-    __shared__ float Bs[2][BK][LDT];
+__global__ __launch_bounds__(256, 3) void gemm_f32_kernel(const GemmArgs g) {
+    __shared__ float smem[2 * 2 * BK * LDT];                       // As | Bs; reused by the epilogue
+    float (*As)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(smem);
+    float (*Bs)[BK][LDT] = reinterpret_cast<float (*)[BK][LDT]>(smem + 2 * BK * LDT);
+    static_assert(2 * 2 * BK * LDT >= 4 * 2048, "the epilogue needs 8192 floats of LDS");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * g.k_per_split;
@@ -146,7 +208,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
         __syncthreads();
         buf ^= 1;
     }
-    store_tile(g, acc, m0, n0, wm, wn, lane);
+    if (wide_ok(g)) store_tile_wide(g, acc, m0, n0, wm, wn, w, lane, smem);
+    else store_tile(g, acc, m0, n0, wm, wn, lane);
 }
 
 // ---- the same product on the bf16 MFMA, each float32 operand split into bf16 hi + lo (RNE both times; x - hi is exact in f32)
@@ -228,8 +291,10 @@ __device__ __forceinline__ void xtile_store(uint4 (*Th)[BM], uint4 (*Tl)[BM], in
 }
 
 template <bool A_KMAJOR, bool B_KMAJOR, bool HALF>
-__global__ __launch_bounds__(256) void gemm_split_kernel(const GemmArgs g) {
-    __shared__ uint4 Ah[XK / 8][BM], Al[XK / 8][BM], Bh[XK / 8][BN], Bl[XK / 8][BN];
+__global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmArgs g) {
+    __shared__ uint4 smem[4][XK / 8][BM];                           // Ah | Al | Bh | Bl (BM == BN); reused by the epilogue
+    uint4 (*Ah)[BM] = smem[0], (*Al)[BM] = smem[1], (*Bh)[BM] = smem[2], (*Bl)[BM] = smem[3];
+    static_assert(sizeof(smem) >= 4 * 2048 * sizeof(float) && BM == BN, "the epilogue needs 8192 floats of LDS");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int kbeg = blockIdx.z * g.k_per_split;
@@ -284,7 +349,9 @@ __global__ __launch_bounds__(256) void gemm_split_kernel(const GemmArgs g) {
                 for (int j = 0; j < 2; ++j) acc[i][j] = mm(ah[i], bh[j], acc[i][j]);
         }
     }
-    store_tile(g, acc, m0, n0, wm, wn, lane);
+    __syncthreads();                                                   // every wave is done with the operand tiles
+    if (wide_ok(g)) store_tile_wide(g, acc, m0, n0, wm, wn, w, lane, reinterpret_cast<float*>(smem));
+    else store_tile(g, acc, m0, n0, wm, wn, lane);
 }
 
 // second pass of split-K: C (+)= sum over the splits, in split order
