@@ -508,8 +508,8 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ pts
 // ---- signed distance: the sign of the closest-point query by angle-weighted pseudonormals (Baerentzen & Aanaes 2005), what
 // igl.signed_distance does for a triangle mesh (reference utils/ray_utils.py:70, trainers/human_nerf_trainer.py:310, 326).
 // Per face (caller's id) 21 floats: unit face normal | pseudonormal of edge 0 (v0-v1), 1 (v1-v2), 2 (v2-v0) = sum of the unit
-// normals of the faces sharing it | angle-weighted pseudonormal of v0, v1, v2.  Built on the first query (three O(F^2) scans
-// in face order: deterministic, ~0.5 ms for SMPL), not by nm_mesh_create: the renderers never ask for a sign.
+// normals of the faces sharing it | angle-weighted pseudonormal of v0, v1, v2.  Built on the first query (seven small kernels,
+// sums in face order: deterministic), not by nm_mesh_create: the renderers never ask for a sign.
 constexpr int kPnFloats = 21;
 
 __global__ __launch_bounds__(256) void face_normal_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces, int F, float* __restrict__ fn) {
@@ -524,14 +524,63 @@ __global__ __launch_bounds__(256) void face_normal_kernel(const float* __restric
     fn[f * 3] = nx * inv; fn[f * 3 + 1] = ny * inv; fn[f * 3 + 2] = nz * inv;
 }
 
-__global__ __launch_bounds__(256) void vertex_normal_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces, int F, int V,
-                                                            const float* __restrict__ fn, float* __restrict__ vn) {
+// ---- angle-weighted vertex pseudonormals and edge pseudonormals (the sum of the normals of the faces on the edge) through a
+// vertex -> incident-faces table (CSR, each list in ascending face order, so every sum runs in face order: deterministic).
+// O(F); loops over all faces per vertex / per edge took 3 ms per SMPL mesh -- paid once per training iteration, because the
+// posed body changes with the pose parameters.
+__global__ __launch_bounds__(256) void corner_count_kernel(const int32_t* __restrict__ faces, int F, int V, int* __restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * F) return;
+    const int v = faces[i];
+    if (v >= 0 && v < V) atomicAdd(cnt + v, 1);
+}
+__global__ __launch_bounds__(1024) void adj_offsets_kernel(const int* __restrict__ cnt, int V, int* __restrict__ off) {   // one workgroup
+    __shared__ int part[1024];
+    const int t = threadIdx.x, per = (V + 1023) / 1024;
+    const int lo = t * per < V ? t * per : V, hi = lo + per < V ? lo + per : V;
+    int s = 0;
+    for (int v = lo; v < hi; ++v) s += cnt[v];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int k = 0; k < 1024; ++k) { const int c = part[k]; part[k] = run; run += c; }
+        off[V] = run;
+    }
+    __syncthreads();
+    int run = part[t];
+    for (int v = lo; v < hi; ++v) { off[v] = run; run += cnt[v]; }
+}
+__global__ __launch_bounds__(256) void corner_fill_kernel(const int32_t* __restrict__ faces, int F, int V, const int* __restrict__ off,
+                                                          int* __restrict__ cur, int* __restrict__ adj) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * F) return;
+    const int v = faces[i];
+    if (v >= 0 && v < V) adj[off[v] + atomicAdd(cur + v, 1)] = i / 3;
+}
+__global__ __launch_bounds__(256) void adj_sort_kernel(const int* __restrict__ off, int V, int* __restrict__ adj) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    const int lo = off[v], hi = off[v + 1];
+    for (int i = lo + 1; i < hi; ++i) {                              // insertion sort: a vertex has a handful of faces
+        const int x = adj[i];
+        int j = i - 1;
+        while (j >= lo && adj[j] > x) { adj[j + 1] = adj[j]; --j; }
+        adj[j + 1] = x;
+    }
+}
+__global__ __launch_bounds__(256) void vertex_normal_adj_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces, int V,
+                                                                const int* __restrict__ off, const int* __restrict__ adj,
+                                                                const float* __restrict__ fn, float* __restrict__ vn) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
     float s[3] = {0.f, 0.f, 0.f};
-    for (int f = 0; f < F; ++f) {                                    // wave-uniform face index: scalar loads
+    int last = -1;
+    for (int q = off[v]; q < off[v + 1]; ++q) {
+        const int f = adj[q];
+        if (f == last) continue;                                     // a degenerate face naming the vertex twice is one term, as above
+        last = f;
         const int i0 = faces[f * 3], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
-        if (i0 != v && i1 != v && i2 != v) continue;
         const int p1 = i0 == v ? i1 : (i1 == v ? i2 : i0), p2 = i0 == v ? i2 : (i1 == v ? i0 : i1);
         float e1[3], e2[3], l1 = 0.f, l2 = 0.f, d = 0.f;
 #pragma unroll
@@ -548,27 +597,31 @@ __global__ __launch_bounds__(256) void vertex_normal_kernel(const float* __restr
     }
     vn[v * 3] = s[0]; vn[v * 3 + 1] = s[1]; vn[v * 3 + 2] = s[2];
 }
-
-__global__ __launch_bounds__(256) void pseudonormal_pack_kernel(const int32_t* __restrict__ faces, int F, const float* __restrict__ fn,
-                                                                const float* __restrict__ vn, float* __restrict__ pn) {
+__global__ __launch_bounds__(256) void pseudonormal_pack_adj_kernel(const int32_t* __restrict__ faces, int F, int V, const int* __restrict__ off,
+                                                                    const int* __restrict__ adj, const float* __restrict__ fn,
+                                                                    const float* __restrict__ vn, float* __restrict__ pn) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;              // (face, edge)
     if (i >= 3 * F) return;
     const int f = i / 3, e = i - 3 * f;
     const int a = faces[f * 3 + e], b = faces[f * 3 + (e + 1) % 3];
     float s[3] = {0.f, 0.f, 0.f};
-    for (int g = 0; g < F; ++g) {
-        const int j0 = faces[g * 3], j1 = faces[g * 3 + 1], j2 = faces[g * 3 + 2];
-        const bool has_a = j0 == a || j1 == a || j2 == a, has_b = j0 == b || j1 == b || j2 == b;
-        if (has_a && has_b) {                                        // every face on this edge, this one included
+    int last = -1;
+    if (a >= 0 && a < V)
+        for (int q = off[a]; q < off[a + 1]; ++q) {                  // faces on corner a, ascending; those that also hold b are on the edge
+            const int g = adj[q];
+            if (g == last) continue;
+            last = g;
+            const int j0 = faces[g * 3], j1 = faces[g * 3 + 1], j2 = faces[g * 3 + 2];
+            if (j0 == b || j1 == b || j2 == b) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) s[k] += fn[g * 3 + k];
+                for (int k = 0; k < 3; ++k) s[k] += fn[g * 3 + k];
+            }
         }
-    }
     float* o = pn + (int64_t)f * kPnFloats;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         o[3 + 3 * e + k] = s[k];
-        o[12 + 3 * e + k] = vn[a * 3 + k];                           // corner e's vertex pseudonormal
+        o[12 + 3 * e + k] = vn[a * 3 + k];
         if (e == 0) o[k] = fn[f * 3 + k];
     }
 }
@@ -619,6 +672,7 @@ struct nm_mesh_s {
     int32_t* d_face;     // caller's face id of sorted triangle t
     Node* d_nodes;
     float* d_pn;         // pseudonormals [F][21], built by the first nm_signed_distance
+    void* d_pn_scratch;  // face / vertex normals and the vertex -> faces table of that build (freed with the handle: no sync on the way)
 };
 
 extern "C" {
@@ -631,6 +685,7 @@ int nm_mesh_destroy(nm_mesh_t m) {
     if (m->d_face) (void)hipFree(m->d_face);
     if (m->d_nodes) (void)hipFree(m->d_nodes);
     if (m->d_pn) (void)hipFree(m->d_pn);
+    if (m->d_pn_scratch) (void)hipFree(m->d_pn_scratch);
     delete m;
     return NM_OK;
 }
@@ -736,20 +791,35 @@ int nm_signed_distance(nm_mesh_t m, const float* pts, int64_t N, float* sdist, i
     NM_REQUIRE(pts && sdist && face && closest, "nm_signed_distance: null pointer");
     hipStream_t st = nm::as_stream(stream);
     if (!m->d_pn) {
-        float *fn = nullptr, *vn = nullptr;
-        int rc = nm::check_hip(hipMalloc(&m->d_pn, (size_t)m->F * kPnFloats * 4), "nm_signed_distance: hipMalloc(pseudonormals)");
-        if (!rc) rc = nm::check_hip(hipMalloc(&fn, (size_t)m->F * 12), "nm_signed_distance: hipMalloc(face normals)");
-        if (!rc) rc = nm::check_hip(hipMalloc(&vn, (size_t)m->V * 12), "nm_signed_distance: hipMalloc(vertex normals)");
+        const int F = m->F, V = m->V;
+        // scratch: fn [F,3] | vn [V,3] | cnt [V] | cur [V] | off [V+1] | adj [3F]
+        const size_t n_f = (size_t)F * 3 + (size_t)V * 3, n_i = (size_t)2 * V + (size_t)V + 1 + (size_t)3 * F;
+        int rc = nm::check_hip(hipMalloc(&m->d_pn, (size_t)F * kPnFloats * 4), "nm_signed_distance: hipMalloc(pseudonormals)");
+        if (!rc) rc = nm::check_hip(hipMalloc(&m->d_pn_scratch, (n_f + n_i) * 4), "nm_signed_distance: hipMalloc(pseudonormal scratch)");
         if (!rc) {
-            hipLaunchKernelGGL(face_normal_kernel, dim3((m->F + 255) / 256), dim3(256), 0, st, m->d_verts, m->d_faces, m->F, fn);
-            hipLaunchKernelGGL(vertex_normal_kernel, dim3((m->V + 255) / 256), dim3(256), 0, st, m->d_verts, m->d_faces, m->F, m->V, fn, vn);
-            hipLaunchKernelGGL(pseudonormal_pack_kernel, dim3((3 * m->F + 255) / 256), dim3(256), 0, st, m->d_faces, m->F, fn, vn, m->d_pn);
-            rc = nm::check_launch("pseudonormal kernels");
-            if (!rc) rc = nm::check_hip(hipStreamSynchronize(st), "nm_signed_distance: sync");      // fn / vn are freed below
+            float* fn = reinterpret_cast<float*>(m->d_pn_scratch);
+            float* vn = fn + (size_t)F * 3;
+            int* cnt = reinterpret_cast<int*>(vn + (size_t)V * 3);
+            int *cur = cnt + V, *off = cur + V, *adj = off + V + 1;
+            rc = nm::check_hip(hipMemsetAsync(cnt, 0, (size_t)2 * V * 4, st), "nm_signed_distance: memset");
+            if (!rc) {
+                const dim3 gc((3 * F + 255) / 256), gv((V + 255) / 256);
+                hipLaunchKernelGGL(face_normal_kernel, dim3((F + 255) / 256), dim3(256), 0, st, m->d_verts, m->d_faces, F, fn);
+                hipLaunchKernelGGL(corner_count_kernel, gc, dim3(256), 0, st, m->d_faces, F, V, cnt);
+                hipLaunchKernelGGL(adj_offsets_kernel, dim3(1), dim3(1024), 0, st, cnt, V, off);
+                hipLaunchKernelGGL(corner_fill_kernel, gc, dim3(256), 0, st, m->d_faces, F, V, off, cur, adj);
+                hipLaunchKernelGGL(adj_sort_kernel, gv, dim3(256), 0, st, off, V, adj);
+                hipLaunchKernelGGL(vertex_normal_adj_kernel, gv, dim3(256), 0, st, m->d_verts, m->d_faces, V, off, adj, fn, vn);
+                hipLaunchKernelGGL(pseudonormal_pack_adj_kernel, gc, dim3(256), 0, st, m->d_faces, F, V, off, adj, fn, vn, m->d_pn);
+                rc = nm::check_launch("pseudonormal kernels");
+            }
         }
-        if (fn) (void)hipFree(fn);
-        if (vn) (void)hipFree(vn);
-        if (rc) { if (m->d_pn) (void)hipFree(m->d_pn); m->d_pn = nullptr; return rc; }
+        if (rc) {
+            if (m->d_pn) (void)hipFree(m->d_pn);
+            if (m->d_pn_scratch) (void)hipFree(m->d_pn_scratch);
+            m->d_pn = nullptr; m->d_pn_scratch = nullptr;
+            return rc;
+        }
     }
     const bool small = m->n_nodes <= 65536 && m->F <= 65536 && !m->force_wide;
     const unsigned waves = (unsigned)((N + kChunk - 1) / kChunk);
