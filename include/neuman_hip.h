@@ -340,6 +340,9 @@ int nm_ssim_u8(const uint8_t* a, const uint8_t* b, int H, int W, int C, double* 
 #define NM_GEMM_BIAS 2
 #define NM_GEMM_RELU 4
 #define NM_GEMM_MASK 8
+#define NM_GEMM_COLSUM 16   /* also write the column sums of the stored output, per band of 64 rows, to workspace [ceil(M/64)][N]
+                              (deterministic; the bias gradient of the layer below is the sum of the bands: nm_colsum on them).  Not
+                              with a split-K product; needs the 16-byte aligned output layout (ldc % 4 == 0) */
 int64_t nm_gemm_workspace_floats(int M, int N, int K);
 int nm_gemm_f32(int a_kmajor, int b_kmajor, int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C,
                 int ldc, const float* bias, const float* mask, int ldmask, int flags, float* workspace,

@@ -26,6 +26,7 @@ struct GemmArgs {
     const float* A; const float* B; float* C;
     const float* bias; const float* mask;
     float* partial;                 // split-K: raw accumulators to partial[z][M][N] instead of C
+    float* colsum;                  // NM_GEMM_COLSUM: [ceil(M/64)][N] column sums of the stored output, one band per wave row-block
     int M, N, K, lda, ldb, ldc, ldmask, k_per_split, flags;
 };
 
@@ -116,6 +117,7 @@ __device__ __forceinline__ void store_tile_wide(const GemmArgs& g, const floatx1
     const int col = n0 + wn + c4;
     float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((g.flags & NM_GEMM_BIAS) && col < g.N) bias = *reinterpret_cast<const float4*>(g.bias + col);
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};                             // NM_GEMM_COLSUM: this lane's four columns over the rows it stores
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -153,8 +155,19 @@ __device__ __forceinline__ void store_tile_wide(const GemmArgs& g, const floatx1
                     x[e] = m[e] > 0.f ? x[e] : 0.f;
                 }
                 *reinterpret_cast<float4*>(g.C + (int64_t)row * g.ldc + col) = make_float4(x[0], x[1], x[2], x[3]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cs[e] += x[e];             // rows ascending within the lane: 16 rows of the wave's 64
             }
         }
+    }
+    if (g.colsum) {                                                  // the four lanes sharing these columns (rows rsub = 0..3 mod 4), then one store
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cs[e] += __shfl_xor(cs[e], 16, 64);
+            cs[e] += __shfl_xor(cs[e], 32, 64);
+        }
+        if (lane < 16 && col < g.N && m0 + wm < g.M)
+            *reinterpret_cast<float4*>(g.colsum + (int64_t)((m0 + wm) >> 6) * g.N + col) = make_float4(cs[0], cs[1], cs[2], cs[3]);
     }
 }
 
@@ -534,9 +547,18 @@ static int gemm_dispatch(int mode, int a_kmajor, int b_kmajor, int M, int N, int
     NM_REQUIRE(!(flags & NM_GEMM_MASK) || (mask && ldmask >= N), "nm_gemm_f32: NM_GEMM_MASK without a mask array");
     hipStream_t st = nm::as_stream(stream);
     GemmArgs g;
-    g.A = A; g.B = B; g.C = C; g.bias = bias; g.mask = mask; g.partial = nullptr;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.mask = mask; g.partial = nullptr; g.colsum = nullptr;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldmask = ldmask; g.flags = flags;
     int splits = pick_splits(M, N, K);
+    if (flags & NM_GEMM_COLSUM) {
+        NM_REQUIRE(splits == 1, "nm_gemm: NM_GEMM_COLSUM on a split-K product (M=%d N=%d K=%d)", M, N, K);
+        NM_REQUIRE(((uintptr_t)C & 15) == 0 && (ldc & 3) == 0 && (!(flags & NM_GEMM_MASK) || ((((uintptr_t)mask & 15) == 0) && (ldmask & 3) == 0)) &&
+                       (!(flags & NM_GEMM_BIAS) || ((uintptr_t)bias & 15) == 0),
+                   "nm_gemm: NM_GEMM_COLSUM needs 16-byte aligned C / mask / bias rows");
+        NM_REQUIRE(workspace && workspace_floats >= (int64_t)((M + 63) / 64) * N, "nm_gemm: NM_GEMM_COLSUM needs %lld floats of workspace",
+                   (long long)((M + 63) / 64) * N);
+        g.colsum = workspace;
+    }
     if (splits > 1) {
         NM_REQUIRE(!(flags & ~NM_GEMM_ACCUMULATE), "nm_gemm_f32: a split-K product (M=%d N=%d K=%d) takes no epilogue but ACCUMULATE", M, N, K);
         NM_REQUIRE(workspace && workspace_floats >= (int64_t)splits * M * N, "nm_gemm_f32: needs %lld floats of workspace (nm_gemm_workspace_floats)",

@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 
-ACC, BIAS, RELU, MASK = 1, 2, 4, 8                    # NM_GEMM_* (include/neuman_hip.h)
+ACC, BIAS, RELU, MASK, COLSUM = 1, 2, 4, 8, 16        # NM_GEMM_* (include/neuman_hip.h)
 PE_KINDS = {'posenc': 0, 'rotate': 1}                 # NM_PE_POSENC / NM_PE_ROTATE
 # arithmetic of the matrix products:
 #   'f32'     f32 MFMA everywhere: gradients within 1e-6 of the reference's float32 autograd (NEUMAN_TRAIN_GEMM=f32)
@@ -186,6 +186,18 @@ class _MLP(torch.autograd.Function):
                                             _lib.stream_ptr()), "nm_colsum")
             return out
 
+        bands = (n4 + 63) // 64
+        cs_buf = torch.empty((bands, width), device=dev, dtype=torch.float32)      # per-64-row column sums out of a product's epilogue
+
+        def band_sum(m):                                                         # -> db [m] = the bands summed (nm_colsum on [bands, m])
+            out = torch.empty(m, device=dev, dtype=torch.float32)
+            need = int(_lib.lib().nm_colsum_workspace_floats(bands, m))
+            if need > ws[0].numel():
+                ws[0] = torch.empty(need, device=dev, dtype=torch.float32)
+            _lib.check(_lib.lib().nm_colsum(_lib.dev_ptr(cs_buf), bands, m, m, _lib.dev_ptr(out), _lib.dev_ptr(ws[0]), ws[0].numel(),
+                                            _lib.stream_ptr()), "nm_colsum")
+            return out
+
         h7 = H[-1]
         dX0 = dD0 = None
         dz = torch.empty((n4, width), device=dev, dtype=torch.float32)
@@ -194,27 +206,28 @@ class _MLP(torch.autograd.Function):
             gWr4, gb4 = wgrad(d_raw, 4, hv, half), bgrad(d_raw, 4)
             g['rgb_w'], g['rgb_b'], g['alpha_b'] = gWr4[:3], gb4[:3], gb4[3:4]
             d_hv = torch.empty((n4, half), device=dev, dtype=torch.float32)
-            _gemm(0, 1, n4, half, 4, d_raw, 4, pk.Wr4, half, d_hv, half, mask=hv, ldmask=half, flags=MASK)
+            _gemm(0, 1, n4, half, 4, d_raw, 4, pk.Wr4, half, d_hv, half, mask=hv, ldmask=half, flags=MASK | COLSUM, ws=cs_buf)
+            g['views_b'] = band_sum(half)                                       # column sums of d_hv, out of that product's epilogue
             g['views_w'] = torch.cat([wgrad(d_hv, half, feat, width), wgrad(d_hv, half, D0, pk.kd)[:, :pk.n_dir]], 1)
-            g['views_b'] = bgrad(d_hv, half)
             if want_in:                                                          # gradient of the encoded view direction
                 dD0 = torch.empty((n4, pk.kd), device=dev, dtype=torch.float32)
                 _gemm(0, 1, n4, pk.kd, half, d_hv, half, pk.Wv[1], pk.kd, dD0, pk.kd)
             d_feat = torch.empty((n4, width), device=dev, dtype=torch.float32)
-            _gemm(0, 1, n4, width, half, d_hv, half, pk.Wv[0], width, d_feat, width)
-            g['feature_w'], g['feature_b'] = wgrad(d_feat, width, h7, width), bgrad(d_feat, width)
+            _gemm(0, 1, n4, width, half, d_hv, half, pk.Wv[0], width, d_feat, width, flags=COLSUM, ws=cs_buf)
+            g['feature_b'] = band_sum(width)
+            g['feature_w'] = wgrad(d_feat, width, h7, width)
             g['alpha_w'] = wgrad(d_raw, 4, h7, width)[3:4]
             _gemm(0, 1, n4, width, width, d_feat, width, pk.Wf, width, dz, width)
-            _gemm(0, 1, n4, width, 4, d_raw, 4, pk.Wa4, width, dz, width, mask=h7, ldmask=width, flags=ACC | MASK)
+            _gemm(0, 1, n4, width, 4, d_raw, 4, pk.Wa4, width, dz, width, mask=h7, ldmask=width, flags=ACC | MASK | COLSUM, ws=cs_buf)
             head = [g['views_w'].contiguous(), g['views_b'].contiguous(), g['feature_w'], g['feature_b'].contiguous(),
                     g['alpha_w'].contiguous(), g['alpha_b'].contiguous(), g['rgb_w'].contiguous(), g['rgb_b'].contiguous()]
         else:
             head = [wgrad(d_raw, 4, h7, width)[:pk.n_out].contiguous(), bgrad(d_raw, 4)[:pk.n_out].contiguous()]
-            _gemm(0, 1, n4, width, 4, d_raw, 4, pk.Wo4, width, dz, width, mask=h7, ldmask=width, flags=MASK)
+            _gemm(0, 1, n4, width, 4, d_raw, 4, pk.Wo4, width, dz, width, mask=h7, ldmask=width, flags=MASK | COLSUM, ws=cs_buf)
         gw, gb = [None] * len(pk.W), [None] * len(pk.W)
         for i in range(len(pk.W) - 1, -1, -1):
             Ws = pk.W[i]
-            gb[i] = bgrad(dz, width)
+            gb[i] = band_sum(width)                                              # of dz: left in cs_buf by the product that made it
             if want_in and (i == 0 or len(Ws) == 2):                             # gradient of the encoded position: both layers it feeds
                 first = dX0 is None
                 if first:
@@ -231,7 +244,7 @@ class _MLP(torch.autograd.Function):
                 gw[i] = wgrad(dz, width, prev, width)
                 Wb = Ws[0]
             nz = torch.empty((n4, width), device=dev, dtype=torch.float32)
-            _gemm(0, 1, n4, width, width, dz, width, Wb, width, nz, width, mask=prev, ldmask=width, flags=MASK)
+            _gemm(0, 1, n4, width, width, dz, width, Wb, width, nz, width, mask=prev, ldmask=width, flags=MASK | COLSUM, ws=cs_buf)
             dz = nz
         grads = []
         for i in range(len(pk.W)):
