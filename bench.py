@@ -193,6 +193,52 @@ def pmc_traffic_per_launch(kernel, launch):
         return None
 
 
+def train_iteration(dev, origins, dirs, cap, rays=2048, iters=5):
+    """median wall time of one training iteration: rays_per_batch random rays of the frame, 128 coarse + 256 fine samples through both
+    networks forward and backward, photometric loss, Adam step (tools/train_step_bench.py is the stand-alone form)"""
+    import torch.nn.functional as F
+    from neuman_hip import ray_utils, render_utils, synthetic, train
+    coarse, fine = synthetic.make_joiner(0).to(dev).train(), synthetic.make_joiner(1).to(dev).train()
+    optim = torch.optim.Adam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4)
+    g = torch.Generator(device='cpu').manual_seed(0)
+    color = torch.rand((rays, 3), generator=g).to(dev)
+    near = torch.full((rays,), float(cap.near['bkg']), device=dev)
+    far = torch.full((rays,), float(cap.far['bkg']), device=dev)
+
+    def step():
+        idx = torch.randint(0, origins.shape[0], (rays,), generator=g).to(dev)
+        o, d = origins[idx].contiguous(), dirs[idx].contiguous()
+        optim.zero_grad()
+        pts, _, z = ray_utils.sample_z(o, d, near, far, S, want_points=True)
+        out = coarse(pts, d[:, None, :].expand(pts.shape))
+        rgb, _, _, w, _ = render_utils.raw2outputs(out, z, d, white_bkg=True)
+        loss = F.mse_loss(rgb, color)
+        with torch.no_grad():
+            zf = ray_utils.importance_z(z, w.detach(), NI)
+        ptsf = o[:, None, :] + d[:, None, :] * zf[..., None]
+        outf = fine(ptsf, d[:, None, :].expand(ptsf.shape))
+        loss = loss + F.mse_loss(render_utils.raw2outputs(outf, zf, d, white_bkg=True)[0], color)
+        loss.backward()
+        optim.step()
+        return loss
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        loss = step()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    ms = sorted(ts)[len(ts) // 2] * 1e3
+    evals = rays * (S + S + NI)
+    return {"rays_per_batch": rays, "samples": [S, S + NI], "ms_per_iteration": ms, "iterations_per_s": 1e3 / ms,
+            "mlp_tflops_fwd_bwd": evals * FLOP_PER_EVAL * 3 / ms / 1e9, "gemm_precision": train.GEMM_PRECISION,
+            "loss": float(loss.detach()), "what": "forward with saved activations, backward-data and backward-weights products of both 8x256 "
+            "networks (csrc/train.hip), differentiable compositing, Adam; parameter gradients 6e-6 from the reference's autograd "
+            "(tests/test_hip_train.py)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -377,6 +423,9 @@ def main():
                 "eps": 1e-4, "rays_per_s_every_sample": total / res[0.0][1], "rays_per_s_terminated": total / res[1e-4][1],
                 "speedup": res[0.0][1] / res[1e-4][1], "fine_evaluations_done": st['evaluated'] / st['total'] if st else None,
                 "rgb_linf_vs_every_sample": float((res[0.0][0] - res[1e-4][0]).abs().max())}}
+            # one iteration of the background trainer (trainers/vanilla_nerf_trainer.py:45-96 + backward + Adam) at the
+            # reference's batch, on the training slice's default arithmetic.  Never `value`.
+            workloads["background_trainer_iteration"] = train_iteration(dev, origins, dirs, cap)
         line = {
             "metric": "rays_per_sec (800x800 frame, 128 samples/ray coarse + 128 importance, NeuMan background NeRF)",
             "value": total * args.steps / dt, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
