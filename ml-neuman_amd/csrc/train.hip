@@ -372,8 +372,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             int accumulate) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)M * N) return;
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += partial[(int64_t)z * M * N + i];
+    // eight independent partial sums (splits z = k mod 8), combined in a fixed order: deterministic, and eight loads in flight
+    // instead of a chain of `splits` dependent adds behind one load each
+    const int64_t MN = (int64_t)M * N;
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int z = 0;
+    for (; z + 8 <= splits; z += 8)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k] += partial[(int64_t)(z + k) * MN + i];
+    for (int k = 0; z < splits; ++z, ++k) p[k] += partial[(int64_t)z * MN + i];
+    const float s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
     float* c = C + (i / N) * ldc + (i % N);
     *c = accumulate ? *c + s : s;
 }
