@@ -532,6 +532,102 @@ __global__ __launch_bounds__(64) void composite_backward_kernel(const float* __r
     }
 }
 
+// The same adjoint with one WAVE per ray (a training batch is a few thousand rays: one lane per ray leaves the GPU idle).  Lane l
+// owns the consecutive samples [l c, l c + c), c = ceil(S / 64) <= kCbMax: the transmittance in front of its run is an exclusive
+// product scan across the lanes, the sum behind its run an exclusive suffix sum, both in f64 through shuffles; inside the run the
+// two recurrences of the serial kernel.  Same formulas, the products / sums associated differently (f64: 1e-16).
+constexpr int kCbMax = 16;                                           // S <= 1024 here; longer rays take the serial kernel
+__device__ __forceinline__ double shfl_up_f64(double v, int d) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __shfl_up((int)(b & 0xffffffffll), d, 64), hi = __shfl_up((int)(b >> 32), d, 64);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double shfl_down_f64(double v, int d) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __shfl_down((int)(b & 0xffffffffll), d, 64), hi = __shfl_down((int)(b >> 32), d, 64);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__global__ __launch_bounds__(256) void composite_backward_wave_kernel(const float* __restrict__ raw, const float* __restrict__ z,
+                                                                     const float* __restrict__ rays_d, int64_t R, int S, int white_bkg,
+                                                                     const float* __restrict__ g_rgb, const float* __restrict__ g_acc,
+                                                                     const float* __restrict__ g_depth, const float* __restrict__ g_w,
+                                                                     float* __restrict__ d_raw) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= R) return;
+    const float dn = sqrtf(rays_d[r * 3] * rays_d[r * 3] + rays_d[r * 3 + 1] * rays_d[r * 3 + 1] + rays_d[r * 3 + 2] * rays_d[r * 3 + 2]);
+    const float gr0 = g_rgb ? g_rgb[r * 3] : 0.f, gr1 = g_rgb ? g_rgb[r * 3 + 1] : 0.f, gr2 = g_rgb ? g_rgb[r * 3 + 2] : 0.f;
+    const double ga = (double)(g_acc ? g_acc[r] : 0.f) - (white_bkg ? (double)gr0 + (double)gr1 + (double)gr2 : 0.0);
+    const double gd = g_depth ? (double)g_depth[r] : 0.0;
+    const float* rw = raw + r * S * 4;
+    const float* zz = z + r * S;
+    float* dr = d_raw + r * S * 4;
+    const int c = (S + 63) / 64, i0 = lane * c, i1 = i0 + c < S ? i0 + c : S;
+    // this lane's run: u_i and the run's product
+    float4 rec[kCbMax];
+    float dist[kCbMax], e[kCbMax];
+    double P = 1.0;
+#pragma unroll
+    for (int k = 0; k < kCbMax; ++k) {
+        const int i = i0 + k;
+        if (k < c && i < i1) {
+            rec[k] = reinterpret_cast<const float4*>(rw)[i];
+            dist[k] = (i + 1 < S ? zz[i + 1] - zz[i] : 1e10f) * dn;
+            e[k] = expf(-fmaxf(rec[k].w, 0.f) * dist[k]);
+            P *= (double)(1.f - (1.f - e[k]) + 1e-10f);
+        }
+    }
+    // exclusive product scan over the lanes: T in front of this lane's run
+    double incl = P;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double t = shfl_up_f64(incl, o);
+        if (lane >= o) incl *= t;
+    }
+    double T = shfl_up_f64(incl, 1);
+    if (lane == 0) T = 1.0;
+    // forward inside the run: T_i, G_i w_i; the run's sum
+    double Ti[kCbMax], Gi[kCbMax], Q = 0.0;
+#pragma unroll
+    for (int k = 0; k < kCbMax; ++k) {
+        const int i = i0 + k;
+        if (k < c && i < i1) {
+            const float a = 1.f - e[k];
+            Ti[k] = T;
+            float cs[3] = {1.f / (1.f + expf(-rec[k].x)), 1.f / (1.f + expf(-rec[k].y)), 1.f / (1.f + expf(-rec[k].z))};
+            Gi[k] = (double)gr0 * cs[0] + (double)gr1 * cs[1] + (double)gr2 * cs[2] + ga + gd * (double)zz[i] + (g_w ? (double)g_w[r * S + i] : 0.0);
+            Q += Gi[k] * ((double)a * T);
+            T *= (double)(1.f - a + 1e-10f);
+        }
+    }
+    // exclusive suffix sum over the lanes: sum of G w behind this lane's run
+    double inclS = Q;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double t = shfl_down_f64(inclS, o);
+        if (lane + o < 64) inclS += t;
+    }
+    double suffix = shfl_down_f64(inclS, 1);
+    if (lane == 63) suffix = 0.0;
+    // backward inside the run
+#pragma unroll
+    for (int k = kCbMax - 1; k >= 0; --k) {
+        const int i = i0 + k;
+        if (k < c && i < i1) {
+            const float a = 1.f - e[k];
+            const double u = (double)(1.f - a + 1e-10f);
+            const double wgt = (double)a * Ti[k];
+            const double da = Gi[k] * Ti[k] - suffix / u;
+            suffix += Gi[k] * wgt;
+            float cs[3] = {1.f / (1.f + expf(-rec[k].x)), 1.f / (1.f + expf(-rec[k].y)), 1.f / (1.f + expf(-rec[k].z))};
+            reinterpret_cast<float4*>(dr)[i] = make_float4((float)(wgt * (double)gr0 * (double)(cs[0] * (1.f - cs[0]))),
+                                                         (float)(wgt * (double)gr1 * (double)(cs[1] * (1.f - cs[1]))),
+                                                         (float)(wgt * (double)gr2 * (double)(cs[2] * (1.f - cs[2]))),
+                                                         rec[k].w > 0.f ? (float)(da * (double)dist[k] * (double)e[k]) : 0.f);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -662,6 +758,11 @@ int nm_composite_backward(const float* raw, const float* z_vals, const float* ra
     NM_REQUIRE(R >= 0 && S >= 1, "nm_composite_backward: bad sizes R=%lld S=%d", (long long)R, S);
     if (R == 0) return NM_OK;
     NM_REQUIRE(raw && z_vals && rays_d && d_raw, "nm_composite_backward: null pointer");
+    if (S <= 64 * kCbMax && (((uintptr_t)raw | (uintptr_t)d_raw) & 15) == 0) {
+        hipLaunchKernelGGL(composite_backward_wave_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, nm::as_stream(stream), raw, z_vals, rays_d, R, S,
+                           white_bkg, g_rgb, g_acc, g_depth, g_weights, d_raw);
+        return nm::check_launch("composite_backward_wave_kernel");
+    }
     hipLaunchKernelGGL(composite_backward_kernel, dim3((unsigned)((R + 63) / 64)), dim3(64), 0, nm::as_stream(stream), raw, z_vals, rays_d, R, S,
                        white_bkg, g_rgb, g_acc, g_depth, g_weights, d_raw);
     return nm::check_launch("composite_backward_kernel");
