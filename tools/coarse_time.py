@@ -1,3 +1,5 @@
+"""Time the coarse (sampling) launch of the C2 frame -- 81.92 M evaluations, density head only, split-fp16 x3 -- a few times and print
+ms / TFLOP/s.  NEUMAN_HIP_LIB selects an experimental build of the library (tools/build_variant.py)."""
 import os, sys
 sys.path.insert(0, os.path.join(os.getcwd(), "ml-neuman_amd"))
 import torch
