@@ -58,3 +58,27 @@ def test_ssim_known_properties():
     c1 = (0.01 * 255) ** 2
     s = OF.ssim_uint8(np.full((9, 9, 1), 100, np.uint8), np.full((9, 9, 1), 140, np.uint8))
     assert abs(s - (2 * u * v + c1) / (u * u + v * v + c1)) < 1e-12
+
+
+def test_ssim_is_the_windowed_definition():
+    """The oracle's SSIM (scipy's uniform_filter) against the definition written out window by window (Wang et al. 2004 with the
+    sample covariance and the 7 x 7 uniform window scikit-image defaults to): every interior pixel's own 49-pixel window, no filter
+    call, no boundary convention -- pins the filter's alignment and the normalisations on the cropped region the score is taken over."""
+    from oracle import frame as OF
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, (15, 17, 2), dtype=np.uint8)
+    b = (a.astype(np.int32) + rng.integers(-30, 31, a.shape)).clip(0, 255).astype(np.uint8)
+    c1, c2 = (0.01 * 255.0) ** 2, (0.03 * 255.0) ** 2
+    per_channel = []
+    for ch in range(a.shape[2]):
+        X, Y = a[..., ch].astype(np.float64), b[..., ch].astype(np.float64)
+        vals = []
+        for y in range(3, a.shape[0] - 3):
+            for x in range(3, a.shape[1] - 3):
+                wx, wy = X[y - 3:y + 4, x - 3:x + 4].ravel(), Y[y - 3:y + 4, x - 3:x + 4].ravel()
+                ux, uy = wx.mean(), wy.mean()
+                vx, vy = ((wx - ux) ** 2).sum() / 48.0, ((wy - uy) ** 2).sum() / 48.0
+                vxy = ((wx - ux) * (wy - uy)).sum() / 48.0
+                vals.append(((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux * ux + uy * uy + c1) * (vx + vy + c2)))
+        per_channel.append(np.mean(vals))
+    assert abs(OF.ssim_uint8(a, b) - float(np.mean(per_channel))) < 1e-12
