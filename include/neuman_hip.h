@@ -154,6 +154,16 @@ int nm_mlp_destroy(nm_mlp_t mlp);
  * sigma_scale carries `out[..., -1] *= interval_comp` (render_utils.py:229); pass 1.0 otherwise. */
 int nm_mlp_forward(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision,
                    float sigma_scale, float* out, nm_stream_t stream);
+/* The forward of a TRAINING step (reference trainers/vanilla_nerf_trainer.py:66, 79: `self.coarse_net(pts, dirs)` with grad):
+ * nm_mlp_forward in split-fp16 x3 (float32 class) that also keeps what the backward pass reads -- save_h [9][n][256] = the outputs of
+ * pts_linears 0..7 after their ReLU, then feature_linear's (models/vanilla.py:125-138); save_hv [n][128] = views_linears[0]'s after its
+ * ReLU (:140-142) -- written from the kernel's epilogues, so a tile's activations never return from HBM between layers.
+ * nm_mlp_refresh_f16 rewrites the handle's split-fp16 weight image from DEVICE-resident parameters (24 device pointers, reference
+ * state_dict order) in three small kernels: what nm_mlp_create packs on the host, bit for bit, for weights an optimiser changes every
+ * iteration.  Not for the plain-head net. */
+int nm_mlp_refresh_f16(nm_mlp_t mlp, const float* const* dev_params, nm_stream_t stream);
+int nm_mlp_forward_save(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, float* save_h, float* save_hv,
+                        float* out, nm_stream_t stream);
 /* Same with ray_to_samples' point construction fused: sample (r,s) is at origin[r] + direction[r]*z[r,s]
  * with view direction direction[r] (ray_utils.py:131-132); out [R,S,4]. */
 int nm_mlp_forward_rays(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals,

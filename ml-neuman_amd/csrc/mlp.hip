@@ -82,6 +82,8 @@ struct MlpArgs {
                              // 1: only the density head is wanted (a pass whose colours the renderer discards): skip the
                              //    feature / views / rgb layers and write (0, 0, 0, sigma)
     PeSpec pos, dir;
+    float* save_h;           // SAVE instantiation: [9][n][256] f32 outputs of stages 0..7 (after ReLU) and 8 (feature, linear)
+    float* save_hv;          //                     [n][128] f32 output of stage 9 (after ReLU)
 };
 
 // ---- positional encoding feature p of a 3-vector (reference models/vanilla.py:60-92) ---------------
@@ -471,7 +473,7 @@ __device__ __forceinline__ MlpArgs resolve_args(MlpArgs a) {
     return a;
 }
 
-template <int PREC, bool PROF>
+template <int PREC, bool PROF, bool SAVE = false>
 __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_in) {
     const MlpArgs a = resolve_args(a_in);
     unsigned long long pr[6] = {0, 0, 0, 0, 0, 0};
@@ -493,6 +495,18 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, s = lane & 31;
+    // SAVE: a block's accumulators as float32 activations, natural feature order: lane (g, s) holds features 32 blk + 8 q + 4 g + j of
+    // sample row0 + 32 mb + s -- one 16-byte store per (mb, q); the two lane halves of a sample write adjacent 16 bytes
+    auto save_block = [&](float* dst, int ld, const f32x16& acc, int blk, int64_t row, float scale, bool relu) {
+        if (row >= a.n) return;
+        float* o = dst + row * ld + 32 * blk + 4 * g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v = make_float4(acc[4 * q] * scale, acc[4 * q + 1] * scale, acc[4 * q + 2] * scale, acc[4 * q + 3] * scale);
+            if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+            *reinterpret_cast<float4*>(o + 8 * q) = v;
+        }
+    };
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint4*>(a.wpack), 0, (int)(nm::kWeightBytes + nm::kWeightPadBytes), 0x00020000);
     const int voff = lane * 16;                                   // the only per-lane part of a weight address
@@ -536,6 +550,10 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
                                sh.steps - sh.pe_steps);
             bias_prefetch(B, a.bias + nm::stage_b_off(st + 1) + 32 * w, g);     // next stage (st + 1 <= 8), block w
             NM_TICK(1)
+            if (SAVE) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) save_block(a.save_h + (int64_t)st * a.n * 256, 256, acc[mb], w, base + 32 * mb + s, acc2out(st), true);
+            }
             ActRegs<4> ar;
             convert_act<4, true, PREC>(acc, ar, acc2act(st));
             NM_TICK(3)
@@ -595,6 +613,10 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
             }
             bias_prefetch(B, a.bias + nm::stage_b_off(9) + 32 * (w & 3), g);
             NM_TICK(1)
+            if (SAVE) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) save_block(a.save_h + (int64_t)8 * a.n * 256, 256, acc[mb], w, base + 32 * mb + s, acc2out(8), false);
+            }
             ActRegs<4> ar;
             convert_act<4, false, PREC>(acc, ar, acc2act(8));
             NM_TICK(3)
@@ -625,6 +647,10 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
                            lds + P_BASE + g * kChunkU4 + row0 + s, sh.pe_steps);
             bias_prefetch(B, w < 4 ? a.bias + nm::stage_b_off(10) : a.bias + nm::stage_b_off(0) + 32 * w, g);
             NM_TICK(1)
+            if (SAVE) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) save_block(a.save_hv, 128, vacc[mb], nb, base + row0 + 32 * mb + s, acc2out(9), true);
+            }
             ActRegs<2> ar;
             convert_act<2, true, PREC>(vacc, ar, acc2act(9));
             NM_TICK(3)
@@ -1237,6 +1263,7 @@ int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, con
     a.pts = pts; a.dirs = dirs; a.origin = origin; a.direction = direction; a.z = z;
     a.out = out; a.dbg = dbg; a.prof = reinterpret_cast<unsigned long long*>(prof); a.n = n; a.S = S; a.in_mode = in_mode; a.stop_stage = stop_stage; a.sigma_scale = sigma_scale;
     a.sigma_only = L.plain_head ? 2 : ((sigma_only && precision != NM_PREC_I8X3) ? 1 : 0);   // (the i8x3 kernel always evaluates the colour head)
+    a.save_h = L.save_h; a.save_hv = L.save_hv;
     a.pos = PeSpec{L.pe_kind, L.pos_nfreq, L.pos_octaves};
     a.dir = PeSpec{L.pe_kind, L.dir_nfreq, L.dir_octaves};
     const int64_t ntiles = (n + kTileM - 1) / kTileM;
@@ -1254,6 +1281,10 @@ int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, con
         if (prof) hipLaunchKernelGGL(nerf_mlp_i8w_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, a8);
         else hipLaunchKernelGGL(nerf_mlp_i8w_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, a8);
         return check_launch("nerf_mlp_i8w_kernel");
+    }
+    if (L.save_h) {                                               // the training forward: split fp16, the full head, activations kept
+        hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_FP16X3, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+        return check_launch("nerf_mlp_kernel (save)");
     }
     if (prof && precision == NM_PREC_FP16X3)
         hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_FP16X3, true>), dim3(grid), dim3(kThreads), 0, stream, a);

@@ -101,7 +101,7 @@ static int validate_desc(const nm_mlp_desc* d) {
 }
 
 // value of the weight that multiplies k-slot (chunk cc of the stage's chunk sequence, element e) for output feature n
-static float stage_weight(const nm_mlp_desc* d, const float* const* P, int st, int n, int cc, int e) {
+static __host__ __device__ float stage_weight(const nm_mlp_desc* d, const float* const* P, int st, int n, int cc, int e) {
     const int kpe = 3 + 6 * d->pos_n_freqs, kdpe = 3 + 6 * d->dir_n_freqs;
     switch (st) {
         case 0: {
@@ -194,6 +194,79 @@ static void pack_image(const nm_mlp_desc* d, const float* const* P, uint8_t* img
             bias[kBiasFloats + kStages + st] = 1.f / (wscale[st] * 32.f);
         }
     }
+}
+
+// ---- the NM_PREC_FP16X3 image rebuilt ON THE DEVICE from device-resident parameters: what pack_image(..., f16 = true) writes, for
+// a training loop whose weights change every iteration (a host repack would cost a 2.4 MB download, a CPU pass and an upload per
+// network and step).  Same scale rule, same rounding (RNE to fp16 twice), same layout: the forward through a refreshed handle is
+// bit-identical to the forward through a handle created from the same values (tests/test_hip_train.py).
+struct DevParams {
+    const float* p[24];
+};
+__global__ __launch_bounds__(256) void f16_stage_scale_kernel(nm_mlp_desc d, DevParams P, float* __restrict__ wscale) {
+    const int st = blockIdx.x;
+    const StageShape sh = stage_shape(st);
+    const int per_row = 2 * sh.steps * 8, total = sh.nblk * 32 * per_row;
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int n = i / per_row, r = i - n * per_row;
+        mx = fmaxf(mx, fabsf(stage_weight(&d, P.p, st, n, r >> 3, r & 7)));
+    }
+    __shared__ float part[256];
+    part[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) part[threadIdx.x] = fmaxf(part[threadIdx.x], part[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int k = 8;
+        while (k > -40 && part[0] * ldexpf(1.f, k) > 32000.f) --k;
+        wscale[st] = ldexpf(1.f, k);
+    }
+}
+__global__ __launch_bounds__(256) void f16_pack_kernel(nm_mlp_desc d, DevParams P, const float* __restrict__ wscale, uint8_t* __restrict__ img) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;                   // (k-step of the image, lane)
+    const int step = gid >> 6, lane = gid & 63;
+    if (step >= (int)(kWeightBytes / kStepBytes)) return;
+    int st = 0, first = 0;
+    for (; st < kStages; ++st) {
+        const int nsteps = stage_shape(st).nblk * stage_shape(st).steps;
+        if (step < first + nsteps) break;
+        first += nsteps;
+    }
+    const int steps = stage_shape(st).steps, nb = (step - first) / steps, t = (step - first) - nb * steps;
+    const float sc = wscale[st];
+    unsigned short h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float ws = stage_weight(&d, P.p, st, 32 * nb + (lane & 31), 2 * t + (lane >> 5), j) * sc;
+        const _Float16 hb = (_Float16)ws;
+        const _Float16 lb = (_Float16)(ws - (float)hb);
+        h[j] = __builtin_bit_cast(unsigned short, hb);
+        l[j] = __builtin_bit_cast(unsigned short, lb);
+    }
+    uint4* hi = reinterpret_cast<uint4*>(img + (int64_t)step * kStepBytes) + lane;
+    *hi = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+    hi[64] = make_uint4(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16), l[4] | ((unsigned)l[5] << 16), l[6] | ((unsigned)l[7] << 16));
+}
+__global__ __launch_bounds__(256) void f16_bias_kernel(DevParams P, const float* __restrict__ wscale, float* __restrict__ bias) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= kBiasFloats + kF16TabFloats) return;
+    if (i >= kBiasFloats) {                                           // [2^-k (11)] [2^-(k + 5) (11)] [2 spare]
+        const int q = i - kBiasFloats;
+        bias[i] = q < kStages ? 1.f / wscale[q] : (q < 2 * kStages ? 1.f / (wscale[q - kStages] * 32.f) : 0.f);
+        return;
+    }
+    int st = 0;
+    while (st + 1 < kStages && i >= stage_b_off(st + 1)) ++st;
+    const int r = i - stage_b_off(st);
+    float v = 0.f;
+    if (st <= 7) v = P.p[P_PTS_W + 2 * st + 1][r];
+    else if (st == 8) v = r < 256 ? P.p[P_FEAT_B][r] : (r == 256 ? P.p[P_ALPHA_B][0] : 0.f);
+    else if (st == 9) v = r < 128 ? P.p[P_VIEWS_B][r] : 0.f;
+    else v = r < 3 ? P.p[P_RGB_B][r] : 0.f;
+    bias[i] = v * wscale[st] * 32.f;
 }
 
 // ---- NM_PREC_I8X3 image: [fragments (i8 limb steps, then bf16 PE steps) | pad | units | biases | kappa] ----------------
@@ -335,6 +408,7 @@ struct nm_mlp_s {
     uint8_t* d_stream8;    // NM_PREC_I8X3: the image's fragments as per-wave streams (nerf_mlp_i8w_kernel)
     float* d_petab;        // 192 floats
     float* d_ref;          // transposed f32 weights | natural biases (NM_PREC_FP32 path)
+    float* d_wscale16;     // nm_mlp_refresh_f16: the per-stage weight scales of the fp16 image (device scratch)
     int ref_off[12], ref_boff[12];
     int pos_octaves, dir_octaves;
 };
@@ -440,7 +514,7 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     m->pos_octaves = octaves(tab, desc->pos_n_freqs);
     m->dir_octaves = octaves(tab + 96, desc->dir_n_freqs);
 
-    m->d_image = nullptr; m->d_image16 = nullptr; m->d_consts8 = nullptr; m->d_stream8 = nullptr; m->d_petab = nullptr; m->d_ref = nullptr;
+    m->d_image = nullptr; m->d_image16 = nullptr; m->d_consts8 = nullptr; m->d_stream8 = nullptr; m->d_petab = nullptr; m->d_ref = nullptr; m->d_wscale16 = nullptr;
     int rc = nm::check_hip(hipMalloc(&m->d_image, (size_t)bytes), "nm_mlp_create: hipMalloc(image)");
     const size_t consts_off = (size_t)(nm::kWeightBytes8 + nm::kWeightPadBytes), consts_bytes = img8.size() - consts_off;
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_consts8, consts_bytes), "nm_mlp_create: hipMalloc(consts8)");
@@ -459,6 +533,25 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     return NM_OK;
 }
 
+int nm_mlp_refresh_f16(nm_mlp_t m, const float* const* dev_params, nm_stream_t stream) {
+    NM_REQUIRE(m && dev_params, "nm_mlp_refresh_f16: null pointer");
+    NM_REQUIRE(!m->desc.plain_head, "nm_mlp_refresh_f16: the plain-head net is not refreshed on the device");
+    nm::DevParams P;
+    for (int i = 0; i < 24; ++i) {
+        NM_REQUIRE(dev_params[i], "nm_mlp_refresh_f16: dev_params[%d] is null", i);
+        P.p[i] = dev_params[i];
+    }
+    if (!m->d_wscale16)
+        if (int rc = nm::check_hip(hipMalloc(&m->d_wscale16, nm::kStages * sizeof(float)), "nm_mlp_refresh_f16: hipMalloc")) return rc;
+    hipStream_t st = nm::as_stream(stream);
+    float* bias = reinterpret_cast<float*>(m->d_image16 + nm::kWeightBytes + nm::kWeightPadBytes);
+    hipLaunchKernelGGL(nm::f16_stage_scale_kernel, dim3(nm::kStages), dim3(256), 0, st, m->desc, P, m->d_wscale16);
+    const int threads = (int)(nm::kWeightBytes / nm::kStepBytes) * 64;
+    hipLaunchKernelGGL(nm::f16_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, m->desc, P, m->d_wscale16, m->d_image16);
+    hipLaunchKernelGGL(nm::f16_bias_kernel, dim3((nm::kBiasFloats + nm::kF16TabFloats + 255) / 256), dim3(256), 0, st, P, m->d_wscale16, bias);
+    return nm::check_launch("nm_mlp_refresh_f16");
+}
+
 int nm_mlp_destroy(nm_mlp_t m) {
     if (!m) return NM_OK;
     if (m->d_image) (void)hipFree(m->d_image);
@@ -467,6 +560,7 @@ int nm_mlp_destroy(nm_mlp_t m) {
     if (m->d_stream8) (void)hipFree(m->d_stream8);
     if (m->d_petab) (void)hipFree(m->d_petab);
     if (m->d_ref) (void)hipFree(m->d_ref);
+    if (m->d_wscale16) (void)hipFree(m->d_wscale16);
     delete m;
     return NM_OK;
 }
@@ -513,6 +607,31 @@ int nm_mlp_forward(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n,
     NM_REQUIRE(n == 0 || (pts && dirs && out), "nm_mlp_forward: null pointer");
     NM_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "nm_mlp_forward: out must be 16-byte aligned");
     return mlp_dispatch(mlp, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, precision, -2, sigma_scale, out, nullptr, stream);
+}
+
+int nm_mlp_forward_save(nm_mlp_t m, const float* pts, const float* dirs, int64_t n, float* save_h, float* save_hv, float* out,
+                        nm_stream_t stream) {
+    NM_REQUIRE(m, "nm_mlp_forward_save: null handle");
+    NM_REQUIRE(!m->desc.plain_head, "nm_mlp_forward_save: the plain-head net has no fused training forward");
+    NM_REQUIRE(n >= 0, "nm_mlp_forward_save: negative n");
+    if (n == 0) return NM_OK;
+    NM_REQUIRE(pts && dirs && save_h && save_hv && out, "nm_mlp_forward_save: null pointer");
+    NM_REQUIRE(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(save_h) | reinterpret_cast<uintptr_t>(save_hv)) & 15) == 0,
+               "nm_mlp_forward_save: outputs must be 16-byte aligned");
+    nm::MlpLaunch L;
+    L.wpack = m->d_image;
+    L.bias = reinterpret_cast<const float*>(m->d_image + nm::kWeightBytes + nm::kWeightPadBytes);
+    L.wpack16 = m->d_image16;
+    L.bias16 = reinterpret_cast<const float*>(m->d_image16 + nm::kWeightBytes + nm::kWeightPadBytes);
+    L.petab = m->d_petab;
+    L.pe_kind = m->desc.pe_kind; L.pos_nfreq = m->desc.pos_n_freqs; L.dir_nfreq = m->desc.dir_n_freqs;
+    L.pos_octaves = m->pos_octaves; L.dir_octaves = m->dir_octaves;
+    L.plain_head = 0;
+    L.wstream8 = m->d_stream8;
+    L.consts8 = m->d_consts8;
+    L.save_h = save_h; L.save_hv = save_hv;
+    return nm::launch_mlp_mfma(L, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, NM_PREC_FP16X3, -2, 1.f, out, nullptr, nullptr,
+                               nm::as_stream(stream), 0, nullptr);
 }
 
 int nm_mlp_forward_rays(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals, int64_t R, int S,

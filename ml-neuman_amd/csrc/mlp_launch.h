@@ -11,6 +11,8 @@ struct MlpLaunch {
     int plain_head;                 // use_viewdirs=False net: output_linear instead of the alpha / feature / views / rgb heads
     const void* wpack16; const float* bias16;     // NM_PREC_FP16X3: the same fragment image as split fp16 of W * 2^8, biases * 2^13
     const void* wstream8; const float* consts8;   // NM_PREC_I8X3: per-wave fragment streams; units | biases | kappa (mlp_layout.h)
+    float* save_h = nullptr;                      // nm_mlp_forward_save (NM_PREC_FP16X3): [9][n][256] post-activation outputs of layers 0..7, then feature
+    float* save_hv = nullptr;                     //   and [n][128] of the views layer: what a training step's backward pass reads
 };
 struct RefLaunch {
     const float* wt; const float* bias; int off[12]; int boff[12]; const float* petab;

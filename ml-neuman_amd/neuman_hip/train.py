@@ -29,6 +29,9 @@ PE_KINDS = {'posenc': 0, 'rotate': 1}                 # NM_PE_POSENC / NM_PE_ROT
 #   'bf16x3'  split-bf16 x3 everywhere (its 1e-5 forward error flips a ReLU here and there: single gradient entries move by ~1e-3 of
 #             the tensor's largest -- fine for SGD, not for the parity tests);  'fp16x3': split-fp16 x3 everywhere (forward-safe only)
 GEMM_PRECISION = os.environ.get('NEUMAN_TRAIN_GEMM', 'mixed16')
+# the forward of a standard Joiner (3-D encodings, 8 x 256, view directions) in ONE kernel that keeps a tile's activations on chip across
+# the layers and only writes the copies the backward pass reads (nm_mlp_forward_save; mixed16 only).  NEUMAN_TRAIN_FUSED=0: the GEMM chain.
+FUSED_FORWARD = os.environ.get('NEUMAN_TRAIN_FUSED', '1') != '0'
 
 
 def _gemm(a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, bias=None, mask=None, ldmask=0, flags=0, ws=None, precision=None):
@@ -111,6 +114,14 @@ def _pad4(x):
     return out
 
 
+def _fused_ok(net):
+    nerf = net.nerf
+    return (FUSED_FORWARD and GEMM_PRECISION == 'mixed16' and hasattr(net, 'train_handle') and nerf.use_viewdirs and net.pos_pe.input_dims == 3
+            and nerf.depth == 8 and nerf.width == 256 and list(nerf.skips) == [4] and getattr(nerf, 'scale_type', 'no') == 'no'
+            and net.pos_pe.mapping == net.dir_pe.mapping
+            and all(p.dtype == torch.float32 and p.is_contiguous() and p.is_cuda for p in nerf.ordered_params()))
+
+
 class _MLP(torch.autograd.Function):
     """net = Joiner (use_viewdirs: pts, dirs -> [rgb, sigma]) or OffsetNet (dirs is None: x -> output_linear)."""
 
@@ -125,6 +136,22 @@ class _MLP(torch.autograd.Function):
         p4 = _pad4(pts)
         n4 = p4.shape[0]
         X0 = _encode(net.pos_pe, p4, pk.kp)
+        if _fused_ok(net) and dirs is not None:
+            import ctypes
+            d4 = _pad4(dirs)
+            D0 = _encode(net.dir_pe, d4, pk.kd)
+            handle = net.train_handle()
+            ptrs = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in nerf.ordered_params()])
+            _lib.check(_lib.lib().nm_mlp_refresh_f16(handle, ptrs, _lib.stream_ptr()), "nm_mlp_refresh_f16")
+            acts = torch.empty((9, n4, width), device=dev, dtype=torch.float32)
+            hv = torch.empty((n4, half), device=dev, dtype=torch.float32)
+            raw = torch.empty((n4, 4), device=dev, dtype=torch.float32)
+            _lib.check(_lib.lib().nm_mlp_forward_save(handle, _lib.dev_ptr(p4), _lib.dev_ptr(d4), n4, _lib.dev_ptr(acts), _lib.dev_ptr(hv),
+                                                      _lib.dev_ptr(raw), _lib.stream_ptr()), "nm_mlp_forward_save")
+            H, feat = [acts[i] for i in range(8)], acts[8]
+            ctx.pk, ctx.X0, ctx.D0, ctx.H, ctx.feat, ctx.hv, ctx.n, ctx.net = pk, X0, D0, H, feat, hv, n, net
+            ctx.p4, ctx.d4 = p4, d4
+            return raw[:n]
         H = []
         h, kh = X0, pk.kp
         for i, Ws in enumerate(pk.W):

@@ -104,6 +104,7 @@ class Joiner(nn.Module):
         self.precision = DEFAULT_PRECISION
         self._handle = None
         self._handle_key = None
+        self._train_handle = None
 
     # ---- weight-pack cache: rebuilt whenever a parameter's storage or version changes -------------
     def _key(self):
@@ -113,6 +114,9 @@ class Joiner(nn.Module):
         if self._handle is not None:
             _lib.lib().nm_mlp_destroy(self._handle)
             self._handle = None
+        if getattr(self, '_train_handle', None) is not None:
+            _lib.lib().nm_mlp_destroy(self._train_handle)
+            self._train_handle = None
 
     def __del__(self):
         try:
@@ -126,6 +130,7 @@ class Joiner(nn.Module):
         state = self.__dict__.copy()
         state['_handle'] = None
         state['_handle_key'] = None
+        state['_train_handle'] = None
         return state
 
     def __deepcopy__(self, memo):
@@ -133,7 +138,7 @@ class Joiner(nn.Module):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = None if k in ('_handle', '_handle_key') else copy.deepcopy(v, memo)
+            new.__dict__[k] = None if k in ('_handle', '_handle_key', '_train_handle') else copy.deepcopy(v, memo)
         return new
 
     def handle(self):
@@ -156,6 +161,19 @@ class Joiner(nn.Module):
                                                 ctypes.byref(out)), "nm_mlp_create")
             self._handle, self._handle_key = out, key
         return self._handle
+
+    def train_handle(self):
+        """A second handle for the training forward (neuman_hip/train.py): created once and never rebuilt -- its split-fp16 weight
+        image is rewritten on the device from the live parameters before every use (nm_mlp_refresh_f16), so an optimiser step costs
+        three small kernels, not a host repack."""
+        if self._train_handle is None:
+            keep, keep_key = self._handle, self._handle_key
+            self._handle = None                                  # build a fresh handle through the same code path, then restore the cache
+            try:
+                self._train_handle = self.handle()
+            finally:
+                self._handle, self._handle_key = keep, keep_key
+        return self._train_handle
 
     def _prec(self, precision, role=None):
         """'mixed': a pass the caller tags role='shading' -- its output is composited into the frame and nothing else --

@@ -274,3 +274,50 @@ def test_human_samples_iteration(G):
         losses.append(float(loss.detach()))
     print("[train] human-samples iteration: losses", " ".join(f"{x:.4f}" for x in losses))
     assert losses[-1] < losses[0]
+
+
+def test_fused_training_forward(G, monkeypatch):
+    """nm_mlp_refresh_f16 + nm_mlp_forward_save: the training forward in one kernel.  (a) the device-side weight packer equals the host
+    packer: the raw output is bit-identical to the rendering forward (split-fp16 x3) through a handle created from the same values,
+    also after an optimiser step changed them; (b) the activations it keeps are the GEMM chain's (float32 class both); (c) gradients
+    through it agree with the GEMM chain's."""
+    monkeypatch.setattr(G.train, "GEMM_PRECISION", "mixed16")
+    g = G.g
+    o, d = cu(g['origin']), cu(g['direction'])
+    z = cu(g['white/fine/z'])
+    pts = (o[:, None, :] + d[:, None, :] * z[..., None]).contiguous()
+    dirs = d[:, None, :].expand(pts.shape).contiguous()
+    net = G.syn.make_joiner(1).cuda().train()
+    assert G.train._fused_ok(net)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    for step in range(2):
+        monkeypatch.setattr(G.train, "FUSED_FORWARD", True)
+        out = net(pts, dirs)
+        with torch.no_grad():
+            ref = net.eval()(pts, dirs, precision='fp16x3')
+        net.train()
+        assert torch.equal(out.detach(), ref), float((out.detach() - ref).abs().max())
+        def mlp_node(t):                                           # the autograd node of train._MLP behind the output's reshape / slice views
+            node = t.grad_fn
+            while node is not None and '_MLP' not in type(node).__name__:
+                node = node.next_functions[0][0]
+            return node
+        fn = mlp_node(out)
+        H_fused = [h.clone() for h in fn.H] + [fn.feat.clone(), fn.hv.clone()]
+        out.square().sum().backward()
+        grads_fused = [p.grad.clone() for p in net.parameters()]
+        opt.zero_grad()
+        monkeypatch.setattr(G.train, "FUSED_FORWARD", False)
+        out2 = net(pts, dirs)
+        fn2 = mlp_node(out2)
+        H_chain = list(fn2.H) + [fn2.feat, fn2.hv]
+        worst = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-6)) for a, b in zip(H_fused, H_chain))
+        assert worst < 2e-5, worst
+        assert float((out2 - out.detach()).abs().max()) < 2e-5 * max(1.0, float(out2.abs().max()))
+        out2.square().sum().backward()
+        gw = max(float((a - p.grad).abs().max() / p.grad.abs().max().clamp_min(1e-12)) for a, p in zip(grads_fused, net.parameters()))
+        print(f"[train] fused forward step {step}: raw bit-identical to the rendering kernel, saved activations {worst:.2e} from the GEMM chain's, "
+              f"parameter gradients {gw:.2e}")
+        assert gw < 2e-3          # (two float32-class forwards decide a few ReLUs at |x| ~ 1e-7 differently; the reference goldens bound each: above)
+        opt.step()                                               # the weights change: the next refresh must follow them
+        opt.zero_grad()
