@@ -4,6 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches itself: it checks that N devices are
+visible (one JSON error line and exit code 2 otherwise) and re-executes under torch.distributed.run with one rank per GPU.
+
 One "step" = one 800x800 frame of the background NeRF: 128 coarse + 128 importance samples per ray (the reference
 evaluates the 8x256 MLP 128 + 256 = 384 times per ray, render_utils.py:108-161), synthetic-dense weights
 (SURVEY 8d), rays already resident in HBM when the timed region starts.  With N > 1 the frame's ray tiles are
@@ -58,6 +61,7 @@ DTYPES = {
     "bf16x3": "bf16x3 (split-bf16 hi+lo MFMA x3, f32 accumulate)",
     "i8x3": "i8x3 (per-row-scaled int16 as 2 int8 limbs, i8 MFMA x3, exact int32 accumulate; encodings on bf16x3)",
     "bf16": "bf16 (f32 accumulate)", "fp32": "f32"}
+PMC_SUMMARIES = ("profiles/r03_bench_pmc_summary.json", "profiles/r02_bench_pmc_summary.json", "profiles/r01_bench_pmc_summary.json")
 KERNEL_OF = {"fp16x3": "nerf_mlp_kernel<4, false>", "bf16x3": "nerf_mlp_kernel<1, false>", "i8x3": "nerf_mlp_i8w_kernel<false>", "bf16": "nerf_mlp_kernel<2, false>",
              "fp32": "nerf_mlp_ref_kernel"}
 
@@ -179,18 +183,18 @@ def pmc_traffic_per_launch(kernel, launch):
     collected in separate rocprofv3 runs, so they cannot be measured inside this process): FETCH_SIZE*2 (gfx950 reports
     half the bytes of wide streaming reads, MI355X_MICROARCH.md) + WRITE_SIZE, KiB -> bytes, of dispatch `launch` of
     `kernel` in a --steps 1 --warmup 0 --timed-only run (exactly one coarse and one fine launch).  None when absent."""
-    path = os.path.join(ROOT, "profiles", "r02_bench_pmc_summary.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r01_bench_pmc_summary.json")
-    try:
-        with open(path) as f:
-            s = json.load(f)
-        key = kernel.split("<")[0]
-        fetch = [x["FETCH_SIZE"] for x in s["fetch"] if x["kernel"].split("<")[0] == key]
-        write = [x["WRITE_SIZE"] for x in s["write"] if x["kernel"].split("<")[0] == key]
-        return (2 * fetch[launch] + write[launch]) * 1024.0
-    except Exception:
-        return None
+    for rel in PMC_SUMMARIES:                                     # newest first; the file used is named in the line (`traffic_source`)
+        path = os.path.join(ROOT, rel)
+        try:
+            with open(path) as f:
+                s = json.load(f)
+            key = kernel.split("<")[0]
+            fetch = [x["FETCH_SIZE"] for x in s["fetch"] if x["kernel"].split("<")[0] == key]
+            write = [x["WRITE_SIZE"] for x in s["write"] if x["kernel"].split("<")[0] == key]
+            return (2 * fetch[launch] + write[launch]) * 1024.0, rel
+        except Exception:
+            continue
+    return None, None
 
 
 def train_iteration(dev, origins, dirs, cap, rays=2048, iters=5):
@@ -239,6 +243,44 @@ def train_iteration(dev, origins, dirs, cap, rays=2048, iters=5):
             "(tests/test_hip_train.py)"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) started by hand: become `torch.distributed.run --nproc-per-node N bench.py ...`.
+    Returns only on error (after printing one JSON line)."""
+    import socket
+    n = args.gpus
+    if args.backend == "nccl":
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            print(json.dumps({"error": f"--gpus {n} but {have} HIP device(s) visible", "n_gpus": n, "n_gpus_visible": have,
+                              "metric": "rays_per_sec", "value": None}), flush=True)
+            raise SystemExit(2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execvpe(cmd[0], cmd, env)
+
+
+def launch_check(args, rank, world):
+    """--launch-check: what a box without N GPUs can execute of the N > 1 start-up -- process group up (backend as asked), one
+    frame-assembly gather of host tensors through the product's gather_frame, one JSON line from rank 0."""
+    from neuman_hip import parallel
+    total, tile = 1000, parallel.balanced_tile(1000, world, 64)
+    idx = parallel.tile_ray_indices(total, tile, rank, world)
+    frame = parallel.gather_frame(idx.to(torch.float32)[:, None] * 2.0, idx, total, tile)
+    if rank == 0:
+        ok = bool(torch.equal(frame[:, 0], torch.arange(total, dtype=torch.float32) * 2.0))
+        print(json.dumps({"launch_check": True, "world": dist.get_world_size(), "backend": dist.get_backend(), "frame_assembled": ok,
+                          "tiles_per_rank": [int(parallel.tile_ray_indices(total, tile, r, world).shape[0] + tile - 1) // tile for r in range(world)]}),
+              flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -252,19 +294,35 @@ def main():
                     "(what a single-GPU box can execute of the N > 1 path; tests/test_parallel_gpu.py)")
     ap.add_argument("--timed-only", action="store_true", help="profiling runs: nothing but the warm-up and the timed steps "
                     "(no quality check, other precisions or CPU baseline), so every MLP launch rocprofv3 sees is a timed one")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo only with --launch-check)")
+    ap.add_argument("--launch-check", action="store_true", help="bring the process group up, assemble one dummy frame through the gather "
+                    "and exit (no device needed with --backend gloo: the CPU-side test of the self-launch)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(json.dumps({"error": f"--gpus {args.gpus} but WORLD_SIZE={world}", "n_gpus": args.gpus, "value": None}), flush=True)
+        raise SystemExit(2)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if args.launch_check:
+        if args.backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(args.backend, rank=rank, world_size=world,
+                                **({"device_id": torch.device("cuda", local)} if args.backend == "nccl" else {}))
+        return launch_check(args, rank, world)
+    if args.backend != "nccl":
+        raise SystemExit("--backend gloo is for --launch-check only: the timed path runs on HIP devices over RCCL")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists for the hot path)")
     torch.cuda.set_device(local)
     if world > 1 or args.dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from neuman_hip import parallel, ray_utils, render_utils, synthetic
     dev = torch.device("cuda", local)
@@ -292,9 +350,16 @@ def main():
             return out
         net.forward_rays = timed
 
+    gather_events = []
+
     def step():
         rgb, depth = render_utils.render_vanilla_rays(coarse, fine, o_loc, d_loc, cap.near['bkg'], cap.far['bkg'], S, NI, True)
-        return parallel.gather_frame(torch.cat([rgb, depth[:, None]], 1), idx, total, TILE, force_collective=args.dist)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        frame = parallel.gather_frame(torch.cat([rgb, depth[:, None]], 1), idx, total, TILE, force_collective=args.dist)
+        e1.record()
+        gather_events.append((e0, e1))
+        return frame
 
     def sync():
         if world > 1 or args.dist:
@@ -306,6 +371,7 @@ def main():
             step()
         for log in mlp_events.values():
             log.clear()
+        gather_events.clear()
         sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -317,11 +383,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = t.item()
 
-    def roofline(which, precision, launch_index):
+    # per rank: [fine evaluations, fine launch ms (sum), coarse evaluations, coarse ms, launches of each, rays, frame-assembly ms (sum)]
+    def log_sums(which):
         log = mlp_events[which]
+        return float(sum(n for _, _, n in log)), float(sum(e0.elapsed_time(e1) for e0, e1, _ in log))
+    mine = torch.tensor([*log_sums("fine"), *log_sums("coarse"), float(len(mlp_events["fine"])), float(o_loc.shape[0]),
+                         float(sum(e0.elapsed_time(e1) for e0, e1 in gather_events))], device=dev, dtype=torch.float64)
+    per_rank = [mine]
+    if world > 1 or args.dist:
+        per_rank = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+    per_rank = [r.tolist() for r in per_rank]
+    slowest = max(range(world), key=lambda r: per_rank[r][1])               # the rank whose fine launches took longest bounds the frame
+
+    def roofline(which, precision, launch_index):
+        col = 0 if which == "fine" else 2
         density_only = which == "coarse" and precision in ("fp16x3", "bf16x3", "bf16")
-        evals = sum(n for _, _, n in log)
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in log)
+        evals, ms = per_rank[slowest][col], per_rank[slowest][col + 1]
+        n_launch = int(per_rank[slowest][4])
+        traffic, traffic_source = pmc_traffic_per_launch(KERNEL_OF[precision], launch_index) if world == 1 else (None, None)
         achieved = evals * FLOP_PER_EVAL / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         kernel = KERNEL_OF[precision]
         # what the matrix pipe really executes: MFMA ops per algorithmic FLOP x the share of the layers evaluated, against the
@@ -332,12 +412,13 @@ def main():
         hardware = {"mfma_type": mfma_type, "mfma_ops_per_algorithmic_flop": issued, "rate": achieved * issued, "peak": hw_peak,
                     "unit": "Tops/s", "frac": achieved * issued / hw_peak} if issued else None
         return {"bound": "mfma", "kernel": kernel, "hardware": hardware,
-                "launch": f"{which} pass, {evals // max(1, len(log))} evaluations per launch on this rank",
+                "launch": f"{which} pass, {int(evals) // max(1, n_launch)} evaluations per launch" + (f" on rank {slowest}, the slowest of {world}" if world > 1 else ""),
                 "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                "traffic": pmc_traffic_per_launch(kernel, launch_index) if world == 1 else None,
-                "traffic_unit": "bytes of HBM traffic per launch (FETCH_SIZE*2 + WRITE_SIZE, rocprofv3 --pmc passes of this command, "
-                                "profiles/r02_bench_pmc_summary.json; algorithmic: 16 B/evaluation out + 4 B/evaluation z in)",
-                "launches": len(log), "avg_launch_ms": ms / max(1, len(log)),
+                "traffic": traffic, "traffic_source": traffic_source if traffic_source else ("not collected at N > 1: PMC passes are single-process runs" if world > 1 else None),
+                "traffic_unit": "bytes of HBM traffic per launch (FETCH_SIZE*2 + WRITE_SIZE) REPLAYED from the committed rocprofv3 --pmc passes of this "
+                                "command named in traffic_source (counters need their own runs; not measured in this process); algorithmic: "
+                                "16 B/evaluation out + 4 B/evaluation z in",
+                "launches": n_launch, "avg_launch_ms": ms / max(1, n_launch),
                 "note": "algorithmic FLOPs = 1,186,816 per MLP evaluation (what the reference performs); fp16x3, bf16x3 and i8x3 all issue 3 MFMAs "
                         "per algorithmic one (i8 at twice the bf16 rate), so hardware MFMA work is 3x the algorithmic figure"
                         + ("; this launch evaluates the density head only (nm_mlp_sigma_rays): the reference composites the coarse "
@@ -435,6 +516,15 @@ def main():
                                    "128 coarse + 256 fine MLP evaluations per ray, synthetic-dense weights (seeds 0/1), near 0 far 3.14",
                        "rays_per_frame": total, "mlp_evals_per_ray": EVALS_PER_RAY,
                        "parallelism": f"ray-tile sharding x{world}, 1 gather/frame", "tile_rays": TILE, "precision": args.precision},
+            "multi_gpu": {"rccl_world": dist.get_world_size() if (world > 1 or args.dist) else 1,
+                          "backend": dist.get_backend() if (world > 1 or args.dist) else None,
+                          "tiles_per_rank": [int(-(-r[5] // TILE)) for r in per_rank], "rays_per_rank": [int(r[5]) for r in per_rank],
+                          "fine_launch_ms_per_rank": [r[1] / max(1.0, r[4]) for r in per_rank],
+                          "coarse_launch_ms_per_rank": [r[3] / max(1.0, r[4]) for r in per_rank],
+                          "frame_assembly_ms_per_rank": [r[6] / max(1, args.steps) for r in per_rank],
+                          "frame_assembly": "one dist.gather per frame to rank 0 + one index_select (parallel.gather_frame); at world 1 a scatter into the frame",
+                          "omitted_at_n_gt_1": None if world == 1 else ["cpu_baseline (rank 0 at N = 1 only)", "parity_vs_oracle (scored in the N = 1 run: the "
+                                               "ranks run the same kernels on disjoint rays)", "roofline.traffic (PMC passes are single-process)"]},
             "parity_vs_oracle": parity,
             "other_precisions": others,
             "other_workloads": workloads,

@@ -27,7 +27,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define NM_HD __host__ __device__
 #else
 #define NM_HD

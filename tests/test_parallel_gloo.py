@@ -79,3 +79,35 @@ def test_world_size_one_needs_no_process_group():
     o, d = torch.randn(300, 3), torch.randn(300, 3)
     frame = parallel.render_sharded(_fake_render, o, d, tile=64)
     assert torch.equal(frame, _fake_render(o, d))
+
+
+def test_bench_launches_itself_at_n_gt_1():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment re-executes under torch.distributed.run, both ranks reach
+    init_process_group and assemble a frame through parallel.gather_frame (gloo + host tensors: what runs without GPUs)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line == {"launch_check": True, "world": 2, "backend": "gloo", "frame_assembled": True, "tiles_per_rank": [8, 8]}
+
+
+def test_bench_refuses_more_gpus_than_visible_with_a_json_line():
+    """asked for more devices than the box has: ONE JSON error line and exit code 2, not an AssertionError"""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    n = (torch.cuda.device_count() if torch.cuda.is_available() else 0) + 7
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["value"] is None and line["n_gpus"] == n and "visible" in line["error"]

@@ -66,3 +66,21 @@ def test_two_ranks_share_the_gpu_and_assemble_real_tiles_over_gloo():
     out = last_json(outs[0][0])
     print(out)
     assert out["bit_identical"] and out["finite"] and out["world"] == 2
+
+
+def test_bench_self_launch_paths_on_a_one_gpu_box():
+    """`python bench.py --gpus 2` started by hand on this one-GPU box prints ONE JSON error line (exit code 2) instead of dying on an
+    assertion; with as many GPUs as asked it re-executes itself under torch.distributed.run (the CPU suite runs that start-up with gloo,
+    tests/test_parallel_gloo.py); the line of an N = 1 run through the process group carries the multi-GPU evidence fields."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2, r.stderr[-2000:]
+    assert last_json(r.stdout)["n_gpus_visible"] == n - 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--dist", "--timed-only"],
+                       env=env_for(0, 1, free_port()), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    mg = last_json(r.stdout)["multi_gpu"]
+    print(mg)
+    assert mg["rccl_world"] == 1 and mg["backend"] == "nccl" and mg["rays_per_rank"] == [640000] and mg["frame_assembly_ms_per_rank"][0] > 0
