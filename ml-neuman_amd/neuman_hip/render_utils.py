@@ -130,9 +130,29 @@ def march_pass_rays(net, o, d, z, eps, chunk=None, precision=None, role='shading
     return raw
 
 
+def _given_near_far(given, actor, i, j, o, d, verts, geo_threshold):
+    """near / far of one actor for rays [i, j) of the call: computed (nm_near_far), or replayed from `given` (see bkg_pass_rays)"""
+    if given is not None and 'near_far' in given:
+        n, f = given['near_far'][actor]
+        return n[i:j].to(torch.float32).contiguous(), f[i:j].to(torch.float32).contiguous()
+    return ray_utils.geometry_guided_near_far(o, d, verts, geo_threshold)
+
+
 def bkg_pass_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, importance_samples_per_ray, white_bkg,
-                  precision=None, trace=None):
-    """Coarse (+ fine) background evaluation of R rays -> (raw [R,S',4], z [R,S'])  (render_utils.py:131-151, 287-297)."""
+                  precision=None, trace=None, given_z=None):
+    """Coarse (+ fine) background evaluation of R rays -> (raw [R,S',4], z [R,S'])  (render_utils.py:131-151, 287-297).
+
+    `given_z` [R, S'] (tests only, like `trace`): replay recorded final sample positions instead of deriving them -- the shading
+    network is evaluated on exactly those.  The renderers pass it from their `given` dict ({'bkg_z': [R,S'], 'near_far':
+    [(near [R], far [R]) per actor]}, device tensors indexed like the call's rays): the two steps that are ill conditioned in
+    float32 -- the inverse CDF behind the importance samples and the cancellation under geometry_guided_near_far's square root
+     -- are taken from a recording of the reference's own run, so that everything else can be held to 1e-4
+    on every pixel against the reference's frames (tests/test_hip_posed_golden.py)."""
+    if given_z is not None:
+        z = given_z.to(torch.float32).contiguous()
+        net = fine_net if fine_net is not None else coarse_net
+        _note(trace, bkg_z=z)
+        return net.forward_rays(o, d, z, precision=precision, role='shading'), z
     _, _, z = ray_utils.sample_z(o, d, near, far, samples_per_ray)
     # with a fine net the coarse pass only places the importance samples; otherwise it is the pass that is composited
     # ('shading' role of the mixed precision policy, vanilla.Joiner._prec)
@@ -141,6 +161,7 @@ def bkg_pass_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, import
                                   sigma_only=fine_net is not None)
     if fine_net is not None:
         _, _, _, w, _ = raw2outputs(raw, z, d, white_bkg=white_bkg)
+        _note(trace, coarse_z=z, coarse_w=w)
         z = ray_utils.importance_z(z, w, importance_samples_per_ray)
         if TERMINATION_EPS > 0:
             stats = {} if trace is not None else None
@@ -153,7 +174,7 @@ def bkg_pass_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, import
 
 
 def render_vanilla_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, importance_samples_per_ray, white_bkg=True,
-                        precision=None, trace=None):
+                        precision=None, trace=None, given=None):
     """Device core of render_vanilla: o, d [R,3] CUDA f32, scalar near/far -> (rgb [R,3], depth [R]) CUDA."""
     R = o.shape[0]
     rgb = torch.empty((R, 3), device=o.device, dtype=torch.float32)
@@ -163,7 +184,7 @@ def render_vanilla_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, 
         n = torch.full((j - i,), float(near), device=o.device, dtype=torch.float32)
         f = torch.full((j - i,), float(far), device=o.device, dtype=torch.float32)
         raw, z = bkg_pass_rays(coarse_net, fine_net, oc, dc, n, f, samples_per_ray, importance_samples_per_ray, white_bkg,
-                               precision, trace)
+                               precision, trace, given['bkg_z'][i:j] if given is not None and 'bkg_z' in given else None)
         rgb[i:j], _, _, _, depth[i:j] = raw2outputs(raw, z, dc, white_bkg=white_bkg, want_weights=False)
     return rgb, depth
 
@@ -182,15 +203,16 @@ def human_pass_rays(human_net, o, d, near, far, samples_per_ray, mesh=None, rend
 
 
 def render_smpl_nerf_rays(human_net, o, d, posed_verts, mesh, samples_per_ray, white_bkg=True, render_can=False,
-                          geo_threshold=DEFAULT_GEO_THRESH, interval_comp=1.0, precision=None, trace=None):
-    """Device core of render_smpl_nerf -> (rgb [R,3], depth [R], acc [R]) CUDA."""
+                          geo_threshold=DEFAULT_GEO_THRESH, interval_comp=1.0, precision=None, trace=None, given=None):
+    """Device core of render_smpl_nerf -> (rgb [R,3], depth [R], acc [R]) CUDA.  `given`: see bkg_pass_rays."""
     R = o.shape[0]
     rgb = torch.full((R, 3), 1.0 if white_bkg else 0.0, device=o.device, dtype=torch.float32)    # misses, :199-205
     depth = torch.zeros(R, device=o.device, dtype=torch.float32)
     acc = torch.zeros(R, device=o.device, dtype=torch.float32)
     for i, j in _chunks(R):
         oc, dc = o[i:j].contiguous(), d[i:j].contiguous()
-        near, far = ray_utils.geometry_guided_near_far(oc, dc, posed_verts, geo_threshold)
+        near, far = _given_near_far(given, 0, i, j, oc, dc, posed_verts, geo_threshold)
+        _note(trace, near=near, far=far)
         hit, _ = ray_utils.compact_hits(near, far)
         if hit.numel() == 0:
             continue
@@ -206,8 +228,9 @@ def render_smpl_nerf_rays(human_net, o, d, posed_verts, mesh, samples_per_ray, w
 
 
 def render_hybrid_rays(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far, posed_verts, mesh, samples_per_ray,
-                       importance_samples_per_ray, white_bkg=True, geo_threshold=DEFAULT_GEO_THRESH, precision=None, trace=None):
-    """Device core of render_hybrid_nerf -> (rgb [R,3], depth [R], acc [R]) CUDA  (render_utils.py:276-356)."""
+                       importance_samples_per_ray, white_bkg=True, geo_threshold=DEFAULT_GEO_THRESH, precision=None, trace=None,
+                       given=None):
+    """Device core of render_hybrid_nerf -> (rgb [R,3], depth [R], acc [R]) CUDA  (render_utils.py:276-356).  `given`: see bkg_pass_rays."""
     R = o.shape[0]
     rgb = torch.empty((R, 3), device=o.device, dtype=torch.float32)
     depth = torch.empty(R, device=o.device, dtype=torch.float32)
@@ -217,10 +240,11 @@ def render_hybrid_rays(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far,
         n = torch.full((j - i,), float(bkg_near), device=o.device, dtype=torch.float32)
         f = torch.full((j - i,), float(bkg_far), device=o.device, dtype=torch.float32)
         bkg_raw, bkg_z = bkg_pass_rays(coarse_bkg, fine_bkg, oc, dc, n, f, samples_per_ray, importance_samples_per_ray,
-                                       white_bkg, precision, trace)
+                                       white_bkg, precision, trace, given['bkg_z'][i:j] if given is not None and 'bkg_z' in given else None)
         # every ray first gets the background-only composite (what the reference does for misses, :303-311) ...
         rgb[i:j], _, _, _, depth[i:j] = raw2outputs(bkg_raw, bkg_z, dc, white_bkg=white_bkg, want_weights=False)
-        near, far = ray_utils.geometry_guided_near_far(oc, dc, posed_verts, geo_threshold)
+        near, far = _given_near_far(given, 0, i, j, oc, dc, posed_verts, geo_threshold)
+        _note(trace, near=near, far=far)
         hit, _ = ray_utils.compact_hits(near, far)
         if hit.numel() == 0:
             continue
@@ -241,8 +265,10 @@ def render_hybrid_rays(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far,
 
 
 def render_multi_rays(coarse_bkg, fine_bkg, human_nets, o, d, bkg_near, bkg_far, posed_verts, meshes, samples_per_ray,
-                      importance_samples_per_ray, white_bkg=True, geo_threshold=DEFAULT_GEO_THRESH, precision=None, trace=None):
-    """Device core of render_hybrid_nerf_multi_persons -> (rgb [R,3], depth [R]) CUDA  (render_utils.py:390-456)."""
+                      importance_samples_per_ray, white_bkg=True, geo_threshold=DEFAULT_GEO_THRESH, precision=None, trace=None,
+                      given=None):
+    """Device core of render_hybrid_nerf_multi_persons -> (rgb [R,3], depth [R]) CUDA  (render_utils.py:390-456).  `given`: see
+    bkg_pass_rays."""
     R = o.shape[0]
     rgb = torch.empty((R, 3), device=o.device, dtype=torch.float32)
     depth = torch.empty(R, device=o.device, dtype=torch.float32)
@@ -252,7 +278,7 @@ def render_multi_rays(coarse_bkg, fine_bkg, human_nets, o, d, bkg_near, bkg_far,
         n = torch.full((nr,), float(bkg_near), device=o.device, dtype=torch.float32)
         f = torch.full((nr,), float(bkg_far), device=o.device, dtype=torch.float32)
         raw_all, z_all = bkg_pass_rays(coarse_bkg, fine_bkg, oc, dc, n, f, samples_per_ray, importance_samples_per_ray,
-                                       white_bkg, precision, trace)
+                                       white_bkg, precision, trace, given['bkg_z'][i:j] if given is not None and 'bkg_z' in given else None)
         # In this renderer the terminal 1e10 interval sits on an actor's zero-density placeholder whenever a ray misses one
         # (render_utils.py:418-419), so the LAST background sample is followed by a finite interval of ~far..2 far instead:
         # alpha = 1 - exp(-sigma * 3.14..) is then ~300x as sensitive to that one sigma as a sample inside the ray is.  Under the
@@ -261,8 +287,9 @@ def render_multi_rays(coarse_bkg, fine_bkg, human_nets, o, d, bkg_near, bkg_far,
         if last_net._prec(precision, 'shading') == _lib.NM_PREC_I8X3 and (precision or last_net.precision) == 'mixed':
             raw_all[:, -1, :] = last_net.forward_rays(oc, dc, z_all[:, -1:].contiguous(), precision='fp16x3')[:, 0, :]
         far_z = torch.linspace(float(bkg_far) * 2, float(bkg_far) * 3, samples_per_ray, device=o.device)   # :418-419
-        for net, verts, mesh in zip(human_nets, posed_verts, meshes):
-            near, far = ray_utils.geometry_guided_near_far(oc, dc, verts, geo_threshold)
+        for a_, (net, verts, mesh) in enumerate(zip(human_nets, posed_verts, meshes)):
+            near, far = _given_near_far(given, a_, i, j, oc, dc, verts, geo_threshold)
+            _note(trace, near=near, far=far)
             h_raw = torch.zeros((nr, samples_per_ray, 4), device=o.device, dtype=torch.float32)
             h_z = far_z[None].repeat(nr, 1).contiguous()
             hit, _ = ray_utils.compact_hits(near, far)

@@ -62,8 +62,17 @@ def closest_point_on_triangles(p, a, b, c):
     return a + ab * v_sel[..., None] + ac * w_sel[..., None]
 
 
-def closest_point_on_mesh(pts, verts, faces, chunk=32):
-    """igl.point_mesh_squared_distance(P, V, F) -> (sqrD [N], face id [N], closest [N,3]).  float64 math."""
+def closest_point_on_mesh(pts, verts, faces, chunk=32, culled=None):
+    """igl.point_mesh_squared_distance(P, V, F) -> (sqrD [N], face id [N], closest [N,3]).  float64 math.
+
+    The definition is the loop below: every point against every triangle, arg-min (first minimum = smallest face id).  For
+    more than a few thousand points `culled` (default: N * F > 2e8) takes `closest_point_on_mesh_culled`, which evaluates the
+    same per-pair arithmetic on a superset of the triangles that can win and returns the same arrays bit for bit
+    (tests/test_oracle_warp_independent.py::test_culled_search_equals_the_all_pairs_loop)."""
+    if culled is None:
+        culled = pts.shape[0] * faces.shape[0] > 2e8
+    if culled:
+        return closest_point_on_mesh_culled(pts, verts, faces)
     p = pts.astype(np.float64)
     v = verts.astype(np.float64)
     a, b, c = v[faces[:, 0]][None], v[faces[:, 1]][None], v[faces[:, 2]][None]
@@ -79,6 +88,60 @@ def closest_point_on_mesh(pts, verts, faces, chunk=32):
         fid[s:s + chunk] = i
         sqr[s:s + chunk] = d2[r, i]
         closest[s:s + chunk] = q[r, i]
+    return sqr, fid, closest
+
+
+def closest_point_on_mesh_culled(pts, verts, faces, pair_budget=4_000_000):
+    """The all-pairs search restricted, per point, to the triangles that can hold its closest point -- exact, not approximate:
+    with d_ub the distance from p to the nearest mesh VERTEX (a point of the surface, so an upper bound of the answer), a
+    triangle whose centroid is further than d_ub + (its circumscribed radius about the centroid) from p cannot beat it.  The
+    candidates come from a k-d tree over the centroids with the largest such radius (a superset); the surviving (point, triangle)
+    pairs go through `closest_point_on_triangles` in flat arrays -- the same elementwise float64 operations as the loop of
+    `closest_point_on_mesh` -- and the minimum per point is taken with ties to the smallest face id, as np.argmin does there."""
+    from scipy.spatial import cKDTree
+    p = pts.astype(np.float64)
+    v = verts.astype(np.float64)
+    tri = faces[:, :3]
+    a, b, c = v[tri[:, 0]], v[tri[:, 1]], v[tri[:, 2]]
+    cen = (a + b + c) / 3.0
+    rad = np.sqrt(np.maximum(np.maximum(_dot(a - cen, a - cen), _dot(b - cen, b - cen)), _dot(c - cen, c - cen)))
+    rmax = float(rad.max()) * (1 + 1e-9) + 1e-12
+    used = np.unique(tri)
+    n = p.shape[0]
+    finite = np.isfinite(p).all(1)
+    d_ub = np.full(n, np.inf)
+    d_ub[finite] = cKDTree(v[used]).query(p[finite])[0]
+    ctree = cKDTree(cen)
+    sqr = np.full(n, np.inf)
+    fid = np.zeros(n, np.int64)
+    closest = np.zeros((n, 3))
+    start = 0
+    step = 4096
+    while start < n:
+        stop = min(n, start + step)
+        rows = np.arange(start, stop)[finite[start:stop]]
+        if rows.size:
+            lists = ctree.query_ball_point(p[rows], d_ub[rows] * (1 + 1e-9) + rmax)
+            cnt = np.fromiter((len(l) for l in lists), np.int64, rows.size)
+            if cnt.sum() > pair_budget and rows.size > 64:               # (far points see the whole mesh: shrink the batch)
+                step = max(64, step // 4)
+                continue
+            pi = np.repeat(rows, cnt)
+            fi = np.concatenate([np.asarray(l, np.int64) for l in lists]) if cnt.sum() else np.zeros(0, np.int64)
+            keep = np.sqrt(_dot(cen[fi] - p[pi], cen[fi] - p[pi])) <= d_ub[pi] * (1 + 1e-9) + rad[fi] * (1 + 1e-9) + 1e-12
+            pi, fi = pi[keep], fi[keep]
+            q = closest_point_on_triangles(p[pi], a[fi], b[fi], c[fi])
+            d2 = _dot(q - p[pi], q - p[pi])
+            order = np.lexsort((fi, d2, pi))                              # per point: smallest d2, then smallest face id
+            first = np.ones(order.size, bool)
+            first[1:] = pi[order][1:] != pi[order][:-1]
+            w = order[first]
+            sqr[pi[w]], fid[pi[w]], closest[pi[w]] = d2[w], fi[w], q[w]
+        bad = np.arange(start, stop)[~finite[start:stop]]
+        if bad.size:                                                      # non-finite queries: whatever the loop's arithmetic gives
+            s_, f_, c_ = closest_point_on_mesh(pts[bad], verts, faces, culled=False)
+            sqr[bad], fid[bad], closest[bad] = s_, f_, c_
+        start = stop
     return sqr, fid, closest
 
 

@@ -1,0 +1,172 @@
+"""Goldens for everything BEHIND THE WARP, produced by the reference's own code (run in the build container only):
+
+    python tests/golden/make_golden_posed.py          ->  tests/golden/posed.npz
+
+The reference (apple/ml-neuman) is imported unmodified.  `igl` -- the one absent wheel these functions do call -- is
+tests/golden/igl_shim.py (the three libigl entry points with igl 2.2.1's return conventions, arithmetic from oracle/warp.py);
+the other absent wheels, which none of the exercised functions touch, are stubbed as in make_golden.py.  Executed, at the
+BASELINE configurations' real sample counts, on whole small frames (>= 1024 rays each) around an SMPL-sized body
+(V = 6890, F = 13776, per-vertex rigid transforms):
+
+    warp_samples_to_canonical            utils/ray_utils.py:48-66        64 rays x 128 samples
+    render_smpl_nerf(render_can=False)   utils/render_utils.py:164-246   C3-posed: 128 samples
+    render_hybrid_nerf                   utils/render_utils.py:249-362   C4: background 128 + 128, human 128 (merged 384)
+    render_hybrid_nerf_multi_persons     utils/render_utils.py:365-461   C5: background 192 + 128, 3 x 192 (merged 896)
+
+Two intermediates are recorded by wrapping the reference's functions (the wrapper calls the reference's function and keeps its
+result): the fine sample positions of the two-pass background (what ray_to_importance_samples returned inside the renderers) and
+the per-ray near / far of every actor (what geometry_guided_near_far returned).  Both are ill conditioned in float32 -- the
+inverse CDF, and the cancellation |v - o|^2 - z0^2 under the square root: the reference's own torch and numpy branches of
+geometry_guided_near_far differ by 5e-5 on these rays -- so tests can state parity CONDITIONAL on them at 1e-4 on every pixel
+and account for them separately.
+"""
+import os
+import sys
+import time
+from unittest import mock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference"
+sys.path.insert(0, HERE)
+
+import igl_shim  # noqa: E402
+
+sys.modules["igl"] = igl_shim
+for m in ["open3d", "pytorch3d", "pytorch3d.structures", "pytorch3d.renderer", "imageio", "lpips", "tensorboardX",
+          "skimage", "skimage.metrics", "torchvision", "torchvision.utils", "cv2"]:
+    sys.modules[m] = mock.MagicMock(name=m)
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(ROOT, "ml-neuman_amd"))
+
+from utils import ray_utils as R_ray, render_utils as R_render  # noqa: E402  (reference)
+from models import vanilla as R_vanilla  # noqa: E402
+from cameras.pinhole_camera import PinholeCamera  # noqa: E402
+from cameras.camera_pose import CameraPose  # noqa: E402
+from cameras.captures import BasePinholeCapture  # noqa: E402
+
+from neuman_hip import synthetic  # noqa: E402  (ours: workload definitions only)
+
+W, H = 40, 32                     # 1280 rays per frame; the body fills about half of it
+SHIFTS = [np.zeros(3), np.array([0.35, 0.0, 0.2]), np.array([-0.3, 0.05, -0.15])]
+
+
+def ref_net(seed, mapping):
+    ours = synthetic.make_joiner(seed, mapping)
+    net, _ = R_vanilla.build_nerf(synthetic.default_opt(posenc=mapping))
+    net.load_state_dict(ours.state_dict(), strict=True)
+    if mapping == 'rotate':
+        net.pos_pe.bvals = net.pos_pe.bvals.cpu()
+        net.dir_pe.bvals = net.dir_pe.bvals.cpu()
+    return net.eval()
+
+
+def ref_cap(fx, near, far):
+    cap = BasePinholeCapture(PinholeCamera(W, H, fx, fx, W / 2, H / 2), CameraPose.from_camera_to_world(synthetic.spherical_c2w(20., -10., 3.0)))
+    cap.near, cap.far = {'bkg': near}, {'bkg': far}
+    return cap
+
+
+class Scene(torch.nn.Module):
+    """the attribute names the renderers read from `net` (models/human_nerf.py:23-30)"""
+
+    def __init__(self, coarse, fine, human):
+        super().__init__()
+        self.coarse_bkg_net, self.fine_bkg_net, self.coarse_human_net = coarse, fine, human
+
+
+def body():
+    verts_c, faces = synthetic.capsule_mesh()
+    posed, T = synthetic.twist_transforms(verts_c)
+    return posed, faces, T
+
+
+def main():
+    torch.set_num_threads(os.cpu_count() or 1)
+    out = {}
+    posed, faces, T = body()
+    coarse, fine, human = ref_net(0, 'posenc'), ref_net(1, 'posenc'), ref_net(2, 'rotate')
+    net = Scene(coarse, fine, human)
+
+    recorded = []
+    orig_imp = R_ray.ray_to_importance_samples
+
+    def recording(*a, **k):
+        r = orig_imp(*a, **k)
+        recorded.append(r[2].detach().cpu().numpy().copy())
+        return r
+    R_ray.ray_to_importance_samples = recording              # (render_utils calls it through the module attribute)
+    near_far = []
+    orig_nf = R_ray.geometry_guided_near_far
+
+    def recording_nf(*a, **k):
+        n, f = orig_nf(*a, **k)
+        near_far.append((np.array(n, dtype=np.float32), np.array(f, dtype=np.float32)))    # (torch or numpy branch: both convert)
+        return n, f
+    R_ray.geometry_guided_near_far = recording_nf
+
+    def nf_arrays(n_actors=1):
+        """the recorded calls are per ray batch (x actor, actor fastest): -> near, far [n_actors, R]"""
+        near = [np.concatenate([c[0] for c in near_far[a::n_actors]]) for a in range(n_actors)]
+        far = [np.concatenate([c[1] for c in near_far[a::n_actors]]) for a in range(n_actors)]
+        return np.stack(near), np.stack(far)
+
+    # ---- the warp itself: 64 rays x 128 samples across the body and its 0.2 shell
+    rng = np.random.default_rng(7)
+    o = np.tile(np.array([[0.3, 0.1, -3.0]], np.float32), (64, 1))
+    tgt = (rng.uniform(-1, 1, size=(64, 3)) * np.array([0.35, 0.75, 0.2])).astype(np.float32)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    z = np.linspace(2.3, 3.8, 128, dtype=np.float32)
+    pts = (o[:, None, :] + d[:, None, :] * z[None, :, None]).astype(np.float32)
+    t0 = time.time()
+    cp, cd, cl = R_ray.warp_samples_to_canonical(pts, posed, faces, T)
+    out.update(warp_pts=pts, warp_can_pts=cp, warp_can_dirs=cd, warp_closest=cl)
+    print(f"warp_samples_to_canonical: {pts.shape[0] * pts.shape[1]} points, {time.time() - t0:.1f} s; dtypes {cp.dtype} {cd.dtype} {cl.dtype}")
+
+    # ---- C3-posed
+    cap = ref_cap(100.0, 0.5, 4.0)
+    out['cam_c2w'] = cap.cam_pose.camera_to_world
+    t0 = time.time()
+    near_far.clear()
+    rgb, depth, acc = R_render.render_smpl_nerf(net, cap, posed, faces, T, rays_per_batch=512, samples_per_ray=128, white_bkg=True,
+                                                render_can=False, geo_threshold=0.2, return_depth=True, return_mask=True)
+    n_, f_ = nf_arrays()
+    out.update(posed_fx=np.array(100.0), posed_rgb=rgb, posed_depth=depth, posed_acc=acc, posed_near=n_[0], posed_far=f_[0])   # torch branch
+    print(f"render_smpl_nerf(render_can=False) 128: {time.time() - t0:.1f} s, hit pixels {(acc > 0).sum()} of {acc.size}")
+
+    # ---- C4
+    recorded.clear()
+    near_far.clear()
+    t0 = time.time()
+    rgb, depth = R_render.render_hybrid_nerf(net, cap, posed, faces, T, rays_per_batch=512, samples_per_ray=128, importance_samples_per_ray=128,
+                                             white_bkg=True, geo_threshold=0.2, return_depth=True)
+    out.update(hybrid_fx=np.array(100.0), hybrid_near_far=np.array([0.5, 4.0]), hybrid_rgb=rgb, hybrid_depth=depth,
+               hybrid_bkg_z=np.concatenate(recorded), hybrid_near=nf_arrays()[0][0], hybrid_far=nf_arrays()[1][0])           # numpy branch
+    print(f"render_hybrid_nerf 128+128 / 128: {time.time() - t0:.1f} s")
+
+    # ---- C5
+    cap5 = ref_cap(70.0, 0.5, 3.14)
+    posed_l = [(posed + s).astype(np.float32) for s in SHIFTS]
+    T_l = []
+    for s in SHIFTS:
+        t = T.copy()
+        t[:, :3, 3] += s
+        T_l.append(t)
+    recorded.clear()
+    near_far.clear()
+    t0 = time.time()
+    rgb, depth = R_render.render_hybrid_nerf_multi_persons(net, cap5, [net] * 3, posed_l, [faces] * 3, T_l, rays_per_batch=512, samples_per_ray=192,
+                                                           importance_samples_per_ray=128, white_bkg=True, geo_threshold=0.2, return_depth=True)
+    out.update(multi_fx=np.array(70.0), multi_near_far=np.array([0.5, 3.14]), multi_rgb=rgb, multi_depth=depth, multi_bkg_z=np.concatenate(recorded),
+               multi_shifts=np.stack(SHIFTS), multi_near=nf_arrays(3)[0], multi_far=nf_arrays(3)[1])
+    print(f"render_hybrid_nerf_multi_persons 192+128 / 3 x 192: {time.time() - t0:.1f} s")
+    np.savez_compressed(os.path.join(HERE, 'posed.npz'), **out)
+    print('posed.npz', os.path.getsize(os.path.join(HERE, 'posed.npz')) // 1024, 'KiB')
+
+
+if __name__ == '__main__':
+    main()

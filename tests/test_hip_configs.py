@@ -7,9 +7,10 @@
 
 Two kinds of statement are made:
 
-* end to end against the oracle's own rendering, with every ray that is off by more than 1e-4 EXPLAINED: it has an
-  importance sample that sits somewhere else than the oracle's (the inverse CDF of ray_utils.py:164-194 amplifies a
-  coarse-weight difference by 1 / pdf), and every ray whose samples did not move is within 1e-4;
+* end to end against the oracle's own rendering, with the deviation ATTRIBUTED quantitatively (oracle/attribution.py): the device's
+  shading pass on the oracle's samples and the oracle's on the device's both within 1e-4 on every ray, the coarse weights within
+  2e-5, every ray beyond 1e-4 among the 6 % most displaced ones, a first-order bound with a measured Lipschitz constant on every
+  ray, and no more such rays than 1.5 x what the oracle and the reference's own renderer disagree on on the same rays;
 * conditional parity at 1e-4 on EVERY pixel: the oracle evaluates its networks, merge and compositing on the device's own
   sample positions and (for posed humans) the device's own warped points -- the renderer's product code path is what
   runs on the device (the `trace` hook records its intermediates), the warp itself is checked against the oracle in
@@ -22,8 +23,6 @@ import torch
 from oracle import compositing, nerf_mlp, ray_ops as O
 
 pytestmark = pytest.mark.gpu
-MOVED = 5e-6          # a fine sample "moved": further than this from the oracle's (f32 ulp of z: 2.4e-7; a 128-sample coarse bin: 2.5e-2;
-                      # displacing EVERY sample of a ray by up to 1e-5 changes its colour by < 6e-5 on this workload)
 
 
 @pytest.fixture(scope="module")
@@ -53,45 +52,28 @@ def oracle_two_pass(nets, o, d, near, far, S, NI):
     return compositing.raw2outputs(out, zf, d)[0], zf
 
 
-def explained(err, z_dev, z_ora, tag, max_bad):
-    """every ray off by more than 1e-4 has a moved sample; every ray with unmoved samples is within 1e-4"""
-    moved = (np.abs(z_dev - z_ora) > MOVED).any(-1)
-    bad = err > 1e-4
-    unmoved_max = err[~moved].max() if (~moved).any() else 0.0
-    print(f"[{tag}] rays > 1e-4: {bad.sum()} / {err.size} (all with a moved sample: {bool((bad & ~moved).sum() == 0)}), rays with a moved "
-          f"sample {moved.sum()}, Linf over rays with unmoved samples {unmoved_max:.2e}, Linf overall {err.max():.2e}")
-    assert (bad & ~moved).sum() == 0, f"{(bad & ~moved).sum()} rays are off by > 1e-4 although every sample sits where the oracle's does"
-    assert unmoved_max <= 1e-4
-    assert bad.sum() <= max_bad, f"{bad.sum()} rays off by more than 1e-4 (allowed {max_bad})"
-    return moved
-
-
 @pytest.mark.parametrize("precision", ["mixed", "fp16x3", "bf16x3"])
 def test_c2_slice_vs_oracle(G, precision):
-    """2048 rays from the middle of the 800x800 frame, 128 + 128 samples, against the oracle end to end"""
+    """2048 rays from the middle of the 800x800 frame, 128 + 128 samples, against the oracle end to end: statements (a)-(d) of
+    oracle/attribution.py (the slice's floor and Lipschitz constant: profiles/r03_parity_floor.json, r03_lipschitz.json)"""
+    from oracle import attribution
     coarse, fine = G.syn.make_joiner(0).cuda(), G.syn.make_joiner(1).cuda()
-    coarse.precision = fine.precision = precision
     cap = G.syn.SimpleCapture(800, 800)
     o, d = O.shot_all_rays(cap.intrinsic_matrix, cap.cam_pose.camera_to_world, cap.shape)
     sl = slice(400 * 800 + 100, 400 * 800 + 100 + 2048)
     o, d = o[sl].astype(np.float32), d[sl].astype(np.float32)
-    o_rgb, o_z = oracle_two_pass([G.nets[0][1], G.nets[1][1]], o, d, 0.0, 3.14, 128, 128)
-    trace = {}
-    rgb, _ = G.render.render_vanilla_rays(coarse, fine, cu(o), cu(d), 0.0, 3.14, 128, 128, trace=trace)
-    rgb, z = rgb.cpu().numpy(), trace['bkg_z'][0].cpu().numpy()
-    err = np.abs(rgb - o_rgb).max(-1)
-    print(f"[C2 {precision}] PSNR vs oracle {psnr(rgb, o_rgb):.1f} dB")
-    # measured (r02, MI355X): mixed / fp16x3 N rays, bf16x3 ~3x as many -- the float32-class coarse pass is what keeps this at
-    # the level two float32 CPU evaluations of the reference differ at (14 of 4800 rays, tools/port_vs_reference.py)
-    explained(err, z, o_z, f"C2 {precision}", {"mixed": 16, "fp16x3": 16, "bf16x3": 60}[precision])
-    assert psnr(rgb, o_rgb) > (80.0 if precision != "bf16x3" else 70.0)
-    # conditional parity on every pixel: the oracle's fine pass on the device's sample positions
-    pts = (o[:, None, :] + d[:, None, :] * z[..., None]).astype(np.float32)
-    c_raw = nerf_mlp.joiner_forward(*G.nets[1][1], pts, np.broadcast_to(d[:, None, :], pts.shape))
-    c_rgb = compositing.raw2outputs(c_raw, z, d)[0]
-    e = np.abs(rgb - c_rgb).max()
-    print(f"[C2 {precision}] oracle fine pass on the device's samples: Linf {e:.2e}")
-    assert e < 1e-4
+    ora = attribution.oracle_two_pass([G.nets[0][1], G.nets[1][1]], o, d, 0.0, 3.14, 128, 128)
+    rgb, z, w, rgb_on = attribution.device_two_pass(G.render, coarse, fine, cu(o), cu(d), 0.0, 3.14, 128, 128, cu(ora["z"]), precision=precision)
+    print(f"[C2 {precision}] PSNR vs oracle {psnr(rgb, ora['rgb']):.1f} dB")
+    rep, fails = attribution.two_pass(rgb, z, w, rgb_on, ora["rgb"], ora["z"], ora["w"], ora["fine_on"], case="c2_slice_2048_128+128",
+                                      tag=f"C2 {precision}")
+    if precision == "bf16x3":
+        # round 1's parity mode, kept as a cross-check of the float32-class default: its sigma error (2e-5) displaces more samples,
+        # so statement (d) is relaxed for it (measured 3x the fp16x3 count); everything conditional on the samples still binds
+        fails = [f for f in fails if not f.startswith("(d)")]
+        assert rep["rays_gt_1e-4"] <= 60
+    assert not fails, fails
+    assert psnr(rgb, ora["rgb"]) > (80.0 if precision != "bf16x3" else 70.0)
 
 
 def test_c3_canonical_slice_at_128_samples(G):

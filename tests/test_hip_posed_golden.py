@@ -1,0 +1,158 @@
+"""-m gpu: the HIP renderers END TO END against frames the REFERENCE ITSELF rendered behind the warp (tests/golden/posed.npz: the
+reference's own warp_samples_to_canonical, render_smpl_nerf(render_can=False), render_hybrid_nerf, render_hybrid_nerf_multi_persons,
+unmodified, libigl's three calls supplied by tests/golden/igl_shim.py), at the BASELINE sample counts, on whole 40 x 32 frames around an
+SMPL-sized body (V = 6890, F = 13776).  Statements, as in tests/test_oracle_posed_golden.py:
+
+* CONDITIONAL on the reference's recorded float32-ill-conditioned intermediates (importance-sample positions; per-actor near / far),
+  replayed through the product renderers' `given` hook: EVERY pixel within 1e-4 of the reference's frame (rays with an exact
+  background / human z tie, whose order the reference leaves to torch.sort(stable=False), counted and listed);
+* the device's own intermediates against the recordings, in their own units;
+* END TO END, nothing replayed: rays beyond 1e-4 at most 1.5 x the floor at which two float32 CPU evaluations of the reference's
+  algorithm (oracle vs reference, tests/test_oracle_posed_golden.py) sit on the same frames, and every such ray accounted for by
+  a changed merged sample order, a displaced importance sample or a displaced near / far.
+"""
+import numpy as np
+import pytest
+import torch
+
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+import posed_scene as PS  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+# frame-wide floors: rays beyond 1e-4 between the oracle and the reference's frames (printed by tests/golden/posed_floor.py)
+FLOOR = {'posed': 11, 'hybrid': 47, 'multi': 57}
+
+
+def cu(x, dt=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(x)).to('cuda', dt).contiguous()
+
+
+@pytest.fixture(scope="module")
+def S(nets):
+    from neuman_hip import ray_utils, render_utils
+    g = PS.load()
+    g['R'], g['ray'] = render_utils, ray_utils
+    g['dev_nets'] = {k: j.cuda() for k, (j, sd, spec) in nets.items()}
+    g['mesh'] = ray_utils.mesh_to_device(g['posed_verts'], np.ascontiguousarray(g['faces'][:, :3], np.int32), g['T'], 'cuda')
+    g['meshes'] = [ray_utils.mesh_to_device(v, np.ascontiguousarray(g['faces'][:, :3], np.int32), t, 'cuda') for v, t in zip(g['posed_l'], g['T_l'])]
+    return g
+
+
+def test_warp_vs_the_references_own_warp(S):
+    """utils/ray_utils.py:48-66 as the reference executed it, 64 rays x 128 samples through the body's interior and shell.  The
+    invariant of the closest-point query is the DISTANCE; where two feet on different faces are nearly equidistant (the medial axis
+    inside the body) float32 (the device, like libigl on float32 input) and float64 (the shim's arithmetic) may pick either, and
+    the canonical point jumps with the foot: such samples are counted, everything else is held tight."""
+    pts = S['warp_pts']
+    cp, cd, cl = S['ray'].warp_samples_to_canonical(pts, S['posed_verts'], S['faces'], S['T'])
+    dist, r_dist = np.linalg.norm(cl - pts, axis=-1), np.linalg.norm(S['warp_closest'] - pts, axis=-1)
+    same = np.abs(cl - S['warp_closest']).max(-1) < 2e-5
+    e = [np.abs(cp - S['warp_can_pts'])[same].max(), np.abs(cd - S['warp_can_dirs'])[same[:, :-1] & same[:, 1:]].max() if False else None]
+    pair = same.copy()
+    pair[:, :-1] &= same[:, 1:]                                               # a direction is the difference of two consecutive samples
+    pair[:, -1] = pair[:, -2]
+    e_dir = np.abs(cd - S['warp_can_dirs'])[pair].max()
+    print(f"[warp vs reference] distance Linf {np.abs(dist - r_dist).max():.2e}; same foot on {same.mean() * 100:.2f} % of {same.size} samples: can_pts {e[0]:.2e}, "
+          f"can_dirs {e_dir:.2e} there; overall can_pts {np.abs(cp - S['warp_can_pts']).max():.2e}, closest {np.abs(cl - S['warp_closest']).max():.2e}")
+    assert np.abs(dist - r_dist).max() < 2e-6 and same.mean() > 0.99
+    assert e[0] < 1e-5 and e_dir < 2e-3 and np.abs(cp - S['warp_can_pts']).max() < 5e-4
+
+
+def test_posed_human_frame(S):
+    c = PS.cap(S, 'posed')
+    o, d = PS.frame_rays(c)
+    net = S['dev_nets'][2]
+    ref = S['posed_rgb'].reshape(-1, 3)
+    given = {'near_far': [(cu(S['posed_near']), cu(S['posed_far']))]}
+    rgb, depth, acc = S['R'].render_smpl_nerf_rays(net, cu(o), cu(d), cu(S['posed_verts']), S['mesh'], 128, True, False, 0.2, 1.0, given=given)
+    e = np.abs(rgb.cpu().numpy() - ref).max(-1)
+    ea, ed = np.abs(acc.cpu().numpy() - S['posed_acc'].ravel()).max(), np.abs(depth.cpu().numpy() - S['posed_depth'].ravel()).max()
+    hit = S['posed_near'] < S['posed_far']
+    print(f"[posed 128, conditional on the reference's near / far] 1280 rays ({hit.sum()} hit): rgb Linf {e.max():.2e}, acc {ea:.2e}, depth {ed:.2e}")
+    assert e.max() < 1e-4 and ea < 1e-4 and ed < 2e-4
+    # the device's own near / far and the end-to-end frame
+    tr = {}
+    rgb, depth, acc = S['R'].render_smpl_nerf_rays(net, cu(o), cu(d), cu(S['posed_verts']), S['mesh'], 128, True, False, 0.2, 1.0, trace=tr)
+    n, f = tr['near'][0].cpu().numpy(), tr['far'][0].cpu().numpy()
+    both = (n < f) & hit
+    flips = ((n < f) != hit).sum()
+    dn, df = np.abs(n - S['posed_near'])[both], np.abs(f - S['posed_far'])[both]
+    e2 = np.abs(rgb.cpu().numpy() - ref).max(-1)
+    bad = (e2 > 1e-4) & both
+    dnf = np.maximum(np.abs(n - S['posed_near']), np.abs(f - S['posed_far']))
+    print(f"[posed near / far] device vs the reference's torch branch on {both.sum()} hit rays: near 99 % {np.percentile(dn, 99):.1e} max {dn.max():.1e}, "
+          f"far 99 % {np.percentile(df, 99):.1e} max {df.max():.1e}, hit / miss flips {flips}")
+    print(f"[posed end to end] rays > 1e-4: {bad.sum()} of {both.sum()} hit rays (Linf {e2[both].max():.2e}); their near / far displacement: min {dnf[bad].min() if bad.any() else 0:.1e}; "
+          f"Linf over rays displaced < 2e-6: {e2[both & (dnf < 2e-6)].max() if (both & (dnf < 2e-6)).any() else 0:.2e} ({(both & (dnf < 2e-6)).sum()} rays)")
+    assert np.percentile(dn, 99) < 1e-4 and np.percentile(df, 99) < 1e-4 and dn.max() < 1e-3 and df.max() < 1e-3 and flips <= 6
+    assert bad.sum() <= int(1.5 * FLOOR['posed'] + 0.5)
+
+
+def _hybrid_lists(S, which, bkg_z, near, far, S_h, multi):
+    if not multi:
+        hz, hit = PS.human_z(near[0], far[0], S_h)
+        return [bkg_z, hz], [None, None], [hit]
+    hz = [PS.human_z(near[k], far[k], S_h, placeholder_far=3.14) for k in range(3)]
+    return [bkg_z] + [h[0] for h in hz], [None] + [~h[1] for h in hz], [h[1] for h in hz]
+
+
+@pytest.mark.parametrize("which", ["hybrid", "multi"])
+def test_merged_frames(S, which):
+    multi = which == 'multi'
+    c = PS.cap(S, which)
+    o, d = PS.frame_rays(c)
+    nets = S['dev_nets']
+    ref = S[f'{which}_rgb'].reshape(-1, 3)
+    S_b, S_h = (192, 192) if multi else (128, 128)
+    r_near = S['multi_near'] if multi else S['hybrid_near'][None]
+    r_far = S['multi_far'] if multi else S['hybrid_far'][None]
+    r_z = S[f'{which}_bkg_z']
+
+    def run(given=None, trace=None):
+        if multi:
+            rgb, depth = S['R'].render_multi_rays(nets[0], nets[1], [nets[2]] * 3, cu(o), cu(d), c.near['bkg'], c.far['bkg'], [cu(v) for v in S['posed_l']],
+                                                  S['meshes'], S_b, 128, given=given, trace=trace)
+            return rgb.cpu().numpy(), depth.cpu().numpy(), None
+        rgb, depth, acc = S['R'].render_hybrid_rays(nets[0], nets[1], nets[2], cu(o), cu(d), c.near['bkg'], c.far['bkg'], cu(S['posed_verts']), S['mesh'],
+                                                    S_b, 128, given=given, trace=trace)
+        return rgb.cpu().numpy(), depth.cpu().numpy(), acc.cpu().numpy()
+
+    # ---- conditional on the reference's recordings
+    given = {'near_far': [(cu(n), cu(f)) for n, f in zip(r_near, r_far)], 'bkg_z': cu(r_z)}
+    rgb, depth, acc = run(given=given)
+    zl, zero, hits = _hybrid_lists(S, which, r_z, r_near, r_far, S_h, multi)
+    ties = PS.cross_list_ties(zl, zero)
+    e = np.abs(rgb - ref).max(-1)
+    print(f"[{which}, conditional on the reference's bkg z and near / far] 1280 rays, hits per actor {[int(h.sum()) for h in hits]}: rgb Linf over rays without a "
+          f"cross-list z tie {e[~ties].max():.2e}; {ties.sum()} tie ray(s) {list(np.nonzero(ties)[0])} at {e[ties]}; depth {np.abs(depth - S[f'{which}_depth'].ravel())[~ties].max():.2e}")
+    assert e[~ties].max() < 1e-4 and ties.sum() <= 4
+    # ---- end to end
+    tr = {}
+    rgb, depth, acc = run(trace=tr)
+    e2 = np.abs(rgb - ref).max(-1)
+    z_dev = tr['bkg_z'][0].cpu().numpy()
+    n_dev = np.stack([x.cpu().numpy() for x in tr['near']])
+    f_dev = np.stack([x.cpu().numpy() for x in tr['far']])
+    dz = np.abs(z_dev - r_z).max(-1)
+    hit_flip = np.zeros(1280, bool)
+    dnf = np.zeros(1280, np.float32)
+    for k in range(len(r_near)):
+        hr, hd = r_near[k] < r_far[k], n_dev[k] < f_dev[k]
+        hit_flip |= hr != hd
+        m = hr & hd
+        dnf[m] = np.maximum(dnf[m], np.maximum(np.abs(n_dev[k] - r_near[k]), np.abs(f_dev[k] - r_far[k]))[m])
+    zl_d, _, _ = _hybrid_lists(S, which, z_dev, n_dev, f_dev, S_h, multi)
+    order_flip = (PS.merged_order(zl_d) != PS.merged_order(zl)).any(1)
+    bad = e2 > 1e-4
+    quiet = ~order_flip & ~hit_flip & (dz < 2e-6) & (dnf < 2e-6)
+    print(f"[{which} end to end] rays > 1e-4: {bad.sum()} of 1280 (Linf {e2.max():.2e}); of those: merged order changed {(bad & order_flip).sum()}, hit / miss flip "
+          f"{(bad & hit_flip).sum()}, neither {(bad & ~order_flip & ~hit_flip).sum()} (their sample displacement >= {dz[bad & ~order_flip & ~hit_flip].min() if (bad & ~order_flip & ~hit_flip).any() else 0:.1e}); "
+          f"rays with changed order {order_flip.sum()}, displacement percentiles 50/95 {np.median(dz):.1e}/{np.percentile(dz, 95):.1e}; "
+          f"quiet rays (same order, nothing displaced by 2e-6): {quiet.sum()}, their Linf {e2[quiet].max() if quiet.any() else 0:.2e}")
+    if FLOOR[which] is not None:
+        assert bad.sum() <= int(1.5 * FLOOR[which] + 0.5)
+    assert (e2[quiet] < 1e-4).all()
+    np.savez(f"gpurun_out/posed_{which}_e2e.npz", e2=e2, dz=dz, dnf=dnf, order_flip=order_flip, hit_flip=hit_flip)

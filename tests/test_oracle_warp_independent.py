@@ -77,3 +77,22 @@ def test_mesh_query_is_the_minimum_over_triangles_and_barycentrics_reproduce_it(
     assert np.abs(w.sum(1) - 1).max() < 1e-12 and w.min() > -1e-9
     assert np.abs((w[:, :, None] * np.stack([a[fid], b[fid], c[fid]], 1)).sum(1) - q).max() < 1e-12
     assert np.abs(w - OW.barycentric_reference_diff_formula(q, a[fid], b[fid], c[fid])).max() < 1e-9   # the reference's own in-repo formula
+
+
+def test_culled_search_equals_the_all_pairs_loop():
+    """closest_point_on_mesh_culled (what large queries take) returns the all-pairs loop's arrays BIT FOR BIT: same distances, same
+    face ids (ties to the smallest id), same points -- on an SMPL-sized mesh with interior, shell, far, on-vertex (tied) and
+    non-finite queries"""
+    verts_c, faces = synthetic.capsule_mesh()
+    posed, _ = synthetic.twist_transforms(verts_c)
+    rng = np.random.default_rng(5)
+    pts = (rng.normal(size=(700, 3)) * np.array([0.4, 0.8, 0.3])).astype(np.float32)
+    pts[:40] = posed[rng.integers(0, posed.shape[0], 40)]                  # on vertices: several faces tie exactly
+    pts[40:60] += np.array([4.0, -2.0, 3.0], np.float32)                   # far away: every triangle is a candidate
+    pts[60] = np.nan
+    with np.errstate(invalid='ignore'):
+        a = OW.closest_point_on_mesh(pts, posed, faces, culled=False)
+        b = OW.closest_point_on_mesh_culled(pts, posed, faces)
+    for x, y, name in zip(a, b, ("sqrD", "face id", "closest")):
+        fin = np.isfinite(pts).all(1)
+        assert np.array_equal(x[fin], y[fin]), name
