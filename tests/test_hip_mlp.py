@@ -210,7 +210,7 @@ def test_i8x3_composited_parity_and_full_size(gpu_nets):
 
 
 @pytest.mark.parametrize("prec", ["fp16x3", "bf16x3", "bf16", "i8x3", "fp32"])
-@pytest.mark.parametrize("R,S", [(1, 1), (3, 43), (64, 128), (700, 37)])
+@pytest.mark.parametrize("R,S", [(1, 1), (3, 43), (64, 128), (700, 37), (2100, 64), (4099, 127)])     # (the last two: several tiles per workgroup)
 def test_sigma_only_is_bit_identical(gpu_nets, prec, R, S):
     """nm_mlp_sigma_rays (the coarse pass of a two-pass render): sigma bit-identical to the full evaluation for every
     precision and ragged size; the colours are 0 where the colour head is skipped (bf16x3 / bf16)."""
