@@ -16,8 +16,6 @@
 //   * the epilogue adds nothing (bias is the accumulator's initial value), applies ReLU, splits to
 //     hi/lo with v_cvt_pk_bf16_f32 and writes one ds_write_b128 per 8 features in exactly the k-slot
 //     order the next layer's packed weights expect (mlp_layout.h).
-#include <stdlib.h>
-#include <string.h>
 #include "mlp_device.h"
 
 namespace {
@@ -802,11 +800,6 @@ namespace nm {
 int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
                     const float* z, int64_t n, int S, int in_mode, int precision, int stop_stage, float sigma_scale, float* out,
                     float* dbg, void* prof, hipStream_t stream, int sigma_only, const MlpChunk* chunk) {
-    // the sampling pass of a two-pass render: density head only, split fp16 -> the phase-shifted kernel (bit-identical sigma;
-    // NEUMAN_SIGMA_KERNEL=lockstep keeps the lock-step kernel's density-only path for A/B measurements)
-    static const bool lockstep_sigma = [] { const char* e = getenv("NEUMAN_SIGMA_KERNEL"); return e && !strcmp(e, "lockstep"); }();
-    if (precision == NM_PREC_FP16X3 && sigma_only && !L.plain_head && !L.save_h && !prof && !dbg && stop_stage == -2 && !lockstep_sigma)
-        return launch_mlp_sigma_phase(L, pts, dirs, origin, direction, z, n, S, in_mode, sigma_scale, out, stream, chunk);
     MlpArgs a;
     a.ray_idx = chunk ? chunk->ray_idx : nullptr;
     a.n_rays_dev = chunk ? chunk->n_rays_dev : nullptr;

@@ -1,7 +1,6 @@
-// Device helpers shared by the MFMA kernels of the fused PE + MLP path (mlp.hip: the lock-step and the wave-specialised i8
-// kernels; mlp_phase.hip: the phase-shifted density kernel): argument block, sample addressing, encodings, the split-16-bit
-// operand conversion, the MFMA step and the activation write -- one definition, so that kernels that must agree bit for bit
-// (the density-only launch and the full evaluation) run the same instruction sequences.
+// Device helpers of the MFMA kernels of the fused PE + MLP path (mlp.hip: the lock-step and the wave-specialised i8 kernels):
+// argument block, sample addressing, encodings, the split-16-bit operand conversion, the MFMA step and the activation write --
+// one definition, so that kernels that must agree bit for bit run the same instruction sequences.
 #pragma once
 #include "common.h"
 #include "mlp_layout.h"

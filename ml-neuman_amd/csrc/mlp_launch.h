@@ -29,10 +29,6 @@ struct MlpChunk {
 int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
                     const float* z, int64_t n, int S, int in_mode, int precision, int stop_stage, float sigma_scale, float* out,
                     float* dbg, void* prof, hipStream_t stream, int sigma_only = 0, const MlpChunk* chunk = nullptr);
-// the density-only fp16x3 launch, two waves per SIMD out of phase (mlp_phase.hip); launch_mlp_mfma routes to it
-int launch_mlp_sigma_phase(const MlpLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
-                           const float* z, int64_t n, int S, int in_mode, float sigma_scale, float* out, hipStream_t stream,
-                           const MlpChunk* chunk);
 int launch_mlp_ref(const RefLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
                    const float* z, int64_t n, int S, int in_mode, int stop_stage, float sigma_scale, float* out, float* dbg,
                    hipStream_t stream);

@@ -18,7 +18,7 @@
 //     node / test a triangle) of which the one with more ready lanes runs.  The round's first version (a per-cell candidate
 //     grid, the exact test inside the divergent candidate loop) took 39.5 ms + 10.6 ms of build for the 7.3 M samples of a
 //     512 x 512 frame; this one takes 7.8 ms + 1.0 ms, VALU-bound (86–90 % of the issue slots busy, `profiles/r01_warp_pmc.json`).
-//   tail_kernel -- one workgroup per ray: the winning triangle's barycentrics, the blended 4x4 (f64, the reference's T is f64),
+//   tail_kernel -- one workgroup per ray: the winning triangle's foot recomputed in f64, its barycentrics, the blended 4x4 (f64, the reference's T is f64),
 //     its inverse and the canonical point in f64; the ray's canonical points are staged in LDS so the finite-difference
 //     directions (:62-64) need no second pass over HBM.
 #include <float.h>
@@ -468,9 +468,34 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ pts
         const double ax = verts[i0 * 3], ay = verts[i0 * 3 + 1], az = verts[i0 * 3 + 2];
         const double v0x = (double)verts[i1 * 3] - ax, v0y = (double)verts[i1 * 3 + 1] - ay, v0z = (double)verts[i1 * 3 + 2] - az;
         const double v1x = (double)verts[i2 * 3] - ax, v1y = (double)verts[i2 * 3 + 1] - ay, v1z = (double)verts[i2 * 3 + 2] - az;
-        const double v2x = (double)q.x - ax, v2y = (double)q.y - ay, v2z = (double)q.z - az;
         const double d00 = v0x * v0x + v0y * v0y + v0z * v0z, d01 = v0x * v1x + v0y * v1y + v0z * v1z;
         const double d11 = v1x * v1x + v1y * v1y + v1z * v1z;
+        // The search's foot q is float32 arithmetic (like libigl's on float32 input): right to ~1e-6, which the finite-difference
+        // directions below divide by a sample spacing of ~1e-2.  The winner is settled, so its foot is recomputed here in float64
+        // (the same Voronoi-region test, Ericson 5.1.5): canonical points to ~1e-7, directions to ~1e-5 of a float64 evaluation of
+        // utils/ray_utils.py:53-64.  A non-finite query keeps the search's q.
+        double qx = q.x, qy = q.y, qz = q.z;
+        {
+            const double px_ = p.x, py_ = p.y, pz_ = p.z;
+            const double apx = px_ - ax, apy = py_ - ay, apz = pz_ - az;
+            const double e1 = v0x * apx + v0y * apy + v0z * apz, e2 = v1x * apx + v1y * apy + v1z * apz;      // d1, d2
+            const double bpx = apx - v0x, bpy = apy - v0y, bpz = apz - v0z;
+            const double e3 = v0x * bpx + v0y * bpy + v0z * bpz, e4 = v1x * bpx + v1y * bpy + v1z * bpz;      // d3, d4
+            const double cpx = apx - v1x, cpy = apy - v1y, cpz = apz - v1z;
+            const double e5 = v0x * cpx + v0y * cpy + v0z * cpz, e6 = v1x * cpx + v1y * cpy + v1z * cpz;      // d5, d6
+            const double vc = e1 * e4 - e3 * e2, vb = e5 * e2 - e1 * e6, va = e3 * e6 - e5 * e4;
+            double fv, fw;
+            if (e1 <= 0 && e2 <= 0) { fv = 0; fw = 0; }                                       // vertex A
+            else if (e3 >= 0 && e4 <= e3) { fv = 1; fw = 0; }                                 // vertex B
+            else if (vc <= 0 && e1 >= 0 && e3 <= 0) { fv = e1 / (e1 - e3); fw = 0; }          // edge AB
+            else if (e6 >= 0 && e5 <= e6) { fv = 0; fw = 1; }                                 // vertex C
+            else if (vb <= 0 && e2 >= 0 && e6 <= 0) { fv = 0; fw = e2 / (e2 - e6); }          // edge AC
+            else if (va <= 0 && (e4 - e3) >= 0 && (e5 - e6) >= 0) { fw = (e4 - e3) / ((e4 - e3) + (e5 - e6)); fv = 1 - fw; }   // edge BC
+            else { const double dn = 1.0 / (va + vb + vc); fv = vb * dn; fw = vc * dn; }      // interior
+            const double tx = ax + v0x * fv + v1x * fw, ty = ay + v0y * fv + v1y * fw, tz = az + v0z * fv + v1z * fw;
+            if (tx == tx && ty == ty && tz == tz && fabs(tx) <= DBL_MAX && fabs(ty) <= DBL_MAX && fabs(tz) <= DBL_MAX) { qx = tx; qy = ty; qz = tz; }
+        }
+        const double v2x = qx - ax, v2y = qy - ay, v2z = qz - az;
         const double d20 = v2x * v0x + v2y * v0y + v2z * v0z, d21 = v2x * v1x + v2y * v1y + v2z * v1z;
         const double den = d00 * d11 - d01 * d01;
         const double bv = (d11 * d20 - d01 * d21) / den, bw = (d00 * d21 - d01 * d20) / den, bu = 1.0 - bv - bw;
@@ -489,7 +514,7 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ pts
         if (live) {
             can_lds[s * 3] = cxp; can_lds[s * 3 + 1] = cyp; can_lds[s * 3 + 2] = czp;
             can_pts[i * 3] = (float)cxp; can_pts[i * 3 + 1] = (float)cyp; can_pts[i * 3 + 2] = (float)czp;
-            if (closest) { closest[i * 3] = q.x; closest[i * 3 + 1] = q.y; closest[i * 3 + 2] = q.z; }
+            if (closest) { closest[i * 3] = (float)qx; closest[i * 3 + 1] = (float)qy; closest[i * 3 + 2] = (float)qz; }
         }
     }
     __syncthreads();

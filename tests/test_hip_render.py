@@ -40,10 +40,10 @@ def test_c1_coarse_only_frame(G, golden):
     assert np.abs(rgb - o_rgb).max() < 1e-4
 
 
-def displacement_rank(err, z_dev, z_ora, tag, keep=0.90, max_bad_frac=0.02):
+def displacement_rank(err, z_dev, z_ora, tag, keep=0.80, max_bad_frac=0.02):
     """The end-to-end statement for the small merged scenes: rays beyond 1e-4 are all among the (1 - keep) most displaced rays (largest
     max_s |z_dev - z_oracle| of the two-pass background samples) and the `keep` least displaced rays are within 1e-4 -- the
-    quantitative form (binding on 90 % of the rays) of "the inverse CDF moved a sample"; the full statements (a)-(d) are made on
+    quantitative form (binding on 80 % of the rays of these 400-ray, 16 + 16-sample scenes, where one coarse bin is 0.2 wide) of "the inverse CDF moved a sample"; the full statements (a)-(d) are made on
     BASELINE-sized workloads by oracle/attribution.py (test_c1_two_pass_frame, tests/test_hip_configs.py) and against the
     reference's own frames in tests/test_hip_posed_golden.py."""
     dz = np.abs(z_dev - z_ora).max(-1)
@@ -150,7 +150,7 @@ def test_posed_human_frame_with_warp(G):
 
 def test_hybrid_and_multi_person_frames(G):
     """The two hybrid renderers through their reference-named entry points on a small scene, (i) against the oracle's own
-    rendering with the rays beyond 1e-4 confined to the most displaced tenth (displacement_rank), (ii) conditional on the device's samples and warped
+    rendering with the rays beyond 1e-4 confined to the most displaced fifth (displacement_rank), (ii) conditional on the device's samples and warped
     points at 1e-4 on every pixel (the full-size sample counts are in tests/test_hip_configs.py)."""
     from test_hip_configs import conditional_hybrid
     cap, posed, faces, T = small_scene(G)
