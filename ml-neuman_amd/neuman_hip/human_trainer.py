@@ -61,6 +61,10 @@ class HumanNeRFLoss:
             setattr(self, k, getattr(opt, k))                                            # :143-152
         self.rng = random.Random(seed)
         self.np_rng = np.random.default_rng(seed)
+        # tests: the random draws of one loss_func call given instead of drawn -- {'offset_net': i, 'dummy_dirs_randn': [R,S,3] (before
+        # normalisation), 'dummy_pts_rand': [R,S,3] in [0, 1), 'can_cap': i, 'can_pixel_choice': [128] indices into np.argwhere(np.ones(shape))}
+        # -- so that a recording of the reference's own run (tests/golden/make_golden_human_loss.py) can be replayed term by term
+        self.replay = None
         self.last = {}                                                                   # intermediates of the last call (tests, logging)
         self._can_tree = None
 
@@ -80,7 +84,9 @@ class HumanNeRFLoss:
         human_pts, human_dirs, human_z_vals = ray_utils.ray_to_samples(human_batch, self.opt.samples_per_ray, device=device, perturb=self.opt.perturb)
         b, n, _ = human_pts.shape
         cur_time = torch.ones_like(human_pts[..., 0:1]) * float(batch['cur_view_f'])
-        offset = self.rng.choice(list(self.net.offset_nets))(torch.cat([human_pts, cur_time], dim=-1))
+        nets = list(self.net.offset_nets)
+        offset_net = nets[int(self.replay['offset_net'])] if self.replay else self.rng.choice(nets)
+        offset = offset_net(torch.cat([human_pts, cur_time], dim=-1))
         mesh, raw_Ts = self.net.vertex_forward(int(batch['cap_id']))                      # autograd: pose / shape / alignment refinement
         flat = human_pts.reshape(-1, 3)
         Ts, _, _ = ray_utils.warp_samples_to_canonical_diff(flat.detach(), verts=mesh[0], faces=self.faces, T=raw_Ts[0])
@@ -93,7 +99,8 @@ class HumanNeRFLoss:
 
     # ---- :280-290
     def _color_range_regularization(self, pts, dirs, tgts):
-        other_view = self.net.coarse_human_net(pts, _unit(torch.randn_like(dirs)))       # the same points seen from random directions
+        draw = torch.as_tensor(self.replay['dummy_dirs_randn']).to(dirs) if self.replay else torch.randn_like(dirs)
+        other_view = self.net.coarse_human_net(pts, _unit(draw))                         # the same points seen from random directions
         rgb = lambda raw: torch.sigmoid(raw.reshape(-1, 4)[:, :3])                       # noqa: E731
         return self.penalize_color_range * F.mse_loss(rgb(other_view), rgb(tgts))
 
@@ -125,7 +132,7 @@ class HumanNeRFLoss:
         dist_human = self._signed_distance(pts)
         smpl_reg = smpl_reg + filled(pred, dist_human < 0, self.penalize_smpl_alpha)
         if self.penalize_dummy > 0:                                                      # random points of a 3-unit box around the canonical body
-            dummy_pts = (torch.rand_like(pts) - 0.5) * 3
+            dummy_pts = ((torch.as_tensor(self.replay['dummy_pts_rand']).to(pts) if self.replay else torch.rand_like(pts)) - 0.5) * 3
             dummy_out = self.net.coarse_human_net(dummy_pts, dirs)
             dist_dummy = self._signed_distance(dummy_pts)
             smpl_reg = smpl_reg + filled(dummy_out, dist_dummy < 0, self.penalize_dummy)
@@ -141,9 +148,9 @@ class HumanNeRFLoss:
     def _sparsity_regularization(self, device):
         sparsity_reg = torch.zeros((), device=device)
         num_can_rays = 128
-        can_cap = self.rng.choice(self.can_caps)
+        can_cap = self.can_caps[int(self.replay['can_cap'])] if self.replay else self.rng.choice(self.can_caps)
         coords = np.argwhere(np.ones(can_cap.shape))
-        coords = coords[self.np_rng.integers(0, len(coords), num_can_rays)][:, ::-1]
+        coords = coords[np.asarray(self.replay['can_pixel_choice']) if self.replay else self.np_rng.integers(0, len(coords), num_can_rays)][:, ::-1]
         can_orig, can_dir = ray_utils.shot_rays(can_cap, coords)
         can_pts, can_dirs, can_z_vals = ray_utils.ray_to_samples(
             {'origin': torch.from_numpy(can_orig).float().to(device), 'direction': torch.from_numpy(can_dir).float().to(device),

@@ -150,14 +150,20 @@ class SMPLDiff(torch.nn.Module):
                 model = pickle.load(f, encoding='latin1')
         dev = torch.device(device)
         t = lambda x: torch.from_numpy(_dense_f32(x)).to(dev)                      # noqa: E731
+        # buffers named, shaped and ordered as models/smpl.py:66-98 registers them, so that a HumanNeRF state_dict ('body_model.*')
+        # matches the reference's key for key
+        self.register_buffer('faces_tensor', torch.from_numpy(np.asarray(model['f']).astype(np.int64)).to(dev))
         self.register_buffer('v_template', t(model['v_template']))                # [V,3]
         self.register_buffer('shapedirs', t(model['shapedirs']))                  # [V,3,NB]
         self.register_buffer('J_regressor', t(model['J_regressor']))              # [J,V]
-        self.register_buffer('lbs_weights', t(model['weights']))                  # [V,J]
+        posedirs = _dense_f32(model['posedirs'])                                  # computed and ignored by the reference's lbs (:320-334)
+        self.register_buffer('posedirs', torch.from_numpy(np.ascontiguousarray(posedirs.reshape(-1, posedirs.shape[-1]).T)).to(dev))
         parents = np.asarray(model['kintree_table'])[0].astype(np.float32).astype(np.int64)
         parents[0] = -1
-        self.parents = [int(p) for p in parents]
-        self.register_buffer('da_smpl', torch.from_numpy(da_pose(len(self.parents))).to(dev)[None])
+        self.register_buffer('parents', torch.from_numpy(parents).to(dev))
+        self.register_buffer('lbs_weights', t(model['weights']))                  # [V,J]
+        self.parents_list = [int(p) for p in parents]
+        self.register_buffer('da_smpl', torch.from_numpy(da_pose(len(self.parents_list))).to(dev)[None], persistent=False)
 
     @staticmethod
     def rodrigues(rot_vecs):
@@ -173,17 +179,17 @@ class SMPLDiff(torch.nn.Module):
 
     def transformations(self, pose, beta):
         """pose [1,J*3], beta [1,NB] -> (vertex transforms T [V,4,4] from the shaped template to the posed body, v_shaped [V,3])"""
-        J = len(self.parents)
+        J = len(self.parents_list)
         v_shaped = self.v_template + torch.einsum('vkl,l->vk', self.shapedirs, beta[0])            # smpl.py:312
         joints = self.J_regressor @ v_shaped                                                       # :315
         R = self.rodrigues(pose.reshape(J, 3))                                                      # :319-320
         rel = joints.clone()
-        rel[1:] = joints[1:] - joints[[p for p in self.parents[1:]]]                               # :474-476
+        rel[1:] = joints[1:] - joints[[p for p in self.parents_list[1:]]]                               # :474-476
         local = torch.cat([torch.cat([R, rel[:, :, None]], 2),
                            torch.tensor([0., 0., 0., 1.], dtype=R.dtype, device=R.device).expand(J, 1, 4)], 1)    # [J,4,4]
         chain = [local[0]]
         for j in range(1, J):                                                                       # :487-493
-            chain.append(chain[self.parents[j]] @ local[j])
+            chain.append(chain[self.parents_list[j]] @ local[j])
         G = torch.stack(chain)
         # remove the rest pose: A_j = G_j - [0 | G_j[:3,:3] J_j]                                    # :499-503
         shift = torch.einsum('jab,jb->ja', G[:, :3, :3], joints)
@@ -192,11 +198,12 @@ class SMPLDiff(torch.nn.Module):
         T = torch.einsum('vj,jab->vab', self.lbs_weights, A)                                        # :338-341
         return T, v_shaped
 
-    def vertex_forward(self, pose, beta, alignment, scale):
+    def vertex_forward(self, pose, beta, alignment, scale, da_pose=None):
         """pose [1,J*3], beta [1,NB], alignment [4,4] (human_nerf.py's self.alignments[idx]: its TRANSPOSE is applied), scale ->
-        world_verts [1,V,3], T_da2scene [1,V,4,4]; differentiable in pose, beta and alignment."""
+        world_verts [1,V,3], T_da2scene [1,V,4,4]; differentiable in pose, beta and alignment.  `da_pose` [1,J*3]: the canonical
+        pose to use instead of the built-in one (HumanNeRF keeps it as its `da_smpl` parameter)."""
         T_pose, v_shaped = self.transformations(pose, beta)
-        T_da, _ = self.transformations(self.da_smpl.to(pose.dtype), beta)
+        T_da, _ = self.transformations((self.da_smpl if da_pose is None else da_pose).to(pose.dtype), beta)
         T_da2pose = T_pose @ torch.inverse(T_da)                                                    # human_nerf.py:109
         T = alignment.T @ T_da2pose                                                                 # :110
         s = torch.eye(4, dtype=T.dtype, device=T.device)

@@ -92,4 +92,38 @@ out["state_dict"] = {"keys_equal": list(r_coarse.state_dict().keys()) == list(o_
                      "shapes_equal": all(a.shape == b.shape for a, b in zip(r_coarse.state_dict().values(), o_coarse.state_dict().values())),
                      "reference_class": f"{type(r_coarse).__module__}.{type(r_coarse).__name__}",
                      "values_round_trip": all(torch.equal(a, b) for a, b in zip(r_coarse.state_dict().values(), o_coarse.state_dict().values()))}
+
+# HumanNeRF with per-frame body parameters (train.py:103): the reference's module (its hard-coded SMPL asset directory redirected to a
+# synthetic model in SMPL's file layout; the class itself unmodified, built on the reference's ORIGINAL models.vanilla) against
+# neuman_hip.human_nerf.HumanNeRF -- same state_dict keys and shapes, strict loads in both directions
+import pickle  # noqa: E402
+import tempfile  # noqa: E402
+import numpy as np  # noqa: E402
+from neuman_hip import human_nerf as our_hn, synthetic  # noqa: E402
+for name in ("models.vanilla", "models.human_nerf"):
+    sys.modules.pop(name, None)
+ref_vanilla = importlib.import_module("models.vanilla")            # a fresh, un-rebound copy
+ref_hn = importlib.import_module("models.human_nerf")
+from models import smpl as ref_smpl  # noqa: E402
+pose, betas, align = synthetic.smpl_like_frames(3, 0)
+al = np.stack([np.concatenate([align[f'{i:05d}.png'], np.array([[0.], [0.], [0.], [1.]])], 1) for i in range(3)]).astype(np.float32)
+with tempfile.TemporaryDirectory() as tmp:
+    with open(os.path.join(tmp, 'SMPL_NEUTRAL.pkl'), 'wb') as f:
+        pickle.dump(synthetic.smpl_like_model(0), f, protocol=2)
+    real_smpl = ref_smpl.SMPL
+    ref_hn.SMPL = lambda path, gender='neutral', device=None: real_smpl(tmp, gender=gender, device=device)
+    with contextlib.redirect_stdout(io.StringIO()):
+        r_net = ref_hn.HumanNeRF(opt, pose.copy(), betas.copy(), al.copy(), scale=1.3)
+        o_net = our_hn.HumanNeRF(opt, pose.copy(), betas.copy(), al.copy(), scale=1.3, smpl_dir=tmp)
+rs, os_ = r_net.state_dict(), o_net.state_dict()
+o_net.load_state_dict(rs, strict=True)
+r_net.load_state_dict(os_, strict=True)
+with torch.no_grad():
+    rv, rT = r_net.vertex_forward(1)
+    ov, oT = o_net.vertex_forward(1)
+out["human_nerf_with_body"] = {"keys_equal": sorted(rs.keys()) == sorted(os_.keys()), "n_keys": len(rs),
+                               "shapes_equal": all(rs[k].shape == os_[k].shape and rs[k].dtype == os_[k].dtype for k in rs),
+                               "only_reference": sorted(set(rs) - set(os_)), "only_ours": sorted(set(os_) - set(rs)),
+                               "reference_class_module": type(r_net.coarse_bkg_net).__module__,
+                               "vertex_forward_linf": [float((rv - ov).abs().max()), float((rT - oT).abs().max())]}
 print(json.dumps(out))

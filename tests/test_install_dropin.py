@@ -37,3 +37,14 @@ def test_checkpoints_load_strictly_both_ways(report):
     s = report["state_dict"]
     assert s["keys_equal"] and s["shapes_equal"] and s["values_round_trip"]
     assert s["reference_class"] == "models.vanilla.Joiner"
+
+
+def test_human_nerf_module_has_the_references_state_dict(report):
+    """neuman_hip.human_nerf.HumanNeRF(opt, poses, betas, alignments, scale) against models/human_nerf.py's (its hard-coded SMPL asset
+    path redirected to a synthetic model; train.py:103's constructor call): the 101 `hybrid_model_state_dict` keys -- networks, offset
+    nets, poses / betas / alignments / da_smpl, body_model.* buffers -- equal in name, shape and dtype, strict loads in both directions,
+    vertex_forward equal to float32 round-off"""
+    h = report["human_nerf_with_body"]
+    assert h["keys_equal"] and h["shapes_equal"] and h["n_keys"] == 101 and not h["only_reference"] and not h["only_ours"], h
+    assert h["reference_class_module"] == "models.vanilla"
+    assert max(h["vertex_forward_linf"]) < 5e-6, h["vertex_forward_linf"]
