@@ -266,6 +266,34 @@ int nm_smpl_frames(nm_smpl_t smpl, const float* poses, const float* betas, const
                    int precise, double* T_out, float* world_out, float* static_out, nm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused per-ray passes (nm_render_rays_bkg / nm_render_rays_human / merge + composite): ONE call per pass of the
+ * reference's renderers -- utils/render_utils.py:131-151 / 287-297 (two-pass background), :213-229 / 320-329 (human pass of
+ * compacted hit rays), :330-345 / 441-456 (merge + composite) -- the pass's kernels enqueued back to back on `stream`: no host
+ * synchronisation inside, no hidden allocation (intermediates in the caller's `workspace`, sized by the *_workspace_floats
+ * queries), the same kernels as the step-by-step entry points and therefore the same bits.
+ *
+ *   nm_render_rays_bkg   origin / direction [R,3], near / far [R], t_vals [S] and u [N] = the caller's torch.linspace(0,1,.);
+ *       fine == NULL and N == 0: one pass (S samples); else coarse density pass -> compositing weights -> importance samples ->
+ *       fine pass on S + N samples.  raw_out [R,S+N,4] and z_out [R,S+N] always; rgb [R,3] / depth [R] / acc [R] when rgb != NULL
+ *       (hybrid renderers composite later, after merging).  precision_*: NM_PREC_* of each pass.
+ *   nm_render_rays_human   already compacted hit rays with their per-ray near / far; mesh == NULL (and T == NULL): canonical
+ *       render (camera-ray directions); else ray_to_samples -> nm_warp_to_canonical(mesh, T) -> network on the warped points and
+ *       finite-difference directions.  sigma_scale = interval_comp (:229).
+ *   nm_merge_composite   nm_merge_sorted + nm_composite of the merged list (disp discarded).
+ * ------------------------------------------------------------------------------------------- */
+int64_t nm_render_rays_bkg_workspace_floats(int64_t R, int S, int N);
+int nm_render_rays_bkg(nm_mlp_t coarse, nm_mlp_t fine, const float* origin, const float* direction, const float* near, const float* far,
+                       int64_t R, int S, int N, const float* t_vals, const float* u, int white_bkg, int precision_coarse, int precision_fine,
+                       float* workspace, float* raw_out, float* z_out, float* rgb, float* depth, float* acc, nm_stream_t stream);
+int64_t nm_render_rays_human_workspace_floats(int64_t R, int S, int posed);
+int nm_render_rays_human(nm_mlp_t human, nm_mesh_t mesh, const double* T, const float* origin, const float* direction, const float* near,
+                         const float* far, int64_t R, int S, const float* t_vals, int white_bkg, float sigma_scale, int precision,
+                         float* workspace, float* raw_out, float* z_out, float* rgb, float* depth, float* acc, nm_stream_t stream);
+int64_t nm_merge_composite_workspace_floats(int64_t R, int Sa, int Sb);
+int nm_merge_composite(const float* za, const float* rawa, int Sa, const float* zb, const float* rawb, int Sb, int64_t R, const float* rays_d,
+                       int white_bkg, float* workspace, float* rgb, float* depth, float* acc, nm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * a13  sorted merge of sample lists -- reference utils/render_utils.py:330-337, 441-448
  *   Two lists per ray, each already sorted in z: (za [R,Sa], rawa [R,Sa,4]) and (zb, rawb).
  *   Writes z_out [R,Sa+Sb] sorted and raw_out [R,Sa+Sb,4] gathered in the same order

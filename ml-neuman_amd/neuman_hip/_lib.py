@@ -84,6 +84,14 @@ SIGNATURES = {
     "nm_shot_rays": (i32, [c_i32p, i64, i32, i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), c_f32p, c_f32p,
                            c_stream]),
     "nm_shot_rays_cams": (i32, [c_i32p, c_i32p, i64, i32, ctypes.c_void_p, i32, c_f32p, c_f32p, c_stream]),
+    "nm_render_rays_bkg_workspace_floats": (i64, [i64, i32, i32]),
+    "nm_render_rays_bkg": (i32, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, i32, c_f32p, c_f32p, i32, i32, i32, c_f32p, c_f32p,
+                                 c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
+    "nm_render_rays_human_workspace_floats": (i64, [i64, i32, i32]),
+    "nm_render_rays_human": (i32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, c_f32p, i32, ctypes.c_float, i32,
+                                   c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
+    "nm_merge_composite_workspace_floats": (i64, [i64, i32, i32]),
+    "nm_merge_composite": (i32, [c_f32p, c_f32p, i32, c_f32p, c_f32p, i32, i64, c_f32p, i32, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "nm_frame_to_uint8": (i32, [c_f32p, i64, ctypes.c_void_p, c_stream]),
     "nm_ssd_u8": (i32, [ctypes.c_void_p, ctypes.c_void_p, i64, ctypes.c_void_p, c_stream]),
 }

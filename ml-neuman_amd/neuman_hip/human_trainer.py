@@ -73,8 +73,8 @@ class HumanNeRFLoss:
         o, d = batch['origin'].to(device, torch.float32).contiguous(), batch['direction'].to(device, torch.float32).contiguous()
         near, far = batch['bkg_near'].to(device, torch.float32).reshape(-1).contiguous(), batch['bkg_far'].to(device, torch.float32).reshape(-1).contiguous()
         with torch.no_grad():
-            raw, z = render_utils.bkg_pass_rays(self.net.coarse_bkg_net, self.net.fine_bkg_net, o, d, near, far, self.opt.samples_per_ray,
-                                                self.opt.importance_samples_per_ray, self.opt.white_bkg)
+            raw, z = render_utils.bkg_pass_rays_fused(self.net.coarse_bkg_net, self.net.fine_bkg_net, o, d, near, far, self.opt.samples_per_ray,
+                                                      self.opt.importance_samples_per_ray, self.opt.white_bkg)
         return d, z, raw
 
     # ---- :241-278

@@ -138,6 +138,35 @@ def _given_near_far(given, actor, i, j, o, d, verts, geo_threshold):
     return ray_utils.geometry_guided_near_far(o, d, verts, geo_threshold)
 
 
+def _ws(n_floats, device):
+    return torch.empty(max(int(n_floats), 4), device=device, dtype=torch.float32)
+
+
+def bkg_pass_rays_fused(coarse_net, fine_net, o, d, near, far, samples_per_ray, importance_samples_per_ray, white_bkg, precision=None):
+    """bkg_pass_rays as ONE C call (nm_render_rays_bkg: sample -> coarse density pass -> compositing weights -> importance samples ->
+    fine pass, enqueued back to back; same kernels, same bits).  What the trainers' frozen background evaluation uses: at 2048 rays
+    the five launches are shorter than the Python between them."""
+    _lib.require_gpu()
+    R, S = o.shape[0], int(samples_per_ray)
+    N = int(importance_samples_per_ray) if fine_net is not None else 0
+    dev = o.device
+    for n_ in (coarse_net, fine_net):
+        if n_ is not None:
+            n_._guard(o, d, near)
+    raw = torch.empty((R, S + N, 4), device=dev, dtype=torch.float32)
+    z = torch.empty((R, S + N), device=dev, dtype=torch.float32)
+    ws = _ws(_lib.lib().nm_render_rays_bkg_workspace_floats(R, S, N), dev)
+    t_vals = torch.linspace(0., 1., steps=S, device=dev)
+    u = torch.linspace(0., 1., steps=N, device=dev) if N else None
+    _lib.check(_lib.lib().nm_render_rays_bkg(
+        coarse_net.handle(), fine_net.handle() if fine_net is not None else None, _lib.dev_ptr(o.contiguous()), _lib.dev_ptr(d.contiguous()),
+        _lib.dev_ptr(near.reshape(-1).contiguous()), _lib.dev_ptr(far.reshape(-1).contiguous()), R, S, N, _lib.dev_ptr(t_vals), _lib.dev_ptr(u),
+        int(bool(white_bkg)), coarse_net._prec(precision, None if fine_net is not None else 'shading'),
+        fine_net._prec(precision, 'shading') if fine_net is not None else 0, _lib.dev_ptr(ws), _lib.dev_ptr(raw), _lib.dev_ptr(z), None, None, None,
+        _lib.stream_ptr()), "nm_render_rays_bkg")
+    return raw, z
+
+
 def bkg_pass_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, importance_samples_per_ray, white_bkg,
                   precision=None, trace=None, given_z=None):
     """Coarse (+ fine) background evaluation of R rays -> (raw [R,S',4], z [R,S'])  (render_utils.py:131-151, 287-297).
@@ -191,15 +220,45 @@ def render_vanilla_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, 
 
 def human_pass_rays(human_net, o, d, near, far, samples_per_ray, mesh=None, render_can=False, sigma_scale=1.0, precision=None,
                     trace=None):
-    """Human-net evaluation of (already compacted) hit rays -> (raw [R,S,4], z [R,S])  (render_utils.py:213-229, 320-329)."""
-    if render_can:
-        _, _, z = ray_utils.sample_z(o, d, near, far, samples_per_ray)
-        _note(trace, human_z=z)
-        return human_net.forward_rays(o, d, z, precision=precision, sigma_scale=sigma_scale, role='shading'), z
-    pts, _, z = ray_utils.sample_z(o, d, near, far, samples_per_ray, want_points=True)
-    can_pts, can_dirs, _ = ray_utils.warp_to_canonical_dev(pts, mesh)
-    _note(trace, human_z=z, can_pts=can_pts, can_dirs=can_dirs)
-    return human_net(can_pts, can_dirs, precision=precision, sigma_scale=sigma_scale, role='shading'), z
+    """Human-net evaluation of (already compacted) hit rays -> (raw [R,S,4], z [R,S])  (render_utils.py:213-229, 320-329): ONE C call
+    per actor pass (nm_render_rays_human: sample -> warp -> network, enqueued back to back)."""
+    _lib.require_gpu()
+    R, S = o.shape[0], int(samples_per_ray)
+    dev = o.device
+    human_net._guard(o, d, near)
+    posed = not render_can
+    raw = torch.empty((R, S, 4), device=dev, dtype=torch.float32)
+    z = torch.empty((R, S), device=dev, dtype=torch.float32)
+    ws = _ws(_lib.lib().nm_render_rays_human_workspace_floats(R, S, int(posed)), dev)
+    t_vals = torch.linspace(0., 1., steps=S, device=dev)
+    _lib.check(_lib.lib().nm_render_rays_human(
+        human_net.handle(), mesh.handle if posed else None, _lib.dev_ptr(mesh.T, torch.float64, 'T') if posed else None, _lib.dev_ptr(o.contiguous()),
+        _lib.dev_ptr(d.contiguous()), _lib.dev_ptr(near.reshape(-1).contiguous()), _lib.dev_ptr(far.reshape(-1).contiguous()), R, S, _lib.dev_ptr(t_vals), 1,
+        float(sigma_scale), human_net._prec(precision, 'shading'), _lib.dev_ptr(ws), _lib.dev_ptr(raw), _lib.dev_ptr(z), None, None, None, _lib.stream_ptr()),
+        "nm_render_rays_human")
+    if trace is not None:
+        if posed:
+            n3 = (R * S * 3 + 3) & ~3
+            _note(trace, human_z=z, can_pts=ws[n3:n3 + R * S * 3].reshape(R, S, 3).clone(), can_dirs=ws[2 * n3:2 * n3 + R * S * 3].reshape(R, S, 3).clone())
+        else:
+            _note(trace, human_z=z)
+    return raw, z
+
+
+def merge_composite(za, rawa, zb, rawb, rays_d, white_bkg=True):
+    """merge_sorted + raw2outputs of the merged list as ONE C call (render_utils.py:330-345) -> (rgb [R,3], depth [R], acc [R])"""
+    _lib.require_gpu()
+    R, Sa = za.shape
+    Sb = zb.shape[1]
+    dev = za.device
+    rgb = torch.empty((R, 3), device=dev, dtype=torch.float32)
+    depth = torch.empty(R, device=dev, dtype=torch.float32)
+    acc = torch.empty(R, device=dev, dtype=torch.float32)
+    ws = _ws(_lib.lib().nm_merge_composite_workspace_floats(R, Sa, Sb), dev)
+    _lib.check(_lib.lib().nm_merge_composite(_lib.dev_ptr(za.contiguous()), _lib.dev_ptr(rawa.contiguous()), Sa, _lib.dev_ptr(zb.contiguous()),
+                                             _lib.dev_ptr(rawb.contiguous()), Sb, R, _lib.dev_ptr(rays_d.contiguous()), int(bool(white_bkg)), _lib.dev_ptr(ws),
+                                             _lib.dev_ptr(rgb), _lib.dev_ptr(depth), _lib.dev_ptr(acc), _lib.stream_ptr()), "nm_merge_composite")
+    return rgb, depth, acc
 
 
 def render_smpl_nerf_rays(human_net, o, d, posed_verts, mesh, samples_per_ray, white_bkg=True, render_can=False,
@@ -254,9 +313,8 @@ def render_hybrid_rays(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far,
         _note(trace, hit=hit + i)
         h_raw, h_z = human_pass_rays(human_net, ho, hd, hn, hf, samples_per_ray, mesh, False, 1.0, precision, trace)
         S_b = bkg_z.shape[1]
-        z_all, raw_all = merge_sorted(ray_utils.gather_rows(bkg_z, hit), ray_utils.gather_rows(bkg_raw.reshape(j - i, -1), hit).reshape(-1, S_b, 4),
-                                      h_z, h_raw)
-        _rgb, _, _, _, _depth = raw2outputs(raw_all, z_all, hd, white_bkg=white_bkg, want_weights=False)
+        _rgb, _depth, _ = merge_composite(ray_utils.gather_rows(bkg_z, hit), ray_utils.gather_rows(bkg_raw.reshape(j - i, -1), hit).reshape(-1, S_b, 4),
+                                          h_z, h_raw, hd, white_bkg)
         _, _, _acc, _, _ = raw2outputs(h_raw, h_z, hd, white_bkg=white_bkg, want_weights=False)          # :345-350
         ray_utils.scatter_rows(rgb[i:j], hit, _rgb)
         ray_utils.scatter_rows(depth[i:j], hit, _depth)

@@ -1,0 +1,86 @@
+"""-m gpu: the fused per-pass entry points (include/neuman_hip.h: nm_render_rays_bkg, nm_render_rays_human, nm_merge_composite -- one C call
+per pass of the reference's renderers, utils/render_utils.py:131-151, 213-229, 330-345) against the step-by-step entry points: the same
+kernels enqueued by one call, so every output is equal BIT FOR BIT; empty batches; their composites against the oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import compositing
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G(nets):
+    import types
+    from neuman_hip import _lib, ray_utils, render_utils, synthetic
+    return types.SimpleNamespace(lib=_lib, ray=ray_utils, render=render_utils, syn=synthetic, nets={k: j.cuda() for k, (j, sd, spec) in nets.items()})
+
+
+def rays(G, R, seed=0):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    o = torch.randn((R, 3), device='cuda', generator=g) * 0.2 + torch.tensor([0., 0., -3.], device='cuda')
+    d = torch.nn.functional.normalize(torch.randn((R, 3), device='cuda', generator=g) * 0.15 + torch.tensor([0., 0., 1.], device='cuda'), dim=-1)
+    return o.contiguous(), d.contiguous()
+
+
+@pytest.mark.parametrize("R,S,N", [(1, 4, 4), (700, 37, 21), (3000, 128, 128), (513, 64, 0)])
+def test_background_pass_in_one_call(G, R, S, N):
+    o, d = rays(G, R)
+    near, far = torch.full((R,), 0.5, device='cuda'), torch.full((R,), 5.0, device='cuda')
+    fine = G.nets[1] if N else None
+    raw_a, z_a = G.render.bkg_pass_rays(G.nets[0], fine, o, d, near, far, S, N, True)
+    raw_b, z_b = G.render.bkg_pass_rays_fused(G.nets[0], fine, o, d, near, far, S, N, True)
+    assert torch.equal(z_a, z_b) and torch.equal(raw_a, raw_b)
+    # and with the composite inside the call
+    lib = G.lib.lib()
+    ws = torch.empty(int(lib.nm_render_rays_bkg_workspace_floats(R, S, N)) + 4, device='cuda')
+    raw_c, z_c = torch.empty_like(raw_a), torch.empty_like(z_a)
+    rgb, depth, acc = torch.empty((R, 3), device='cuda'), torch.empty(R, device='cuda'), torch.empty(R, device='cuda')
+    t_vals = torch.linspace(0., 1., steps=S, device='cuda')
+    u = torch.linspace(0., 1., steps=N, device='cuda') if N else None
+    P = G.lib.dev_ptr
+    G.lib.check(lib.nm_render_rays_bkg(G.nets[0].handle(), fine.handle() if fine is not None else None, P(o), P(d), P(near), P(far), R, S, N, P(t_vals), P(u), 1,
+                                       G.nets[0]._prec(None, None if fine is not None else 'shading'), fine._prec(None, 'shading') if fine is not None else 0,
+                                       P(ws), P(raw_c), P(z_c), P(rgb), P(depth), P(acc), G.lib.stream_ptr()), "nm_render_rays_bkg")
+    r2 = G.render.raw2outputs(raw_a, z_a, d, want_weights=False)
+    assert torch.equal(raw_c, raw_a) and torch.equal(rgb, r2[0]) and torch.equal(acc, r2[2]) and torch.equal(depth, r2[4])
+    o_rgb = compositing.raw2outputs(raw_a.cpu().numpy(), z_a.cpu().numpy(), d.cpu().numpy())[0]
+    assert np.abs(rgb.cpu().numpy() - o_rgb).max() < 2e-5
+
+
+def test_human_pass_and_merge_composite_in_one_call(G):
+    verts_c, faces = G.syn.capsule_mesh(n_rings=20, n_seg=24)
+    posed, T = G.syn.twist_transforms(verts_c)
+    mesh = G.ray.mesh_to_device(posed, np.ascontiguousarray(faces[:, :3], np.int32), T, 'cuda')
+    o, d = rays(G, 600, 3)
+    near, far = G.ray.geometry_guided_near_far(o, d, torch.as_tensor(posed).cuda(), 0.2)
+    hit, _ = G.ray.compact_hits(near, far)
+    assert 50 < hit.numel() < 600
+    ho, hd, hn, hf = (G.ray.gather_rows(x, hit) for x in (o, d, near, far))
+    human = G.nets[2]
+    for render_can in (False, True):
+        trace = {}
+        raw, z = G.render.human_pass_rays(human, ho, hd, hn, hf, 48, mesh, render_can, 0.7, trace=trace)
+        # step by step
+        if render_can:
+            z2 = G.ray.sample_z(ho, hd, hn, hf, 48)[2]
+            raw2 = human.forward_rays(ho, hd, z2, sigma_scale=0.7, role='shading')
+        else:
+            pts, _, z2 = G.ray.sample_z(ho, hd, hn, hf, 48, want_points=True)
+            cp, cd, _ = G.ray.warp_to_canonical_dev(pts, mesh)
+            raw2 = human(cp, cd, sigma_scale=0.7, role='shading')
+            assert torch.equal(trace['can_pts'][0], cp) and torch.equal(trace['can_dirs'][0], cd)
+        assert torch.equal(z, z2) and torch.equal(raw, raw2)
+    # merge + composite
+    bkg_raw, bkg_z = G.render.bkg_pass_rays(G.nets[0], G.nets[1], ho, hd, torch.full_like(hn, 0.5), torch.full_like(hn, 5.0), 32, 32, True)
+    rgb, depth, acc = G.render.merge_composite(bkg_z, bkg_raw, z, raw, hd)
+    z_all, raw_all = G.render.merge_sorted(bkg_z, bkg_raw, z, raw)
+    r2 = G.render.raw2outputs(raw_all, z_all, hd, want_weights=False)
+    assert torch.equal(rgb, r2[0]) and torch.equal(acc, r2[2]) and torch.equal(depth, r2[4])
+    # empty batches are accepted
+    e = torch.empty((0, 3), device='cuda')
+    raw0, z0 = G.render.human_pass_rays(human, e, e, torch.empty(0, device='cuda'), torch.empty(0, device='cuda'), 16, mesh, False, 1.0)
+    assert raw0.shape == (0, 16, 4) and z0.shape == (0, 16)
