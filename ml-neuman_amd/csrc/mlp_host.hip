@@ -406,6 +406,7 @@ struct nm_mlp_s {
     uint8_t* d_image16;    // NM_PREC_FP16X3: the same layout, split fp16 of W * 2^8 | pad | bias * 2^13
     float* d_consts8;      // NM_PREC_I8X3: units | biases | kappa (the tail of the nm_mlp_pack_i8 image)
     uint8_t* d_stream8;    // NM_PREC_I8X3: the image's fragments as per-wave streams (nerf_mlp_i8w_kernel)
+    uint8_t* d_image8;     // NM_PREC_I8X3: the block image itself, fragments + prefetch pad (nerf_mlp_i8s_kernel)
     float* d_petab;        // 192 floats
     float* d_ref;          // transposed f32 weights | natural biases (NM_PREC_FP32 path)
     float* d_wscale16;     // nm_mlp_refresh_f16: the per-stage weight scales of the fp16 image (device scratch)
@@ -514,13 +515,15 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     m->pos_octaves = octaves(tab, desc->pos_n_freqs);
     m->dir_octaves = octaves(tab + 96, desc->dir_n_freqs);
 
-    m->d_image = nullptr; m->d_image16 = nullptr; m->d_consts8 = nullptr; m->d_stream8 = nullptr; m->d_petab = nullptr; m->d_ref = nullptr; m->d_wscale16 = nullptr;
+    m->d_image = nullptr; m->d_image16 = nullptr; m->d_consts8 = nullptr; m->d_stream8 = nullptr; m->d_image8 = nullptr; m->d_petab = nullptr; m->d_ref = nullptr; m->d_wscale16 = nullptr;
     int rc = nm::check_hip(hipMalloc(&m->d_image, (size_t)bytes), "nm_mlp_create: hipMalloc(image)");
     const size_t consts_off = (size_t)(nm::kWeightBytes8 + nm::kWeightPadBytes), consts_bytes = img8.size() - consts_off;
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_consts8, consts_bytes), "nm_mlp_create: hipMalloc(consts8)");
     if (!rc) rc = nm::check_hip(hipMemcpy(m->d_consts8, img8.data() + consts_off, consts_bytes, hipMemcpyHostToDevice), "nm_mlp_create: upload consts8");
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_stream8, str8.size()), "nm_mlp_create: hipMalloc(stream8)");
     if (!rc) rc = nm::check_hip(hipMemcpy(m->d_stream8, str8.data(), str8.size(), hipMemcpyHostToDevice), "nm_mlp_create: upload stream8");
+    if (!rc) rc = nm::check_hip(hipMalloc(&m->d_image8, consts_off), "nm_mlp_create: hipMalloc(image8)");
+    if (!rc) rc = nm::check_hip(hipMemcpy(m->d_image8, img8.data(), consts_off, hipMemcpyHostToDevice), "nm_mlp_create: upload image8");
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_petab, sizeof(tab)), "nm_mlp_create: hipMalloc(petab)");
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_ref, ref.size() * 4), "nm_mlp_create: hipMalloc(ref)");
     if (!rc) rc = nm::check_hip(hipMemcpy(m->d_image, img.data(), (size_t)bytes, hipMemcpyHostToDevice), "nm_mlp_create: upload image");
@@ -558,6 +561,7 @@ int nm_mlp_destroy(nm_mlp_t m) {
     if (m->d_image16) (void)hipFree(m->d_image16);
     if (m->d_consts8) (void)hipFree(m->d_consts8);
     if (m->d_stream8) (void)hipFree(m->d_stream8);
+    if (m->d_image8) (void)hipFree(m->d_image8);
     if (m->d_petab) (void)hipFree(m->d_petab);
     if (m->d_ref) (void)hipFree(m->d_ref);
     if (m->d_wscale16) (void)hipFree(m->d_wscale16);
@@ -598,6 +602,10 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
     L.plain_head = m->desc.plain_head;
     L.wstream8 = m->d_stream8;
     L.consts8 = m->d_consts8;
+    // NM_PREC_I8X3: the activation-stationary kernel (mlp_i8s.hip) when asked for (NEUMAN_I8_KERNEL=as; experiment, round 3)
+    static const bool i8_as = [] { const char* e = getenv("NEUMAN_I8_KERNEL"); return e && !strcmp(e, "as"); }();
+    if (i8_as && precision == NM_PREC_I8X3 && stop_stage == -2 && !dbg && !prof)
+        return nm::launch_mlp_i8s(L, m->d_image8, pts, dirs, origin, direction, z, n, S, in_mode, sigma_scale, out, nm::as_stream(stream), chunk);
     return nm::launch_mlp_mfma(L, pts, dirs, origin, direction, z, n, S, in_mode, precision, stop_stage, sigma_scale, out, dbg,
                                prof, nm::as_stream(stream), sigma_only, chunk);
 }

@@ -1,0 +1,336 @@
+// NM_PREC_I8X3, activation-stationary: the same 16-bit fixed-point arithmetic as nerf_mlp_i8w_kernel (mlp.hip; DESIGN.md "K4-i8") with
+// the roles of the two operands swapped.  There, a wave owns 64 FEATURES of 64 samples: the activations of the tile live in LDS (every wave
+// reads all of them for every block it computes), the weights stream from L2 into every wave group separately (2 x 1.27 MB per 128
+// samples), and requantisation needs the row maximum over all features = a partial-maximum exchange through LDS and two barriers per
+// stage.  Here a wave owns 32 SAMPLES and ALL features:
+//
+//   * its input activations of a stage -- 256 features as two int8 limbs -- are 8 k-steps x {hi, lo} x 16 B per lane = 64 registers,
+//     resident for the whole stage; the accumulator layout of v_mfma_i32_32x32x32_i8 gives a lane, for its sample, exactly the 16 k-slots
+//     the next stage's B operand wants from it (mlp_layout.h slot_feature8), so the requantised outputs of block b ARE the next stage's
+//     fragment of k-step b, in place -- activations never touch LDS, never cross lanes (one v_permlane32_swap for the row maximum);
+//   * the row maximum is local to the wave: no exchange, no barrier; waves never wait for each other except for the weight ring;
+//   * the weights are the A operands, one 1 KB fragment per limb and k-step, used for one MFMA triple.
+//
+// Reference semantics: models/vanilla.py Embedder.forward (:82-92), NeRF.forward (:120-152), Joiner.forward (:162-166).
+#include "mlp_device.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(16))) int i32x16;
+typedef __attribute__((ext_vector_type(2))) short i16x2;
+
+constexpr int kWaves = 8, kRows = 32;                        // 8 waves x 32 samples = 256 samples per workgroup
+constexpr int kTile = kWaves * kRows;
+// LDS: the encodings of each wave's 32 rows, wave-private: [wave][8 chunks][hi: 32 rows | lo: 32 rows][16 B] = 8 KB per wave
+constexpr int kPWaveU4 = nm::kPeChunks * 2 * kRows;          // 512 uint4
+constexpr int kPeU4 = kWaves * kPWaveU4;
+
+struct Args8s {
+    MlpArgs a;
+    const float* consts8;      // units (kBiasFloats) | biases in those units (kBiasFloats) | kappa (16)
+    const uint4* image8;       // the block image (mlp_layout.h frag_off8): [stage][block][step][hi | lo][64 lanes][16 B]
+};
+
+__device__ __forceinline__ i32x4 as_i32x4(uint4 v) { return __builtin_bit_cast(i32x4, v); }
+
+// ---- encodings of this wave's 32 rows (octave recurrence, mlp_device.h fill_pe_fast, wave-private layout)
+__device__ __forceinline__ void fill_pe_wave(uint4* pw, bool is_dir, const MlpArgs& a, int64_t base_row, int lane) {
+    const PeSpec spec = is_dir ? a.dir : a.pos;
+    const float* tab = a.petab + (is_dir ? 96 : 0);
+    unsigned short* hi = reinterpret_cast<unsigned short*>(pw);
+    auto put = [&](int row, int p, float v) {
+        const int off = ((p >> 3) * (2 * kRows) + row) * 8 + (p & 7);
+        const bf16x2 hb = __builtin_convertvector((f32x2){v, 0.f}, bf16x2);
+        const f32x2 hf = __builtin_convertvector(hb, f32x2);
+        const bf16x2 lb = __builtin_convertvector((f32x2){v - hf.x, 0.f}, bf16x2);
+        hi[off] = (unsigned short)(__builtin_bit_cast(unsigned, hb) & 0xffffu);
+        hi[off + kRows * 8] = (unsigned short)(__builtin_bit_cast(unsigned, lb) & 0xffffu);
+    };
+    if (spec.octaves) {
+#pragma unroll 1
+        for (int round = 0; round < 2; ++round) {
+            const int j = 2 * round + (lane >> 5), row = lane & 31;
+            if (j > 2) break;
+            int64_t i = base_row + row;
+            if (i >= a.n) i = a.n - 1;
+            float x0, x1, x2;
+            sample_input(a, i, is_dir, x0, x1, x2);
+            const float xj = j == 0 ? x0 : (j == 1 ? x1 : x2);
+            const float a0 = spec.kind == NM_PE_POSENC ? xj * tab[0] : fmaf(x2, tab[3 * j + 2], fmaf(x1, tab[3 * j + 1], x0 * tab[3 * j]));
+            put(row, j, xj);
+            double sn, cs;
+            sincos_f64((double)a0, sn, cs);
+            const int n3 = 3 * spec.nfreq;
+            for (int b = 0; b < spec.nfreq; ++b) {
+                if (spec.kind == NM_PE_POSENC) { put(row, 3 + 6 * b + j, (float)sn); put(row, 3 + 6 * b + 3 + j, (float)cs); }
+                else { put(row, 3 + 3 * b + j, (float)sn); put(row, 3 + n3 + 3 * b + j, (float)cs); }
+                const double s2 = 2.0 * sn * cs, c2 = 1.0 - 2.0 * sn * sn;
+                sn = s2; cs = c2;
+            }
+        }
+    } else {
+        const int nchunks = is_dir ? 4 : nm::kPeChunks;
+        for (int item = lane; item < nchunks * kRows; item += 64) {
+            const int c = item >> 5, row = item & 31;
+            int64_t i = base_row + row;
+            if (i >= a.n) i = a.n - 1;
+            float x0, x1, x2;
+            sample_input(a, i, is_dir, x0, x1, x2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) put(row, 8 * c + e, pe_feature(8 * c + e, x0, x1, x2, spec, tab));
+        }
+    }
+}
+
+struct X8 {
+    uint4 h[8], l[8];          // the wave's activations: k-step t = feature block t of the producing stage, hi / lo limbs
+};
+
+// one k-step of the weight image for this lane
+struct W8 {
+    v4u h, l;
+};
+__device__ __forceinline__ void w_load(W8& w, __amdgpu_buffer_rsrc_t wsrc, int voff, int soff) {
+    w.h = __builtin_amdgcn_raw_buffer_load_b128(wsrc, voff, soff, 0);
+    w.l = __builtin_amdgcn_raw_buffer_load_b128(wsrc, voff, soff + 1024, 0);
+}
+
+// NSTEPS limb k-steps of one output block: t = hh * 256 + cross (exact), weights prefetched two steps ahead
+template <int NSTEPS>
+__device__ __forceinline__ void k_i8(i32x16& t, const X8& X, __amdgpu_buffer_rsrc_t wsrc, int voff, int soff) {
+    i32x16 ah, ac;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ah[r] = 0; ac[r] = 0; }
+    W8 w[2];
+    w_load(w[0], wsrc, voff, soff);
+    w_load(w[1], wsrc, voff, soff + nm::kStepBytes);
+#pragma unroll
+    for (int s = 0; s < NSTEPS; ++s) {
+        const v4u wh = w[s & 1].h, wl = w[s & 1].l;
+        ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, wh), as_i32x4(X.l[s]), ac, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, wl), as_i32x4(X.h[s]), ac, 0, 0, 0);
+        ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, wh), as_i32x4(X.h[s]), ah, 0, 0, 0);
+        if (s + 2 < NSTEPS) w_load(w[s & 1], wsrc, voff, soff + (s + 2) * nm::kStepBytes);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = (ah[r] << 8) + ac[r];
+}
+// NSTEPS split-bf16 k-steps over the wave's encoding rows (chunks c0 ..), accumulated into f
+template <int NSTEPS>
+__device__ __forceinline__ void k_bf(f32x16& f, const uint4* pw, int c0, int g, int s, __amdgpu_buffer_rsrc_t wsrc, int voff, int soff) {
+#pragma unroll
+    for (int t = 0; t < NSTEPS; ++t) {
+        W8 w;
+        w_load(w, wsrc, voff, soff + t * nm::kStepBytes);
+        const uint4 xh = pw[(c0 + 2 * t + g) * (2 * kRows) + s], xl = pw[(c0 + 2 * t + g) * (2 * kRows) + kRows + s];
+        f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w.h), as_bf16x8(xl), f, 0, 0, 0);
+        f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w.l), as_bf16x8(xh), f, 0, 0, 0);
+        f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w.h), as_bf16x8(xh), f, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void bias16(f32x16& f, const float* bias_blk, int g) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 bs = *reinterpret_cast<const float4*>(bias_blk + 8 * q + 4 * g);
+        f[4 * q] = bs.x; f[4 * q + 1] = bs.y; f[4 * q + 2] = bs.z; f[4 * q + 3] = bs.w;
+    }
+}
+__device__ __forceinline__ void dequant16(f32x16& f, const i32x16& t, float sx256, const float* bias_blk, int g) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 bs = *reinterpret_cast<const float4*>(bias_blk + 8 * q + 4 * g);
+        const float bsv[4] = {bs.x, bs.y, bs.z, bs.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[4 * q + j] = fmaf((float)t[4 * q + j], sx256, bsv[j]);
+    }
+}
+template <bool RELU>
+__device__ __forceinline__ float max16(float m, const f32x16& f) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m = fmaxf(m, RELU ? f[r] : fabsf(f[r]));
+    return m;
+}
+__device__ __forceinline__ float row_max(float m) {                  // the two lane halves of a sample hold different features
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+    return fmaxf(__uint_as_float(sw.x), __uint_as_float(sw.y));
+}
+// one block's 16 outputs of this lane -> the next stage's k-step fragment (two balanced int8 limbs); nerf_mlp_i8w_kernel's quant_storew
+template <bool RELU>
+__device__ __forceinline__ void quant16(const f32x16& f, float inv, uint4& xh, uint4& xl) {
+    i16x2 P[8], Y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float y0 = f[2 * i] * inv, y1 = f[2 * i + 1] * inv;
+        if (RELU) {
+            y0 = __builtin_amdgcn_fmed3f(y0, 0.f, 1.f);
+            y1 = __builtin_amdgcn_fmed3f(y1, 0.f, 1.f);
+        }
+        const i16x2 p = __builtin_amdgcn_cvt_pknorm_i16(y0, y1);
+        P[i] = p;
+        Y[i] = p + (i16x2){128, 128};
+    }
+    unsigned lo[4], hi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        lo[k] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, P[2 * k + 1]), __builtin_bit_cast(unsigned, P[2 * k]), 0x06040200u);
+        hi[k] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, Y[2 * k + 1]), __builtin_bit_cast(unsigned, Y[2 * k]), 0x07050301u);
+    }
+    xh = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    xl = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+__device__ __forceinline__ float inv_of(float M) { return M > 0.f ? ((float)nm::kFixedMax / 32767.f) * __builtin_amdgcn_rcpf(M) : 0.f; }
+__device__ __forceinline__ float scale_of(float M) { return M > 0.f ? M * (1.f / (float)nm::kFixedMax) : 1.f; }
+
+__global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args8s A) {
+    __shared__ uint4 lds[kPeU4];
+    const MlpArgs a = resolve_args(A.a);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, s = lane & 31;
+    const int voff = lane * 16;
+    uint4* pw = lds + w * kPWaveU4;
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(A.image8), 0, (int)(nm::kWeightBytes8 + nm::kWeightPadBytes), 0x00020000);
+    const float* units = A.consts8;
+    const float* bias = A.consts8 + nm::kBiasFloats;
+    const float* kappa = A.consts8 + 2 * nm::kBiasFloats;
+    const int64_t ntiles = (a.n + kTile - 1) / kTile;
+    for (int i = lane; i < kPWaveU4; i += 64) pw[i] = make_uint4(0, 0, 0, 0);          // pad slots: finite once
+
+#pragma unroll 1
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * kTile + w * kRows;                                  // this wave's first sample
+        if (row0 >= a.n) continue;                                                      // (waves are independent: no barrier anywhere)
+        fill_pe_wave(pw, false, a, row0, lane);
+        X8 X;
+        float sx;                                                                       // the row scale of X: x = sx * (256 hi + lo) * unit[feature]
+        // ---------------- stage 0: encodings only (split bf16), ReLU
+        {
+            f32x16 f[8];
+            float m = 0.f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                bias16(f[b], bias + nm::stage_b_off(0) + 32 * b, g);
+                k_bf<4>(f[b], pw, 0, g, s, wsrc, voff, (int)nm::frag_off8(0, b, 0));
+                m = max16<true>(m, f[b]);
+            }
+            const float M = row_max(m), inv = inv_of(M);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) quant16<true>(f[b], inv, X.h[b], X.l[b]);
+            sx = scale_of(M);
+        }
+        // ---------------- stages 1..7: 256 -> 256, ReLU; stage 5 adds the position encoding
+#pragma unroll 1
+        for (int st = 1; st <= 7; ++st) {
+            const float sxin = sx * (256.f * kappa[st]);
+            const int wo = (int)nm::stage_w_off8(1) + (st - 1) * 8 * 8 * nm::kStepBytes + (st > 5 ? 8 * 4 * nm::kStepBytes : 0);   // stage_w_off8(st)
+            const int bsteps = st == 5 ? 12 : 8;
+            f32x16 f[8];
+            float m = 0.f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                i32x16 t;
+                k_i8<8>(t, X, wsrc, voff, wo + b * bsteps * nm::kStepBytes);
+                dequant16(f[b], t, sxin, bias + 256 * st + 32 * b, g);
+                if (st == 5) k_bf<4>(f[b], pw, 0, g, s, wsrc, voff, wo + (b * bsteps + 8) * nm::kStepBytes);
+                m = max16<true>(m, f[b]);
+            }
+            const float M = row_max(m), inv = inv_of(M);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) quant16<true>(f[b], inv, X.h[b], X.l[b]);
+            sx = scale_of(M);
+            if (st == 5) fill_pe_wave(pw, true, a, row0, lane);                          // the position encoding is done with: direction encoding
+        }
+        // ---------------- stage 8: alpha (block 8, row 0) + feature (linear, 256)
+        float sigma;
+        {
+            const float sxin = sx * (256.f * kappa[8]);
+            {
+                i32x16 t;
+                f32x16 fa;
+                k_i8<8>(t, X, wsrc, voff, (int)nm::frag_off8(8, 8, 0));
+                dequant16(fa, t, sxin, bias + nm::stage_b_off(8) + 256, g);
+                sigma = fa[0] * units[nm::stage_b_off(8) + 256];
+            }
+            f32x16 f[8];
+            float m = 0.f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                i32x16 t;
+                k_i8<8>(t, X, wsrc, voff, (int)nm::frag_off8(8, b, 0));
+                dequant16(f[b], t, sxin, bias + nm::stage_b_off(8) + 32 * b, g);
+                m = max16<false>(m, f[b]);
+            }
+            const float M = row_max(m), inv = inv_of(M);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) quant16<false>(f[b], inv, X.h[b], X.l[b]);
+            sx = scale_of(M);
+        }
+        // ---------------- stage 9: views layer, K = feature(256) ++ d_pe(32), N = 128, ReLU
+        {
+            const float sxin = sx * (256.f * kappa[9]);
+            f32x16 f[4];
+            float m = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                i32x16 t;
+                k_i8<8>(t, X, wsrc, voff, (int)nm::frag_off8(9, b, 0));
+                dequant16(f[b], t, sxin, bias + nm::stage_b_off(9) + 32 * b, g);
+                k_bf<2>(f[b], pw, 0, g, s, wsrc, voff, (int)nm::frag_off8(9, b, 8));
+                m = max16<true>(m, f[b]);
+            }
+            const float M = row_max(m), inv = inv_of(M);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) quant16<true>(f[b], inv, X.h[b], X.l[b]);
+            sx = scale_of(M);
+        }
+        // ---------------- stage 10: rgb (rows 0..2 of one block), K = 128
+        {
+            i32x16 t;
+            f32x16 fr;
+            k_i8<4>(t, X, wsrc, voff, (int)nm::frag_off8(10, 0, 0));
+            dequant16(fr, t, sx * (256.f * kappa[10]), bias + nm::stage_b_off(10), g);
+            const int64_t i = row0 + s;
+            if (g == 0 && i < a.n)
+                reinterpret_cast<float4*>(a.out)[sample_record(a, i)] =
+                    make_float4(fr[0] * units[nm::stage_b_off(10)], fr[1] * units[nm::stage_b_off(10) + 1], fr[2] * units[nm::stage_b_off(10) + 2],
+                                sigma * a.sigma_scale);
+        }
+    }
+}
+
+}  // namespace
+
+namespace nm {
+
+int launch_mlp_i8s(const MlpLaunch& L, const void* image8, const float* pts, const float* dirs, const float* origin, const float* direction,
+                   const float* z, int64_t n, int S, int in_mode, float sigma_scale, float* out, hipStream_t stream, const MlpChunk* chunk) {
+    Args8s A;
+    MlpArgs& a = A.a;
+    a.ray_idx = chunk ? chunk->ray_idx : nullptr;
+    a.n_rays_dev = chunk ? chunk->n_rays_dev : nullptr;
+    a.s0 = chunk ? chunk->s0 : 0;
+    a.S_total = chunk ? chunk->S_total : S;
+    a.wpack = nullptr; a.bias = nullptr;
+    a.petab = L.petab;
+    a.pts = pts; a.dirs = dirs; a.origin = origin; a.direction = direction; a.z = z;
+    a.out = out; a.dbg = nullptr; a.prof = nullptr; a.n = n; a.S = S; a.in_mode = in_mode; a.stop_stage = -2; a.sigma_scale = sigma_scale;
+    a.sigma_only = 0;
+    a.save_h = nullptr; a.save_hv = nullptr;
+    a.pos = PeSpec{L.pe_kind, L.pos_nfreq, L.pos_octaves};
+    a.dir = PeSpec{L.pe_kind, L.dir_nfreq, L.dir_octaves};
+    A.consts8 = L.consts8;
+    A.image8 = reinterpret_cast<const uint4*>(image8);
+    const int64_t ntiles = (n + kTile - 1) / kTile;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int grid = (int)(ntiles < cus ? ntiles : cus);
+    hipLaunchKernelGGL(nerf_mlp_i8s_kernel, dim3(grid), dim3(kWaves * 64), 0, stream, A);
+    return check_launch("nerf_mlp_i8s_kernel");
+}
+
+}  // namespace nm

@@ -29,6 +29,9 @@ struct MlpChunk {
 int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
                     const float* z, int64_t n, int S, int in_mode, int precision, int stop_stage, float sigma_scale, float* out,
                     float* dbg, void* prof, hipStream_t stream, int sigma_only = 0, const MlpChunk* chunk = nullptr);
+// NM_PREC_I8X3, activation-stationary schedule (mlp_i8s.hip); image8 = the block image of mlp_layout.h frag_off8 on the device
+int launch_mlp_i8s(const MlpLaunch& L, const void* image8, const float* pts, const float* dirs, const float* origin, const float* direction,
+                   const float* z, int64_t n, int S, int in_mode, float sigma_scale, float* out, hipStream_t stream, const MlpChunk* chunk);
 int launch_mlp_ref(const RefLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
                    const float* z, int64_t n, int S, int in_mode, int stop_stage, float sigma_scale, float* out, float* dbg,
                    hipStream_t stream);
