@@ -9,10 +9,16 @@
 //     the next stage's B operand wants from it (mlp_layout.h slot_feature8), so the requantised outputs of block b ARE the next stage's
 //     fragment of k-step b, in place -- activations never touch LDS, never cross lanes (one v_permlane32_swap for the row maximum);
 //   * the row maximum is local to the wave: no exchange, no barrier; waves never wait for each other except for the weight ring;
-//   * the weights are the A operands, one 1 KB fragment per limb and k-step, used for one MFMA triple.
+//   * the weights are the A operands, one 1 KB fragment per limb and k-step, used for one MFMA triple.  All 8 waves of the workgroup want
+//     the same fragments at about the same time, so the block image (mlp_layout.h frag_off8, consumed strictly linearly: 628 k-steps of
+//     2 KB per 256-sample tile) is streamed ONCE per workgroup from L2 into an LDS ring of whole output blocks by LDS-DMA
+//     (global_load_lds_dwordx4: lane-linear, exactly the fragment format), one block ahead of the block being multiplied; the only
+//     workgroup barrier is the one per output block that hands a ring slot over.
 //
 // Reference semantics: models/vanilla.py Embedder.forward (:82-92), NeRF.forward (:120-152), Joiner.forward (:162-166).
 #include "mlp_device.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -20,11 +26,24 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(16))) int i32x16;
 typedef __attribute__((ext_vector_type(2))) short i16x2;
 
-constexpr int kWaves = 8, kRows = 32;                        // 8 waves x 32 samples = 256 samples per workgroup
+constexpr int kWaves = 8, kRows = 32;                        // 8 waves x 32 samples = 256 samples per workgroup, one workgroup per CU
 constexpr int kTile = kWaves * kRows;
 // LDS: the encodings of each wave's 32 rows, wave-private: [wave][8 chunks][hi: 32 rows | lo: 32 rows][16 B] = 8 KB per wave
 constexpr int kPWaveU4 = nm::kPeChunks * 2 * kRows;          // 512 uint4
 constexpr int kPeU4 = kWaves * kPWaveU4;
+// the weight ring: kSlots slots of one output block (at most 12 k-steps of 2 KB)
+constexpr int kStepU4 = nm::kStepBytes / 16;
+constexpr int kSlotU4 = 12 * kStepU4;
+constexpr int kSlots = 3;                                    // the block being multiplied + two being copied
+constexpr int kBiasU4 = (nm::kBiasFloats + 16 + 3) / 4;      // the bias table and kappa, resident in LDS (a global load per block would sit in the same
+                                                             // in-order VMEM queue as the copies and force them to land early)
+// flat block index of a tile: stage 0: 0-7 | 1-4: 8-39 | 5: 40-47 | 6, 7: 48-63 | 8: 64-72 | 9: 73-76 | 10: 77
+constexpr int kTileBlocks = 78;
+__host__ __device__ constexpr int block_steps(int i) {
+    i = i >= kTileBlocks ? i - kTileBlocks : i;
+    return i < 8 ? 4 : (i >= 40 && i < 48) ? 12 : i < 73 ? 8 : i < 77 ? 10 : 4;
+}
+__host__ __device__ constexpr int block_pieces(int nsteps) { return (2 * nsteps + kWaves - 1) / kWaves; }   // 1 KB pieces per wave
 
 struct Args8s {
     MlpArgs a;
@@ -87,46 +106,86 @@ struct X8 {
     uint4 h[8], l[8];          // the wave's activations: k-step t = feature block t of the producing stage, hi / lo limbs
 };
 
-// one k-step of the weight image for this lane
-struct W8 {
-    v4u h, l;
+// ---- the weight ring.  Producer side: every wave copies its share (1 KB pieces i = w, w + 8, ..) of the block TWO ahead; consumer side:
+// all waves read every fragment of the current block.  Hand-over, once per block: each wave waits until its own pieces of the block it is
+// about to enter have landed (counted vmcnt: the pieces of the block after it stay in flight -- issue to landing is about 1 us, longer
+// than a block), then the barrier makes everybody's pieces visible and proves that nobody still reads the slot that is refilled next.
+// The only other VMEM operations of the kernel are the sample loads at the top of a tile and the 16-byte store at its end (the compiler
+// waits vmcnt(0) for the former: two copies land early, once per tile).
+struct Ring {
+    const char* src;           // image + lane * 16 + w * 1024
+    const uint4* rd;           // ring + lane
+    unsigned lds0;             // LDS byte address of slot 0 + w * 1024
+    int off;                   // image offset of the block to copy next
+    int slot;                  // slot of the block to enter next
 };
-__device__ __forceinline__ void w_load(W8& w, __amdgpu_buffer_rsrc_t wsrc, int voff, int soff) {
-    w.h = __builtin_amdgcn_raw_buffer_load_b128(wsrc, voff, soff, 0);
-    w.l = __builtin_amdgcn_raw_buffer_load_b128(wsrc, voff, soff + 1024, 0);
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// copy the block at R.off (NP pieces per wave; a 10-step block is padded to 3: the excess lands in the unused tail of the slot)
+template <int NP>
+__device__ __forceinline__ void ring_issue(Ring& R, int slot, int nsteps) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+        glds16(R.src + R.off + i * (kWaves * 1024), __builtin_amdgcn_readfirstlane(R.lds0 + slot * (kSlotU4 * 16) + i * (kWaves * 1024)));
+    R.off += nsteps * nm::kStepBytes;
+    if (R.off == (int)nm::kWeightBytes8) R.off = 0;
+}
+__device__ __forceinline__ void ring_issue_n(Ring& R, int slot, int nsteps) {
+    const int np = block_pieces(nsteps);
+    if (np == 1) ring_issue<1>(R, slot, nsteps);
+    else if (np == 2) ring_issue<2>(R, slot, nsteps);
+    else ring_issue<3>(R, slot, nsteps);
+}
+// enter flat block i of the tile and start the copy of block i + 2; returns this lane's view of block i
+__device__ __forceinline__ const uint4* ring_enter(Ring& R, int i) {
+    const int np1 = block_pieces(block_steps(i + 1));
+    if (np1 == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (np1 == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const uint4* cur = R.rd + R.slot * kSlotU4;
+    const int refill = R.slot == 0 ? kSlots - 1 : R.slot - 1;          // the slot of block i - 1 = of block i + 2
+    R.slot = R.slot == kSlots - 1 ? 0 : R.slot + 1;
+    ring_issue_n(R, refill, block_steps(i + 2));
+    return cur;
+}
+struct W8 {
+    uint4 h, l;
+};
 
 // NSTEPS limb k-steps of one output block: t = hh * 256 + cross (exact), weights prefetched two steps ahead
 template <int NSTEPS>
-__device__ __forceinline__ void k_i8(i32x16& t, const X8& X, __amdgpu_buffer_rsrc_t wsrc, int voff, int soff) {
+__device__ __forceinline__ void k_i8(i32x16& t, const X8& X, const uint4* ws) {
     i32x16 ah, ac;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { ah[r] = 0; ac[r] = 0; }
     W8 w[2];
-    w_load(w[0], wsrc, voff, soff);
-    w_load(w[1], wsrc, voff, soff + nm::kStepBytes);
+    w[0].h = ws[0]; w[0].l = ws[64];
+    w[1].h = ws[kStepU4]; w[1].l = ws[kStepU4 + 64];
 #pragma unroll
     for (int s = 0; s < NSTEPS; ++s) {
-        const v4u wh = w[s & 1].h, wl = w[s & 1].l;
-        ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, wh), as_i32x4(X.l[s]), ac, 0, 0, 0);
-        ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, wl), as_i32x4(X.h[s]), ac, 0, 0, 0);
-        ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, wh), as_i32x4(X.h[s]), ah, 0, 0, 0);
-        if (s + 2 < NSTEPS) w_load(w[s & 1], wsrc, voff, soff + (s + 2) * nm::kStepBytes);
+        const uint4 wh = w[s & 1].h, wl = w[s & 1].l;
+        ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(wh), as_i32x4(X.l[s]), ac, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(wl), as_i32x4(X.h[s]), ac, 0, 0, 0);
+        ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(wh), as_i32x4(X.h[s]), ah, 0, 0, 0);
+        if (s + 2 < NSTEPS) { w[s & 1].h = ws[(s + 2) * kStepU4]; w[s & 1].l = ws[(s + 2) * kStepU4 + 64]; }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[r] = (ah[r] << 8) + ac[r];
 }
 // NSTEPS split-bf16 k-steps over the wave's encoding rows (chunks c0 ..), accumulated into f
 template <int NSTEPS>
-__device__ __forceinline__ void k_bf(f32x16& f, const uint4* pw, int c0, int g, int s, __amdgpu_buffer_rsrc_t wsrc, int voff, int soff) {
+__device__ __forceinline__ void k_bf(f32x16& f, const uint4* pw, int g, int s, const uint4* ws) {
 #pragma unroll
     for (int t = 0; t < NSTEPS; ++t) {
-        W8 w;
-        w_load(w, wsrc, voff, soff + t * nm::kStepBytes);
-        const uint4 xh = pw[(c0 + 2 * t + g) * (2 * kRows) + s], xl = pw[(c0 + 2 * t + g) * (2 * kRows) + kRows + s];
-        f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w.h), as_bf16x8(xl), f, 0, 0, 0);
-        f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w.l), as_bf16x8(xh), f, 0, 0, 0);
-        f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w.h), as_bf16x8(xh), f, 0, 0, 0);
+        const uint4 wh = ws[t * kStepU4], wl = ws[t * kStepU4 + 64];
+        const uint4 xh = pw[(2 * t + g) * (2 * kRows) + s], xl = pw[(2 * t + g) * (2 * kRows) + kRows + s];
+        f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wh), as_bf16x8(xl), f, 0, 0, 0);
+        f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wl), as_bf16x8(xh), f, 0, 0, 0);
+        f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wh), as_bf16x8(xh), f, 0, 0, 0);
     }
 }
 __device__ __forceinline__ void bias16(f32x16& f, const float* bias_blk, int g) {
@@ -184,24 +243,35 @@ __device__ __forceinline__ float inv_of(float M) { return M > 0.f ? ((float)nm::
 __device__ __forceinline__ float scale_of(float M) { return M > 0.f ? M * (1.f / (float)nm::kFixedMax) : 1.f; }
 
 __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args8s A) {
-    __shared__ uint4 lds[kPeU4];
+    __shared__ uint4 lds[kPeU4 + kSlots * kSlotU4 + kBiasU4];
     const MlpArgs a = resolve_args(A.a);
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, s = lane & 31;
-    const int voff = lane * 16;
     uint4* pw = lds + w * kPWaveU4;
-    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(A.image8), 0, (int)(nm::kWeightBytes8 + nm::kWeightPadBytes), 0x00020000);
-    const float* units = A.consts8;
-    const float* bias = A.consts8 + nm::kBiasFloats;
-    const float* kappa = A.consts8 + 2 * nm::kBiasFloats;
+    Ring R;
+    R.src = reinterpret_cast<const char*>(A.image8) + lane * 16 + w * 1024;
+    R.rd = lds + kPeU4 + lane;
+    R.lds0 = (unsigned)(uintptr_t)(lds + kPeU4) + w * 1024;
+    R.off = 0;
+    R.slot = 0;
+    {                                                                                   // the bias table
+        float* lb = reinterpret_cast<float*>(lds + kPeU4 + kSlots * kSlotU4);
+        for (int i = tid; i < nm::kBiasFloats + 16; i += kWaves * 64) lb[i] = A.consts8[nm::kBiasFloats + i];
+    }
+    __syncthreads();
+    ring_issue_n(R, 0, block_steps(0));                                                 // blocks 0 and 1 of the first tile
+    ring_issue_n(R, 1, block_steps(1));
+    const float u_sigma = A.consts8[nm::stage_b_off(8) + 256];
+    const float u_r = A.consts8[nm::stage_b_off(10)], u_g = A.consts8[nm::stage_b_off(10) + 1], u_b = A.consts8[nm::stage_b_off(10) + 2];
+    const float* bias = reinterpret_cast<const float*>(lds + kPeU4 + kSlots * kSlotU4);
+    const float* kappa = bias + nm::kBiasFloats;
     const int64_t ntiles = (a.n + kTile - 1) / kTile;
     for (int i = lane; i < kPWaveU4; i += 64) pw[i] = make_uint4(0, 0, 0, 0);          // pad slots: finite once
 
 #pragma unroll 1
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t row0 = tile * kTile + w * kRows;                                  // this wave's first sample
-        if (row0 >= a.n) continue;                                                      // (waves are independent: no barrier anywhere)
+        const int64_t row0 = tile * kTile + w * kRows;                                  // this wave's first sample (rows past n: clamped)
         fill_pe_wave(pw, false, a, row0, lane);
         X8 X;
         float sx;                                                                       // the row scale of X: x = sx * (256 hi + lo) * unit[feature]
@@ -211,8 +281,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
             float m = 0.f;
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
+                const uint4* ws = ring_enter(R, b);
                 bias16(f[b], bias + nm::stage_b_off(0) + 32 * b, g);
-                k_bf<4>(f[b], pw, 0, g, s, wsrc, voff, (int)nm::frag_off8(0, b, 0));
+                k_bf<4>(f[b], pw, g, s, ws);
                 m = max16<true>(m, f[b]);
             }
             const float M = row_max(m), inv = inv_of(M);
@@ -224,16 +295,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
 #pragma unroll 1
         for (int st = 1; st <= 7; ++st) {
             const float sxin = sx * (256.f * kappa[st]);
-            const int wo = (int)nm::stage_w_off8(1) + (st - 1) * 8 * 8 * nm::kStepBytes + (st > 5 ? 8 * 4 * nm::kStepBytes : 0);   // stage_w_off8(st)
             const int bsteps = st == 5 ? 12 : 8;
             f32x16 f[8];
             float m = 0.f;
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 i32x16 t;
-                k_i8<8>(t, X, wsrc, voff, wo + b * bsteps * nm::kStepBytes);
+                const uint4* ws = ring_enter(R, 8 * st + b);
+                k_i8<8>(t, X, ws);
                 dequant16(f[b], t, sxin, bias + 256 * st + 32 * b, g);
-                if (st == 5) k_bf<4>(f[b], pw, 0, g, s, wsrc, voff, wo + (b * bsteps + 8) * nm::kStepBytes);
+                if (st == 5) k_bf<4>(f[b], pw, g, s, ws + 8 * kStepU4);
                 m = max16<true>(m, f[b]);
             }
             const float M = row_max(m), inv = inv_of(M);
@@ -246,21 +317,21 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
         float sigma;
         {
             const float sxin = sx * (256.f * kappa[8]);
-            {
-                i32x16 t;
-                f32x16 fa;
-                k_i8<8>(t, X, wsrc, voff, (int)nm::frag_off8(8, 8, 0));
-                dequant16(fa, t, sxin, bias + nm::stage_b_off(8) + 256, g);
-                sigma = fa[0] * units[nm::stage_b_off(8) + 256];
-            }
             f32x16 f[8];
             float m = 0.f;
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 i32x16 t;
-                k_i8<8>(t, X, wsrc, voff, (int)nm::frag_off8(8, b, 0));
+                k_i8<8>(t, X, ring_enter(R, 64 + b));
                 dequant16(f[b], t, sxin, bias + nm::stage_b_off(8) + 32 * b, g);
                 m = max16<false>(m, f[b]);
+            }
+            {
+                i32x16 t;
+                f32x16 fa;
+                k_i8<8>(t, X, ring_enter(R, 72));
+                dequant16(fa, t, sxin, bias + nm::stage_b_off(8) + 256, g);
+                sigma = fa[0] * u_sigma;
             }
             const float M = row_max(m), inv = inv_of(M);
 #pragma unroll
@@ -275,9 +346,10 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 i32x16 t;
-                k_i8<8>(t, X, wsrc, voff, (int)nm::frag_off8(9, b, 0));
+                const uint4* ws = ring_enter(R, 73 + b);
+                k_i8<8>(t, X, ws);
                 dequant16(f[b], t, sxin, bias + nm::stage_b_off(9) + 32 * b, g);
-                k_bf<2>(f[b], pw, 0, g, s, wsrc, voff, (int)nm::frag_off8(9, b, 8));
+                k_bf<2>(f[b], pw, g, s, ws + 8 * kStepU4);
                 m = max16<true>(m, f[b]);
             }
             const float M = row_max(m), inv = inv_of(M);
@@ -289,15 +361,16 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
         {
             i32x16 t;
             f32x16 fr;
-            k_i8<4>(t, X, wsrc, voff, (int)nm::frag_off8(10, 0, 0));
+            k_i8<4>(t, X, ring_enter(R, 77));
             dequant16(fr, t, sx * (256.f * kappa[10]), bias + nm::stage_b_off(10), g);
             const int64_t i = row0 + s;
             if (g == 0 && i < a.n)
                 reinterpret_cast<float4*>(a.out)[sample_record(a, i)] =
-                    make_float4(fr[0] * units[nm::stage_b_off(10)], fr[1] * units[nm::stage_b_off(10) + 1], fr[2] * units[nm::stage_b_off(10) + 2],
+                    make_float4(fr[0] * u_r, fr[1] * u_g, fr[2] * u_b,
                                 sigma * a.sigma_scale);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    // the copy started for a tile that never comes
 }
 
 }  // namespace
@@ -329,6 +402,11 @@ int launch_mlp_i8s(const MlpLaunch& L, const void* image8, const float* pts, con
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     const int grid = (int)(ntiles < cus ? ntiles : cus);
+    if (getenv("NEUMAN_I8S_DEBUG")) {
+        int nb = -1;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nerf_mlp_i8s_kernel, kWaves * 64, 0);
+        fprintf(stderr, "nerf_mlp_i8s_kernel: occupancy %d blocks/CU (%s), grid %d, cus %d\n", nb, hipGetErrorString(e), grid, cus);
+    }
     hipLaunchKernelGGL(nerf_mlp_i8s_kernel, dim3(grid), dim3(kWaves * 64), 0, stream, A);
     return check_launch("nerf_mlp_i8s_kernel");
 }
