@@ -19,6 +19,7 @@
 #include "mlp_device.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <vector>
 
 namespace {
 
@@ -106,6 +107,22 @@ struct X8 {
     uint4 h[8], l[8];          // the wave's activations: k-step t = feature block t of the producing stage, hi / lo limbs
 };
 
+// -DNM_AS_PROF: cycle buckets per wave (s_memtime = shader cycles): 0 wait at the top-of-block barrier (own copies + the other waves),
+// 1 copy issue, 2 k-loop, 4 epilogue, 5 requantisation at the end of a stage, 6 encodings, 7 rest
+#ifdef NM_AS_PROF
+struct Prof {
+    unsigned long long t, acc[8];
+};
+#define PROF_DECL Prof P; P.t = __builtin_amdgcn_s_memtime(); for (int i_ = 0; i_ < 8; ++i_) P.acc[i_] = 0;
+#define PROF_TICK(b) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); P.acc[b] += n_ - P.t; P.t = n_; }
+#define PROF_ARG , Prof& P
+#define PROF_PASS , P
+#else
+#define PROF_DECL
+#define PROF_TICK(b)
+#define PROF_ARG
+#define PROF_PASS
+#endif
 // ---- the weight ring.  Producer side: every wave copies its share (1 KB pieces i = w, w + 8, ..) of the block TWO ahead; consumer side:
 // all waves read every fragment of the current block.  Hand-over, once per block: each wave waits until its own pieces of the block it is
 // about to enter have landed (counted vmcnt: the pieces of the block after it stay in flight -- issue to landing is about 1 us, longer
@@ -118,39 +135,42 @@ struct Ring {
     unsigned lds0;             // LDS byte address of slot 0 + w * 1024
     int off;                   // image offset of the block to copy next
     int slot;                  // slot of the block to enter next
+    int refill, np, nsteps2;   // the copy in progress: slot, pieces per wave, k-steps of the block
 };
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
-// copy the block at R.off (NP pieces per wave; a 10-step block is padded to 3: the excess lands in the unused tail of the slot)
-template <int NP>
-__device__ __forceinline__ void ring_issue(Ring& R, int slot, int nsteps) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i)
-        glds16(R.src + R.off + i * (kWaves * 1024), __builtin_amdgcn_readfirstlane(R.lds0 + slot * (kSlotU4 * 16) + i * (kWaves * 1024)));
+// this wave's piece j of the block at R.off -> slot (a 10-step block is padded to 3 pieces: the excess lands in the unused tail of the slot)
+__device__ __forceinline__ void ring_piece(const Ring& R, int off, int slot, int j) {
+    glds16(R.src + off + j * (kWaves * 1024), __builtin_amdgcn_readfirstlane(R.lds0 + slot * (kSlotU4 * 16) + j * (kWaves * 1024)));
+}
+__device__ __forceinline__ void ring_advance(Ring& R, int nsteps) {
     R.off += nsteps * nm::kStepBytes;
     if (R.off == (int)nm::kWeightBytes8) R.off = 0;
 }
-__device__ __forceinline__ void ring_issue_n(Ring& R, int slot, int nsteps) {
-    const int np = block_pieces(nsteps);
-    if (np == 1) ring_issue<1>(R, slot, nsteps);
-    else if (np == 2) ring_issue<2>(R, slot, nsteps);
-    else ring_issue<3>(R, slot, nsteps);
-}
-// enter flat block i of the tile and start the copy of block i + 2; returns this lane's view of block i
-__device__ __forceinline__ const uint4* ring_enter(Ring& R, int i) {
+// enter flat block i of the tile; returns this lane's view of block i.  The copy of block i + 2 (into the slot block i - 1 has just given
+// up) is issued from inside the k-loop (ring_copy after k-steps 0, 2, 4): the texture path takes one 1 KB piece at a time, and eight
+// waves issuing theirs right after the barrier would all start their MFMAs late.
+__device__ __forceinline__ const uint4* ring_enter(Ring& R, int i PROF_ARG) {
+    PROF_TICK(4)
     const int np1 = block_pieces(block_steps(i + 1));
     if (np1 == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else if (np1 == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    PROF_TICK(0)
     const uint4* cur = R.rd + R.slot * kSlotU4;
-    const int refill = R.slot == 0 ? kSlots - 1 : R.slot - 1;          // the slot of block i - 1 = of block i + 2
+    R.refill = R.slot == 0 ? kSlots - 1 : R.slot - 1;                  // the slot of block i - 1 = of block i + 2
     R.slot = R.slot == kSlots - 1 ? 0 : R.slot + 1;
-    ring_issue_n(R, refill, block_steps(i + 2));
+    R.np = block_pieces(block_steps(i + 2));
+    R.nsteps2 = block_steps(i + 2);
     return cur;
+}
+__device__ __forceinline__ void ring_copy(Ring& R, int j) {
+    if (j < R.np) ring_piece(R, R.off, R.refill, j);
+    if (j == R.np - 1) ring_advance(R, R.nsteps2);
 }
 struct W8 {
     uint4 h, l;
@@ -158,7 +178,7 @@ struct W8 {
 
 // NSTEPS limb k-steps of one output block: t = hh * 256 + cross (exact), weights prefetched two steps ahead
 template <int NSTEPS>
-__device__ __forceinline__ void k_i8(i32x16& t, const X8& X, const uint4* ws) {
+__device__ __forceinline__ void k_i8(i32x16& t, const X8& X, const uint4* ws, Ring& R) {
     i32x16 ah, ac;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { ah[r] = 0; ac[r] = 0; }
@@ -172,15 +192,17 @@ __device__ __forceinline__ void k_i8(i32x16& t, const X8& X, const uint4* ws) {
         ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(wl), as_i32x4(X.h[s]), ac, 0, 0, 0);
         ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(wh), as_i32x4(X.h[s]), ah, 0, 0, 0);
         if (s + 2 < NSTEPS) { w[s & 1].h = ws[(s + 2) * kStepU4]; w[s & 1].l = ws[(s + 2) * kStepU4 + 64]; }
+        if (s == 0 || s == 2 || s == 4) ring_copy(R, s >> 1);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) t[r] = (ah[r] << 8) + ac[r];
 }
 // NSTEPS split-bf16 k-steps over the wave's encoding rows (chunks c0 ..), accumulated into f
-template <int NSTEPS>
-__device__ __forceinline__ void k_bf(f32x16& f, const uint4* pw, int g, int s, const uint4* ws) {
+template <int NSTEPS, bool COPY = false>
+__device__ __forceinline__ void k_bf(f32x16& f, const uint4* pw, int g, int s, const uint4* ws, Ring* R = nullptr) {
 #pragma unroll
     for (int t = 0; t < NSTEPS; ++t) {
+        if (COPY && (t == 1 || t == 3)) ring_copy(*R, t >> 1);
         const uint4 wh = ws[t * kStepU4], wl = ws[t * kStepU4 + 64];
         const uint4 xh = pw[(2 * t + g) * (2 * kRows) + s], xl = pw[(2 * t + g) * (2 * kRows) + kRows + s];
         f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wh), as_bf16x8(xl), f, 0, 0, 0);
@@ -260,19 +282,23 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
         for (int i = tid; i < nm::kBiasFloats + 16; i += kWaves * 64) lb[i] = A.consts8[nm::kBiasFloats + i];
     }
     __syncthreads();
-    ring_issue_n(R, 0, block_steps(0));                                                 // blocks 0 and 1 of the first tile
-    ring_issue_n(R, 1, block_steps(1));
+    ring_piece(R, 0, 0, 0);                                                             // blocks 0 and 1 of the first tile (one piece each)
+    ring_piece(R, block_steps(0) * nm::kStepBytes, 1, 0);
+    R.off = (block_steps(0) + block_steps(1)) * nm::kStepBytes;
     const float u_sigma = A.consts8[nm::stage_b_off(8) + 256];
     const float u_r = A.consts8[nm::stage_b_off(10)], u_g = A.consts8[nm::stage_b_off(10) + 1], u_b = A.consts8[nm::stage_b_off(10) + 2];
     const float* bias = reinterpret_cast<const float*>(lds + kPeU4 + kSlots * kSlotU4);
     const float* kappa = bias + nm::kBiasFloats;
     const int64_t ntiles = (a.n + kTile - 1) / kTile;
     for (int i = lane; i < kPWaveU4; i += 64) pw[i] = make_uint4(0, 0, 0, 0);          // pad slots: finite once
+    PROF_DECL
 
 #pragma unroll 1
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row0 = tile * kTile + w * kRows;                                  // this wave's first sample (rows past n: clamped)
+        PROF_TICK(7)
         fill_pe_wave(pw, false, a, row0, lane);
+        PROF_TICK(6)
         X8 X;
         float sx;                                                                       // the row scale of X: x = sx * (256 hi + lo) * unit[feature]
         // ---------------- stage 0: encodings only (split bf16), ReLU
@@ -281,15 +307,18 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
             float m = 0.f;
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
-                const uint4* ws = ring_enter(R, b);
+                const uint4* ws = ring_enter(R, b PROF_PASS);
                 bias16(f[b], bias + nm::stage_b_off(0) + 32 * b, g);
-                k_bf<4>(f[b], pw, g, s, ws);
+                k_bf<4, true>(f[b], pw, g, s, ws, &R);
+                PROF_TICK(2)
                 m = max16<true>(m, f[b]);
             }
+            PROF_TICK(4)
             const float M = row_max(m), inv = inv_of(M);
 #pragma unroll
             for (int b = 0; b < 8; ++b) quant16<true>(f[b], inv, X.h[b], X.l[b]);
             sx = scale_of(M);
+            PROF_TICK(5)
         }
         // ---------------- stages 1..7: 256 -> 256, ReLU; stage 5 adds the position encoding
 #pragma unroll 1
@@ -301,17 +330,24 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 i32x16 t;
-                const uint4* ws = ring_enter(R, 8 * st + b);
-                k_i8<8>(t, X, ws);
+                const uint4* ws = ring_enter(R, 8 * st + b PROF_PASS);
+                k_i8<8>(t, X, ws, R);
+                PROF_TICK(2)
                 dequant16(f[b], t, sxin, bias + 256 * st + 32 * b, g);
                 if (st == 5) k_bf<4>(f[b], pw, g, s, ws + 8 * kStepU4);
                 m = max16<true>(m, f[b]);
             }
+            PROF_TICK(4)
             const float M = row_max(m), inv = inv_of(M);
 #pragma unroll
             for (int b = 0; b < 8; ++b) quant16<true>(f[b], inv, X.h[b], X.l[b]);
             sx = scale_of(M);
-            if (st == 5) fill_pe_wave(pw, true, a, row0, lane);                          // the position encoding is done with: direction encoding
+            PROF_TICK(5)
+            if (st == 5) {
+                PROF_TICK(7)
+                fill_pe_wave(pw, true, a, row0, lane);
+                PROF_TICK(6)
+            }                          // the position encoding is done with: direction encoding
         }
         // ---------------- stage 8: alpha (block 8, row 0) + feature (linear, 256)
         float sigma;
@@ -322,21 +358,25 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 i32x16 t;
-                k_i8<8>(t, X, ring_enter(R, 64 + b));
+                k_i8<8>(t, X, ring_enter(R, 64 + b PROF_PASS), R);
+                PROF_TICK(2)
                 dequant16(f[b], t, sxin, bias + nm::stage_b_off(8) + 32 * b, g);
                 m = max16<false>(m, f[b]);
             }
             {
                 i32x16 t;
                 f32x16 fa;
-                k_i8<8>(t, X, ring_enter(R, 72));
+                k_i8<8>(t, X, ring_enter(R, 72 PROF_PASS), R);
+                PROF_TICK(2)
                 dequant16(fa, t, sxin, bias + nm::stage_b_off(8) + 256, g);
                 sigma = fa[0] * u_sigma;
             }
+            PROF_TICK(4)
             const float M = row_max(m), inv = inv_of(M);
 #pragma unroll
             for (int b = 0; b < 8; ++b) quant16<false>(f[b], inv, X.h[b], X.l[b]);
             sx = scale_of(M);
+            PROF_TICK(5)
         }
         // ---------------- stage 9: views layer, K = feature(256) ++ d_pe(32), N = 128, ReLU
         {
@@ -346,22 +386,26 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 i32x16 t;
-                const uint4* ws = ring_enter(R, 73 + b);
-                k_i8<8>(t, X, ws);
+                const uint4* ws = ring_enter(R, 73 + b PROF_PASS);
+                k_i8<8>(t, X, ws, R);
+                PROF_TICK(2)
                 dequant16(f[b], t, sxin, bias + nm::stage_b_off(9) + 32 * b, g);
                 k_bf<2>(f[b], pw, g, s, ws + 8 * kStepU4);
                 m = max16<true>(m, f[b]);
             }
+            PROF_TICK(4)
             const float M = row_max(m), inv = inv_of(M);
 #pragma unroll
             for (int b = 0; b < 4; ++b) quant16<true>(f[b], inv, X.h[b], X.l[b]);
             sx = scale_of(M);
+            PROF_TICK(5)
         }
         // ---------------- stage 10: rgb (rows 0..2 of one block), K = 128
         {
             i32x16 t;
             f32x16 fr;
-            k_i8<4>(t, X, ring_enter(R, 77));
+            k_i8<4>(t, X, ring_enter(R, 77 PROF_PASS), R);
+            PROF_TICK(2)
             dequant16(fr, t, sx * (256.f * kappa[10]), bias + nm::stage_b_off(10), g);
             const int64_t i = row0 + s;
             if (g == 0 && i < a.n)
@@ -370,6 +414,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
                                 sigma * a.sigma_scale);
         }
     }
+#ifdef NM_AS_PROF
+    PROF_TICK(7)
+    if (lane == 0 && a.prof)
+        for (int i = 0; i < 8; ++i) a.prof[((size_t)blockIdx.x * kWaves + w) * 8 + i] = P.acc[i];
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    // the copy started for a tile that never comes
 }
 
@@ -407,7 +456,28 @@ int launch_mlp_i8s(const MlpLaunch& L, const void* image8, const float* pts, con
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nerf_mlp_i8s_kernel, kWaves * 64, 0);
         fprintf(stderr, "nerf_mlp_i8s_kernel: occupancy %d blocks/CU (%s), grid %d, cus %d\n", nb, hipGetErrorString(e), grid, cus);
     }
+#ifdef NM_AS_PROF
+    static unsigned long long* d_prof = nullptr;
+    const size_t nprof = (size_t)grid * kWaves * 8;
+    if (!d_prof) (void)hipMalloc(&d_prof, (size_t)1024 * kWaves * 8 * 8);
+    (void)hipMemsetAsync(d_prof, 0, nprof * 8, stream);
+    a.prof = d_prof;
+#endif
     hipLaunchKernelGGL(nerf_mlp_i8s_kernel, dim3(grid), dim3(kWaves * 64), 0, stream, A);
+#ifdef NM_AS_PROF
+    if (n > 1000000) {
+        std::vector<unsigned long long> h(nprof);
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(h.data(), d_prof, nprof * 8, hipMemcpyDeviceToHost);
+        static const char* names[8] = {"top barrier", "copy issue", "k-loop", "-", "epilogue", "requantise", "encodings", "rest"};
+        double acc[8] = {0}, tot = 0;
+        for (size_t i = 0; i < nprof; ++i) acc[i & 7] += (double)h[i];
+        for (int i = 0; i < 8; ++i) tot += acc[i];
+        fprintf(stderr, "mean cycles per wave %.0f:", tot / (grid * (double)kWaves));
+        for (int i = 0; i < 8; ++i) fprintf(stderr, "  %s %.1f%%", names[i], 100.0 * acc[i] / tot);
+        fprintf(stderr, "\n");
+    }
+#endif
     return check_launch("nerf_mlp_i8s_kernel");
 }
 
