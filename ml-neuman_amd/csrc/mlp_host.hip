@@ -376,6 +376,16 @@ static void pack_image8(const nm_mlp_desc* d, const float* const* P, uint8_t* im
     }
 }
 
+// workgroup stream image of the activation-stationary kernel (mlp_i8s.hip): the block image in the order that kernel consumes it --
+// as it is, except that the alpha block of stage 8 comes BEFORE the eight feature blocks (all of the stage's outputs are held in registers
+// until the row maximum is known; the alpha block must not be the one that is multiplied while they are all live)
+static void pack_stream8s(const uint8_t* img8, uint8_t* out) {
+    memcpy(out, img8, (size_t)(kWeightBytes8 + kWeightPadBytes));
+    const int64_t blk = 8 * (int64_t)kStepBytes;
+    memcpy(out + frag_off8(8, 0, 0), img8 + frag_off8(8, 8, 0), (size_t)blk);
+    memcpy(out + frag_off8(8, 0, 0) + blk, img8 + frag_off8(8, 0, 0), (size_t)(8 * blk));
+}
+
 // per-wave stream image (mlp_layout.h wstream_*): the steps of the NM_PREC_I8X3 image in each wave's consumption order
 static void pack_stream8(const uint8_t* img8, uint8_t* out) {
     memset(out, 0, (size_t)kWeightBytes8w);
@@ -406,7 +416,7 @@ struct nm_mlp_s {
     uint8_t* d_image16;    // NM_PREC_FP16X3: the same layout, split fp16 of W * 2^8 | pad | bias * 2^13
     float* d_consts8;      // NM_PREC_I8X3: units | biases | kappa (the tail of the nm_mlp_pack_i8 image)
     uint8_t* d_stream8;    // NM_PREC_I8X3: the image's fragments as per-wave streams (nerf_mlp_i8w_kernel)
-    uint8_t* d_image8;     // NM_PREC_I8X3: the block image itself, fragments + prefetch pad (nerf_mlp_i8s_kernel)
+    uint8_t* d_image8;     // NM_PREC_I8X3: the workgroup stream of nerf_mlp_i8s_kernel (pack_stream8s), fragments + prefetch pad
     float* d_petab;        // 192 floats
     float* d_ref;          // transposed f32 weights | natural biases (NM_PREC_FP32 path)
     float* d_wscale16;     // nm_mlp_refresh_f16: the per-stage weight scales of the fp16 image (device scratch)
@@ -472,9 +482,11 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     nm::pack_image(desc, host_params, img16.data(), true);
     std::vector<uint8_t> img8((size_t)nm::image8_bytes());
     std::vector<uint8_t> str8((size_t)nm::kWeightBytes8w);
+    std::vector<uint8_t> str8s((size_t)(nm::kWeightBytes8 + nm::kWeightPadBytes));
     if (!plain) {                                               // (no i8x3 form of the plain-head net: those buffers stay zero)
         nm::pack_image8(desc, host_params, img8.data());
         nm::pack_stream8(img8.data(), str8.data());
+        nm::pack_stream8s(img8.data(), str8s.data());
     }
 
     // reference-layout image for the exact-f32 kernel
@@ -523,7 +535,7 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_stream8, str8.size()), "nm_mlp_create: hipMalloc(stream8)");
     if (!rc) rc = nm::check_hip(hipMemcpy(m->d_stream8, str8.data(), str8.size(), hipMemcpyHostToDevice), "nm_mlp_create: upload stream8");
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_image8, consts_off), "nm_mlp_create: hipMalloc(image8)");
-    if (!rc) rc = nm::check_hip(hipMemcpy(m->d_image8, img8.data(), consts_off, hipMemcpyHostToDevice), "nm_mlp_create: upload image8");
+    if (!rc) rc = nm::check_hip(hipMemcpy(m->d_image8, str8s.data(), consts_off, hipMemcpyHostToDevice), "nm_mlp_create: upload image8");
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_petab, sizeof(tab)), "nm_mlp_create: hipMalloc(petab)");
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_ref, ref.size() * 4), "nm_mlp_create: hipMalloc(ref)");
     if (!rc) rc = nm::check_hip(hipMemcpy(m->d_image, img.data(), (size_t)bytes, hipMemcpyHostToDevice), "nm_mlp_create: upload image");

@@ -26,6 +26,9 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(16))) int i32x16;
 typedef __attribute__((ext_vector_type(2))) short i16x2;
+typedef __attribute__((address_space(3))) const float lds_cfloat;      // (an LDS address is 32 bits and fits a ds_read's base register)
+typedef __attribute__((ext_vector_type(4))) float vf4;
+typedef __attribute__((address_space(3))) const vf4 lds_cvf4;
 
 constexpr int kWaves = 8, kRows = 32;                        // 8 waves x 32 samples = 256 samples per workgroup, one workgroup per CU
 constexpr int kTile = kWaves * kRows;
@@ -49,7 +52,7 @@ __host__ __device__ constexpr int block_pieces(int nsteps) { return (2 * nsteps 
 struct Args8s {
     MlpArgs a;
     const float* consts8;      // units (kBiasFloats) | biases in those units (kBiasFloats) | kappa (16)
-    const uint4* image8;       // the block image (mlp_layout.h frag_off8): [stage][block][step][hi | lo][64 lanes][16 B]
+    const uint4* image8;       // the stream (mlp_host.hip pack_stream8s): [stage][block][step][hi | lo][64 lanes][16 B], alpha block first in stage 8
 };
 
 __device__ __forceinline__ i32x4 as_i32x4(uint4 v) { return __builtin_bit_cast(i32x4, v); }
@@ -210,17 +213,18 @@ __device__ __forceinline__ void k_bf(f32x16& f, const uint4* pw, int g, int s, c
         f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wh), as_bf16x8(xh), f, 0, 0, 0);
     }
 }
-__device__ __forceinline__ void bias16(f32x16& f, const float* bias_blk, int g) {
+// (bias_blk: the block's 32 biases + 4 * g, this lane's half of every group of 8)
+__device__ __forceinline__ void bias16(f32x16& f, lds_cfloat* bias_blk) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float4 bs = *reinterpret_cast<const float4*>(bias_blk + 8 * q + 4 * g);
+        const vf4 bs = *(lds_cvf4*)(bias_blk + 8 * q);
         f[4 * q] = bs.x; f[4 * q + 1] = bs.y; f[4 * q + 2] = bs.z; f[4 * q + 3] = bs.w;
     }
 }
-__device__ __forceinline__ void dequant16(f32x16& f, const i32x16& t, float sx256, const float* bias_blk, int g) {
+__device__ __forceinline__ void dequant16(f32x16& f, const i32x16& t, float sx256, lds_cfloat* bias_blk) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float4 bs = *reinterpret_cast<const float4*>(bias_blk + 8 * q + 4 * g);
+        const vf4 bs = *(lds_cvf4*)(bias_blk + 8 * q);
         const float bsv[4] = {bs.x, bs.y, bs.z, bs.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) f[4 * q + j] = fmaf((float)t[4 * q + j], sx256, bsv[j]);
@@ -287,8 +291,11 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
     R.off = (block_steps(0) + block_steps(1)) * nm::kStepBytes;
     const float u_sigma = A.consts8[nm::stage_b_off(8) + 256];
     const float u_r = A.consts8[nm::stage_b_off(10)], u_g = A.consts8[nm::stage_b_off(10) + 1], u_b = A.consts8[nm::stage_b_off(10) + 2];
-    const float* bias = reinterpret_cast<const float*>(lds + kPeU4 + kSlots * kSlotU4);
-    const float* kappa = bias + nm::kBiasFloats;
+    const float* kappa = reinterpret_cast<const float*>(lds + kPeU4 + kSlots * kSlotU4) + nm::kBiasFloats;
+    unsigned bias_lds = (unsigned)(uintptr_t)(lds + kPeU4 + kSlots * kSlotU4) + 16 * g;        // this lane's half of every group of 8:
+    asm volatile("" : "+v"(bias_lds));                                                  // ONE address register, everything else an immediate
+    lds_cfloat* bias = (lds_cfloat*)(uintptr_t)bias_lds;                                // (left alone, the compiler keeps one per block, hoisted
+                                                                                        // out of the tile loop and spilled)
     const int64_t ntiles = (a.n + kTile - 1) / kTile;
     for (int i = lane; i < kPWaveU4; i += 64) pw[i] = make_uint4(0, 0, 0, 0);          // pad slots: finite once
     PROF_DECL
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 const uint4* ws = ring_enter(R, b PROF_PASS);
-                bias16(f[b], bias + nm::stage_b_off(0) + 32 * b, g);
+                bias16(f[b], bias + nm::stage_b_off(0) + 32 * b);
                 k_bf<4, true>(f[b], pw, g, s, ws, &R);
                 PROF_TICK(2)
                 m = max16<true>(m, f[b]);
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
                 const uint4* ws = ring_enter(R, 8 * st + b PROF_PASS);
                 k_i8<8>(t, X, ws, R);
                 PROF_TICK(2)
-                dequant16(f[b], t, sxin, bias + 256 * st + 32 * b, g);
+                dequant16(f[b], t, sxin, bias + 256 * st + 32 * b);
                 if (st == 5) k_bf<4>(f[b], pw, g, s, ws + 8 * kStepU4);
                 m = max16<true>(m, f[b]);
             }
@@ -349,27 +356,27 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
                 PROF_TICK(6)
             }                          // the position encoding is done with: direction encoding
         }
-        // ---------------- stage 8: alpha (block 8, row 0) + feature (linear, 256)
+        // ---------------- stage 8: alpha (row 0 of its block; first in the stream) + feature (linear, 256)
         float sigma;
         {
             const float sxin = sx * (256.f * kappa[8]);
+            {
+                i32x16 t;
+                f32x16 fa;
+                k_i8<8>(t, X, ring_enter(R, 64 PROF_PASS), R);
+                PROF_TICK(2)
+                dequant16(fa, t, sxin, bias + nm::stage_b_off(8) + 256);
+                sigma = fa[0] * u_sigma;
+            }
             f32x16 f[8];
             float m = 0.f;
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 i32x16 t;
-                k_i8<8>(t, X, ring_enter(R, 64 + b PROF_PASS), R);
+                k_i8<8>(t, X, ring_enter(R, 65 + b PROF_PASS), R);
                 PROF_TICK(2)
-                dequant16(f[b], t, sxin, bias + nm::stage_b_off(8) + 32 * b, g);
+                dequant16(f[b], t, sxin, bias + nm::stage_b_off(8) + 32 * b);
                 m = max16<false>(m, f[b]);
-            }
-            {
-                i32x16 t;
-                f32x16 fa;
-                k_i8<8>(t, X, ring_enter(R, 72 PROF_PASS), R);
-                PROF_TICK(2)
-                dequant16(fa, t, sxin, bias + nm::stage_b_off(8) + 256, g);
-                sigma = fa[0] * u_sigma;
             }
             PROF_TICK(4)
             const float M = row_max(m), inv = inv_of(M);
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
                 const uint4* ws = ring_enter(R, 73 + b PROF_PASS);
                 k_i8<8>(t, X, ws, R);
                 PROF_TICK(2)
-                dequant16(f[b], t, sxin, bias + nm::stage_b_off(9) + 32 * b, g);
+                dequant16(f[b], t, sxin, bias + nm::stage_b_off(9) + 32 * b);
                 k_bf<2>(f[b], pw, g, s, ws + 8 * kStepU4);
                 m = max16<true>(m, f[b]);
             }
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
             f32x16 fr;
             k_i8<4>(t, X, ring_enter(R, 77 PROF_PASS), R);
             PROF_TICK(2)
-            dequant16(fr, t, sx * (256.f * kappa[10]), bias + nm::stage_b_off(10), g);
+            dequant16(fr, t, sx * (256.f * kappa[10]), bias + nm::stage_b_off(10));
             const int64_t i = row0 + s;
             if (g == 0 && i < a.n)
                 reinterpret_cast<float4*>(a.out)[sample_record(a, i)] =
