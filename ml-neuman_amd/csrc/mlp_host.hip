@@ -614,9 +614,10 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
     L.plain_head = m->desc.plain_head;
     L.wstream8 = m->d_stream8;
     L.consts8 = m->d_consts8;
-    // NM_PREC_I8X3: the activation-stationary kernel (mlp_i8s.hip) when asked for (NEUMAN_I8_KERNEL=as; experiment, round 3)
-    static const bool i8_as = [] { const char* e = getenv("NEUMAN_I8_KERNEL"); return e && !strcmp(e, "as"); }();
-    if (i8_as && precision == NM_PREC_I8X3 && stop_stage == -2 && !dbg && !prof)
+    // NM_PREC_I8X3, whole network, all four outputs: the activation-stationary kernel (mlp_i8s.hip) -- bit-identical to the wave-specialised
+    // one of mlp.hip, which keeps the stage-by-stage / profiling / density-only forms (and everything under NEUMAN_I8_KERNEL=w or =r)
+    static const bool i8_as = [] { const char* e = getenv("NEUMAN_I8_KERNEL"); return !e || !strcmp(e, "as"); }();
+    if (i8_as && precision == NM_PREC_I8X3 && stop_stage == -2 && !dbg && !prof && !sigma_only)
         return nm::launch_mlp_i8s(L, m->d_image8, pts, dirs, origin, direction, z, n, S, in_mode, sigma_scale, out, nm::as_stream(stream), chunk);
     return nm::launch_mlp_mfma(L, pts, dirs, origin, direction, z, n, S, in_mode, precision, stop_stage, sigma_scale, out, dbg,
                                prof, nm::as_stream(stream), sigma_only, chunk);
