@@ -63,7 +63,7 @@ DTYPES = {
     "i8x3": "i8x3 (per-row-scaled int16 as 2 int8 limbs, i8 MFMA x3, exact int32 accumulate; encodings on bf16x3)",
     "bf16": "bf16 (f32 accumulate)", "fp32": "f32"}
 PMC_SUMMARIES = ("profiles/r03_bench_pmc_summary.json", "profiles/r02_bench_pmc_summary.json", "profiles/r01_bench_pmc_summary.json")
-KERNEL_OF = {"fp16x3": "nerf_mlp_kernel<4, false>", "bf16x3": "nerf_mlp_kernel<1, false>", "i8x3": "nerf_mlp_i8w_kernel<false>", "bf16": "nerf_mlp_kernel<2, false>",
+KERNEL_OF = {"fp16x3": "nerf_mlp_kernel<4, false>", "bf16x3": "nerf_mlp_kernel<1, false>", "i8x3": "nerf_mlp_i8s_kernel", "bf16": "nerf_mlp_kernel<2, false>",
              "fp32": "nerf_mlp_ref_kernel"}
 
 

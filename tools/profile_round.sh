@@ -3,7 +3,7 @@
 #   tools/profile_round.sh r01      -> gpurun_out/<tag>/{bench_kernel_stats.csv, bench_pmc_summary.json, bench_line.json, ...}
 # Counters are collected in their own passes, with --kernel-trace only (no sys/hip/hsa trace domains).
 # The profiled command is `bench.py --timed-only` in the default (mixed) precision: every MLP launch rocprofv3 sees is a
-# timed one -- nerf_mlp_kernel<4,false> = the coarse (fp16x3) launch, nerf_mlp_i8w_kernel<false> = the fine (i8x3) launch.
+# timed one -- nerf_mlp_kernel<4,false> = the coarse (fp16x3) launch, nerf_mlp_i8s_kernel = the fine (i8x3) launch.
 # FULL=1 also collects the in-kernel cycle buckets, the clock / power samples and the zero-weight probe (minutes of GPU time).
 set -u
 TAG=${1:-r00}
@@ -40,7 +40,7 @@ for a, b in zip([x for x in out['sq'] if 'nerf_mlp' in x['kernel']], [x for x in
 out['note'] = ("bench.py --steps 1 --warmup 0 --timed-only (default precision: mixed) under rocprofv3 --pmc <one group per pass> "
                "--kernel-trace; FETCH_SIZE/WRITE_SIZE in KiB (FETCH_SIZE under-reports wide streaming reads by 2x on gfx950, "
                "MI355X_MICROARCH.md); one coarse launch (nerf_mlp_kernel<4, false>, 81.92 M evaluations) and one fine launch "
-               "(nerf_mlp_i8w_kernel<false>, 163.84 M evaluations)")
+               "(nerf_mlp_i8s_kernel, 163.84 M evaluations)")
 json.dump(out, open('$OUT/bench_pmc_summary.json', 'w'), indent=1)
 print(json.dumps(out['derived']))
 PY
