@@ -484,14 +484,17 @@ def main():
                         dte = (time.perf_counter() - t1) / args.steps
                     finally:
                         render_utils.TERMINATION_EPS = 0.0
-                    res[eps] = (rgb_e, dte, tr.get('march', [None])[0])
+                    res[eps] = (rgb_e, dte, tr.get('march', [None])[0], tr.get('march_coarse', [None])[0])
             st = res[1e-4][2]
             workloads = {"opaque_preset_early_termination": {
-                "what": "800x800, 128 + 128 samples, synthetic.make_joiner(1, preset='opaque') as coarse and fine net; fine pass marched front to "
-                        "back in 32-sample chunks with ballot / prefix-sum compaction of the live rays between chunks (nm_mlp_forward_ray_chunk, "
-                        "nm_transmittance_chunk, nm_compact_hits), no host synchronisation between chunks",
+                "what": "800x800, 128 + 128 samples, synthetic.make_joiner(1, preset='opaque') as coarse and fine net; both passes marched front to "
+                        "back in chunks with ballot / prefix-sum compaction of the live rays between chunks (nm_mlp_sigma_ray_chunk / "
+                        "nm_mlp_forward_ray_chunk, nm_transmittance_chunk, nm_compact_hits): the fine pass cut at eps, the coarse pass at eps * 1e-3 "
+                        "(render_utils.TERMINATION_COARSE); one host read per chunk (the live count: no launch once nobody is live, chunk halved "
+                        "to 16 samples while rays are being cut)",
                 "eps": 1e-4, "rays_per_s_every_sample": total / res[0.0][1], "rays_per_s_terminated": total / res[1e-4][1],
                 "speedup": res[0.0][1] / res[1e-4][1], "fine_evaluations_done": st['evaluated'] / st['total'] if st else None,
+                "coarse_evaluations_done": (lambda c_: c_['evaluated'] / c_['total'] if c_ else None)(res[1e-4][3]),
                 "rgb_linf_vs_every_sample": float((res[0.0][0] - res[1e-4][0]).abs().max())}}
             # one iteration of the background trainer (trainers/vanilla_nerf_trainer.py:45-96 + backward + Adam) at the
             # reference's batch, on the training slice's default arithmetic.  Never `value`.

@@ -186,6 +186,11 @@ int nm_mlp_sigma_rays(nm_mlp_t mlp, const float* origin, const float* direction,
 int nm_mlp_forward_ray_chunk(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals, int S_total,
                              const int32_t* ray_idx, const int32_t* n_rays_dev, int64_t n_rays, int s0, int S, int precision,
                              float sigma_scale, float* out, nm_stream_t stream);
+/* The same chunk, density only (nm_mlp_sigma_rays' arithmetic: sigma bit-identical, colours 0) -- the march of a COARSE pass, whose
+ * colours the reference composites and discards (render_utils.py:139-141). */
+int nm_mlp_sigma_ray_chunk(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals, int S_total,
+                           const int32_t* ray_idx, const int32_t* n_rays_dev, int64_t n_rays, int s0, int S, int precision,
+                           float sigma_scale, float* out, nm_stream_t stream);
 /* T[r] *= prod_{i in chunk} (1 - alpha_i + 1e-10) for the listed rays (ray_idx nullable = rays 0..n_rays-1): the
  * transmittance factors of raw2outputs (render_utils.py:85-95) over samples s0 .. s0+S-1 of raw [R,S_total,4]; rays whose T
  * falls below the caller's epsilon are dropped by nm_compact_hits(eps, T). */

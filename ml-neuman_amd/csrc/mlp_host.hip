@@ -684,6 +684,17 @@ int nm_mlp_forward_ray_chunk(nm_mlp_t mlp, const float* origin, const float* dir
                         nullptr, stream, nullptr, 0, &c);
 }
 
+int nm_mlp_sigma_ray_chunk(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals, int S_total,
+                           const int32_t* ray_idx, const int32_t* n_rays_dev, int64_t n_rays, int s0, int S, int precision,
+                           float sigma_scale, float* out, nm_stream_t stream) {
+    NM_REQUIRE(n_rays == 0 || (origin && direction && z_vals && ray_idx && out), "nm_mlp_sigma_ray_chunk: null pointer");
+    NM_REQUIRE(n_rays >= 0 && S >= 1 && s0 >= 0 && s0 + S <= S_total, "nm_mlp_sigma_ray_chunk: bad sizes (s0=%d S=%d S_total=%d)", s0, S, S_total);
+    NM_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, "nm_mlp_sigma_ray_chunk: out must be 16-byte aligned");
+    nm::MlpChunk c{ray_idx, n_rays_dev, s0, S_total};
+    return mlp_dispatch(mlp, nullptr, nullptr, origin, direction, z_vals, n_rays * (int64_t)S, S, 2, precision, -2, sigma_scale, out,
+                        nullptr, stream, nullptr, 1, &c);
+}
+
 int nm_mlp_forward_profile(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision, float* out,
                            uint64_t* cycles, nm_stream_t stream) {
     NM_REQUIRE(n == 0 || (pts && dirs && out && cycles), "nm_mlp_forward_profile: null pointer");

@@ -29,6 +29,11 @@ MAX_RAYS_PER_LAUNCH = int(os.environ.get("NEUMAN_MAX_RAYS_PER_LAUNCH", 1 << 20))
 # and the frame is bit-identical to the unchunked path.  eps > 0 changes a pixel by at most eps per channel.
 TERMINATION_EPS = float(os.environ.get("NEUMAN_TERMINATION_EPS", "0"))
 TERMINATION_CHUNK = int(os.environ.get("NEUMAN_TERMINATION_CHUNK", "32"))
+# With termination on, the COARSE pass of a two-pass render is marched too, cut at eps * this: the weights it then never computes
+# are below that each and in sum, 100 x under the 1e-5 the inverse CDF adds to every bin (ray_utils.py:168), so the importance samples
+# stay where they were to a fraction of an empty bin's width.
+TERMINATION_COARSE = float(os.environ.get("NEUMAN_TERMINATION_COARSE", "1e-3"))
+TERMINATION_MIN_CHUNK = 16
 
 
 # ------------------------------------------------------------------------------------------------
@@ -89,15 +94,28 @@ def _note(trace, **kw):
             trace.setdefault(k, []).append(v)
 
 
-def march_pass_rays(net, o, d, z, eps, chunk=None, precision=None, role='shading', stats=None):
-    """Shading pass with early ray termination: the S sorted samples of every ray are evaluated front to back in chunks of
-    `chunk`; after each chunk the rays whose transmittance (the running product of raw2outputs' factors, nm_transmittance_chunk)
-    is below `eps` leave the list (ballot / prefix-sum compaction on the device, nm_compact_hits) and the next MLP launch covers
-    the compacted live rays only (nm_mlp_forward_ray_chunk).  Samples never evaluated keep sigma = 0, i.e. weight exactly 0 in
-    raw2outputs; what they would have contributed is bounded by the transmittance at the cut: < eps per channel.  No host
-    synchronisation between chunks.  -> raw [R,S,4]; `stats` (a dict) receives the evaluation counts (one host sync, at the end)."""
+def march_pass_rays(net, o, d, z, eps, chunk=None, precision=None, role='shading', stats=None, sigma_only=False, occluder=None,
+                    adaptive=None):
+    """A pass with early ray termination: the S sorted samples of every ray are evaluated front to back in chunks of `chunk`; after
+    each chunk the rays whose transmittance (the running product of raw2outputs' factors, nm_transmittance_chunk) is below `eps`
+    leave the list (ballot / prefix-sum compaction on the device, nm_compact_hits) and the next MLP launch covers the compacted live
+    rays only (nm_mlp_forward_ray_chunk; `sigma_only`: nm_mlp_sigma_ray_chunk, a coarse pass).  Samples never evaluated keep
+    sigma = 0, i.e. weight exactly 0 in raw2outputs; what they would have contributed is bounded by the transmittance at the cut:
+    < eps per channel.
+
+    occluder = (z_far [R], T_occ [R]): the ray's list will be merged with another whose samples all lie in front of z_far and whose
+    total transmittance is T_occ (the hybrid renderers: the human samples).  Once the march is past z_far the transmittance of the
+    MERGED list is T * T_occ, and that is what is compared with eps.
+
+    adaptive (default: eps > 0): ONE host read per chunk -- the live count.  No launch once nobody is live; the chunk is halved
+    (not below TERMINATION_MIN_CHUNK) while more than 2 % of the live rays were cut by the last one -- rays are only ever cut at a chunk
+    boundary, so near the cut a chunk is half its length of wasted evaluations per ray -- and doubled back otherwise.
+    adaptive=False: fixed chunks, no host synchronisation between them (and with eps = 0, bit-identical to the unchunked launch).
+
+    -> raw [R,S,4]; `stats` (a dict) receives the evaluation counts."""
     _lib.require_gpu()
     chunk = chunk or TERMINATION_CHUNK
+    adaptive = (eps > 0) if adaptive is None else bool(adaptive)
     R, S = z.shape
     dev = z.device
     raw = torch.zeros((R, S, 4), device=dev, dtype=torch.float32)
@@ -108,26 +126,94 @@ def march_pass_rays(net, o, d, z, eps, chunk=None, precision=None, role='shading
     ws = torch.empty(int(_lib.lib().nm_compact_workspace_ints(R)), device=dev, dtype=torch.int32)
     evaluated = torch.zeros(1, device=dev, dtype=torch.int64) if stats is not None else None
     o, d, z = o.contiguous(), d.contiguous(), z.contiguous()
-    for s0 in range(0, S, chunk):
+    s0, n_live, launches = 0, R, 0
+    while s0 < S:
         c = min(chunk, S - s0)
         if evaluated is not None:
             evaluated += counts[0].to(torch.int64) * c
-        net.forward_ray_chunk(o, d, z, live, counts, s0, c, raw, precision=precision, role=role)
-        if s0 + c >= S or eps <= 0:                               # (eps = 0: nothing is ever dropped, not even rays whose T underflowed to 0)
+        net.forward_ray_chunk(o, d, z, live, counts, s0, c, raw, precision=precision, role=role, sigma_only=sigma_only)
+        launches += 1
+        s0 += c
+        if s0 >= S or eps <= 0:                                   # (eps = 0: nothing is ever dropped, not even rays whose T underflowed to 0)
             continue
         _lib.check(_lib.lib().nm_transmittance_chunk(_lib.dev_ptr(raw), _lib.dev_ptr(z), _lib.dev_ptr(d), _lib.dev_ptr(live, torch.int32),
-                                                     _lib.dev_ptr(counts, torch.int32), R, s0, c, S, _lib.dev_ptr(T), _lib.stream_ptr()),
+                                                     _lib.dev_ptr(counts, torch.int32), R, s0 - c, c, S, _lib.dev_ptr(T), _lib.stream_ptr()),
                    "nm_transmittance_chunk")
+        T_eff = T if occluder is None else T * torch.where(z[:, s0] >= occluder[0], occluder[1], torch.ones_like(T))
         nxt = torch.empty(R, device=dev, dtype=torch.int32)
         counts = torch.zeros(2, device=dev, dtype=torch.int32)
-        _lib.check(_lib.lib().nm_compact_hits(_lib.dev_ptr(thr), _lib.dev_ptr(T), R, _lib.dev_ptr(nxt, torch.int32), None,
+        _lib.check(_lib.lib().nm_compact_hits(_lib.dev_ptr(thr), _lib.dev_ptr(T_eff.contiguous()), R, _lib.dev_ptr(nxt, torch.int32), None,
                                               _lib.dev_ptr(counts, torch.int32), _lib.dev_ptr(ws, torch.int32), _lib.stream_ptr()), "nm_compact_hits")
         live = nxt
+        if adaptive:
+            n_new = int(counts[0].item())
+            if n_new == 0:
+                break
+            cut = 1.0 - n_new / max(1, n_live)
+            chunk = max(TERMINATION_MIN_CHUNK, chunk // 2) if cut > 0.02 else min(max(chunk, TERMINATION_CHUNK), chunk * 2)
+            n_live = n_new
     if stats is not None:
         n = int(evaluated.item())
         stats['evaluated'] = stats.get('evaluated', 0) + n
         stats['total'] = stats.get('total', 0) + R * S
+        stats['launches'] = stats.get('launches', 0) + launches
     return raw
+
+
+def transmittance_of(raw, z, d):
+    """prod_i (1 - alpha_i + 1e-10) over a whole list: raw2outputs' factors (render_utils.py:85-95) -> T [R]"""
+    R, S = z.shape
+    T = torch.ones(R, device=z.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nm_transmittance_chunk(_lib.dev_ptr(raw.contiguous()), _lib.dev_ptr(z.contiguous()), _lib.dev_ptr(d.contiguous()), None, None,
+                                                 R, 0, S, S, _lib.dev_ptr(T), _lib.stream_ptr()), "nm_transmittance_chunk")
+    return T
+
+
+def human_march_rays(human_net, o, d, near, far, samples_per_ray, mesh, eps, sigma_scale=1.0, precision=None, chunk=None, trace=None,
+                     stats=None):
+    """human_pass_rays (posed) with early ray termination -> (raw [R,S,4], z [R,S]).  The warp is the expensive step here, and a ray that
+    has entered an opaque body needs neither the closest-point queries nor the network behind the surface.  Front to back in chunks; the
+    live rays' samples of a chunk are gathered, warped (one sample past the chunk: the canonical direction of a sample is the forward
+    difference to the next warped point, ray_utils.py:62-64 -- the last sample of a ray repeats its predecessor's), evaluated and
+    scattered back; rays whose transmittance over their own (human) samples is below eps are dropped.  Merged with any other list the
+    transmittance can only be lower, so what is skipped weighs < eps in every composite the renderers make of it.  Every evaluated
+    sample is bit-identical to human_pass_rays' (per-sample arithmetic; tests/test_hip_march.py)."""
+    _lib.require_gpu()
+    R, S = o.shape[0], int(samples_per_ray)
+    dev = o.device
+    chunk = chunk or TERMINATION_MIN_CHUNK
+    pts, _, z = ray_utils.sample_z(o.contiguous(), d.contiguous(), near.reshape(-1).contiguous(), far.reshape(-1).contiguous(), S, want_points=True)
+    raw = torch.zeros((R, S, 4), device=dev, dtype=torch.float32)
+    T = torch.ones(R, device=dev, dtype=torch.float32)
+    d = d.contiguous()
+    live = torch.arange(R, device=dev)
+    s0, evaluated, launches = 0, 0, 0
+    while s0 < S and live.numel() > 0:
+        c = min(chunk, S - s0)
+        a = s0 - 1 if (s0 + c == S and c == 1) else s0                               # a lone last sample takes its predecessor along
+        b = min(S, s0 + c + 1)
+        can_pts, can_dirs, _ = ray_utils.warp_to_canonical_dev(pts[live, a:b].contiguous(), mesh)
+        k = s0 - a
+        out = human_net(can_pts[:, k:k + c].contiguous(), can_dirs[:, k:k + c].contiguous(), precision=precision, sigma_scale=sigma_scale,
+                        role='shading')
+        raw[live, s0:s0 + c] = out
+        evaluated += live.numel() * c
+        launches += 1
+        s0 += c
+        if s0 >= S or eps <= 0:
+            continue
+        idx = live.to(torch.int32)
+        cnt = torch.tensor([idx.numel(), 0], device=dev, dtype=torch.int32)
+        _lib.check(_lib.lib().nm_transmittance_chunk(_lib.dev_ptr(raw), _lib.dev_ptr(z), _lib.dev_ptr(d), _lib.dev_ptr(idx, torch.int32),
+                                                     _lib.dev_ptr(cnt, torch.int32), R, s0 - c, c, S, _lib.dev_ptr(T), _lib.stream_ptr()),
+                   "nm_transmittance_chunk")
+        live = live[T[live] >= eps]
+    if stats is not None:
+        stats['human_evaluated'] = stats.get('human_evaluated', 0) + evaluated
+        stats['human_total'] = stats.get('human_total', 0) + R * S
+        stats['human_launches'] = stats.get('human_launches', 0) + launches
+    _note(trace, human_z=z)
+    return raw, z
 
 
 def _given_near_far(given, actor, i, j, o, d, verts, geo_threshold):
@@ -168,7 +254,7 @@ def bkg_pass_rays_fused(coarse_net, fine_net, o, d, near, far, samples_per_ray, 
 
 
 def bkg_pass_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, importance_samples_per_ray, white_bkg,
-                  precision=None, trace=None, given_z=None):
+                  precision=None, trace=None, given_z=None, occluder=None):
     """Coarse (+ fine) background evaluation of R rays -> (raw [R,S',4], z [R,S'])  (render_utils.py:131-151, 287-297).
 
     `given_z` [R, S'] (tests only, like `trace`): replay recorded final sample positions instead of deriving them -- the shading
@@ -186,15 +272,24 @@ def bkg_pass_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, import
     # with a fine net the coarse pass only places the importance samples; otherwise it is the pass that is composited
     # ('shading' role of the mixed precision policy, vanilla.Joiner._prec)
     # (and only its density is used, render_utils.py:139-141: the colour head is skipped)
-    raw = coarse_net.forward_rays(o, d, z, precision=precision, role=None if fine_net is not None else 'shading',
-                                  sigma_only=fine_net is not None)
+    if TERMINATION_EPS > 0:
+        # marched: a coarse pass at eps * TERMINATION_COARSE on its own transmittance only (where the importance samples go must not
+        # depend on what the list is merged with later); a pass that is composited at eps, `occluder` included (march_pass_rays)
+        stats = {} if trace is not None else None
+        raw = march_pass_rays(coarse_net, o, d, z, TERMINATION_EPS * (TERMINATION_COARSE if fine_net is not None else 1.0), precision=precision,
+                              role=None if fine_net is not None else 'shading', stats=stats, sigma_only=fine_net is not None,
+                              occluder=None if fine_net is not None else occluder)
+        _note(trace, **{'march_coarse' if fine_net is not None else 'march': stats})
+    else:
+        raw = coarse_net.forward_rays(o, d, z, precision=precision, role=None if fine_net is not None else 'shading',
+                                      sigma_only=fine_net is not None)
     if fine_net is not None:
         _, _, _, w, _ = raw2outputs(raw, z, d, white_bkg=white_bkg)
         _note(trace, coarse_z=z, coarse_w=w)
         z = ray_utils.importance_z(z, w, importance_samples_per_ray)
         if TERMINATION_EPS > 0:
             stats = {} if trace is not None else None
-            raw = march_pass_rays(fine_net, o, d, z, TERMINATION_EPS, precision=precision, stats=stats)
+            raw = march_pass_rays(fine_net, o, d, z, TERMINATION_EPS, precision=precision, stats=stats, occluder=occluder)
             _note(trace, march=stats)
         else:
             raw = fine_net.forward_rays(o, d, z, precision=precision, role='shading')
@@ -278,7 +373,12 @@ def render_smpl_nerf_rays(human_net, o, d, posed_verts, mesh, samples_per_ray, w
         ho, hd = ray_utils.gather_rows(oc, hit), ray_utils.gather_rows(dc, hit)
         hn, hf = ray_utils.gather_rows(near, hit), ray_utils.gather_rows(far, hit)
         _note(trace, hit=hit + i)
-        raw, z = human_pass_rays(human_net, ho, hd, hn, hf, samples_per_ray, mesh, render_can, interval_comp, precision, trace)
+        if TERMINATION_EPS > 0 and not render_can:
+            mstats = {} if trace is not None else None
+            raw, z = human_march_rays(human_net, ho, hd, hn, hf, samples_per_ray, mesh, TERMINATION_EPS, interval_comp, precision, None, trace, mstats)
+            _note(trace, march_human=mstats)
+        else:
+            raw, z = human_pass_rays(human_net, ho, hd, hn, hf, samples_per_ray, mesh, render_can, interval_comp, precision, trace)
         _rgb, _, _acc, _, _depth = raw2outputs(raw, z, hd, white_bkg=white_bkg, want_weights=False)
         ray_utils.scatter_rows(rgb[i:j], hit, _rgb)
         ray_utils.scatter_rows(depth[i:j], hit, _depth)
@@ -289,7 +389,9 @@ def render_smpl_nerf_rays(human_net, o, d, posed_verts, mesh, samples_per_ray, w
 def render_hybrid_rays(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far, posed_verts, mesh, samples_per_ray,
                        importance_samples_per_ray, white_bkg=True, geo_threshold=DEFAULT_GEO_THRESH, precision=None, trace=None,
                        given=None):
-    """Device core of render_hybrid_nerf -> (rgb [R,3], depth [R], acc [R]) CUDA  (render_utils.py:276-356).  `given`: see bkg_pass_rays."""
+    """Device core of render_hybrid_nerf -> (rgb [R,3], depth [R], acc [R]) CUDA  (render_utils.py:276-356).  `given`: see bkg_pass_rays.
+    With TERMINATION_EPS > 0 the human pass runs first (marched on its own transmittance) and the background passes are marched on the
+    transmittance of the MERGED list where they can know it (behind the body: their own x the body's): a pixel moves by < 2 eps."""
     R = o.shape[0]
     rgb = torch.empty((R, 3), device=o.device, dtype=torch.float32)
     depth = torch.empty(R, device=o.device, dtype=torch.float32)
@@ -298,20 +400,43 @@ def render_hybrid_rays(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far,
         oc, dc = o[i:j].contiguous(), d[i:j].contiguous()
         n = torch.full((j - i,), float(bkg_near), device=o.device, dtype=torch.float32)
         f = torch.full((j - i,), float(bkg_far), device=o.device, dtype=torch.float32)
+        given_z = given['bkg_z'][i:j] if given is not None and 'bkg_z' in given else None
+
+        def human_lists():
+            near, far = _given_near_far(given, 0, i, j, oc, dc, posed_verts, geo_threshold)
+            _note(trace, near=near, far=far)
+            hit, _ = ray_utils.compact_hits(near, far)
+            if hit.numel() == 0:
+                return hit, None, None, None, None
+            ho, hd = ray_utils.gather_rows(oc, hit), ray_utils.gather_rows(dc, hit)
+            hn, hf = ray_utils.gather_rows(near, hit), ray_utils.gather_rows(far, hit)
+            _note(trace, hit=hit + i)
+            if TERMINATION_EPS > 0:
+                mstats = {} if trace is not None else None
+                h_raw, h_z = human_march_rays(human_net, ho, hd, hn, hf, samples_per_ray, mesh, TERMINATION_EPS, 1.0, precision, None, trace, mstats)
+                _note(trace, march_human=mstats)
+            else:
+                h_raw, h_z = human_pass_rays(human_net, ho, hd, hn, hf, samples_per_ray, mesh, False, 1.0, precision, trace)
+            return hit, hd, hf, h_raw, h_z
+
+        occluder = None
+        if TERMINATION_EPS > 0:                                                                  # the body first: it may hide the background
+            hit, hd, hf, h_raw, h_z = human_lists()
+            if hit.numel() > 0:
+                z_far = torch.full((j - i,), float('inf'), device=o.device, dtype=torch.float32)
+                T_occ = torch.ones(j - i, device=o.device, dtype=torch.float32)
+                ray_utils.scatter_rows(z_far, hit, hf.reshape(-1))
+                ray_utils.scatter_rows(T_occ, hit, transmittance_of(h_raw, h_z, hd))
+                occluder = (z_far, T_occ)
         bkg_raw, bkg_z = bkg_pass_rays(coarse_bkg, fine_bkg, oc, dc, n, f, samples_per_ray, importance_samples_per_ray,
-                                       white_bkg, precision, trace, given['bkg_z'][i:j] if given is not None and 'bkg_z' in given else None)
+                                       white_bkg, precision, trace, given_z, occluder)
         # every ray first gets the background-only composite (what the reference does for misses, :303-311) ...
         rgb[i:j], _, _, _, depth[i:j] = raw2outputs(bkg_raw, bkg_z, dc, white_bkg=white_bkg, want_weights=False)
-        near, far = _given_near_far(given, 0, i, j, oc, dc, posed_verts, geo_threshold)
-        _note(trace, near=near, far=far)
-        hit, _ = ray_utils.compact_hits(near, far)
+        if TERMINATION_EPS <= 0:
+            hit, hd, hf, h_raw, h_z = human_lists()
         if hit.numel() == 0:
             continue
         # ... and hit rays are overwritten by the merged human + background composite (:313-353)
-        ho, hd = ray_utils.gather_rows(oc, hit), ray_utils.gather_rows(dc, hit)
-        hn, hf = ray_utils.gather_rows(near, hit), ray_utils.gather_rows(far, hit)
-        _note(trace, hit=hit + i)
-        h_raw, h_z = human_pass_rays(human_net, ho, hd, hn, hf, samples_per_ray, mesh, False, 1.0, precision, trace)
         S_b = bkg_z.shape[1]
         _rgb, _depth, _ = merge_composite(ray_utils.gather_rows(bkg_z, hit), ray_utils.gather_rows(bkg_raw.reshape(j - i, -1), hit).reshape(-1, S_b, 4),
                                           h_z, h_raw, hd, white_bkg)
@@ -326,7 +451,8 @@ def render_multi_rays(coarse_bkg, fine_bkg, human_nets, o, d, bkg_near, bkg_far,
                       importance_samples_per_ray, white_bkg=True, geo_threshold=DEFAULT_GEO_THRESH, precision=None, trace=None,
                       given=None):
     """Device core of render_hybrid_nerf_multi_persons -> (rgb [R,3], depth [R]) CUDA  (render_utils.py:390-456).  `given`: see
-    bkg_pass_rays."""
+    bkg_pass_rays.  TERMINATION_EPS > 0: as render_hybrid_rays (the actors first, each marched on its own transmittance; the background
+    behind the farthest body a ray hits on its own x all the bodies'); a pixel moves by < (1 + actors) eps."""
     R = o.shape[0]
     rgb = torch.empty((R, 3), device=o.device, dtype=torch.float32)
     depth = torch.empty(R, device=o.device, dtype=torch.float32)
@@ -335,31 +461,61 @@ def render_multi_rays(coarse_bkg, fine_bkg, human_nets, o, d, bkg_near, bkg_far,
         nr = j - i
         n = torch.full((nr,), float(bkg_near), device=o.device, dtype=torch.float32)
         f = torch.full((nr,), float(bkg_far), device=o.device, dtype=torch.float32)
-        raw_all, z_all = bkg_pass_rays(coarse_bkg, fine_bkg, oc, dc, n, f, samples_per_ray, importance_samples_per_ray,
-                                       white_bkg, precision, trace, given['bkg_z'][i:j] if given is not None and 'bkg_z' in given else None)
-        # In this renderer the terminal 1e10 interval sits on an actor's zero-density placeholder whenever a ray misses one
-        # (render_utils.py:418-419), so the LAST background sample is followed by a finite interval of ~far..2 far instead:
-        # alpha = 1 - exp(-sigma * 3.14..) is then ~300x as sensitive to that one sigma as a sample inside the ray is.  Under the
-        # mixed policy (i8x3 shading passes) that single sample per ray is re-evaluated in the float32-class arithmetic.
-        last_net = fine_bkg if fine_bkg is not None else coarse_bkg
-        if last_net._prec(precision, 'shading') == _lib.NM_PREC_I8X3 and (precision or last_net.precision) == 'mixed':
-            raw_all[:, -1, :] = last_net.forward_rays(oc, dc, z_all[:, -1:].contiguous(), precision='fp16x3')[:, 0, :]
         far_z = torch.linspace(float(bkg_far) * 2, float(bkg_far) * 3, samples_per_ray, device=o.device)   # :418-419
-        for a_, (net, verts, mesh) in enumerate(zip(human_nets, posed_verts, meshes)):
+
+        def actor_lists(a_):
+            """one actor's list over all rays of the batch: its samples where it is hit, the zero-density placeholders elsewhere"""
+            net, verts, mesh = human_nets[a_], posed_verts[a_], meshes[a_]
             near, far = _given_near_far(given, a_, i, j, oc, dc, verts, geo_threshold)
             _note(trace, near=near, far=far)
             h_raw = torch.zeros((nr, samples_per_ray, 4), device=o.device, dtype=torch.float32)
             h_z = far_z[None].repeat(nr, 1).contiguous()
             hit, _ = ray_utils.compact_hits(near, far)
             _note(trace, hit=hit + i)
+            occ = None
             if hit.numel() > 0:
                 ho, hd = ray_utils.gather_rows(oc, hit), ray_utils.gather_rows(dc, hit)
                 hn, hf = ray_utils.gather_rows(near, hit), ray_utils.gather_rows(far, hit)
-                r_, z_ = human_pass_rays(net, ho, hd, hn, hf, samples_per_ray, mesh, False, 1.0, precision, trace)
+                if TERMINATION_EPS > 0:
+                    mstats = {} if trace is not None else None
+                    r_, z_ = human_march_rays(net, ho, hd, hn, hf, samples_per_ray, mesh, TERMINATION_EPS, 1.0, precision, None, trace, mstats)
+                    _note(trace, march_human=mstats)
+                    occ = (hit, hf.reshape(-1), transmittance_of(r_, z_, hd))
+                else:
+                    r_, z_ = human_pass_rays(net, ho, hd, hn, hf, samples_per_ray, mesh, False, 1.0, precision, trace)
                 ray_utils.scatter_rows(h_raw.reshape(nr, -1), hit, r_.reshape(hit.shape[0], -1))
                 ray_utils.scatter_rows(h_z, hit, z_)
             else:
                 _note(trace, human_z=None, can_pts=None, can_dirs=None)
+            return h_z, h_raw, occ
+
+        lists, occluder = None, None
+        if TERMINATION_EPS > 0:                                                                  # the bodies first: they may hide the background
+            lists = [actor_lists(a_) for a_ in range(len(human_nets))]
+            z_far = torch.full((nr,), float('-inf'), device=o.device, dtype=torch.float32)
+            T_occ = torch.ones(nr, device=o.device, dtype=torch.float32)
+            for _, _, occ in lists:
+                if occ is not None:
+                    hit, hf, Th = occ
+                    idx = hit.to(torch.int64)
+                    z_far[idx] = torch.maximum(z_far[idx], hf)
+                    T_occ[idx] = T_occ[idx] * Th
+            z_far = torch.where(torch.isinf(z_far), torch.full_like(z_far, float('inf')), z_far)  # rays that hit nobody: never
+            occluder = (z_far, T_occ)
+        raw_all, z_all = bkg_pass_rays(coarse_bkg, fine_bkg, oc, dc, n, f, samples_per_ray, importance_samples_per_ray,
+                                       white_bkg, precision, trace, given['bkg_z'][i:j] if given is not None and 'bkg_z' in given else None, occluder)
+        # In this renderer the terminal 1e10 interval sits on an actor's zero-density placeholder whenever a ray misses one
+        # (render_utils.py:418-419), so the LAST background sample is followed by a finite interval of ~far..2 far instead:
+        # alpha = 1 - exp(-sigma * 3.14..) is then ~300x as sensitive to that one sigma as a sample inside the ray is.  Under the
+        # mixed policy (i8x3 shading passes) that single sample per ray is re-evaluated in the float32-class arithmetic.
+        last_net = fine_bkg if fine_bkg is not None else coarse_bkg
+        if last_net._prec(precision, 'shading') == _lib.NM_PREC_I8X3 and (precision or last_net.precision) == 'mixed':
+            last = last_net.forward_rays(oc, dc, z_all[:, -1:].contiguous(), precision='fp16x3')[:, 0, :]
+            if TERMINATION_EPS > 0:                                                              # a sample the march never reached stays unevaluated
+                last = torch.where((raw_all[:, -1, :] == 0).all(-1, keepdim=True), raw_all[:, -1, :], last)
+            raw_all[:, -1, :] = last
+        for a_ in range(len(human_nets)):
+            h_z, h_raw, _ = lists[a_] if lists is not None else actor_lists(a_)
             z_all, raw_all = merge_sorted(z_all, raw_all, h_z, h_raw)                                   # :441-448, list by list
         rgb[i:j], _, _, _, depth[i:j] = raw2outputs(raw_all, z_all, dc, white_bkg=white_bkg, want_weights=False)
     return rgb, depth

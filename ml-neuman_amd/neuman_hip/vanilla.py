@@ -241,13 +241,15 @@ class Joiner(nn.Module):
                          _lib.dev_ptr(out), _lib.stream_ptr()), "nm_mlp_sigma_rays" if sigma_only else "nm_mlp_forward_rays")
         return out
 
-    def forward_ray_chunk(self, origin, direction, z_vals, ray_idx, n_rays_dev, s0, chunk, out, precision=None, sigma_scale=1.0, role=None):
+    def forward_ray_chunk(self, origin, direction, z_vals, ray_idx, n_rays_dev, s0, chunk, out, precision=None, sigma_scale=1.0, role=None,
+                          sigma_only=False):
         """One chunk of a front-to-back march (nm_mlp_forward_ray_chunk): samples s0 .. s0+chunk-1 of the rays listed in
         `ray_idx` (int32; only its first *n_rays_dev entries are live -- the count stays on the device) are evaluated and written
-        into `out` [R,S,4]; nothing else of `out` is touched."""
+        into `out` [R,S,4]; nothing else of `out` is touched.  sigma_only: as forward_rays."""
         self._guard(origin, direction, z_vals)
         R, S = z_vals.shape
-        _lib.check(_lib.lib().nm_mlp_forward_ray_chunk(
+        entry = _lib.lib().nm_mlp_sigma_ray_chunk if sigma_only else _lib.lib().nm_mlp_forward_ray_chunk
+        _lib.check(entry(
             self.handle(), _lib.dev_ptr(origin, name='origin'), _lib.dev_ptr(direction, name='direction'), _lib.dev_ptr(z_vals, name='z_vals'), S,
             _lib.dev_ptr(ray_idx, torch.int32, 'ray_idx'), _lib.dev_ptr(n_rays_dev, torch.int32, 'n_rays_dev'), ray_idx.shape[0], int(s0), int(chunk),
             self._prec(precision, role), float(sigma_scale), _lib.dev_ptr(out), _lib.stream_ptr()), "nm_mlp_forward_ray_chunk")

@@ -95,3 +95,117 @@ def test_renderer_switch(scene):
     assert st['evaluated'] < 0.8 * st['total'] and (a - b).abs().max().item() <= 1e-4
     c, _ = R.render_vanilla_rays(net, net, o, d, 0.0, 3.14, 128, 128)
     assert torch.equal(a, c)
+
+
+# ---- round 3: the coarse pass, the human passes and the hybrid renderers ------------------------------------------------------
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+import posed_scene as PS  # noqa: E402
+
+
+def test_density_only_chunks_are_bit_identical_to_the_density_only_launch(scene):
+    """the coarse pass marched with eps = 0 (nm_mlp_sigma_ray_chunk) = nm_mlp_sigma_rays, bit for bit"""
+    o, d, net = scene['o'], scene['d'], scene['net']
+    R = o.shape[0]
+    _, _, z = scene['ray'].sample_z(o, d, torch.zeros(R, device='cuda'), torch.full((R,), 3.14, device='cuda'), 128)
+    full = net.forward_rays(o, d, z, sigma_only=True)
+    marched = scene['render'].march_pass_rays(net, o, d, z, 0.0, chunk=48, role=None, sigma_only=True)
+    assert torch.equal(marched, full)
+
+
+def test_adaptive_march_stops_launching_and_stays_within_eps(scene):
+    """the same frame slice as above with the adaptive schedule (one host read per chunk): fewer evaluations than fixed 32-sample
+    chunks, still within eps; and the vanilla renderer with the coarse pass marched too"""
+    o, d, net = scene['o'], scene['d'], scene['net']
+    z = fine_z(scene)
+    full = net.forward_rays(o, d, z, role='shading')
+    rgb_full = scene['render'].raw2outputs(full, z, d)[0]
+    st_fixed, st_adapt = {}, {}
+    fixed = scene['render'].march_pass_rays(net, o, d, z, 1e-4, stats=st_fixed, adaptive=False)
+    adapt = scene['render'].march_pass_rays(net, o, d, z, 1e-4, stats=st_adapt)
+    for m in (fixed, adapt):
+        assert (scene['render'].raw2outputs(m, z, d)[0] - rgb_full).abs().max().item() <= 1e-4
+    print(f"[march] evaluated: fixed chunks {st_fixed['evaluated'] / st_fixed['total']:.3f} in {st_fixed['launches']} launches, adaptive "
+          f"{st_adapt['evaluated'] / st_adapt['total']:.3f} in {st_adapt['launches']} launches")
+    assert st_adapt['evaluated'] < st_fixed['evaluated']
+    R = scene['render']
+    a, _ = R.render_vanilla_rays(net, net, o, d, 0.0, 3.14, 128, 128)
+    old = R.TERMINATION_EPS
+    try:
+        R.TERMINATION_EPS = 1e-4
+        tr = {}
+        b, _ = R.render_vanilla_rays(net, net, o, d, 0.0, 3.14, 128, 128, trace=tr)
+    finally:
+        R.TERMINATION_EPS = old
+    c, f = tr['march_coarse'][0], tr['march'][0]
+    print(f"[march] vanilla renderer, eps 1e-4: coarse pass {c['evaluated'] / c['total']:.3f} evaluated, fine pass {f['evaluated'] / f['total']:.3f}, "
+          f"colour Linf vs every sample {(a - b).abs().max().item():.2e}")
+    assert c['evaluated'] < 0.8 * c['total'] and (a - b).abs().max().item() <= 1e-4
+
+
+@pytest.fixture(scope="module")
+def body():
+    from neuman_hip import ray_utils, render_utils, synthetic
+    g = PS.load()
+    g['R'], g['ray'] = render_utils, ray_utils
+    g['mesh'] = ray_utils.mesh_to_device(g['posed_verts'], np.ascontiguousarray(g['faces'][:, :3], np.int32), g['T'], 'cuda')
+    g['meshes'] = [ray_utils.mesh_to_device(v, np.ascontiguousarray(g['faces'][:, :3], np.int32), t, 'cuda') for v, t in zip(g['posed_l'], g['T_l'])]
+    g['bkg'] = synthetic.make_joiner(1, preset='opaque').cuda()
+    g['human'] = synthetic.make_joiner(2, 'rotate', preset='opaque').cuda()
+    return g
+
+
+def test_human_march_without_termination_is_bit_identical(body):
+    """human_march_rays at eps = 0 = human_pass_rays (one fused call): every sample's warp, direction and network output"""
+    c = PS.cap(body, 'posed')
+    o, d = (cu(x) for x in PS.frame_rays(c))
+    near, far = body['ray'].geometry_guided_near_far(o, d, cu(body['posed_verts']), 0.2)
+    hit, _ = body['ray'].compact_hits(near, far)
+    assert hit.numel() > 200
+    ho, hd = body['ray'].gather_rows(o, hit), body['ray'].gather_rows(d, hit)
+    hn, hf = body['ray'].gather_rows(near, hit), body['ray'].gather_rows(far, hit)
+    for S_h, chunk in ((128, 16), (128, 40), (33, 16)):                                  # 33 = 2 x 16 + a lone last sample
+        full, z = body['R'].human_pass_rays(body['human'], ho, hd, hn, hf, S_h, body['mesh'])
+        marched, zm = body['R'].human_march_rays(body['human'], ho, hd, hn, hf, S_h, body['mesh'], 0.0, chunk=chunk)
+        assert torch.equal(z, zm) and torch.equal(marched, full), (S_h, chunk)
+
+
+@pytest.mark.parametrize("which", ["posed", "hybrid", "multi"])
+def test_renderers_with_termination(body, which):
+    """opaque body in front of an opaque background: eps = 1e-4 skips evaluations in every pass and moves no pixel by more than the
+    bound (eps for the body alone, 2 eps for body + background, (1 + actors) eps for three bodies); eps = 0 is the plain path"""
+    R = body['R']
+    c = PS.cap(body, which)
+    o, d = (cu(x) for x in PS.frame_rays(c))
+    bkg, human = body['bkg'], body['human']
+
+    def run(trace=None):
+        if which == 'posed':
+            return R.render_smpl_nerf_rays(human, o, d, cu(body['posed_verts']), body['mesh'], 128, True, False, 0.2, 1.0, trace=trace)[0]
+        if which == 'hybrid':
+            return R.render_hybrid_rays(bkg, bkg, human, o, d, c.near['bkg'], c.far['bkg'], cu(body['posed_verts']), body['mesh'], 128, 128, trace=trace)[0]
+        return R.render_multi_rays(bkg, bkg, [human] * 3, o, d, c.near['bkg'], c.far['bkg'], [cu(v) for v in body['posed_l']], body['meshes'], 192, 128,
+                                   trace=trace)[0]
+
+    a = run()
+    old = R.TERMINATION_EPS
+    try:
+        R.TERMINATION_EPS = 1e-4
+        tr = {}
+        b = run(tr)
+    finally:
+        R.TERMINATION_EPS = old
+    assert torch.equal(run(), a)
+    bound = {'posed': 1e-4, 'hybrid': 2e-4, 'multi': 4e-4}[which]
+    hs = tr['march_human']
+    he, ht = sum(s_['human_evaluated'] for s_ in hs), sum(s_['human_total'] for s_ in hs)
+    msg = f"[march] {which}: body passes {he / ht:.3f} evaluated"
+    if which != 'posed':
+        f_, c_ = tr['march'][0], tr['march_coarse'][0]
+        msg += f", background coarse {c_['evaluated'] / c_['total']:.3f}, fine {f_['evaluated'] / f_['total']:.3f}"
+        assert f_['evaluated'] < 0.9 * f_['total']
+    e = (a - b).abs().max().item()
+    print(msg + f", colour Linf vs every sample {e:.2e} (bound {bound:g})")
+    assert he < 0.8 * ht and e <= bound
