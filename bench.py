@@ -489,8 +489,8 @@ def main():
             workloads = {"opaque_preset_early_termination": {
                 "what": "800x800, 128 + 128 samples, synthetic.make_joiner(1, preset='opaque') as coarse and fine net; both passes marched front to "
                         "back in chunks with ballot / prefix-sum compaction of the live rays between chunks (nm_mlp_sigma_ray_chunk / "
-                        "nm_mlp_forward_ray_chunk, nm_transmittance_chunk, nm_compact_hits): the fine pass cut at eps, the coarse pass at eps * 1e-3 "
-                        "(render_utils.TERMINATION_COARSE); one host read per chunk (the live count: no launch once nobody is live, chunk halved "
+                        "nm_mlp_forward_ray_chunk, nm_transmittance_chunk, nm_compact_hits): the fine pass cut at eps, the coarse pass at transmittance 4e-13 "
+                        "(render_utils.TERMINATION_COARSE: under half a float32 ulp of sample_pdf's 1e-5, so the importance samples are bit-identical); one host read per chunk (the live count: no launch once nobody is live, chunk halved "
                         "to 16 samples while rays are being cut)",
                 "eps": 1e-4, "rays_per_s_every_sample": total / res[0.0][1], "rays_per_s_terminated": total / res[1e-4][1],
                 "speedup": res[0.0][1] / res[1e-4][1], "fine_evaluations_done": st['evaluated'] / st['total'] if st else None,

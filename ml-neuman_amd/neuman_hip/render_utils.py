@@ -29,10 +29,12 @@ MAX_RAYS_PER_LAUNCH = int(os.environ.get("NEUMAN_MAX_RAYS_PER_LAUNCH", 1 << 20))
 # and the frame is bit-identical to the unchunked path.  eps > 0 changes a pixel by at most eps per channel.
 TERMINATION_EPS = float(os.environ.get("NEUMAN_TERMINATION_EPS", "0"))
 TERMINATION_CHUNK = int(os.environ.get("NEUMAN_TERMINATION_CHUNK", "32"))
-# With termination on, the COARSE pass of a two-pass render is marched too, cut at eps * this: the weights it then never computes
-# are below that each and in sum, 100 x under the 1e-5 the inverse CDF adds to every bin (ray_utils.py:168), so the importance samples
-# stay where they were to a fraction of an empty bin's width.
-TERMINATION_COARSE = float(os.environ.get("NEUMAN_TERMINATION_COARSE", "1e-3"))
+# With termination on, the COARSE pass of a two-pass render is marched too, at this transmittance whatever eps is: the weights it then
+# never computes are all below it, and 4e-13 is less than half a float32 ulp of the 1e-5 that sample_pdf adds to every weight
+# (ray_utils.py:168: spacing of float32 at 1e-5 = 9.1e-13) -- `weights + 1e-5` is the same float32 number with or without them, so
+# the importance samples are BIT-IDENTICAL to the full evaluation's.  (A cut at eps * 1e-3 = 1e-7 was tried first: it perturbs the
+# CDF at float32-rounding level, which the inverse CDF amplifies in near-empty bins: 1.6e-4 on the worst pixel of a frame.)
+TERMINATION_COARSE = float(os.environ.get("NEUMAN_TERMINATION_COARSE", "4e-13"))
 TERMINATION_MIN_CHUNK = 16
 
 
@@ -273,10 +275,10 @@ def bkg_pass_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, import
     # ('shading' role of the mixed precision policy, vanilla.Joiner._prec)
     # (and only its density is used, render_utils.py:139-141: the colour head is skipped)
     if TERMINATION_EPS > 0:
-        # marched: a coarse pass at eps * TERMINATION_COARSE on its own transmittance only (where the importance samples go must not
-        # depend on what the list is merged with later); a pass that is composited at eps, `occluder` included (march_pass_rays)
+        # marched: a coarse pass at TERMINATION_COARSE on its own transmittance only (where the importance samples go must not depend
+        # on what the list is merged with later); a pass that is composited at eps, `occluder` included (march_pass_rays)
         stats = {} if trace is not None else None
-        raw = march_pass_rays(coarse_net, o, d, z, TERMINATION_EPS * (TERMINATION_COARSE if fine_net is not None else 1.0), precision=precision,
+        raw = march_pass_rays(coarse_net, o, d, z, TERMINATION_COARSE if fine_net is not None else TERMINATION_EPS, precision=precision,
                               role=None if fine_net is not None else 'shading', stats=stats, sigma_only=fine_net is not None,
                               occluder=None if fine_net is not None else occluder)
         _note(trace, **{'march_coarse' if fine_net is not None else 'march': stats})

@@ -139,6 +139,9 @@ def test_adaptive_march_stops_launching_and_stays_within_eps(scene):
         b, _ = R.render_vanilla_rays(net, net, o, d, 0.0, 3.14, 128, 128, trace=tr)
     finally:
         R.TERMINATION_EPS = old
+    tr0 = {}
+    R.render_vanilla_rays(net, net, o, d, 0.0, 3.14, 128, 128, trace=tr0)
+    assert torch.equal(tr['bkg_z'][0], tr0['bkg_z'][0]), "the marched coarse pass must leave the importance samples bit-identical"
     c, f = tr['march_coarse'][0], tr['march'][0]
     print(f"[march] vanilla renderer, eps 1e-4: coarse pass {c['evaluated'] / c['total']:.3f} evaluated, fine pass {f['evaluated'] / f['total']:.3f}, "
           f"colour Linf vs every sample {(a - b).abs().max().item():.2e}")
