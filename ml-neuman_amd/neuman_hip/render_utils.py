@@ -177,7 +177,8 @@ def human_march_rays(human_net, o, d, near, far, samples_per_ray, mesh, eps, sig
     has entered an opaque body needs neither the closest-point queries nor the network behind the surface.  Front to back in chunks; the
     live rays' samples of a chunk are gathered, warped (one sample past the chunk: the canonical direction of a sample is the forward
     difference to the next warped point, ray_utils.py:62-64 -- the last sample of a ray repeats its predecessor's), evaluated and
-    scattered back; rays whose transmittance over their own (human) samples is below eps are dropped.  Merged with any other list the
+    scattered back; rays whose transmittance over their own (human) samples is below eps are dropped (chunks of `chunk` samples, doubled
+    after every chunk that cut fewer than 2 % of the live rays, halved otherwise).  Merged with any other list the
     transmittance can only be lower, so what is skipped weighs < eps in every composite the renderers make of it.  Every evaluated
     sample is bit-identical to human_pass_rays' (per-sample arithmetic; tests/test_hip_march.py)."""
     _lib.require_gpu()
@@ -209,7 +210,10 @@ def human_march_rays(human_net, o, d, near, far, samples_per_ray, mesh, eps, sig
         _lib.check(_lib.lib().nm_transmittance_chunk(_lib.dev_ptr(raw), _lib.dev_ptr(z), _lib.dev_ptr(d), _lib.dev_ptr(idx, torch.int32),
                                                      _lib.dev_ptr(cnt, torch.int32), R, s0 - c, c, S, _lib.dev_ptr(T), _lib.stream_ptr()),
                    "nm_transmittance_chunk")
+        n_live = live.numel()
         live = live[T[live] >= eps]
+        # (march_pass_rays' rule: short chunks while rays are being cut, doubling when nothing happens)
+        chunk = max(TERMINATION_MIN_CHUNK, chunk // 2) if live.numel() < 0.98 * n_live else chunk * 2
     if stats is not None:
         stats['human_evaluated'] = stats.get('human_evaluated', 0) + evaluated
         stats['human_total'] = stats.get('human_total', 0) + R * S
