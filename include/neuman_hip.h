@@ -267,6 +267,20 @@ typedef struct nm_smpl_s* nm_smpl_t;
 int nm_smpl_create(const float* v_template, const float* shapedirs, const float* j_regressor, const int32_t* parents,
                    const float* lbs_weights, const float* da_pose, int V, int J, int NB, nm_smpl_t* out);
 int nm_smpl_destroy(nm_smpl_t smpl);
+/* The differentiable form of ONE frame -- HumanNeRF.vertex_forward under autograd in the human trainer (models/human_nerf.py:92-122
+ * over models/smpl.py:266-360; SURVEY 8f-1: gradients of the loss with respect to the frame's pose, shape and alignment), float32
+ * throughout like the reference.  DEVICE pointers: pose [J*3], beta [NB] f32, alignment [4,4] f64 (its TRANSPOSE is applied),
+ * da_pose [J*3] f32 or null (= the handle's).  workspace: nm_smpl_vertex_workspace_floats() floats.
+ *   forward:  world_out [V,3], T_out [V,4,4] f32 (T_da2scene of the vertices; two launches)
+ *   backward: upstream g_world [V,3] and / or g_T [V,4,4] (null = zero) -> g_pose [J*3], g_beta [NB], g_align [4,4] (gradient with
+ *             respect to `alignment` as passed).  Six launches, every reduction in a fixed order (no float atomics): run to run
+ *             bit-identical.  Nothing is kept between the two calls: backward recomputes the joints. */
+int64_t nm_smpl_vertex_workspace_floats(nm_smpl_t smpl);
+int nm_smpl_vertex_forward(nm_smpl_t smpl, const float* pose, const float* beta, const double* alignment, double scale, const float* da_pose,
+                           float* workspace, float* world_out, float* T_out, nm_stream_t stream);
+int nm_smpl_vertex_backward(nm_smpl_t smpl, const float* pose, const float* beta, const double* alignment, double scale, const float* da_pose,
+                            const float* g_world, const float* g_T, float* workspace, float* g_pose, float* g_beta, float* g_align,
+                            nm_stream_t stream);
 int nm_smpl_frames(nm_smpl_t smpl, const float* poses, const float* betas, const double* alignments, int B, double scale,
                    int precise, double* T_out, float* world_out, float* static_out, nm_stream_t stream);
 

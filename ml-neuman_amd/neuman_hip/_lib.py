@@ -67,6 +67,10 @@ SIGNATURES = {
     "nm_warp_to_canonical": (i32, [ctypes.c_void_p, c_f32p, i64, i32, ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_stream]),
     "nm_smpl_create": (i32, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, i32, i32, i32, ctypes.POINTER(ctypes.c_void_p)]),
     "nm_smpl_destroy": (i32, [ctypes.c_void_p]),
+    "nm_smpl_vertex_workspace_floats": (i64, [ctypes.c_void_p]),
+    "nm_smpl_vertex_forward": (i32, [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_double, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
+    "nm_smpl_vertex_backward": (i32, [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_double, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                      c_f32p, c_f32p, c_stream]),
     "nm_smpl_frames": (i32, [ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_void_p, i32, ctypes.c_double, i32, ctypes.c_void_p, c_f32p, c_f32p,
                              c_stream]),
     "nm_gemm_workspace_floats": (i64, [i32, i32, i32]),

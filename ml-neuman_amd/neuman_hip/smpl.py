@@ -136,6 +136,44 @@ def vertex_forward(body_model, pose, beta, alignment, scale):
 # ------------------------------------------------------------------------------------------------
 # differentiable skinning for training: gradients to poses / betas / alignments
 # ------------------------------------------------------------------------------------------------
+class _VertexForwardFn(torch.autograd.Function):
+    """HumanNeRF.vertex_forward of one frame on the hand-written kernels (csrc/smpl.hip: nm_smpl_vertex_forward / _backward): two launches
+    forward, six backward, instead of the ~800 launches torch's autograd makes of the same chain."""
+
+    @staticmethod
+    def forward(ctx, owner, pose, beta, alignment, scale, da_pose):
+        h = owner._hip_handle()
+        dev = pose.device
+        V = owner.v_template.shape[0]
+        po, be = pose.detach().reshape(-1).contiguous().float(), beta.detach().reshape(-1).contiguous().float()
+        al = alignment.detach().to(torch.float64).contiguous()
+        da = da_pose.detach().reshape(-1).contiguous().float()
+        ws = torch.empty(int(_lib.lib().nm_smpl_vertex_workspace_floats(h)), device=dev, dtype=torch.float32)
+        world = torch.empty((V, 3), device=dev, dtype=torch.float32)
+        T = torch.empty((V, 4, 4), device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib().nm_smpl_vertex_forward(h, _lib.dev_ptr(po), _lib.dev_ptr(be), _lib.dev_ptr(al, torch.float64), float(scale), _lib.dev_ptr(da),
+                                                     _lib.dev_ptr(ws), _lib.dev_ptr(world), _lib.dev_ptr(T), _lib.stream_ptr()), "nm_smpl_vertex_forward")
+        ctx.owner, ctx.scale, ctx.shapes = owner, float(scale), (pose.shape, beta.shape)
+        ctx.save_for_backward(po, be, al, da)
+        return world, T
+
+    @staticmethod
+    def backward(ctx, g_world, g_T):
+        po, be, al, da = ctx.saved_tensors
+        owner = ctx.owner
+        h = owner._hip_handle()
+        dev = po.device
+        ws = torch.empty(int(_lib.lib().nm_smpl_vertex_workspace_floats(h)), device=dev, dtype=torch.float32)
+        g_pose, g_beta = torch.empty_like(po), torch.empty_like(be)
+        g_al = torch.empty(16, device=dev, dtype=torch.float32)
+        gw = g_world.contiguous().float() if g_world is not None else None
+        gt = g_T.contiguous().float() if g_T is not None else None
+        _lib.check(_lib.lib().nm_smpl_vertex_backward(h, _lib.dev_ptr(po), _lib.dev_ptr(be), _lib.dev_ptr(al, torch.float64), ctx.scale, _lib.dev_ptr(da),
+                                                      _lib.dev_ptr(gw), _lib.dev_ptr(gt), _lib.dev_ptr(ws), _lib.dev_ptr(g_pose), _lib.dev_ptr(g_beta),
+                                                      _lib.dev_ptr(g_al), _lib.stream_ptr()), "nm_smpl_vertex_backward")
+        return None, g_pose.reshape(ctx.shapes[0]), g_beta.reshape(ctx.shapes[1]), g_al.reshape(4, 4), None, None
+
+
 class SMPLDiff(torch.nn.Module):
     """HumanNeRF.vertex_forward (models/human_nerf.py:92-122) with autograd, for the trainer's pose refinement: the skinning
     chain of models/smpl.py:266-360 (shape blend, joint regression, Rodrigues, 24-joint kinematic chain, blend of the joint
@@ -198,10 +236,46 @@ class SMPLDiff(torch.nn.Module):
         T = torch.einsum('vj,jab->vab', self.lbs_weights, A)                                        # :338-341
         return T, v_shaped
 
+    def _hip_handle(self):
+        """the device copy of the model behind the hand-written kernels (created on first use)"""
+        if getattr(self, '_handle', None) is None:
+            import ctypes
+            f = lambda t: np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))      # noqa: E731
+            vt, sd, jr, w = f(self.v_template), f(self.shapedirs), f(self.J_regressor), f(self.lbs_weights)
+            p32 = np.ascontiguousarray(np.asarray(self.parents_list, np.int32))
+            da = f(self.da_smpl).reshape(-1)
+            self._handle = ctypes.c_void_p()
+            _lib.check(_lib.lib().nm_smpl_create(vt.ctypes.data_as(ctypes.c_void_p), sd.ctypes.data_as(ctypes.c_void_p), jr.ctypes.data_as(ctypes.c_void_p),
+                                                 p32.ctypes.data_as(ctypes.c_void_p), w.ctypes.data_as(ctypes.c_void_p), da.ctypes.data_as(ctypes.c_void_p),
+                                                 vt.shape[0], jr.shape[0], sd.shape[-1], ctypes.byref(self._handle)), "nm_smpl_create")
+        return self._handle
+
+    def __del__(self):
+        try:
+            if getattr(self, '_handle', None):
+                _lib.lib().nm_smpl_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def __getstate__(self):                                          # (copies / pickles rebuild the device copy on first use)
+        st = self.__dict__.copy()
+        st['_handle'] = None
+        return st
+
     def vertex_forward(self, pose, beta, alignment, scale, da_pose=None):
         """pose [1,J*3], beta [1,NB], alignment [4,4] (human_nerf.py's self.alignments[idx]: its TRANSPOSE is applied), scale ->
         world_verts [1,V,3], T_da2scene [1,V,4,4]; differentiable in pose, beta and alignment.  `da_pose` [1,J*3]: the canonical
-        pose to use instead of the built-in one (HumanNeRF keeps it as its `da_smpl` parameter)."""
+        pose to use instead of the built-in one (HumanNeRF keeps it as its `da_smpl` parameter).  On the GPU: csrc/smpl.hip's
+        kernels, forward and backward (`vertex_forward_torch` is the same chain as torch tensor algebra, kept as the checker)."""
+        if pose.is_cuda and pose.dtype == torch.float32 and isinstance(scale, (int, float)):
+            da = self.da_smpl if da_pose is None else da_pose
+            world, T = _VertexForwardFn.apply(self, pose, beta, alignment, float(scale), da)
+            return world[None], T[None]
+        return self.vertex_forward_torch(pose, beta, alignment, scale, da_pose)
+
+    def vertex_forward_torch(self, pose, beta, alignment, scale, da_pose=None):
+        """vertex_forward as batched tensor algebra under torch's autograd (any device, any dtype)"""
         T_pose, v_shaped = self.transformations(pose, beta)
         T_da, _ = self.transformations((self.da_smpl if da_pose is None else da_pose).to(pose.dtype), beta)
         T_da2pose = T_pose @ torch.inverse(T_da)                                                    # human_nerf.py:109

@@ -1,0 +1,60 @@
+"""-m gpu: the hand-written differentiable skinning (csrc/smpl.hip nm_smpl_vertex_forward / nm_smpl_vertex_backward behind
+SMPLDiff.vertex_forward = HumanNeRF.vertex_forward, models/human_nerf.py:92-122 over models/smpl.py:266-360) against the same chain
+as torch tensor algebra under torch's autograd (SMPLDiff.vertex_forward_torch, itself held to the reference's autograd by
+tests/golden/smpl_grad.npz): outputs and the gradients to pose, shape and alignment, for gradients arriving through the vertices,
+through the transforms, and through both."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def body():
+    from neuman_hip import smpl, synthetic
+    return smpl.SMPLDiff(synthetic.smpl_like_model(0), 'cuda'), synthetic
+
+
+def leaf(x):
+    return torch.tensor(np.ascontiguousarray(x), dtype=torch.float32, device='cuda', requires_grad=True)
+
+
+@pytest.mark.parametrize("through", ["world", "T", "both"])
+def test_forward_and_gradients_equal_torch_autograd(body, through):
+    b, syn = body
+    pose, betas, align = syn.smpl_like_frames(3, 0)
+    g = torch.Generator(device='cuda').manual_seed(5)
+    V = b.v_template.shape[0]
+    gw = torch.randn((1, V, 3), device='cuda', generator=g)
+    gT = torch.randn((1, V, 4, 4), device='cuda', generator=g)
+    for f in range(3):
+        al = np.concatenate([align[f'{f:05d}.png'], np.array([[0.], [0.], [0.], [1.]])], 1).astype(np.float32)
+        res = {}
+        for name in ("hip", "torch"):
+            p, be, a = leaf(pose[f][None] * 0.7), leaf(betas[f][None] * 0.5), leaf(al)
+            fn = b.vertex_forward if name == "hip" else b.vertex_forward_torch
+            world, T = fn(p, be, a, 1.3)
+            loss = (world * gw).sum() * (through != "T") + (T * gT).sum() * (through != "world")
+            loss.backward()
+            res[name] = [x.detach().double().cpu().numpy() for x in (world, T, p.grad, be.grad, a.grad)]
+        for what, x, y in zip(("world", "T", "g_pose", "g_beta", "g_align"), res["hip"], res["torch"]):
+            scale = np.abs(y).max() + 1e-30
+            e = np.abs(x - y).max() / scale
+            print(f"[smpl-diff] frame {f}, gradient through {through}: {what} max |hip - torch| / max |torch| = {e:.2e}")
+            assert e < (2e-5 if what in ("world", "T") else 2e-4), (f, what, e)
+
+
+def test_run_to_run_bit_identical_and_no_leftover_state(body):
+    b, syn = body
+    pose, betas, align = syn.smpl_like_frames(2, 1)
+    al = np.concatenate([align['00001.png'], np.array([[0.], [0.], [0.], [1.]])], 1).astype(np.float32)
+    outs = []
+    for _ in range(2):
+        p, be, a = leaf(pose[1][None]), leaf(betas[1][None]), leaf(al)
+        world, T = b.vertex_forward(p, be, a, 1.0)
+        (world.square().sum() + T.square().sum()).backward()
+        outs.append([x.detach().clone() for x in (world, T, p.grad, be.grad, a.grad)])
+        b.vertex_forward(leaf(pose[0][None]), leaf(betas[0][None]), leaf(al), 2.0)               # another frame in between
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
