@@ -242,6 +242,14 @@ int nm_warp_to_canonical(nm_mesh_t mesh, const float* pts, int64_t R, int S, con
 int nm_signed_distance(nm_mesh_t mesh, const float* pts, int64_t N, float* sdist, int32_t* face, float* closest,
                        nm_stream_t stream);
 
+/* The differentiable warp of the human trainer (utils/ray_utils.py:85-93 + trainers/human_nerf_trainer.py:262-266), per sample i of N:
+ *   can[i] = inv( sum_k bary[i][k] T[tri[i][k]] ) [pts[i]; 1]     T [V,4,4] f32, tri [N,3] int32 vertex ids, bary / pts / can [N,3] f32
+ * forward and backward as one kernel each.  backward: g_can [N,3] -> g_T [V,4,4] (cleared here, then float atomics: the summation
+ * order over a vertex's samples is not fixed) and g_bary [N,3]; the points carry no gradient (the trainer detaches them). */
+int nm_warp_apply_forward(const float* T, const int32_t* tri, const float* bary, const float* pts, int64_t N, float* can, nm_stream_t stream);
+int nm_warp_apply_backward(const float* T, const int32_t* tri, const float* bary, const float* pts, const float* g_can, int64_t N, int64_t V,
+                           float* g_T, float* g_bary, nm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * a12  SMPL linear blend skinning, batched over frames -- reference models/smpl.py:266-360 (lbs),
  *   :407-438 (batch_rodrigues), :454-505 (batch_rigid_transform), :109-216 (SMPL.verts_transformations /

@@ -700,6 +700,98 @@ struct nm_mesh_s {
     void* d_pn_scratch;  // face / vertex normals and the vertex -> faces table of that build (freed with the handle: no sync on the way)
 };
 
+// =====================================================================================================================================
+// The differentiable warp of the human trainer (reference utils/ray_utils.py:85-93 + trainers/human_nerf_trainer.py:262-266): per sample
+// T_interp = sum_k bary_k T[tri_k] (blend of the closest triangle's vertex transforms), canonical point = inv(T_interp) [p; 1].  Forward
+// and backward as ONE kernel each instead of a gather, a product, a sum, a batched LU inverse and a batched 4x4 product under autograd
+// (and their adjoints, among them the sort-based index_put of the gather).  Gradients: to the vertex transforms T (float atomics: the
+// order in which the samples of a vertex arrive is not fixed) and to the barycentric coordinates (which torch differentiates on to the
+// posed vertices).  The points carry no gradient (the trainer detaches them, :262).
+namespace {
+
+__device__ __forceinline__ void inv4x4_all(const double* m, double* o) {
+    const double s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2], s2 = m[0] * m[7] - m[4] * m[3];
+    const double s3 = m[1] * m[6] - m[5] * m[2], s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
+    const double c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11], c3 = m[9] * m[14] - m[13] * m[10];
+    const double c2 = m[8] * m[15] - m[12] * m[11], c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
+    const double inv = 1.0 / (s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0);
+    o[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * inv;    o[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * inv;
+    o[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * inv; o[3] = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * inv;
+    o[4] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * inv;   o[5] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * inv;
+    o[6] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * inv; o[7] = (m[8] * s5 - m[10] * s2 + m[11] * s1) * inv;
+    o[8] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * inv;    o[9] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * inv;
+    o[10] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * inv; o[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * inv;
+    o[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * inv;  o[13] = (m[0] * c3 - m[1] * c1 + m[2] * c0) * inv;
+    o[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * inv; o[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * inv;
+}
+
+// blended transform of sample i and its inverse (float32 values; the inverse through float64 cofactors)
+__device__ __forceinline__ void blend_inverse(const float* __restrict__ T, const int32_t* __restrict__ tri, const float* __restrict__ bary, int64_t i,
+                                              float* inv) {
+    const float b0 = bary[i * 3], b1 = bary[i * 3 + 1], b2 = bary[i * 3 + 2];
+    const float* T0 = T + (int64_t)tri[i * 3] * 16;
+    const float* T1 = T + (int64_t)tri[i * 3 + 1] * 16;
+    const float* T2 = T + (int64_t)tri[i * 3 + 2] * 16;
+    double M[16], Mi[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) M[q] = (double)(T0[q] * b0 + T1[q] * b1 + T2[q] * b2);
+    inv4x4_all(M, Mi);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) inv[q] = (float)Mi[q];
+}
+
+__global__ __launch_bounds__(256) void warp_apply_forward_kernel(const float* __restrict__ T, const int32_t* __restrict__ tri,
+                                                                 const float* __restrict__ bary, const float* __restrict__ pts, int64_t N,
+                                                                 float* __restrict__ can) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float inv[16];
+    blend_inverse(T, tri, bary, i, inv);
+    const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) can[i * 3 + k] = inv[k * 4] * x + inv[k * 4 + 1] * y + inv[k * 4 + 2] * z + inv[k * 4 + 3];
+}
+
+__global__ __launch_bounds__(256) void warp_apply_backward_kernel(const float* __restrict__ T, const int32_t* __restrict__ tri,
+                                                                  const float* __restrict__ bary, const float* __restrict__ pts,
+                                                                  const float* __restrict__ g_can, int64_t N, float* __restrict__ g_T,
+                                                                  float* __restrict__ g_bary) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float inv[16];
+    blend_inverse(T, tri, bary, i, inv);
+    const float h[4] = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], 1.f};
+    const float g[3] = {g_can[i * 3], g_can[i * 3 + 1], g_can[i * 3 + 2]};
+    // can = inv[:3] h: g_inv[k][l] = g[k] h[l] (k < 3);  M = inv^-1: g_M = -inv^T g_inv inv^T
+    //   (inv^T g_inv)[a][l] = (sum_k inv[k][a] g[k]) h[l] = u[a] h[l];  g_M[a][b] = -u[a] (sum_l h[l] inv[b][l]) = -u[a] w[b]
+    float u[4], w[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        u[a] = inv[a] * g[0] + inv[4 + a] * g[1] + inv[8 + a] * g[2];
+        w[a] = inv[a * 4] * h[0] + inv[a * 4 + 1] * h[1] + inv[a * 4 + 2] * h[2] + inv[a * 4 + 3] * h[3];
+    }
+    float gb[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int64_t v = tri[i * 3 + k];
+        const float b = bary[i * 3 + k];
+        const float* Tv = T + v * 16;
+        float* gTv = g_T + v * 16;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float gm = -u[a] * w[c];
+                gb[k] += gm * Tv[a * 4 + c];
+                atomicAdd(gTv + a * 4 + c, b * gm);
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g_bary[i * 3 + k] = gb[k];
+}
+
+}  // namespace
+
 extern "C" {
 
 int nm_mesh_destroy(nm_mesh_t m) {
@@ -856,6 +948,24 @@ int nm_signed_distance(nm_mesh_t m, const float* pts, int64_t N, float* sdist, i
     hipLaunchKernelGGL(signed_distance_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, pts, N, m->d_verts, m->d_faces, m->d_pn, face, closest,
                        sdist);
     return nm::check_launch("signed_distance_kernel");
+}
+
+int nm_warp_apply_forward(const float* T, const int32_t* tri, const float* bary, const float* pts, int64_t N, float* can, nm_stream_t stream) {
+    NM_REQUIRE(N == 0 || (T && tri && bary && pts && can), "nm_warp_apply_forward: null pointer");
+    if (N == 0) return NM_OK;
+    hipLaunchKernelGGL(warp_apply_forward_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, nm::as_stream(stream), T, tri, bary, pts, N, can);
+    return nm::check_launch("warp_apply_forward_kernel");
+}
+
+int nm_warp_apply_backward(const float* T, const int32_t* tri, const float* bary, const float* pts, const float* g_can, int64_t N, int64_t V,
+                           float* g_T, float* g_bary, nm_stream_t stream) {
+    NM_REQUIRE(T && g_T && V >= 1, "nm_warp_apply_backward: null pointer");
+    hipStream_t st = nm::as_stream(stream);
+    if (int rc = nm::check_hip(hipMemsetAsync(g_T, 0, (size_t)V * 64, st), "nm_warp_apply_backward: clear g_T")) return rc;
+    if (N == 0) return NM_OK;
+    NM_REQUIRE(tri && bary && pts && g_can && g_bary, "nm_warp_apply_backward: null pointer");
+    hipLaunchKernelGGL(warp_apply_backward_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, T, tri, bary, pts, g_can, N, g_T, g_bary);
+    return nm::check_launch("warp_apply_backward_kernel");
 }
 
 }  // extern "C"

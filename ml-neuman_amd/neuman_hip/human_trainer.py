@@ -89,8 +89,10 @@ class HumanNeRFLoss:
         offset = offset_net(torch.cat([human_pts, cur_time], dim=-1))
         mesh, raw_Ts = self.net.vertex_forward(int(batch['cap_id']))                      # autograd: pose / shape / alignment refinement
         flat = human_pts.reshape(-1, 3)
-        Ts, _, _ = ray_utils.warp_samples_to_canonical_diff(flat.detach(), verts=mesh[0], faces=self.faces, T=raw_Ts[0])
-        can_pts = (Ts @ ray_utils.to_homogeneous(flat)[..., None])[:, :3, 0].reshape(b, n, 3)
+        # :262-266: T_interp_inv [p; 1] with T_interp the barycentric blend of the closest triangle's vertex transforms -- one fused
+        # differentiable call (blend, inverse and product; ray_utils.warp_samples_to_canonical_diff is the reference-shaped form)
+        can_flat, _, _ = ray_utils.warp_points_to_canonical_diff(flat.detach(), mesh[0], self.faces, raw_Ts[0])
+        can_pts = can_flat.reshape(b, n, 3)
         can_pts = can_pts + offset
         step = can_pts[:, 1:] - can_pts[:, :-1]                                          # view direction of a warped sample: towards the next one
         can_dirs = _unit(torch.cat([step, step[:, -1:]], dim=1))

@@ -365,6 +365,66 @@ def signed_distance(pts, verts, faces):
     return s.cpu().numpy(), f.cpu().numpy(), c.cpu().numpy()
 
 
+class _WarpApplyFn(torch.autograd.Function):
+    """can = inv(sum_k bary_k T[tri_k]) [p; 1] per sample (csrc/warp.hip nm_warp_apply_forward / _backward): one kernel each way for the
+    blend, the 4x4 inverse and the product that the reference leaves to autograd (ray_utils.py:85-93, human_nerf_trainer.py:262-266)."""
+
+    @staticmethod
+    def forward(ctx, T, bary, tri, pts):
+        Tc, bc = T.detach().reshape(-1, 16).contiguous().float(), bary.detach().contiguous().float()
+        N = pts.shape[0]
+        can = torch.empty((N, 3), device=pts.device, dtype=torch.float32)
+        _lib.check(_lib.lib().nm_warp_apply_forward(_lib.dev_ptr(Tc), _lib.dev_ptr(tri, torch.int32), _lib.dev_ptr(bc), _lib.dev_ptr(pts), N,
+                                                    _lib.dev_ptr(can), _lib.stream_ptr()), "nm_warp_apply_forward")
+        ctx.save_for_backward(Tc, bc, tri, pts)
+        ctx.T_shape = T.shape
+        return can
+
+    @staticmethod
+    def backward(ctx, g_can):
+        Tc, bc, tri, pts = ctx.saved_tensors
+        N, V = pts.shape[0], Tc.shape[0]
+        g_T = torch.empty_like(Tc)
+        g_b = torch.empty_like(bc)
+        _lib.check(_lib.lib().nm_warp_apply_backward(_lib.dev_ptr(Tc), _lib.dev_ptr(tri, torch.int32), _lib.dev_ptr(bc), _lib.dev_ptr(pts),
+                                                     _lib.dev_ptr(g_can.contiguous().float()), N, V, _lib.dev_ptr(g_T), _lib.dev_ptr(g_b),
+                                                     _lib.stream_ptr()), "nm_warp_apply_backward")
+        return g_T.reshape(ctx.T_shape), g_b, None, None
+
+
+def _closest_barycentric(p, verts, f3, mesh=None):
+    """the closest-point query (libneuman_hip) and the reference's differentiable barycentric lines (ray_utils.py:70-84) ->
+    (barycentric [N,3] with autograd to `verts`, face ids [N] long, signed distance [N])"""
+    mesh = mesh or Mesh(verts.detach(), f3.to(torch.int32), torch.zeros((verts.shape[0], 16), dtype=torch.float64), verts.device)
+    signed_dist, f_id, closest = signed_distance_dev(p, mesh)
+    f_id = f_id.long()
+    closest_tri = verts[f3[f_id]]
+    v0v1 = closest_tri[:, 1] - closest_tri[:, 0]
+    v0v2 = closest_tri[:, 2] - closest_tri[:, 0]
+    v1v2 = closest_tri[:, 2] - closest_tri[:, 1]
+    v2v0 = closest_tri[:, 0] - closest_tri[:, 2]
+    v1p = closest - closest_tri[:, 1]
+    v2p = closest - closest_tri[:, 2]
+    N = torch.cross(v0v1, v0v2, dim=1)
+    denom = (N * N).sum(1)
+    u = (N * torch.cross(v1v2, v1p, dim=1)).sum(1) / denom
+    v = (N * torch.cross(v2v0, v2p, dim=1)).sum(1) / denom
+    w = 1 - u - v
+    return torch.stack([u, v, w], dim=1), f_id, signed_dist
+
+
+def warp_points_to_canonical_diff(pts, verts, faces, T):
+    """What the human trainer makes of warp_samples_to_canonical_diff (human_nerf_trainer.py:262-266: the inverse blended transforms
+    applied to the very points they were found for), fused: pts [N,3] (detached), verts [V,3] / T [V,4,4] CUDA tensors that may
+    require grad -> (canonical points [N,3] with autograd to T and, through the barycentric coordinates, to verts; f_id; signed_dist)."""
+    dev = verts.device
+    f3 = torch.as_tensor(np.ascontiguousarray(np.asarray(faces)[:, :3]).astype(np.int64)).to(dev)
+    p = pts.detach().to(dev, torch.float32).contiguous()
+    bary, f_id, signed_dist = _closest_barycentric(p, verts, f3)
+    tri = f3[f_id].to(torch.int32).contiguous()
+    return _WarpApplyFn.apply(T.to(dev), bary, tri, p), f_id, signed_dist
+
+
 def warp_samples_to_canonical_diff(pts, verts, faces, T):
     """reference ray_utils.py:69-93: pts [N,3] numpy (detached), verts [V,3] / T [V,4,4] torch tensors that may require grad
     -> (T_interp_inv [N,4,4], f_id, signed_dist).  The closest-point query and its sign run in libneuman_hip; the barycentric

@@ -58,3 +58,38 @@ def test_run_to_run_bit_identical_and_no_leftover_state(body):
         b.vertex_forward(leaf(pose[0][None]), leaf(betas[0][None]), leaf(al), 2.0)               # another frame in between
     for x, y in zip(*outs):
         assert torch.equal(x, y)
+
+
+def test_fused_warp_apply_equals_the_reference_shaped_lines(body):
+    """ray_utils.warp_points_to_canonical_diff (one kernel each way for blend + inverse + product) against
+    warp_samples_to_canonical_diff followed by the batched product, both under autograd: canonical points and the gradients to the
+    vertex transforms and the posed vertices"""
+    from neuman_hip import ray_utils
+    b, syn = body
+    pose, betas, align = syn.smpl_like_frames(1, 0)
+    al = np.concatenate([align['00000.png'], np.array([[0.], [0.], [0.], [1.]])], 1).astype(np.float32)
+    faces = syn.smpl_like_model(0)['f'].astype(np.int32)
+    g = torch.Generator(device='cuda').manual_seed(9)
+    res = {}
+    for name in ("fused", "lines"):
+        p, be, a = leaf(pose[0][None] * 0.5), leaf(betas[0][None] * 0.5), leaf(al)
+        world, T = b.vertex_forward_torch(p, be, a, 1.0)
+        verts, T = world[0], T[0]
+        if name == "fused":
+            g.manual_seed(9)
+        else:
+            g.manual_seed(9)
+        pts = (verts.detach()[torch.randint(0, verts.shape[0], (20000,), device='cuda', generator=g)]
+               + 0.03 * torch.randn((20000, 3), device='cuda', generator=g)).contiguous()
+        gc = torch.randn((20000, 3), device='cuda', generator=g)
+        if name == "fused":
+            can, _, _ = ray_utils.warp_points_to_canonical_diff(pts, verts, faces, T)
+        else:
+            Ts, _, _ = ray_utils.warp_samples_to_canonical_diff(pts, verts, faces, T)
+            can = (Ts @ ray_utils.to_homogeneous(pts)[..., None])[:, :3, 0]
+        (can * gc).sum().backward()
+        res[name] = [x.detach().double().cpu().numpy() for x in (can, p.grad, be.grad, a.grad)]
+    for what, x, y in zip(("can_pts", "g_pose", "g_beta", "g_align"), res["fused"], res["lines"]):
+        e = np.abs(x - y).max() / (np.abs(y).max() + 1e-30)
+        print(f"[warp-apply] {what}: max |fused - lines| / max |lines| = {e:.2e}")
+        assert e < (2e-5 if what == "can_pts" else 5e-4), (what, e)
