@@ -364,7 +364,7 @@ def safe_load_weights(model, saved_weights):
 def load_background_checkpoint(path, coarse_net, fine_net):
     """models/human_nerf.py:53-61, render_vanilla callers: a NeRFTrainer checkpoint holds 'coarse_model_state_dict' / 'fine_model_state_dict'"""
     import torch
-    ckpt = torch.load(path, map_location='cpu')
+    ckpt = torch.load(path, map_location='cpu', weights_only=False)
     safe_load_weights(coarse_net, ckpt['coarse_model_state_dict'])
     safe_load_weights(fine_net, ckpt['fine_model_state_dict'])
     return ckpt
@@ -373,7 +373,7 @@ def load_background_checkpoint(path, coarse_net, fine_net):
 def load_hybrid_checkpoint(path, net):
     """train.py:97-103 / render_*.py: a HumanNeRFTrainer checkpoint holds 'hybrid_model_state_dict' for the whole HumanNeRF module"""
     import torch
-    ckpt = torch.load(path, map_location='cpu')
+    ckpt = torch.load(path, map_location='cpu', weights_only=False)
     safe_load_weights(net, ckpt['hybrid_model_state_dict'])
     return ckpt
 
@@ -381,7 +381,7 @@ def load_hybrid_checkpoint(path, net):
 def load_canonical_human(path, human_net):
     """models/human_nerf.py:63-74: only the `coarse_human_net.` tensors of a hybrid checkpoint"""
     import torch
-    sd = torch.load(path, map_location='cpu')['hybrid_model_state_dict']
+    sd = torch.load(path, map_location='cpu', weights_only=False)['hybrid_model_state_dict']
     safe_load_weights(human_net, {k.split('coarse_human_net.', 1)[1]: v for k, v in sd.items() if 'coarse_human_net.' in k})
 
 

@@ -110,11 +110,11 @@ class Joiner(nn.Module):
     def _key(self):
         return tuple((p.data_ptr(), p._version) for p in self.nerf.ordered_params())
 
-    def _release(self):
+    def _release(self, train_too=True):
         if self._handle is not None:
             _lib.lib().nm_mlp_destroy(self._handle)
             self._handle = None
-        if getattr(self, '_train_handle', None) is not None:
+        if train_too and getattr(self, '_train_handle', None) is not None:
             _lib.lib().nm_mlp_destroy(self._train_handle)
             self._train_handle = None
 
@@ -144,7 +144,7 @@ class Joiner(nn.Module):
     def handle(self):
         key = self._key()
         if self._handle is None or key != self._handle_key:
-            self._release()
+            self._release(train_too=False)                       # (the training handle refreshes its own image on the device: train_handle)
             n = self.nerf
             if n.scale_type != 'no':
                 raise NotImplementedError("scale_type != 'no' (offset nets) is outside the HIP path")
