@@ -51,7 +51,9 @@ class HumanNeRFLoss:
     penalize_outside_factor, dist_exponent).  `net` is a HumanNeRF-like holder: coarse_bkg_net, fine_bkg_net, coarse_human_net
     (Joiners), offset_nets (list), and vertex_forward(cap_id) -> (world_verts [1,V,3], T [1,V,4,4]) with autograd (SMPLDiff).
     `faces` [F,3] are the body's triangles, `can_mesh` = (verts [V,3], faces) the canonical (da-pose) body for the shape
-    regulariser, `can_caps` the canonical cameras of the sparsity regulariser (:157-172)."""
+    regulariser -- or, as the reference keeps one per frame (captures[cap_id].can_mesh, built from that frame's betas:
+    human_nerf_trainer.py:308), a dict / list / callable cap_id -> (verts, faces) -- `can_caps` the canonical cameras of the sparsity
+    regulariser (:157-172)."""
 
     def __init__(self, opt, net, faces, can_mesh, can_caps, interval_comp=1.0, lpips_loss_fn=None, seed=0):
         self.opt, self.net, self.faces, self.can_mesh, self.can_caps = opt, net, np.ascontiguousarray(np.asarray(faces)[:, :3], np.int32), can_mesh, can_caps
@@ -66,7 +68,7 @@ class HumanNeRFLoss:
         # -- so that a recording of the reference's own run (tests/golden/make_golden_human_loss.py) can be replayed term by term
         self.replay = None
         self.last = {}                                                                   # intermediates of the last call (tests, logging)
-        self._can_tree = None
+        self._can_tree = {}                                                              # cap_id (None: the one shared mesh) -> search tree
 
     # ---- :180-239: frozen background, rendering kernels, nothing kept for autograd
     def _eval_bkg_samples(self, batch, device):
@@ -113,15 +115,19 @@ class HumanNeRFLoss:
         squash = lambda raw: torch.tanh(torch.relu(raw[..., 3]))                        # noqa: E731
         return self.penalize_symmetric_alpha * F.mse_loss(squash(tgts), squash(mirrored))
 
-    def _signed_distance(self, pts):
-        """igl.signed_distance of the reference (:310, :326) on the device: negative inside the canonical body (the search tree of
-        the canonical mesh is built once)"""
-        if self._can_tree is None:
-            verts, faces = self.can_mesh
+    def _signed_distance(self, pts, cap_id=None):
+        """igl.signed_distance of the reference (:310, :326) on the device: negative inside the canonical body of frame `cap_id`
+        (:308; one search tree per canonical mesh, built on first use)"""
+        cm = self.can_mesh
+        one_mesh = isinstance(cm, tuple) or (isinstance(cm, list) and len(cm) == 2 and getattr(cm[0], 'ndim', 0) == 2)
+        per_frame = not one_mesh
+        key = int(cap_id) if per_frame and cap_id is not None else None
+        if key not in self._can_tree:
+            verts, faces = (self.can_mesh(key) if callable(self.can_mesh) else self.can_mesh[key]) if per_frame else self.can_mesh
             v = torch.as_tensor(np.ascontiguousarray(verts, dtype=np.float32))
-            self._can_tree = ray_utils.Mesh(v, np.ascontiguousarray(np.asarray(faces)[:, :3], np.int32), torch.zeros((v.shape[0], 16), dtype=torch.float64),
-                                            pts.device)
-        return ray_utils.signed_distance_dev(pts.reshape(-1, 3).detach(), self._can_tree)[0]
+            self._can_tree[key] = ray_utils.Mesh(v, np.ascontiguousarray(np.asarray(faces)[:, :3], np.int32),
+                                                 torch.zeros((v.shape[0], 16), dtype=torch.float64), pts.device)
+        return ray_utils.signed_distance_dev(pts.reshape(-1, 3).detach(), self._can_tree[key])[0]
 
     # ---- :305-343
     def _smpl_shape_regularization(self, batch, pts, dirs, pred):
@@ -131,12 +137,12 @@ class HumanNeRFLoss:
         def filled(raw, mask, weight):                                                   # occupancy 1 where the body is
             return weight * ((1 - _occupancy(raw)[mask]) ** 2).mean() if bool(mask.any()) else 0.0
 
-        dist_human = self._signed_distance(pts)
+        dist_human = self._signed_distance(pts, batch.get('cap_id'))
         smpl_reg = smpl_reg + filled(pred, dist_human < 0, self.penalize_smpl_alpha)
         if self.penalize_dummy > 0:                                                      # random points of a 3-unit box around the canonical body
             dummy_pts = ((torch.as_tensor(self.replay['dummy_pts_rand']).to(pts) if self.replay else torch.rand_like(pts)) - 0.5) * 3
             dummy_out = self.net.coarse_human_net(dummy_pts, dirs)
-            dist_dummy = self._signed_distance(dummy_pts)
+            dist_dummy = self._signed_distance(dummy_pts, batch.get('cap_id'))
             smpl_reg = smpl_reg + filled(dummy_out, dist_dummy < 0, self.penalize_dummy)
             outside = dist_dummy > 0
             if bool(outside.any()):                                                      # occupancy 0 outside, weighted by the distance from the surface

@@ -176,3 +176,22 @@ def test_trainer_loop_schedules_and_checkpoint(setup, tmp_path):
     ckpt = torch.load(tmp_path / 'human' / 'checkpoint.pth.tar', map_location='cpu', weights_only=False)
     assert set(ckpt) == {'epoch', 'iteration', 'optim_state_dict', 'hybrid_model_state_dict'} and ckpt['iteration'] == 5
     assert any(k.startswith('coarse_human_net.') for k in ckpt['hybrid_model_state_dict']) and 'poses' in ckpt['hybrid_model_state_dict']
+
+
+def test_shape_regulariser_uses_the_frames_own_canonical_mesh():
+    """human_nerf_trainer.py:308 takes captures[batch['cap_id']].can_mesh: with one canonical body per frame (dict / list / callable)
+    the inside / outside test must change with cap_id; with one (verts, faces) tuple it must not"""
+    import types
+    from neuman_hip import human_trainer, synthetic
+    verts, faces = synthetic.capsule_mesh(12, 16)
+    pts = torch.tensor(np.random.default_rng(0).uniform(-0.6, 0.6, (4000, 3)).astype(np.float32), device='cuda')
+    opt = types.SimpleNamespace(penalize_smpl_alpha=1.0, penalize_symmetric_alpha=0.0, penalize_dummy=0.0, penalize_hard_surface=0.0, penalize_color_range=0.0,
+                                penalize_mask=0.0, penalize_lpips=0.0, penalize_sharp_edge=0.0)
+    fat = (verts * np.array([1.6, 1.0, 1.6], np.float32), faces)
+    for per_frame in ({0: (verts, faces), 1: fat}, [(verts, faces), fat], lambda i: (verts, faces) if i == 0 else fat):
+        L = human_trainer.HumanNeRFLoss(opt, None, faces, per_frame, [])
+        d0, d1 = L._signed_distance(pts, 0), L._signed_distance(pts, 1)
+        assert int((d1 < 0).sum()) > int((d0 < 0).sum()) > 0 and len(L._can_tree) == 2
+        assert torch.equal(d0, L._signed_distance(pts, 0))
+    L = human_trainer.HumanNeRFLoss(opt, None, faces, (verts, faces), [])
+    assert torch.equal(L._signed_distance(pts, 0), L._signed_distance(pts, 1)) and len(L._can_tree) == 1
