@@ -376,14 +376,28 @@ static void pack_image8(const nm_mlp_desc* d, const float* const* P, uint8_t* im
     }
 }
 
-// workgroup stream image of the activation-stationary kernel (mlp_i8s.hip): the block image in the order that kernel consumes it --
-// as it is, except that the alpha block of stage 8 comes BEFORE the eight feature blocks (all of the stage's outputs are held in registers
-// until the row maximum is known; the alpha block must not be the one that is multiplied while they are all live)
+// workgroup stream image of the activation-stationary kernel (mlp_i8s.hip): the k-steps of the block image in the order that kernel
+// consumes them.  As the block image, except: stage 5's four encoding steps per block come AFTER its eight i8 blocks, as four units of
+// two blocks (so that every hidden stage is eight identical i8 blocks -- they are added on top of the dequantised sums, as everywhere);
+// the alpha block of stage 8 comes BEFORE the eight feature blocks (all of the stage's outputs are held in registers until the row
+// maximum is known; the alpha block must not be the one that is multiplied while they are all live).  Same size as the block image.
 static void pack_stream8s(const uint8_t* img8, uint8_t* out) {
-    memcpy(out, img8, (size_t)(kWeightBytes8 + kWeightPadBytes));
-    const int64_t blk = 8 * (int64_t)kStepBytes;
-    memcpy(out + frag_off8(8, 0, 0), img8 + frag_off8(8, 8, 0), (size_t)blk);
-    memcpy(out + frag_off8(8, 0, 0) + blk, img8 + frag_off8(8, 0, 0), (size_t)(8 * blk));
+    memset(out, 0, (size_t)(kWeightBytes8 + kWeightPadBytes));
+    uint8_t* dst = out;
+    auto put = [&](int st, int nb, int t0, int n) {
+        for (int t = 0; t < n; ++t, dst += kStepBytes) memcpy(dst, img8 + frag_off8(st, nb, t0 + t), (size_t)kStepBytes);
+    };
+    for (int nb = 0; nb < 8; ++nb) put(0, nb, 0, 4);
+    for (int st = 1; st <= 7; ++st) {
+        for (int nb = 0; nb < 8; ++nb) put(st, nb, 0, 8);
+        if (st == 5)
+            for (int nb = 0; nb < 8; ++nb) put(5, nb, 8, 4);
+    }
+    put(8, 8, 0, 8);
+    for (int nb = 0; nb < 8; ++nb) put(8, nb, 0, 8);
+    for (int nb = 0; nb < 4; ++nb) put(9, nb, 0, 10);
+    put(10, 0, 0, 4);
+    if (dst - out != kWeightBytes8) abort();
 }
 
 // per-wave stream image (mlp_layout.h wstream_*): the steps of the NM_PREC_I8X3 image in each wave's consumption order

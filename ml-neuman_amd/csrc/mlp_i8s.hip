@@ -41,11 +41,12 @@ constexpr int kSlotU4 = 12 * kStepU4;
 constexpr int kSlots = 3;                                    // the block being multiplied + two being copied
 constexpr int kBiasU4 = (nm::kBiasFloats + 16 + 3) / 4;      // the bias table and kappa, resident in LDS (a global load per block would sit in the same
                                                              // in-order VMEM queue as the copies and force them to land early)
-// flat block index of a tile: stage 0: 0-7 | 1-4: 8-39 | 5: 40-47 | 6, 7: 48-63 | 8: 64-72 | 9: 73-76 | 10: 77
-constexpr int kTileBlocks = 78;
+// flat RING block index of a tile (what one barrier hands over): stage 0: 0-7 (4 steps) | 1-4: 8-39 | 5: 40-47 and its encoding part
+// 48-51 (two output blocks x 4 steps each) | 6, 7: 52-67 | 8: 68-76 | 9: 77-80 (10 steps) | 10: 81 (4 steps)
+constexpr int kTileBlocks = 82;
 __host__ __device__ constexpr int block_steps(int i) {
     i = i >= kTileBlocks ? i - kTileBlocks : i;
-    return i < 8 ? 4 : (i >= 40 && i < 48) ? 12 : i < 73 ? 8 : i < 77 ? 10 : 4;
+    return i < 8 ? 4 : i < 77 ? 8 : i < 81 ? 10 : 4;
 }
 __host__ __device__ constexpr int block_pieces(int nsteps) { return (2 * nsteps + kWaves - 1) / kWaves; }   // 1 KB pieces per wave
 
@@ -179,33 +180,62 @@ struct W8 {
     uint4 h, l;
 };
 
-// NSTEPS limb k-steps of one output block: t = hh * 256 + cross (exact), weights prefetched two steps ahead
+// NSTEPS limb k-steps of one output block: t = 256 * sum(hi.hi) + sum(hi.lo + lo.hi), exact, in ONE int32 accumulator: the hi.hi pass first,
+// shifted in place, then the cross terms on top of it (|t| < 2^31 either way).  The hi weight fragments are read from LDS twice (LDS has
+// the bandwidth; registers are what this kernel has none of): 16 registers less than two accumulators.  One accumulator is one
+// dependency chain -- an MFMA every ~64 cycles from this wave, which is what the SIMD's matrix pipe can take from each of its two waves --
+// and the issue slots between its links are where a pending block's dequantisation fits (PEND).
+// PEND: fp = the previous block's outputs (written here, two per MFMA of the first pass), tp = its accumulators, bias_blk = its biases
+// (this lane's half of every group of 8), m = the running row maximum
+template <int NSTEPS, bool PEND>
+__device__ __forceinline__ void k_i8_impl(i32x16& t, const X8& X, const uint4* ws, Ring& R, f32x16& fp, const i32x16& tp, lds_cfloat* bias_blk,
+                                          float sx256, float& m) {
+    i32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0;
+    uint4 w[2];
+    w[0] = ws[0];
+    w[1] = ws[kStepU4];
+#pragma unroll
+    for (int s = 0; s < NSTEPS; ++s) {                                                    // hi.hi
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(w[s & 1]), as_i32x4(X.h[s]), acc, 0, 0, 0);
+        if (s + 2 < NSTEPS) w[s & 1] = ws[(s + 2) * kStepU4];
+        if (s == 0 || s == 2 || s == 4) ring_copy(R, s >> 1);
+        if (PEND) {
+            const int r = 2 * s;                                                           // values 0 .. 2 NSTEPS - 1 of the pending block
+            const float b0 = bias_blk[8 * (r >> 2) + (r & 3)], b1 = bias_blk[8 * (r >> 2) + (r & 3) + 1];
+            const float f0 = fmaf((float)tp[r], sx256, b0), f1 = fmaf((float)tp[r + 1], sx256, b1);
+            fp[r] = f0;
+            fp[r + 1] = f1;
+            m = fmaxf(m, fmaxf(f0, f1));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    W8 v[2];
+    v[0].h = ws[0]; v[0].l = ws[64];
+    v[1].h = ws[kStepU4]; v[1].l = ws[kStepU4 + 64];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] <<= 8;
+#pragma unroll
+    for (int s = 0; s < NSTEPS; ++s) {                                                    // hi.lo + lo.hi
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(v[s & 1].h), as_i32x4(X.l[s]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(v[s & 1].l), as_i32x4(X.h[s]), acc, 0, 0, 0);
+        if (s + 2 < NSTEPS) { v[s & 1].h = ws[(s + 2) * kStepU4]; v[s & 1].l = ws[(s + 2) * kStepU4 + 64]; }
+    }
+    t = acc;
+}
 template <int NSTEPS>
 __device__ __forceinline__ void k_i8(i32x16& t, const X8& X, const uint4* ws, Ring& R) {
-    i32x16 ah, ac;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { ah[r] = 0; ac[r] = 0; }
-    W8 w[2];
-    w[0].h = ws[0]; w[0].l = ws[64];
-    w[1].h = ws[kStepU4]; w[1].l = ws[kStepU4 + 64];
-#pragma unroll
-    for (int s = 0; s < NSTEPS; ++s) {
-        const uint4 wh = w[s & 1].h, wl = w[s & 1].l;
-        ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(wh), as_i32x4(X.l[s]), ac, 0, 0, 0);
-        ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(wl), as_i32x4(X.h[s]), ac, 0, 0, 0);
-        ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(wh), as_i32x4(X.h[s]), ah, 0, 0, 0);
-        if (s + 2 < NSTEPS) { w[s & 1].h = ws[(s + 2) * kStepU4]; w[s & 1].l = ws[(s + 2) * kStepU4 + 64]; }
-        if (s == 0 || s == 2 || s == 4) ring_copy(R, s >> 1);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) t[r] = (ah[r] << 8) + ac[r];
+    f32x16 nf;
+    float nm_ = 0.f;
+    k_i8_impl<NSTEPS, false>(t, X, ws, R, nf, t, nullptr, 0.f, nm_);
 }
 // NSTEPS split-bf16 k-steps over the wave's encoding rows (chunks c0 ..), accumulated into f
 template <int NSTEPS, bool COPY = false>
-__device__ __forceinline__ void k_bf(f32x16& f, const uint4* pw, int g, int s, const uint4* ws, Ring* R = nullptr) {
+__device__ __forceinline__ void k_bf(f32x16& f, const uint4* pw, int g, int s, const uint4* ws, Ring* R = nullptr, int j0 = 0) {
 #pragma unroll
     for (int t = 0; t < NSTEPS; ++t) {
-        if (COPY && (t == 1 || t == 3)) ring_copy(*R, t >> 1);
+        if (COPY && (t == 1 || t == 3)) ring_copy(*R, j0 + (t >> 1));
         const uint4 wh = ws[t * kStepU4], wl = ws[t * kStepU4 + 64];
         const uint4 xh = pw[(2 * t + g) * (2 * kRows) + s], xl = pw[(2 * t + g) * (2 * kRows) + kRows + s];
         f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wh), as_bf16x8(xl), f, 0, 0, 0);
@@ -327,23 +357,40 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
             sx = scale_of(M);
             PROF_TICK(5)
         }
-        // ---------------- stages 1..7: 256 -> 256, ReLU; stage 5 adds the position encoding
+        // ---------------- stages 1..7: 256 -> 256, ReLU; stage 5 adds the position encoding (four more ring blocks of two output blocks each)
 #pragma unroll 1
         for (int st = 1; st <= 7; ++st) {
             const float sxin = sx * (256.f * kappa[st]);
-            const int bsteps = st == 5 ? 12 : 8;
+            const int i0 = 8 * st + (st > 5 ? 4 : 0);
             f32x16 f[8];
             float m = 0.f;
+            i32x16 tp;                                                                  // block b - 1, dequantised under block b's MFMAs
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
-                i32x16 t;
-                const uint4* ws = ring_enter(R, 8 * st + b PROF_PASS);
-                k_i8<8>(t, X, ws, R);
+                const uint4* ws = ring_enter(R, i0 + b PROF_PASS);
+                if (b == 0) {
+                    k_i8<8>(tp, X, ws, R);
+                } else {
+                    i32x16 t;
+                    k_i8_impl<8, true>(t, X, ws, R, f[b - 1], tp, bias + 256 * st + 32 * (b - 1), sxin, m);
+                    tp = t;
+                }
                 PROF_TICK(2)
-                dequant16(f[b], t, sxin, bias + 256 * st + 32 * b);
-                if (st == 5) k_bf<4>(f[b], pw, g, s, ws + 8 * kStepU4);
-                m = max16<true>(m, f[b]);
             }
+            dequant16(f[7], tp, sxin, bias + 256 * st + 32 * 7);
+            if (st == 5) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint4* ws = ring_enter(R, 48 + u PROF_PASS);
+                    k_bf<4, true>(f[2 * u], pw, g, s, ws, &R, 0);
+                    k_bf<4, true>(f[2 * u + 1], pw, g, s, ws + 4 * kStepU4, &R, 2);
+                    PROF_TICK(2)
+                }
+                m = 0.f;                                                                // (the running maximum was taken before the encodings)
+#pragma unroll
+                for (int b = 0; b < 7; ++b) m = max16<true>(m, f[b]);
+            }
+            m = max16<true>(m, f[7]);
             PROF_TICK(4)
             const float M = row_max(m), inv = inv_of(M);
 #pragma unroll
@@ -352,9 +399,9 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
             PROF_TICK(5)
             if (st == 5) {
                 PROF_TICK(7)
-                fill_pe_wave(pw, true, a, row0, lane);
+                fill_pe_wave(pw, true, a, row0, lane);                                  // the position encoding is done with: direction encoding
                 PROF_TICK(6)
-            }                          // the position encoding is done with: direction encoding
+            }
         }
         // ---------------- stage 8: alpha (row 0 of its block; first in the stream) + feature (linear, 256)
         float sigma;
@@ -363,7 +410,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
             {
                 i32x16 t;
                 f32x16 fa;
-                k_i8<8>(t, X, ring_enter(R, 64 PROF_PASS), R);
+                k_i8<8>(t, X, ring_enter(R, 68 PROF_PASS), R);
                 PROF_TICK(2)
                 dequant16(fa, t, sxin, bias + nm::stage_b_off(8) + 256);
                 sigma = fa[0] * u_sigma;
@@ -373,7 +420,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 i32x16 t;
-                k_i8<8>(t, X, ring_enter(R, 65 + b PROF_PASS), R);
+                k_i8<8>(t, X, ring_enter(R, 69 + b PROF_PASS), R);
                 PROF_TICK(2)
                 dequant16(f[b], t, sxin, bias + nm::stage_b_off(8) + 32 * b);
                 m = max16<false>(m, f[b]);
@@ -393,7 +440,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 i32x16 t;
-                const uint4* ws = ring_enter(R, 73 + b PROF_PASS);
+                const uint4* ws = ring_enter(R, 77 + b PROF_PASS);
                 k_i8<8>(t, X, ws, R);
                 PROF_TICK(2)
                 dequant16(f[b], t, sxin, bias + nm::stage_b_off(9) + 32 * b);
@@ -411,7 +458,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
         {
             i32x16 t;
             f32x16 fr;
-            k_i8<4>(t, X, ring_enter(R, 77 PROF_PASS), R);
+            k_i8<4>(t, X, ring_enter(R, 81 PROF_PASS), R);
             PROF_TICK(2)
             dequant16(fr, t, sx * (256.f * kappa[10]), bias + nm::stage_b_off(10));
             const int64_t i = row0 + s;
