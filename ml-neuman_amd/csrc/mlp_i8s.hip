@@ -180,49 +180,40 @@ struct W8 {
     uint4 h, l;
 };
 
-// NSTEPS limb k-steps of one output block: t = 256 * sum(hi.hi) + sum(hi.lo + lo.hi), exact, in ONE int32 accumulator: the hi.hi pass first,
-// shifted in place, then the cross terms on top of it (|t| < 2^31 either way).  The hi weight fragments are read from LDS twice (LDS has
-// the bandwidth; registers are what this kernel has none of): 16 registers less than two accumulators.  One accumulator is one
-// dependency chain -- an MFMA every ~64 cycles from this wave, which is what the SIMD's matrix pipe can take from each of its two waves --
-// and the issue slots between its links are where a pending block's dequantisation fits (PEND).
+// NSTEPS limb k-steps of one output block: t = 256 * sum(hi.hi) + sum(hi.lo + lo.hi), exact, in two int32 accumulators (two dependency
+// chains; every weight fragment read from LDS once).  Between the k-steps rides the dequantisation of the PREVIOUS block (PEND), two
+// values per step: in lock-step with its SIMD partner a wave would otherwise do it while nobody uses the matrix pipe.
 // PEND: fp = the previous block's outputs (written here, two per MFMA of the first pass), tp = its accumulators, bias_blk = its biases
 // (this lane's half of every group of 8), m = the running row maximum
-template <int NSTEPS, bool PEND>
+template <int NSTEPS, bool PEND, bool RELU = true>
 __device__ __forceinline__ void k_i8_impl(i32x16& t, const X8& X, const uint4* ws, Ring& R, f32x16& fp, const i32x16& tp, lds_cfloat* bias_blk,
                                           float sx256, float& m) {
-    i32x16 acc;
+    i32x16 ah, ac;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0;
-    uint4 w[2];
-    w[0] = ws[0];
-    w[1] = ws[kStepU4];
+    for (int r = 0; r < 16; ++r) { ah[r] = 0; ac[r] = 0; }
+    W8 w[2];
+    w[0].h = ws[0]; w[0].l = ws[64];
+    w[1].h = ws[kStepU4]; w[1].l = ws[kStepU4 + 64];
 #pragma unroll
-    for (int s = 0; s < NSTEPS; ++s) {                                                    // hi.hi
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(w[s & 1]), as_i32x4(X.h[s]), acc, 0, 0, 0);
-        if (s + 2 < NSTEPS) w[s & 1] = ws[(s + 2) * kStepU4];
+    for (int s = 0; s < NSTEPS; ++s) {
+        const uint4 wh = w[s & 1].h, wl = w[s & 1].l;
+        ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(wh), as_i32x4(X.l[s]), ac, 0, 0, 0);
+        ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(wl), as_i32x4(X.h[s]), ac, 0, 0, 0);
+        ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(wh), as_i32x4(X.h[s]), ah, 0, 0, 0);
+        if (s + 2 < NSTEPS) { w[s & 1].h = ws[(s + 2) * kStepU4]; w[s & 1].l = ws[(s + 2) * kStepU4 + 64]; }
         if (s == 0 || s == 2 || s == 4) ring_copy(R, s >> 1);
         if (PEND) {
-            const int r = 2 * s;                                                           // values 0 .. 2 NSTEPS - 1 of the pending block
+            const int r = 2 * s;
             const float b0 = bias_blk[8 * (r >> 2) + (r & 3)], b1 = bias_blk[8 * (r >> 2) + (r & 3) + 1];
             const float f0 = fmaf((float)tp[r], sx256, b0), f1 = fmaf((float)tp[r + 1], sx256, b1);
             fp[r] = f0;
             fp[r + 1] = f1;
-            m = fmaxf(m, fmaxf(f0, f1));
+            m = RELU ? fmaxf(m, fmaxf(f0, f1)) : fmaxf(m, fmaxf(fabsf(f0), fabsf(f1)));
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    W8 v[2];
-    v[0].h = ws[0]; v[0].l = ws[64];
-    v[1].h = ws[kStepU4]; v[1].l = ws[kStepU4 + 64];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] <<= 8;
-#pragma unroll
-    for (int s = 0; s < NSTEPS; ++s) {                                                    // hi.lo + lo.hi
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(v[s & 1].h), as_i32x4(X.l[s]), acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(v[s & 1].l), as_i32x4(X.h[s]), acc, 0, 0, 0);
-        if (s + 2 < NSTEPS) { v[s & 1].h = ws[(s + 2) * kStepU4]; v[s & 1].l = ws[(s + 2) * kStepU4 + 64]; }
-    }
-    t = acc;
+    for (int r = 0; r < 16; ++r) t[r] = (ah[r] << 8) + ac[r];
 }
 template <int NSTEPS>
 __device__ __forceinline__ void k_i8(i32x16& t, const X8& X, const uint4* ws, Ring& R) {
@@ -418,7 +409,7 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
             f32x16 f[8];
             float m = 0.f;
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
+            for (int b = 0; b < 8; ++b) {                                               // (the riding dequantisation measured no gain here)
                 i32x16 t;
                 k_i8<8>(t, X, ring_enter(R, 69 + b PROF_PASS), R);
                 PROF_TICK(2)
