@@ -198,8 +198,8 @@ __device__ __forceinline__ void k_i8_impl(i32x16& t, const X8& X, const uint4* w
     for (int s = 0; s < NSTEPS; ++s) {
         const uint4 wh = w[s & 1].h, wl = w[s & 1].l;
         ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(wh), as_i32x4(X.l[s]), ac, 0, 0, 0);
-        ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(wl), as_i32x4(X.h[s]), ac, 0, 0, 0);
-        ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(wh), as_i32x4(X.h[s]), ah, 0, 0, 0);
+        ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(wh), as_i32x4(X.h[s]), ah, 0, 0, 0);      // (between the two links of the cross-term
+        ac = __builtin_amdgcn_mfma_i32_32x32x32_i8(as_i32x4(wl), as_i32x4(X.h[s]), ac, 0, 0, 0);      // chain: -2.5 % at steady state)
         if (s + 2 < NSTEPS) { w[s & 1].h = ws[(s + 2) * kStepU4]; w[s & 1].l = ws[(s + 2) * kStepU4 + 64]; }
         if (s == 0 || s == 2 || s == 4) ring_copy(R, s >> 1);
         if (PEND) {
