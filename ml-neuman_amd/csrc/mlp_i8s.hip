@@ -10,10 +10,11 @@
 //     fragment of k-step b, in place -- activations never touch LDS, never cross lanes (one v_permlane32_swap for the row maximum);
 //   * the row maximum is local to the wave: no exchange, no barrier; waves never wait for each other except for the weight ring;
 //   * the weights are the A operands, one 1 KB fragment per limb and k-step, used for one MFMA triple.  All 8 waves of the workgroup want
-//     the same fragments at about the same time, so the block image (mlp_layout.h frag_off8, consumed strictly linearly: 628 k-steps of
-//     2 KB per 256-sample tile) is streamed ONCE per workgroup from L2 into an LDS ring of whole output blocks by LDS-DMA
-//     (global_load_lds_dwordx4: lane-linear, exactly the fragment format), one block ahead of the block being multiplied; the only
-//     workgroup barrier is the one per output block that hands a ring slot over.
+//     the same fragments at about the same time, so the weight image -- re-cut on the host in exactly the order it is consumed
+//     (mlp_host.hip pack_stream8s: 628 k-steps of 2 KB per 256-sample tile) -- is streamed ONCE per workgroup from L2 into an LDS ring
+//     of whole ring blocks by LDS-DMA (global_load_lds_dwordx4: lane-linear, exactly the fragment format), two blocks ahead of the block
+//     being multiplied; the only workgroup barrier is the one per ring block that hands a slot over.
+//   Measurements, the variants tried and why the kernel is the way it is: profiles/r03_as_kernel_experiments.md, DESIGN.md "K4-i8s".
 //
 // Reference semantics: models/vanilla.py Embedder.forward (:82-92), NeRF.forward (:120-152), Joiner.forward (:162-166).
 #include "mlp_device.h"
@@ -35,7 +36,7 @@ constexpr int kTile = kWaves * kRows;
 // LDS: the encodings of each wave's 32 rows, wave-private: [wave][8 chunks][hi: 32 rows | lo: 32 rows][16 B] = 8 KB per wave
 constexpr int kPWaveU4 = nm::kPeChunks * 2 * kRows;          // 512 uint4
 constexpr int kPeU4 = kWaves * kPWaveU4;
-// the weight ring: kSlots slots of one output block (at most 12 k-steps of 2 KB)
+// the weight ring: kSlots slots of one ring block (at most 10 k-steps of 2 KB; sized for 12)
 constexpr int kStepU4 = nm::kStepBytes / 16;
 constexpr int kSlotU4 = 12 * kStepU4;
 constexpr int kSlots = 3;                                    // the block being multiplied + two being copied
@@ -53,7 +54,7 @@ __host__ __device__ constexpr int block_pieces(int nsteps) { return (2 * nsteps 
 struct Args8s {
     MlpArgs a;
     const float* consts8;      // units (kBiasFloats) | biases in those units (kBiasFloats) | kappa (16)
-    const uint4* image8;       // the stream (mlp_host.hip pack_stream8s): [stage][block][step][hi | lo][64 lanes][16 B], alpha block first in stage 8
+    const uint4* image8;       // the stream (mlp_host.hip pack_stream8s): [ring block][step][hi | lo][64 lanes][16 B] in block_steps() order
 };
 
 __device__ __forceinline__ i32x4 as_i32x4(uint4 v) { return __builtin_bit_cast(i32x4, v); }
