@@ -146,6 +146,11 @@ int nm_mlp_pack_f16(const nm_mlp_desc* desc, const float* const* host_params, vo
  * units | one scalar per stage); nm_mlp_create uploads its fragments re-ordered into per-wave streams. */
 int64_t nm_mlp_pack_i8_bytes(const nm_mlp_desc* desc);
 int nm_mlp_pack_i8(const nm_mlp_desc* desc, const float* const* host_params, void* host_out);
+/* host-only: the limb fragments of that image as the activation-stationary kernel streams them (what nm_mlp_create uploads for it):
+ * k-steps of 2 KB in consumption order -- stage 0; stages 1-7, stage 5's four encoding steps per block behind its eight i8 blocks;
+ * stage 8 with the alpha block first; stage 9; stage 10 -- followed by 8 KB of zeros (the ring copies whole 1 KB pieces: a 10-step block is rounded up). */
+int64_t nm_mlp_pack_i8s_bytes(const nm_mlp_desc* desc);
+int nm_mlp_pack_i8s(const nm_mlp_desc* desc, const float* const* host_params, void* host_out);
 int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, const float* host_pos_tab,
                   const float* host_dir_tab, nm_mlp_t* out);
 int nm_mlp_destroy(nm_mlp_t mlp);

@@ -483,6 +483,22 @@ int nm_mlp_pack_i8(const nm_mlp_desc* desc, const float* const* host_params, voi
     return NM_OK;
 }
 
+int64_t nm_mlp_pack_i8s_bytes(const nm_mlp_desc* desc) {
+    if (nm::validate_desc(desc) != NM_OK) return -1;
+    return nm::kWeightBytes8 + nm::kWeightPadBytes;
+}
+
+int nm_mlp_pack_i8s(const nm_mlp_desc* desc, const float* const* host_params, void* host_out) {
+    if (int e = nm::validate_desc(desc)) return e;
+    NM_REQUIRE(host_params && host_out, "nm_mlp_pack_i8s: null pointer");
+    NM_REQUIRE(!desc->plain_head, "nm_mlp_pack_i8s: the plain-head (use_viewdirs=False) net has no i8x3 image");
+    for (int i = 0; i < 24; ++i) NM_REQUIRE(host_params[i], "nm_mlp_pack_i8s: host_params[%d] is null", i);
+    std::vector<uint8_t> img8((size_t)nm::image8_bytes());
+    nm::pack_image8(desc, host_params, img8.data());
+    nm::pack_stream8s(img8.data(), static_cast<uint8_t*>(host_out));
+    return NM_OK;
+}
+
 int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, const float* host_pos_tab,
                   const float* host_dir_tab, nm_mlp_t* out) {
     if (int e = nm::validate_desc(desc)) return e;

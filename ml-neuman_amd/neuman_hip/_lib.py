@@ -42,6 +42,8 @@ SIGNATURES = {
     "nm_compact_workspace_ints": (i64, [i64]),
     "nm_compact_hits": (i32, [c_f32p, c_f32p, i64, c_i32p, c_i32p, c_i32p, c_i32p, c_stream]),
     "nm_mlp_pack_bytes": (i64, [ctypes.POINTER(MlpDesc)]),
+    "nm_mlp_pack_i8s_bytes": (i64, [ctypes.POINTER(MlpDesc)]),
+    "nm_mlp_pack_i8s": (i32, [ctypes.POINTER(MlpDesc), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     "nm_mlp_pack": (i32, [ctypes.POINTER(MlpDesc), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     "nm_mlp_pack_f16": (i32, [ctypes.POINTER(MlpDesc), ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p]),
     "nm_mlp_pack_i8_bytes": (i64, [ctypes.POINTER(MlpDesc)]),

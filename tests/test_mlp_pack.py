@@ -330,3 +330,36 @@ def test_pack_i8_matches_oracle(nets, seed):
     print(np.abs(got[:, :3] - ref[:, :3]).max(), np.abs(got[:, 3] - ref[:, 3]).max())
     assert np.abs(got[:, :3] - ref[:, :3]).max() < 3e-4
     assert np.abs(got[:, 3] - ref[:, 3]).max() < 2e-3 * max(1.0, np.abs(ref[:, 3]).max())
+
+
+def test_pack_i8s_stream_is_the_block_image_in_consumption_order(nets):
+    """nm_mlp_pack_i8s (what the activation-stationary i8x3 kernel streams through its LDS ring, csrc/mlp_i8s.hip): the 2 KB k-steps of the
+    nm_mlp_pack_i8 block image, each exactly once, in the order the kernel's flat ring-block table consumes them -- stage 0; the hidden
+    stages with stage 5's four encoding steps per block BEHIND its eight i8 blocks; stage 8 with the alpha block FIRST; 9; 10 -- then zeros."""
+    joiner, sd, spec = nets[0]
+    lib = _lib.lib()
+    desc = _lib.MlpDesc(8, 256, 4, _lib.NM_PE_POSENC, 10, 4)
+    host = [p.detach().contiguous() for p in joiner.nerf.ordered_params()]
+    arr = (ctypes.c_void_p * 24)(*[t.data_ptr() for t in host])
+    img = ctypes.create_string_buffer(lib.nm_mlp_pack_i8_bytes(ctypes.byref(desc)))
+    _lib.check(lib.nm_mlp_pack_i8(ctypes.byref(desc), arr, img), "nm_mlp_pack_i8")
+    nbytes = lib.nm_mlp_pack_i8s_bytes(ctypes.byref(desc))
+    assert nbytes == w_off8(11) + 4 * 2048
+    stream = ctypes.create_string_buffer(nbytes)
+    _lib.check(lib.nm_mlp_pack_i8s(ctypes.byref(desc), arr, stream), "nm_mlp_pack_i8s")
+    steps = {0: (8, 4), 5: (8, 12), 8: (9, 8), 9: (4, 10), 10: (1, 4)}                     # stage -> (blocks, k-steps per block) of the block image
+    frag = lambda st, nb, t: w_off8(st) + (nb * steps.get(st, (8, 8))[1] + t) * 2048      # noqa: E731
+    order = [(0, nb, t) for nb in range(8) for t in range(4)]
+    for st in range(1, 8):
+        order += [(st, nb, t) for nb in range(8) for t in range(8)]
+        if st == 5:
+            order += [(5, nb, 8 + t) for nb in range(8) for t in range(4)]
+    order += [(8, 8, t) for t in range(8)] + [(8, nb, t) for nb in range(8) for t in range(8)]
+    order += [(9, nb, t) for nb in range(4) for t in range(10)] + [(10, 0, t) for t in range(4)]
+    assert len(order) * 2048 == w_off8(11) and len(set(order)) == len(order)
+    for k, (st, nb, t) in enumerate(order):
+        assert stream.raw[k * 2048:(k + 1) * 2048] == img.raw[frag(st, nb, t):frag(st, nb, t) + 2048], (k, st, nb, t)
+    assert stream.raw[w_off8(11):] == bytes(4 * 2048)
+    # the kernel's ring-block table (block_steps in csrc/mlp_i8s.hip) covers exactly this stream
+    table = [4] * 8 + [8] * 69 + [10] * 4 + [4]
+    assert len(table) == 82 and sum(table) * 2048 == w_off8(11)
