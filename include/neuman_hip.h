@@ -321,6 +321,16 @@ int64_t nm_render_rays_human_workspace_floats(int64_t R, int S, int posed);
 int nm_render_rays_human(nm_mlp_t human, nm_mesh_t mesh, const double* T, const float* origin, const float* direction, const float* near,
                          const float* far, int64_t R, int S, const float* t_vals, int white_bkg, float sigma_scale, int precision,
                          float* workspace, float* raw_out, float* z_out, float* rgb, float* depth, float* acc, nm_stream_t stream);
+/* render_hybrid_nerf's per-batch body (utils/render_utils.py:287-353; SURVEY 8b nm_render_rays_hybrid) as one call: two-pass background
+ * of every ray (scalar bkg_near / bkg_far) and its composite, near / far against the posed body `verts` [V,3] (geo_threshold), compaction
+ * of the hit rays (ONE host read: their count), human pass of the hit rays through `mesh` / `T`, merged composite and the human-only
+ * accumulation scattered back -> rgb [R,3], depth [R], acc [R] (0 where the body is missed).  t_vals [S], u [N], t_vals_human
+ * [S_human] = the caller's torch.linspace(0, 1, .).  Same kernels, same bits as the separate calls. */
+int64_t nm_render_rays_hybrid_workspace_floats(int64_t R, int S, int N, int S_human);
+int nm_render_rays_hybrid(nm_mlp_t coarse, nm_mlp_t fine, nm_mlp_t human, nm_mesh_t mesh, const double* T, const float* verts, int V,
+                          double geo_threshold, const float* origin, const float* direction, int64_t R, float bkg_near, float bkg_far, int S, int N,
+                          int S_human, const float* t_vals, const float* u, const float* t_vals_human, int white_bkg, int precision_coarse,
+                          int precision_fine, int precision_human, float* workspace, float* rgb, float* depth, float* acc, nm_stream_t stream);
 int64_t nm_merge_composite_workspace_floats(int64_t R, int Sa, int Sb);
 int nm_merge_composite(const float* za, const float* rawa, int Sa, const float* zb, const float* rawb, int Sb, int64_t R, const float* rays_d,
                        int white_bkg, float* workspace, float* rgb, float* depth, float* acc, nm_stream_t stream);

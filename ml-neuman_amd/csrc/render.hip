@@ -91,4 +91,82 @@ int nm_merge_composite(const float* za, const float* rawa, int Sa, const float* 
     return nm_composite(raw, z, rays_d, R, Sa + Sb, white_bkg, nullptr, rgb, disp, acc, nullptr, depth, stream);
 }
 
+// ---- render_hybrid_nerf's per-batch body (utils/render_utils.py:287-353) as one call: two-pass background for every ray and its
+// composite (what a ray that misses the body keeps, :303-311), near / far against the posed body, compaction of the hit rays (the one
+// host read of the call: their count -- the reference's boolean-mask indexing implies the same), human pass of the hit rays, merged
+// composite (:330-345) and the human-only accumulation (:345-350) scattered back.  Built from the entry points above and below: same
+// kernels, same bits as calling them one by one (tests/test_hip_fused.py).
+namespace {
+struct HybridWs {
+    float *near_b, *far_b, *bkg_ws, *raw_b, *z_b, *near_h, *far_h, *ho, *hd, *hn, *hf, *bz, *braw, *h_raw, *h_z, *human_ws, *merge_ws, *rgb_h, *depth_h, *acc_h,
+        *scratch;
+    int32_t *hit, *counts, *cws;
+    int64_t total;
+};
+inline HybridWs hybrid_layout(float* base, int64_t R, int S, int N, int Sh) {
+    HybridWs w;
+    int64_t o = 0;
+    auto take = [&](int64_t n) { float* p = base ? base + o : nullptr; o += align4(n); return p; };
+    const int Sb = S + N;
+    w.near_b = take(R); w.far_b = take(R);
+    w.bkg_ws = take(nm_render_rays_bkg_workspace_floats(R, S, N));
+    w.raw_b = take(R * Sb * 4); w.z_b = take(R * Sb);
+    w.near_h = take(R); w.far_h = take(R);
+    w.hit = reinterpret_cast<int32_t*>(take(R)); w.counts = reinterpret_cast<int32_t*>(take(4));
+    w.cws = reinterpret_cast<int32_t*>(take(nm_compact_workspace_ints(R)));
+    w.ho = take(R * 3); w.hd = take(R * 3); w.hn = take(R); w.hf = take(R);
+    w.bz = take(R * Sb); w.braw = take(R * Sb * 4);
+    w.h_raw = take(R * Sh * 4); w.h_z = take(R * Sh);
+    w.human_ws = take(nm_render_rays_human_workspace_floats(R, Sh, 1));
+    w.merge_ws = take(nm_merge_composite_workspace_floats(R, Sb, Sh));
+    w.rgb_h = take(R * 3); w.depth_h = take(R); w.acc_h = take(R); w.scratch = take(R * 6);
+    w.total = o;
+    return w;
+}
+}  // namespace
+
+int64_t nm_render_rays_hybrid_workspace_floats(int64_t R, int S, int N, int S_human) { return hybrid_layout(nullptr, R, S, N, S_human).total; }
+
+int nm_render_rays_hybrid(nm_mlp_t coarse, nm_mlp_t fine, nm_mlp_t human, nm_mesh_t mesh, const double* T, const float* verts, int V,
+                          double geo_threshold, const float* origin, const float* direction, int64_t R, float bkg_near, float bkg_far, int S, int N,
+                          int S_human, const float* t_vals, const float* u, const float* t_vals_human, int white_bkg, int precision_coarse,
+                          int precision_fine, int precision_human, float* workspace, float* rgb, float* depth, float* acc, nm_stream_t stream) {
+    NM_REQUIRE(R == 0 || (coarse && human && mesh && T && verts && origin && direction && t_vals && t_vals_human && workspace && rgb && depth && acc),
+               "nm_render_rays_hybrid: null pointer");
+    NM_REQUIRE(R >= 0 && S >= 1 && N >= 0 && S_human >= 2 && V >= 1, "nm_render_rays_hybrid: bad sizes");
+    if (R == 0) return NM_OK;
+    hipStream_t st = nm::as_stream(stream);
+    const HybridWs w = hybrid_layout(workspace, R, S, N, S_human);
+    const int Sb = S + N;
+    int rc;
+    union { float f; uint32_t u; } nb{bkg_near}, fb{bkg_far};
+    if ((rc = nm::check_hip(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.near_b), (int)nb.u, (size_t)R, st), "nm_render_rays_hybrid: near"))) return rc;
+    if ((rc = nm::check_hip(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(w.far_b), (int)fb.u, (size_t)R, st), "nm_render_rays_hybrid: far"))) return rc;
+    // every ray: the background-only composite; acc is forced to 0 where the body is missed (:311)
+    if ((rc = nm_render_rays_bkg(coarse, fine, origin, direction, w.near_b, w.far_b, R, S, N, t_vals, u, white_bkg, precision_coarse, precision_fine, w.bkg_ws,
+                                 w.raw_b, w.z_b, rgb, depth, acc, stream))) return rc;
+    if ((rc = nm::check_hip(hipMemsetAsync(acc, 0, (size_t)R * 4, st), "nm_render_rays_hybrid: acc"))) return rc;
+    if ((rc = nm_near_far(origin, direction, R, verts, V, geo_threshold, w.near_h, w.far_h, stream))) return rc;
+    if ((rc = nm_compact_hits(w.near_h, w.far_h, R, w.hit, nullptr, w.counts, w.cws, stream))) return rc;
+    int32_t n_hit = 0;
+    if ((rc = nm::check_hip(hipMemcpyAsync(&n_hit, w.counts, 4, hipMemcpyDeviceToHost, st), "nm_render_rays_hybrid: hit count"))) return rc;
+    if ((rc = nm::check_hip(hipStreamSynchronize(st), "nm_render_rays_hybrid: hit count"))) return rc;
+    if (n_hit == 0) return NM_OK;
+    // the hit rays: overwritten by the merged human + background composite (:313-353)
+    if ((rc = nm_gather_rows(origin, w.hit, nullptr, n_hit, 3, w.ho, stream))) return rc;
+    if ((rc = nm_gather_rows(direction, w.hit, nullptr, n_hit, 3, w.hd, stream))) return rc;
+    if ((rc = nm_gather_rows(w.near_h, w.hit, nullptr, n_hit, 1, w.hn, stream))) return rc;
+    if ((rc = nm_gather_rows(w.far_h, w.hit, nullptr, n_hit, 1, w.hf, stream))) return rc;
+    if ((rc = nm_gather_rows(w.z_b, w.hit, nullptr, n_hit, Sb, w.bz, stream))) return rc;
+    if ((rc = nm_gather_rows(w.raw_b, w.hit, nullptr, n_hit, Sb * 4, w.braw, stream))) return rc;
+    if ((rc = nm_render_rays_human(human, mesh, T, w.ho, w.hd, w.hn, w.hf, n_hit, S_human, t_vals_human, white_bkg, 1.f, precision_human, w.human_ws, w.h_raw,
+                                   w.h_z, nullptr, nullptr, nullptr, stream))) return rc;
+    if ((rc = nm_merge_composite(w.bz, w.braw, Sb, w.h_z, w.h_raw, S_human, n_hit, w.hd, white_bkg, w.merge_ws, w.rgb_h, w.depth_h, w.acc_h, stream))) return rc;
+    if ((rc = nm_composite(w.h_raw, w.h_z, w.hd, n_hit, S_human, white_bkg, nullptr, w.scratch, w.scratch + 3 * (int64_t)n_hit, w.acc_h, nullptr,
+                           w.scratch + 5 * (int64_t)n_hit, stream))) return rc;                     // the human-only accumulation (:345-350)
+    if ((rc = nm_scatter_rows(w.rgb_h, w.hit, nullptr, n_hit, 3, rgb, stream))) return rc;
+    if ((rc = nm_scatter_rows(w.depth_h, w.hit, nullptr, n_hit, 1, depth, stream))) return rc;
+    return nm_scatter_rows(w.acc_h, w.hit, nullptr, n_hit, 1, acc, stream);
+}
+
 }  // extern "C"

@@ -100,6 +100,10 @@ SIGNATURES = {
     "nm_render_rays_human_workspace_floats": (i64, [i64, i32, i32]),
     "nm_render_rays_human": (i32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, i64, i32, c_f32p, i32, ctypes.c_float, i32,
                                    c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
+    "nm_render_rays_hybrid_workspace_floats": (i64, [i64, i32, i32, i32]),
+    "nm_render_rays_hybrid": (i32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_f32p, i32, ctypes.c_double, c_f32p, c_f32p,
+                                    i64, ctypes.c_float, ctypes.c_float, i32, i32, i32, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, c_f32p, c_f32p, c_f32p, c_f32p,
+                                    c_stream]),
     "nm_merge_composite_workspace_floats": (i64, [i64, i32, i32]),
     "nm_merge_composite": (i32, [c_f32p, c_f32p, i32, c_f32p, c_f32p, i32, i64, c_f32p, i32, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "nm_frame_to_uint8": (i32, [c_f32p, i64, ctypes.c_void_p, c_stream]),

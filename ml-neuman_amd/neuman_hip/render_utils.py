@@ -397,7 +397,11 @@ def render_hybrid_rays(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far,
                        given=None):
     """Device core of render_hybrid_nerf -> (rgb [R,3], depth [R], acc [R]) CUDA  (render_utils.py:276-356).  `given`: see bkg_pass_rays.
     With TERMINATION_EPS > 0 the human pass runs first (marched on its own transmittance) and the background passes are marched on the
-    transmittance of the MERGED list where they can know it (behind the body: their own x the body's): a pixel moves by < 2 eps."""
+    transmittance of the MERGED list where they can know it (behind the body: their own x the body's): a pixel moves by < 2 eps.
+    The plain case (no trace, no replay, no termination) is ONE C call per batch: render_hybrid_rays_fused, bit-identical."""
+    if TERMINATION_EPS <= 0 and trace is None and given is None:
+        return render_hybrid_rays_fused(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far, posed_verts, mesh, samples_per_ray,
+                                        importance_samples_per_ray, white_bkg, geo_threshold, precision)
     R = o.shape[0]
     rgb = torch.empty((R, 3), device=o.device, dtype=torch.float32)
     depth = torch.empty(R, device=o.device, dtype=torch.float32)
@@ -450,6 +454,35 @@ def render_hybrid_rays(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far,
         ray_utils.scatter_rows(rgb[i:j], hit, _rgb)
         ray_utils.scatter_rows(depth[i:j], hit, _depth)
         ray_utils.scatter_rows(acc[i:j], hit, _acc)
+    return rgb, depth, acc
+
+
+def render_hybrid_rays_fused(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far, posed_verts, mesh, samples_per_ray,
+                             importance_samples_per_ray, white_bkg=True, geo_threshold=DEFAULT_GEO_THRESH, precision=None):
+    """render_hybrid_rays' batch body as ONE C call (nm_render_rays_hybrid): same kernels, same bits; no trace / replay / early
+    termination hooks -- the plain path of a frame render."""
+    _lib.require_gpu()
+    R = o.shape[0]
+    dev = o.device
+    rgb = torch.empty((R, 3), device=dev, dtype=torch.float32)
+    depth = torch.empty(R, device=dev, dtype=torch.float32)
+    acc = torch.empty(R, device=dev, dtype=torch.float32)
+    S, N, Sh = int(samples_per_ray), int(importance_samples_per_ray) if fine_bkg is not None else 0, int(samples_per_ray)
+    verts = posed_verts.to(dev, torch.float32).contiguous()
+    t_vals = torch.linspace(0., 1., steps=S, device=dev)
+    u = torch.linspace(0., 1., steps=N, device=dev) if N else None
+    for i, j in _chunks(R):
+        oc, dc = o[i:j].contiguous(), d[i:j].contiguous()
+        n = j - i
+        ws = _ws(_lib.lib().nm_render_rays_hybrid_workspace_floats(n, S, N, Sh), dev)
+        r_, d_, a_ = rgb[i:j], depth[i:j], acc[i:j]
+        _lib.check(_lib.lib().nm_render_rays_hybrid(
+            coarse_bkg.handle(), fine_bkg.handle() if fine_bkg is not None else None, human_net.handle(), mesh.handle, _lib.dev_ptr(mesh.T, torch.float64, 'T'),
+            _lib.dev_ptr(verts), verts.shape[0], float(geo_threshold), _lib.dev_ptr(oc), _lib.dev_ptr(dc), n, float(bkg_near), float(bkg_far), S, N, Sh,
+            _lib.dev_ptr(t_vals), _lib.dev_ptr(u), _lib.dev_ptr(t_vals), int(bool(white_bkg)),
+            coarse_bkg._prec(precision, None if fine_bkg is not None else 'shading'), fine_bkg._prec(precision, 'shading') if fine_bkg is not None else 0,
+            human_net._prec(precision, 'shading'), _lib.dev_ptr(ws), _lib.dev_ptr(r_), _lib.dev_ptr(d_), _lib.dev_ptr(a_), _lib.stream_ptr()),
+            "nm_render_rays_hybrid")
     return rgb, depth, acc
 
 

@@ -84,3 +84,29 @@ def test_human_pass_and_merge_composite_in_one_call(G):
     e = torch.empty((0, 3), device='cuda')
     raw0, z0 = G.render.human_pass_rays(human, e, e, torch.empty(0, device='cuda'), torch.empty(0, device='cuda'), 16, mesh, False, 1.0)
     assert raw0.shape == (0, 16, 4) and z0.shape == (0, 16)
+
+
+def test_hybrid_batch_as_one_call_is_bit_identical():
+    """nm_render_rays_hybrid (render_utils.render_hybrid_rays_fused) = render_hybrid_rays' per-batch sequence of calls, bit for bit:
+    a body in front of the background at 64 + 64 background and 64 human samples, hits and misses in one batch"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+    import posed_scene as PS
+    from neuman_hip import ray_utils, render_utils, synthetic
+    g = PS.load()
+    c = PS.cap(g, 'hybrid')
+    o, d = (torch.as_tensor(x).cuda().contiguous() for x in PS.frame_rays(c))
+    mesh = ray_utils.mesh_to_device(g['posed_verts'], np.ascontiguousarray(g['faces'][:, :3], np.int32), g['T'], 'cuda')
+    nets = [synthetic.make_joiner(0).cuda(), synthetic.make_joiner(1).cuda(), synthetic.make_joiner(2, 'rotate').cuda()]
+    verts = torch.as_tensor(g['posed_verts']).cuda().float()
+    a = render_utils.render_hybrid_rays(nets[0], nets[1], nets[2], o, d, c.near['bkg'], c.far['bkg'], verts, mesh, 64, 64, trace={})   # (trace: the step-by-step path)
+    b = render_utils.render_hybrid_rays_fused(nets[0], nets[1], nets[2], o, d, c.near['bkg'], c.far['bkg'], verts, mesh, 64, 64)
+    assert float(a[2].max()) > 0 and float((a[2] == 0).float().mean()) > 0.1                # hits and misses
+    for x, y, what in zip(a, b, ("rgb", "depth", "acc")):
+        assert torch.equal(x, y), what
+    # one net, no fine pass (render_hybrid_nerf with a coarse-only background model)
+    a = render_utils.render_hybrid_rays(nets[0], None, nets[2], o, d, c.near['bkg'], c.far['bkg'], verts, mesh, 64, 0, trace={})
+    b = render_utils.render_hybrid_rays_fused(nets[0], None, nets[2], o, d, c.near['bkg'], c.far['bkg'], verts, mesh, 64, 0)
+    for x, y, what in zip(a, b, ("rgb", "depth", "acc")):
+        assert torch.equal(x, y), what
