@@ -201,6 +201,11 @@ int nm_mlp_sigma_ray_chunk(nm_mlp_t mlp, const float* origin, const float* direc
  * falls below the caller's epsilon are dropped by nm_compact_hits(eps, T). */
 int nm_transmittance_chunk(const float* raw, const float* z_vals, const float* rays_d, const int32_t* ray_idx, const int32_t* n_rays_dev,
                            int64_t n_rays, int s0, int S, int S_total, float* T, nm_stream_t stream);
+/* The same with the samples' z INTERVALS given (dz [R,S_total], before the multiplication by |rays_d|): a list that will be merged
+ * with other lists before it is composited (render_utils.py:330-345, 441-456) -- the interval behind a sample then ends at its
+ * successor in the merged order, and the transmittance the early-termination cut is decided on is the merged list's. */
+int nm_transmittance_chunk_dz(const float* raw, const float* dz, const float* rays_d, const int32_t* ray_idx, const int32_t* n_rays_dev,
+                              int64_t n_rays, int s0, int S, int S_total, float* T, nm_stream_t stream);
 /* Debug: stop after `stage` and write that stage's activations as f32 [n, width_of_stage]:
  *   -1 -> position PE (64 wide, col 63 = 0);  0..7 -> relu(pts_linears[i]) (256);
  *    8 -> feature_linear output (256);  9 -> relu(views_linears[0]) (128). */

@@ -13,7 +13,10 @@
 
 namespace {
 
-// one wave per live ray; lanes over the chunk's samples
+// one wave per live ray; lanes over the chunk's samples.  GIVEN_DZ: `z` holds the samples' INTERVALS instead of their positions
+// (a list that will be merged with others before it is composited: the interval behind a sample ends at its successor in the
+// MERGED order, render_utils.py:330-345)
+template <bool GIVEN_DZ>
 __global__ __launch_bounds__(256) void transmittance_chunk_kernel(const float* __restrict__ raw, const float* __restrict__ z,
                                                                   const float* __restrict__ rays_d, const int* __restrict__ ray_idx,
                                                                   const int* __restrict__ n_rays_dev, int n_rays, int s0, int S, int S_total,
@@ -31,7 +34,7 @@ __global__ __launch_bounds__(256) void transmittance_chunk_kernel(const float* _
         float prod = 1.f;
         for (int t = lane; t < S; t += 64) {
             const int i = s0 + t;
-            const float dist = (i + 1 < S_total ? zr[i + 1] - zr[i] : 1e10f) * dn;             // render_utils.py:85-88
+            const float dist = (GIVEN_DZ ? zr[i] : (i + 1 < S_total ? zr[i + 1] - zr[i] : 1e10f)) * dn;   // render_utils.py:85-88
             const float alpha = 1.f - expf(-fmaxf(rw[i].w, 0.f) * dist);                       // :94
             prod *= 1.f - alpha + 1e-10f;                                                      // :95
         }
@@ -54,9 +57,23 @@ int nm_transmittance_chunk(const float* raw, const float* z_vals, const float* r
     if (n_rays == 0) return NM_OK;
     int64_t blocks = (n_rays + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(transmittance_chunk_kernel, dim3((unsigned)blocks), dim3(256), 0, nm::as_stream(stream), raw, z_vals, rays_d, ray_idx,
+    hipLaunchKernelGGL(transmittance_chunk_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, nm::as_stream(stream), raw, z_vals, rays_d, ray_idx,
                        n_rays_dev, (int)n_rays, s0, S, S_total, T);
     return nm::check_launch("transmittance_chunk_kernel");
+}
+
+int nm_transmittance_chunk_dz(const float* raw, const float* dz, const float* rays_d, const int32_t* ray_idx, const int32_t* n_rays_dev,
+                              int64_t n_rays, int s0, int S, int S_total, float* T, nm_stream_t stream) {
+    NM_REQUIRE(n_rays == 0 || (raw && dz && rays_d && T), "nm_transmittance_chunk_dz: null pointer");
+    NM_REQUIRE(n_rays >= 0 && n_rays < (1ll << 31) && S >= 1 && s0 >= 0 && s0 + S <= S_total, "nm_transmittance_chunk_dz: bad sizes (s0=%d S=%d S_total=%d)",
+               s0, S, S_total);
+    NM_REQUIRE((reinterpret_cast<uintptr_t>(raw) & 15) == 0, "nm_transmittance_chunk_dz: raw must be 16-byte aligned");
+    if (n_rays == 0) return NM_OK;
+    int64_t blocks = (n_rays + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(transmittance_chunk_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, nm::as_stream(stream), raw, dz, rays_d, ray_idx,
+                       n_rays_dev, (int)n_rays, s0, S, S_total, T);
+    return nm::check_launch("transmittance_chunk_kernel<dz>");
 }
 
 }  // extern "C"

@@ -290,6 +290,8 @@ __device__ __forceinline__ void quant16(const f32x16& f, float inv, uint4& xh, u
 __device__ __forceinline__ float inv_of(float M) { return M > 0.f ? ((float)nm::kFixedMax / 32767.f) * __builtin_amdgcn_rcpf(M) : 0.f; }
 __device__ __forceinline__ float scale_of(float M) { return M > 0.f ? M * (1.f / (float)nm::kFixedMax) : 1.f; }
 
+// (HIP's second __launch_bounds__ argument is the minimum number of WAVES PER SIMD -- not CUDA's blocks per multiprocessor: 2 = the
+// 8 waves of the ONE workgroup a CU holds, i.e. a 256-register budget per wave; the 147 KB of LDS allow no second workgroup anyway)
 __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args8s A) {
     __shared__ uint4 lds[kPeU4 + kSlots * kSlotU4 + kBiasU4];
     const MlpArgs a = resolve_args(A.a);

@@ -1,4 +1,4 @@
-// Fused per-ray entry points (SURVEY 8b's proposed ABI: nm_render_rays_bkg / _human, nm_merge_composite): ONE C call per pass of the
+// Sequenced per-ray entry points (SURVEY 8b's proposed ABI: nm_render_rays_bkg / _human, nm_merge_composite): ONE C call per pass of the
 // reference's renderers, the kernels of the pass enqueued back to back on the caller's stream -- no host synchronisation inside, no
 // hidden allocation (every intermediate lives in the caller's workspace or output arrays), same kernels and therefore the same bits
 // as the step-by-step entry points.  Reference: utils/render_utils.py:131-151 / 287-297 (two-pass background), :213-229 / 320-329

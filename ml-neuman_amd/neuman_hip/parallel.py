@@ -6,8 +6,18 @@ blocks would be unbalanced) into a local [n_local, C] buffer; rank 0 receives on
 ``torch.distributed.gather`` (RCCL over xGMI with backend "nccl", gloo in the CPU tests) and permutes them into
 the frame.  The reference itself never shards renders (single device, sequential `rays_per_batch` loop).
 """
+import os
+import time
+
 import torch
 import torch.distributed as dist
+
+# tile of the frame renderers' sharding (render_frame_sharded): the local rays of a rank are rendered as ONE ray list whatever
+# the tile is, so the tile only sets how finely the ranks interleave across the image -- 1024 rays is less than an image row of
+# the human configurations, so every rank's rays cross the body (hit rays cluster in the image centre, SURVEY 8e)
+FRAME_TILE = int(os.environ.get("NEUMAN_FRAME_TILE", "1024"))
+# run the collective path on an initialised process group of ONE rank as well (what a one-GPU box can execute of the N > 1 path)
+FORCE_COLLECTIVE = os.environ.get("NEUMAN_FORCE_COLLECTIVE", "0") == "1"
 
 
 def rank_world():
@@ -83,14 +93,17 @@ def gather_frame(local, local_idx, total_rays, tile, dst=0, force_collective=Fal
         out[local_idx] = local
         return out
     cap = max_local_rays(total_rays, tile, world)
+    home = local.device
+    if local.is_cuda and dist.get_backend() == "gloo":          # ranks sharing a GPU in the tests: gloo moves host tensors
+        local = local.cpu()
     send = torch.zeros((cap, local.shape[1]), device=local.device, dtype=local.dtype)
     send[:local.shape[0]] = local
     big = torch.empty((world, cap, local.shape[1]), device=local.device, dtype=local.dtype) if rank == dst else None
     dist.gather(send, gather_list=list(big.unbind(0)) if rank == dst else None, dst=dst)
     if rank != dst:
         return None
-    rows = frame_source_rows(total_rays, tile, world, device=local.device)
-    return big.reshape(world * cap, local.shape[1]).index_select(0, rows)
+    rows = frame_source_rows(total_rays, tile, world, device=home)
+    return big.reshape(world * cap, local.shape[1]).to(home).index_select(0, rows)
 
 
 def render_sharded(render_rays_fn, origins, dirs, tile=8192, dst=0, force_collective=False):
@@ -104,3 +117,55 @@ def render_sharded(render_rays_fn, origins, dirs, tile=8192, dst=0, force_collec
     idx = tile_ray_indices(total, tile, rank, world, device=origins.device)
     local = render_rays_fn(origins[idx].contiguous(), dirs[idx].contiguous())
     return gather_frame(local, idx, total, tile, dst, force_collective)
+
+
+def sharding_active():
+    """True when the frame renderers shard: an initialised process group of more than one rank (or of one, with FORCE_COLLECTIVE)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or FORCE_COLLECTIVE
+
+
+LAST_FRAME_STATS = {}
+
+
+def render_frame_sharded(rays_fn, origins, dirs, max_tile=None, dst=0):
+    """What render_vanilla / render_smpl_nerf / render_hybrid_nerf / render_hybrid_nerf_multi_persons call under a process group
+    (reference render_test_views.py:70-90, render_gathering.py:186-200 render one frame on one device; here the frame's rays are
+    split over the ranks).
+
+    rays_fn(o [n,3], d [n,3]) -> tuple of per-ray tensors ([n] or [n,C]) on the rays' device.  Every rank holds the frame's rays,
+    the weights and the posed meshes; it renders the rays of its interleaved tiles as ONE list (so the renderers' own batching, hit
+    compaction and C calls see a smaller frame, nothing else), the columns travel as one [n_local, sum C] buffer through ONE gather,
+    and rank `dst` gets the tuple for the whole frame; the other ranks get None.  Rays are independent: the frame is bit-identical
+    to the unsharded one (tests/test_parallel_gpu.py).  LAST_FRAME_STATS: this rank's tile / ray counts and milliseconds."""
+    rank, world = rank_world()
+    total = origins.shape[0]
+    tile = balanced_tile(total, world, max_tile or FRAME_TILE)
+    idx = tile_ray_indices(total, tile, rank, world, device=origins.device)
+    cuda = origins.is_cuda
+    if cuda:
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    outs = rays_fn(origins[idx].contiguous(), dirs[idx].contiguous())
+    cols = [x.reshape(x.shape[0], -1).to(torch.float32) for x in outs]
+    local = torch.cat(cols, 1) if len(cols) > 1 else cols[0]
+    if cuda:
+        torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    frame = gather_frame(local, idx, total, tile, dst, force_collective=FORCE_COLLECTIVE)
+    if cuda:
+        torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    LAST_FRAME_STATS.clear()
+    LAST_FRAME_STATS.update(rank=rank, world=world, tile=tile, tiles=(idx.shape[0] + tile - 1) // tile, rays=int(idx.shape[0]),
+                            render_ms=(t1 - t0) * 1e3, gather_ms=(t2 - t1) * 1e3)
+    if frame is None:
+        return None
+    res, c0 = [], 0
+    for x, c in zip(outs, cols):
+        w = c.shape[1]
+        part = frame[:, c0:c0 + w]
+        res.append(part.reshape(total, *x.shape[1:]))
+        c0 += w
+    return tuple(res)

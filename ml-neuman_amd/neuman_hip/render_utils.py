@@ -20,7 +20,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib, ray_utils
+from . import _lib, parallel, ray_utils
 from .ray_utils import DEFAULT_GEO_THRESH
 
 MAX_RAYS_PER_LAUNCH = int(os.environ.get("NEUMAN_MAX_RAYS_PER_LAUNCH", 1 << 20))
@@ -36,6 +36,7 @@ TERMINATION_CHUNK = int(os.environ.get("NEUMAN_TERMINATION_CHUNK", "32"))
 # CDF at float32-rounding level, which the inverse CDF amplifies in near-empty bins: 1.6e-4 on the worst pixel of a frame.)
 TERMINATION_COARSE = float(os.environ.get("NEUMAN_TERMINATION_COARSE", "4e-13"))
 TERMINATION_MIN_CHUNK = 16
+FUSED_HYBRID_RAYS = int(os.environ.get("NEUMAN_FUSED_HYBRID_RAYS", 1 << 17))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -96,8 +97,32 @@ def _note(trace, **kw):
             trace.setdefault(k, []).append(v)
 
 
+def _transmittance_chunk(raw, z, dz, d, live, counts, R, s0, c, S, T):
+    """T[live] *= prod over samples s0 .. s0+c-1 of raw2outputs' factors; intervals from z, or the given ones (merged lists)"""
+    if dz is None:
+        _lib.check(_lib.lib().nm_transmittance_chunk(_lib.dev_ptr(raw), _lib.dev_ptr(z), _lib.dev_ptr(d), _lib.dev_ptr(live, torch.int32),
+                                                     _lib.dev_ptr(counts, torch.int32), R, s0, c, S, _lib.dev_ptr(T), _lib.stream_ptr()),
+                   "nm_transmittance_chunk")
+    else:
+        _lib.check(_lib.lib().nm_transmittance_chunk_dz(_lib.dev_ptr(raw), _lib.dev_ptr(dz), _lib.dev_ptr(d), _lib.dev_ptr(live, torch.int32),
+                                                        _lib.dev_ptr(counts, torch.int32), R, s0, c, S, _lib.dev_ptr(T), _lib.stream_ptr()),
+                   "nm_transmittance_chunk_dz")
+
+
+def merged_intervals(z_lists):
+    """For every sample of every list ([R, S_k] each, sorted per ray): the distance to its successor in the MERGED order of all the
+    lists (stable, earlier list first -- the order of the reference's sort(cat(...)), render_utils.py:330-337, 441-448); the last
+    sample of the merged list gets raw2outputs' 1e10 (render_utils.py:86).  -> one [R, S_k] tensor per list.  These are the
+    intervals the samples will be composited with once the lists are merged: what an early-termination cut has to be decided on."""
+    z = torch.cat(z_lists, 1)
+    zs, order = torch.sort(z, dim=1, stable=True)
+    dz_s = torch.cat([zs[:, 1:] - zs[:, :-1], torch.full_like(zs[:, :1], 1e10)], 1)
+    dz = torch.empty_like(z).scatter_(1, order, dz_s)
+    return [t.contiguous() for t in torch.split(dz, [zl.shape[1] for zl in z_lists], 1)]
+
+
 def march_pass_rays(net, o, d, z, eps, chunk=None, precision=None, role='shading', stats=None, sigma_only=False, occluder=None,
-                    adaptive=None):
+                    adaptive=None, dz=None):
     """A pass with early ray termination: the S sorted samples of every ray are evaluated front to back in chunks of `chunk`; after
     each chunk the rays whose transmittance (the running product of raw2outputs' factors, nm_transmittance_chunk) is below `eps`
     leave the list (ballot / prefix-sum compaction on the device, nm_compact_hits) and the next MLP launch covers the compacted live
@@ -107,7 +132,10 @@ def march_pass_rays(net, o, d, z, eps, chunk=None, precision=None, role='shading
 
     occluder = (z_far [R], T_occ [R]): the ray's list will be merged with another whose samples all lie in front of z_far and whose
     total transmittance is T_occ (the hybrid renderers: the human samples).  Once the march is past z_far the transmittance of the
-    MERGED list is T * T_occ, and that is what is compared with eps.
+    MERGED list is T * T_occ, and that is what is compared with eps.  `dz` [R,S]: the samples' intervals in the merged list
+    (merged_intervals) -- merging shortens the interval behind every sample that gets a foreign successor, so a transmittance
+    taken over the list's OWN intervals is not an upper bound of the merged one; with `dz` (here and in T_occ) T * T_occ is the
+    merged list's transmittance itself (before z_far: an upper bound of it, T_occ counted as 1).
 
     adaptive (default: eps > 0): ONE host read per chunk -- the live count.  No launch once nobody is live; the chunk is halved
     (not below TERMINATION_MIN_CHUNK) while more than 2 % of the live rays were cut by the last one -- rays are only ever cut at a chunk
@@ -138,9 +166,7 @@ def march_pass_rays(net, o, d, z, eps, chunk=None, precision=None, role='shading
         s0 += c
         if s0 >= S or eps <= 0:                                   # (eps = 0: nothing is ever dropped, not even rays whose T underflowed to 0)
             continue
-        _lib.check(_lib.lib().nm_transmittance_chunk(_lib.dev_ptr(raw), _lib.dev_ptr(z), _lib.dev_ptr(d), _lib.dev_ptr(live, torch.int32),
-                                                     _lib.dev_ptr(counts, torch.int32), R, s0 - c, c, S, _lib.dev_ptr(T), _lib.stream_ptr()),
-                   "nm_transmittance_chunk")
+        _transmittance_chunk(raw, z, dz, d, live, counts, R, s0 - c, c, S, T)
         T_eff = T if occluder is None else T * torch.where(z[:, s0] >= occluder[0], occluder[1], torch.ones_like(T))
         nxt = torch.empty(R, device=dev, dtype=torch.int32)
         counts = torch.zeros(2, device=dev, dtype=torch.int32)
@@ -162,25 +188,28 @@ def march_pass_rays(net, o, d, z, eps, chunk=None, precision=None, role='shading
     return raw
 
 
-def transmittance_of(raw, z, d):
-    """prod_i (1 - alpha_i + 1e-10) over a whole list: raw2outputs' factors (render_utils.py:85-95) -> T [R]"""
+def transmittance_of(raw, z, d, dz=None):
+    """prod_i (1 - alpha_i + 1e-10) over a whole list: raw2outputs' factors (render_utils.py:85-95) -> T [R].  With the list's own
+    intervals (the last one 1e10), or -- `dz`, merged_intervals -- with the intervals it has once merged with other lists."""
     R, S = z.shape
     T = torch.ones(R, device=z.device, dtype=torch.float32)
-    _lib.check(_lib.lib().nm_transmittance_chunk(_lib.dev_ptr(raw.contiguous()), _lib.dev_ptr(z.contiguous()), _lib.dev_ptr(d.contiguous()), None, None,
-                                                 R, 0, S, S, _lib.dev_ptr(T), _lib.stream_ptr()), "nm_transmittance_chunk")
+    _transmittance_chunk(raw.contiguous(), z.contiguous(), None if dz is None else dz.contiguous(), d.contiguous(), None, None, R, 0, S, S, T)
     return T
 
 
 def human_march_rays(human_net, o, d, near, far, samples_per_ray, mesh, eps, sigma_scale=1.0, precision=None, chunk=None, trace=None,
-                     stats=None):
+                     stats=None, dz=None):
     """human_pass_rays (posed) with early ray termination -> (raw [R,S,4], z [R,S]).  The warp is the expensive step here, and a ray that
     has entered an opaque body needs neither the closest-point queries nor the network behind the surface.  Front to back in chunks; the
     live rays' samples of a chunk are gathered, warped (one sample past the chunk: the canonical direction of a sample is the forward
     difference to the next warped point, ray_utils.py:62-64 -- the last sample of a ray repeats its predecessor's), evaluated and
     scattered back; rays whose transmittance over their own (human) samples is below eps are dropped (chunks of `chunk` samples, doubled
-    after every chunk that cut fewer than 2 % of the live rays, halved otherwise).  Merged with any other list the
-    transmittance can only be lower, so what is skipped weighs < eps in every composite the renderers make of it.  Every evaluated
-    sample is bit-identical to human_pass_rays' (per-sample arithmetic; tests/test_hip_march.py)."""
+    after every chunk that cut fewer than 2 % of the live rays, halved otherwise).  `dz` [R,S] (the hybrid renderers): the samples'
+    intervals in the list they will be MERGED into (merged_intervals) -- merging puts foreign samples inside the human intervals, which
+    shortens them and RAISES the transmittance, so the cut is decided on the product of the human factors over the merged intervals:
+    the merged list's transmittance can only be lower than that (the foreign samples' own factors are <= 1 + 1e-10), and what is skipped
+    weighs < eps in the composite.  Without `dz` (render_smpl_nerf: the list is composited alone) the list's own intervals.  Every
+    evaluated sample is bit-identical to human_pass_rays' (per-sample arithmetic; tests/test_hip_march.py)."""
     _lib.require_gpu()
     R, S = o.shape[0], int(samples_per_ray)
     dev = o.device
@@ -207,9 +236,7 @@ def human_march_rays(human_net, o, d, near, far, samples_per_ray, mesh, eps, sig
             continue
         idx = live.to(torch.int32)
         cnt = torch.tensor([idx.numel(), 0], device=dev, dtype=torch.int32)
-        _lib.check(_lib.lib().nm_transmittance_chunk(_lib.dev_ptr(raw), _lib.dev_ptr(z), _lib.dev_ptr(d), _lib.dev_ptr(idx, torch.int32),
-                                                     _lib.dev_ptr(cnt, torch.int32), R, s0 - c, c, S, _lib.dev_ptr(T), _lib.stream_ptr()),
-                   "nm_transmittance_chunk")
+        _transmittance_chunk(raw, z, dz, d, idx, cnt, R, s0 - c, c, S, T)
         n_live = live.numel()
         live = live[T[live] >= eps]
         # (march_pass_rays' rule: short chunks while rays are being cut, doubling when nothing happens)
@@ -259,9 +286,43 @@ def bkg_pass_rays_fused(coarse_net, fine_net, o, d, near, far, samples_per_ray, 
     return raw, z
 
 
+def bkg_place_z(coarse_net, fine_net, o, d, near, far, samples_per_ray, importance_samples_per_ray, white_bkg, precision=None, trace=None):
+    """Where the background list's FINAL samples are (render_utils.py:131-147, 287-293): the stratified samples, or -- with a fine net --
+    the coarse density pass, its compositing weights and the importance samples merged in.  -> (z [R,S'], raw of the coarse pass when it
+    is the pass that is composited [no fine net; evaluated here unless termination is on], else None)"""
+    _, _, z = ray_utils.sample_z(o, d, near, far, samples_per_ray)
+    if fine_net is None:
+        return z, (None if TERMINATION_EPS > 0 else coarse_net.forward_rays(o, d, z, precision=precision, role='shading'))
+    # with a fine net the coarse pass only places the importance samples (only its density is used, render_utils.py:139-141: the
+    # colour head is skipped) and is not the pass the mixed precision policy tags 'shading' (vanilla.Joiner._prec)
+    if TERMINATION_EPS > 0:
+        # marched at TERMINATION_COARSE on its own transmittance only (where the importance samples go must not depend on what the
+        # list is merged with later)
+        stats = {} if trace is not None else None
+        raw = march_pass_rays(coarse_net, o, d, z, TERMINATION_COARSE, precision=precision, role=None, stats=stats, sigma_only=True)
+        _note(trace, march_coarse=stats)
+    else:
+        raw = coarse_net.forward_rays(o, d, z, precision=precision, role=None, sigma_only=True)
+    _, _, _, w, _ = raw2outputs(raw, z, d, white_bkg=white_bkg)
+    _note(trace, coarse_z=z, coarse_w=w)
+    return ray_utils.importance_z(z, w, importance_samples_per_ray), None
+
+
+def bkg_shade(net, o, d, z, precision=None, trace=None, occluder=None, dz=None):
+    """The background pass that is composited, on its final samples (render_utils.py:148-151, 294-297): whole, or -- TERMINATION_EPS > 0 --
+    marched front to back at eps (`occluder`, `dz`: march_pass_rays)"""
+    if TERMINATION_EPS > 0:
+        stats = {} if trace is not None else None
+        raw = march_pass_rays(net, o, d, z, TERMINATION_EPS, precision=precision, stats=stats, occluder=occluder, dz=dz)
+        _note(trace, march=stats)
+        return raw
+    return net.forward_rays(o, d, z, precision=precision, role='shading')
+
+
 def bkg_pass_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, importance_samples_per_ray, white_bkg,
-                  precision=None, trace=None, given_z=None, occluder=None):
-    """Coarse (+ fine) background evaluation of R rays -> (raw [R,S',4], z [R,S'])  (render_utils.py:131-151, 287-297).
+                  precision=None, trace=None, given_z=None, occluder=None, dz=None):
+    """Coarse (+ fine) background evaluation of R rays -> (raw [R,S',4], z [R,S'])  (render_utils.py:131-151, 287-297):
+    bkg_place_z + bkg_shade.
 
     `given_z` [R, S'] (tests only, like `trace`): replay recorded final sample positions instead of deriving them -- the shading
     network is evaluated on exactly those.  The renderers pass it from their `given` dict ({'bkg_z': [R,S'], 'near_far':
@@ -269,36 +330,14 @@ def bkg_pass_rays(coarse_net, fine_net, o, d, near, far, samples_per_ray, import
     float32 -- the inverse CDF behind the importance samples and the cancellation under geometry_guided_near_far's square root
      -- are taken from a recording of the reference's own run, so that everything else can be held to 1e-4
     on every pixel against the reference's frames (tests/test_hip_posed_golden.py)."""
+    net = fine_net if fine_net is not None else coarse_net
     if given_z is not None:
         z = given_z.to(torch.float32).contiguous()
-        net = fine_net if fine_net is not None else coarse_net
         _note(trace, bkg_z=z)
         return net.forward_rays(o, d, z, precision=precision, role='shading'), z
-    _, _, z = ray_utils.sample_z(o, d, near, far, samples_per_ray)
-    # with a fine net the coarse pass only places the importance samples; otherwise it is the pass that is composited
-    # ('shading' role of the mixed precision policy, vanilla.Joiner._prec)
-    # (and only its density is used, render_utils.py:139-141: the colour head is skipped)
-    if TERMINATION_EPS > 0:
-        # marched: a coarse pass at TERMINATION_COARSE on its own transmittance only (where the importance samples go must not depend
-        # on what the list is merged with later); a pass that is composited at eps, `occluder` included (march_pass_rays)
-        stats = {} if trace is not None else None
-        raw = march_pass_rays(coarse_net, o, d, z, TERMINATION_COARSE if fine_net is not None else TERMINATION_EPS, precision=precision,
-                              role=None if fine_net is not None else 'shading', stats=stats, sigma_only=fine_net is not None,
-                              occluder=None if fine_net is not None else occluder)
-        _note(trace, **{'march_coarse' if fine_net is not None else 'march': stats})
-    else:
-        raw = coarse_net.forward_rays(o, d, z, precision=precision, role=None if fine_net is not None else 'shading',
-                                      sigma_only=fine_net is not None)
-    if fine_net is not None:
-        _, _, _, w, _ = raw2outputs(raw, z, d, white_bkg=white_bkg)
-        _note(trace, coarse_z=z, coarse_w=w)
-        z = ray_utils.importance_z(z, w, importance_samples_per_ray)
-        if TERMINATION_EPS > 0:
-            stats = {} if trace is not None else None
-            raw = march_pass_rays(fine_net, o, d, z, TERMINATION_EPS, precision=precision, stats=stats, occluder=occluder)
-            _note(trace, march=stats)
-        else:
-            raw = fine_net.forward_rays(o, d, z, precision=precision, role='shading')
+    z, raw = bkg_place_z(coarse_net, fine_net, o, d, near, far, samples_per_ray, importance_samples_per_ray, white_bkg, precision, trace)
+    if raw is None:
+        raw = bkg_shade(net, o, d, z, precision, trace, occluder, dz)
     _note(trace, bkg_z=z)
     return raw, z
 
@@ -396,8 +435,10 @@ def render_hybrid_rays(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far,
                        importance_samples_per_ray, white_bkg=True, geo_threshold=DEFAULT_GEO_THRESH, precision=None, trace=None,
                        given=None):
     """Device core of render_hybrid_nerf -> (rgb [R,3], depth [R], acc [R]) CUDA  (render_utils.py:276-356).  `given`: see bkg_pass_rays.
-    With TERMINATION_EPS > 0 the human pass runs first (marched on its own transmittance) and the background passes are marched on the
-    transmittance of the MERGED list where they can know it (behind the body: their own x the body's): a pixel moves by < 2 eps.
+    With TERMINATION_EPS > 0 the background's sample positions are settled first, then the human pass and the background shading pass
+    are marched, each on the transmittance its samples have in the MERGED list (merged_intervals: the body's factors over the merged
+    intervals bound the merged transmittance from above; behind the body the background sees its own x the body's): a pixel moves
+    by < 2 eps, for bodies of any opacity (tests/test_hip_march.py: opaque and semi-transparent).
     The plain case (no trace, no replay, no termination) is ONE C call per batch: render_hybrid_rays_fused, bit-identical."""
     if TERMINATION_EPS <= 0 and trace is None and given is None:
         return render_hybrid_rays_fused(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far, posed_verts, mesh, samples_per_ray,
@@ -412,7 +453,7 @@ def render_hybrid_rays(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far,
         f = torch.full((j - i,), float(bkg_far), device=o.device, dtype=torch.float32)
         given_z = given['bkg_z'][i:j] if given is not None and 'bkg_z' in given else None
 
-        def human_lists():
+        def human_lists(merge_z=None):
             near, far = _given_near_far(given, 0, i, j, oc, dc, posed_verts, geo_threshold)
             _note(trace, near=near, far=far)
             hit, _ = ray_utils.compact_hits(near, far)
@@ -423,27 +464,40 @@ def render_hybrid_rays(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far,
             _note(trace, hit=hit + i)
             if TERMINATION_EPS > 0:
                 mstats = {} if trace is not None else None
-                h_raw, h_z = human_march_rays(human_net, ho, hd, hn, hf, samples_per_ray, mesh, TERMINATION_EPS, 1.0, precision, None, trace, mstats)
+                dz_h = None
+                if merge_z is not None:                                                            # the intervals the body's samples have once merged
+                    _, _, h_z0 = ray_utils.sample_z(ho, hd, hn, hf, samples_per_ray)
+                    dz_h = merged_intervals([ray_utils.gather_rows(merge_z, hit), h_z0])[1]
+                h_raw, h_z = human_march_rays(human_net, ho, hd, hn, hf, samples_per_ray, mesh, TERMINATION_EPS, 1.0, precision, None, trace, mstats,
+                                              dz=dz_h)
                 _note(trace, march_human=mstats)
             else:
                 h_raw, h_z = human_pass_rays(human_net, ho, hd, hn, hf, samples_per_ray, mesh, False, 1.0, precision, trace)
             return hit, hd, hf, h_raw, h_z
 
-        occluder = None
-        if TERMINATION_EPS > 0:                                                                  # the body first: it may hide the background
-            hit, hd, hf, h_raw, h_z = human_lists()
+        if TERMINATION_EPS > 0 and given_z is None:
+            # sample positions first (they do not depend on the body), then the body -- it may hide the background -- then the
+            # background shading pass; both marched on the transmittance of the MERGED list (merged_intervals): a pixel moves < 2 eps
+            bkg_z, _ = bkg_place_z(coarse_bkg, fine_bkg, oc, dc, n, f, samples_per_ray, importance_samples_per_ray, white_bkg, precision, trace)
+            _note(trace, bkg_z=bkg_z)
+            dz_b = torch.cat([bkg_z[:, 1:] - bkg_z[:, :-1], torch.full_like(bkg_z[:, :1], 1e10)], 1)
+            hit, hd, hf, h_raw, h_z = human_lists(bkg_z)
+            occluder = None
             if hit.numel() > 0:
                 z_far = torch.full((j - i,), float('inf'), device=o.device, dtype=torch.float32)
                 T_occ = torch.ones(j - i, device=o.device, dtype=torch.float32)
+                dz_bh, dz_h = merged_intervals([ray_utils.gather_rows(bkg_z, hit), h_z])
+                ray_utils.scatter_rows(dz_b, hit, dz_bh)
                 ray_utils.scatter_rows(z_far, hit, hf.reshape(-1))
-                ray_utils.scatter_rows(T_occ, hit, transmittance_of(h_raw, h_z, hd))
+                ray_utils.scatter_rows(T_occ, hit, transmittance_of(h_raw, h_z, hd, dz_h))
                 occluder = (z_far, T_occ)
-        bkg_raw, bkg_z = bkg_pass_rays(coarse_bkg, fine_bkg, oc, dc, n, f, samples_per_ray, importance_samples_per_ray,
-                                       white_bkg, precision, trace, given_z, occluder)
+            bkg_raw = bkg_shade(fine_bkg if fine_bkg is not None else coarse_bkg, oc, dc, bkg_z, precision, trace, occluder, dz_b.contiguous())
+        else:
+            bkg_raw, bkg_z = bkg_pass_rays(coarse_bkg, fine_bkg, oc, dc, n, f, samples_per_ray, importance_samples_per_ray,
+                                           white_bkg, precision, trace, given_z)
+            hit, hd, hf, h_raw, h_z = human_lists()
         # every ray first gets the background-only composite (what the reference does for misses, :303-311) ...
         rgb[i:j], _, _, _, depth[i:j] = raw2outputs(bkg_raw, bkg_z, dc, white_bkg=white_bkg, want_weights=False)
-        if TERMINATION_EPS <= 0:
-            hit, hd, hf, h_raw, h_z = human_lists()
         if hit.numel() == 0:
             continue
         # ... and hit rays are overwritten by the merged human + background composite (:313-353)
@@ -471,10 +525,14 @@ def render_hybrid_rays_fused(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bk
     verts = posed_verts.to(dev, torch.float32).contiguous()
     t_vals = torch.linspace(0., 1., steps=S, device=dev)
     u = torch.linspace(0., 1., steps=N, device=dev) if N else None
-    for i, j in _chunks(R):
+    # the C call sizes its hit-ray buffers for every ray of the batch (it cannot read the hit count back without a host
+    # synchronisation): ~28 KB per ray at 128 + 128 + 128 samples, so batches of FUSED_HYBRID_RAYS rays (3.7 GB) and ONE workspace
+    step = min(MAX_RAYS_PER_LAUNCH, FUSED_HYBRID_RAYS)
+    ws = _ws(_lib.lib().nm_render_rays_hybrid_workspace_floats(min(R, step), S, N, Sh), dev)
+    for i in range(0, R, step):
+        j = min(i + step, R)
         oc, dc = o[i:j].contiguous(), d[i:j].contiguous()
         n = j - i
-        ws = _ws(_lib.lib().nm_render_rays_hybrid_workspace_floats(n, S, N, Sh), dev)
         r_, d_, a_ = rgb[i:j], depth[i:j], acc[i:j]
         _lib.check(_lib.lib().nm_render_rays_hybrid(
             coarse_bkg.handle(), fine_bkg.handle() if fine_bkg is not None else None, human_net.handle(), mesh.handle, _lib.dev_ptr(mesh.T, torch.float64, 'T'),
@@ -490,8 +548,9 @@ def render_multi_rays(coarse_bkg, fine_bkg, human_nets, o, d, bkg_near, bkg_far,
                       importance_samples_per_ray, white_bkg=True, geo_threshold=DEFAULT_GEO_THRESH, precision=None, trace=None,
                       given=None):
     """Device core of render_hybrid_nerf_multi_persons -> (rgb [R,3], depth [R]) CUDA  (render_utils.py:390-456).  `given`: see
-    bkg_pass_rays.  TERMINATION_EPS > 0: as render_hybrid_rays (the actors first, each marched on its own transmittance; the background
-    behind the farthest body a ray hits on its own x all the bodies'); a pixel moves by < (1 + actors) eps."""
+    bkg_pass_rays.  TERMINATION_EPS > 0: as render_hybrid_rays (sample positions of all lists, then the actors, then the background
+    shading pass, each marched on the transmittance of its samples over their intervals in the MERGED list; the background behind the
+    farthest body a ray hits on its own x all the bodies'); a pixel moves by < (1 + actors) eps."""
     R = o.shape[0]
     rgb = torch.empty((R, 3), device=o.device, dtype=torch.float32)
     depth = torch.empty(R, device=o.device, dtype=torch.float32)
@@ -502,35 +561,55 @@ def render_multi_rays(coarse_bkg, fine_bkg, human_nets, o, d, bkg_near, bkg_far,
         f = torch.full((nr,), float(bkg_far), device=o.device, dtype=torch.float32)
         far_z = torch.linspace(float(bkg_far) * 2, float(bkg_far) * 3, samples_per_ray, device=o.device)   # :418-419
 
-        def actor_lists(a_):
-            """one actor's list over all rays of the batch: its samples where it is hit, the zero-density placeholders elsewhere"""
-            net, verts, mesh = human_nets[a_], posed_verts[a_], meshes[a_]
-            near, far = _given_near_far(given, a_, i, j, oc, dc, verts, geo_threshold)
+        def actor_rays(a_):
+            """one actor's hit list and the z of its list over ALL rays of the batch: its samples where it is hit, the zero-density
+            placeholders elsewhere (render_utils.py:405-419)"""
+            near, far = _given_near_far(given, a_, i, j, oc, dc, posed_verts[a_], geo_threshold)
             _note(trace, near=near, far=far)
-            h_raw = torch.zeros((nr, samples_per_ray, 4), device=o.device, dtype=torch.float32)
             h_z = far_z[None].repeat(nr, 1).contiguous()
             hit, _ = ray_utils.compact_hits(near, far)
             _note(trace, hit=hit + i)
+            if hit.numel() == 0:
+                return hit, None, h_z
+            ho, hd = ray_utils.gather_rows(oc, hit), ray_utils.gather_rows(dc, hit)
+            hn, hf = ray_utils.gather_rows(near, hit), ray_utils.gather_rows(far, hit)
+            return hit, (ho, hd, hn, hf), h_z
+
+        def actor_lists(a_, rays=None, dz=None):
+            """the actor's list evaluated -> (h_z [nr,S], h_raw [nr,S,4], (hit, far, transmittance over `dz`) when marched)"""
+            hit, hr, h_z = rays if rays is not None else actor_rays(a_)
+            h_raw = torch.zeros((nr, samples_per_ray, 4), device=o.device, dtype=torch.float32)
             occ = None
             if hit.numel() > 0:
-                ho, hd = ray_utils.gather_rows(oc, hit), ray_utils.gather_rows(dc, hit)
-                hn, hf = ray_utils.gather_rows(near, hit), ray_utils.gather_rows(far, hit)
+                ho, hd, hn, hf = hr
                 if TERMINATION_EPS > 0:
                     mstats = {} if trace is not None else None
-                    r_, z_ = human_march_rays(net, ho, hd, hn, hf, samples_per_ray, mesh, TERMINATION_EPS, 1.0, precision, None, trace, mstats)
+                    dz_h = ray_utils.gather_rows(dz, hit) if dz is not None else None
+                    r_, z_ = human_march_rays(human_nets[a_], ho, hd, hn, hf, samples_per_ray, meshes[a_], TERMINATION_EPS, 1.0, precision, None, trace,
+                                              mstats, dz=dz_h)
                     _note(trace, march_human=mstats)
-                    occ = (hit, hf.reshape(-1), transmittance_of(r_, z_, hd))
+                    occ = (hit, hf.reshape(-1), transmittance_of(r_, z_, hd, dz_h))
                 else:
-                    r_, z_ = human_pass_rays(net, ho, hd, hn, hf, samples_per_ray, mesh, False, 1.0, precision, trace)
+                    r_, z_ = human_pass_rays(human_nets[a_], ho, hd, hn, hf, samples_per_ray, meshes[a_], False, 1.0, precision, trace)
                 ray_utils.scatter_rows(h_raw.reshape(nr, -1), hit, r_.reshape(hit.shape[0], -1))
                 ray_utils.scatter_rows(h_z, hit, z_)
             else:
                 _note(trace, human_z=None, can_pts=None, can_dirs=None)
             return h_z, h_raw, occ
 
-        lists, occluder = None, None
-        if TERMINATION_EPS > 0:                                                                  # the bodies first: they may hide the background
-            lists = [actor_lists(a_) for a_ in range(len(human_nets))]
+        lists = None
+        given_z = given['bkg_z'][i:j] if given is not None and 'bkg_z' in given else None
+        if TERMINATION_EPS > 0 and given_z is None:
+            # sample positions of every list first (none depends on another list's densities), then the bodies -- they may hide the
+            # background -- then the background shading pass, each marched on the transmittance its samples have in the MERGED list
+            z_all, _ = bkg_place_z(coarse_bkg, fine_bkg, oc, dc, n, f, samples_per_ray, importance_samples_per_ray, white_bkg, precision, trace)
+            _note(trace, bkg_z=z_all)
+            rays_l = [actor_rays(a_) for a_ in range(len(human_nets))]
+            for hit, hr, h_z in rays_l:                                                              # (z of the hit rows, as human_march_rays will sample them)
+                if hit.numel() > 0:
+                    ray_utils.scatter_rows(h_z, hit, ray_utils.sample_z(hr[0], hr[1], hr[2], hr[3], samples_per_ray)[2])
+            dz_l = merged_intervals([z_all] + [h_z for _, _, h_z in rays_l])
+            lists = [actor_lists(a_, rays_l[a_], dz_l[1 + a_]) for a_ in range(len(human_nets))]
             z_far = torch.full((nr,), float('-inf'), device=o.device, dtype=torch.float32)
             T_occ = torch.ones(nr, device=o.device, dtype=torch.float32)
             for _, _, occ in lists:
@@ -540,9 +619,10 @@ def render_multi_rays(coarse_bkg, fine_bkg, human_nets, o, d, bkg_near, bkg_far,
                     z_far[idx] = torch.maximum(z_far[idx], hf)
                     T_occ[idx] = T_occ[idx] * Th
             z_far = torch.where(torch.isinf(z_far), torch.full_like(z_far, float('inf')), z_far)  # rays that hit nobody: never
-            occluder = (z_far, T_occ)
-        raw_all, z_all = bkg_pass_rays(coarse_bkg, fine_bkg, oc, dc, n, f, samples_per_ray, importance_samples_per_ray,
-                                       white_bkg, precision, trace, given['bkg_z'][i:j] if given is not None and 'bkg_z' in given else None, occluder)
+            raw_all = bkg_shade(fine_bkg if fine_bkg is not None else coarse_bkg, oc, dc, z_all, precision, trace, (z_far, T_occ), dz_l[0])
+        else:
+            raw_all, z_all = bkg_pass_rays(coarse_bkg, fine_bkg, oc, dc, n, f, samples_per_ray, importance_samples_per_ray,
+                                           white_bkg, precision, trace, given_z)
         # In this renderer the terminal 1e10 interval sits on an actor's zero-density placeholder whenever a ray misses one
         # (render_utils.py:418-419), so the LAST background sample is followed by a finite interval of ~far..2 far instead:
         # alpha = 1 - exp(-sigma * 3.14..) is then ~300x as sensitive to that one sigma as a sample inside the ray is.  Under the
@@ -592,6 +672,15 @@ def _all_rays(cap, device):
         return (torch.from_numpy(o).to(device, torch.float32).contiguous(),
                 torch.from_numpy(d).to(device, torch.float32).contiguous())
     return ray_utils.shot_all_rays_dev(cap, device)
+
+
+def _frame(rays_fn, o, d):
+    """The frame's rays through `rays_fn` -> tuple of per-ray tensors: on this device alone, or -- under an initialised process
+    group (parallel.sharding_active) -- the rays of this rank's interleaved tiles only, with ONE gather assembling the frame on
+    rank 0 (None on the other ranks; parallel.render_frame_sharded)."""
+    if parallel.sharding_active():
+        return parallel.render_frame_sharded(rays_fn, o, d)
+    return rays_fn(o, d)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -669,8 +758,11 @@ def render_vanilla(coarse_net, cap, fine_net=None, rays_per_batch=32768, samples
                                          return_depth, device)
     with torch.no_grad():
         o, d = _all_rays(cap, device)
-        rgb, depth = render_vanilla_rays(coarse_net, fine_net, o, d, cap.near[near_far_source], cap.far[near_far_source],
-                                         samples_per_ray, importance_samples_per_ray, white_bkg)
+        out = _frame(lambda oo, dd: render_vanilla_rays(coarse_net, fine_net, oo, dd, cap.near[near_far_source], cap.far[near_far_source],
+                                                        samples_per_ray, importance_samples_per_ray, white_bkg), o, d)
+        if out is None:                                                                          # a rank other than 0 of a sharded render
+            return None
+        rgb, depth = out
         rgb = rgb.reshape(*cap.shape, -1).cpu().numpy()
         depth = depth.reshape(*cap.shape).cpu().numpy()
     return (rgb, depth) if return_depth else rgb
@@ -718,8 +810,11 @@ def render_smpl_nerf(net, cap, posed_verts, faces, Ts, rays_per_batch=32768, sam
         o, d = _pixel_rays(cap, device)
         verts = torch.as_tensor(np.ascontiguousarray(posed_verts, dtype=np.float32)).to(device)
         mesh = None if render_can else ray_utils.mesh_to_device(posed_verts, faces, Ts, device)
-        rgb, depth, acc = render_smpl_nerf_rays(net.coarse_human_net, o, d, verts, mesh, samples_per_ray, white_bkg, render_can,
-                                                geo_threshold, interval_comp)
+        out = _frame(lambda oo, dd: render_smpl_nerf_rays(net.coarse_human_net, oo, dd, verts, mesh, samples_per_ray, white_bkg, render_can,
+                                                          geo_threshold, interval_comp), o, d)
+        if out is None:
+            return None
+        rgb, depth, acc = out
         rgb = rgb.reshape(*cap.shape, -1).cpu().numpy()
         depth = depth.reshape(*cap.shape).cpu().numpy()
         acc = acc.reshape(*cap.shape).cpu().numpy()
@@ -740,9 +835,12 @@ def render_hybrid_nerf(net, cap, posed_verts, faces, Ts, rays_per_batch=32768, s
         o, d = _pixel_rays(cap, device)
         verts = torch.as_tensor(np.ascontiguousarray(posed_verts, dtype=np.float32)).to(device)
         mesh = ray_utils.mesh_to_device(posed_verts, faces, Ts, device)
-        rgb, depth, _ = render_hybrid_rays(net.coarse_bkg_net, net.fine_bkg_net, net.coarse_human_net, o, d, cap.near['bkg'],
-                                           cap.far['bkg'], verts, mesh, samples_per_ray, importance_samples_per_ray, white_bkg,
-                                           geo_threshold)
+        out = _frame(lambda oo, dd: render_hybrid_rays(net.coarse_bkg_net, net.fine_bkg_net, net.coarse_human_net, oo, dd, cap.near['bkg'],
+                                                       cap.far['bkg'], verts, mesh, samples_per_ray, importance_samples_per_ray, white_bkg,
+                                                       geo_threshold)[:2], o, d)
+        if out is None:
+            return None
+        rgb, depth = out
         rgb = rgb.reshape(*cap.shape, -1).cpu().numpy()
         depth = depth.reshape(*cap.shape).cpu().numpy()
     return (rgb, depth) if return_depth else rgb
@@ -757,9 +855,12 @@ def render_hybrid_nerf_multi_persons(bkg_model, cap, human_models, posed_verts, 
         o, d = _pixel_rays(cap, device)
         verts = [torch.as_tensor(np.ascontiguousarray(v, dtype=np.float32)).to(device) for v in posed_verts]
         meshes = [ray_utils.mesh_to_device(v, f, t, device) for v, f, t in zip(posed_verts, faces, Ts)]
-        rgb, depth = render_multi_rays(bkg_model.coarse_bkg_net, bkg_model.fine_bkg_net,
-                                       [m.coarse_human_net for m in human_models], o, d, cap.near['bkg'], cap.far['bkg'], verts,
-                                       meshes, samples_per_ray, importance_samples_per_ray, white_bkg, geo_threshold)
+        out = _frame(lambda oo, dd: render_multi_rays(bkg_model.coarse_bkg_net, bkg_model.fine_bkg_net,
+                                                      [m.coarse_human_net for m in human_models], oo, dd, cap.near['bkg'], cap.far['bkg'], verts,
+                                                      meshes, samples_per_ray, importance_samples_per_ray, white_bkg, geo_threshold), o, d)
+        if out is None:
+            return None
+        rgb, depth = out
         rgb = rgb.reshape(*cap.shape, -1).cpu().numpy()
         depth = depth.reshape(*cap.shape).cpu().numpy()
     return (rgb, depth) if return_depth else rgb

@@ -4,7 +4,10 @@
 * the RCCL gather collective on an initialised "nccl" group of ONE rank (render_sharded with force_collective), device tensors;
 * bench.py's exact timed step through that group (`--dist`);
 * two processes sharing the GPU, each rendering its own interleaved tiles on the device, frame assembled through gloo --
-  bit-identical to the unsharded frame.
+  bit-identical to the unsharded frame;
+* the four reference-named frame drivers (render_vanilla, render_smpl_nerf, render_hybrid_nerf = BASELINE config 4,
+  render_hybrid_nerf_multi_persons = config 5) called under a process group: both ways above, bit-identical frames on rank 0,
+  None on the other rank.
 """
 import json
 import os
@@ -84,3 +87,55 @@ def test_bench_self_launch_paths_on_a_one_gpu_box():
     mg = last_json(r.stdout)["multi_gpu"]
     print(mg)
     assert mg["rccl_world"] == 1 and mg["backend"] == "nccl" and mg["rays_per_rank"] == [640000] and mg["frame_assembly_ms_per_rank"][0] > 0
+
+
+DRIVERS = ("render_vanilla", "render_smpl_nerf", "render_hybrid_nerf", "render_hybrid_nerf_multi_persons")
+
+
+def test_frame_drivers_shard_through_rccl_on_a_group_of_one_rank():
+    """BASELINE configs 4 / 5 'ray-batch sharded ... with RCCL gather': the drivers themselves shard when a process group exists
+    (render_utils._frame -> parallel.render_frame_sharded).  One rank, real RCCL gather, device tensors."""
+    env = env_for(0, 1, free_port())
+    env["NEUMAN_FORCE_COLLECTIVE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(HERE, "helpers", "dist_drivers_check.py"), "nccl"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = last_json(r.stdout)
+    print(out)
+    for k in DRIVERS:
+        assert out[k]["bit_identical"] and out[k]["finite"], (k, out[k])
+    assert 0.02 < out["render_hybrid_nerf"]["hit_fraction"] < 0.9
+
+
+def test_frame_drivers_shard_across_two_ranks_sharing_the_gpu():
+    """two ranks, each rendering the rays of its interleaved tiles through the SAME driver call (hit compaction, the hybrid C call and
+    the three-actor merge all see half a frame), gloo assembly: the hybrid and the three-actor frames are bit-identical to the
+    unsharded ones"""
+    port = free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "helpers", "dist_drivers_check.py"), "gloo"], env=env_for(r, 2, port),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    out = last_json(outs[0][0])
+    print(out)
+    assert out["world"] == 2
+    for k in DRIVERS:
+        assert out[k]["bit_identical"] and out[k]["finite"], (k, out[k])
+        assert sum(out[k]["rays_per_rank"]) == out["rays"] and len(out[k]["rays_per_rank"]) == 2
+
+
+def test_interleaved_tiles_balance_the_hit_rays_at_world_8():
+    """hit rays cluster in the image centre, so tiles are interleaved.  For the C4 (1280x720, one body) and C5 (1920x1080,
+    three bodies) cameras the per-rank count of hit rays (x actors) at world 8 is within 5 % of the mean with the frame renderers'
+    tile (parallel.FRAME_TILE); one device computes every rank's list (tools/bench_configs.py --imbalance)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_configs.py"), "--imbalance"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 3
+    for ln in lines:
+        msg = {k: round(v["hit_ray_imbalance"], 4) for k, v in ln.items() if isinstance(v, dict)}
+        print(ln["config"], "hit fraction", round(ln["hit_fraction"], 3), msg)
+        for w in (2, 4, 8):
+            assert ln[f"world{w}_frame_tile"]["hit_ray_imbalance"] <= 0.05, (ln["config"], w, ln[f"world{w}_frame_tile"])
+            assert sum(ln[f"world{w}_frame_tile"]["rays_per_rank"]) == ln["rays"]
