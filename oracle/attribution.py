@@ -86,10 +86,14 @@ def two_pass(rgb_dev, z_dev, w_dev, rgb_dev_on_oracle_z, rgb_ora, z_ora, w_ora, 
     # (d)
     floor = _profile("r03_parity_floor.json").get(case, {}).get("oracle_vs_reference_rays_gt_1e-4") if case else None
     cap = int(np.floor(1.5 * floor + 0.5)) if floor is not None else int(np.ceil(1.5 * FLOOR_RATE * R))
+    measured = _profile("r04_parity_gates.json").get(case, {}).get("device_vs_oracle_rays_gt_1e-4") if case else None
+    if measured is not None:                                       # what the device measured last round, + 3: a doubling does not pass
+        cap = min(cap, int(measured) + 3)
     rep["d_floor_oracle_vs_reference"] = floor if floor is not None else f"{FLOOR_RATE:.4f} x rays"
+    rep["d_measured_last_round"] = measured
     rep["d_allowed_rays_gt_1e-4"] = cap
     if bad.sum() > cap:
-        fails.append(f"(d) {bad.sum()} rays beyond 1e-4 > 1.5 x floor = {cap}")
+        fails.append(f"(d) {bad.sum()} rays beyond 1e-4 > min(1.5 x floor, last round's count + 3) = {cap}")
     if tag:
         print(f"[{tag}] " + ", ".join(f"{k}={v:.2e}" if isinstance(v, float) else f"{k}={v}" for k, v in rep.items()))
     return rep, fails

@@ -51,7 +51,11 @@ from cameras.captures import BasePinholeCapture  # noqa: E402
 
 from neuman_hip import synthetic, vanilla as our_vanilla  # noqa: E402  (ours: workload definitions and initial weights only)
 
-OPT = dict(samples_per_ray=24, importance_samples_per_ray=24, perturb=0.0, white_bkg=True, penalize_smpl_alpha=1.0,
+FULL = '--full' in sys.argv     # the trainer's real sizes: 128 + 128 background and 128 human samples (the merged 384-sample list of
+#                                 human_nerf_trainer.py:415-428) on 512 rays -> human_loss_full.npz; default: 24 + 24 / 24 on 256 rays -> human_loss.npz
+N_RAYS = 512 if FULL else 256
+OUT_NAME = 'human_loss_full.npz' if FULL else 'human_loss.npz'
+OPT = dict(samples_per_ray=128 if FULL else 24, importance_samples_per_ray=128 if FULL else 24, perturb=0.0, white_bkg=True, penalize_smpl_alpha=1.0,
            penalize_symmetric_alpha=0.1, penalize_dummy=1.0, penalize_hard_surface=0.1, penalize_color_range=0.1, penalize_mask=0.01,
            penalize_lpips=0.0, penalize_sharp_edge=0.1, penalize_outside_factor=2.0, dist_exponent=2.0)
 INTERVAL_COMP = 0.8
@@ -129,15 +133,15 @@ def main():
     cap = ref_cap(48, 48, 110., synthetic.spherical_c2w(15., -5., 3.0), 0.5, 5.0)
     out['cam_c2w'] = cap.cam_pose.camera_to_world
     coords = np.argwhere(np.ones(cap.shape))[:, ::-1]
-    coords = coords[np.random.default_rng(1).choice(len(coords), 256, replace=False)]
+    coords = coords[np.random.default_rng(1).choice(len(coords), N_RAYS, replace=False)]
     o, d = R_ray.shot_rays(cap, coords)
     o, d = torch.from_numpy(o).float(), torch.from_numpy(d).float()
     near, far = R_ray.geometry_guided_near_far(o, d, world[0], 0.2)
     hit = near < far
     near = torch.where(hit, near, torch.full_like(near, 2.0))
     far = torch.where(hit, far, torch.full_like(far, 3.0))
-    color = torch.rand((256, 3), generator=torch.Generator().manual_seed(5))
-    batch = {'origin': o, 'direction': d, 'bkg_near': torch.full((256, 1), 0.5), 'bkg_far': torch.full((256, 1), 5.0), 'human_near': near[:, None].contiguous(),
+    color = torch.rand((N_RAYS, 3), generator=torch.Generator().manual_seed(5))
+    batch = {'origin': o, 'direction': d, 'bkg_near': torch.full((N_RAYS, 1), 0.5), 'bkg_far': torch.full((N_RAYS, 1), 5.0), 'human_near': near[:, None].contiguous(),
              'human_far': far[:, None].contiguous(), 'is_hit': hit, 'is_bkg': (~hit).long(), 'color': color, 'cur_view_f': torch.tensor(0.35),
              'cap_id': torch.tensor(1), 'patch_counter': torch.tensor(0)}
     out.update({'batch_' + k: v.numpy() for k, v in batch.items()})
@@ -227,8 +231,9 @@ def main():
         dev = float((p_.grad - g0[k]).abs().max() / g0[k].abs().max())
         out['grad_floor_' + k] = np.array(dev)
         print(f"grad floor {k:32s} {dev:.3e}   (poses + 1e-6)")
-    np.savez_compressed(os.path.join(HERE, 'human_loss.npz'), **out)
-    print('human_loss.npz', os.path.getsize(os.path.join(HERE, 'human_loss.npz')) // 1024, 'KiB')
+    out['opt_samples'] = np.array([OPT['samples_per_ray'], OPT['importance_samples_per_ray']])
+    np.savez_compressed(os.path.join(HERE, OUT_NAME), **out)
+    print(OUT_NAME, os.path.getsize(os.path.join(HERE, OUT_NAME)) // 1024, 'KiB')
 
 
 if __name__ == '__main__':

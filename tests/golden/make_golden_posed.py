@@ -1,6 +1,12 @@
 """Goldens for everything BEHIND THE WARP, produced by the reference's own code (run in the build container only):
 
     python tests/golden/make_golden_posed.py          ->  tests/golden/posed.npz
+    python tests/golden/make_golden_posed.py --big    ->  tests/golden/posed_big.npz   (the posed and the hybrid frame again at 64 x 64 =
+                                                          4096 rays each, so that the conditional statements cover a whole frame of
+                                                          hit rays instead of a 320-ray band; the background's fine sample positions are
+                                                          stored as the 128 importance samples per ray -- what sample_pdf returned --
+                                                          and the generator checks that merging them into the stratified samples
+                                                          reproduces what ray_to_importance_samples returned, bit for bit)
 
 The reference (apple/ml-neuman) is imported unmodified.  `igl` -- the one absent wheel these functions do call -- is
 tests/golden/igl_shim.py (the three libigl entry points with igl 2.2.1's return conventions, arithmetic from oracle/warp.py);
@@ -64,7 +70,7 @@ def ref_net(seed, mapping):
     return net.eval()
 
 
-def ref_cap(fx, near, far):
+def ref_cap(fx, near, far, W=W, H=H):
     cap = BasePinholeCapture(PinholeCamera(W, H, fx, fx, W / 2, H / 2), CameraPose.from_camera_to_world(synthetic.spherical_c2w(20., -10., 3.0)))
     cap.near, cap.far = {'bkg': near}, {'bkg': far}
     return cap
@@ -168,5 +174,52 @@ def main():
     print('posed.npz', os.path.getsize(os.path.join(HERE, 'posed.npz')) // 1024, 'KiB')
 
 
+def main_big():
+    """the posed and the hybrid frame at 64 x 64 (same camera pose and field of view as the 40 x 32 frames)"""
+    torch.set_num_threads(os.cpu_count() or 1)
+    WB, HB, FX = 64, 64, 160.0
+    out = {'big_wh': np.array([WB, HB]), 'big_fx': np.array(FX)}
+    posed, faces, T = body()
+    net = Scene(ref_net(0, 'posenc'), ref_net(1, 'posenc'), ref_net(2, 'rotate'))
+    z_full, z_new, z_old, near_far = [], [], [], []
+    orig_imp, orig_pdf, orig_nf = R_ray.ray_to_importance_samples, R_ray.sample_pdf, R_ray.geometry_guided_near_far
+
+    def rec_imp(ray_batch, z_vals, *a, **k):
+        z_old.append(z_vals.detach().cpu().numpy().copy())
+        r = orig_imp(ray_batch, z_vals, *a, **k)
+        z_full.append(r[2].detach().cpu().numpy().copy())
+        return r
+
+    def rec_pdf(*a, **k):
+        r = orig_pdf(*a, **k)
+        z_new.append(r.detach().cpu().numpy().copy())
+        return r
+
+    def rec_nf(*a, **k):
+        n, f = orig_nf(*a, **k)
+        near_far.append((np.array(n, dtype=np.float32), np.array(f, dtype=np.float32)))
+        return n, f
+    R_ray.ray_to_importance_samples, R_ray.sample_pdf, R_ray.geometry_guided_near_far = rec_imp, rec_pdf, rec_nf
+    cap = ref_cap(FX, 0.5, 4.0, WB, HB)
+    out['cam_c2w'] = cap.cam_pose.camera_to_world
+    t0 = time.time()
+    rgb, depth, acc = R_render.render_smpl_nerf(net, cap, posed, faces, T, rays_per_batch=1024, samples_per_ray=128, white_bkg=True,
+                                                render_can=False, geo_threshold=0.2, return_depth=True, return_mask=True)
+    out.update(posed_rgb=rgb, posed_depth=depth, posed_acc=acc, posed_near=np.concatenate([c[0] for c in near_far]),
+               posed_far=np.concatenate([c[1] for c in near_far]))
+    print(f"render_smpl_nerf(render_can=False) 128, {WB} x {HB}: {time.time() - t0:.1f} s, hit pixels {(acc > 0).sum()} of {acc.size}")
+    near_far.clear()
+    t0 = time.time()
+    rgb, depth = R_render.render_hybrid_nerf(net, cap, posed, faces, T, rays_per_batch=1024, samples_per_ray=128, importance_samples_per_ray=128,
+                                             white_bkg=True, geo_threshold=0.2, return_depth=True)
+    zf, zn, zo = np.concatenate(z_full), np.concatenate(z_new), np.concatenate(z_old)
+    assert np.array_equal(np.sort(np.concatenate([zo, zn], -1), -1), zf), "stratified + importance samples do not reproduce the recorded list"
+    out.update(hybrid_near_far=np.array([0.5, 4.0]), hybrid_rgb=rgb, hybrid_depth=depth, hybrid_z_samples=zn,
+               hybrid_near=np.concatenate([c[0] for c in near_far]), hybrid_far=np.concatenate([c[1] for c in near_far]))
+    print(f"render_hybrid_nerf 128+128 / 128, {WB} x {HB}: {time.time() - t0:.1f} s")
+    np.savez_compressed(os.path.join(HERE, 'posed_big.npz'), **out)
+    print('posed_big.npz', os.path.getsize(os.path.join(HERE, 'posed_big.npz')) // 1024, 'KiB')
+
+
 if __name__ == '__main__':
-    main()
+    main_big() if '--big' in sys.argv else main()

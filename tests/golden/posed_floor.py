@@ -2,7 +2,7 @@
 oracle (oracle/render.py) and the reference's own run (the goldens) -- sit from each other on the same frames with nothing
 replayed.  Prints, per frame, the number of rays beyond 1e-4; tests/test_hip_posed_golden.py holds the device to 1.5 x these.
 
-    python tests/golden/posed_floor.py            (CPU, ~4 min; needs nothing but this repo)
+    python tests/golden/posed_floor.py [--big]    (CPU, ~4 min; needs nothing but this repo; --big: the 64 x 64 frames of posed_big.npz)
 """
 import json
 import os
@@ -17,6 +17,21 @@ sys.path.insert(0, os.path.join(ROOT, "ml-neuman_amd"))
 from oracle import render  # noqa: E402
 sys.path.insert(0, os.path.join(ROOT, "tests", "helpers"))
 import posed_scene as PS  # noqa: E402
+
+
+def main_big():
+    S = PS.load_big()
+    nets = PS.oracle_nets()
+    out = {}
+    c = PS.cap_big(S)
+    rgb = render.render_smpl_nerf(nets[2], c, S['posed_verts'], S['faces'], S['T'], rays_per_batch=1024, samples_per_ray=128)
+    e = np.abs(rgb - S['posed_rgb']).max(-1)
+    out['posed_big'] = {'rays_gt_1e-4': int((e > 1e-4).sum()), 'linf': float(e.max()), 'hit_rays': int((S['posed_near'] < S['posed_far']).sum())}
+    rgb = render.render_hybrid_nerf(nets[0], nets[1], nets[2], c, S['posed_verts'], S['faces'], S['T'], rays_per_batch=1024, samples_per_ray=128,
+                                    importance_samples_per_ray=128)
+    e = np.abs(rgb - S['hybrid_rgb']).max(-1)
+    out['hybrid_big'] = {'rays_gt_1e-4': int((e > 1e-4).sum()), 'linf': float(e.max()), 'rays': int(e.size)}
+    print(json.dumps(out))
 
 
 def main():
@@ -41,4 +56,4 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    main_big() if '--big' in sys.argv else main()

@@ -10,6 +10,7 @@ from oracle import ray_ops as O
 from oracle.nerf_mlp import JoinerSpec
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "golden", "posed.npz")
+GOLDEN_BIG = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "golden", "posed_big.npz")
 W, H = 40, 32
 
 
@@ -25,6 +26,28 @@ def load():
         t[:, :3, 3] += s
         g['T_l'].append(t)
     return g
+
+
+def load_big():
+    """tests/golden/posed_big.npz (make_golden_posed.py --big): the reference's posed and hybrid frames at 64 x 64 = 4096 rays.  The
+    background's final sample positions are rebuilt from the recorded importance samples: sort(cat(stratified z, sample_pdf's z)) --
+    what ray_to_importance_samples returned, bit for bit (asserted by the generator)."""
+    g = dict(np.load(GOLDEN_BIG))
+    verts_c, faces = synthetic.capsule_mesh()
+    posed, T = synthetic.twist_transforms(verts_c)
+    g['posed_verts'], g['faces'], g['T'] = posed, faces, T
+    g['W'], g['H'] = int(g['big_wh'][0]), int(g['big_wh'][1])
+    R = g['W'] * g['H']
+    near, far = (float(x) for x in g['hybrid_near_far'])
+    zero = np.zeros((R, 3), np.float32)
+    z_c = O.ray_to_samples(zero, zero, np.full((R, 1), near, np.float32), np.full((R, 1), far, np.float32), 128)[2]
+    g['hybrid_bkg_z'] = np.sort(np.concatenate([z_c, g['hybrid_z_samples']], -1), -1)
+    return g
+
+
+def cap_big(g):
+    near, far = (float(x) for x in g['hybrid_near_far'])
+    return synthetic.SimpleCapture(g['W'], g['H'], fx=float(g['big_fx']), c2w=g['cam_c2w'], near=near, far=far)
 
 
 def oracle_nets():

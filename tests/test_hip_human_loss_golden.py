@@ -17,13 +17,24 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "human_loss.npz")
+GOLDEN = {"small": os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "human_loss.npz"),
+          # make_golden_human_loss.py --full: the trainer's real sizes -- 512 rays, 128 + 128 background and 128 human samples, the
+          # merged 384-sample list of trainers/human_nerf_trainer.py:415-428
+          "full": os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "human_loss_full.npz")}
 
 
-@pytest.fixture(scope="module")
-def S():
+SUMMARY = {}               # the numbers of the last run, for __graft_entry__.smoke()'s parity lines
+
+
+@pytest.fixture(scope="module", params=["small", "full"])
+def S(request):
+    return build_scene(request.param)
+
+
+def build_scene(size):
     from neuman_hip import human_nerf, human_trainer, synthetic, vanilla
-    g = dict(np.load(GOLDEN))
+    g = dict(np.load(GOLDEN[size]))
+    n_s, n_i = (int(x) for x in g['opt_samples']) if 'opt_samples' in g else (24, 24)
     dev = torch.device('cuda')
     opt = synthetic.default_opt(use_cuda=True, num_offset_nets=1, offset_scale=0.05, offset_scale_type='linear', posenc='posenc')
     pose, betas, align = synthetic.smpl_like_frames(3, 0)
@@ -44,14 +55,14 @@ def S():
     faces = model['f'].astype(np.int32)
     batch = {k[6:]: torch.as_tensor(v).to(dev) for k, v in g.items() if k.startswith('batch_')}
     batch['cap_id'], batch['cur_view_f'], batch['patch_counter'] = int(g['batch_cap_id']), float(g['batch_cur_view_f']), int(g['batch_patch_counter'])
-    opt_l = types.SimpleNamespace(samples_per_ray=24, importance_samples_per_ray=24, perturb=0.0, white_bkg=True, penalize_smpl_alpha=1.0,
+    opt_l = types.SimpleNamespace(samples_per_ray=n_s, importance_samples_per_ray=n_i, perturb=0.0, white_bkg=True, penalize_smpl_alpha=1.0,
                                   penalize_symmetric_alpha=0.1, penalize_dummy=1.0, penalize_hard_surface=0.1, penalize_color_range=0.1, penalize_mask=0.01,
                                   penalize_lpips=0.0, penalize_sharp_edge=0.1, penalize_outside_factor=2.0, dist_exponent=2.0)
     can_caps = [synthetic.SimpleCapture(32, 32, fx=40., c2w=c) for c in g['can_c2w']]
     loss = human_trainer.HumanNeRFLoss(opt_l, net, faces, (g['can_verts'], faces), can_caps, interval_comp=0.8)
     loss.replay = {'offset_net': int(g['offset_net_choice']), 'dummy_dirs_randn': g['dummy_dirs_randn'], 'dummy_pts_rand': g['dummy_pts_rand'],
                    'can_cap': int(g['can_cap_choice']), 'can_pixel_choice': g['can_pixel_choice']}
-    return types.SimpleNamespace(g=g, net=net, loss=loss, batch=batch)
+    return types.SimpleNamespace(g=g, net=net, loss=loss, batch=batch, size=size, samples=(n_s, n_i))
 
 
 def test_the_batch_is_the_references(S):
@@ -71,7 +82,7 @@ def test_loss_terms_and_gradients_vs_the_references_autograd(S):
     ld, rgb = S.loss.loss_func(S.batch, return_rgb=True)
     vals = {k: float(v.detach()) for k, v in ld.items()}
     ref = {k: float(S.g['loss_' + k]) for k in vals}
-    print("[human loss] " + "  ".join(f"{k} {vals[k]:.6e} (ref {ref[k]:.6e})" for k in vals))
+    print(f"[human loss {S.size}: {S.g['batch_origin'].shape[0]} rays, {S.samples[0]} + {S.samples[1]} / {S.samples[0]} samples] " + "  ".join(f"{k} {vals[k]:.6e} (ref {ref[k]:.6e})" for k in vals))
     # measured (r03, MI355X): see the printed line; tolerances <= 10 x measured
     tol = {'fine_rgb_loss': 2e-4, 'lpips_loss': 0.0, 'color_range_reg': 2e-5, 'smpl_sym_reg': 2e-5, 'smpl_shape_reg': 2e-5, 'mask_loss': 1e-6, 'sparsity_reg': 2e-5}
     for k in vals:
@@ -93,6 +104,11 @@ def test_loss_terms_and_gradients_vs_the_references_autograd(S):
         cos[k] = float((d * r).sum() / np.sqrt((d * d).sum() * (r * r).sum()))
     print("[human loss] gradient deviation relative to each tensor's largest entry (the reference's own float32 floor: its gradient after moving the poses by 1e-6): "
           + "  ".join(f"{k} {v:.2e} ({float(S.g['grad_floor_' + k]):.1e}, cos {cos[k]:.4f})" for k, v in worst.items()))
+    rel = {k: abs(vals[k] - ref[k]) / max(1.0, abs(ref[k])) for k in vals}
+    net_g = {k: v for k, v in worst.items() if k not in ("poses", "betas", "alignments")}
+    SUMMARY[S.size] = {'rays': int(S.g['batch_origin'].shape[0]), 'samples': list(S.samples), 'worst_term': max(rel, key=rel.get), 'worst_term_dev': float(max(rel.values())),
+                       'worst_network_grad': max(net_g, key=net_g.get), 'worst_network_grad_dev': float(max(net_g.values())),
+                       'smpl_grad_dev': {k: worst[k] for k in ("poses", "betas", "alignments")}, 'rgb_hit_median': float(np.median(e[hit]))}
     assert np.median(e[hit]) < 5e-5 and (e[hit] > 1e-4).mean() < 0.05
     # The gradients of the SMPL parameters are NOT well defined in float32: the reference's own autograd result moves by 7 % / 10 % / 7 %
     # (poses / betas / alignments) when the poses move by 1e-6 (tests/golden/make_golden_human_loss.py stores that floor) -- they run

@@ -27,21 +27,47 @@ import posed_scene as PS  # noqa: E402
 pytestmark = pytest.mark.gpu
 # frame-wide floors: rays beyond 1e-4 between the oracle and the reference's frames (printed by tests/golden/posed_floor.py)
 FLOOR = {'posed': 11, 'hybrid': 47, 'multi': 57}
+FLOOR_BIG = {'posed': 29, 'hybrid': 105}          # tests/golden/posed_floor.py --big
+# end-to-end caps: min(1.5 x floor, what the device measured + 5) -- small frames measured in round 3: hybrid 43, multi 55
+E2E_CAP = {'small': {'posed': int(1.5 * 11 + 0.5), 'hybrid': 48, 'multi': 60}, 'big': {'posed': 44, 'hybrid': 158}}
+TIE_CAP = {'small': 4, 'big': 12}
 
 
 def cu(x, dt=torch.float32):
     return torch.as_tensor(np.ascontiguousarray(x)).to('cuda', dt).contiguous()
 
 
+SUMMARY = {}               # the numbers of the last run of each check, for __graft_entry__.smoke()'s parity lines
+
+
 @pytest.fixture(scope="module")
 def S(nets):
+    return build_scene({k: j for k, (j, sd, spec) in nets.items()})
+
+
+def build_scene(joiners, with_big=True):
+    """{seed: Joiner (0, 1: background coarse / fine, 2: human)} -> the scene of tests/golden/posed.npz (and posed_big.npz) on the device"""
     from neuman_hip import ray_utils, render_utils
     g = PS.load()
     g['R'], g['ray'] = render_utils, ray_utils
-    g['dev_nets'] = {k: j.cuda() for k, (j, sd, spec) in nets.items()}
+    g['dev_nets'] = {k: j.cuda() for k, j in joiners.items()}
     g['mesh'] = ray_utils.mesh_to_device(g['posed_verts'], np.ascontiguousarray(g['faces'][:, :3], np.int32), g['T'], 'cuda')
     g['meshes'] = [ray_utils.mesh_to_device(v, np.ascontiguousarray(g['faces'][:, :3], np.int32), t, 'cuda') for v, t in zip(g['posed_l'], g['T_l'])]
+    g['nrays'] = PS.W * PS.H
+    if with_big:
+        b = PS.load_big()                                         # the same body and nets on 64 x 64 frames (tests/golden/posed_big.npz)
+        for k in ('R', 'ray', 'dev_nets', 'mesh'):
+            b[k] = g[k]
+        b['nrays'] = b['W'] * b['H']
+        g['big'] = b
     return g
+
+
+def pick(S, size):
+    """the 40 x 32 goldens with their 320-ray bands, or the 64 x 64 ones with the WHOLE frame as the band"""
+    if size == 'small':
+        return S, None
+    return S['big'], (0, S['big']['nrays'])
 
 
 def test_warp_vs_the_references_own_warp(S):
@@ -60,6 +86,8 @@ def test_warp_vs_the_references_own_warp(S):
     e_dir = np.abs(cd - S['warp_can_dirs'])[pair].max()
     print(f"[warp vs reference] distance Linf {np.abs(dist - r_dist).max():.2e}; same foot on {same.mean() * 100:.2f} % of {same.size} samples: can_pts {e[0]:.2e}, "
           f"can_dirs {e_dir:.2e} there; overall can_pts {np.abs(cp - S['warp_can_pts']).max():.2e}, closest {np.abs(cl - S['warp_closest']).max():.2e}")
+    SUMMARY['warp'] = {'distance_linf': float(np.abs(dist - r_dist).max()), 'same_foot_pct': float(same.mean() * 100), 'can_pts_same_foot': float(e[0]),
+                       'samples': int(same.size)}
     assert np.abs(dist - r_dist).max() < 2e-6 and same.mean() > 0.99
     assert e[0] < 1e-5 and e_dir < 2e-3 and np.abs(cp - S['warp_can_pts']).max() < 5e-4
 
@@ -91,8 +119,11 @@ def foot_jump_rays(trace, k, o, d, verts, faces, T, band):
     return rays[dev > FOOT_TOL]
 
 
-def test_posed_human_frame(S):
-    c = PS.cap(S, 'posed')
+@pytest.mark.parametrize("size", ["small", "big"])
+def test_posed_human_frame(S, size):
+    S, whole = pick(S, size)
+    NR = S['nrays']
+    c = PS.cap(S, 'posed') if size == 'small' else PS.cap_big(S)
     o, d = PS.frame_rays(c)
     net = S['dev_nets'][2]
     ref = S['posed_rgb'].reshape(-1, 3)
@@ -102,17 +133,18 @@ def test_posed_human_frame(S):
     e = np.abs(rgb.cpu().numpy() - ref).max(-1)
     ea, ed = np.abs(acc.cpu().numpy() - S['posed_acc'].ravel()), np.abs(depth.cpu().numpy() - S['posed_depth'].ravel())
     hit = S['posed_near'] < S['posed_far']
-    a, b = BAND
-    jump = foot_jump_rays(trc, 0, o, d, S['posed_verts'], S['faces'], S['T'], BAND)
-    ok = np.ones(1280, bool)
+    a, b = whole or BAND
+    jump = foot_jump_rays(trc, 0, o, d, S['posed_verts'], S['faces'], S['T'], (a, b))
+    ok = np.ones(NR, bool)
     ok[jump] = False
-    band = np.zeros(1280, bool)
+    band = np.zeros(NR, bool)
     band[a:b] = True
-    print(f"[posed 128, conditional on the reference's near / far] rays {a}..{b} ({(hit & band).sum()} hit): {jump.size} ray(s) with a sample whose foot is on "
+    print(f"[posed 128 {size}, conditional on the reference's near / far] rays {a}..{b} ({(hit & band).sum()} hit): {jump.size} ray(s) with a sample whose foot is on "
           f"another face (Linf there {e[jump].max() if jump.size else 0:.2e}); every other ray: rgb Linf {e[band & ok].max():.2e}, acc {ea[band & ok].max():.2e}, "
           f"depth {ed[band & ok].max():.2e}; whole frame: rays > 1e-4 {(e > 1e-4).sum()} of {hit.sum()} hit, acc Linf {ea.max():.2e}")
+    SUMMARY['posed_' + size] = {'rays': int(band.sum()), 'hit': int((hit & band).sum()), 'cond_linf': float(e[band & ok].max()), 'foot_jump_rays': int(jump.size)}
     assert e[band & ok].max() < 1e-4 and ea[band & ok].max() < 1e-4 and ed[band & ok].max() < 2e-4
-    assert jump.size <= 0.1 * (hit & band).sum() and ea.max() < 1e-4
+    assert jump.size <= 0.05 * (hit & band).sum() and ea.max() < 1e-4          # measured: 6 of 275 (2.2 %) on the band
     # the device's own near / far and the end-to-end frame
     tr = {}
     rgb, depth, acc = S['R'].render_smpl_nerf_rays(net, cu(o), cu(d), cu(S['posed_verts']), S['mesh'], 128, True, False, 0.2, 1.0, trace=tr)
@@ -123,12 +155,13 @@ def test_posed_human_frame(S):
     e2 = np.abs(rgb.cpu().numpy() - ref).max(-1)
     bad = (e2 > 1e-4) & both
     dnf = np.maximum(np.abs(n - S['posed_near']), np.abs(f - S['posed_far']))
-    print(f"[posed near / far] device vs the reference's torch branch on {both.sum()} hit rays: near 99 % {np.percentile(dn, 99):.1e} max {dn.max():.1e}, "
+    print(f"[posed near / far {size}] device vs the reference's torch branch on {both.sum()} hit rays: near 99 % {np.percentile(dn, 99):.1e} max {dn.max():.1e}, "
           f"far 99 % {np.percentile(df, 99):.1e} max {df.max():.1e}, hit / miss flips {flips}")
-    print(f"[posed end to end] rays > 1e-4: {bad.sum()} of {both.sum()} hit rays (Linf {e2[both].max():.2e}); their near / far displacement: min {dnf[bad].min() if bad.any() else 0:.1e}; "
+    print(f"[posed end to end {size}] rays > 1e-4: {bad.sum()} of {both.sum()} hit rays (Linf {e2[both].max():.2e}); their near / far displacement: min {dnf[bad].min() if bad.any() else 0:.1e}; "
           f"Linf over rays displaced < 2e-6: {e2[both & (dnf < 2e-6)].max() if (both & (dnf < 2e-6)).any() else 0:.2e} ({(both & (dnf < 2e-6)).sum()} rays)")
     assert np.percentile(dn, 99) < 1e-4 and np.percentile(df, 99) < 1e-4 and dn.max() < 1e-3 and df.max() < 1e-3 and flips <= 6
-    assert bad.sum() <= int(1.5 * FLOOR['posed'] + 0.5)
+    SUMMARY['posed_' + size].update(e2e_gt_1e4=int(bad.sum()), e2e_cap=E2E_CAP[size]['posed'])
+    assert bad.sum() <= E2E_CAP[size]['posed'], (bad.sum(), E2E_CAP[size]['posed'])
 
 
 def _hybrid_lists(S, which, bkg_z, near, far, S_h, multi):
@@ -139,10 +172,12 @@ def _hybrid_lists(S, which, bkg_z, near, far, S_h, multi):
     return [bkg_z] + [h[0] for h in hz], [None] + [~h[1] for h in hz], [h[1] for h in hz]
 
 
-@pytest.mark.parametrize("which", ["hybrid", "multi"])
-def test_merged_frames(S, which):
+@pytest.mark.parametrize("which,size", [("hybrid", "small"), ("multi", "small"), ("hybrid", "big")])
+def test_merged_frames(S, which, size):
     multi = which == 'multi'
-    c = PS.cap(S, which)
+    S, whole = pick(S, size)
+    NR = S['nrays']
+    c = PS.cap(S, which) if size == 'small' else PS.cap_big(S)
     o, d = PS.frame_rays(c)
     nets = S['dev_nets']
     ref = S[f'{which}_rgb'].reshape(-1, 3)
@@ -167,19 +202,22 @@ def test_merged_frames(S, which):
     zl, zero, hits = _hybrid_lists(S, which, r_z, r_near, r_far, S_h, multi)
     ties = PS.cross_list_ties(zl, zero)
     e = np.abs(rgb - ref).max(-1)
-    a, b = MULTI_BAND if multi else BAND
+    a, b = whole or (MULTI_BAND if multi else BAND)
     ok = ~ties
     verts_l, T_l = (S['posed_l'], S['T_l']) if multi else ([S['posed_verts']], [S['T']])
     jumps = [foot_jump_rays(trc, k, o, d, verts_l[k], S['faces'], T_l[k], (a, b)) for k in range(len(verts_l))]
     for j in jumps:
         ok[j] = False
-    band = np.zeros(1280, bool)
+    band = np.zeros(NR, bool)
     band[a:b] = True
     n_hit_band = sum(int((h & band).sum()) for h in hits)
-    print(f"[{which}, conditional on the reference's bkg z and near / far] rays {a}..{b}, actor hits there {n_hit_band}: rgb Linf over rays without a cross-list z tie "
+    print(f"[{which} {size}, conditional on the reference's bkg z and near / far] rays {a}..{b}, actor hits there {n_hit_band}: rgb Linf over rays without a cross-list z tie "
           f"or a foot on another face {e[band & ok].max():.2e}; tie rays (frame) {list(np.nonzero(ties)[0])} at {e[ties]}; rays with a displaced foot per actor "
           f"{[j.size for j in jumps]}; depth {np.abs(depth - S[f'{which}_depth'].ravel())[band & ok].max():.2e}; whole frame rays > 1e-4: {(e > 1e-4).sum()}")
-    assert e[band & ok].max() < 1e-4 and ties.sum() <= 4 and sum(j.size for j in jumps) <= 0.1 * max(1, n_hit_band)
+    SUMMARY[f'{which}_{size}'] = {'rays': int(band.sum()), 'actor_hits': n_hit_band, 'cond_linf': float(e[band & ok].max()), 'tie_rays': int(ties.sum()),
+                                  'foot_jump_rays': int(sum(j.size for j in jumps))}
+    # measured on the 40 x 32 frames: 1-3 tie rays, displaced feet on 2.2 % of the band's hit rays
+    assert e[band & ok].max() < 1e-4 and ties.sum() <= TIE_CAP[size] and sum(j.size for j in jumps) <= 0.05 * max(1, n_hit_band)
     # ---- end to end
     tr = {}
     rgb, depth, acc = run(trace=tr)
@@ -188,8 +226,8 @@ def test_merged_frames(S, which):
     n_dev = np.stack([x.cpu().numpy() for x in tr['near']])
     f_dev = np.stack([x.cpu().numpy() for x in tr['far']])
     dz = np.abs(z_dev - r_z).max(-1)
-    hit_flip = np.zeros(1280, bool)
-    dnf = np.zeros(1280, np.float32)
+    hit_flip = np.zeros(NR, bool)
+    dnf = np.zeros(NR, np.float32)
     for k in range(len(r_near)):
         hr, hd = r_near[k] < r_far[k], n_dev[k] < f_dev[k]
         hit_flip |= hr != hd
@@ -199,10 +237,11 @@ def test_merged_frames(S, which):
     order_flip = (PS.merged_order(zl_d) != PS.merged_order(zl)).any(1)
     bad = e2 > 1e-4
     quiet = ~order_flip & ~hit_flip & (dz < 2e-6) & (dnf < 2e-6)
-    print(f"[{which} end to end] rays > 1e-4: {bad.sum()} of 1280 (Linf {e2.max():.2e}); of those: merged order changed {(bad & order_flip).sum()}, hit / miss flip "
+    print(f"[{which} end to end {size}] rays > 1e-4: {bad.sum()} of {NR} (Linf {e2.max():.2e}); of those: merged order changed {(bad & order_flip).sum()}, hit / miss flip "
           f"{(bad & hit_flip).sum()}, neither {(bad & ~order_flip & ~hit_flip).sum()} (their sample displacement >= {dz[bad & ~order_flip & ~hit_flip].min() if (bad & ~order_flip & ~hit_flip).any() else 0:.1e}); "
           f"rays with changed order {order_flip.sum()}, displacement percentiles 50/95 {np.median(dz):.1e}/{np.percentile(dz, 95):.1e}; "
           f"quiet rays (same order, nothing displaced by 2e-6): {quiet.sum()}, their Linf {e2[quiet].max() if quiet.any() else 0:.2e}")
-    if FLOOR[which] is not None:
-        assert bad.sum() <= int(1.5 * FLOOR[which] + 0.5)
+    SUMMARY[f'{which}_{size}'].update(e2e_gt_1e4=int(bad.sum()), e2e_cap=E2E_CAP[size][which], e2e_floor=(FLOOR if size == 'small' else FLOOR_BIG)[which],
+                                      quiet_rays=int(quiet.sum()), quiet_linf=float(e2[quiet].max()) if quiet.any() else 0.0)
+    assert bad.sum() <= E2E_CAP[size][which], (bad.sum(), E2E_CAP[size][which])
     assert (e2[quiet] < 1e-4).all()

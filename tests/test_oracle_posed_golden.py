@@ -111,3 +111,22 @@ def test_multi_person_frame_conditional(S):
     print(f"[multi 192+128 / 3 x 192 -> 896 merged, conditional] {b - a} rays, hits per actor {hits}: rgb Linf {e[~ties].max():.2e}, tie rays {ties.sum()}")
     assert min(hits) > 20 and e[~ties].max() < 1e-4 and ties.sum() <= 2              # measured 1.6e-5
     assert np.abs(depth - S['multi_depth'].ravel()[a:b])[~ties].max() < 5e-4
+
+
+def test_big_hybrid_frame_conditional_on_every_ray():
+    """tests/golden/posed_big.npz: the reference's render_hybrid_nerf at 128 + 128 / 128 on a 64 x 64 frame -- the conditional statement
+    over ALL 4096 rays (1896 of them through the body) instead of a 320-ray band: within 1e-4 of the reference's frame on every ray
+    without an exact background / human z tie."""
+    S = PS.load_big()
+    nets = PS.oracle_nets()
+    c = PS.cap_big(S)
+    given = {'near_far': [(S['hybrid_near'], S['hybrid_far'])], 'bkg_z': S['hybrid_bkg_z']}
+    rgb, depth = render.render_hybrid_nerf(nets[0], nets[1], nets[2], c, S['posed_verts'], S['faces'], S['T'], rays_per_batch=1024, samples_per_ray=128,
+                                           importance_samples_per_ray=128, return_depth=True, given=given)
+    hz, hit = PS.human_z(S['hybrid_near'], S['hybrid_far'], 128)
+    ties = PS.cross_list_ties([S['hybrid_bkg_z'], hz])
+    e = np.abs(rgb.reshape(-1, 3) - S['hybrid_rgb'].reshape(-1, 3)).max(-1)
+    print(f"[hybrid big 64 x 64, conditional on the reference's bkg z and near / far] 4096 rays ({hit.sum()} hit): rgb Linf over rays without a cross-list z tie "
+          f"{e[~ties].max():.2e}; {ties.sum()} tie ray(s) at {e[ties]}; depth {np.abs(depth.ravel() - S['hybrid_depth'].ravel())[~ties].max():.2e}")
+    assert hit.sum() > 1500 and e[~ties].max() < 1e-4 and ties.sum() <= 12
+    assert np.abs(depth.ravel() - S['hybrid_depth'].ravel())[~ties].max() < 2e-4
