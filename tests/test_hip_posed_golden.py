@@ -29,8 +29,10 @@ pytestmark = pytest.mark.gpu
 FLOOR = {'posed': 11, 'hybrid': 47, 'multi': 57}
 FLOOR_BIG = {'posed': 29, 'hybrid': 105}          # tests/golden/posed_floor.py --big
 # end-to-end caps: min(1.5 x floor, what the device measured + 5) -- small frames measured in round 3: hybrid 43, multi 55
-E2E_CAP = {'small': {'posed': int(1.5 * 11 + 0.5), 'hybrid': 48, 'multi': 60}, 'big': {'posed': 44, 'hybrid': 158}}
-TIE_CAP = {'small': 4, 'big': 12}
+E2E_CAP = {'small': {'posed': int(1.5 * 11 + 0.5), 'hybrid': 48, 'multi': 60}, 'big': {'posed': 39, 'hybrid': 105}}     # big measured (r04): posed 34 (floor 29), hybrid 100 (floor 105)
+TIE_CAP = {'small': 4, 'big': 6}            # measured 3 / 4
+# rays beyond 1e-4 over the WHOLE frame in the conditional runs (flagged or not): measured + 3
+COND_CAP = {'small': {'posed': 7, 'hybrid': 4, 'multi': 6}, 'big': {'posed': 11, 'hybrid': 4}}     # measured 4 / 1 / 3 and 8 / 1
 
 
 def cu(x, dt=torch.float32):
@@ -97,12 +99,23 @@ FOOT_TOL = 1e-5          # measured on the band: 6 of 275 hit rays beyond it (th
 MULTI_BAND = (560, 720)
 
 
-def foot_jump_rays(trace, k, o, d, verts, faces, T, band):
+DIR_TOL = 5e-4           # big frames: a canonical DIRECTION is a finite difference of warped points over one sample spacing (ray_utils.py:62-64)
+SPACING_TOL = 1e-3       # big frames: rays grazing the 0.2 shell have all 128 samples within < 0.13 of depth
+
+
+def foot_jump_rays(trace, k, o, d, verts, faces, T, band, strict=False):
     """rays of actor k within `band` that hold a sample whose canonical point differs from the oracle's warp of the SAME point by more
     than FOOT_TOL: the closest-point foot is ill conditioned there -- deep inside the body the feet on neighbouring
     faces are equidistant to 1e-7 while lying 1e-5 apart (at the medial axis: on opposite sides of the body), and the float32 search
     (the device, like libigl on float32 input) and the float64 shim pick different ones.  The distance, the query's invariant, agrees to
-    6e-8 (test_warp_vs_the_references_own_warp); the finite-difference directions divide the foot's displacement by the sample spacing."""
+    6e-8 (test_warp_vs_the_references_own_warp); the finite-difference directions divide the foot's displacement by the sample spacing.
+
+    strict (the 64 x 64 frames, where the statement covers EVERY hit ray of a frame): also the rays with a canonical direction more than
+    DIR_TOL from the oracle's (a foot displaced by 5e-6 over a spacing of 5e-3 turns the direction by 1e-3, and the colour follows the
+    view direction with a slope of ~0.2: measured 1.5e-4 at 7e-4), and the grazing rays whose sample spacing is below SPACING_TOL --
+    there the reference's OWN float32 rounding of the closest point (3e-8, tests/golden/igl_shim.py returns it in the query's dtype
+    like the bindings) turns its directions by 1e-3..1e-2: the CPU oracle and the reference disagree on exactly those rays by the same
+    amounts (ray 2427 of posed_big.npz: spacing 2.2e-5, oracle vs reference 2.9e-3, device vs oracle 4e-6)."""
     from oracle import warp
     hit = trace['hit'][k].cpu().numpy()
     if trace['can_pts'][k] is None:
@@ -113,9 +126,13 @@ def foot_jump_rays(trace, k, o, d, verts, faces, T, band):
     rays = hit[sel]
     z = trace['human_z'][k].cpu().numpy()[sel]
     pts = (o[rays, None, :] + d[rays, None, :] * z[..., None]).astype(np.float32)
-    ocp, _, _ = warp.warp_samples_to_canonical(pts, verts, faces, T)
+    ocp, ocd, _ = warp.warp_samples_to_canonical(pts, verts, faces, T)
     dev = np.abs(ocp - trace['can_pts'][k].cpu().numpy()[sel]).max((-1, -2))
-    foot_jump_rays.last = (rays, dev)
+    dev_d = np.abs(ocd - trace['can_dirs'][k].cpu().numpy()[sel]).max((-1, -2))
+    spacing = (z[:, -1] - z[:, 0]) / (z.shape[1] - 1)
+    foot_jump_rays.last = (rays, dev, dev_d, spacing)
+    if strict:
+        return rays[(dev > FOOT_TOL) | (dev_d > DIR_TOL) | (spacing < SPACING_TOL)]
     return rays[dev > FOOT_TOL]
 
 
@@ -134,17 +151,21 @@ def test_posed_human_frame(S, size):
     ea, ed = np.abs(acc.cpu().numpy() - S['posed_acc'].ravel()), np.abs(depth.cpu().numpy() - S['posed_depth'].ravel())
     hit = S['posed_near'] < S['posed_far']
     a, b = whole or BAND
-    jump = foot_jump_rays(trc, 0, o, d, S['posed_verts'], S['faces'], S['T'], (a, b))
+    jump = foot_jump_rays(trc, 0, o, d, S['posed_verts'], S['faces'], S['T'], (a, b), strict=size == 'big')
     ok = np.ones(NR, bool)
     ok[jump] = False
     band = np.zeros(NR, bool)
     band[a:b] = True
     print(f"[posed 128 {size}, conditional on the reference's near / far] rays {a}..{b} ({(hit & band).sum()} hit): {jump.size} ray(s) with a sample whose foot is on "
-          f"another face (Linf there {e[jump].max() if jump.size else 0:.2e}); every other ray: rgb Linf {e[band & ok].max():.2e}, acc {ea[band & ok].max():.2e}, "
+          f"another face{' / a turned direction / a grazing interval' if size == 'big' else ''} (Linf there {e[jump].max() if jump.size else 0:.2e}); every other ray: rgb Linf {e[band & ok].max():.2e}, acc {ea[band & ok].max():.2e}, "
           f"depth {ed[band & ok].max():.2e}; whole frame: rays > 1e-4 {(e > 1e-4).sum()} of {hit.sum()} hit, acc Linf {ea.max():.2e}")
     SUMMARY['posed_' + size] = {'rays': int(band.sum()), 'hit': int((hit & band).sum()), 'cond_linf': float(e[band & ok].max()), 'foot_jump_rays': int(jump.size)}
     assert e[band & ok].max() < 1e-4 and ea[band & ok].max() < 1e-4 and ed[band & ok].max() < 2e-4
-    assert jump.size <= 0.05 * (hit & band).sum() and ea.max() < 1e-4          # measured: 6 of 275 (2.2 %) on the band
+    # measured: 6 of 275 (2.2 %) on the band; big, with the direction and spacing criteria: 285 of 1896 (15 %), and over the WHOLE
+    # frame 8 rays beyond 1e-4 (3 of them are rays on which the CPU oracle and the reference disagree by the same amount)
+    assert jump.size <= (0.20 if size == 'big' else 0.05) * (hit & band).sum() and ea.max() < 1e-4
+    SUMMARY['posed_' + size]['cond_gt_1e4_whole_frame'] = int((e > 1e-4).sum())
+    assert (e > 1e-4).sum() <= COND_CAP[size]['posed']
     # the device's own near / far and the end-to-end frame
     tr = {}
     rgb, depth, acc = S['R'].render_smpl_nerf_rays(net, cu(o), cu(d), cu(S['posed_verts']), S['mesh'], 128, True, False, 0.2, 1.0, trace=tr)
@@ -205,7 +226,7 @@ def test_merged_frames(S, which, size):
     a, b = whole or (MULTI_BAND if multi else BAND)
     ok = ~ties
     verts_l, T_l = (S['posed_l'], S['T_l']) if multi else ([S['posed_verts']], [S['T']])
-    jumps = [foot_jump_rays(trc, k, o, d, verts_l[k], S['faces'], T_l[k], (a, b)) for k in range(len(verts_l))]
+    jumps = [foot_jump_rays(trc, k, o, d, verts_l[k], S['faces'], T_l[k], (a, b), strict=size == 'big') for k in range(len(verts_l))]
     for j in jumps:
         ok[j] = False
     band = np.zeros(NR, bool)
@@ -217,7 +238,9 @@ def test_merged_frames(S, which, size):
     SUMMARY[f'{which}_{size}'] = {'rays': int(band.sum()), 'actor_hits': n_hit_band, 'cond_linf': float(e[band & ok].max()), 'tie_rays': int(ties.sum()),
                                   'foot_jump_rays': int(sum(j.size for j in jumps))}
     # measured on the 40 x 32 frames: 1-3 tie rays, displaced feet on 2.2 % of the band's hit rays
-    assert e[band & ok].max() < 1e-4 and ties.sum() <= TIE_CAP[size] and sum(j.size for j in jumps) <= 0.05 * max(1, n_hit_band)
+    assert e[band & ok].max() < 1e-4 and ties.sum() <= TIE_CAP[size] and sum(j.size for j in jumps) <= (0.20 if size == 'big' else 0.05) * max(1, n_hit_band)
+    SUMMARY[f'{which}_{size}']['cond_gt_1e4_whole_frame'] = int((e > 1e-4).sum())
+    assert (e > 1e-4).sum() <= COND_CAP[size][which]
     # ---- end to end
     tr = {}
     rgb, depth, acc = run(trace=tr)
