@@ -336,6 +336,18 @@ int nm_render_rays_hybrid(nm_mlp_t coarse, nm_mlp_t fine, nm_mlp_t human, nm_mes
                           double geo_threshold, const float* origin, const float* direction, int64_t R, float bkg_near, float bkg_far, int S, int N,
                           int S_human, const float* t_vals, const float* u, const float* t_vals_human, int white_bkg, int precision_coarse,
                           int precision_fine, int precision_human, float* workspace, float* rgb, float* depth, float* acc, nm_stream_t stream);
+/* ONE KERNEL for the merge + composite tail of the hybrid renderers (utils/render_utils.py:330-345, 441-456): k <= 4 sorted lists per
+ * ray (z[l] [.,S[l]], raw[l] [.,S[l],4]; rows[l] nullable: list l's arrays are indexed by rows[l][ray] -- e.g. the background arrays of
+ * ALL rays read in place for the hit rays) -> the merged order (ties: the earlier list first, exactly what nm_merge_sorted applied list
+ * by list gives) -> raw2outputs' sums.  The merged list lives in LDS only; bit-identical to nm_merge_sorted (+ ...) + nm_composite.
+ * z / raw / rows / S are HOST arrays of k entries. */
+int nm_merge_composite_lists(int k, const float* const* z, const float* const* raw, const int32_t* const* rows, const int* S, int64_t R,
+                             const float* rays_d, int white_bkg, float* rgb, float* depth, float* acc, nm_stream_t stream);
+/* ONE KERNEL for the coarse tail of a two-pass render (utils/render_utils.py:139-147; ray_utils.py:138-194): the compositing weights of
+ * raw [R,S,4] (raw2outputs), their inverse-CDF samples at u [N] and the sorted merge with z_vals -> z_out [R,S+N]; sigma is read once,
+ * the weights are written only when weights_out [R,S] != NULL.  Bit-identical to nm_composite + nm_importance_z. */
+int nm_importance_from_raw(const float* raw, const float* z_vals, const float* rays_d, int64_t R, int S, const float* u, int N, float* z_out,
+                           float* weights_out, nm_stream_t stream);
 int64_t nm_merge_composite_workspace_floats(int64_t R, int Sa, int Sb);
 int nm_merge_composite(const float* za, const float* rawa, int Sa, const float* zb, const float* rawb, int Sb, int64_t R, const float* rays_d,
                        int white_bkg, float* workspace, float* rgb, float* depth, float* acc, nm_stream_t stream);

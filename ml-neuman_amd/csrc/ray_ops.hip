@@ -71,80 +71,6 @@ __global__ __launch_bounds__(256) void z_to_points_kernel(const float* __restric
 // a5 raw2outputs (reference utils/render_utils.py:69-105): one wave per ray.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
-
-__global__ __launch_bounds__(64 * kRayWavesPerBlock) void composite_kernel(
-    const float4* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ rays_d, int64_t R, int S,
-    int white_bkg, const float* __restrict__ noise, float* __restrict__ rgb, float* __restrict__ disp,
-    float* __restrict__ acc, float* __restrict__ weights, float* __restrict__ depth) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave0 = blockIdx.x * (int64_t)kRayWavesPerBlock + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * kRayWavesPerBlock;
-    for (int64_t r = wave0; r < R; r += nwaves) {
-        const float dx = rays_d[r * 3 + 0], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
-        const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);            // render_utils.py:88
-        const float* zr = z_vals + r * S;
-        double t_carry = 1.0;
-        float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
-        for (int c0 = 0; c0 < S; c0 += 64) {
-            const int s = c0 + lane;
-            const bool valid = s < S;
-            float w = 0.f, f = 1.f;
-            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            float z = 0.f;
-            if (valid) {
-                q = raw[r * S + s];
-                z = zr[s];
-                float dist = (s + 1 < S) ? (zr[s + 1] - z) : 1e10f;         // render_utils.py:85-86
-                dist = dist * dnorm;
-                float sigma = q.w;
-                if (noise) sigma = sigma + noise[r * S + s];               // render_utils.py:93-94
-                const float alpha = 1.f - expf(-fmaxf(sigma, 0.f) * dist);  // render_utils.py:81
-                w = alpha;
-                f = 1.f - alpha + 1e-10f;                                   // render_utils.py:95
-            }
-            // transmittance: running product in f64, rounded to f32 per entry -- order independent, and what torch's
-            // CPU cumprod computes for f32 inputs (the weights feed the inverse-CDF step function)
-            double incl = (double)f;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const double t = __shfl_up(incl, o, 64);
-                if (lane >= o) incl *= t;
-            }
-            double excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = 1.0;
-            w = w * (float)(t_carry * excl);
-            t_carry = t_carry * __shfl(incl, 63, 64);
-            if (valid) {
-                if (weights) weights[r * S + s] = w;
-                sr += w * sigmoidf_(q.x);                                   // render_utils.py:90, 96
-                sg += w * sigmoidf_(q.y);
-                sb += w * sigmoidf_(q.z);
-                sd += w * z;                                                // render_utils.py:98
-                sa += w;                                                    // render_utils.py:100
-            }
-        }
-        sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
-        if (lane == 0) {
-            if (white_bkg) {                                                // render_utils.py:102-103
-                const float bg = 1.f - sa;
-                sr = sr + bg; sg = sg + bg; sb = sb + bg;
-            }
-            rgb[r * 3 + 0] = sr; rgb[r * 3 + 1] = sg; rgb[r * 3 + 2] = sb;
-            depth[r] = sd;
-            acc[r] = sa;
-            if (disp) {
-                const float q = sd / sa;                                    // NaN when acc == 0, as torch.max propagates it
-                const float m = (q != q) ? q : fmaxf(1e-10f, q);            // render_utils.py:99
-                disp[r] = 1.f / m;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// a6/a7 sample_pdf (det) + ray_to_importance_samples (reference utils/ray_utils.py:138-194)
-// one wave per ray; per-wave LDS: bins[B] | cdf[B] | zs[N]   (z itself is re-read from global / L1)
-// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int upper_bound_lds(const float* a, int n, float v) {  // first i with a[i] > v
     int lo = 0, hi = n;
     while (lo < hi) {
@@ -162,21 +88,180 @@ __device__ __forceinline__ int lower_bound_lds(const float* a, int n, float v) {
     return lo;
 }
 
+
+struct CompositeSums {
+    float r, g, b, d, a;
+};
+// One ray's compositing (render_utils.py:85-100), the wave's lanes across its S samples in chunks of 64.  raw_at(s) / z_at(s): the
+// s-th record and depth of the list (global memory, or a merged list staged in LDS); w_out(s, w): called with every weight.  Every
+// kernel that composites goes through this one body, so they all produce the same bits.
+template <class RawAt, class ZAt, class WOut>
+__device__ __forceinline__ CompositeSums composite_ray(int S, float dnorm, int lane, const float* noise_row, RawAt raw_at, ZAt z_at, WOut w_out) {
+    double t_carry = 1.0;
+    float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+    for (int c0 = 0; c0 < S; c0 += 64) {
+        const int s = c0 + lane;
+        const bool valid = s < S;
+        float w = 0.f, f = 1.f;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        float z = 0.f;
+        if (valid) {
+            q = raw_at(s);
+            z = z_at(s);
+            float dist = (s + 1 < S) ? (z_at(s + 1) - z) : 1e10f;       // render_utils.py:85-86
+            dist = dist * dnorm;
+            float sigma = q.w;
+            if (noise_row) sigma = sigma + noise_row[s];               // render_utils.py:93-94
+            const float alpha = 1.f - expf(-fmaxf(sigma, 0.f) * dist);  // render_utils.py:81
+            w = alpha;
+            f = 1.f - alpha + 1e-10f;                                   // render_utils.py:95
+        }
+        // transmittance: running product in f64, rounded to f32 per entry -- order independent, and what torch's
+        // CPU cumprod computes for f32 inputs (the weights feed the inverse-CDF step function)
+        double incl = (double)f;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const double t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl *= t;
+        }
+        double excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0;
+        w = w * (float)(t_carry * excl);
+        t_carry = t_carry * __shfl(incl, 63, 64);
+        if (valid) {
+            w_out(s, w);
+            sr += w * sigmoidf_(q.x);                                   // render_utils.py:90, 96
+            sg += w * sigmoidf_(q.y);
+            sb += w * sigmoidf_(q.z);
+            sd += w * z;                                                // render_utils.py:98
+            sa += w;                                                    // render_utils.py:100
+        }
+    }
+    CompositeSums c;
+    c.r = wave_sum(sr); c.g = wave_sum(sg); c.b = wave_sum(sb); c.d = wave_sum(sd); c.a = wave_sum(sa);
+    return c;
+}
+__device__ __forceinline__ void composite_store(CompositeSums c, int white_bkg, int64_t r, float* rgb, float* disp, float* acc, float* depth) {
+    if (white_bkg) {                                                    // render_utils.py:102-103
+        const float bg = 1.f - c.a;
+        c.r = c.r + bg; c.g = c.g + bg; c.b = c.b + bg;
+    }
+    rgb[r * 3 + 0] = c.r; rgb[r * 3 + 1] = c.g; rgb[r * 3 + 2] = c.b;
+    depth[r] = c.d;
+    acc[r] = c.a;
+    if (disp) {
+        const float q = c.d / c.a;                                      // NaN when acc == 0, as torch.max propagates it
+        const float m = (q != q) ? q : fmaxf(1e-10f, q);                // render_utils.py:99
+        disp[r] = 1.f / m;
+    }
+}
+
+__global__ __launch_bounds__(64 * kRayWavesPerBlock) void composite_kernel(
+    const float4* __restrict__ raw, const float* __restrict__ z_vals, const float* __restrict__ rays_d, int64_t R, int S,
+    int white_bkg, const float* __restrict__ noise, float* __restrict__ rgb, float* __restrict__ disp,
+    float* __restrict__ acc, float* __restrict__ weights, float* __restrict__ depth) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = blockIdx.x * (int64_t)kRayWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * kRayWavesPerBlock;
+    for (int64_t r = wave0; r < R; r += nwaves) {
+        const float dx = rays_d[r * 3 + 0], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
+        const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);            // render_utils.py:88
+        const float* zr = z_vals + r * S;
+        const float4* rr = raw + r * S;
+        float* wr = weights ? weights + r * S : nullptr;
+        const CompositeSums c = composite_ray(S, dnorm, lane, noise ? noise + r * S : nullptr, [&](int s) { return rr[s]; }, [&](int s) { return zr[s]; },
+                                              [&](int s, float w) { if (wr) wr[s] = w; });
+        if (lane == 0) composite_store(c, white_bkg, r, rgb, disp, acc, depth);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a13 + a5 as ONE kernel: k sorted lists per ray -> merged order -> compositing, the merged list never written to HBM
+// (reference utils/render_utils.py:330-345, 441-456: sort(cat(z lists)), the three-index gather of cat(raw lists), raw2outputs).
+// One wave per ray.  The lists' z are staged in LDS; every sample's position in the merged order is its own index plus, per other
+// list, the number of that list's samples before it (binary search; on equal z the EARLIER list first = what merging list by list with
+// nm_merge_sorted gives); its record goes to that position of an LDS copy of the merged list, and composite_ray runs on the copy.
+// rows[l] (nullable): list l's arrays are indexed by rows[l][ray] instead of ray (the background list of the hit rays in place).
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxMergeLists = 4;
+struct MergeLists {
+    const float* z[kMaxMergeLists];
+    const float4* raw[kMaxMergeLists];
+    const int32_t* rows[kMaxMergeLists];
+    int S[kMaxMergeLists];
+    int k, S_total;
+};
+__global__ __launch_bounds__(256) void merge_composite_kernel(const MergeLists L, int64_t R, const float* __restrict__ rays_d, int white_bkg,
+                                                              float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ acc) {
+    extern __shared__ float4 lds_v4[];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int St = L.S_total;
+    // per wave: merged records [St] float4 | merged z [St] | the lists' z, concatenated [St]
+    float4* mraw = lds_v4 + (size_t)wib * ((size_t)St + (St + 1) / 2);
+    float* mz = reinterpret_cast<float*>(mraw + St);
+    float* lz = mz + St;
+    for (int64_t r0 = blockIdx.x * (int64_t)wpb; r0 < R; r0 += (int64_t)gridDim.x * wpb) {
+        const bool live = r0 + wib < R;
+        const int64_t r = live ? r0 + wib : R - 1;
+        int off = 0;
+        for (int l = 0; l < L.k; ++l) {
+            const int64_t row = L.rows[l] ? (int64_t)L.rows[l][r] : r;
+            const float* zr = L.z[l] + row * L.S[l];
+            for (int i = lane; i < L.S[l]; i += 64) lz[off + i] = zr[i];
+            off += L.S[l];
+        }
+        __syncthreads();
+        off = 0;
+        for (int l = 0; l < L.k; ++l) {
+            const int64_t row = L.rows[l] ? (int64_t)L.rows[l][r] : r;
+            const float4* rr = L.raw[l] + row * L.S[l];
+            for (int i = lane; i < L.S[l]; i += 64) {
+                const float v = lz[off + i];
+                int k = i, o2 = 0;
+                for (int m = 0; m < L.k; ++m) {
+                    if (m < l) k += upper_bound_lds(lz + o2, L.S[m], v);           // an earlier list's equal samples come first
+                    else if (m > l) k += lower_bound_lds(lz + o2, L.S[m], v);
+                    o2 += L.S[m];
+                }
+                mz[k] = v;
+                mraw[k] = rr[i];
+            }
+            off += L.S[l];
+        }
+        __syncthreads();
+        const float dx = rays_d[r * 3 + 0], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
+        const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+        const CompositeSums c = composite_ray(St, dnorm, lane, nullptr, [&](int s) { return mraw[s]; }, [&](int s) { return mz[s]; }, [&](int, float) {});
+        if (lane == 0 && live) composite_store(c, white_bkg, r, rgb, nullptr, acc, depth);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a6/a7 sample_pdf (det) + ray_to_importance_samples (reference utils/ray_utils.py:138-194)
+// one wave per ray; per-wave LDS: bins[B] | cdf[B] | zs[N]   (z itself is re-read from global / L1)
+// ------------------------------------------------------------------------------------------------
 constexpr int kMaxImportanceChunks = 8;     // importance samples per ray <= 512 when merged with the old samples
-// MODE 0: bins/weights given (sample_pdf).  MODE 1: derive from z/w (importance), optionally merge.
+// MODE 0: bins/weights given (sample_pdf).  MODE 1: derive from z/w (importance), optionally merge.  MODE 2: as MODE 1 with the
+// compositing weights computed HERE from the pass's raw output (raw2outputs' weights, composite_ray: the same bits as nm_composite
+// writes) -- the coarse tail `raw2outputs -> sample_pdf -> sort(cat)` of a two-pass render (render_utils.py:139-147) as one kernel
+// that reads sigma once and writes only the merged sample positions (the weights too when w_out != NULL).
 template <int MODE>
 __global__ __launch_bounds__(64 * kRayWavesPerBlock) void sample_pdf_kernel(
     const float* __restrict__ in_a /* bins [R,B] | z [R,S] */, const float* __restrict__ in_w /* weights [R,B-1] | w [R,S] */,
-    int64_t R, int B, const float* __restrict__ u, int N, int including_old, float* __restrict__ out) {
+    int64_t R, int B, const float* __restrict__ u, int N, int including_old, float* __restrict__ out,
+    const float4* __restrict__ raw = nullptr, const float* __restrict__ rays_d = nullptr, float* __restrict__ w_out = nullptr) {
     extern __shared__ float lds_f[];
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
     const int S = B + 1;                       // MODE 1: samples per ray
-    const int per_wave = 2 * B + N + (MODE == 1 ? S : 0);
+    const int per_wave = 2 * B + N + (MODE >= 1 ? S : 0) + (MODE == 2 ? S : 0);
     float* bins = lds_f + wib * per_wave;
     float* cdf = bins + B;
     float* zs = cdf + B;
-    float* zl = zs + N;                        // MODE 1 only: the ray's coarse z
+    float* zl = zs + N;                        // MODE 1, 2: the ray's coarse z
+    float* wl = zl + S;                        // MODE 2: the ray's compositing weights
     const int nW = B - 1;                      // number of pdf weights
     // block-uniform trip count so __syncthreads() is legal; a wave past the end idles on r = R-1 without storing
     for (int64_t r0 = blockIdx.x * (int64_t)kRayWavesPerBlock; r0 < R; r0 += (int64_t)gridDim.x * kRayWavesPerBlock) {
@@ -195,7 +280,16 @@ __global__ __launch_bounds__(64 * kRayWavesPerBlock) void sample_pdf_kernel(
             const float* zr = in_a + r * S;
             for (int i = lane; i < S; i += 64) zl[i] = zr[i];
             for (int i = lane; i < B; i += 64) bins[i] = .5f * (zr[i + 1] + zr[i]);     // ray_utils.py:148
-            for (int i = lane; i < nW; i += 64) wsum_d += (double)(in_w[r * S + 1 + i] + 1e-5f);   // weights[..., 1:-1], :149
+            if (MODE == 2) {
+                const float dx = rays_d[r * 3 + 0], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
+                const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+                const float4* rr = raw + r * S;
+                float* wr = (w_out && live) ? w_out + r * S : nullptr;
+                (void)composite_ray(S, dnorm, lane, nullptr, [&](int s_) { return rr[s_]; }, [&](int s_) { return zr[s_]; },
+                                    [&](int s_, float w_) { wl[s_] = w_; if (wr) wr[s_] = w_; });
+                __syncthreads();
+            }
+            for (int i = lane; i < nW; i += 64) wsum_d += (double)((MODE == 2 ? wl[1 + i] : in_w[r * S + 1 + i]) + 1e-5f);   // weights[..., 1:-1], :149
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) wsum_d += __shfl_xor(wsum_d, o, 64);
@@ -207,7 +301,7 @@ __global__ __launch_bounds__(64 * kRayWavesPerBlock) void sample_pdf_kernel(
             const int i = c0 + lane;
             float p = 0.f;
             if (i < nW) {
-                const float wv = (MODE == 0 ? in_w[r * nW + i] : in_w[r * S + 1 + i]) + 1e-5f;
+                const float wv = (MODE == 0 ? in_w[r * nW + i] : MODE == 2 ? wl[1 + i] : in_w[r * S + 1 + i]) + 1e-5f;
                 p = wv / wsum;
             }
             double inc = (double)p;
@@ -238,7 +332,7 @@ __global__ __launch_bounds__(64 * kRayWavesPerBlock) void sample_pdf_kernel(
                 const float t = (uj - cdf0) / denom;
                 smp = b0 + t * (b1 - b0);
             }
-            if (MODE == 1 && including_old) {
+            if (MODE >= 1 && including_old) {
                 float prev = __shfl_up(smp, 1, 64);
                 if (lane == 0) prev = prev_last;
                 inverted |= j < N && smp < prev;
@@ -248,7 +342,7 @@ __global__ __launch_bounds__(64 * kRayWavesPerBlock) void sample_pdf_kernel(
                 out[r * N + j] = smp;
             }
         }
-        if (MODE == 1 && including_old && __any(inverted)) {
+        if (MODE >= 1 && including_old && __any(inverted)) {
             // The inverse-CDF output is monotone up to f32 rounding; the reference's torch.sort (ray_utils.py:151) puts the
             // rare inversions in order, and so does this exact, stable rank sort (a wave-uniform branch taken only by rays
             // that have one; N <= 64 * kMaxImportanceChunks is checked on the host).  Values and ranks of every chunk are
@@ -273,7 +367,7 @@ __global__ __launch_bounds__(64 * kRayWavesPerBlock) void sample_pdf_kernel(
                 if (c * 64 + lane < N) zs[rk[c]] = v[c];
         }
         __syncthreads();
-        if (MODE == 1 && including_old && live) {
+        if (MODE >= 1 && including_old && live) {
             // ---- rank merge of z (S, sorted) and zs (N, sorted) == sort(cat)              // ray_utils.py:151-152
             float* o = out + r * (int64_t)(S + N);
             for (int i = lane; i < S; i += 64) {
@@ -411,6 +505,51 @@ int nm_importance_z(const float* z_vals, const float* weights, int64_t R, int S,
     hipLaunchKernelGGL(sample_pdf_kernel<1>, dim3(grid_for(R, kRayWavesPerBlock)), dim3(64 * kRayWavesPerBlock), lds,
                        nm::as_stream(stream), z_vals, weights, R, B, u, N, including_old, z_out);
     return nm::check_launch("sample_pdf_kernel<1>");
+}
+
+int nm_importance_from_raw(const float* raw, const float* z_vals, const float* rays_d, int64_t R, int S, const float* u, int N, float* z_out,
+                           float* weights_out, nm_stream_t stream) {
+    NM_REQUIRE(R == 0 || (raw && z_vals && rays_d && u && z_out), "nm_importance_from_raw: null pointer");
+    NM_REQUIRE(R >= 0 && S >= 3 && N >= 1, "nm_importance_from_raw: bad sizes S=%d N=%d", S, N);
+    NM_REQUIRE((reinterpret_cast<uintptr_t>(raw) & 15) == 0, "nm_importance_from_raw: raw must be 16-byte aligned");
+    const int B = S - 1;
+    const size_t lds = (size_t)kRayWavesPerBlock * (2 * B + N + 2 * S) * sizeof(float);
+    NM_REQUIRE(lds <= 64 * 1024, "nm_importance_from_raw: S=%d N=%d exceed the per-wave LDS budget", S, N);
+    NM_REQUIRE(N <= 64 * kMaxImportanceChunks, "nm_importance_from_raw: N=%d importance samples exceed %d", N, 64 * kMaxImportanceChunks);
+    if (R == 0) return NM_OK;
+    hipLaunchKernelGGL(sample_pdf_kernel<2>, dim3(grid_for(R, kRayWavesPerBlock)), dim3(64 * kRayWavesPerBlock), lds, nm::as_stream(stream), z_vals,
+                       (const float*)nullptr, R, B, u, N, 1, z_out, reinterpret_cast<const float4*>(raw), rays_d, weights_out);
+    return nm::check_launch("sample_pdf_kernel<2>");
+}
+
+int nm_merge_composite_lists(int k, const float* const* z, const float* const* raw, const int32_t* const* rows, const int* S, int64_t R,
+                             const float* rays_d, int white_bkg, float* rgb, float* depth, float* acc, nm_stream_t stream) {
+    NM_REQUIRE(k >= 1 && k <= kMaxMergeLists && z && raw && S, "nm_merge_composite_lists: 1 <= k <= %d lists (k=%d)", kMaxMergeLists, k);
+    NM_REQUIRE(R == 0 || (rays_d && rgb && depth && acc), "nm_merge_composite_lists: null pointer");
+    MergeLists L;
+    L.k = k;
+    L.S_total = 0;
+    for (int l = 0; l < kMaxMergeLists; ++l) {
+        const bool on = l < k;
+        L.z[l] = on ? z[l] : nullptr;
+        L.raw[l] = on ? reinterpret_cast<const float4*>(raw[l]) : nullptr;
+        L.rows[l] = (on && rows) ? rows[l] : nullptr;
+        L.S[l] = on ? S[l] : 0;
+        if (on) {
+            NM_REQUIRE(R == 0 || (z[l] && raw[l]), "nm_merge_composite_lists: list %d is null", l);
+            NM_REQUIRE(S[l] >= 1, "nm_merge_composite_lists: list %d is empty", l);
+            NM_REQUIRE((reinterpret_cast<uintptr_t>(raw[l]) & 15) == 0, "nm_merge_composite_lists: raw arrays must be 16-byte aligned");
+            L.S_total += S[l];
+        }
+    }
+    if (R == 0) return NM_OK;
+    const size_t per_wave = ((size_t)L.S_total + (L.S_total + 1) / 2) * 16;
+    NM_REQUIRE(per_wave <= 64 * 1024, "nm_merge_composite_lists: %d merged samples exceed the per-wave LDS budget", L.S_total);
+    int wpb = (int)((64 * 1024) / per_wave);
+    if (wpb > 4) wpb = 4;
+    hipLaunchKernelGGL(merge_composite_kernel, dim3(grid_for(R, wpb)), dim3(64 * wpb), per_wave * wpb, nm::as_stream(stream), L, R, rays_d, white_bkg, rgb,
+                       depth, acc);
+    return nm::check_launch("merge_composite_kernel");
 }
 
 int nm_merge_sorted(const float* za, const float* rawa, int Sa, const float* zb, const float* rawb, int Sb, int64_t R,

@@ -35,8 +35,9 @@ int nm_render_rays_bkg(nm_mlp_t coarse, nm_mlp_t fine, const float* origin, cons
         // (scratch: rgb [R,3] | disp | acc | depth of the coarse composite, discarded as the reference discards them, :139-141)
         if ((rc = nm_ray_to_samples(origin, direction, near, far, R, S, t_vals, 0, nullptr, nullptr, nullptr, zc, stream))) return rc;
         if ((rc = nm_mlp_sigma_rays(coarse, origin, direction, zc, R, S, precision_coarse, 1.f, rawc, stream))) return rc;
-        if ((rc = nm_composite(rawc, zc, direction, R, S, white_bkg, nullptr, scratch, scratch + 3 * R, scratch + 4 * R, wc, scratch + 5 * R, stream))) return rc;
-        if ((rc = nm_importance_z(zc, wc, R, S, u, N, 1, z_out, stream))) return rc;
+        // (the coarse composite's colours are discarded, as the reference discards them, :139-141: ONE kernel from sigma to the samples)
+        (void)wc;
+        if ((rc = nm_importance_from_raw(rawc, zc, direction, R, S, u, N, z_out, nullptr, stream))) return rc;
         if ((rc = nm_mlp_forward_rays(fine, origin, direction, z_out, R, S + N, precision_fine, 1.f, raw_out, stream))) return rc;
     }
     if (rgb) {
@@ -77,18 +78,18 @@ int nm_render_rays_human(nm_mlp_t human, nm_mesh_t mesh, const double* T, const 
     return NM_OK;
 }
 
-int64_t nm_merge_composite_workspace_floats(int64_t R, int Sa, int Sb) { return align4(R * (Sa + Sb)) + align4(R * (Sa + Sb) * 4) + align4(R); }
+// (the merged list lives in LDS now: nothing is needed; kept for callers that size a workspace)
+int64_t nm_merge_composite_workspace_floats(int64_t R, int Sa, int Sb) { (void)R; (void)Sa; (void)Sb; return 4; }
 
 int nm_merge_composite(const float* za, const float* rawa, int Sa, const float* zb, const float* rawb, int Sb, int64_t R, const float* rays_d,
                        int white_bkg, float* workspace, float* rgb, float* depth, float* acc, nm_stream_t stream) {
-    NM_REQUIRE(R == 0 || (za && rawa && zb && rawb && rays_d && workspace && rgb && depth && acc), "nm_merge_composite: null pointer");
+    (void)workspace;
+    NM_REQUIRE(R == 0 || (za && rawa && zb && rawb && rays_d && rgb && depth && acc), "nm_merge_composite: null pointer");
     if (R == 0) return NM_OK;
-    float* z = workspace;
-    float* raw = z + align4(R * (Sa + Sb));
-    float* disp = raw + align4(R * (Sa + Sb) * 4);
-    int rc;
-    if ((rc = nm_merge_sorted(za, rawa, Sa, zb, rawb, Sb, R, z, raw, stream))) return rc;
-    return nm_composite(raw, z, rays_d, R, Sa + Sb, white_bkg, nullptr, rgb, disp, acc, nullptr, depth, stream);
+    const float* zs[2] = {za, zb};
+    const float* raws[2] = {rawa, rawb};
+    const int Ss[2] = {Sa, Sb};
+    return nm_merge_composite_lists(2, zs, raws, nullptr, Ss, R, rays_d, white_bkg, rgb, depth, acc, stream);
 }
 
 // ---- render_hybrid_nerf's per-batch body (utils/render_utils.py:287-353) as one call: two-pass background for every ray and its
@@ -115,10 +116,10 @@ inline HybridWs hybrid_layout(float* base, int64_t R, int S, int N, int Sh) {
     w.hit = reinterpret_cast<int32_t*>(take(R)); w.counts = reinterpret_cast<int32_t*>(take(4));
     w.cws = reinterpret_cast<int32_t*>(take(nm_compact_workspace_ints(R)));
     w.ho = take(R * 3); w.hd = take(R * 3); w.hn = take(R); w.hf = take(R);
-    w.bz = take(R * Sb); w.braw = take(R * Sb * 4);
+    w.bz = nullptr; w.braw = nullptr;                             // (the merge reads the background rows in place)
     w.h_raw = take(R * Sh * 4); w.h_z = take(R * Sh);
     w.human_ws = take(nm_render_rays_human_workspace_floats(R, Sh, 1));
-    w.merge_ws = take(nm_merge_composite_workspace_floats(R, Sb, Sh));
+    w.merge_ws = nullptr;
     w.rgb_h = take(R * 3); w.depth_h = take(R); w.acc_h = take(R); w.scratch = take(R * 6);
     w.total = o;
     return w;
@@ -157,11 +158,15 @@ int nm_render_rays_hybrid(nm_mlp_t coarse, nm_mlp_t fine, nm_mlp_t human, nm_mes
     if ((rc = nm_gather_rows(direction, w.hit, nullptr, n_hit, 3, w.hd, stream))) return rc;
     if ((rc = nm_gather_rows(w.near_h, w.hit, nullptr, n_hit, 1, w.hn, stream))) return rc;
     if ((rc = nm_gather_rows(w.far_h, w.hit, nullptr, n_hit, 1, w.hf, stream))) return rc;
-    if ((rc = nm_gather_rows(w.z_b, w.hit, nullptr, n_hit, Sb, w.bz, stream))) return rc;
-    if ((rc = nm_gather_rows(w.raw_b, w.hit, nullptr, n_hit, Sb * 4, w.braw, stream))) return rc;
     if ((rc = nm_render_rays_human(human, mesh, T, w.ho, w.hd, w.hn, w.hf, n_hit, S_human, t_vals_human, white_bkg, 1.f, precision_human, w.human_ws, w.h_raw,
                                    w.h_z, nullptr, nullptr, nullptr, stream))) return rc;
-    if ((rc = nm_merge_composite(w.bz, w.braw, Sb, w.h_z, w.h_raw, S_human, n_hit, w.hd, white_bkg, w.merge_ws, w.rgb_h, w.depth_h, w.acc_h, stream))) return rc;
+    {                                                                 // merged composite: the background lists of the hit rays read in place
+        const float* zs[2] = {w.z_b, w.h_z};
+        const float* raws[2] = {w.raw_b, w.h_raw};
+        const int32_t* rows[2] = {w.hit, nullptr};
+        const int Ss[2] = {Sb, S_human};
+        if ((rc = nm_merge_composite_lists(2, zs, raws, rows, Ss, n_hit, w.hd, white_bkg, w.rgb_h, w.depth_h, w.acc_h, stream))) return rc;
+    }
     if ((rc = nm_composite(w.h_raw, w.h_z, w.hd, n_hit, S_human, white_bkg, nullptr, w.scratch, w.scratch + 3 * (int64_t)n_hit, w.acc_h, nullptr,
                            w.scratch + 5 * (int64_t)n_hit, stream))) return rc;                     // the human-only accumulation (:345-350)
     if ((rc = nm_scatter_rows(w.rgb_h, w.hit, nullptr, n_hit, 3, rgb, stream))) return rc;

@@ -105,6 +105,9 @@ SIGNATURES = {
     "nm_render_rays_hybrid": (i32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_f32p, i32, ctypes.c_double, c_f32p, c_f32p,
                                     i64, ctypes.c_float, ctypes.c_float, i32, i32, i32, c_f32p, c_f32p, c_f32p, i32, i32, i32, i32, c_f32p, c_f32p, c_f32p, c_f32p,
                                     c_stream]),
+    "nm_merge_composite_lists": (i32, [i32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                       ctypes.POINTER(ctypes.c_int), i64, c_f32p, i32, c_f32p, c_f32p, c_f32p, c_stream]),
+    "nm_importance_from_raw": (i32, [c_f32p, c_f32p, c_f32p, i64, i32, c_f32p, i32, c_f32p, c_f32p, c_stream]),
     "nm_merge_composite_workspace_floats": (i64, [i64, i32, i32]),
     "nm_merge_composite": (i32, [c_f32p, c_f32p, i32, c_f32p, c_f32p, i32, i64, c_f32p, i32, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "nm_frame_to_uint8": (i32, [c_f32p, i64, ctypes.c_void_p, c_stream]),

@@ -173,6 +173,22 @@ def importance_z(z_vals, weights, importance_samples_per_ray, including_old=True
     return out
 
 
+def importance_z_from_raw(raw, z_vals, rays_d, importance_samples_per_ray, want_weights=False):
+    """The coarse tail of a two-pass render as ONE kernel (reference render_utils.py:139-147: raw2outputs' weights -> sample_pdf ->
+    sort(cat)): raw [R,S,4] of the coarse pass -> z [R, S + N] (and the weights [R,S] when asked for).  Bit-identical to raw2outputs +
+    importance_z."""
+    _lib.require_gpu()
+    raw, z_vals, rays_d = _f32c(raw.detach()), _f32c(z_vals), _f32c(rays_d)
+    R, S = z_vals.shape
+    N = int(importance_samples_per_ray)
+    u = torch.linspace(0., 1., steps=N, device=z_vals.device)
+    out = torch.empty((R, S + N), device=z_vals.device, dtype=torch.float32)
+    w = torch.empty((R, S), device=z_vals.device, dtype=torch.float32) if want_weights else None
+    _lib.check(_lib.lib().nm_importance_from_raw(_lib.dev_ptr(raw), _lib.dev_ptr(z_vals), _lib.dev_ptr(rays_d), R, S, _lib.dev_ptr(u), N, _lib.dev_ptr(out),
+                                                 _lib.dev_ptr(w), _lib.stream_ptr()), "nm_importance_from_raw")
+    return out, w
+
+
 def ray_to_importance_samples(ray_batch, z_vals, weights, importance_samples_per_ray, device='cpu', including_old=True,
                               append_t=None):
     """reference ray_utils.py:138-160."""

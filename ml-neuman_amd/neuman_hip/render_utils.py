@@ -303,9 +303,10 @@ def bkg_place_z(coarse_net, fine_net, o, d, near, far, samples_per_ray, importan
         _note(trace, march_coarse=stats)
     else:
         raw = coarse_net.forward_rays(o, d, z, precision=precision, role=None, sigma_only=True)
-    _, _, _, w, _ = raw2outputs(raw, z, d, white_bkg=white_bkg)
+    # raw2outputs' weights -> sample_pdf -> sorted merge: one kernel (the weights reach HBM only for a trace)
+    z_fine, w = ray_utils.importance_z_from_raw(raw, z, d, importance_samples_per_ray, want_weights=trace is not None)
     _note(trace, coarse_z=z, coarse_w=w)
-    return ray_utils.importance_z(z, w, importance_samples_per_ray), None
+    return z_fine, None
 
 
 def bkg_shade(net, o, d, z, precision=None, trace=None, occluder=None, dz=None):
@@ -398,6 +399,32 @@ def merge_composite(za, rawa, zb, rawb, rays_d, white_bkg=True):
     _lib.check(_lib.lib().nm_merge_composite(_lib.dev_ptr(za.contiguous()), _lib.dev_ptr(rawa.contiguous()), Sa, _lib.dev_ptr(zb.contiguous()),
                                              _lib.dev_ptr(rawb.contiguous()), Sb, R, _lib.dev_ptr(rays_d.contiguous()), int(bool(white_bkg)), _lib.dev_ptr(ws),
                                              _lib.dev_ptr(rgb), _lib.dev_ptr(depth), _lib.dev_ptr(acc), _lib.stream_ptr()), "nm_merge_composite")
+    return rgb, depth, acc
+
+
+def merge_composite_lists(z_lists, raw_lists, rays_d, white_bkg=True, rows=None):
+    """k <= 4 sorted lists per ray -> merged order -> raw2outputs' sums, ONE kernel, the merged list never in HBM
+    (render_utils.py:330-345, 441-456).  rows[l] (int32 [R] or None): list l's tensors are indexed by rows[l][ray] -- a list that
+    exists for ALL rays of a batch read in place for the compacted hit rays.  -> (rgb [R,3], depth [R], acc [R]); bit-identical to
+    merge_sorted list by list + raw2outputs."""
+    _lib.require_gpu()
+    k = len(z_lists)
+    R = rays_d.shape[0]
+    dev = rays_d.device
+    zs = [z.to(torch.float32).contiguous() for z in z_lists]
+    raws = [r_.to(torch.float32).contiguous() for r_ in raw_lists]
+    rows = [None] * k if rows is None else [None if x is None else x.to(torch.int32).contiguous() for x in rows]
+    for l_ in range(k):
+        if rows[l_] is None and zs[l_].shape[0] != R:
+            raise _lib.NeumanHipError(f"merge_composite_lists: list {l_} has {zs[l_].shape[0]} rows for {R} rays")
+    arr = ctypes.c_void_p * k
+    rgb = torch.empty((R, 3), device=dev, dtype=torch.float32)
+    depth = torch.empty(R, device=dev, dtype=torch.float32)
+    acc = torch.empty(R, device=dev, dtype=torch.float32)
+    _lib.check(_lib.lib().nm_merge_composite_lists(
+        k, arr(*[z.data_ptr() for z in zs]), arr(*[r_.data_ptr() for r_ in raws]), arr(*[None if x is None else x.data_ptr() for x in rows]),
+        (ctypes.c_int * k)(*[int(z.shape[1]) for z in zs]), R, _lib.dev_ptr(rays_d.contiguous()), int(bool(white_bkg)), _lib.dev_ptr(rgb), _lib.dev_ptr(depth),
+        _lib.dev_ptr(acc), _lib.stream_ptr()), "nm_merge_composite_lists")
     return rgb, depth, acc
 
 
@@ -501,9 +528,7 @@ def render_hybrid_rays(coarse_bkg, fine_bkg, human_net, o, d, bkg_near, bkg_far,
         if hit.numel() == 0:
             continue
         # ... and hit rays are overwritten by the merged human + background composite (:313-353)
-        S_b = bkg_z.shape[1]
-        _rgb, _depth, _ = merge_composite(ray_utils.gather_rows(bkg_z, hit), ray_utils.gather_rows(bkg_raw.reshape(j - i, -1), hit).reshape(-1, S_b, 4),
-                                          h_z, h_raw, hd, white_bkg)
+        _rgb, _depth, _ = merge_composite_lists([bkg_z, h_z], [bkg_raw, h_raw], hd, white_bkg, rows=[hit, None])     # (the background rows in place)
         _, _, _acc, _, _ = raw2outputs(h_raw, h_z, hd, white_bkg=white_bkg, want_weights=False)          # :345-350
         ray_utils.scatter_rows(rgb[i:j], hit, _rgb)
         ray_utils.scatter_rows(depth[i:j], hit, _depth)
@@ -633,10 +658,14 @@ def render_multi_rays(coarse_bkg, fine_bkg, human_nets, o, d, bkg_near, bkg_far,
             if TERMINATION_EPS > 0:                                                              # a sample the march never reached stays unevaluated
                 last = torch.where((raw_all[:, -1, :] == 0).all(-1, keepdim=True), raw_all[:, -1, :], last)
             raw_all[:, -1, :] = last
-        for a_ in range(len(human_nets)):
-            h_z, h_raw, _ = lists[a_] if lists is not None else actor_lists(a_)
-            z_all, raw_all = merge_sorted(z_all, raw_all, h_z, h_raw)                                   # :441-448, list by list
-        rgb[i:j], _, _, _, depth[i:j] = raw2outputs(raw_all, z_all, dc, white_bkg=white_bkg, want_weights=False)
+        if lists is None:
+            lists = [actor_lists(a_) for a_ in range(len(human_nets))]
+        if len(lists) <= 3:                                                                      # :441-456 as one kernel: 4-way merge + composite
+            rgb[i:j], depth[i:j], _ = merge_composite_lists([z_all] + [l_[0] for l_ in lists], [raw_all] + [l_[1] for l_ in lists], dc, white_bkg)
+        else:                                                                                    # more than three actors: list by list
+            for h_z, h_raw, _ in lists:
+                z_all, raw_all = merge_sorted(z_all, raw_all, h_z, h_raw)
+            rgb[i:j], _, _, _, depth[i:j] = raw2outputs(raw_all, z_all, dc, white_bkg=white_bkg, want_weights=False)
     return rgb, depth
 
 

@@ -110,3 +110,64 @@ def test_hybrid_batch_as_one_call_is_bit_identical():
     b = render_utils.render_hybrid_rays_fused(nets[0], None, nets[2], o, d, c.near['bkg'], c.far['bkg'], verts, mesh, 64, 0)
     for x, y, what in zip(a, b, ("rgb", "depth", "acc")):
         assert torch.equal(x, y), what
+
+
+def _lists(R, sizes, seed, ties=True):
+    """k sorted z lists with records; some exact cross-list ties (the reference's sort leaves their order to torch; ours is stable)"""
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    zs, raws = [], []
+    for i, S in enumerate(sizes):
+        z = torch.sort(torch.rand((R, S), device='cuda', generator=g) * 3.0 + 0.3 * i, dim=1)[0].contiguous()
+        if ties and i > 0:
+            z[:, S // 3] = zs[0][:, min(sizes[0] - 1, S // 2)]                  # an exact tie with list 0
+            z = torch.sort(z, dim=1)[0].contiguous()
+        raw = (torch.randn((R, S, 4), device='cuda', generator=g) * torch.tensor([1., 1., 1., 4.], device='cuda')).contiguous()
+        zs.append(z)
+        raws.append(raw)
+    return zs, raws
+
+
+@pytest.mark.parametrize("R,sizes", [(1, (3, 2)), (777, (256, 128)), (301, (320, 192, 192, 192)), (130, (64, 17, 5)), (64, (384,))])
+def test_merge_composite_as_one_kernel_is_bit_identical(G, R, sizes):
+    """nm_merge_composite_lists (k-way merge + raw2outputs in one kernel, the merged list in LDS only) == nm_merge_sorted list by list +
+    nm_composite, including 320 + 3 x 192 = 896 merged samples (BASELINE config 5) and exact z ties between lists"""
+    _, d = rays(G, R, 5)
+    zs, raws = _lists(R, sizes, 11)
+    z_all, raw_all = zs[0], raws[0]
+    for z, raw in zip(zs[1:], raws[1:]):
+        z_all, raw_all = G.render.merge_sorted(z_all, raw_all, z, raw)
+    ref = G.render.raw2outputs(raw_all, z_all, d, white_bkg=True, want_weights=False)
+    for white in (True, False):
+        ref = G.render.raw2outputs(raw_all, z_all, d, white_bkg=white, want_weights=False)
+        rgb, depth, acc = G.render.merge_composite_lists(zs, raws, d, white)
+        assert torch.equal(rgb, ref[0]) and torch.equal(acc, ref[2]) and torch.equal(depth, ref[4]), (sizes, white)
+    if len(sizes) == 2:                                           # the two-list entry point is the same kernel
+        rgb2, depth2, acc2 = G.render.merge_composite(zs[0], raws[0], zs[1], raws[1], d, False)
+        assert torch.equal(rgb2, rgb) and torch.equal(depth2, depth) and torch.equal(acc2, acc)
+
+
+def test_merge_composite_reads_a_list_in_place_through_a_row_index(G):
+    """rows: the background list exists for ALL rays of a batch; the hit rays' rows are read in place (no gathered copy)"""
+    R_all, R = 900, 333
+    _, d_all = rays(G, R_all, 6)
+    (zb,), (rawb,) = _lists(R_all, (256,), 3, ties=False)
+    hit = torch.sort(torch.randperm(R_all, device='cuda')[:R])[0].to(torch.int32)
+    (zh,), (rawh,) = _lists(R, (128,), 4, ties=False)
+    hd = d_all[hit.long()].contiguous()
+    a = G.render.merge_composite_lists([zb, zh], [rawb, rawh], hd, True, rows=[hit, None])
+    b = G.render.merge_composite_lists([zb[hit.long()].contiguous(), zh], [rawb[hit.long()].contiguous(), rawh], hd, True)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("R,S,N", [(1, 3, 1), (1000, 128, 128), (257, 192, 128), (64, 33, 77)])
+def test_coarse_tail_as_one_kernel_is_bit_identical(G, R, S, N):
+    """nm_importance_from_raw (compositing weights -> inverse CDF -> sorted merge in one kernel, sigma read once) == nm_composite's weights +
+    nm_importance_z: same sample positions, same weights, bit for bit"""
+    _, d = rays(G, R, 7)
+    (z,), (raw,) = _lists(R, (S,), 21, ties=False)
+    w = G.render.raw2outputs(raw, z, d)[3]
+    z_ref = G.ray.importance_z(z, w, N)
+    z_one, w_one = G.ray.importance_z_from_raw(raw, z, d, N, want_weights=True)
+    assert torch.equal(z_one, z_ref) and torch.equal(w_one, w)
+    z_two, none = G.ray.importance_z_from_raw(raw, z, d, N)
+    assert none is None and torch.equal(z_two, z_ref)
