@@ -6,6 +6,7 @@
 // 256 B - 1 KiB transaction.  Built with -ffp-contract=off: the reference evaluates `a*b + c` as two
 // roundings (torch elementwise ops), so nothing here may be fused unless written as fmaf().
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -193,46 +194,98 @@ struct MergeLists {
 };
 __global__ __launch_bounds__(256) void merge_composite_kernel(const MergeLists L, int64_t R, const float* __restrict__ rays_d, int white_bkg,
                                                               float* __restrict__ rgb, float* __restrict__ depth, float* __restrict__ acc) {
-    extern __shared__ float4 lds_v4[];
+    extern __shared__ float lds_f[];
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int St = L.S_total;
-    // per wave: merged records [St] float4 | merged z [St] | the lists' z, concatenated [St]
-    float4* mraw = lds_v4 + (size_t)wib * ((size_t)St + (St + 1) / 2);
-    float* mz = reinterpret_cast<float*>(mraw + St);
-    float* lz = mz + St;
+    // per wave: the lists' z, concatenated [St] | merged z [St] | merged source (list << 16 | index) [St].  The records themselves are
+    // read from global memory in merged order by the compositing pass (runs of one list: coalesced), once each.
+    // (Measured, 524 288 rays x (320 + 3 x 192): 9.0 ms against 16.6 ms for three nm_merge_sorted + nm_composite; staging the records in
+    //  LDS at their merged position as well -- 24 B per sample, 7 waves per CU instead of 12 -- 13.8 ms: the kernel is bound by the latency
+    //  of the per-ray chains (searches, the f64 transmittance scan), i.e. by the waves in flight, not by bytes.)
+    float* lz = lds_f + (size_t)wib * 3 * St;
+    float* mz = lz + St;
+    unsigned* msrc = reinterpret_cast<unsigned*>(mz + St);
+    int off[kMaxMergeLists + 1];
+    off[0] = 0;
+#pragma unroll
+    for (int l = 0; l < kMaxMergeLists; ++l) off[l + 1] = off[l] + L.S[l];
+    int steps = 0;                                                 // binary-search steps: enough for the longest list
+#pragma unroll
+    for (int l = 0; l < kMaxMergeLists; ++l)
+        while ((1 << steps) <= L.S[l]) ++steps;
     for (int64_t r0 = blockIdx.x * (int64_t)wpb; r0 < R; r0 += (int64_t)gridDim.x * wpb) {
         const bool live = r0 + wib < R;
         const int64_t r = live ? r0 + wib : R - 1;
-        int off = 0;
-        for (int l = 0; l < L.k; ++l) {
-            const int64_t row = L.rows[l] ? (int64_t)L.rows[l][r] : r;
-            const float* zr = L.z[l] + row * L.S[l];
-            for (int i = lane; i < L.S[l]; i += 64) lz[off + i] = zr[i];
-            off += L.S[l];
+        const float4* rbase[kMaxMergeLists];
+#pragma unroll
+        for (int l = 0; l < kMaxMergeLists; ++l) {
+            rbase[l] = nullptr;
+            if (l < L.k) {
+                const int64_t row = L.rows[l] ? (int64_t)L.rows[l][r] : r;
+                const float* zr = L.z[l] + row * L.S[l];
+                rbase[l] = L.raw[l] + row * L.S[l];
+                for (int i = lane; i < L.S[l]; i += 64) lz[off[l] + i] = zr[i];
+            }
         }
         __syncthreads();
-        off = 0;
-        for (int l = 0; l < L.k; ++l) {
-            const int64_t row = L.rows[l] ? (int64_t)L.rows[l][r] : r;
-            const float4* rr = L.raw[l] + row * L.S[l];
-            for (int i = lane; i < L.S[l]; i += 64) {
-                const float v = lz[off + i];
-                int k = i, o2 = 0;
-                for (int m = 0; m < L.k; ++m) {
-                    if (m < l) k += upper_bound_lds(lz + o2, L.S[m], v);           // an earlier list's equal samples come first
-                    else if (m > l) k += lower_bound_lds(lz + o2, L.S[m], v);
-                    o2 += L.S[m];
-                }
-                mz[k] = v;
-                mraw[k] = rr[i];
+        // position in the merged order = own index + per other list the number of its samples that come first (an earlier list's
+        // equal samples do, a later list's do not).  Branch-free searches with a fixed number of steps, the lists side by side and two
+        // elements per lane, so that the LDS round trips of a step overlap instead of forming one chain per list.
+        for (int e0 = 0; e0 < St; e0 += 128) {
+            int e[2], l_of[2], cnt[2][kMaxMergeLists];
+            float v[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                e[q] = e0 + 64 * q + lane;
+                const int ec = e[q] < St ? e[q] : St - 1;
+                v[q] = lz[ec];
+                l_of[q] = (ec >= off[1]) + (ec >= off[2]) + (ec >= off[3]);
+#pragma unroll
+                for (int m = 0; m < kMaxMergeLists; ++m) cnt[q][m] = 0;
             }
-            off += L.S[l];
+            for (int st = steps - 1; st >= 0; --st) {
+                const int half = 1 << st;
+                float x[2][kMaxMergeLists];
+                // all eight probes of the step are issued before any is used (an unused list has S = 0: its count stays 0)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int m = 0; m < kMaxMergeLists; ++m) {
+                        const int t = cnt[q][m] + half;
+                        x[q][m] = lz[off[m] + (t <= L.S[m] ? t - 1 : 0)];
+                    }
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int m = 0; m < kMaxMergeLists; ++m) {
+                        const int t = cnt[q][m] + half;
+                        const bool first = m < l_of[q] ? x[q][m] <= v[q] : x[q][m] < v[q];
+                        cnt[q][m] = (t <= L.S[m] && first) ? t : cnt[q][m];
+                    }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (e[q] >= St) continue;
+                int k = e[q] - off[l_of[q]];
+#pragma unroll
+                for (int m = 0; m < kMaxMergeLists; ++m)
+                    if (m < L.k && m != l_of[q]) k += cnt[q][m];
+                mz[k] = v[q];
+                msrc[k] = ((unsigned)l_of[q] << 16) | (unsigned)(e[q] - off[l_of[q]]);
+            }
         }
         __syncthreads();
         const float dx = rays_d[r * 3 + 0], dy = rays_d[r * 3 + 1], dz = rays_d[r * 3 + 2];
         const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
-        const CompositeSums c = composite_ray(St, dnorm, lane, nullptr, [&](int s) { return mraw[s]; }, [&](int s) { return mz[s]; }, [&](int, float) {});
+        const CompositeSums c = composite_ray(St, dnorm, lane, nullptr,
+                                              [&](int s) {
+                                                  const unsigned src = msrc[s];
+                                                  const unsigned l = src >> 16;
+                                                  const float4* base = l == 0 ? rbase[0] : l == 1 ? rbase[1] : l == 2 ? rbase[2] : rbase[3];
+                                                  return base[src & 0xffffu];
+                                              },
+                                              [&](int s) { return mz[s]; }, [&](int, float) {});
         if (lane == 0 && live) composite_store(c, white_bkg, r, rgb, nullptr, acc, depth);
         __syncthreads();
     }
@@ -543,8 +596,8 @@ int nm_merge_composite_lists(int k, const float* const* z, const float* const* r
         }
     }
     if (R == 0) return NM_OK;
-    const size_t per_wave = ((size_t)L.S_total + (L.S_total + 1) / 2) * 16;
-    NM_REQUIRE(per_wave <= 64 * 1024, "nm_merge_composite_lists: %d merged samples exceed the per-wave LDS budget", L.S_total);
+    const size_t per_wave = (size_t)L.S_total * 12;
+    NM_REQUIRE(per_wave <= 64 * 1024 && L.S_total < 65536, "nm_merge_composite_lists: %d merged samples exceed the per-wave LDS budget", L.S_total);
     int wpb = (int)((64 * 1024) / per_wave);
     if (wpb > 4) wpb = 4;
     hipLaunchKernelGGL(merge_composite_kernel, dim3(grid_for(R, wpb)), dim3(64 * wpb), per_wave * wpb, nm::as_stream(stream), L, R, rays_d, white_bkg, rgb,

@@ -223,6 +223,48 @@ def test_near_far_and_compaction(H, golden):
         assert h.numel() == 0 and m.numel() == R2
 
 
+def test_near_far_wave_skip_is_bit_identical(H):
+    """near_far_kernel skips the vertex loop for a wave whose 64 rays all pass the body's bounding sphere at more than radius + tau.
+    The same rays once grouped by distance from the body (whole waves far away: skipped) and once interleaved with a ray through the
+    body's centre in every wave (nothing skipped) must give the same near / far bit for bit -- grazing rays at the 0.2 shell included --
+    and so must rays seen from far away, non-unit directions (never skipped) and a single vertex."""
+    from neuman_hip import synthetic
+    rng = np.random.default_rng(11)
+    verts = (synthetic.human_vertex_cloud(0) + np.array([0.3, -0.1, 0.2], np.float32)).astype(np.float32)
+    for cam_z, spread in ((-3.0, 0.6), (-40.0, 0.05), (-3.0, 0.25)):
+        R = 64 * 300
+        o = np.tile(np.array([[0.2, 0.0, cam_z]], np.float32), (R, 1))
+        tgt = rng.normal(size=(R, 3)).astype(np.float32) * spread * abs(cam_z) * np.array([1.0, 1.0, 0.0], np.float32) + verts.mean(0)
+        d = tgt - o
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        miss_dist = np.linalg.norm(np.cross(verts.mean(0) - o, d), axis=1)
+        order = np.argsort(miss_dist)                                       # grouped: the last waves are far from the body
+        o_g, d_g = o[order], d[order]
+        n_g, f_g = H.ray.geometry_guided_near_far(cu(o_g), cu(d_g), cu(verts), 0.2)
+        # interleaved: every wave of 64 holds one ray through the centre in lane 0
+        R2 = (R // 63) * 64
+        keep = R // 63 * 63
+        o_i, d_i = np.empty((R2, 3), np.float32), np.empty((R2, 3), np.float32)
+        o_i[:], d_i[:] = o[0], (verts.mean(0) - o[0]) / np.linalg.norm(verts.mean(0) - o[0])
+        slots = np.arange(R2)[np.arange(R2) % 64 != 0]
+        o_i[slots], d_i[slots] = o_g[:keep], d_g[:keep]
+        n_i, f_i = H.ray.geometry_guided_near_far(cu(o_i), cu(d_i), cu(verts), 0.2)
+        n_g, f_g, n_i, f_i = (x.cpu().numpy() for x in (n_g, f_g, n_i, f_i))
+        np.testing.assert_array_equal(n_g[:keep], n_i[slots])
+        np.testing.assert_array_equal(f_g[:keep], f_i[slots])
+        hit = n_g < f_g
+        assert 0.02 < hit.mean() < 0.999 and np.isposinf(n_g[~hit]).all() and np.isneginf(f_g[~hit]).all()
+    # directions that are not unit vectors: the reference's expression as it is, never skipped
+    d2 = (d_g * 1.7).astype(np.float32)
+    n_a, f_a = H.ray.geometry_guided_near_far(cu(o_g), cu(d2), cu(verts), 0.2)
+    on, of = O.geometry_guided_near_far(o_g, d2, verts, 0.2)
+    assert ((n_a.cpu().numpy() < f_a.cpu().numpy()) != (on < of)).mean() < 2e-3
+    # one vertex: the sphere has radius 0
+    n_1, f_1 = H.ray.geometry_guided_near_far(cu(o_g), cu(d_g), cu(verts[:1]), 0.2)
+    on, of = O.geometry_guided_near_far(o_g, d_g, verts[:1], 0.2)
+    np.testing.assert_array_equal(n_1.cpu().numpy() < f_1.cpu().numpy(), on < of)
+
+
 @pytest.mark.parametrize("R,Sa,Sb", [(50, 256, 128), (3, 1, 1), (17, 320, 192), (4, 512, 192), (2, 704, 192)])
 def test_merge_sorted_vs_oracle(H, R, Sa, Sb):
     rng = np.random.default_rng(Sa + Sb)
