@@ -206,6 +206,10 @@ int nm_transmittance_chunk(const float* raw, const float* z_vals, const float* r
  * successor in the merged order, and the transmittance the early-termination cut is decided on is the merged list's. */
 int nm_transmittance_chunk_dz(const float* raw, const float* dz, const float* rays_d, const int32_t* ray_idx, const int32_t* n_rays_dev,
                               int64_t n_rays, int s0, int S, int S_total, float* T, nm_stream_t stream);
+/* Debug: the 4-wave / two-sub-tile NM_PREC_I8X3 kernel (csrc/mlp_i8t.hip) on n points, plus the activation state of its FIRST tile after
+ * `stage` (0..9): state [256 lanes][130] = the two sub-tiles' resident input fragments of the next stage (128 dwords) and their row scales.
+ * What the generated instruction stream is checked against stage by stage (tests/test_hip_i8_as.py). */
+int nm_mlp_forward_i8t_debug(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int stage, uint32_t* state, float* out, nm_stream_t stream);
 /* Debug: stop after `stage` and write that stage's activations as f32 [n, width_of_stage]:
  *   -1 -> position PE (64 wide, col 63 = 0);  0..7 -> relu(pts_linears[i]) (256);
  *    8 -> feature_linear output (256);  9 -> relu(views_linears[0]) (128). */
