@@ -691,6 +691,7 @@ class Gen:
     def build(self):
         A = self.A
         A.comment("constants")
+        A.salu(f"s_mov_b32 s{S_KOFF}, m0")
         A.salu(f"s_mov_b32 s{S_SEL_LO}, 0x06040200")
         A.salu(f"s_mov_b32 s{S_SEL_HI}, 0x07050301")
         A.salu(f"s_mov_b32 s{S_C128}, 0x00800080")
@@ -713,6 +714,7 @@ class Gen:
         self.hidden_stage_body()
         self.dump_body()
         A.raw(".Li8t_end:")
+        A.salu(f"s_mov_b32 m0, s{S_KOFF}")
         A.nop(Asm.MFMA_D_STATES)
         return A
 
@@ -751,8 +753,13 @@ __device__ __forceinline__ void stages_asm(const Args8t& A, const MlpArgs& a, Ri
     register unsigned v_cp0 asm("v{V_CP0}") = (unsigned)((uintptr_t)R.src - (uintptr_t)A.image8);       // lane * 16 + wave * 1024
     float4* rec = reinterpret_cast<float4*>(a.out);
     const int64_t ia = row0 + s, ib = row0 + 32 + s;
-    const unsigned long long pa = (g == 0 && ia < a.n) ? (unsigned long long)(uintptr_t)(rec + sample_record(a, ia)) : 0ull;
-    const unsigned long long pb = (g == 0 && ib < a.n) ? (unsigned long long)(uintptr_t)(rec + sample_record(a, ib)) : 0ull;
+    // (branch-free on purpose: hipcc places the spill of a value that lives across the statement below at the top of the join block of a
+    //  divergent region, BEFORE the exec mask is restored -- half the lanes then reload garbage in the next tile.  The record index is
+    //  computed for a clamped row by every lane, the predicate is a select.)
+    const int64_t ca = ia < a.n ? ia : a.n - 1, cb = ib < a.n ? ib : a.n - 1;
+    const unsigned long long qa = (unsigned long long)(uintptr_t)(rec + sample_record(a, ca)), qb = (unsigned long long)(uintptr_t)(rec + sample_record(a, cb));
+    const unsigned long long pa = (g == 0 && ia < a.n) ? qa : 0ull;
+    const unsigned long long pb = (g == 0 && ib < a.n) ? qb : 0ull;
     register unsigned v_outa0 asm("v{V_OUTA}") = (unsigned)pa;
     register unsigned v_outa1 asm("v{V_OUTA + 1}") = (unsigned)(pa >> 32);
     register unsigned v_outb0 asm("v{V_OUTB}") = (unsigned)pb;
@@ -768,16 +775,32 @@ __device__ __forceinline__ void stages_asm(const Args8t& A, const MlpArgs& a, Ri
     register float s_ug asm("s{S_UG}") = u_g;
     register float s_ub asm("s{S_UB}") = u_b;
     register float s_sigsc asm("s{S_SIGSC}") = a.sigma_scale;
-    register int s_dbgst asm("s{S_DBGST}") = (A.dbg && tile == 0 && blockIdx.x == 0) ? A.dbg_stage : -1;
+    register int s_dbgst asm("s{S_DBGST}") = (A.dbg && tile == A.dbg_tile && blockIdx.x == 0) ? A.dbg_stage : -1;
     register unsigned s_dbg0 asm("s{S_DBG}") = (unsigned)(uintptr_t)A.dbg;
     register unsigned s_dbg1 asm("s{S_DBG + 1}") = (unsigned)((unsigned long long)(uintptr_t)A.dbg >> 32);
     register unsigned s_kappa asm("s{S_KAPPA}") = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)kappa);
+#ifdef NM_I8T_SYNC
+    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
     asm volatile(
+#ifdef NM_I8T_EMPTY
+        "s_nop 0\\n\\t"
+#else
 {body}
+#endif
         : "+s"(s_off), "+s"(s_slot)
         : "v"(v_rdbase), "v"(v_bias), "v"(v_pe), "v"(v_cp0), "v"(v_outa0), "v"(v_outa1), "v"(v_outb0), "v"(v_outb1), "v"(v_dbgoff), "s"(s_img0), "s"(s_img1), "s"(s_ring0), "s"(s_usig), "s"(s_ur), "s"(s_ug),
           "s"(s_ub), "s"(s_sigsc), "s"(s_dbgst), "s"(s_dbg0), "s"(s_dbg1), "s"(s_kappa)
+#ifdef NM_I8T_FEWCLOB
+        : {", ".join(c for c in clob if not (c.startswith('"a') or (c.startswith('"v') and c[2:-1].isdigit() and int(c[2:-1]) >= 128)))});
+#else
         : {", ".join(clob)});
+#endif
+#ifdef NM_I8T_SYNC
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+#endif
     R.off = (int)s_off;
     R.slot = (int)s_slot;
 }}
