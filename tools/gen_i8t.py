@@ -379,20 +379,22 @@ class Gen:
     # ---------------------------------------------------------------------------------------------------------------------------------------
     # blocks
     # ---------------------------------------------------------------------------------------------------------------------------------------
-    def i8_block(self, nsteps, fillers, per_gap=5):
+    def i8_block(self, nsteps, fillers, per_gap=5, pre=(), urgent=None):
         """one ring block of `nsteps` limb k-steps for both sub-tiles: four accumulator chains (A.cross, A.hihi, B.cross, B.hihi), every
         weight fragment read from the ring once for six MFMAs; `fillers` (closures) go into the gaps between MFMAs, the block's ring copies
-        first among them"""
+        first among them.  pre: instructions that must precede the first MFMA; urgent[s]: instructions that must be issued before the MFMAs
+        of step s + 1 (the requantisation of the previous stage's block s + 1 = this stage's input of step s + 1): spread over step s."""
         A = self.A
         plan = self.ring_enter()
         copies = self.copy_fillers(plan)
-        fillers = list(fillers)
-        # spread the copies over the block: one right away (frees nobody), the others every other step
-        fill_iter = iter(fillers)
+        fill_iter = iter(list(fillers))
+        urgent = urgent or {}
         wb = lambda s, part: ar(A_W + 8 * (s & 1) + 4 * part, 4)                 # noqa: E731
         rd = vr(V_RD)
         A.ds_read128(wb(0, 0), rd, 0)
         A.ds_read128(wb(0, 1), rd, 1024)
+        for f in pre:
+            f()
         copy_steps = sorted(set((k * nsteps) // max(1, len(copies)) for k in range(len(copies))))
         ci = 0
         for s in range(nsteps):
@@ -403,6 +405,8 @@ class Gen:
             if ci < len(copies) and s == copy_steps[ci]:
                 gap_extra.append(copies[ci])
                 ci += 1
+            urg = list(urgent.get(s, ()))
+            per_urg = (len(urg) + 5) // 6
             first = s == 0
             seq = []
             for h in H:
@@ -417,12 +421,18 @@ class Gen:
                 while gap_extra and budget > 0:
                     gap_extra.pop(0)()
                     budget -= 1
+                for _ in range(per_urg):
+                    if urg:
+                        urg.pop(0)()
+                        budget -= 1
                 while budget > 0:
                     f = next(fill_iter, None)
                     if f is None:
                         break
                     f()
                     budget -= 1
+            for f in gap_extra + urg:
+                f()
         while ci < len(copies):
             copies[ci]()
             ci += 1
@@ -467,8 +477,23 @@ class Gen:
     # ---------------------------------------------------------------------------------------------------------------------------------------
     # stage tails
     # ---------------------------------------------------------------------------------------------------------------------------------------
-    def tail(self, homes, nblk, relu, max_now):
-        """row maximum (recomputed over all outputs when max_now), row scale, requantisation of the stage's outputs into X"""
+    def collect(self, fn):
+        """run an emitting function with the emitter in recording mode -> the list of closures that replay its instructions one by one"""
+        rec = []
+        A = self.A
+        real_op = A.op
+        A.op = lambda *a, **k: rec.append(lambda a=a, k=k: real_op(*a, **k))
+        try:
+            fn()
+        finally:
+            A.op = real_op
+        return rec
+
+    def finish(self, homes, nblk, relu, max_now):
+        """end of a stage: the row maximum (recomputed over all outputs when max_now: stages whose encoding part came last) and the row
+        scales.  The requantisation itself is DEFERRED: -> plan[b] = the instructions that turn output block b of both sub-tiles into
+        X[.].h[b], X[.].l[b]; the next stage issues plan[0] before its first MFMA and plan[s + 1] under the MFMAs of its first block's step s
+        (its input of step s + 1), so that only a sixteenth of the requantisation is exposed."""
         A = self.A
         for hi, h in enumerate(H):
             if max_now:
@@ -484,16 +509,41 @@ class Gen:
                     for r in range(1, 16, 2):
                         self.max2(hi, src(r - 1), src(r), relu)()
             self.row_scale(hi)
+        plan = []
         for b in range(nblk):
-            for h in H:
-                slot = homes[(h, b)]
-                if slot.kind == 'a':
-                    for f in self.unpark(slot, V_VB):
-                        f()
-                    base = V_VB
-                else:
-                    base = slot.base
-                self.quant(h, b, base, relu)
+            def one(b=b):
+                for h in H:
+                    slot = homes[(h, b)]
+                    if slot.kind == 'a':
+                        for f in self.unpark(slot, V_VB):
+                            f()
+                        base = V_VB
+                    else:
+                        base = slot.base
+                    self.quant(h, b, base, relu)
+            plan.append(self.collect(one))
+        return plan
+
+    def quant_plan(self, homes, nblk, relu):
+        """the deferred requantisation of a PREVIOUS stage as seen from the next one (same instructions as finish() returns)"""
+        plan = []
+        for b in range(nblk):
+            def one(b=b):
+                for h in H:
+                    slot = homes[(h, b)]
+                    if slot.kind == 'a':
+                        for f in self.unpark(slot, V_VB):
+                            f()
+                        base = V_VB
+                    else:
+                        base = slot.base
+                    self.quant(h, b, base, relu)
+            plan.append(self.collect(one))
+        return plan
+
+    @staticmethod
+    def first_block_args(plan):
+        return dict(pre=plan[0], urgent={s: plan[s + 1] for s in range(len(plan) - 1)})
 
     def sxin(self, kappa_off_reg):
         """sxin = sx * (256 * kappa[st]) for both sub-tiles; kappa read from LDS at kappa base + kappa_off_reg (a VGPR holding the address)"""
@@ -519,13 +569,15 @@ class Gen:
     # ---------------------------------------------------------------------------------------------------------------------------------------
     # stages
     # ---------------------------------------------------------------------------------------------------------------------------------------
-    def hidden_blocks(self, bias_addr, bias_off, relu, nblk=8, homes=HOME, extra_first=()):
+    def hidden_blocks(self, bias_addr, bias_off, relu, nblk=8, homes=HOME, extra_first=(), first_args=None, after_first=None):
         """the i8 blocks of a 256-wide (or, stage 9, 128-wide) stage.  The dequantisation of block b - 1 -- and the move of a block that
         does not live in the VALU half of the file to its parking place -- ride under the MFMAs of block b; the last block's follows its
         combine."""
         pending = list(extra_first)              # fillers that ride under the next block
         for b in range(nblk):
-            self.i8_block(8, pending)
+            self.i8_block(8, pending, **((first_args or {}) if b == 0 else {}))
+            if b == 0 and after_first is not None:
+                after_first()
             pending = []
             land = {}
             for h in H:
@@ -550,7 +602,7 @@ class Gen:
                 for q in range(4):
                     A.ds_read128(slot.r(4 * q, 4), vr(V_BIAS), (stage_b_off(0) + 32 * b) * 4 + 32 * q)
             self.enc_block([(h, HOME[(h, b)], 0) for h in H], {'A': 0, 'B': POS_B}, 4)
-        self.tail(HOME, 8, True, True)
+        self.finish(HOME, 8, True, True)
 
     def hidden_stage_body(self):
         """stages 1..7 as a subroutine: s[S_ST] = stage, V_BIASST = bias base of the stage; stage 5 runs its four encoding blocks"""
@@ -560,7 +612,17 @@ class Gen:
         ka = self.kappa_addr(st_sgpr=S_ST)
         self.sxin(ka)
         start_blk = self.blk
-        pending = self.hidden_blocks(vr(V_BIASST), 0, True)
+
+        def dump_prev():                              # X of the previous stage is complete after this stage's first block
+            A.salu(f"s_sub_u32 s{S_TMP}, s{S_ST}, 1")
+            A.salu(f"s_cmp_eq_u32 s{S_DBGST}, s{S_TMP}")
+            A.raw(".Li8t_hidden_dump_go:")
+            A.raw("s_cbranch_scc0 .Li8t_hidden_nodump")
+            A.barrier_state()
+            A.raw(f"s_call_b64 s[{S_RET2}:{S_RET2 + 1}], .Li8t_dump")
+            A.raw(".Li8t_hidden_nodump:")
+            A.barrier_state()
+        pending = self.hidden_blocks(vr(V_BIASST), 0, True, first_args=self.first_block_args(self.quant_plan(HOME, 8, True)), after_first=dump_prev)
         for f in pending:
             f()
         A.salu(f"s_cmp_eq_u32 s{S_ST}, 5")
@@ -584,7 +646,7 @@ class Gen:
                     self.max2(hi, src(r - 1), src(r), True)()
         A.raw(".Li8t_hidden_tail:")
         A.barrier_state()
-        self.tail(HOME, 8, True, False)
+        self.finish(HOME, 8, True, False)
         A.barrier_state()
         A.raw(f"s_setpc_b64 s[{S_RET}:{S_RET + 1}]")
         self.blk = start_blk                     # (the callers account for the ring blocks)
@@ -604,8 +666,9 @@ class Gen:
         A.comment("==== stage 8: alpha (row 0 of its block, first in the stream) + feature (linear, 256)")
         self.sxin(self.kappa_addr(st=8))
         boff = stage_b_off(8) * 4
-        # alpha block
-        self.i8_block(8, [])
+        # alpha block; stage 7's requantisation rides under it
+        self.i8_block(8, [], **self.first_block_args(self.quant_plan(HOME, 8, True)))
+        self.dump_check(7)
         for h in H:
             for f in self.combine(h, LAND[h])[:1]:
                 f()
@@ -617,23 +680,25 @@ class Gen:
         pending = self.hidden_blocks(vr(V_BIAS), boff, False)
         for f in pending:
             f()
-        self.tail(HOME, 8, False, False)
+        self.finish(HOME, 8, False, False)
 
     def stage9(self):
         A = self.A
         A.comment("==== stage 9: views layer, K = feature(256) ++ d_pe(32), N = 128, ReLU")
         self.sxin(self.kappa_addr(st=9))
-        pending = self.hidden_blocks(vr(V_BIAS), stage_b_off(9) * 4, True, nblk=4, homes=HOME9)
+        pending = self.hidden_blocks(vr(V_BIAS), stage_b_off(9) * 4, True, nblk=4, homes=HOME9, first_args=self.first_block_args(self.quant_plan(HOME, 8, False)),
+                                     after_first=lambda: self.dump_check(8))
         for f in pending:
             f()
         self.enc_block([(h, HOME9[(h, b)], 2 * b) for b in range(4) for h in H], {'A': DIR_A, 'B': DIR_B}, 2)
-        self.tail(HOME9, 4, True, True)
+        self.finish(HOME9, 4, True, True)
 
     def stage10(self):
         A = self.A
         A.comment("==== stage 10: rgb (rows 0..2 of one block), K = 128; the sample's record")
         self.sxin(self.kappa_addr(st=10))
-        self.i8_block(4, [])
+        self.i8_block(4, [], **self.first_block_args(self.quant_plan(HOME9, 4, True)))
+        self.dump_check(9)
         boff = stage_b_off(10) * 4
         A.ds_read128(vr(V_VB, 4), vr(V_BIAS), boff)
         for hi, h in enumerate(H):
@@ -698,15 +763,11 @@ class Gen:
         for j in range(1, 4):
             A.valu(f"v_add_u32 {vr(V_CP1 + j - 1)}, {j * 4096}, {vr(V_CP0)}", [vr(V_CP1 + j - 1)], [vr(V_CP0)])
         self.stage0()
-        self.dump_check(0)
         for st in range(1, 8):
             self.call_hidden(st)
-            self.dump_check(st)
         assert self.blk == 68, self.blk
         self.stage8()
-        self.dump_check(8)
         self.stage9()
-        self.dump_check(9)
         self.stage10()
         assert self.blk == 83, self.blk
         A.raw("s_branch .Li8t_end")
