@@ -27,7 +27,7 @@ import sys
 import numpy as np
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-OUT = os.path.join(ROOT, "ml-neuman_amd", "csrc", "mlp_i8t_body.h")
+OUT = os.environ.get("I8T_OUT") or os.path.join(ROOT, "ml-neuman_amd", "csrc", "mlp_i8t_body.h")
 
 # ---- layout constants (csrc/mlp_layout.h, csrc/mlp_i8t.hip) ------------------------------------------------------------------------------
 STEP = 2048
@@ -89,8 +89,12 @@ A_X = {('A', 'h'): 0, ('A', 'l'): 32, ('B', 'h'): 64, ('B', 'l'): 96}
 A_W = 128
 A_PARK = 144
 S_IMG, S_RING0, S_OFF, S_SLOT, S_USIG, S_UR, S_UG, S_UB, S_SIGSC, S_DBGST, S_DBG, S_KAPPA = 36, 38, 39, 40, 41, 42, 43, 44, 45, 46, 50, 49
-S_SEL_LO, S_SEL_HI, S_C128, S_REFILL, S_P, S_TMP, S_RET, S_RET2, S_ST, S_SAVE, S_KOFF = 52, 53, 54, 55, 56, 58, 60, 62, 64, 66, 68
+S_SEL_LO, S_SEL_HI, S_C128, S_REFILL, S_P, S_TMP, S_RET, S_RET2, S_ST, S_SAVE, S_KOFF, S_RDOFF = 52, 53, 54, 55, 56, 58, 60, 62, 64, 66, 68, 59
 H = ('A', 'B')
+PROBE_NO_VALU = os.environ.get("I8T_NO_VALU") == "1"      # timing probes: the stream without its VALU work / without its weight reads (garbage results)
+PROBE_NO_WREAD = os.environ.get("I8T_NO_WREAD") == "1"
+PROBE_NO_MFMA = os.environ.get("I8T_NO_MFMA") == "1"
+PER_GAP = int(os.environ.get("I8T_PER_GAP", "5"))          # non-MFMA instructions placed behind every MFMA of an i8 block
 
 
 class Slot:
@@ -125,7 +129,7 @@ HOME9 = {(h, b): VSLOT[2 * b + (h == 'B')] for b in range(4) for h in H}      # 
 
 # ---- the emitter ----------------------------------------------------------------------------------------------------------------------------
 class Asm:
-    MFMA_D_STATES = 16          # MFMA result -> any reader / writer that is not the accumulate chain (8-pass XDL needs 12; margin)
+    MFMA_D_STATES = int(os.environ.get("I8T_MFMA_D", "16"))          # MFMA result -> any reader / writer that is not the accumulate chain (8-pass XDL needs 12; margin)
     VALU_MFMA_STATES = 2        # VALU-written register -> MFMA operand
     VALU_PERM_STATES = 2        # VALU-written register -> v_permlane32_swap
     TRANS_STATES = 1
@@ -230,6 +234,8 @@ class Asm:
 
     # -- shorthands
     def valu(self, text, dst, src):
+        if PROBE_NO_VALU and not text.startswith(("v_add_u32", "v_mov_b32", "v_cmp")):
+            return
         self.op('valu', text, dst, src)
 
     def salu(self, text):
@@ -237,13 +243,20 @@ class Asm:
 
     def ds_read128(self, dst, addr, off):
         assert 0 <= off < 65536 and off % 16 == 0, off
+        if PROBE_NO_WREAD and dst.startswith(f"a[{A_W}") or PROBE_NO_WREAD and dst.startswith(f"a[{A_W + 4}") or PROBE_NO_WREAD and dst.startswith(f"a[{A_W + 8}") \
+                or PROBE_NO_WREAD and dst.startswith(f"a[{A_W + 12}"):
+            return
         self.op('ds_read', f"ds_read_b128 {dst}, {addr} offset:{off}", [dst], [addr])
 
     def mfma_i8(self, acc, a, b, first):
+        if PROBE_NO_MFMA:
+            return
         c = "0" if first else acc
         self.op('mfma', f"v_mfma_i32_32x32x32_i8 {acc}, {a}, {b}, {c}", [acc], [a, b] + ([] if first else [acc]), chain=None if first else acc)
 
     def mfma_bf(self, acc, a, b):
+        if PROBE_NO_MFMA:
+            return
         self.op('mfma', f"v_mfma_f32_32x32x16_bf16 {acc}, {a}, {b}, {acc}", [acc], [a, b, acc], chain=acc)
 
 
@@ -260,31 +273,32 @@ class Gen:
         i %= 83
         return 4 if i < 8 else (8 if i < 82 else 4)
 
-    def ring_enter(self):
-        """top of ring block self.blk: own pieces landed (counted vmcnt), barrier, read pointer of the block, refill slot = the one block
-        blk - 1 has just given up; returns the copy plan of block blk + 2 (pieces per wave, its steps)"""
+    def ring_start(self):
+        """top of ring block self.blk: its read pointer.  The block was handed over inside its predecessor (ring_handover): its data is
+        visible to every wave, s[S_RDOFF] is its slot's offset."""
+        A = self.A
+        A.comment(f"---- ring block {self.blk}")
+        A.valu(f"v_add_u32 {vr(V_RD)}, s{S_RDOFF}, {vr(V_RDBASE)}", [vr(V_RD)], [vr(V_RDBASE)])
+
+    def ring_handover(self):
+        """inside block i = self.blk, two k-steps before its end: hand-over of block i + 1.  Every wave waits for its own pieces of block
+        i + 1 (issued one block ago: nothing younger is in flight) and meets the others: the block's data is visible from here on, and
+        everybody is at least this far into block i, i.e. done with block i - 1, whose slot takes the pieces of block i + 2 -> their copy plan.
+        s[S_SLOT] = slot of the block handed over next."""
         A = self.A
         i = self.blk
-        np1 = 2 * self.block_steps(i + 1) // 4
-        A.comment(f"---- ring block {i}")
-        A.raw(f"s_waitcnt vmcnt({np1})")
+        A.raw("s_waitcnt vmcnt(0)")
         A.raw("s_barrier")
-        A.salu(f"s_lshl_b32 s{S_TMP}, s{S_SLOT}, 14")
-        A.valu(f"v_add_u32 {vr(V_RD)}, s{S_TMP}, {vr(V_RDBASE)}", [vr(V_RD)], [vr(V_RDBASE)])
-        # refill = slot == 0 ? 2 : slot - 1 ;  slot = slot == 2 ? 0 : slot + 1
-        A.salu(f"s_sub_u32 s{S_TMP}, s{S_SLOT}, 1")
-        A.salu(f"s_cmp_eq_u32 s{S_SLOT}, 0")
-        A.salu(f"s_cselect_b32 s{S_TMP}, 2, s{S_TMP}")
-        A.salu(f"s_lshl_b32 s{S_TMP}, s{S_TMP}, 14")
-        A.salu(f"s_add_u32 s{S_REFILL}, s{S_RING0}, s{S_TMP}")
+        A.salu(f"s_lshl_b32 s{S_RDOFF}, s{S_SLOT}, 14")                        # block i + 1 reads here
         A.salu(f"s_add_u32 s{S_TMP}, s{S_SLOT}, 1")
         A.salu(f"s_cmp_eq_u32 s{S_SLOT}, 2")
-        A.salu(f"s_cselect_b32 s{S_SLOT}, 0, s{S_TMP}")
+        A.salu(f"s_cselect_b32 s{S_SLOT}, 0, s{S_TMP}")                        # slot of block i + 2 = the one block i - 1 gave up
+        A.salu(f"s_lshl_b32 s{S_TMP}, s{S_SLOT}, 14")
+        A.salu(f"s_add_u32 s{S_REFILL}, s{S_RING0}, s{S_TMP}")
         A.salu(f"s_add_u32 s{S_P}, s{S_IMG}, s{S_OFF}")
         A.salu(f"s_addc_u32 s{S_P + 1}, s{S_IMG + 1}, 0")
         n2 = self.block_steps(i + 2)
-        self.blk += 1
-        return [('piece', j, n2) for j in range(2 * n2 // 4)]
+        return self.copy_fillers([('piece', j, n2) for j in range(2 * n2 // 4)])
 
     def copy_piece(self, j, n2, last):
         A = self.A
@@ -318,16 +332,20 @@ class Gen:
         return [lambda r=r: self.A.valu(f"v_lshl_add_u32 {slot.r(r)}, {vr(ah + r)}, 8, {vr(ac + r)}", [slot.r(r)], [vr(ah + r), vr(ac + r)]) for r in range(16)]
 
     def dequant(self, h, slot, relu, with_max=True, regs=range(16)):
-        """f = fma(float(t), sxin, bias) in place; running row maximum (max of f under ReLU, of |f| otherwise)"""
+        """f = fma(float(t), sxin, bias) in place; running row maximum (max of f under ReLU, of |f| otherwise).  Emitted by kind -- all the
+        conversions, then the multiply-adds, then the maxima -- so that no instruction follows the one it depends on."""
         hi = H.index(h)
         out = []
         regs = list(regs)
         for r in regs:
             out.append(lambda r=r: self.A.valu(f"v_cvt_f32_i32 {slot.r(r)}, {slot.r(r)}", [slot.r(r)], [slot.r(r)]))
+        for r in regs:
             out.append(lambda r=r: self.A.valu(f"v_fma_f32 {slot.r(r)}, {slot.r(r)}, {vr(V_SXIN[hi])}, {vr(V_VB + r)}", [slot.r(r)],
                                                [slot.r(r), vr(V_SXIN[hi]), vr(V_VB + r)]))
-            if with_max and (r & 1):
-                out.append(self.max2(hi, slot.r(r - 1), slot.r(r), relu))
+        if with_max:
+            for r in regs:
+                if r & 1:
+                    out.append(self.max2(hi, slot.r(r - 1), slot.r(r), relu))
         return out
 
     def max2(self, hi, x, y, relu):
@@ -360,7 +378,8 @@ class Gen:
         A.valu(f"v_cndmask_b32 {sx}, 1.0, {t1}, vcc", [sx], [t1, 'vcc'])
 
     def quant(self, h, b, base, relu):
-        """16 outputs in v[base ..] -> X[h].h[b], X[h].l[b]   (mlp_i8as.h quant16; the block's registers are consumed)"""
+        """16 outputs in v[base ..] -> X[h].h[b], X[h].l[b]   (mlp_i8as.h quant16; the block's registers are consumed).  By kind again: the
+        16 multiplies, the 8 packed conversions, the 8 limb offsets, the 8 byte shuffles (in place), the 8 moves into the input file."""
         A = self.A
         hi = H.index(h)
         inv = vr(V_INV[hi])
@@ -368,43 +387,57 @@ class Gen:
             A.valu(f"v_mul_f32 {vr(base + r)}, {vr(base + r)}, {inv}" + (" clamp" if relu else ""), [vr(base + r)], [vr(base + r), inv])
         for i in range(8):
             A.valu(f"v_cvt_pknorm_i16_f32 {vr(base + 2 * i)}, {vr(base + 2 * i)}, {vr(base + 2 * i + 1)}", [vr(base + 2 * i)], [vr(base + 2 * i), vr(base + 2 * i + 1)])
+        for i in range(8):
             A.valu(f"v_pk_add_i16 {vr(base + 2 * i + 1)}, {vr(base + 2 * i)}, s{S_C128}", [vr(base + 2 * i + 1)], [vr(base + 2 * i)])
         xh, xl = A_X[(h, 'h')] + 4 * b, A_X[(h, 'l')] + 4 * b
+        # P[i] sits in register 2 i, Y[i] = P[i] + 128 in 2 i + 1;  lo[k] = perm(P[2k+1], P[2k]) -> register 4 k, hi[k] = perm(Y[2k+1], Y[2k]) -> 4 k + 1
         for k in range(4):
-            A.valu(f"v_perm_b32 {vr(V_T0)}, {vr(base + 4 * k + 2)}, {vr(base + 4 * k)}, s{S_SEL_LO}", [vr(V_T0)], [vr(base + 4 * k + 2), vr(base + 4 * k)])
-            A.valu(f"v_perm_b32 {vr(V_T1)}, {vr(base + 4 * k + 3)}, {vr(base + 4 * k + 1)}, s{S_SEL_HI}", [vr(V_T1)], [vr(base + 4 * k + 3), vr(base + 4 * k + 1)])
-            A.valu(f"v_accvgpr_write_b32 {ar(xl + k)}, {vr(V_T0)}", [ar(xl + k)], [vr(V_T0)])
-            A.valu(f"v_accvgpr_write_b32 {ar(xh + k)}, {vr(V_T1)}", [ar(xh + k)], [vr(V_T1)])
+            A.valu(f"v_perm_b32 {vr(base + 4 * k)}, {vr(base + 4 * k + 2)}, {vr(base + 4 * k)}, s{S_SEL_LO}", [vr(base + 4 * k)], [vr(base + 4 * k + 2), vr(base + 4 * k)])
+            A.valu(f"v_perm_b32 {vr(base + 4 * k + 1)}, {vr(base + 4 * k + 3)}, {vr(base + 4 * k + 1)}, s{S_SEL_HI}", [vr(base + 4 * k + 1)],
+                   [vr(base + 4 * k + 3), vr(base + 4 * k + 1)])
+        for k in range(4):
+            A.valu(f"v_accvgpr_write_b32 {ar(xl + k)}, {vr(base + 4 * k)}", [ar(xl + k)], [vr(base + 4 * k)])
+            A.valu(f"v_accvgpr_write_b32 {ar(xh + k)}, {vr(base + 4 * k + 1)}", [ar(xh + k)], [vr(base + 4 * k + 1)])
 
     # ---------------------------------------------------------------------------------------------------------------------------------------
     # blocks
     # ---------------------------------------------------------------------------------------------------------------------------------------
-    def i8_block(self, nsteps, fillers, per_gap=5, pre=(), urgent=None):
+    def i8_block(self, nsteps, fillers, per_gap=None, pre=(), urgent=None, prefetched=False, prefetch_next=False):
         """one ring block of `nsteps` limb k-steps for both sub-tiles: four accumulator chains (A.cross, A.hihi, B.cross, B.hihi), every
-        weight fragment read from the ring once for six MFMAs; `fillers` (closures) go into the gaps between MFMAs, the block's ring copies
-        first among them.  pre: instructions that must precede the first MFMA; urgent[s]: instructions that must be issued before the MFMAs
-        of step s + 1 (the requantisation of the previous stage's block s + 1 = this stage's input of step s + 1): spread over step s."""
+        weight fragment read from the ring once for six MFMAs; `fillers` (closures) go into the gaps between MFMAs.  pre: instructions that
+        must precede the first MFMA; urgent[s]: instructions that must be issued before the MFMAs of step s + 1 (the requantisation of the
+        previous stage's block s + 1 = this stage's input of step s + 1): spread over step s.  The hand-over of the NEXT ring block happens
+        two steps before the end, the copies of the block after it ride in the last two steps; prefetched: the weights of step 0 were read by
+        the previous block (prefetch_next, after its hand-over)."""
         A = self.A
-        plan = self.ring_enter()
-        copies = self.copy_fillers(plan)
+        per_gap = per_gap or PER_GAP
+        self.ring_start()
         fill_iter = iter(list(fillers))
         urgent = urgent or {}
         wb = lambda s, part: ar(A_W + 8 * (s & 1) + 4 * part, 4)                 # noqa: E731
         rd = vr(V_RD)
-        A.ds_read128(wb(0, 0), rd, 0)
-        A.ds_read128(wb(0, 1), rd, 1024)
+        if not prefetched:
+            A.ds_read128(wb(0, 0), rd, 0)
+            A.ds_read128(wb(0, 1), rd, 1024)
         for f in pre:
             f()
-        copy_steps = sorted(set((k * nsteps) // max(1, len(copies)) for k in range(len(copies))))
-        ci = 0
+        copies = []
         for s in range(nsteps):
             gap_extra = []
+            if s == nsteps - 2:
+                copies = self.ring_handover()
+                if prefetch_next:
+                    gap_extra.append(lambda: A.valu(f"v_add_u32 {vr(V_T2)}, s{S_RDOFF}, {vr(V_RDBASE)}", [vr(V_T2)], [vr(V_RDBASE)]))
             if s + 1 < nsteps:
                 gap_extra.append(lambda s=s: A.ds_read128(wb(s + 1, 0), rd, (s + 1) * STEP))
                 gap_extra.append(lambda s=s: A.ds_read128(wb(s + 1, 1), rd, (s + 1) * STEP + 1024))
-            if ci < len(copies) and s == copy_steps[ci]:
-                gap_extra.append(copies[ci])
-                ci += 1
+            elif prefetch_next:                       # the last step: step 0 of the next block (its buffer was free after the previous step's MFMAs)
+                gap_extra.append(lambda: A.ds_read128(wb(0, 0), vr(V_T2), 0))
+                gap_extra.append(lambda: A.ds_read128(wb(0, 1), vr(V_T2), 1024))
+            if s >= nsteps - 2:                       # this block's copies: half in each of the last two steps
+                k = (len(copies) + 1) // 2 if s == nsteps - 2 else len(copies)
+                gap_extra += copies[:k]
+                copies = copies[k:]
             urg = list(urgent.get(s, ()))
             per_urg = (len(urg) + 5) // 6
             first = s == 0
@@ -433,24 +466,24 @@ class Gen:
                     budget -= 1
             for f in gap_extra + urg:
                 f()
-        while ci < len(copies):
-            copies[ci]()
-            ci += 1
         for f in fill_iter:                       # whatever did not fit under the MFMAs
             f()
+        self.blk += 1
 
     def enc_block(self, chains, pe_off, steps_per_chain, fillers=()):
         """one ring block of split-bf16 steps over the encodings: chains = [(sub-tile, slot, first weight step in the block)], every chain
         runs `steps_per_chain` steps t = 0 .. with the operands of chunk pair t of the sub-tile's encoding rows; the chains are interleaved
-        step by step (a chain's three MFMAs per step depend on each other)"""
+        step by step (a chain's three MFMAs per step depend on each other).  The next ring block is handed over before the last step."""
         A = self.A
-        plan = self.ring_enter()
-        copies = self.copy_fillers(plan)
+        self.ring_start()
         rd, pe = vr(V_RD), vr(V_PE)
-        fill_iter = iter(list(copies) + list(fillers))
+        fill = list(fillers)
         wsteps = sorted(set(ws for _, _, ws in chains))
         assert len(wsteps) * steps_per_chain <= 8
         for t in range(steps_per_chain):
+            if t == steps_per_chain - 1:
+                fill = self.ring_handover() + fill
+            fill_iter = iter(fill)
             # operands of this step: x hi / lo of A and of B -> V_VB[0..15]
             for hi, h in enumerate(H):
                 base = pe_off[h] + t * 2048
@@ -471,8 +504,10 @@ class Gen:
                             f = next(fill_iter, None)
                             if f is not None:
                                 f()
-        for f in fill_iter:
+            fill = list(fill_iter)
+        for f in fill:
             f()
+        self.blk += 1
 
     # ---------------------------------------------------------------------------------------------------------------------------------------
     # stage tails
@@ -575,7 +610,7 @@ class Gen:
         combine."""
         pending = list(extra_first)              # fillers that ride under the next block
         for b in range(nblk):
-            self.i8_block(8, pending, **((first_args or {}) if b == 0 else {}))
+            self.i8_block(8, pending, prefetched=b > 0, prefetch_next=b < nblk - 1, **((first_args or {}) if b == 0 else {}))
             if b == 0 and after_first is not None:
                 after_first()
             pending = []
@@ -762,6 +797,11 @@ class Gen:
         A.salu(f"s_mov_b32 s{S_C128}, 0x00800080")
         for j in range(1, 4):
             A.valu(f"v_add_u32 {vr(V_CP1 + j - 1)}, {j * 4096}, {vr(V_CP0)}", [vr(V_CP1 + j - 1)], [vr(V_CP0)])
+        # the tile's first block was handed over by the previous tile's last (or by the kernel's start-up): its slot precedes s[S_SLOT]
+        A.salu(f"s_sub_u32 s{S_TMP}, s{S_SLOT}, 1")
+        A.salu(f"s_cmp_eq_u32 s{S_SLOT}, 0")
+        A.salu(f"s_cselect_b32 s{S_TMP}, 2, s{S_TMP}")
+        A.salu(f"s_lshl_b32 s{S_RDOFF}, s{S_TMP}, 14")
         self.stage0()
         for st in range(1, 8):
             self.call_hidden(st)

@@ -1,1 +1,3 @@
-for v in emptyfew emptynoinl; do echo "== $v"; NEUMAN_HIP_LIB=$PWD/ml-neuman_amd/lib/exp/libneuman_hip_$v.so timeout 300 python tools/i8t_debug2.py 2>&1 | grep '"which": "tile256"' | cut -c1-120; done
+for v in "$@"; do NEUMAN_HIP_LIB=$PWD/ml-neuman_amd/lib/exp/libneuman_hip_$v.so NEUMAN_I8_KERNEL=t python tools/i8_time.py 2>&1 | grep kernel; done
+NEUMAN_I8_KERNEL=t python tools/i8_time.py 2>&1 | grep kernel
+python tools/i8_time.py 2>&1 | grep kernel
