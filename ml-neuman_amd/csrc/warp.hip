@@ -314,13 +314,20 @@ __device__ __forceinline__ void cswap(uint32_t& a, uint32_t& b) {               
 // The three constants below were swept on the posed-frame workload (pending 4 / 6 / 8 / 12: 8.2 / 8.0 / 7.8 / 7.8 ms; refill
 // threshold 3 / 8: 8.2 / 7.8 ms).
 constexpr int kChunk = 512;
+// samples per wave of a launch: kChunk when there are enough samples to fill the chip that way (a frame's warp: millions), fewer for the
+// small batches of a training iteration (92 k samples = 180 waves of 512 on 256 CUs: 2.5 ms per search, latency-bound; 2048 waves of 64
+// take a tenth of that).  A sample's result does not depend on the chunking.
+inline int chunk_for(int64_t N) {
+    int64_t c = (N / 2048 + 63) / 64 * 64;
+    return (int)(c < 64 ? 64 : c > kChunk ? kChunk : c);
+}
 constexpr int kRefill = 8;                            // idle lanes that trigger a refill (or any, when no lane has work)
 
 template <bool SMALL>
 __global__ __launch_bounds__(64) void search_kernel(Tree tr, int search_all_mode, const float* __restrict__ pts, int64_t N,
                                                                  const TriRec* __restrict__ rec, const int32_t* __restrict__ face_of,
                                                                  const Node* __restrict__ nodes, float* __restrict__ q_out,
-                                                                 int32_t* __restrict__ f_out, int f_stride) {
+                                                                 int32_t* __restrict__ f_out, int f_stride, int chunk) {
     extern __shared__ double lds_raw[];
     const int depth = 3 * (tr.L - 1);
     // node stack entry: {distance^2, node} as float2, or -- SMALL: at most 65,536 nodes and triangles -- one dword holding the
@@ -348,8 +355,8 @@ __global__ __launch_bounds__(64) void search_kernel(Tree tr, int search_all_mode
             k = e.x; id = __float_as_int(e.y);
         }
     };
-    int64_t next = (int64_t)blockIdx.x * kChunk;                                 // wave-uniform: first sample not handed out
-    const int64_t end = next + kChunk < N ? next + kChunk : N;
+    int64_t next = (int64_t)blockIdx.x * chunk;                                  // wave-uniform: first sample not handed out
+    const int64_t end = next + chunk < N ? next + chunk : N;
     bool active = false;
     int64_t i = 0;
     V3 p = {0.f, 0.f, 0.f};
@@ -888,13 +895,14 @@ int nm_warp_to_canonical(nm_mesh_t m, const float* pts, int64_t R, int S, const 
     const bool small = m->n_nodes <= 65536 && m->F <= 65536 && !m->force_wide;
     const int64_t N = R * (int64_t)S;
     NM_REQUIRE(N < (1ll << 31) * (int64_t)kChunk, "nm_warp_to_canonical: too many samples for one launch");
-    const unsigned waves = (unsigned)((N + kChunk - 1) / kChunk);
+    const int chunk = chunk_for(N);
+    const unsigned waves = (unsigned)((N + chunk - 1) / chunk);
     const size_t lds = (size_t)(3 * (m->tr.L - 1) + 1) * 64 * (small ? 4 : 8) + (size_t)(kTriSlots + 1) * 64 * (small ? 2 : 4);
     hipStream_t st = nm::as_stream(stream);
     int32_t* f_out = reinterpret_cast<int32_t*>(can_dirs);
     const int all = m->search == NM_SEARCH_ALL ? 1 : 0;
-    if (small) hipLaunchKernelGGL(search_kernel<true>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, can_pts, f_out, 3);
-    else hipLaunchKernelGGL(search_kernel<false>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, can_pts, f_out, 3);
+    if (small) hipLaunchKernelGGL(search_kernel<true>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, can_pts, f_out, 3, chunk);
+    else hipLaunchKernelGGL(search_kernel<false>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, can_pts, f_out, 3, chunk);
     if (int rc = nm::check_launch("search_kernel")) return rc;
     const int threads = S <= 64 ? 64 : (S <= 128 ? 128 : 256);
     hipLaunchKernelGGL(tail_kernel, dim3((unsigned)R), dim3(threads), (size_t)S * 24, st, pts, S, m->d_verts, m->d_faces, T, can_pts, can_dirs, closest);
@@ -939,11 +947,12 @@ int nm_signed_distance(nm_mesh_t m, const float* pts, int64_t N, float* sdist, i
         }
     }
     const bool small = m->n_nodes <= 65536 && m->F <= 65536 && !m->force_wide;
-    const unsigned waves = (unsigned)((N + kChunk - 1) / kChunk);
+    const int chunk = chunk_for(N);
+    const unsigned waves = (unsigned)((N + chunk - 1) / chunk);
     const size_t lds = (size_t)(3 * (m->tr.L - 1) + 1) * 64 * (small ? 4 : 8) + (size_t)(kTriSlots + 1) * 64 * (small ? 2 : 4);
     const int all = m->search == NM_SEARCH_ALL ? 1 : 0;
-    if (small) hipLaunchKernelGGL(search_kernel<true>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, closest, face, 1);
-    else hipLaunchKernelGGL(search_kernel<false>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, closest, face, 1);
+    if (small) hipLaunchKernelGGL(search_kernel<true>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, closest, face, 1, chunk);
+    else hipLaunchKernelGGL(search_kernel<false>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, closest, face, 1, chunk);
     if (int rc = nm::check_launch("search_kernel")) return rc;
     hipLaunchKernelGGL(signed_distance_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, pts, N, m->d_verts, m->d_faces, m->d_pn, face, closest,
                        sdist);

@@ -117,17 +117,35 @@ class HumanNeRFLoss:
 
     def _signed_distance(self, pts, cap_id=None):
         """igl.signed_distance of the reference (:310, :326) on the device: negative inside the canonical body of frame `cap_id`
-        (:308; one search tree per canonical mesh, built on first use)"""
+        (:308; one search tree per canonical mesh, built on first use).
+
+        `can_mesh` is either ONE mesh -- a (verts [V,3], faces [F,>=3]) pair -- or PER-FRAME meshes: a dict {cap_id: (verts, faces)}
+        or a callable cap_id -> (verts, faces).  (A list / tuple of per-frame pairs is taken as a dict over its indices; anything whose
+        first element is not a [V,3] array is rejected rather than guessed at.)  At most `_CAN_TREE_MAX` trees stay on the device."""
         cm = self.can_mesh
-        one_mesh = isinstance(cm, tuple) or (isinstance(cm, list) and len(cm) == 2 and getattr(cm[0], 'ndim', 0) == 2)
-        per_frame = not one_mesh
-        key = int(cap_id) if per_frame and cap_id is not None else None
+        if callable(cm) or isinstance(cm, dict):
+            per_frame = True
+        elif isinstance(cm, (tuple, list)) and len(cm) == 2 and getattr(np.asarray(cm[0]), 'ndim', 0) == 2 and np.asarray(cm[0]).shape[-1] == 3:
+            per_frame = False
+        elif isinstance(cm, (tuple, list)) and len(cm) > 0 and isinstance(cm[0], (tuple, list)) and len(cm[0]) == 2:
+            per_frame = True
+        else:
+            raise ValueError("can_mesh must be (verts [V,3], faces) or per-frame meshes as a dict / list of such pairs / callable cap_id -> pair")
+        if per_frame and cap_id is None:
+            raise ValueError("per-frame canonical meshes need the batch's cap_id")
+        key = int(cap_id) if per_frame else None
         if key not in self._can_tree:
-            verts, faces = (self.can_mesh(key) if callable(self.can_mesh) else self.can_mesh[key]) if per_frame else self.can_mesh
+            verts, faces = (cm(key) if callable(cm) else cm[key]) if per_frame else cm
             v = torch.as_tensor(np.ascontiguousarray(verts, dtype=np.float32))
+            if v.ndim != 2 or v.shape[1] != 3:
+                raise ValueError(f"canonical mesh vertices must be [V,3], got {tuple(v.shape)}")
+            while len(self._can_tree) >= self._CAN_TREE_MAX:                             # (oldest first: dicts keep insertion order)
+                self._can_tree.pop(next(iter(self._can_tree)))
             self._can_tree[key] = ray_utils.Mesh(v, np.ascontiguousarray(np.asarray(faces)[:, :3], np.int32),
                                                  torch.zeros((v.shape[0], 16), dtype=torch.float64), pts.device)
         return ray_utils.signed_distance_dev(pts.reshape(-1, 3).detach(), self._can_tree[key])[0]
+
+    _CAN_TREE_MAX = 8
 
     # ---- :305-343
     def _smpl_shape_regularization(self, batch, pts, dirs, pred):
@@ -137,12 +155,17 @@ class HumanNeRFLoss:
         def filled(raw, mask, weight):                                                   # occupancy 1 where the body is
             return weight * ((1 - _occupancy(raw)[mask]) ** 2).mean() if bool(mask.any()) else 0.0
 
-        dist_human = self._signed_distance(pts, batch.get('cap_id'))
-        smpl_reg = smpl_reg + filled(pred, dist_human < 0, self.penalize_smpl_alpha)
+        dummy_pts = None
         if self.penalize_dummy > 0:                                                      # random points of a 3-unit box around the canonical body
             dummy_pts = ((torch.as_tensor(self.replay['dummy_pts_rand']).to(pts) if self.replay else torch.rand_like(pts)) - 0.5) * 3
+        # both signed-distance queries of the iteration (:310, :326) go against the same canonical body: ONE search launch
+        both = self._signed_distance(pts if dummy_pts is None else torch.cat([pts.reshape(-1, 3), dummy_pts.reshape(-1, 3)], 0), batch.get('cap_id'))
+        n_h = pts.reshape(-1, 3).shape[0]
+        dist_human = both[:n_h]
+        smpl_reg = smpl_reg + filled(pred, dist_human < 0, self.penalize_smpl_alpha)
+        if dummy_pts is not None:
             dummy_out = self.net.coarse_human_net(dummy_pts, dirs)
-            dist_dummy = self._signed_distance(dummy_pts, batch.get('cap_id'))
+            dist_dummy = both[n_h:]
             smpl_reg = smpl_reg + filled(dummy_out, dist_dummy < 0, self.penalize_dummy)
             outside = dist_dummy > 0
             if bool(outside.any()):                                                      # occupancy 0 outside, weighted by the distance from the surface
