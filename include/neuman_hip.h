@@ -210,6 +210,9 @@ int nm_transmittance_chunk_dz(const float* raw, const float* dz, const float* ra
  * `stage` (0..9): state [256 lanes][130] = the two sub-tiles' resident input fragments of the next stage (128 dwords) and their row scales.
  * What the generated instruction stream is checked against stage by stage (tests/test_hip_i8_as.py). */
 int nm_mlp_forward_i8t_debug(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int stage, uint32_t* state, float* out, nm_stream_t stream);
+/* Debug: the density-only NM_PREC_FP16X3 activation-stationary kernel (csrc/mlp_f16t.hip) on n points (out [n,4] = (0, 0, 0, sigma)), plus the
+ * activations of its first tile after `stage` (0..7): state [128 samples][256] float32 in natural feature order (hi + lo parts, unscaled). */
+int nm_mlp_sigma_f16t_debug(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int stage, float* state, float* out, nm_stream_t stream);
 /* Debug: stop after `stage` and write that stage's activations as f32 [n, width_of_stage]:
  *   -1 -> position PE (64 wide, col 63 = 0);  0..7 -> relu(pts_linears[i]) (256);
  *    8 -> feature_linear output (256);  9 -> relu(views_linears[0]) (128). */

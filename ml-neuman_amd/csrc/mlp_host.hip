@@ -422,6 +422,32 @@ static void pack_stream8t(const uint8_t* img8, uint8_t* out) {
     if (dst - out != kWeightBytes8) abort();
 }
 
+// ---- the density-only fp16x3 activation-stationary kernel's stream (mlp_f16t.hip): the k-steps of stages 0..7 and of the alpha block of the
+// fp16 image (frag_off) in the order the kernel consumes them -- output blocks in PAIRS (two accumulator chains), a ring unit = 8 steps of
+// block b followed by the same 8 steps of block b + 1 (stage 0: its 4 steps; stage 5: its 4 encoding steps first, as a unit of their own).
+// Built on the device from the image (so that nm_mlp_refresh_f16 can rebuild it): step i of the stream <- image byte offset tab[i].
+constexpr int kSigmaSteps = 8 * 4 + 6 * 8 * 16 + 8 * 20 + 16;            // 976
+static void sigma_stream_table(std::vector<int>& tab) {
+    tab.clear();
+    auto put = [&](int st, int nb, int t0, int n) { for (int t = 0; t < n; ++t) tab.push_back((int)frag_off(st, nb, t0 + t)); };
+    for (int st = 0; st <= 7; ++st) {
+        const StageShape sh = stage_shape(st);
+        for (int b = 0; b < 8; b += 2) {
+            if (sh.pe_steps) { put(st, b, 0, sh.pe_steps); put(st, b + 1, 0, sh.pe_steps); }
+            for (int t0 = sh.pe_steps; t0 < sh.steps; t0 += 8) { put(st, b, t0, 8); put(st, b + 1, t0, 8); }
+        }
+    }
+    put(8, 8, 0, 8);
+    put(8, 8, 8, 8);
+    if ((int)tab.size() != kSigmaSteps) abort();
+}
+__global__ void sigma_stream_kernel(const uint4* __restrict__ image, const int* __restrict__ tab, int nsteps, uint4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;                       // one 16-byte piece each
+    if (i >= nsteps * (kStepBytes / 16)) return;
+    const int step = i / (kStepBytes / 16), j = i % (kStepBytes / 16);
+    out[i] = image[tab[step] / 16 + j];
+}
+
 // per-wave stream image (mlp_layout.h wstream_*): the steps of the NM_PREC_I8X3 image in each wave's consumption order
 static void pack_stream8(const uint8_t* img8, uint8_t* out) {
     memset(out, 0, (size_t)kWeightBytes8w);
@@ -454,6 +480,8 @@ struct nm_mlp_s {
     uint8_t* d_stream8;    // NM_PREC_I8X3: the image's fragments as per-wave streams (nerf_mlp_i8w_kernel)
     uint8_t* d_image8;     // NM_PREC_I8X3: the workgroup stream of nerf_mlp_i8s_kernel (pack_stream8s), fragments + prefetch pad
     uint8_t* d_image8t;    // NM_PREC_I8X3: the workgroup stream of nerf_mlp_i8t_kernel (pack_stream8t)
+    uint8_t* d_stream16t;  // NM_PREC_FP16X3, density only: the stream of nerf_sigma_f16t_kernel (sigma_stream_kernel over d_image16)
+    int* d_sigma_tab;      //   its step table
     float* d_petab;        // 192 floats
     float* d_ref;          // transposed f32 weights | natural biases (NM_PREC_FP32 path)
     float* d_wscale16;     // nm_mlp_refresh_f16: the per-stage weight scales of the fp16 image (device scratch)
@@ -582,7 +610,7 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     m->pos_octaves = octaves(tab, desc->pos_n_freqs);
     m->dir_octaves = octaves(tab + 96, desc->dir_n_freqs);
 
-    m->d_image = nullptr; m->d_image16 = nullptr; m->d_consts8 = nullptr; m->d_stream8 = nullptr; m->d_image8 = nullptr; m->d_image8t = nullptr; m->d_petab = nullptr; m->d_ref = nullptr; m->d_wscale16 = nullptr;
+    m->d_image = nullptr; m->d_image16 = nullptr; m->d_consts8 = nullptr; m->d_stream8 = nullptr; m->d_image8 = nullptr; m->d_image8t = nullptr; m->d_stream16t = nullptr; m->d_sigma_tab = nullptr; m->d_petab = nullptr; m->d_ref = nullptr; m->d_wscale16 = nullptr;
     int rc = nm::check_hip(hipMalloc(&m->d_image, (size_t)bytes), "nm_mlp_create: hipMalloc(image)");
     const size_t consts_off = (size_t)(nm::kWeightBytes8 + nm::kWeightPadBytes), consts_bytes = img8.size() - consts_off;
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_consts8, consts_bytes), "nm_mlp_create: hipMalloc(consts8)");
@@ -600,6 +628,20 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     if (!rc) rc = nm::check_hip(hipMemcpy(m->d_image16, img16.data(), (size_t)bytes, hipMemcpyHostToDevice), "nm_mlp_create: upload image16");
     if (!rc) rc = nm::check_hip(hipMemcpy(m->d_petab, tab, sizeof(tab), hipMemcpyHostToDevice), "nm_mlp_create: upload petab");
     if (!rc) rc = nm::check_hip(hipMemcpy(m->d_ref, ref.data(), ref.size() * 4, hipMemcpyHostToDevice), "nm_mlp_create: upload ref");
+    if (!rc && !plain) {
+        std::vector<int> stab;
+        nm::sigma_stream_table(stab);
+        rc = nm::check_hip(hipMalloc(&m->d_sigma_tab, stab.size() * sizeof(int)), "nm_mlp_create: hipMalloc(sigma table)");
+        if (!rc) rc = nm::check_hip(hipMemcpy(m->d_sigma_tab, stab.data(), stab.size() * sizeof(int), hipMemcpyHostToDevice), "nm_mlp_create: upload sigma table");
+        if (!rc) rc = nm::check_hip(hipMalloc(&m->d_stream16t, (size_t)nm::kSigmaSteps * nm::kStepBytes), "nm_mlp_create: hipMalloc(stream16t)");
+        if (!rc) {
+            const int n16 = nm::kSigmaSteps * (nm::kStepBytes / 16);
+            hipLaunchKernelGGL(nm::sigma_stream_kernel, dim3((n16 + 255) / 256), dim3(256), 0, 0, reinterpret_cast<const uint4*>(m->d_image16), m->d_sigma_tab,
+                               nm::kSigmaSteps, reinterpret_cast<uint4*>(m->d_stream16t));
+            rc = nm::check_launch("sigma_stream_kernel");
+            if (!rc) rc = nm::check_hip(hipDeviceSynchronize(), "nm_mlp_create: sigma stream");
+        }
+    }
     if (rc) { nm_mlp_destroy(m); return rc; }
     *out = m;
     return NM_OK;
@@ -621,6 +663,11 @@ int nm_mlp_refresh_f16(nm_mlp_t m, const float* const* dev_params, nm_stream_t s
     const int threads = (int)(nm::kWeightBytes / nm::kStepBytes) * 64;
     hipLaunchKernelGGL(nm::f16_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, m->desc, P, m->d_wscale16, m->d_image16);
     hipLaunchKernelGGL(nm::f16_bias_kernel, dim3((nm::kBiasFloats + nm::kF16TabFloats + 255) / 256), dim3(256), 0, st, P, m->d_wscale16, bias);
+    if (m->d_stream16t) {                                                  // the density-only stream follows the image
+        const int n16 = nm::kSigmaSteps * (nm::kStepBytes / 16);
+        hipLaunchKernelGGL(nm::sigma_stream_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4*>(m->d_image16), m->d_sigma_tab,
+                           nm::kSigmaSteps, reinterpret_cast<uint4*>(m->d_stream16t));
+    }
     return nm::check_launch("nm_mlp_refresh_f16");
 }
 
@@ -632,6 +679,8 @@ int nm_mlp_destroy(nm_mlp_t m) {
     if (m->d_stream8) (void)hipFree(m->d_stream8);
     if (m->d_image8) (void)hipFree(m->d_image8);
     if (m->d_image8t) (void)hipFree(m->d_image8t);
+    if (m->d_stream16t) (void)hipFree(m->d_stream16t);
+    if (m->d_sigma_tab) (void)hipFree(m->d_sigma_tab);
     if (m->d_petab) (void)hipFree(m->d_petab);
     if (m->d_ref) (void)hipFree(m->d_ref);
     if (m->d_wscale16) (void)hipFree(m->d_wscale16);
@@ -675,6 +724,12 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
     // NM_PREC_I8X3, whole network, all four outputs: the activation-stationary kernel (mlp_i8s.hip) -- bit-identical to the wave-specialised
     // one of mlp.hip, which keeps the stage-by-stage / profiling / density-only forms (and everything under NEUMAN_I8_KERNEL=w or =r)
     static const bool i8_as = [] { const char* e = getenv("NEUMAN_I8_KERNEL"); return !e || !strcmp(e, "as"); }();
+    // NM_PREC_FP16X3, density only (the sampling pass of a two-pass render): the activation-stationary kernel of mlp_f16t.hip -- bit-identical
+    // sigma -- under NEUMAN_SIGMA_KERNEL=t
+    const char* sk = getenv("NEUMAN_SIGMA_KERNEL");              // (read per call: the parity tests switch it inside one process)
+    const bool sigma_t = sk && !strcmp(sk, "t") && m->d_stream16t;
+    if (sigma_t && precision == NM_PREC_FP16X3 && sigma_only == 1 && stop_stage == -2 && !dbg && !prof && !m->desc.plain_head)
+        return nm::launch_sigma_f16t(L, m->d_stream16t, pts, dirs, origin, direction, z, n, S, in_mode, sigma_scale, out, nm::as_stream(stream), chunk, nullptr, -1);
     static const bool i8_t = [] { const char* e = getenv("NEUMAN_I8_KERNEL"); return e && !strcmp(e, "t"); }();
     if (i8_t && precision == NM_PREC_I8X3 && stop_stage == -2 && !dbg && !prof && !sigma_only)
         return nm::launch_mlp_i8t(L, m->d_image8t, pts, dirs, origin, direction, z, n, S, in_mode, sigma_scale, out, nm::as_stream(stream), chunk, nullptr, -1);
@@ -775,6 +830,18 @@ int nm_mlp_forward_i8t_debug(nm_mlp_t mlp, const float* pts, const float* dirs, 
     L.plain_head = 0;
     L.consts8 = mlp->d_consts8;
     return nm::launch_mlp_i8t(L, mlp->d_image8t, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, 1.f, out, nm::as_stream(stream), nullptr, state, stage);
+}
+
+int nm_mlp_sigma_f16t_debug(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int stage, float* state, float* out, nm_stream_t stream) {
+    NM_REQUIRE(mlp && pts && dirs && state && out && n > 0, "nm_mlp_sigma_f16t_debug: null pointer");
+    NM_REQUIRE(stage >= 0 && stage % 100 <= 7 && !mlp->desc.plain_head, "nm_mlp_sigma_f16t_debug: stage %d outside 0..7 (+ 100 x tile round)", stage);
+    nm::MlpLaunch L;
+    L.petab = mlp->d_petab;
+    L.pe_kind = mlp->desc.pe_kind; L.pos_nfreq = mlp->desc.pos_n_freqs; L.dir_nfreq = mlp->desc.dir_n_freqs;
+    L.pos_octaves = mlp->pos_octaves; L.dir_octaves = mlp->dir_octaves;
+    L.plain_head = 0;
+    L.bias16 = reinterpret_cast<const float*>(mlp->d_image16 + nm::kWeightBytes + nm::kWeightPadBytes);
+    return nm::launch_sigma_f16t(L, mlp->d_stream16t, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, 1.f, out, nm::as_stream(stream), nullptr, state, stage);
 }
 
 int nm_mlp_forward_debug(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision, int stage,

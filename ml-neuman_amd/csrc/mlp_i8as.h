@@ -23,12 +23,23 @@ struct Args8s {
 __device__ __forceinline__ i32x4 as_i32x4(uint4 v) { return __builtin_bit_cast(i32x4, v); }
 
 // ---- encodings of this wave's 32 rows (octave recurrence, mlp_device.h fill_pe_fast, wave-private layout)
+//   F16: the NM_PREC_FP16X3 form (fp16 parts of 32 v; the general path clamps like split8<false, true>, the octave path has |v| <= max(1, |x|))
+template <bool F16 = false>
 __device__ __forceinline__ void fill_pe_wave(uint4* pw, bool is_dir, const MlpArgs& a, int64_t base_row, int lane) {
     const PeSpec spec = is_dir ? a.dir : a.pos;
     const float* tab = a.petab + (is_dir ? 96 : 0);
     unsigned short* hi = reinterpret_cast<unsigned short*>(pw);
-    auto put = [&](int row, int p, float v) {
+    auto put = [&](int row, int p, float v, bool clamp = false) {
         const int off = ((p >> 3) * (2 * kRows) + row) * 8 + (p & 7);
+        if (F16) {
+            float sv = v * kF16ActScale;
+            if (clamp) sv = __builtin_amdgcn_fmed3f(sv, -65504.f, 65504.f);
+            const _Float16 hb = (_Float16)sv;
+            const _Float16 lb = (_Float16)(sv - (float)hb);
+            hi[off] = __builtin_bit_cast(unsigned short, hb);
+            hi[off + kRows * 8] = __builtin_bit_cast(unsigned short, lb);
+            return;
+        }
         const bf16x2 hb = __builtin_convertvector((f32x2){v, 0.f}, bf16x2);
         const f32x2 hf = __builtin_convertvector(hb, f32x2);
         const bf16x2 lb = __builtin_convertvector((f32x2){v - hf.x, 0.f}, bf16x2);
@@ -66,7 +77,7 @@ __device__ __forceinline__ void fill_pe_wave(uint4* pw, bool is_dir, const MlpAr
             float x0, x1, x2;
             sample_input(a, i, is_dir, x0, x1, x2);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) put(row, 8 * c + e, pe_feature(8 * c + e, x0, x1, x2, spec, tab));
+            for (int e = 0; e < 8; ++e) put(row, 8 * c + e, pe_feature(8 * c + e, x0, x1, x2, spec, tab), true);
         }
     }
 }

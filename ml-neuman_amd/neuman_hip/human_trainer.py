@@ -125,7 +125,7 @@ class HumanNeRFLoss:
         cm = self.can_mesh
         if callable(cm) or isinstance(cm, dict):
             per_frame = True
-        elif isinstance(cm, (tuple, list)) and len(cm) == 2 and getattr(np.asarray(cm[0]), 'ndim', 0) == 2 and np.asarray(cm[0]).shape[-1] == 3:
+        elif isinstance(cm, (tuple, list)) and len(cm) == 2 and hasattr(cm[0], 'shape') and len(cm[0].shape) == 2 and cm[0].shape[-1] == 3:
             per_frame = False
         elif isinstance(cm, (tuple, list)) and len(cm) > 0 and isinstance(cm[0], (tuple, list)) and len(cm[0]) == 2:
             per_frame = True
