@@ -427,25 +427,35 @@ static void pack_stream8t(const uint8_t* img8, uint8_t* out) {
 // block b followed by the same 8 steps of block b + 1 (stage 0: its 4 steps; stage 5: its 4 encoding steps first, as a unit of their own).
 // Built on the device from the image (so that nm_mlp_refresh_f16 can rebuild it): step i of the stream <- image byte offset tab[i].
 constexpr int kSigmaSteps = 8 * 4 + 6 * 8 * 16 + 8 * 20 + 16;            // 976
-static void sigma_stream_table(std::vector<int>& tab) {
+// 1 KB pieces (a k-step's hi or lo half of one output block) in the order nerf_sigma_f16t_kernel consumes them: first the parts that go through
+// its LDS ring -- per ring unit (a pair of output blocks x 4 or 8 k-steps) and k-step: block A hi, A lo, block B hi, B lo minus the last `ndir`
+// of them; the alpha row's 16 k-steps as two units of (hi, lo) -- then, for every pair k-step in the same order, the `ndir` parts that are loaded
+// straight into registers (tools/gen_f16t.py NDIR)
+static void sigma_stream_table(std::vector<int>& tab, int ndir) {
     tab.clear();
-    auto put = [&](int st, int nb, int t0, int n) { for (int t = 0; t < n; ++t) tab.push_back((int)frag_off(st, nb, t0 + t)); };
+    std::vector<int> direct;
+    auto put = [&](int st, int b, int t0, int n) {
+        for (int t = 0; t < n; ++t)
+            for (int k = 0; k < 4; ++k) {
+                const int off = (int)frag_off(st, b + (k >> 1), t0 + t) + 1024 * (k & 1);
+                (k < 4 - ndir ? tab : direct).push_back(off);
+            }
+    };
     for (int st = 0; st <= 7; ++st) {
         const StageShape sh = stage_shape(st);
         for (int b = 0; b < 8; b += 2) {
-            if (sh.pe_steps) { put(st, b, 0, sh.pe_steps); put(st, b + 1, 0, sh.pe_steps); }
-            for (int t0 = sh.pe_steps; t0 < sh.steps; t0 += 8) { put(st, b, t0, 8); put(st, b + 1, t0, 8); }
+            if (sh.pe_steps) put(st, b, 0, sh.pe_steps);
+            for (int t0 = sh.pe_steps; t0 < sh.steps; t0 += 8) put(st, b, t0, 8);
         }
     }
-    put(8, 8, 0, 8);
-    put(8, 8, 8, 8);
-    if ((int)tab.size() != kSigmaSteps) abort();
+    for (int t = 0; t < 16; ++t) { tab.push_back((int)frag_off(8, 8, t)); tab.push_back((int)frag_off(8, 8, t) + 1024); }
+    tab.insert(tab.end(), direct.begin(), direct.end());
+    if ((int)tab.size() != 2 * kSigmaSteps) abort();
 }
-__global__ void sigma_stream_kernel(const uint4* __restrict__ image, const int* __restrict__ tab, int nsteps, uint4* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;                       // one 16-byte piece each
-    if (i >= nsteps * (kStepBytes / 16)) return;
-    const int step = i / (kStepBytes / 16), j = i % (kStepBytes / 16);
-    out[i] = image[tab[step] / 16 + j];
+__global__ void sigma_stream_kernel(const uint4* __restrict__ image, const int* __restrict__ tab, int npieces, uint4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;                       // 16 bytes each
+    if (i >= npieces * 64) return;
+    out[i] = image[tab[i >> 6] / 16 + (i & 63)];
 }
 
 // per-wave stream image (mlp_layout.h wstream_*): the steps of the NM_PREC_I8X3 image in each wave's consumption order
@@ -481,7 +491,8 @@ struct nm_mlp_s {
     uint8_t* d_image8;     // NM_PREC_I8X3: the workgroup stream of nerf_mlp_i8s_kernel (pack_stream8s), fragments + prefetch pad
     uint8_t* d_image8t;    // NM_PREC_I8X3: the workgroup stream of nerf_mlp_i8t_kernel (pack_stream8t)
     uint8_t* d_stream16t;  // NM_PREC_FP16X3, density only: the stream of nerf_sigma_f16t_kernel (sigma_stream_kernel over d_image16)
-    int* d_sigma_tab;      //   its step table
+    int* d_sigma_tab;      //   its piece table
+    int sigma_ndir;        //   parts of a pair k-step that bypass the LDS ring (the kernel is generated for one value: NEUMAN_F16T_NDIR is for experiments)
     float* d_petab;        // 192 floats
     float* d_ref;          // transposed f32 weights | natural biases (NM_PREC_FP32 path)
     float* d_wscale16;     // nm_mlp_refresh_f16: the per-stage weight scales of the fp16 image (device scratch)
@@ -630,14 +641,15 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     if (!rc) rc = nm::check_hip(hipMemcpy(m->d_ref, ref.data(), ref.size() * 4, hipMemcpyHostToDevice), "nm_mlp_create: upload ref");
     if (!rc && !plain) {
         std::vector<int> stab;
-        nm::sigma_stream_table(stab);
+        m->sigma_ndir = [] { const char* e = getenv("NEUMAN_F16T_NDIR"); return e ? atoi(e) : 0; }();
+        nm::sigma_stream_table(stab, m->sigma_ndir);
         rc = nm::check_hip(hipMalloc(&m->d_sigma_tab, stab.size() * sizeof(int)), "nm_mlp_create: hipMalloc(sigma table)");
         if (!rc) rc = nm::check_hip(hipMemcpy(m->d_sigma_tab, stab.data(), stab.size() * sizeof(int), hipMemcpyHostToDevice), "nm_mlp_create: upload sigma table");
         if (!rc) rc = nm::check_hip(hipMalloc(&m->d_stream16t, (size_t)nm::kSigmaSteps * nm::kStepBytes), "nm_mlp_create: hipMalloc(stream16t)");
         if (!rc) {
             const int n16 = nm::kSigmaSteps * (nm::kStepBytes / 16);
             hipLaunchKernelGGL(nm::sigma_stream_kernel, dim3((n16 + 255) / 256), dim3(256), 0, 0, reinterpret_cast<const uint4*>(m->d_image16), m->d_sigma_tab,
-                               nm::kSigmaSteps, reinterpret_cast<uint4*>(m->d_stream16t));
+                               2 * nm::kSigmaSteps, reinterpret_cast<uint4*>(m->d_stream16t));
             rc = nm::check_launch("sigma_stream_kernel");
             if (!rc) rc = nm::check_hip(hipDeviceSynchronize(), "nm_mlp_create: sigma stream");
         }
@@ -666,7 +678,7 @@ int nm_mlp_refresh_f16(nm_mlp_t m, const float* const* dev_params, nm_stream_t s
     if (m->d_stream16t) {                                                  // the density-only stream follows the image
         const int n16 = nm::kSigmaSteps * (nm::kStepBytes / 16);
         hipLaunchKernelGGL(nm::sigma_stream_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4*>(m->d_image16), m->d_sigma_tab,
-                           nm::kSigmaSteps, reinterpret_cast<uint4*>(m->d_stream16t));
+                           2 * nm::kSigmaSteps, reinterpret_cast<uint4*>(m->d_stream16t));
     }
     return nm::check_launch("nm_mlp_refresh_f16");
 }
@@ -725,11 +737,11 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
     // one of mlp.hip, which keeps the stage-by-stage / profiling / density-only forms (and everything under NEUMAN_I8_KERNEL=w or =r)
     static const bool i8_as = [] { const char* e = getenv("NEUMAN_I8_KERNEL"); return !e || !strcmp(e, "as"); }();
     // NM_PREC_FP16X3, density only (the sampling pass of a two-pass render): the activation-stationary kernel of mlp_f16t.hip -- bit-identical
-    // sigma -- under NEUMAN_SIGMA_KERNEL=t
+    // sigma; NEUMAN_SIGMA_KERNEL=w keeps nerf_mlp_kernel for it
     const char* sk = getenv("NEUMAN_SIGMA_KERNEL");              // (read per call: the parity tests switch it inside one process)
-    const bool sigma_t = sk && !strcmp(sk, "t") && m->d_stream16t;
+    const bool sigma_t = !(sk && !strcmp(sk, "w")) && m->d_stream16t;
     if (sigma_t && precision == NM_PREC_FP16X3 && sigma_only == 1 && stop_stage == -2 && !dbg && !prof && !m->desc.plain_head)
-        return nm::launch_sigma_f16t(L, m->d_stream16t, pts, dirs, origin, direction, z, n, S, in_mode, sigma_scale, out, nm::as_stream(stream), chunk, nullptr, -1);
+        return nm::launch_sigma_f16t(L, m->d_stream16t, m->sigma_ndir, pts, dirs, origin, direction, z, n, S, in_mode, sigma_scale, out, nm::as_stream(stream), chunk, nullptr, -1);
     static const bool i8_t = [] { const char* e = getenv("NEUMAN_I8_KERNEL"); return e && !strcmp(e, "t"); }();
     if (i8_t && precision == NM_PREC_I8X3 && stop_stage == -2 && !dbg && !prof && !sigma_only)
         return nm::launch_mlp_i8t(L, m->d_image8t, pts, dirs, origin, direction, z, n, S, in_mode, sigma_scale, out, nm::as_stream(stream), chunk, nullptr, -1);
@@ -841,7 +853,7 @@ int nm_mlp_sigma_f16t_debug(nm_mlp_t mlp, const float* pts, const float* dirs, i
     L.pos_octaves = mlp->pos_octaves; L.dir_octaves = mlp->dir_octaves;
     L.plain_head = 0;
     L.bias16 = reinterpret_cast<const float*>(mlp->d_image16 + nm::kWeightBytes + nm::kWeightPadBytes);
-    return nm::launch_sigma_f16t(L, mlp->d_stream16t, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, 1.f, out, nm::as_stream(stream), nullptr, state, stage);
+    return nm::launch_sigma_f16t(L, mlp->d_stream16t, mlp->sigma_ndir, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, 1.f, out, nm::as_stream(stream), nullptr, state, stage);
 }
 
 int nm_mlp_forward_debug(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int precision, int stage,

@@ -38,6 +38,7 @@ OUT = os.environ.get("F16T_OUT") or os.path.join(ROOT, "ml-neuman_amd", "csrc", 
 STEP = 2048
 K_STAGES = 11
 PER_GAP = int(os.environ.get("F16T_PER_GAP", "4"))
+PROBE = os.environ.get("F16T_PROBE", "")                  # timing probes (garbage results): novalu | nowread | nomfma | nocopy | nobarrier
 
 
 def stage_b_off(s):                                        # fp16 image: stage_shape(s).nblk * 32 floats per stage
@@ -46,8 +47,20 @@ def stage_b_off(s):                                        # fp16 image: stage_s
 
 
 K_BIAS_FLOATS = stage_b_off(11)
-K_STREAM_BYTES = (8 * 4 + 6 * 8 * 16 + 8 * 20 + 16) * STEP
 SLOT_SHIFT = 15                                            # 32 KB ring slots
+# Which 1 KB parts of a pair k-step (block A hi, A lo, block B hi, B lo) do NOT go through the LDS ring but straight from the stream (L2 / the CU's
+# vector cache) into registers, D k-steps ahead: 0: none; 1: B lo; 2: B hi and B lo.  An experiment (profiles/r04_f16t_kernel.md): the launch
+# takes the same time with 0, 1 and 2 -- it is the energy of moving a fragment, not the pipe it moves through, that costs -- so 0 is what is built.
+NDIR = int(os.environ.get("F16T_NDIR", "0"))
+D = 16                                                     # direct parts in flight: k-steps ahead (divides every stage's first pair k-step)
+PARTS = [(0, 0), (0, 1), (1, 0), (1, 1)]
+DIRECT = PARTS[4 - NDIR:]
+LDS_PARTS = PARTS[:4 - NDIR]
+NL = len(LDS_PARTS)
+PAIR_STEPS = 480                                           # pair k-steps of a tile (the alpha row's 16 are single-block steps, all LDS)
+K_LDS_BYTES = (PAIR_STEPS * NL + 16 * 2) * 1024
+K_DIR_BYTES = PAIR_STEPS * NDIR * 1024
+assert K_LDS_BYTES + K_DIR_BYTES == 976 * STEP
 
 V_RDBASE, V_BIAS, V_PE, V_CP0, V_OUT = 4, 5, 6, 7, 8
 V_RD, V_T2, V_BIASST = 10, 11, 12
@@ -59,9 +72,12 @@ V_XO = 62
 V_ACC = 190
 V_DBGOFF = 254
 A_XE = 0
-A_W = 128
+A_W = 128                                                  # two buffers of the LDS-read parts of a k-step
+A_DIR = A_W + 8 * NL                                       # D entries of the direct parts (the last ones spill into v32..v47)
+V_L16 = 32 + 16                                            # lane * 16
 S_IMG, S_RING0, S_OFF, S_SLOT, S_OS, S_SIGSC, S_DBGST, S_TAB, S_DBG = 36, 38, 39, 40, 41, 42, 43, 44, 46
 S_REFILL, S_P, S_TMP, S_RDOFF, S_RET, S_RET2, S_ST, S_SAVE, S_M0, S_CLAMP = 52, 54, 56, 57, 58, 60, 62, 64, 66, 67
+S_BB, S_BP = 48, 68                                        # the direct stream: its base (input), the running pointer
 
 
 def xreg(par, t, part):
@@ -75,24 +91,41 @@ def xreg1(par, t, part, i):
     return ar(A_XE + base) if par == 0 else vr(V_XO + base)
 
 
+def lbuf(s, idx):
+    return ar(A_W + 4 * NL * (s & 1) + 4 * idx, 4)
+
+
+def dbuf(e, k):
+    g = e * NDIR + k
+    nag = (256 - A_DIR) // 4
+    if g < nag:
+        return ar(A_DIR + 4 * g, 4)
+    assert 32 + 4 * (g - nag) + 3 < V_L16
+    return vr(32 + 4 * (g - nag), 4)
+
+
 class GenF:
     def __init__(self):
         self.A = Asm()
         self.unit = 0                                     # ring unit index within the tile (static)
-        self.units = []
+        self.bn = 0                                       # pair k-step index within the tile (static; inside a subroutine: its first caller's)
+        self.in_sub = False
+        self.unit_loads = 0
+        self.units = []                                   # (k-steps, LDS parts per k-step)
         for st in range(8):
             for _ in range(4):
                 if st == 0:
-                    self.units.append(8)
+                    self.units.append((4, NL))
                 else:
                     if st == 5:
-                        self.units.append(8)
-                    self.units += [16, 16]
-        self.units += [8, 8]
-        assert len(self.units) == 66 and sum(self.units) * STEP == K_STREAM_BYTES
+                        self.units.append((4, NL))
+                    self.units += [(8, NL), (8, NL)]
+        self.units += [(8, 2), (8, 2)]
+        assert len(self.units) == 66 and sum(n * k for n, k in self.units) * 1024 == K_LDS_BYTES
 
-    def usteps(self, i):
-        return self.units[i % len(self.units)]
+    def ubytes(self, i):
+        n, k = self.units[i % len(self.units)]
+        return n * k * 1024
 
     # ---- ring (the protocol of gen_i8t: hand-over inside the predecessor, copies behind it) ------------------------------------------------
     def ring_start(self):
@@ -103,22 +136,25 @@ class GenF:
     def ring_handover(self):
         A = self.A
         i = self.unit
-        A.raw("s_waitcnt vmcnt(0)")
-        A.raw("s_barrier")
+        # the pieces of unit i + 1 were issued inside unit i - 1; everything this unit has issued since (direct loads only) is younger
+        A.raw(f"s_waitcnt vmcnt({self.unit_loads})")
+        if PROBE != "nobarrier":
+            A.raw("s_barrier")
         A.salu(f"s_lshl_b32 s{S_RDOFF}, s{S_SLOT}, {SLOT_SHIFT}")
         A.salu(f"s_add_u32 s{S_TMP}, s{S_SLOT}, 1")
         A.salu(f"s_cmp_eq_u32 s{S_SLOT}, 2")
         A.salu(f"s_cselect_b32 s{S_SLOT}, 0, s{S_TMP}")
         A.salu(f"s_lshl_b32 s{S_TMP}, s{S_SLOT}, {SLOT_SHIFT}")
         A.salu(f"s_add_u32 s{S_REFILL}, s{S_RING0}, s{S_TMP}")
-        n2 = self.usteps(i + 2)
-        pieces = n2 * 2 // 4
+        nbytes = self.ubytes(i + 2)
+        assert nbytes % 4096 == 0
+        pieces = nbytes // 4096
         out = []
         for j in range(pieces):
-            out.append(lambda j=j, last=(j == pieces - 1), n2=n2: self.copy_piece(j, n2, last))
+            out.append(lambda j=j, last=(j == pieces - 1), nbytes=nbytes: self.copy_piece(j, nbytes, last))
         return out
 
-    def copy_piece(self, j, n2, last):
+    def copy_piece(self, j, nbytes, last):
         A = self.A
         A.salu(f"s_add_u32 s{S_TMP}, s{S_OFF}, {j * 4096}")
         A.salu(f"s_add_u32 s{S_P}, s{S_IMG}, s{S_TMP}")
@@ -126,11 +162,23 @@ class GenF:
         A.salu(f"s_add_u32 m0, s{S_REFILL}, {j * 4096}")
         A.raw("s_nop 0")
         A.n += 1
-        A.op('vmem', f"global_load_lds_dwordx4 {vr(V_CP0)}, s[{S_P}:{S_P + 1}]", [], [vr(V_CP0)])
+        if PROBE != "nocopy":
+            A.op('vmem', f"global_load_lds_dwordx4 {vr(V_CP0)}, s[{S_P}:{S_P + 1}]", [], [vr(V_CP0)])
         if last:
-            A.salu(f"s_add_u32 s{S_OFF}, s{S_OFF}, {n2 * STEP}")
-            A.salu(f"s_cmp_eq_u32 s{S_OFF}, {K_STREAM_BYTES}")
+            A.salu(f"s_add_u32 s{S_OFF}, s{S_OFF}, {nbytes}")
+            A.salu(f"s_cmp_eq_u32 s{S_OFF}, {K_LDS_BYTES}")
             A.salu(f"s_cselect_b32 s{S_OFF}, 0, s{S_OFF}")
+
+    def direct_loads(self, e):
+        """the direct parts of a pair k-step -> entry e, and the pointer moves on"""
+        A = self.A
+        for k in range(NDIR):
+            d = dbuf(e, k)
+            A.op('vmem', f"global_load_dwordx4 {d}, {vr(V_L16)}, s[{S_BP}:{S_BP + 1}]" + (f" offset:{1024 * k}" if k else ""), [], [vr(V_L16)])
+            self.unit_loads += 1
+        if NDIR:
+            A.salu(f"s_add_u32 s{S_BP}, s{S_BP}, {1024 * NDIR}")
+            A.salu(f"s_addc_u32 s{S_BP + 1}, s{S_BP + 1}, 0")
 
     # ---- pieces ----------------------------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -147,6 +195,8 @@ class GenF:
         (split8<true, true>: x scale, clamp to [0, 65504], RNE to fp16 pairs, back, exact difference, RNE).  -> closures, by kind"""
         A = self.A
         out = []
+        if PROBE == "novalu":
+            return out
         f = lambda i: self.acc(slot, 1, i)                                      # noqa: E731
         for i in range(16):
             out.append(lambda i=i: A.valu(f"v_mul_f32 {f(i)}, {f(i)}, {vr(sc)}", [f(i)], [f(i), vr(sc)]))
@@ -196,16 +246,23 @@ class GenF:
         fillers ride behind the MFMAs; leftovers are flushed at the end of the unit."""
         A = self.A
         self.ring_start()
+        self.unit_loads = 0
         fill_iter = iter(list(fillers))
         nb = len(slots)
         rd = vr(V_RD)
-        wb = lambda s, blk, part: ar(A_W + 16 * (s & 1) + 8 * blk + 4 * part, 4)   # noqa: E731
+        lparts = LDS_PARTS if nb == 2 else PARTS[:2]
+        assert (nsteps, len(lparts)) == self.units[self.unit % len(self.units)]
+
+        def wsrc(s, blk, part):
+            if (blk, part) in lparts:
+                return lbuf(s, lparts.index((blk, part)))
+            return dbuf(self.bn % D, DIRECT.index((blk, part)))
 
         def wreads(s, addr):
             out = []
-            for blk in range(nb):
-                for part in range(2):
-                    out.append(lambda blk=blk, part=part: A.ds_read128(wb(s, blk, part), addr, (blk * nsteps + s) * STEP + 1024 * part))
+            for idx in range(len(lparts)):
+                if PROBE != "nowread":
+                    out.append(lambda idx=idx: A.ds_read128(lbuf(s, idx), addr, (s * len(lparts) + idx) * 1024))
             return out
         for f in wreads(0, rd):
             f()
@@ -229,10 +286,16 @@ class GenF:
             seq = []
             for part in range(3):
                 for blk in range(nb):
-                    a, b = [(wb(s, blk, 0), xl), (wb(s, blk, 1), xh), (wb(s, blk, 0), xh)][part]
-                    seq.append((self.acc(slots[blk]), a, b))
-            for acc, a, b in seq:
-                A.op('mfma', f"v_mfma_f32_32x32x16_f16 {acc}, {a}, {b}, {acc}", [acc], [a, b, acc], chain=acc)
+                    wp, b = [(0, xl), (1, xh), (0, xh)][part]
+                    seq.append((self.acc(slots[blk]), wsrc(s, blk, wp), b, nb == 2 and (blk, wp) in DIRECT))
+            waited = False
+            for acc, a, b, direct in seq:
+                if direct and not waited:                                             # this k-step's direct parts: everything younger may stay in flight
+                    younger = D - 1 if self.in_sub else min(D - 1, PAIR_STEPS - 1 - self.bn)
+                    A.raw(f"s_waitcnt vmcnt({NDIR * younger})")
+                    waited = True
+                if PROBE != "nomfma":
+                    A.op('mfma', f"v_mfma_f32_32x32x16_f16 {acc}, {a}, {b}, {acc}", [acc], [a, b, acc], chain=acc)
                 budget = PER_GAP
                 while gap_extra and budget > 0:
                     gap_extra.pop(0)()
@@ -243,8 +306,14 @@ class GenF:
                         break
                     f()
                     budget -= 1
+            if nb == 2:
+                if NDIR and (self.in_sub or self.bn + D < PAIR_STEPS):                # the entry just consumed takes the parts of k-step bn + D
+                    self.direct_loads(self.bn % D)
+                self.bn += 1
             for f in gap_extra:
                 f()
+            if PROBE == "nomfma":
+                A.wait_lds(0)
         for f in fill_iter:
             f()
         self.unit += 1
@@ -332,12 +401,15 @@ class GenF:
         A = self.A
         A.raw(f".Lf16t_stage{par}:")
         A.barrier_state()
-        start = self.unit
+        start, bstart = self.unit, self.bn
         st = 1 if par else 2
+        self.bn = 16 + 64 * (st - 1)
+        self.in_sub = True
         self.stage_pairs(st, self.last_pair_split(st - 1), vr(V_BIASST), 0, dump_after_first=lambda: self.dump_check(prev_st_sgpr=S_ST, par=par))
         A.barrier_state()
         A.raw(f"s_setpc_b64 s[{S_RET}:{S_RET + 1}]")
-        self.unit = start
+        self.unit, self.bn = start, bstart
+        self.in_sub = False
 
     def call_generic(self, st):
         A = self.A
@@ -348,6 +420,8 @@ class GenF:
         A.barrier_state()
         A.raw(f"s_call_b64 s[{S_RET}:{S_RET + 1}], .Lf16t_stage{st & 1}")
         self.unit += 8
+        self.bn += 64
+        assert self.bn % D == 0
 
     def inline_stage(self, st):
         """stages 4 and 7: the units copied behind their last two hand-overs (stage 5's encoding unit, the alpha row's) are not the 16-step
@@ -366,6 +440,12 @@ class GenF:
         A.salu(f"s_cmp_eq_u32 s{S_SLOT}, 0")
         A.salu(f"s_cselect_b32 s{S_TMP}, 2, s{S_TMP}")
         A.salu(f"s_lshl_b32 s{S_RDOFF}, s{S_TMP}, {SLOT_SHIFT}")
+        if NDIR:
+            A.comment("the direct parts of the first D pair k-steps")
+            A.salu(f"s_mov_b64 s[{S_BP}:{S_BP + 1}], s[{S_BB}:{S_BB + 1}]")
+            A.valu(f"v_and_b32 {vr(V_L16)}, 1023, {vr(V_CP0)}", [vr(V_L16)], [vr(V_CP0)])
+            for e in range(D):
+                self.direct_loads(e)
         A.comment("==== stage 0: encodings -> 256, ReLU")
         self.load_scale(0)
         self.stage_pairs(0, [], vr(V_BIAS), stage_b_off(0) * 4)
@@ -378,7 +458,7 @@ class GenF:
         self.call_generic(6)
         self.inline_stage(7)
         A.comment("==== the alpha row of stage 8 -> sigma")
-        assert self.unit == 64, self.unit
+        assert self.unit == 64 and self.bn == PAIR_STEPS, (self.unit, self.bn)
         self.bias_init(0, vr(V_BIAS), (stage_b_off(8) + 256) * 4)
         self.pair_unit(8, 'h', 0, 0, (0,), self.last_pair_split(7))
         self.dump_check(prev_st=7, par=0)
@@ -423,7 +503,7 @@ def wrapper(A):
                 k, rs = m.group(4), [int(m.group(5))]
             {'v': used_v, 'a': used_a, 's': used_s}[k].update(rs)
     pinned_v = {V_RDBASE, V_BIAS, V_PE, V_CP0, V_OUT, V_OUT + 1, V_DBGOFF}
-    pinned_s = {S_IMG, S_IMG + 1, S_RING0, S_OFF, S_SLOT, S_OS, S_SIGSC, S_DBGST, S_TAB, S_DBG, S_DBG + 1}
+    pinned_s = {S_IMG, S_IMG + 1, S_RING0, S_OFF, S_SLOT, S_OS, S_SIGSC, S_DBGST, S_TAB, S_DBG, S_DBG + 1, S_BB, S_BB + 1}
     assert min(used_v) >= 4
     clob = [f'"v{i}"' for i in sorted(used_v - pinned_v)] + [f'"a{i}"' for i in sorted(used_a)] + [f'"s{i}"' for i in sorted(used_s - pinned_s)]
     clob += ['"vcc"', '"scc"', '"memory"']
@@ -433,6 +513,9 @@ def wrapper(A):
 // {len(A.lines)} lines: {st['mfma']} MFMA, {st['valu']} VALU, {st['ds']} LDS reads, {st['vmem']} VMEM, {st['salu']} SALU, {st['nop_states']} padded wait states
 // (static counts of the text; the two generic-stage subroutines run three times each per tile).
 #pragma once
+constexpr int kF16tNdir = {NDIR};                  // 1 KB parts of a pair k-step that bypass the LDS ring (mlp_host.hip sigma_stream_table must cut the stream for it)
+constexpr int kF16tLdsBytes = {K_LDS_BYTES};       // the ring's part of the stream; the direct parts follow
+constexpr int kF16tUnit0Pieces = {4 * NL // 4};    // 1 KB pieces per wave of a stage-0 ring unit (4 k-steps)
 
 __device__ __forceinline__ void sigma_stages_asm(const ArgsF& A, const MlpArgs& a, RingF& R, const uint4* pw, unsigned bias_lds, unsigned tab_lds, int g, int s,
                                                  int tid, int64_t tile, int64_t row0, float os) {{
@@ -459,11 +542,14 @@ __device__ __forceinline__ void sigma_stages_asm(const ArgsF& A, const MlpArgs& 
     register unsigned s_tab asm("s{S_TAB}") = __builtin_amdgcn_readfirstlane(tab_lds);
     register unsigned s_dbg0 asm("s{S_DBG}") = (unsigned)(uintptr_t)A.dbg;
     register unsigned s_dbg1 asm("s{S_DBG + 1}") = (unsigned)((unsigned long long)(uintptr_t)A.dbg >> 32);
+    const unsigned long long bb = (unsigned long long)(uintptr_t)A.stream + (unsigned long long)kF16tLdsBytes;
+    register unsigned s_bb0 asm("s{S_BB}") = (unsigned)bb;
+    register unsigned s_bb1 asm("s{S_BB + 1}") = (unsigned)(bb >> 32);
     asm volatile(
 {body}
         : "+s"(s_off), "+s"(s_slot)
         : "v"(v_rdbase), "v"(v_bias), "v"(v_pe), "v"(v_cp0), "v"(v_out0), "v"(v_out1), "v"(v_dbgoff), "s"(s_img0), "s"(s_img1), "s"(s_ring0), "s"(s_os),
-          "s"(s_sigsc), "s"(s_dbgst), "s"(s_tab), "s"(s_dbg0), "s"(s_dbg1)
+          "s"(s_sigsc), "s"(s_dbgst), "s"(s_tab), "s"(s_dbg0), "s"(s_dbg1), "s"(s_bb0), "s"(s_bb1)
         : {", ".join(clob)});
     R.off = (int)s_off;
     R.slot = (int)s_slot;
