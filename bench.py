@@ -62,7 +62,7 @@ DTYPES = {
     "bf16x3": "bf16x3 (split-bf16 hi+lo MFMA x3, f32 accumulate)",
     "i8x3": "i8x3 (per-row-scaled int16 as 2 int8 limbs, i8 MFMA x3, exact int32 accumulate; encodings on bf16x3)",
     "bf16": "bf16 (f32 accumulate)", "fp32": "f32"}
-PMC_SUMMARIES = ("profiles/r03_bench_pmc_summary.json", "profiles/r02_bench_pmc_summary.json", "profiles/r01_bench_pmc_summary.json")
+PMC_SUMMARIES = ("profiles/r04_bench_pmc_summary.json", "profiles/r03_bench_pmc_summary.json", "profiles/r02_bench_pmc_summary.json", "profiles/r01_bench_pmc_summary.json")
 KERNEL_OF = {"fp16x3": "nerf_mlp_kernel<4, false>", "bf16x3": "nerf_mlp_kernel<1, false>", "i8x3": "nerf_mlp_i8s_kernel", "bf16": "nerf_mlp_kernel<2, false>",
              "fp32": "nerf_mlp_ref_kernel"}
 
@@ -166,6 +166,13 @@ def parity_vs_oracle(oracle, coarse, fine, origins, dirs, precision, full=True):
         out["attribution"] = rep
         out["attribution_statements_violated"] = fails
     return out
+
+
+def kernel_of(which, precision):
+    """the kernel a pass's MLP launch runs: the density-only fp16x3 launch of the sampling pass has its own (csrc/mlp_f16t.hip)"""
+    if which == "coarse" and precision == "fp16x3" and os.environ.get("NEUMAN_SIGMA_KERNEL") != "w":
+        return "nerf_sigma_f16t_kernel"
+    return KERNEL_OF[precision]
 
 
 def pmc_traffic_per_launch(kernel, launch):
@@ -391,9 +398,9 @@ def main():
         density_only = which == "coarse" and precision in ("fp16x3", "bf16x3", "bf16")
         evals, ms = per_rank[slowest][col], per_rank[slowest][col + 1]
         n_launch = int(per_rank[slowest][4])
-        traffic, traffic_source = pmc_traffic_per_launch(KERNEL_OF[precision], launch_index) if world == 1 else (None, None)
+        kernel = kernel_of(which, precision)
+        traffic, traffic_source = pmc_traffic_per_launch(kernel, launch_index) if world == 1 else (None, None)
         achieved = evals * FLOP_PER_EVAL / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        kernel = KERNEL_OF[precision]
         # what the matrix pipe really executes: MFMA ops per algorithmic FLOP x the share of the layers evaluated, against the
         # dense peak of the MFMA type in use (MI355X_MICROARCH.md: bf16 / fp16 2.5 PFLOP/s; i8 ~2x the bf16 rate)
         issued = {"fp16x3": 3.0, "bf16x3": 3.0, "i8x3": 3.0, "bf16": 1.0}.get(precision, 0.0) * ((593408 - 102144) / 593408 if density_only else 1.0)
@@ -417,7 +424,7 @@ def main():
 
     p_coarse = "fp16x3" if args.precision == "mixed" else args.precision
     p_fine = "i8x3" if args.precision == "mixed" else args.precision
-    same_kernel = p_coarse == p_fine                                        # then the fine launch is that kernel's second dispatch
+    same_kernel = kernel_of("coarse", p_coarse) == kernel_of("fine", p_fine)  # then the fine launch is that kernel's second dispatch
 
     if rank == 0:
         rl_fine, rl_coarse = roofline("fine", p_fine, 1 if same_kernel else 0), roofline("coarse", p_coarse, 0)

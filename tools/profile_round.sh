@@ -3,7 +3,7 @@
 #   tools/profile_round.sh r01      -> gpurun_out/<tag>/{bench_kernel_stats.csv, bench_pmc_summary.json, bench_line.json, ...}
 # Counters are collected in their own passes, with --kernel-trace only (no sys/hip/hsa trace domains).
 # The profiled command is `bench.py --timed-only` in the default (mixed) precision: every MLP launch rocprofv3 sees is a
-# timed one -- nerf_mlp_kernel<4,false> = the coarse (fp16x3) launch, nerf_mlp_i8s_kernel = the fine (i8x3) launch.
+# timed one -- nerf_sigma_f16t_kernel = the coarse (fp16x3, density only) launch, nerf_mlp_i8s_kernel = the fine (i8x3) launch.
 # FULL=1 also collects the in-kernel cycle buckets, the clock / power samples and the zero-weight probe (minutes of GPU time).
 set -u
 TAG=${1:-r00}
@@ -29,17 +29,17 @@ for tag, n in [('fetch', 'FETCH_SIZE'), ('write', 'WRITE_SIZE'), ('sq', 'SQ_INST
     d = collections.OrderedDict()
     for r in csv.DictReader(open('/tmp/prof_$TAG/pmc_%s/bench_counter_collection.csv' % n)):
         k = short(r['Kernel_Name'])
-        if not any(s in k for s in ('nerf_mlp', 'composite', 'sample_pdf')):
+        if not any(s in k for s in ('nerf_mlp', 'nerf_sigma', 'composite', 'sample_pdf')):
             continue
         d.setdefault((k, r['Dispatch_Id']), {})[r['Counter_Name']] = float(r['Counter_Value'])
     out[tag] = [{'kernel': k[0], 'dispatch': k[1], **v} for k, v in d.items()]
 out['derived'] = []
-for a, b in zip([x for x in out['sq'] if 'nerf_mlp' in x['kernel']], [x for x in out['grbm'] if 'nerf_mlp' in x['kernel']]):
+for a, b in zip([x for x in out['sq'] if 'nerf_' in x['kernel']], [x for x in out['grbm'] if 'nerf_' in x['kernel']]):
     out['derived'].append({'kernel': a['kernel'], 'mfma_pipe_busy_frac': a['SQ_VALU_MFMA_BUSY_CYCLES'] / (256 * 4 * b['GRBM_GUI_ACTIVE'] / 8),
                            'cycles_per_xcd': b['GRBM_GUI_ACTIVE'] / 8})
 out['note'] = ("bench.py --steps 1 --warmup 0 --timed-only (default precision: mixed) under rocprofv3 --pmc <one group per pass> "
                "--kernel-trace; FETCH_SIZE/WRITE_SIZE in KiB (FETCH_SIZE under-reports wide streaming reads by 2x on gfx950, "
-               "MI355X_MICROARCH.md); one coarse launch (nerf_mlp_kernel<4, false>, 81.92 M evaluations) and one fine launch "
+               "MI355X_MICROARCH.md); one coarse launch (nerf_sigma_f16t_kernel, 81.92 M evaluations) and one fine launch "
                "(nerf_mlp_i8s_kernel, 163.84 M evaluations)")
 json.dump(out, open('$OUT/bench_pmc_summary.json', 'w'), indent=1)
 print(json.dumps(out['derived']))
