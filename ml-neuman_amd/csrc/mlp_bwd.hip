@@ -1,0 +1,182 @@
+// The backward-data chain of the 8 x 256 trunk in ONE kernel: dZ of a 128-sample tile stays in LDS from layer 7 down to layer 0.
+//
+// What it replaces: the loop of neuman_hip/train.py _MLP.backward that turns the gradient of layer i's pre-activation into layer i - 1's --
+// autograd's adjoint of models/vanilla.py:126-131 (h = relu(linear_i(h)); the skip concatenation before layer 5) inside the training steps of
+// trainers/vanilla_nerf_trainer.py:45-96 and trainers/human_nerf_trainer.py:382-446 -- seven products [n, 256] x [256, 256] through HBM
+// with a column-sum pass each (21 launches per net), as
+//
+//     dZ_{i-1} = (dZ_i W_i[:, hidden part]) * (H_{i-1} > 0),        db_{i-1} = column sums of dZ_{i-1},        i = 7 .. 1
+//
+// in nerf_mlp_kernel's frame (mlp.hip): one workgroup of 8 waves per 128-sample tile, dZ in LDS as split bf16 (hi | lo: the arithmetic of
+// the GEMM chain's backward products, nm_gemm_bf16x3: range-safe for gradients of any magnitude), wave w owns output features 32 w .. 32 w + 31
+// of all 128 samples, the transposed weights stream from L2 as packed MFMA fragments (bwd_pack_kernel: from the LIVE parameters, every call).
+// Per stage the epilogue masks with the saved activation (read once, f32), stores the f32 copy the weight-gradient product reads, reduces
+// the tile's column sums inside the wave (its 32 features' 128 samples are all its own) and writes the split bf16 operand of the next stage.
+// The weight-gradient products stay separate launches: their 256 x 256 accumulators per layer do not fit a workgroup beside this.
+#include "mlp_device.h"
+
+namespace {
+
+constexpr int kBwdStages = 7;
+constexpr int kBwdStageBytes = 8 * 16 * nm::kStepBytes;            // 8 output blocks x 16 k-steps
+constexpr int kBwdImageBytes = kBwdStages * kBwdStageBytes;
+constexpr int kBwdPadBytes = 4 * nm::kStepBytes;                   // the weight pipeline prefetches two steps past a run's end
+
+struct BwdArgs {
+    const uint4* wpack;        // [7][8 blocks][16 steps] fragments: stage j = layer 7 - j, W^T (hidden columns), split bf16
+    const float* dz_top;       // [n][256] gradient of layer 7's pre-activation (masked by H7 > 0 already)
+    const float* acts;         // [9][n][256] saved post-activation outputs of layers 0..7 (+ feature): stage j masks with acts[6 - j]
+    float* dz_out;             // [7][n][256]: dz_out[j] = gradient of layer (6 - j)'s pre-activation
+    float* colsum;             // [tiles][7][256] per-tile column sums of dz_out[j]
+    int64_t n;
+};
+
+__global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs a) {
+    __shared__ uint4 lds[LDS_U4];
+    constexpr int PREC = NM_PREC_BF16X3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, s = lane & 31;
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.wpack), 0, kBwdImageBytes + kBwdPadBytes, 0x00020000);
+    const int voff = lane * 16;
+    auto wo = [](int j, int blk) { return j * kBwdStageBytes + blk * 16 * nm::kStepBytes; };
+    const int64_t ntiles = (a.n + kTileM - 1) / kTileM;
+    WPre W;
+    w_prefetch<PREC>(W, wsrc, voff, wo(0, w));
+#pragma unroll 1
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = tile * kTileM;
+        // ---- dZ_7 of the tile -> split bf16 in LDS, k-slot order (chunk c, element e) = feature slot_feature(c, e): two runs of 4 features
+#pragma unroll 1
+        for (int item = tid; item < nm::kHChunks * kTileM; item += kThreads) {
+            const int c = item >> 7, row = item & (kTileM - 1);
+            const int64_t i = base + row;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (i < a.n) {
+                const float* src = a.dz_top + i * 256 + nm::slot_feature(c, 0);
+                const float4 lo4 = *reinterpret_cast<const float4*>(src), hi4 = *reinterpret_cast<const float4*>(src + 8);
+                v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w; v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
+            }
+            uint4 hi, lo;
+            split8<false, false>(v, hi, lo);
+            lds[H_BASE + c * kChunkU4 + row] = hi;
+            lds[H_BASE + c * kChunkU4 + kLoU4 + row] = lo;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int j = 0; j < kBwdStages; ++j) {
+            f32x16 acc[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+            k_run<4, PREC>(acc, W, wsrc, voff, wo(j, w), j + 1 < kBwdStages ? wo(j + 1, w) : wo(0, w), lds + H_BASE + g * kChunkU4 + s, 16);
+            // ---- mask with the saved activation of layer 6 - j, store the f32 copy, column sums
+            const float* mask = a.acts + (int64_t)(kBwdStages - 1 - j) * a.n * 256;
+            float* out = a.dz_out + (int64_t)j * a.n * 256;
+            float cs[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cs[r] = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const int64_t row = base + 32 * mb + s;
+                const bool live = row < a.n;
+                const int64_t off = (live ? row : 0) * 256 + 32 * w + 4 * g;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 m = *reinterpret_cast<const float4*>(mask + off + 8 * q);
+                    float4 v = make_float4(acc[mb][4 * q], acc[mb][4 * q + 1], acc[mb][4 * q + 2], acc[mb][4 * q + 3]);
+                    v.x = (live && m.x > 0.f) ? v.x : 0.f;
+                    v.y = (live && m.y > 0.f) ? v.y : 0.f;
+                    v.z = (live && m.z > 0.f) ? v.z : 0.f;
+                    v.w = (live && m.w > 0.f) ? v.w : 0.f;
+                    acc[mb][4 * q] = v.x; acc[mb][4 * q + 1] = v.y; acc[mb][4 * q + 2] = v.z; acc[mb][4 * q + 3] = v.w;
+                    if (live) *reinterpret_cast<float4*>(out + off + 8 * q) = v;
+                    cs[4 * q] += v.x; cs[4 * q + 1] += v.y; cs[4 * q + 2] += v.z; cs[4 * q + 3] += v.w;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {                         // over the 32 samples of a lane half (fixed order: deterministic)
+                float v = cs[r];
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+                cs[r] = v;
+            }
+            if (s == 0) {
+                float* o = a.colsum + ((int64_t)tile * kBwdStages + j) * 256 + 32 * w + 4 * g;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(o + 8 * q) = make_float4(cs[4 * q], cs[4 * q + 1], cs[4 * q + 2], cs[4 * q + 3]);
+            }
+            if (j + 1 < kBwdStages) {
+                ActRegs<4> ar;
+                convert_act<4, false, PREC>(acc, ar);
+                __syncthreads();                                   // every wave has finished reading this stage's operand
+                write_act<4, PREC>(ar, lds, w, 0, g, s);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// the transposed hidden weights of layers 7 .. 1 as MFMA A-operand fragments (mlp_layout.h: lane (g, s) of k-step t of output block nb holds
+// output feature 32 nb + s, k-slots (chunk 2 t + g, e = 0 .. 7)), split bf16: stage j multiplies dZ of layer i = 7 - j, so its "output
+// feature" is an INPUT feature of layer i (skip layer 5: behind the encoding columns) and its k index an OUTPUT feature of layer i
+__global__ __launch_bounds__(256) void bwd_pack_kernel(nm::DevParams P, int kpe, uint8_t* __restrict__ img) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int step = gid >> 6, lane = gid & 63;
+    if (step >= kBwdStages * 8 * 16) return;
+    const int j = step / 128, nb = (step % 128) / 16, t = step % 16;
+    const int i = 7 - j;
+    const float* Wi = P.p[nm::P_PTS_W + 2 * i];
+    const int K = i == 5 ? kpe + 256 : 256, col = (i == 5 ? kpe : 0) + 32 * nb + (lane & 31);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = Wi[(int64_t)nm::slot_feature(2 * t + (lane >> 5), e) * K + col];
+    uint4 hi, lo;
+    split8<false, false>(v, hi, lo);
+    uint4* dst = reinterpret_cast<uint4*>(img + (int64_t)step * nm::kStepBytes) + lane;
+    dst[0] = hi;
+    dst[64] = lo;
+}
+
+// gb[j][f] = sum over tiles of colsum[tile][j][f]: 32 columns per workgroup, 8 interleaved row groups, fixed order
+__global__ __launch_bounds__(256) void bwd_colsum_kernel(const float* __restrict__ colsum, int64_t ntiles, float* __restrict__ gb) {
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5, c = blockIdx.x * 32 + cx;
+    float acc = 0.f;
+    for (int64_t t = ry; t < ntiles; t += 8) acc += colsum[t * (kBwdStages * 256) + c];
+    __shared__ float part[8][32];
+    part[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0) {
+        float v = part[0][cx];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v += part[k][cx];
+        gb[c] = v;
+    }
+}
+
+}  // namespace
+
+namespace nm {
+
+int64_t mlp_bwd_image_bytes() { return kBwdImageBytes + kBwdPadBytes; }
+
+int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_top, const float* acts, int64_t n, float* dz_out, float* colsum,
+                   float* gb, hipStream_t stream) {
+    hipLaunchKernelGGL(bwd_pack_kernel, dim3((kBwdStages * 8 * 16 * 64 + 255) / 256), dim3(256), 0, stream, P, kpe, image);
+    BwdArgs a;
+    a.wpack = reinterpret_cast<const uint4*>(image);
+    a.dz_top = dz_top; a.acts = acts; a.dz_out = dz_out; a.colsum = colsum; a.n = n;
+    const int64_t ntiles = (n + kTileM - 1) / kTileM;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int grid = (int)(ntiles < cus ? ntiles : cus);
+    hipLaunchKernelGGL(nerf_mlp_bwd_kernel, dim3(grid), dim3(kThreads), 0, stream, a);
+    hipLaunchKernelGGL(bwd_colsum_kernel, dim3(kBwdStages * 256 / 32), dim3(256), 0, stream, colsum, ntiles, gb);
+    return check_launch("nerf_mlp_bwd_kernel");
+}
+
+}  // namespace nm

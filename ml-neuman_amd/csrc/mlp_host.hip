@@ -84,9 +84,7 @@ static inline float f16_to_f32(uint16_t h) {
     return f;
 }
 
-// indices into host_params (reference state_dict order, include/neuman_hip.h)
-enum { P_OUT_W = 16, P_OUT_B = 17 };      // plain head (use_viewdirs=False): output_linear follows the 16 pts_linears tensors
-enum { P_PTS_W = 0, P_VIEWS_W = 16, P_VIEWS_B = 17, P_FEAT_W = 18, P_FEAT_B = 19, P_ALPHA_W = 20, P_ALPHA_B = 21, P_RGB_W = 22, P_RGB_B = 23 };
+// (indices into host_params: mlp_launch.h P_*)
 
 static int validate_desc(const nm_mlp_desc* d) {
     NM_REQUIRE(d, "nm_mlp: null descriptor");
@@ -200,22 +198,19 @@ static void pack_image(const nm_mlp_desc* d, const float* const* P, uint8_t* img
 // a training loop whose weights change every iteration (a host repack would cost a 2.4 MB download, a CPU pass and an upload per
 // network and step).  Same scale rule, same rounding (RNE to fp16 twice), same layout: the forward through a refreshed handle is
 // bit-identical to the forward through a handle created from the same values (tests/test_hip_train.py).
-struct DevParams {
-    const float* p[24];
-};
-__global__ __launch_bounds__(256) void f16_stage_scale_kernel(nm_mlp_desc d, DevParams P, float* __restrict__ wscale) {
+__global__ __launch_bounds__(1024) void f16_stage_scale_kernel(nm_mlp_desc d, DevParams P, float* __restrict__ wscale) {
     const int st = blockIdx.x;
     const StageShape sh = stage_shape(st);
     const int per_row = 2 * sh.steps * 8, total = sh.nblk * 32 * per_row;
     float mx = 0.f;
-    for (int i = threadIdx.x; i < total; i += 256) {
+    for (int i = threadIdx.x; i < total; i += 1024) {
         const int n = i / per_row, r = i - n * per_row;
         mx = fmaxf(mx, fabsf(stage_weight(&d, P.p, st, n, r >> 3, r & 7)));
     }
-    __shared__ float part[256];
+    __shared__ float part[1024];
     part[threadIdx.x] = mx;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if (threadIdx.x < o) part[threadIdx.x] = fmaxf(part[threadIdx.x], part[threadIdx.x + o]);
         __syncthreads();
     }
@@ -492,6 +487,7 @@ struct nm_mlp_s {
     uint8_t* d_image8t;    // NM_PREC_I8X3: the workgroup stream of nerf_mlp_i8t_kernel (pack_stream8t)
     uint8_t* d_stream16t;  // NM_PREC_FP16X3, density only: the stream of nerf_sigma_f16t_kernel (sigma_stream_kernel over d_image16)
     int* d_sigma_tab;      //   its piece table
+    uint8_t* d_bwd_image;  // the transposed hidden weights of the backward-data chain (mlp_bwd.hip), repacked from live parameters per call
     int sigma_ndir;        //   parts of a pair k-step that bypass the LDS ring (the kernel is generated for one value: NEUMAN_F16T_NDIR is for experiments)
     float* d_petab;        // 192 floats
     float* d_ref;          // transposed f32 weights | natural biases (NM_PREC_FP32 path)
@@ -621,7 +617,7 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     m->pos_octaves = octaves(tab, desc->pos_n_freqs);
     m->dir_octaves = octaves(tab + 96, desc->dir_n_freqs);
 
-    m->d_image = nullptr; m->d_image16 = nullptr; m->d_consts8 = nullptr; m->d_stream8 = nullptr; m->d_image8 = nullptr; m->d_image8t = nullptr; m->d_stream16t = nullptr; m->d_sigma_tab = nullptr; m->d_petab = nullptr; m->d_ref = nullptr; m->d_wscale16 = nullptr;
+    m->d_image = nullptr; m->d_image16 = nullptr; m->d_consts8 = nullptr; m->d_stream8 = nullptr; m->d_image8 = nullptr; m->d_image8t = nullptr; m->d_stream16t = nullptr; m->d_sigma_tab = nullptr; m->d_bwd_image = nullptr; m->d_petab = nullptr; m->d_ref = nullptr; m->d_wscale16 = nullptr;
     int rc = nm::check_hip(hipMalloc(&m->d_image, (size_t)bytes), "nm_mlp_create: hipMalloc(image)");
     const size_t consts_off = (size_t)(nm::kWeightBytes8 + nm::kWeightPadBytes), consts_bytes = img8.size() - consts_off;
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_consts8, consts_bytes), "nm_mlp_create: hipMalloc(consts8)");
@@ -671,7 +667,7 @@ int nm_mlp_refresh_f16(nm_mlp_t m, const float* const* dev_params, nm_stream_t s
         if (int rc = nm::check_hip(hipMalloc(&m->d_wscale16, nm::kStages * sizeof(float)), "nm_mlp_refresh_f16: hipMalloc")) return rc;
     hipStream_t st = nm::as_stream(stream);
     float* bias = reinterpret_cast<float*>(m->d_image16 + nm::kWeightBytes + nm::kWeightPadBytes);
-    hipLaunchKernelGGL(nm::f16_stage_scale_kernel, dim3(nm::kStages), dim3(256), 0, st, m->desc, P, m->d_wscale16);
+    hipLaunchKernelGGL(nm::f16_stage_scale_kernel, dim3(nm::kStages), dim3(1024), 0, st, m->desc, P, m->d_wscale16);
     const int threads = (int)(nm::kWeightBytes / nm::kStepBytes) * 64;
     hipLaunchKernelGGL(nm::f16_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, m->desc, P, m->d_wscale16, m->d_image16);
     hipLaunchKernelGGL(nm::f16_bias_kernel, dim3((nm::kBiasFloats + nm::kF16TabFloats + 255) / 256), dim3(256), 0, st, P, m->d_wscale16, bias);
@@ -693,6 +689,7 @@ int nm_mlp_destroy(nm_mlp_t m) {
     if (m->d_image8t) (void)hipFree(m->d_image8t);
     if (m->d_stream16t) (void)hipFree(m->d_stream16t);
     if (m->d_sigma_tab) (void)hipFree(m->d_sigma_tab);
+    if (m->d_bwd_image) (void)hipFree(m->d_bwd_image);
     if (m->d_petab) (void)hipFree(m->d_petab);
     if (m->d_ref) (void)hipFree(m->d_ref);
     if (m->d_wscale16) (void)hipFree(m->d_wscale16);
@@ -781,6 +778,29 @@ int nm_mlp_forward_save(nm_mlp_t m, const float* pts, const float* dirs, int64_t
     L.save_h = save_h; L.save_hv = save_hv;
     return nm::launch_mlp_mfma(L, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, NM_PREC_FP16X3, -2, 1.f, out, nullptr, nullptr,
                                nm::as_stream(stream), 0, nullptr);
+}
+
+int64_t nm_mlp_backward_chain_workspace_floats(int64_t n) { return ((n + nm::kTileM - 1) / nm::kTileM) * 7 * 256; }
+
+int nm_mlp_backward_chain(nm_mlp_t m, const float* const* dev_params, const float* dz_top, const float* acts, int64_t n, float* dz_out,
+                          float* bias_grads, float* workspace, int64_t workspace_floats, nm_stream_t stream) {
+    NM_REQUIRE(m && dev_params, "nm_mlp_backward_chain: null pointer");
+    NM_REQUIRE(n >= 0, "nm_mlp_backward_chain: negative n");
+    if (n == 0) return NM_OK;
+    NM_REQUIRE(dz_top && acts && dz_out && bias_grads && workspace, "nm_mlp_backward_chain: null pointer");
+    NM_REQUIRE(workspace_floats >= nm_mlp_backward_chain_workspace_floats(n), "nm_mlp_backward_chain: workspace of %lld floats, %lld needed",
+               (long long)workspace_floats, (long long)nm_mlp_backward_chain_workspace_floats(n));
+    NM_REQUIRE(((reinterpret_cast<uintptr_t>(dz_top) | reinterpret_cast<uintptr_t>(acts) | reinterpret_cast<uintptr_t>(dz_out) |
+                 reinterpret_cast<uintptr_t>(workspace)) & 15) == 0, "nm_mlp_backward_chain: buffers must be 16-byte aligned");
+    nm::DevParams P;
+    for (int i = 0; i < 16; ++i) {
+        NM_REQUIRE(dev_params[i], "nm_mlp_backward_chain: dev_params[%d] is null", i);
+        P.p[i] = dev_params[i];
+    }
+    for (int i = 16; i < 24; ++i) P.p[i] = nullptr;
+    if (!m->d_bwd_image)
+        if (int rc = nm::check_hip(hipMalloc(&m->d_bwd_image, (size_t)nm::mlp_bwd_image_bytes()), "nm_mlp_backward_chain: hipMalloc")) return rc;
+    return nm::launch_mlp_bwd(P, 3 + 6 * m->desc.pos_n_freqs, m->d_bwd_image, dz_top, acts, n, dz_out, workspace, bias_grads, nm::as_stream(stream));
 }
 
 int nm_mlp_forward_rays(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals, int64_t R, int S,

@@ -4,6 +4,13 @@
 
 namespace nm {
 
+// indices into the 24 parameter arrays of a net (reference state_dict order, include/neuman_hip.h)
+enum { P_OUT_W = 16, P_OUT_B = 17 };      // plain head (use_viewdirs=False): output_linear follows the 16 pts_linears tensors
+enum { P_PTS_W = 0, P_VIEWS_W = 16, P_VIEWS_B = 17, P_FEAT_W = 18, P_FEAT_B = 19, P_ALPHA_W = 20, P_ALPHA_B = 21, P_RGB_W = 22, P_RGB_B = 23 };
+struct DevParams {                        // the same arrays on the device (a net under training: the live parameters)
+    const float* p[24];
+};
+
 struct MlpLaunch {
     const void* wpack; const float* bias; const float* petab;
     int pe_kind, pos_nfreq, dir_nfreq;
@@ -42,6 +49,11 @@ int launch_mlp_i8t(const MlpLaunch& L, const void* image8t, const float* pts, co
 int launch_sigma_f16t(const MlpLaunch& L, const void* stream16t, int stream_ndir, const float* pts, const float* dirs, const float* origin, const float* direction,
                       const float* z, int64_t n, int S, int in_mode, float sigma_scale, float* out, hipStream_t stream, const MlpChunk* chunk,
                       float* dbg, int dbg_stage);
+// the backward-data chain of the 8 x 256 trunk (mlp_bwd.hip): packs W^T of layers 7..1 from the live parameters into `image`
+// (mlp_bwd_image_bytes()), dz_out [7][n][256], colsum [tiles][7][256] scratch, gb [7][256] = bias gradients of layers 6..0
+int64_t mlp_bwd_image_bytes();
+int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_top, const float* acts, int64_t n, float* dz_out, float* colsum,
+                   float* gb, hipStream_t stream);
 int launch_mlp_ref(const RefLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
                    const float* z, int64_t n, int S, int in_mode, int stop_stage, float sigma_scale, float* out, float* dbg,
                    hipStream_t stream);

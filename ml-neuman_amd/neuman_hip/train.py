@@ -32,6 +32,9 @@ GEMM_PRECISION = os.environ.get('NEUMAN_TRAIN_GEMM', 'mixed16')
 # the forward of a standard Joiner (3-D encodings, 8 x 256, view directions) in ONE kernel that keeps a tile's activations on chip across
 # the layers and only writes the copies the backward pass reads (nm_mlp_forward_save; mixed16 only).  NEUMAN_TRAIN_FUSED=0: the GEMM chain.
 FUSED_FORWARD = os.environ.get('NEUMAN_TRAIN_FUSED', '1') != '0'
+# ... and the backward-data chain of its trunk in one kernel as well (nm_mlp_backward_chain: dZ of a tile stays on chip from layer 7 to layer 0,
+# bias gradients out of the same pass); the weight-gradient products stay per layer.  NEUMAN_TRAIN_FUSED_BWD=0: the GEMM chain.
+FUSED_BACKWARD = os.environ.get('NEUMAN_TRAIN_FUSED_BWD', '1') != '0'
 
 
 def _gemm(a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, bias=None, mask=None, ldmask=0, flags=0, ws=None, precision=None):
@@ -151,6 +154,7 @@ class _MLP(torch.autograd.Function):
             H, feat = [acts[i] for i in range(8)], acts[8]
             ctx.pk, ctx.X0, ctx.D0, ctx.H, ctx.feat, ctx.hv, ctx.n, ctx.net = pk, X0, D0, H, feat, hv, n, net
             ctx.p4, ctx.d4 = p4, d4
+            ctx.acts = acts
             return raw[:n]
         H = []
         h, kh = X0, pk.kp
@@ -252,9 +256,26 @@ class _MLP(torch.autograd.Function):
             head = [wgrad(d_raw, 4, h7, width)[:pk.n_out].contiguous(), bgrad(d_raw, 4)[:pk.n_out].contiguous()]
             _gemm(0, 1, n4, width, 4, d_raw, 4, pk.Wo4, width, dz, width, mask=h7, ldmask=width, flags=MASK | COLSUM, ws=cs_buf)
         gw, gb = [None] * len(pk.W), [None] * len(pk.W)
+        chain = None
+        if FUSED_BACKWARD and getattr(ctx, 'acts', None) is not None and len(pk.W) == 8 and width == 256:
+            import ctypes
+            gb[7] = band_sum(width)                                              # of dz_7: left in cs_buf by the product that made it
+            chain = torch.empty((7, n4, width), device=dev, dtype=torch.float32)   # dz of layers 6 .. 0
+            gbs = torch.empty((7, width), device=dev, dtype=torch.float32)
+            need = int(_lib.lib().nm_mlp_backward_chain_workspace_floats(n4))
+            if need > ws[0].numel():
+                ws[0] = torch.empty(need, device=dev, dtype=torch.float32)
+            ptrs = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in nerf.ordered_params()])
+            _lib.check(_lib.lib().nm_mlp_backward_chain(net.train_handle(), ptrs, _lib.dev_ptr(dz), _lib.dev_ptr(ctx.acts), n4, _lib.dev_ptr(chain),
+                                                        _lib.dev_ptr(gbs), _lib.dev_ptr(ws[0]), ws[0].numel(), _lib.stream_ptr()), "nm_mlp_backward_chain")
+            for i in range(7):
+                gb[i] = gbs[6 - i]
         for i in range(len(pk.W) - 1, -1, -1):
             Ws = pk.W[i]
-            gb[i] = band_sum(width)                                              # of dz: left in cs_buf by the product that made it
+            if chain is None:
+                gb[i] = band_sum(width)                                          # of dz: left in cs_buf by the product that made it
+            elif i < 7:
+                dz = chain[6 - i]
             if want_in and (i == 0 or len(Ws) == 2):                             # gradient of the encoded position: both layers it feeds
                 first = dX0 is None
                 if first:
@@ -270,9 +291,10 @@ class _MLP(torch.autograd.Function):
             else:
                 gw[i] = wgrad(dz, width, prev, width)
                 Wb = Ws[0]
-            nz = torch.empty((n4, width), device=dev, dtype=torch.float32)
-            _gemm(0, 1, n4, width, width, dz, width, Wb, width, nz, width, mask=prev, ldmask=width, flags=MASK | COLSUM, ws=cs_buf)
-            dz = nz
+            if chain is None:
+                nz = torch.empty((n4, width), device=dev, dtype=torch.float32)
+                _gemm(0, 1, n4, width, width, dz, width, Wb, width, nz, width, mask=prev, ldmask=width, flags=MASK | COLSUM, ws=cs_buf)
+                dz = nz
         grads = []
         for i in range(len(pk.W)):
             grads += [gw[i].contiguous(), gb[i].contiguous()]

@@ -321,3 +321,37 @@ def test_fused_training_forward(G, monkeypatch):
         assert gw < 2e-3          # (two float32-class forwards decide a few ReLUs at |x| ~ 1e-7 differently; the reference goldens bound each: above)
         opt.step()                                               # the weights change: the next refresh must follow them
         opt.zero_grad()
+
+
+@pytest.mark.parametrize("n_rays", [7, 300])
+def test_fused_backward_chain(G, monkeypatch, n_rays):
+    """nm_mlp_backward_chain: the backward-data chain of the trunk in one kernel (dZ of a 128-sample tile on chip from layer 7 to layer 0,
+    bias gradients out of the same pass) against the per-layer GEMM chain it replaces -- same split-bf16 x3 products, another summation
+    order: every parameter gradient and the input gradients within 2e-5 of the tensor's largest entry; ragged tiles; the weights are
+    repacked from the live parameters in the call (an optimiser step between the two backward passes is followed)."""
+    monkeypatch.setattr(G.train, "GEMM_PRECISION", "mixed16")
+    monkeypatch.setattr(G.train, "FUSED_FORWARD", True)
+    g = torch.Generator(device='cuda').manual_seed(n_rays)
+    S = 37
+    pts = (torch.rand((n_rays, S, 3), device='cuda', generator=g) * 2 - 1).requires_grad_(True)
+    dirs = torch.nn.functional.normalize(torch.randn((n_rays, 1, 3), device='cuda', generator=g), dim=-1).expand(n_rays, S, 3).contiguous().requires_grad_(True)
+    net = G.syn.make_joiner(1).cuda().train()
+    tgt = torch.rand((n_rays, S, 4), device='cuda', generator=g)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-2)
+    for step in range(2):
+        res = {}
+        for fused in (True, False):
+            monkeypatch.setattr(G.train, "FUSED_BACKWARD", fused)
+            for p in list(net.parameters()) + [pts, dirs]:
+                p.grad = None
+            out = net(pts, dirs)
+            ((out - tgt) ** 2).sum().backward()
+            res[fused] = [p.grad.clone() for p in net.parameters()] + [pts.grad.clone(), dirs.grad.clone()]
+        worst = 0.0
+        for a, b in zip(res[True], res[False]):
+            assert torch.isfinite(a).all()
+            worst = max(worst, float((a - b).abs().max() / b.abs().max().clamp_min(1e-20)))
+        print(f"[train] fused backward chain, step {step}, {n_rays * S} samples: worst gradient deviation from the GEMM chain {worst:.2e} of the tensor's largest entry")
+        assert worst < 2e-5, worst
+        monkeypatch.setattr(G.train, "FUSED_BACKWARD", True)
+        opt.step()
