@@ -101,6 +101,18 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
             if (SAVE) {
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) save_block(a.save_h + (int64_t)st * a.n * 256, 256, acc[mb], w, base + 32 * mb + s, acc2out(st), true);
+                if (a.save_bits) {                                     // one bit per saved activation: (value > 0); the two lane halves of a sample share a word
+                    const float sc = acc2out(st);
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) {
+                        unsigned bits = 0;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) bits |= (acc[mb][r] * sc > 0.f ? 1u : 0u) << (8 * (r >> 2) + 4 * g + (r & 3));
+                        bits |= (unsigned)__shfl_xor((int)bits, 32, 64);
+                        const int64_t row = base + 32 * mb + s;
+                        if (g == 0 && row < a.n) a.save_bits[((int64_t)st * a.n + row) * 8 + w] = bits;
+                    }
+                }
             }
             ActRegs<4> ar;
             convert_act<4, true, PREC>(acc, ar, acc2act(st));
@@ -811,7 +823,7 @@ int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, con
     a.pts = pts; a.dirs = dirs; a.origin = origin; a.direction = direction; a.z = z;
     a.out = out; a.dbg = dbg; a.prof = reinterpret_cast<unsigned long long*>(prof); a.n = n; a.S = S; a.in_mode = in_mode; a.stop_stage = stop_stage; a.sigma_scale = sigma_scale;
     a.sigma_only = L.plain_head ? 2 : ((sigma_only && precision != NM_PREC_I8X3) ? 1 : 0);   // (the i8x3 kernel always evaluates the colour head)
-    a.save_h = L.save_h; a.save_hv = L.save_hv;
+    a.save_h = L.save_h; a.save_hv = L.save_hv; a.save_bits = L.save_bits;
     a.pos = PeSpec{L.pe_kind, L.pos_nfreq, L.pos_octaves};
     a.dir = PeSpec{L.pe_kind, L.dir_nfreq, L.dir_octaves};
     const int64_t ntiles = (n + kTileM - 1) / kTileM;

@@ -26,6 +26,7 @@ struct BwdArgs {
     const uint4* wpack;        // [7][8 blocks][16 steps] fragments: stage j = layer 7 - j, W^T (hidden columns), split bf16
     const float* dz_top;       // [n][256] gradient of layer 7's pre-activation (masked by H7 > 0 already)
     const float* acts;         // [9][n][256] saved post-activation outputs of layers 0..7 (+ feature): stage j masks with acts[6 - j]
+    const unsigned* bits;      // nullable: [8][n][8] their signs (nm_mlp_forward_save_bits): read instead of acts, 1/32 of the bytes
     float* dz_out;             // [7][n][256]: dz_out[j] = gradient of layer (6 - j)'s pre-activation
     float* colsum;             // [tiles][7][256] per-tile column sums of dz_out[j]
     int64_t n;
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
             k_run<4, PREC>(acc, W, wsrc, voff, wo(j, w), j + 1 < kBwdStages ? wo(j + 1, w) : wo(0, w), lds + H_BASE + g * kChunkU4 + s, 16);
             // ---- mask with the saved activation of layer 6 - j, store the f32 copy, column sums
             const float* mask = a.acts + (int64_t)(kBwdStages - 1 - j) * a.n * 256;
+            const unsigned* mbits = a.bits ? a.bits + (int64_t)(kBwdStages - 1 - j) * a.n * 8 + w : nullptr;
             float* out = a.dz_out + (int64_t)j * a.n * 256;
             float cs[16];
 #pragma unroll
@@ -82,14 +84,21 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                 const int64_t row = base + 32 * mb + s;
                 const bool live = row < a.n;
                 const int64_t off = (live ? row : 0) * 256 + 32 * w + 4 * g;
+                const unsigned word = (mbits && live) ? mbits[row * 8] >> (4 * g) : 0u;     // bit 8 q + j' of it: feature 8 q + 4 g + j'
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 m = *reinterpret_cast<const float4*>(mask + off + 8 * q);
+                    bool k0, k1, k2, k3;
+                    if (mbits) {
+                        k0 = (word >> (8 * q)) & 1u; k1 = (word >> (8 * q + 1)) & 1u; k2 = (word >> (8 * q + 2)) & 1u; k3 = (word >> (8 * q + 3)) & 1u;
+                    } else {
+                        const float4 m = *reinterpret_cast<const float4*>(mask + off + 8 * q);
+                        k0 = live && m.x > 0.f; k1 = live && m.y > 0.f; k2 = live && m.z > 0.f; k3 = live && m.w > 0.f;
+                    }
                     float4 v = make_float4(acc[mb][4 * q], acc[mb][4 * q + 1], acc[mb][4 * q + 2], acc[mb][4 * q + 3]);
-                    v.x = (live && m.x > 0.f) ? v.x : 0.f;
-                    v.y = (live && m.y > 0.f) ? v.y : 0.f;
-                    v.z = (live && m.z > 0.f) ? v.z : 0.f;
-                    v.w = (live && m.w > 0.f) ? v.w : 0.f;
+                    v.x = k0 ? v.x : 0.f;
+                    v.y = k1 ? v.y : 0.f;
+                    v.z = k2 ? v.z : 0.f;
+                    v.w = k3 ? v.w : 0.f;
                     acc[mb][4 * q] = v.x; acc[mb][4 * q + 1] = v.y; acc[mb][4 * q + 2] = v.z; acc[mb][4 * q + 3] = v.w;
                     if (live) *reinterpret_cast<float4*>(out + off + 8 * q) = v;
                     cs[4 * q] += v.x; cs[4 * q + 1] += v.y; cs[4 * q + 2] += v.z; cs[4 * q + 3] += v.w;
@@ -161,12 +170,12 @@ namespace nm {
 
 int64_t mlp_bwd_image_bytes() { return kBwdImageBytes + kBwdPadBytes; }
 
-int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_top, const float* acts, int64_t n, float* dz_out, float* colsum,
+int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_top, const float* acts, const unsigned* relu_bits, int64_t n, float* dz_out, float* colsum,
                    float* gb, hipStream_t stream) {
     hipLaunchKernelGGL(bwd_pack_kernel, dim3((kBwdStages * 8 * 16 * 64 + 255) / 256), dim3(256), 0, stream, P, kpe, image);
     BwdArgs a;
     a.wpack = reinterpret_cast<const uint4*>(image);
-    a.dz_top = dz_top; a.acts = acts; a.dz_out = dz_out; a.colsum = colsum; a.n = n;
+    a.dz_top = dz_top; a.acts = acts; a.bits = relu_bits; a.dz_out = dz_out; a.colsum = colsum; a.n = n;
     const int64_t ntiles = (n + kTileM - 1) / kTileM;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {

@@ -757,6 +757,11 @@ int nm_mlp_forward(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n,
 
 int nm_mlp_forward_save(nm_mlp_t m, const float* pts, const float* dirs, int64_t n, float* save_h, float* save_hv, float* out,
                         nm_stream_t stream) {
+    return nm_mlp_forward_save_bits(m, pts, dirs, n, save_h, save_hv, nullptr, out, stream);
+}
+
+int nm_mlp_forward_save_bits(nm_mlp_t m, const float* pts, const float* dirs, int64_t n, float* save_h, float* save_hv, uint32_t* save_bits,
+                             float* out, nm_stream_t stream) {
     NM_REQUIRE(m, "nm_mlp_forward_save: null handle");
     NM_REQUIRE(!m->desc.plain_head, "nm_mlp_forward_save: the plain-head net has no fused training forward");
     NM_REQUIRE(n >= 0, "nm_mlp_forward_save: negative n");
@@ -775,19 +780,19 @@ int nm_mlp_forward_save(nm_mlp_t m, const float* pts, const float* dirs, int64_t
     L.plain_head = 0;
     L.wstream8 = m->d_stream8;
     L.consts8 = m->d_consts8;
-    L.save_h = save_h; L.save_hv = save_hv;
+    L.save_h = save_h; L.save_hv = save_hv; L.save_bits = save_bits;
     return nm::launch_mlp_mfma(L, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, NM_PREC_FP16X3, -2, 1.f, out, nullptr, nullptr,
                                nm::as_stream(stream), 0, nullptr);
 }
 
 int64_t nm_mlp_backward_chain_workspace_floats(int64_t n) { return ((n + nm::kTileM - 1) / nm::kTileM) * 7 * 256; }
 
-int nm_mlp_backward_chain(nm_mlp_t m, const float* const* dev_params, const float* dz_top, const float* acts, int64_t n, float* dz_out,
-                          float* bias_grads, float* workspace, int64_t workspace_floats, nm_stream_t stream) {
+int nm_mlp_backward_chain(nm_mlp_t m, const float* const* dev_params, const float* dz_top, const float* acts, const uint32_t* relu_bits, int64_t n,
+                          float* dz_out, float* bias_grads, float* workspace, int64_t workspace_floats, nm_stream_t stream) {
     NM_REQUIRE(m && dev_params, "nm_mlp_backward_chain: null pointer");
     NM_REQUIRE(n >= 0, "nm_mlp_backward_chain: negative n");
     if (n == 0) return NM_OK;
-    NM_REQUIRE(dz_top && acts && dz_out && bias_grads && workspace, "nm_mlp_backward_chain: null pointer");
+    NM_REQUIRE(dz_top && (acts || relu_bits) && dz_out && bias_grads && workspace, "nm_mlp_backward_chain: null pointer");
     NM_REQUIRE(workspace_floats >= nm_mlp_backward_chain_workspace_floats(n), "nm_mlp_backward_chain: workspace of %lld floats, %lld needed",
                (long long)workspace_floats, (long long)nm_mlp_backward_chain_workspace_floats(n));
     NM_REQUIRE(((reinterpret_cast<uintptr_t>(dz_top) | reinterpret_cast<uintptr_t>(acts) | reinterpret_cast<uintptr_t>(dz_out) |
@@ -800,7 +805,7 @@ int nm_mlp_backward_chain(nm_mlp_t m, const float* const* dev_params, const floa
     for (int i = 16; i < 24; ++i) P.p[i] = nullptr;
     if (!m->d_bwd_image)
         if (int rc = nm::check_hip(hipMalloc(&m->d_bwd_image, (size_t)nm::mlp_bwd_image_bytes()), "nm_mlp_backward_chain: hipMalloc")) return rc;
-    return nm::launch_mlp_bwd(P, 3 + 6 * m->desc.pos_n_freqs, m->d_bwd_image, dz_top, acts, n, dz_out, workspace, bias_grads, nm::as_stream(stream));
+    return nm::launch_mlp_bwd(P, 3 + 6 * m->desc.pos_n_freqs, m->d_bwd_image, dz_top, acts, relu_bits, n, dz_out, workspace, bias_grads, nm::as_stream(stream));
 }
 
 int nm_mlp_forward_rays(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals, int64_t R, int S,

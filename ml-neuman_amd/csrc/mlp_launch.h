@@ -20,6 +20,7 @@ struct MlpLaunch {
     const void* wstream8; const float* consts8;   // NM_PREC_I8X3: per-wave fragment streams; units | biases | kappa (mlp_layout.h)
     float* save_h = nullptr;                      // nm_mlp_forward_save (NM_PREC_FP16X3): [9][n][256] post-activation outputs of layers 0..7, then feature
     float* save_hv = nullptr;                     //   and [n][128] of the views layer: what a training step's backward pass reads
+    unsigned* save_bits = nullptr;                //   nullable: [8][n][8] one bit per trunk activation (> 0): what nm_mlp_backward_chain masks with
 };
 struct RefLaunch {
     const float* wt; const float* bias; int off[12]; int boff[12]; const float* petab;
@@ -52,7 +53,7 @@ int launch_sigma_f16t(const MlpLaunch& L, const void* stream16t, int stream_ndir
 // the backward-data chain of the 8 x 256 trunk (mlp_bwd.hip): packs W^T of layers 7..1 from the live parameters into `image`
 // (mlp_bwd_image_bytes()), dz_out [7][n][256], colsum [tiles][7][256] scratch, gb [7][256] = bias gradients of layers 6..0
 int64_t mlp_bwd_image_bytes();
-int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_top, const float* acts, int64_t n, float* dz_out, float* colsum,
+int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_top, const float* acts, const unsigned* relu_bits, int64_t n, float* dz_out, float* colsum,
                    float* gb, hipStream_t stream);
 int launch_mlp_ref(const RefLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
                    const float* z, int64_t n, int S, int in_mode, int stop_stage, float sigma_scale, float* out, float* dbg,

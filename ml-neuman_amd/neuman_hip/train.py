@@ -149,12 +149,14 @@ class _MLP(torch.autograd.Function):
             acts = torch.empty((9, n4, width), device=dev, dtype=torch.float32)
             hv = torch.empty((n4, half), device=dev, dtype=torch.float32)
             raw = torch.empty((n4, 4), device=dev, dtype=torch.float32)
-            _lib.check(_lib.lib().nm_mlp_forward_save(handle, _lib.dev_ptr(p4), _lib.dev_ptr(d4), n4, _lib.dev_ptr(acts), _lib.dev_ptr(hv),
-                                                      _lib.dev_ptr(raw), _lib.stream_ptr()), "nm_mlp_forward_save")
+            bits = torch.empty((8, n4, 8), device=dev, dtype=torch.int32) if FUSED_BACKWARD else None     # (what the backward-data chain masks with)
+            _lib.check(_lib.lib().nm_mlp_forward_save_bits(handle, _lib.dev_ptr(p4), _lib.dev_ptr(d4), n4, _lib.dev_ptr(acts), _lib.dev_ptr(hv),
+                                                           ctypes.c_void_p(bits.data_ptr() if bits is not None else 0), _lib.dev_ptr(raw),
+                                                           _lib.stream_ptr()), "nm_mlp_forward_save_bits")
             H, feat = [acts[i] for i in range(8)], acts[8]
             ctx.pk, ctx.X0, ctx.D0, ctx.H, ctx.feat, ctx.hv, ctx.n, ctx.net = pk, X0, D0, H, feat, hv, n, net
             ctx.p4, ctx.d4 = p4, d4
-            ctx.acts = acts
+            ctx.acts, ctx.bits = acts, bits
             return raw[:n]
         H = []
         h, kh = X0, pk.kp
@@ -266,7 +268,8 @@ class _MLP(torch.autograd.Function):
             if need > ws[0].numel():
                 ws[0] = torch.empty(need, device=dev, dtype=torch.float32)
             ptrs = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in nerf.ordered_params()])
-            _lib.check(_lib.lib().nm_mlp_backward_chain(net.train_handle(), ptrs, _lib.dev_ptr(dz), _lib.dev_ptr(ctx.acts), n4, _lib.dev_ptr(chain),
+            _lib.check(_lib.lib().nm_mlp_backward_chain(net.train_handle(), ptrs, _lib.dev_ptr(dz), _lib.dev_ptr(ctx.acts),
+                                                        ctypes.c_void_p(ctx.bits.data_ptr() if ctx.bits is not None else 0), n4, _lib.dev_ptr(chain),
                                                         _lib.dev_ptr(gbs), _lib.dev_ptr(ws[0]), ws[0].numel(), _lib.stream_ptr()), "nm_mlp_backward_chain")
             for i in range(7):
                 gb[i] = gbs[6 - i]

@@ -355,3 +355,48 @@ def test_fused_backward_chain(G, monkeypatch, n_rays):
         assert worst < 2e-5, worst
         monkeypatch.setattr(G.train, "FUSED_BACKWARD", True)
         opt.step()
+
+
+def test_backward_chain_sign_bits_equal_the_saved_activations(G):
+    """nm_mlp_forward_save_bits: one bit per trunk activation (> 0) beside the float32 copies; nm_mlp_backward_chain masks with either --
+    the same bits out, and the saved activations are untouched by the extra output"""
+    import ctypes
+    from neuman_hip import _lib
+    net = G.syn.make_joiner(1).cuda().train()
+    g = torch.Generator(device='cuda').manual_seed(9)
+    n = 1000                                                              # ragged: 7 full tiles + 104 rows
+    pts = (torch.rand((n, 3), device='cuda', generator=g) * 2 - 1).contiguous()
+    dirs = torch.nn.functional.normalize(torch.randn((n, 3), device='cuda', generator=g), dim=-1).contiguous()
+    h = net.train_handle()
+    ptrs = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in net.nerf.ordered_params()])
+    lib = _lib.lib()
+    _lib.check(lib.nm_mlp_refresh_f16(h, ptrs, _lib.stream_ptr()), "refresh")
+    acts, hv, raw = torch.empty((9, n, 256), device='cuda'), torch.empty((n, 128), device='cuda'), torch.empty((n, 4), device='cuda')
+    acts2, hv2, raw2 = torch.empty_like(acts), torch.empty_like(hv), torch.empty_like(raw)
+    bits = torch.zeros((8, n, 8), device='cuda', dtype=torch.int32)
+    _lib.check(lib.nm_mlp_forward_save(h, _lib.dev_ptr(pts), _lib.dev_ptr(dirs), n, _lib.dev_ptr(acts), _lib.dev_ptr(hv), _lib.dev_ptr(raw), _lib.stream_ptr()), "save")
+    _lib.check(lib.nm_mlp_forward_save_bits(h, _lib.dev_ptr(pts), _lib.dev_ptr(dirs), n, _lib.dev_ptr(acts2), _lib.dev_ptr(hv2), ctypes.c_void_p(bits.data_ptr()),
+                                            _lib.dev_ptr(raw2), _lib.stream_ptr()), "save_bits")
+    assert torch.equal(acts, acts2) and torch.equal(hv, hv2) and torch.equal(raw, raw2)
+    want = (acts[:8] > 0).reshape(8, n, 8, 32).to(torch.int64)
+    got = (bits.to(torch.int64)[..., None] >> torch.arange(32, device='cuda')) & 1
+    assert torch.equal(got, want)
+    dz = torch.randn((n, 256), device='cuda', generator=g) * (acts[7] > 0)
+    ws = torch.empty(int(lib.nm_mlp_backward_chain_workspace_floats(n)), device='cuda')
+    outs = []
+    for use_bits in (True, False):
+        out, gb = torch.full((7, n, 256), 7.0, device='cuda'), torch.empty((7, 256), device='cuda')
+        _lib.check(lib.nm_mlp_backward_chain(h, ptrs, _lib.dev_ptr(dz), _lib.dev_ptr(acts), ctypes.c_void_p(bits.data_ptr() if use_bits else 0), n, _lib.dev_ptr(out),
+                                             _lib.dev_ptr(gb), _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()), "chain")
+        outs.append((out, gb))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    # against float64: dz_{i-1} = (dz_i W_i[:, hidden]) * (H_{i-1} > 0); bias gradients = column sums
+    W = [p.detach().double() for p in net.nerf.ordered_params()][0:16:2]
+    d = dz.double()
+    for i in range(7, 0, -1):
+        Wi = W[i][:, -256:]
+        d = (d @ Wi) * (acts[i - 1] > 0)
+        got_dz, got_gb = outs[0][0][7 - i].double(), outs[0][1][7 - i].double()
+        assert float((got_dz - d).abs().max()) < 2e-5 * float(d.abs().max()), i
+        assert float((got_gb - d.sum(0)).abs().max()) < 2e-5 * float(d.sum(0).abs().max()) + 1e-6, i
+        d = got_dz
