@@ -148,18 +148,18 @@ __global__ __launch_bounds__(256) void bwd_pack_kernel(nm::DevParams P, int kpe,
     dst[64] = lo;
 }
 
-// gb[j][f] = sum over tiles of colsum[tile][j][f]: 32 columns per workgroup, 8 interleaved row groups, fixed order
-__global__ __launch_bounds__(256) void bwd_colsum_kernel(const float* __restrict__ colsum, int64_t ntiles, float* __restrict__ gb) {
+// gb[j][f] = sum over tiles of colsum[tile][j][f]: 32 columns per workgroup, 32 interleaved row groups, fixed order
+__global__ __launch_bounds__(1024) void bwd_colsum_kernel(const float* __restrict__ colsum, int64_t ntiles, float* __restrict__ gb) {
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5, c = blockIdx.x * 32 + cx;
     float acc = 0.f;
-    for (int64_t t = ry; t < ntiles; t += 8) acc += colsum[t * (kBwdStages * 256) + c];
-    __shared__ float part[8][32];
+    for (int64_t t = ry; t < ntiles; t += 32) acc += colsum[t * (kBwdStages * 256) + c];
+    __shared__ float part[32][33];
     part[ry][cx] = acc;
     __syncthreads();
     if (ry == 0) {
         float v = part[0][cx];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) v += part[k][cx];
+        for (int k = 1; k < 32; ++k) v += part[k][cx];
         gb[c] = v;
     }
 }
@@ -184,7 +184,7 @@ int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_
     }
     const int grid = (int)(ntiles < cus ? ntiles : cus);
     hipLaunchKernelGGL(nerf_mlp_bwd_kernel, dim3(grid), dim3(kThreads), 0, stream, a);
-    hipLaunchKernelGGL(bwd_colsum_kernel, dim3(kBwdStages * 256 / 32), dim3(256), 0, stream, colsum, ntiles, gb);
+    hipLaunchKernelGGL(bwd_colsum_kernel, dim3(kBwdStages * 256 / 32), dim3(1024), 0, stream, colsum, ntiles, gb);
     return check_launch("nerf_mlp_bwd_kernel");
 }
 

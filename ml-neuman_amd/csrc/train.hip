@@ -367,6 +367,101 @@ __global__ __launch_bounds__(256, 3) void gemm_split_kernel(const GemmArgs g) {
     else store_tile(g, acc, m0, n0, wm, wn, lane);
 }
 
+// Backward-weights of a 256-wide layer, dW [256, 256] = dZ^T A over all n samples (both operands K-major: [n, 256] row-major), as ONE
+// 256 x 256 tile per workgroup: every operand element is read from HBM exactly once (the 128 x 128 tiling of gemm_split_kernel reads
+// each operand row for both of its tile columns), 512 threads = 8 waves of 128 x 64 (4 x 2 accumulator blocks = 128 registers), a
+// contiguous range of samples per workgroup (split-K over the grid, partial[z][256][256] -> splitk_reduce_kernel).  A step = 32 samples:
+// coalesced 4-byte loads along the features, eight samples of one feature per lane (the transpose happens in registers), split into
+// 16-bit parts, one ds_write_b128 per part -- then two MFMA k-steps x 3 products x 8 blocks per wave.
+template <bool HALF>
+__global__ __launch_bounds__(512, 2) void wgrad256_kernel(const GemmArgs g) {
+    __shared__ uint4 smem[4][XK / 8][256];                          // Ah | Al | Bh | Bl: [octet of 8 samples][feature]
+    uint4 (*Ah)[256] = smem[0], (*Al)[256] = smem[1], (*Bh)[256] = smem[2], (*Bl)[256] = smem[3];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int kbeg = blockIdx.x * g.k_per_split;
+    const int kend = kbeg + g.k_per_split < g.K ? kbeg + g.k_per_split : g.K;
+    const int wm = (w >> 2) * 128, wn = (w & 3) * 64;
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    // items of a step: (matrix, octet, feature) = 2 x 4 x 256; thread t takes items t + 512 q, q = 0..3: feature = t & 255, octet = (t >> 8) + 2 (q & 1),
+    // matrix = q >> 1 -- consecutive lanes read consecutive features of one sample row (256 B per wave instruction)
+    float r[4][8];
+    const int f = tid & 255, o2 = tid >> 8;
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float* S = (q >> 1) ? g.B : g.A;
+            const int ld = (q >> 1) ? g.ldb : g.lda;
+            const int k = k0 + 8 * (o2 + 2 * (q & 1));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[q][j] = (k + j < kend) ? S[(int64_t)(k + j) * ld + f] : 0.f;
+        }
+    };
+    if (kbeg < kend) load(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += XK) {
+        __syncthreads();                                               // the previous step's fragments have been read
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 hi, lo;
+            split8<HALF>(r[q], hi, lo);
+            const int o = o2 + 2 * (q & 1);
+            if (q >> 1) { Bh[o][f] = hi; Bl[o][f] = lo; }
+            else { Ah[o][f] = hi; Al[o][f] = lo; }
+        }
+        __syncthreads();
+        if (k0 + XK < kend) load(k0 + XK);                             // the next step's loads fly during this step's MFMAs
+#pragma unroll
+        for (int s = 0; s < XK / 16; ++s) {
+            const int o = 2 * s + (lane >> 5), c = lane & 31;
+            bf16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ah[i] = __builtin_bit_cast(bf16x8, Ah[o][wm + 32 * i + c]);
+                al[i] = __builtin_bit_cast(bf16x8, Al[o][wm + 32 * i + c]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = __builtin_bit_cast(bf16x8, Bh[o][wn + 32 * j + c]);
+                bl[j] = __builtin_bit_cast(bf16x8, Bl[o][wn + 32 * j + c]);
+            }
+            auto mm = [](bf16x8 x, bf16x8 y, floatx16 c) {
+                if (HALF) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+                return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+            };
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mm(al[i], bh[j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mm(ah[i], bl[j], acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mm(ah[i], bh[j], acc[i][j]);
+        }
+    }
+    // accumulator block (i, j): register v of lane (g, c) = row wm + 32 i + (v & 3) + 8 (v >> 2) + 4 g, column wn + 32 j + c
+    float* P = g.partial + (int64_t)blockIdx.x * 256 * 256;
+    const int gq = lane >> 5, c = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) P[(wm + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * gq) * 256 + wn + 32 * j + c] = acc[i][j][v];
+}
+constexpr int kWgradSplits = 256;
+__host__ inline bool wgrad256_ok(int mode, int a_kmajor, int b_kmajor, int M, int N, int K, int flags) {
+    return mode != 0 && a_kmajor && b_kmajor && M == 256 && N == 256 && K >= 16384 && !(flags & ~NM_GEMM_ACCUMULATE);
+}
+
 // second pass of split-K: C (+)= sum over the splits, in split order
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int splits, int M, int N, float* __restrict__ C, int ldc,
                                                             int accumulate) {
@@ -634,6 +729,7 @@ extern "C" {
 
 int64_t nm_gemm_workspace_floats(int M, int N, int K) {
     const int s = pick_splits(M, N, K);
+    if (M == 256 && N == 256 && K >= 16384) return (int64_t)(s > kWgradSplits ? s : kWgradSplits) * M * N;     // (wgrad256_kernel's partials)
     return s > 1 ? (int64_t)s * M * N : 0;
 }
 
@@ -653,6 +749,20 @@ static int gemm_dispatch(int mode, int a_kmajor, int b_kmajor, int M, int N, int
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.mask = mask; g.partial = nullptr; g.colsum = nullptr;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldmask = ldmask; g.flags = flags;
+    if (wgrad256_ok(mode, a_kmajor, b_kmajor, M, N, K, flags)) {          // backward-weights of a 256-wide layer: one 256 x 256 tile per workgroup
+        NM_REQUIRE(workspace && workspace_floats >= (int64_t)kWgradSplits * M * N, "nm_gemm: needs %lld floats of workspace (nm_gemm_workspace_floats)",
+                   (long long)kWgradSplits * M * N);
+        g.partial = workspace;
+        g.k_per_split = ((K + kWgradSplits - 1) / kWgradSplits + XK - 1) / XK * XK;
+        const int nsplit = (K + g.k_per_split - 1) / g.k_per_split;
+        if (mode == 1) hipLaunchKernelGGL((wgrad256_kernel<false>), dim3(nsplit), dim3(512), 0, st, g);
+        else hipLaunchKernelGGL((wgrad256_kernel<true>), dim3(nsplit), dim3(512), 0, st, g);
+        if (int rc = nm::check_launch("wgrad256_kernel")) return rc;
+        const int64_t n = (int64_t)M * N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, nsplit, M, N, C, ldc,
+                           (flags & NM_GEMM_ACCUMULATE) ? 1 : 0);
+        return nm::check_launch("splitk_reduce_kernel");
+    }
     int splits = pick_splits(M, N, K);
     if (flags & NM_GEMM_COLSUM) {
         NM_REQUIRE(splits == 1, "nm_gemm: NM_GEMM_COLSUM on a split-K product (M=%d N=%d K=%d)", M, N, K);

@@ -29,7 +29,8 @@ def cu(x):
     return torch.as_tensor(np.ascontiguousarray(x)).to('cuda', torch.float32).contiguous()
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (4, 4, 4), (260, 132, 36), (1000, 256, 64), (256, 28, 8192), (4, 256, 20000), (512, 512, 4100)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (4, 4, 4), (260, 132, 36), (1000, 256, 64), (256, 28, 8192), (4, 256, 20000), (512, 512, 4100),
+                                   (256, 256, 20004), (256, 256, 16384)])       # (the last two: K-major x K-major = wgrad256_kernel)
 @pytest.mark.parametrize("akm,bkm", [(0, 0), (0, 1), (1, 1), (1, 0)])
 @pytest.mark.parametrize("prec", ["f32", "bf16x3", "fp16x3"])
 def test_gemm(G, M, N, K, akm, bkm, prec, monkeypatch):
