@@ -169,22 +169,25 @@ int nm_mlp_forward(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n,
 int nm_mlp_refresh_f16(nm_mlp_t mlp, const float* const* dev_params, nm_stream_t stream);
 int nm_mlp_forward_save(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, float* save_h, float* save_hv,
                         float* out, nm_stream_t stream);
-/* ... and, with save_bits [8][n][8] != NULL, one bit per trunk activation: bit (f & 31) of word f >> 5 of (layer, sample) = (output f of
- * pts_linears[layer] > 0) -- all the backward-data chain needs of them (1/32 of the bytes). */
+/* ... and, with save_bits [8][n][8] != NULL, one bit per trunk activation (> 0): word f >> 5 of (layer, sample) holds output f = 32 w + 8 q + 4 g + j
+ * of pts_linears[layer] at bit 16 g + 15 - (4 q + j) (the producing kernel's register order) -- all the backward-data chain needs of them (1/32 of the bytes). */
 int nm_mlp_forward_save_bits(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, float* save_h, float* save_hv,
                              uint32_t* save_bits, float* out, nm_stream_t stream);
-/* The backward-data chain of the trunk in a TRAINING step (autograd's adjoint of models/vanilla.py:126-131 inside
- * trainers/vanilla_nerf_trainer.py:45-96 / human_nerf_trainer.py:382-446 `loss.backward()`), one kernel: from dz_top [n][256] = the
- * gradient of pts_linears[7]'s pre-activation,
- *     dz_out[j] [n][256] = gradient of pts_linears[6 - j]'s pre-activation = (dZ_{7-j} W_{7-j}[:, hidden columns]) * (save_h[6 - j] > 0),
- *     bias_grads[j] [256] = its column sums = pts_linears[6 - j].bias.grad,                                    j = 0 .. 6,
- * with a 128-sample tile's dZ kept on chip between the layers (split-bf16 x3 products, as nm_gemm_bf16x3).  acts = nm_mlp_forward_save's
- * save_h, relu_bits = nm_mlp_forward_save_bits' save_bits (either may be NULL; the bits are read when given); dev_params = the 24 DEVICE pointers of nm_mlp_refresh_f16 (the first 16 are read: the weights are repacked, transposed, from
- * their live values in the call); workspace of nm_mlp_backward_chain_workspace_floats(n) floats.  The weight gradients are the caller's
- * products of dz_out with the saved activations (nm_gemm_*). */
+/* The backward-data chain of the trunk in a TRAINING step (autograd's adjoint of models/vanilla.py:126-134 inside
+ * trainers/vanilla_nerf_trainer.py:45-96 / human_nerf_trainer.py:382-446 `loss.backward()`), one kernel with a 128-sample tile's dZ kept on
+ * chip between the layers (split-bf16 x3 products, as nm_gemm_bf16x3):
+ *     dZ_{i-1} = (dZ_i W_i[:, hidden columns]) * (H_{i-1} > 0),   bias gradient of layer i-1 = column sums of dZ_{i-1},   i = 7 .. 1.
+ * Two forms: from dz_top [n][256] = dZ_7 (d_feat = d_raw = NULL): dz_out [7][n][256] = dZ_6 .. dZ_0, bias_grads [7][256];
+ * or from d_feat [n][256] (gradient of feature_linear's output) and d_raw [n][4] (column 3: d sigma), the first stage forming
+ *     dZ_7 = (d_feat W_feature + d sigma w_alpha) * (H_7 > 0)                                             (models/vanilla.py:133-134)
+ * itself: dz_out [8][n][256] = dZ_7 .. dZ_0, bias_grads [8][256].  acts = nm_mlp_forward_save's save_h, relu_bits = nm_mlp_forward_save_bits'
+ * save_bits (either may be NULL; the bits are read when given); dev_params = the 24 DEVICE pointers of nm_mlp_refresh_f16 (the weights are
+ * repacked, transposed, from their live values in the call); workspace of nm_mlp_backward_chain_workspace_floats(n) floats.  The weight
+ * gradients are the caller's products of dz_out with the saved activations (nm_gemm_*). */
 int64_t nm_mlp_backward_chain_workspace_floats(int64_t n);
-int nm_mlp_backward_chain(nm_mlp_t mlp, const float* const* dev_params, const float* dz_top, const float* acts, const uint32_t* relu_bits,
-                          int64_t n, float* dz_out, float* bias_grads, float* workspace, int64_t workspace_floats, nm_stream_t stream);
+int nm_mlp_backward_chain(nm_mlp_t mlp, const float* const* dev_params, const float* dz_top, const float* d_feat, const float* d_raw,
+                          const float* acts, const uint32_t* relu_bits, int64_t n, float* dz_out, float* bias_grads, float* workspace,
+                          int64_t workspace_floats, nm_stream_t stream);
 /* Same with ray_to_samples' point construction fused: sample (r,s) is at origin[r] + direction[r]*z[r,s]
  * with view direction direction[r] (ray_utils.py:131-132); out [R,S,4]. */
 int nm_mlp_forward_rays(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals,

@@ -101,13 +101,15 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
             if (SAVE) {
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) save_block(a.save_h + (int64_t)st * a.n * 256, 256, acc[mb], w, base + 32 * mb + s, acc2out(st), true);
-                if (a.save_bits) {                                     // one bit per saved activation: (value > 0); the two lane halves of a sample share a word
-                    const float sc = acc2out(st);
+                if (a.save_bits) {                                     // one bit per saved activation: (value > 0).  A lane's 16 values MSB first
+                    // (bits = 2 bits + carry: a compare and an add-with-carry each); the two lane halves of a sample share a word, half g in
+                    // bits 16 g .. 16 g + 15: register r = 4 q + j of half g (feature 32 w + 8 q + 4 g + j) is bit 16 g + 15 - r
 #pragma unroll
                     for (int mb = 0; mb < 4; ++mb) {
                         unsigned bits = 0;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) bits |= (acc[mb][r] * sc > 0.f ? 1u : 0u) << (8 * (r >> 2) + 4 * g + (r & 3));
+                        for (int r = 0; r < 16; ++r) bits = bits + bits + (acc[mb][r] > 0.f ? 1u : 0u);
+                        bits <<= 16 * g;
                         bits |= (unsigned)__shfl_xor((int)bits, 32, 64);
                         const int64_t row = base + 32 * mb + s;
                         if (g == 0 && row < a.n) a.save_bits[((int64_t)st * a.n + row) * 8 + w] = bits;

@@ -17,22 +17,28 @@
 
 namespace {
 
-constexpr int kBwdStages = 7;
+constexpr int kBwdStages = 7;                                       // trunk layers 7 .. 1
+constexpr int kBwdSlots = kBwdStages + 1;                           // + the head stage (feature_linear), image slot 0
 constexpr int kBwdStageBytes = 8 * 16 * nm::kStepBytes;            // 8 output blocks x 16 k-steps
-constexpr int kBwdImageBytes = kBwdStages * kBwdStageBytes;
+constexpr int kBwdImageBytes = kBwdSlots * kBwdStageBytes;
 constexpr int kBwdPadBytes = 4 * nm::kStepBytes;                   // the weight pipeline prefetches two steps past a run's end
 
 struct BwdArgs {
-    const uint4* wpack;        // [7][8 blocks][16 steps] fragments: stage j = layer 7 - j, W^T (hidden columns), split bf16
-    const float* dz_top;       // [n][256] gradient of layer 7's pre-activation (masked by H7 > 0 already)
+    const uint4* wpack;        // [8][8 blocks][16 steps] fragments, split bf16: slot 0 = feature_linear's W^T, slot 1 + j = layer 7 - j's W^T (hidden columns)
+    const float* dz_top;       // [n][256] gradient of layer 7's pre-activation (masked by H7 > 0 already); HEAD: unused
+    const float* d_feat;       // HEAD: [n][256] gradient of feature_linear's output, d_raw [n][4] (column 3 = d sigma), w_alpha [256]:
+    const float* d_raw;        //   the first stage forms dZ_7 = (d_feat W_f + d sigma w_alpha) * (H_7 > 0) itself
+    const float* w_alpha;
     const float* acts;         // [9][n][256] saved post-activation outputs of layers 0..7 (+ feature): stage j masks with acts[6 - j]
     const unsigned* bits;      // nullable: [8][n][8] their signs (nm_mlp_forward_save_bits): read instead of acts, 1/32 of the bytes
-    float* dz_out;             // [7][n][256]: dz_out[j] = gradient of layer (6 - j)'s pre-activation
-    float* colsum;             // [tiles][7][256] per-tile column sums of dz_out[j]
+    float* dz_out;             // [NS][n][256]: stage s's output (HEAD: dZ_7, dZ_6 .. dZ_0; else dZ_6 .. dZ_0)
+    float* colsum;             // [tiles][NS][256] per-tile column sums of dz_out[s]
     int64_t n;
 };
 
+template <bool HEAD>
 __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs a) {
+    constexpr int NS = HEAD ? kBwdSlots : kBwdStages;               // stages of a tile; stage s reads image slot s + (HEAD ? 0 : 1)
     __shared__ uint4 lds[LDS_U4];
     constexpr int PREC = NM_PREC_BF16X3;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -40,7 +46,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
     const int g = lane >> 5, s = lane & 31;
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.wpack), 0, kBwdImageBytes + kBwdPadBytes, 0x00020000);
     const int voff = lane * 16;
-    auto wo = [](int j, int blk) { return j * kBwdStageBytes + blk * 16 * nm::kStepBytes; };
+    auto wo = [](int j, int blk) { return (j + (HEAD ? 0 : 1)) * kBwdStageBytes + blk * 16 * nm::kStepBytes; };
     const int64_t ntiles = (a.n + kTileM - 1) / kTileM;
     WPre W;
     w_prefetch<PREC>(W, wsrc, voff, wo(0, w));
@@ -54,7 +60,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
             const int64_t i = base + row;
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (i < a.n) {
-                const float* src = a.dz_top + i * 256 + nm::slot_feature(c, 0);
+                const float* src = (HEAD ? a.d_feat : a.dz_top) + i * 256 + nm::slot_feature(c, 0);
                 const float4 lo4 = *reinterpret_cast<const float4*>(src), hi4 = *reinterpret_cast<const float4*>(src + 8);
                 v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w; v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
             }
@@ -65,16 +71,25 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
         }
         __syncthreads();
 #pragma unroll 1
-        for (int j = 0; j < kBwdStages; ++j) {
+        for (int j = 0; j < NS; ++j) {
             f32x16 acc[4];
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-            k_run<4, PREC>(acc, W, wsrc, voff, wo(j, w), j + 1 < kBwdStages ? wo(j + 1, w) : wo(0, w), lds + H_BASE + g * kChunkU4 + s, 16);
+            k_run<4, PREC>(acc, W, wsrc, voff, wo(j, w), j + 1 < NS ? wo(j + 1, w) : wo(0, w), lds + H_BASE + g * kChunkU4 + s, 16);
             // ---- mask with the saved activation of layer 6 - j, store the f32 copy, column sums
-            const float* mask = a.acts + (int64_t)(kBwdStages - 1 - j) * a.n * 256;
-            const unsigned* mbits = a.bits ? a.bits + (int64_t)(kBwdStages - 1 - j) * a.n * 8 + w : nullptr;
+            const int layer = NS - 1 - j;                                // the layer whose saved output masks this stage's result (HEAD, j = 0: 7)
+            const float* mask = a.acts + (int64_t)layer * a.n * 256;
+            const unsigned* mbits = a.bits ? a.bits + (int64_t)layer * a.n * 8 + w : nullptr;
+            float wa[16];
+            if (HEAD && j == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 t = *reinterpret_cast<const float4*>(a.w_alpha + 32 * w + 4 * g + 8 * q);
+                    wa[4 * q] = t.x; wa[4 * q + 1] = t.y; wa[4 * q + 2] = t.z; wa[4 * q + 3] = t.w;
+                }
+            }
             float* out = a.dz_out + (int64_t)j * a.n * 256;
             float cs[16];
 #pragma unroll
@@ -84,12 +99,17 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                 const int64_t row = base + 32 * mb + s;
                 const bool live = row < a.n;
                 const int64_t off = (live ? row : 0) * 256 + 32 * w + 4 * g;
-                const unsigned word = (mbits && live) ? mbits[row * 8] >> (4 * g) : 0u;     // bit 8 q + j' of it: feature 8 q + 4 g + j'
+                if (HEAD && j == 0) {                                     // + d sigma x alpha_linear's row (models/vanilla.py:133)
+                    const float ds = live ? a.d_raw[row * 4 + 3] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mb][r] = fmaf(ds, wa[r], acc[mb][r]);
+                }
+                const unsigned word = (mbits && live) ? mbits[row * 8] >> (16 * g) : 0u;    // bit 15 - (4 q + j) of it: register 4 q + j of this lane
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     bool k0, k1, k2, k3;
                     if (mbits) {
-                        k0 = (word >> (8 * q)) & 1u; k1 = (word >> (8 * q + 1)) & 1u; k2 = (word >> (8 * q + 2)) & 1u; k3 = (word >> (8 * q + 3)) & 1u;
+                        k0 = (word >> (15 - 4 * q)) & 1u; k1 = (word >> (14 - 4 * q)) & 1u; k2 = (word >> (13 - 4 * q)) & 1u; k3 = (word >> (12 - 4 * q)) & 1u;
                     } else {
                         const float4 m = *reinterpret_cast<const float4*>(mask + off + 8 * q);
                         k0 = live && m.x > 0.f; k1 = live && m.y > 0.f; k2 = live && m.z > 0.f; k3 = live && m.w > 0.f;
@@ -112,11 +132,11 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                 cs[r] = v;
             }
             if (s == 0) {
-                float* o = a.colsum + ((int64_t)tile * kBwdStages + j) * 256 + 32 * w + 4 * g;
+                float* o = a.colsum + ((int64_t)tile * NS + j) * 256 + 32 * w + 4 * g;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(o + 8 * q) = make_float4(cs[4 * q], cs[4 * q + 1], cs[4 * q + 2], cs[4 * q + 3]);
             }
-            if (j + 1 < kBwdStages) {
+            if (j + 1 < NS) {
                 ActRegs<4> ar;
                 convert_act<4, false, PREC>(acc, ar);
                 __syncthreads();                                   // every wave has finished reading this stage's operand
@@ -130,13 +150,14 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
 // the transposed hidden weights of layers 7 .. 1 as MFMA A-operand fragments (mlp_layout.h: lane (g, s) of k-step t of output block nb holds
 // output feature 32 nb + s, k-slots (chunk 2 t + g, e = 0 .. 7)), split bf16: stage j multiplies dZ of layer i = 7 - j, so its "output
 // feature" is an INPUT feature of layer i (skip layer 5: behind the encoding columns) and its k index an OUTPUT feature of layer i
-__global__ __launch_bounds__(256) void bwd_pack_kernel(nm::DevParams P, int kpe, uint8_t* __restrict__ img) {
+__global__ __launch_bounds__(256) void bwd_pack_kernel(nm::DevParams P, int kpe, int head, uint8_t* __restrict__ img) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int step = gid >> 6, lane = gid & 63;
-    if (step >= kBwdStages * 8 * 16) return;
-    const int j = step / 128, nb = (step % 128) / 16, t = step % 16;
-    const int i = 7 - j;
-    const float* Wi = P.p[nm::P_PTS_W + 2 * i];
+    if (step >= kBwdSlots * 8 * 16) return;
+    const int slot = step / 128, nb = (step % 128) / 16, t = step % 16;
+    if (slot == 0 && !head) return;
+    const int i = 8 - slot;                                           // layer; slot 0: feature_linear
+    const float* Wi = slot == 0 ? P.p[nm::P_FEAT_W] : P.p[nm::P_PTS_W + 2 * i];
     const int K = i == 5 ? kpe + 256 : 256, col = (i == 5 ? kpe : 0) + 32 * nb + (lane & 31);
     float v[8];
 #pragma unroll
@@ -149,10 +170,10 @@ __global__ __launch_bounds__(256) void bwd_pack_kernel(nm::DevParams P, int kpe,
 }
 
 // gb[j][f] = sum over tiles of colsum[tile][j][f]: 32 columns per workgroup, 32 interleaved row groups, fixed order
-__global__ __launch_bounds__(1024) void bwd_colsum_kernel(const float* __restrict__ colsum, int64_t ntiles, float* __restrict__ gb) {
+__global__ __launch_bounds__(1024) void bwd_colsum_kernel(const float* __restrict__ colsum, int64_t ntiles, int width, float* __restrict__ gb) {
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5, c = blockIdx.x * 32 + cx;
     float acc = 0.f;
-    for (int64_t t = ry; t < ntiles; t += 32) acc += colsum[t * (kBwdStages * 256) + c];
+    for (int64_t t = ry; t < ntiles; t += 32) acc += colsum[t * width + c];
     __shared__ float part[32][33];
     part[ry][cx] = acc;
     __syncthreads();
@@ -170,12 +191,14 @@ namespace nm {
 
 int64_t mlp_bwd_image_bytes() { return kBwdImageBytes + kBwdPadBytes; }
 
-int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_top, const float* acts, const unsigned* relu_bits, int64_t n, float* dz_out, float* colsum,
-                   float* gb, hipStream_t stream) {
-    hipLaunchKernelGGL(bwd_pack_kernel, dim3((kBwdStages * 8 * 16 * 64 + 255) / 256), dim3(256), 0, stream, P, kpe, image);
+int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_top, const float* d_feat, const float* d_raw, const float* acts,
+                   const unsigned* relu_bits, int64_t n, float* dz_out, float* colsum, float* gb, hipStream_t stream) {
+    const bool head = d_feat != nullptr;
+    hipLaunchKernelGGL(bwd_pack_kernel, dim3((kBwdSlots * 8 * 16 * 64 + 255) / 256), dim3(256), 0, stream, P, kpe, head ? 1 : 0, image);
     BwdArgs a;
     a.wpack = reinterpret_cast<const uint4*>(image);
-    a.dz_top = dz_top; a.acts = acts; a.bits = relu_bits; a.dz_out = dz_out; a.colsum = colsum; a.n = n;
+    a.dz_top = dz_top; a.d_feat = d_feat; a.d_raw = d_raw; a.w_alpha = P.p[P_ALPHA_W];
+    a.acts = acts; a.bits = relu_bits; a.dz_out = dz_out; a.colsum = colsum; a.n = n;
     const int64_t ntiles = (n + kTileM - 1) / kTileM;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -183,8 +206,10 @@ int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     const int grid = (int)(ntiles < cus ? ntiles : cus);
-    hipLaunchKernelGGL(nerf_mlp_bwd_kernel, dim3(grid), dim3(kThreads), 0, stream, a);
-    hipLaunchKernelGGL(bwd_colsum_kernel, dim3(kBwdStages * 256 / 32), dim3(1024), 0, stream, colsum, ntiles, gb);
+    const int ns = head ? kBwdSlots : kBwdStages;
+    if (head) hipLaunchKernelGGL(nerf_mlp_bwd_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, a);
+    else hipLaunchKernelGGL(nerf_mlp_bwd_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, a);
+    hipLaunchKernelGGL(bwd_colsum_kernel, dim3(ns * 256 / 32), dim3(1024), 0, stream, colsum, ntiles, ns * 256, gb);
     return check_launch("nerf_mlp_bwd_kernel");
 }
 

@@ -70,7 +70,7 @@ struct MlpArgs {
     PeSpec pos, dir;
     float* save_h;           // SAVE instantiation: [9][n][256] f32 outputs of stages 0..7 (after ReLU) and 8 (feature, linear)
     float* save_hv;          //                     [n][128] f32 output of stage 9 (after ReLU)
-    unsigned* save_bits;     //                     nullable: [8][n][8] the signs of stages 0..7: bit (f & 31) of word f >> 5 = (output f > 0)
+    unsigned* save_bits;     //                     nullable: [8][n][8] the signs of stages 0..7: word f >> 5 of (stage, sample); feature 32 w + 8 q + 4 g + j = bit 16 g + 15 - (4 q + j)
 };
 
 // ---- positional encoding feature p of a 3-vector (reference models/vanilla.py:60-92) ---------------

@@ -785,27 +785,30 @@ int nm_mlp_forward_save_bits(nm_mlp_t m, const float* pts, const float* dirs, in
                                nm::as_stream(stream), 0, nullptr);
 }
 
-int64_t nm_mlp_backward_chain_workspace_floats(int64_t n) { return ((n + nm::kTileM - 1) / nm::kTileM) * 7 * 256; }
+int64_t nm_mlp_backward_chain_workspace_floats(int64_t n) { return ((n + nm::kTileM - 1) / nm::kTileM) * 8 * 256; }
 
-int nm_mlp_backward_chain(nm_mlp_t m, const float* const* dev_params, const float* dz_top, const float* acts, const uint32_t* relu_bits, int64_t n,
-                          float* dz_out, float* bias_grads, float* workspace, int64_t workspace_floats, nm_stream_t stream) {
+int nm_mlp_backward_chain(nm_mlp_t m, const float* const* dev_params, const float* dz_top, const float* d_feat, const float* d_raw, const float* acts,
+                          const uint32_t* relu_bits, int64_t n, float* dz_out, float* bias_grads, float* workspace, int64_t workspace_floats,
+                          nm_stream_t stream) {
     NM_REQUIRE(m && dev_params, "nm_mlp_backward_chain: null pointer");
     NM_REQUIRE(n >= 0, "nm_mlp_backward_chain: negative n");
     if (n == 0) return NM_OK;
-    NM_REQUIRE(dz_top && (acts || relu_bits) && dz_out && bias_grads && workspace, "nm_mlp_backward_chain: null pointer");
+    NM_REQUIRE((dz_top || (d_feat && d_raw)) && (acts || relu_bits) && dz_out && bias_grads && workspace, "nm_mlp_backward_chain: null pointer");
+    NM_REQUIRE(!d_feat || !m->desc.plain_head, "nm_mlp_backward_chain: the plain-head net has no feature layer (pass dz_top)");
     NM_REQUIRE(workspace_floats >= nm_mlp_backward_chain_workspace_floats(n), "nm_mlp_backward_chain: workspace of %lld floats, %lld needed",
                (long long)workspace_floats, (long long)nm_mlp_backward_chain_workspace_floats(n));
-    NM_REQUIRE(((reinterpret_cast<uintptr_t>(dz_top) | reinterpret_cast<uintptr_t>(acts) | reinterpret_cast<uintptr_t>(dz_out) |
-                 reinterpret_cast<uintptr_t>(workspace)) & 15) == 0, "nm_mlp_backward_chain: buffers must be 16-byte aligned");
+    NM_REQUIRE(((reinterpret_cast<uintptr_t>(dz_top) | reinterpret_cast<uintptr_t>(d_feat) | reinterpret_cast<uintptr_t>(d_raw) | reinterpret_cast<uintptr_t>(acts) |
+                 reinterpret_cast<uintptr_t>(dz_out) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0, "nm_mlp_backward_chain: buffers must be 16-byte aligned");
     nm::DevParams P;
-    for (int i = 0; i < 16; ++i) {
-        NM_REQUIRE(dev_params[i], "nm_mlp_backward_chain: dev_params[%d] is null", i);
-        P.p[i] = dev_params[i];
+    const int need = d_feat ? 24 : 16;
+    for (int i = 0; i < 24; ++i) {
+        NM_REQUIRE(i >= need || dev_params[i], "nm_mlp_backward_chain: dev_params[%d] is null", i);
+        P.p[i] = i < need ? dev_params[i] : nullptr;
     }
-    for (int i = 16; i < 24; ++i) P.p[i] = nullptr;
     if (!m->d_bwd_image)
         if (int rc = nm::check_hip(hipMalloc(&m->d_bwd_image, (size_t)nm::mlp_bwd_image_bytes()), "nm_mlp_backward_chain: hipMalloc")) return rc;
-    return nm::launch_mlp_bwd(P, 3 + 6 * m->desc.pos_n_freqs, m->d_bwd_image, dz_top, acts, relu_bits, n, dz_out, workspace, bias_grads, nm::as_stream(stream));
+    return nm::launch_mlp_bwd(P, 3 + 6 * m->desc.pos_n_freqs, m->d_bwd_image, dz_top, d_feat, d_raw, acts, relu_bits, n, dz_out, workspace, bias_grads,
+                              nm::as_stream(stream));
 }
 
 int nm_mlp_forward_rays(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals, int64_t R, int S,

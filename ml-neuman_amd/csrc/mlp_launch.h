@@ -50,11 +50,13 @@ int launch_mlp_i8t(const MlpLaunch& L, const void* image8t, const float* pts, co
 int launch_sigma_f16t(const MlpLaunch& L, const void* stream16t, int stream_ndir, const float* pts, const float* dirs, const float* origin, const float* direction,
                       const float* z, int64_t n, int S, int in_mode, float sigma_scale, float* out, hipStream_t stream, const MlpChunk* chunk,
                       float* dbg, int dbg_stage);
-// the backward-data chain of the 8 x 256 trunk (mlp_bwd.hip): packs W^T of layers 7..1 from the live parameters into `image`
-// (mlp_bwd_image_bytes()), dz_out [7][n][256], colsum [tiles][7][256] scratch, gb [7][256] = bias gradients of layers 6..0
+// the backward-data chain of the 8 x 256 trunk (mlp_bwd.hip): packs the transposed weights from the live parameters into `image`
+// (mlp_bwd_image_bytes()).  d_feat == nullptr: from dz_top = dZ_7, NS = 7 stages -> dz_out [7][n][256] = dZ_6 .. dZ_0; d_feat != nullptr: the
+// first stage forms dZ_7 from d_feat and d_raw's sigma column itself, NS = 8 -> dz_out [8][n][256] = dZ_7 .. dZ_0.  colsum [tiles][NS][256]
+// scratch, gb [NS][256] = the column sums (bias gradients)
 int64_t mlp_bwd_image_bytes();
-int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_top, const float* acts, const unsigned* relu_bits, int64_t n, float* dz_out, float* colsum,
-                   float* gb, hipStream_t stream);
+int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_top, const float* d_feat, const float* d_raw, const float* acts,
+                   const unsigned* relu_bits, int64_t n, float* dz_out, float* colsum, float* gb, hipStream_t stream);
 int launch_mlp_ref(const RefLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
                    const float* z, int64_t n, int S, int in_mode, int stop_stage, float sigma_scale, float* out, float* dbg,
                    hipStream_t stream);

@@ -56,7 +56,7 @@ SIGNATURES = {
     "nm_mlp_forward_save": (i32, [ctypes.c_void_p, c_f32p, c_f32p, i64, c_f32p, c_f32p, c_f32p, c_stream]),
     "nm_mlp_backward_chain_workspace_floats": (i64, [i64]),
     "nm_mlp_forward_save_bits": (i32, [ctypes.c_void_p, c_f32p, c_f32p, i64, c_f32p, c_f32p, ctypes.c_void_p, c_f32p, c_stream]),
-    "nm_mlp_backward_chain": (i32, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_void_p, i64, c_f32p, c_f32p, c_f32p, i64, c_stream]),
+    "nm_mlp_backward_chain": (i32, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p, i64, c_f32p, c_f32p, c_f32p, i64, c_stream]),
     "nm_mlp_forward_rays": (i32, [ctypes.c_void_p, c_f32p, c_f32p, c_f32p, i64, i32, i32, ctypes.c_float, c_f32p, c_stream]),
     "nm_mlp_sigma_rays": (i32, [ctypes.c_void_p, c_f32p, c_f32p, c_f32p, i64, i32, i32, ctypes.c_float, c_f32p, c_stream]),
     "nm_mlp_forward_ray_chunk": (i32, [ctypes.c_void_p, c_f32p, c_f32p, c_f32p, i32, c_i32p, c_i32p, i64, i32, i32, i32, ctypes.c_float, c_f32p,

@@ -234,6 +234,8 @@ class _MLP(torch.autograd.Function):
         h7 = H[-1]
         dX0 = dD0 = None
         dz = torch.empty((n4, width), device=dev, dtype=torch.float32)
+        use_chain = FUSED_BACKWARD and getattr(ctx, 'acts', None) is not None and len(pk.W) == 8 and width == 256
+        d_feat = None
         if views:
             g = {}
             gWr4, gb4 = wgrad(d_raw, 4, hv, half), bgrad(d_raw, 4)
@@ -250,8 +252,9 @@ class _MLP(torch.autograd.Function):
             g['feature_b'] = band_sum(width)
             g['feature_w'] = wgrad(d_feat, width, h7, width)
             g['alpha_w'] = wgrad(d_raw, 4, h7, width)[3:4]
-            _gemm(0, 1, n4, width, width, d_feat, width, pk.Wf, width, dz, width)
-            _gemm(0, 1, n4, width, 4, d_raw, 4, pk.Wa4, width, dz, width, mask=h7, ldmask=width, flags=ACC | MASK | COLSUM, ws=cs_buf)
+            if not use_chain:                                                   # (the chain kernel's first stage forms dZ_7 itself)
+                _gemm(0, 1, n4, width, width, d_feat, width, pk.Wf, width, dz, width)
+                _gemm(0, 1, n4, width, 4, d_raw, 4, pk.Wa4, width, dz, width, mask=h7, ldmask=width, flags=ACC | MASK | COLSUM, ws=cs_buf)
             head = [g['views_w'].contiguous(), g['views_b'].contiguous(), g['feature_w'], g['feature_b'].contiguous(),
                     g['alpha_w'].contiguous(), g['alpha_b'].contiguous(), g['rgb_w'].contiguous(), g['rgb_b'].contiguous()]
         else:
@@ -259,26 +262,33 @@ class _MLP(torch.autograd.Function):
             _gemm(0, 1, n4, width, 4, d_raw, 4, pk.Wo4, width, dz, width, mask=h7, ldmask=width, flags=MASK | COLSUM, ws=cs_buf)
         gw, gb = [None] * len(pk.W), [None] * len(pk.W)
         chain = None
-        if FUSED_BACKWARD and getattr(ctx, 'acts', None) is not None and len(pk.W) == 8 and width == 256:
+        if use_chain:
             import ctypes
-            gb[7] = band_sum(width)                                              # of dz_7: left in cs_buf by the product that made it
-            chain = torch.empty((7, n4, width), device=dev, dtype=torch.float32)   # dz of layers 6 .. 0
-            gbs = torch.empty((7, width), device=dev, dtype=torch.float32)
+            from_feat = views and d_feat is not None
+            ns = 8 if from_feat else 7
+            if not from_feat:
+                gb[7] = band_sum(width)                                          # of dz_7: left in cs_buf by the product that made it
+            chain = torch.empty((ns, n4, width), device=dev, dtype=torch.float32)    # dZ of layers (7,) 6 .. 0
+            gbs = torch.empty((ns, width), device=dev, dtype=torch.float32)
             need = int(_lib.lib().nm_mlp_backward_chain_workspace_floats(n4))
             if need > ws[0].numel():
                 ws[0] = torch.empty(need, device=dev, dtype=torch.float32)
             ptrs = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in nerf.ordered_params()])
-            _lib.check(_lib.lib().nm_mlp_backward_chain(net.train_handle(), ptrs, _lib.dev_ptr(dz), _lib.dev_ptr(ctx.acts),
+            _lib.check(_lib.lib().nm_mlp_backward_chain(net.train_handle(), ptrs, _lib.dev_ptr(None if from_feat else dz), _lib.dev_ptr(d_feat if from_feat else None),
+                                                        _lib.dev_ptr(d_raw if from_feat else None), _lib.dev_ptr(ctx.acts),
                                                         ctypes.c_void_p(ctx.bits.data_ptr() if ctx.bits is not None else 0), n4, _lib.dev_ptr(chain),
                                                         _lib.dev_ptr(gbs), _lib.dev_ptr(ws[0]), ws[0].numel(), _lib.stream_ptr()), "nm_mlp_backward_chain")
+            off = 1 if from_feat else 0                                               # chain[off + 6 - i] = dZ_i for i <= 6
+            if from_feat:
+                dz, gb[7] = chain[0], gbs[0]
             for i in range(7):
-                gb[i] = gbs[6 - i]
+                gb[i] = gbs[off + 6 - i]
         for i in range(len(pk.W) - 1, -1, -1):
             Ws = pk.W[i]
             if chain is None:
                 gb[i] = band_sum(width)                                          # of dz: left in cs_buf by the product that made it
             elif i < 7:
-                dz = chain[6 - i]
+                dz = chain[off + 6 - i]
             if want_in and (i == 0 or len(Ws) == 2):                             # gradient of the encoded position: both layers it feeds
                 first = dX0 is None
                 if first:

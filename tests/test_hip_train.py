@@ -379,16 +379,18 @@ def test_backward_chain_sign_bits_equal_the_saved_activations(G):
     _lib.check(lib.nm_mlp_forward_save_bits(h, _lib.dev_ptr(pts), _lib.dev_ptr(dirs), n, _lib.dev_ptr(acts2), _lib.dev_ptr(hv2), ctypes.c_void_p(bits.data_ptr()),
                                             _lib.dev_ptr(raw2), _lib.stream_ptr()), "save_bits")
     assert torch.equal(acts, acts2) and torch.equal(hv, hv2) and torch.equal(raw, raw2)
-    want = (acts[:8] > 0).reshape(8, n, 8, 32).to(torch.int64)
-    got = (bits.to(torch.int64)[..., None] >> torch.arange(32, device='cuda')) & 1
+    want = (acts[:8] > 0).reshape(8, n, 8, 32).to(torch.int64)           # feature 8 q + 4 g + j of word w <-> bit 16 g + 15 - (4 q + j)
+    f = torch.arange(32, device='cuda')
+    pos = 16 * ((f >> 2) & 1) + 15 - (4 * (f >> 3) + (f & 3))
+    got = (bits.to(torch.int64)[..., None] >> pos) & 1
     assert torch.equal(got, want)
     dz = torch.randn((n, 256), device='cuda', generator=g) * (acts[7] > 0)
     ws = torch.empty(int(lib.nm_mlp_backward_chain_workspace_floats(n)), device='cuda')
     outs = []
     for use_bits in (True, False):
         out, gb = torch.full((7, n, 256), 7.0, device='cuda'), torch.empty((7, 256), device='cuda')
-        _lib.check(lib.nm_mlp_backward_chain(h, ptrs, _lib.dev_ptr(dz), _lib.dev_ptr(acts), ctypes.c_void_p(bits.data_ptr() if use_bits else 0), n, _lib.dev_ptr(out),
-                                             _lib.dev_ptr(gb), _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()), "chain")
+        _lib.check(lib.nm_mlp_backward_chain(h, ptrs, _lib.dev_ptr(dz), None, None, _lib.dev_ptr(acts), ctypes.c_void_p(bits.data_ptr() if use_bits else 0), n,
+                                             _lib.dev_ptr(out), _lib.dev_ptr(gb), _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()), "chain")
         outs.append((out, gb))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     # against float64: dz_{i-1} = (dz_i W_i[:, hidden]) * (H_{i-1} > 0); bias gradients = column sums
@@ -401,3 +403,19 @@ def test_backward_chain_sign_bits_equal_the_saved_activations(G):
         assert float((got_dz - d).abs().max()) < 2e-5 * float(d.abs().max()), i
         assert float((got_gb - d.sum(0)).abs().max()) < 2e-5 * float(d.sum(0).abs().max()) + 1e-6, i
         d = got_dz
+    # the form that starts one stage earlier: dZ_7 = (d_feat W_feature + d sigma w_alpha) * (H_7 > 0) formed by the kernel itself
+    params = [p.detach().double() for p in net.nerf.ordered_params()]
+    Wf, wa = params[18], params[20][0]
+    d_feat = torch.randn((n, 256), device='cuda', generator=g)
+    d_raw = torch.randn((n, 4), device='cuda', generator=g)
+    out8, gb8 = torch.full((8, n, 256), 7.0, device='cuda'), torch.empty((8, 256), device='cuda')
+    _lib.check(lib.nm_mlp_backward_chain(h, ptrs, None, _lib.dev_ptr(d_feat), _lib.dev_ptr(d_raw), _lib.dev_ptr(acts), ctypes.c_void_p(bits.data_ptr()), n,
+                                         _lib.dev_ptr(out8), _lib.dev_ptr(gb8), _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()), "chain (head)")
+    d7 = (d_feat.double() @ Wf + d_raw[:, 3:4].double() * wa[None, :]) * (acts[7] > 0)
+    assert float((out8[0].double() - d7).abs().max()) < 2e-5 * float(d7.abs().max())
+    assert float((gb8[0].double() - d7.sum(0)).abs().max()) < 2e-5 * float(d7.sum(0).abs().max()) + 1e-6
+    # ... and continues exactly as the other form does from its own dZ_7
+    out7, gb7 = torch.empty((7, n, 256), device='cuda'), torch.empty((7, 256), device='cuda')
+    _lib.check(lib.nm_mlp_backward_chain(h, ptrs, _lib.dev_ptr(out8[0].contiguous()), None, None, _lib.dev_ptr(acts), ctypes.c_void_p(bits.data_ptr()), n,
+                                         _lib.dev_ptr(out7), _lib.dev_ptr(gb7), _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()), "chain")
+    assert torch.equal(out8[1:], out7) and torch.equal(gb8[1:], gb7)

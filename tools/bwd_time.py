@@ -19,7 +19,7 @@ ms = []
 for _ in range(5):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    _lib.check(_lib.lib().nm_mlp_backward_chain(h, ptrs, _lib.dev_ptr(dz), _lib.dev_ptr(acts), ctypes.c_void_p(bits.data_ptr() if os.environ.get('BWD_BITS', '1') == '1' else 0), n, _lib.dev_ptr(out), _lib.dev_ptr(gb), _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()), "chain")
+    _lib.check(_lib.lib().nm_mlp_backward_chain(h, ptrs, _lib.dev_ptr(dz), None, None, _lib.dev_ptr(acts), ctypes.c_void_p(bits.data_ptr() if os.environ.get('BWD_BITS', '1') == '1' else 0), n, _lib.dev_ptr(out), _lib.dev_ptr(gb), _lib.dev_ptr(ws), ws.numel(), _lib.stream_ptr()), "chain")
     e1.record()
     torch.cuda.synchronize()
     ms.append(e0.elapsed_time(e1))
