@@ -285,6 +285,13 @@ int nm_signed_distance(nm_mesh_t mesh, const float* pts, int64_t N, float* sdist
 int nm_warp_apply_forward(const float* T, const int32_t* tri, const float* bary, const float* pts, int64_t N, float* can, nm_stream_t stream);
 int nm_warp_apply_backward(const float* T, const int32_t* tri, const float* bary, const float* pts, const float* g_can, int64_t N, int64_t V,
                            float* g_T, float* g_bary, nm_stream_t stream);
+/* The barycentric coordinates the warp blends with (utils/ray_utils.py:72-84), per sample i of N, of the closest point closest[i] (a constant:
+ * the reference gets it from igl as numpy) in the triangle tri[i] of verts [V,3]:  bary [N,3] = (u, v, 1 - u - v), the reference's float32
+ * cross / dot / divide sequence -- and their adjoint, g_bary [N,3] -> g_verts [V,3] (cleared here, then float atomics), which is what carries
+ * the loss to the SMPL parameters through the posed vertices (trainers/human_nerf_trainer.py:241-278). */
+int nm_bary_forward(const float* verts, const int32_t* tri, const float* closest, int64_t N, float* bary, nm_stream_t stream);
+int nm_bary_backward(const float* verts, const int32_t* tri, const float* closest, const float* g_bary, int64_t N, int64_t V, float* g_verts,
+                     nm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * a12  SMPL linear blend skinning, batched over frames -- reference models/smpl.py:266-360 (lbs),

@@ -797,9 +797,68 @@ __global__ __launch_bounds__(256) void warp_apply_backward_kernel(const float* _
     for (int k = 0; k < 3; ++k) g_bary[i * 3 + k] = gb[k];
 }
 
+// ---- barycentric coordinates of the closest point in its triangle, the reference's lines (utils/ray_utils.py:72-84) in float32, forward and adjoint.
+//   N = e01 x e02, u = N . (e12 x (P - B)) / N.N, v = N . (e20 x (P - C)) / N.N, w = 1 - u - v      (A, B, C = the triangle's vertices; P constant)
+__device__ __forceinline__ V3 sub3(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 crs3(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
+__global__ __launch_bounds__(256) void bary_forward_kernel(const float* __restrict__ verts, const int32_t* __restrict__ tri, const float* __restrict__ closest,
+                                                           int64_t N, float* __restrict__ bary) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const V3 A = ld3(verts + (int64_t)tri[i * 3] * 3), B = ld3(verts + (int64_t)tri[i * 3 + 1] * 3), C = ld3(verts + (int64_t)tri[i * 3 + 2] * 3);
+    const V3 P = ld3(closest + i * 3);
+    const V3 e01 = sub3(B, A), e02 = sub3(C, A), e12 = sub3(C, B), e20 = sub3(A, C);
+    const V3 Nn = crs3(e01, e02);
+    const float den = dot3(Nn, Nn);
+    const float u = dot3(Nn, crs3(e12, sub3(P, B))) / den, v = dot3(Nn, crs3(e20, sub3(P, C))) / den;
+    bary[i * 3] = u; bary[i * 3 + 1] = v; bary[i * 3 + 2] = 1.f - u - v;
+}
+__global__ __launch_bounds__(256) void bary_backward_kernel(const float* __restrict__ verts, const int32_t* __restrict__ tri, const float* __restrict__ closest,
+                                                            const float* __restrict__ g_bary, int64_t N, float* __restrict__ g_verts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int64_t ia = tri[i * 3], ib = tri[i * 3 + 1], ic = tri[i * 3 + 2];
+    const V3 A = ld3(verts + ia * 3), B = ld3(verts + ib * 3), C = ld3(verts + ic * 3), P = ld3(closest + i * 3);
+    const V3 e01 = sub3(B, A), e02 = sub3(C, A), e12 = sub3(C, B), e20 = sub3(A, C), p1 = sub3(P, B), p2 = sub3(P, C);
+    const V3 Nn = crs3(e01, e02), a = crs3(e12, p1), b = crs3(e20, p2);
+    const float den = dot3(Nn, Nn), u = dot3(Nn, a) / den, v = dot3(Nn, b) / den;
+    const float gw = g_bary[i * 3 + 2], gu = g_bary[i * 3] - gw, gv = g_bary[i * 3 + 1] - gw;
+    const float k = 2.f * (gu * u + gv * v) / den;
+    const V3 gN = {(gu * a.x + gv * b.x) / den - k * Nn.x, (gu * a.y + gv * b.y) / den - k * Nn.y, (gu * a.z + gv * b.z) / den - k * Nn.z};
+    const V3 ga = {gu * Nn.x / den, gu * Nn.y / den, gu * Nn.z / den}, gb = {gv * Nn.x / den, gv * Nn.y / den, gv * Nn.z / den};
+    // c = x cross y: g_x = y cross g_c, g_y = g_c cross x
+    const V3 g01 = crs3(e02, gN), g02 = crs3(gN, e01), g12 = crs3(p1, ga), gp1 = crs3(ga, e12), g20 = crs3(p2, gb), gp2 = crs3(gb, e20);
+    const V3 gA = {-g01.x - g02.x + g20.x, -g01.y - g02.y + g20.y, -g01.z - g02.z + g20.z};
+    const V3 gB = {g01.x - g12.x - gp1.x, g01.y - g12.y - gp1.y, g01.z - g12.z - gp1.z};
+    const V3 gC = {g02.x + g12.x - g20.x - gp2.x, g02.y + g12.y - g20.y - gp2.y, g02.z + g12.z - g20.z - gp2.z};
+    atomicAdd(g_verts + ia * 3, gA.x); atomicAdd(g_verts + ia * 3 + 1, gA.y); atomicAdd(g_verts + ia * 3 + 2, gA.z);
+    atomicAdd(g_verts + ib * 3, gB.x); atomicAdd(g_verts + ib * 3 + 1, gB.y); atomicAdd(g_verts + ib * 3 + 2, gB.z);
+    atomicAdd(g_verts + ic * 3, gC.x); atomicAdd(g_verts + ic * 3 + 1, gC.y); atomicAdd(g_verts + ic * 3 + 2, gC.z);
+}
+
 }  // namespace
 
 extern "C" {
+
+int nm_bary_forward(const float* verts, const int32_t* tri, const float* closest, int64_t N, float* bary, nm_stream_t stream) {
+    NM_REQUIRE(N == 0 || (verts && tri && closest && bary), "nm_bary_forward: null pointer");
+    if (N == 0) return NM_OK;
+    hipLaunchKernelGGL(bary_forward_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, nm::as_stream(stream), verts, tri, closest, N, bary);
+    return nm::check_launch("bary_forward_kernel");
+}
+
+int nm_bary_backward(const float* verts, const int32_t* tri, const float* closest, const float* g_bary, int64_t N, int64_t V, float* g_verts,
+                     nm_stream_t stream) {
+    NM_REQUIRE(verts && g_verts && V >= 1, "nm_bary_backward: null pointer");
+    hipStream_t st = nm::as_stream(stream);
+    if (int rc = nm::check_hip(hipMemsetAsync(g_verts, 0, (size_t)V * 12, st), "nm_bary_backward: clear g_verts")) return rc;
+    if (N == 0) return NM_OK;
+    NM_REQUIRE(tri && closest && g_bary, "nm_bary_backward: null pointer");
+    hipLaunchKernelGGL(bary_backward_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, verts, tri, closest, g_bary, N, g_verts);
+    return nm::check_launch("bary_backward_kernel");
+}
 
 int nm_mesh_destroy(nm_mesh_t m) {
     if (!m) return NM_OK;

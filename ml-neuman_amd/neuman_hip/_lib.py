@@ -75,6 +75,8 @@ SIGNATURES = {
     "nm_warp_to_canonical": (i32, [ctypes.c_void_p, c_f32p, i64, i32, ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_stream]),
     "nm_warp_apply_forward": (i32, [c_f32p, c_i32p, c_f32p, c_f32p, i64, c_f32p, c_stream]),
     "nm_warp_apply_backward": (i32, [c_f32p, c_i32p, c_f32p, c_f32p, c_f32p, i64, i64, c_f32p, c_f32p, c_stream]),
+    "nm_bary_forward": (i32, [c_f32p, c_i32p, c_f32p, i64, c_f32p, c_stream]),
+    "nm_bary_backward": (i32, [c_f32p, c_i32p, c_f32p, c_f32p, i64, i64, c_f32p, c_stream]),
     "nm_smpl_create": (i32, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, i32, i32, i32, ctypes.POINTER(ctypes.c_void_p)]),
     "nm_smpl_destroy": (i32, [ctypes.c_void_p]),
     "nm_smpl_vertex_workspace_floats": (i64, [ctypes.c_void_p]),

@@ -6,6 +6,7 @@ runs in libneuman_hip.so.  Functions that the reference defines on torch tensors
 on CPU tensors -- there is no host fallback.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -408,12 +409,41 @@ class _WarpApplyFn(torch.autograd.Function):
         return g_T.reshape(ctx.T_shape), g_b, None, None
 
 
+class _BaryFn(torch.autograd.Function):
+    """barycentric coordinates of the (constant) closest points in their triangles, reference ray_utils.py:72-84, with the adjoint to the
+    vertices: one kernel each way (csrc/warp.hip nm_bary_forward / _backward) instead of ~20 + ~40 elementwise launches and a sorted
+    index_put for the gather's backward"""
+
+    @staticmethod
+    def forward(ctx, verts, tri, closest):
+        vc = verts.detach().contiguous().float()
+        N = tri.shape[0]
+        bary = torch.empty((N, 3), device=vc.device, dtype=torch.float32)
+        _lib.check(_lib.lib().nm_bary_forward(_lib.dev_ptr(vc), _lib.dev_ptr(tri, torch.int32), _lib.dev_ptr(closest), N, _lib.dev_ptr(bary), _lib.stream_ptr()),
+                   "nm_bary_forward")
+        ctx.save_for_backward(vc, tri, closest)
+        return bary
+
+    @staticmethod
+    def backward(ctx, g_bary):
+        vc, tri, closest = ctx.saved_tensors
+        g_v = torch.empty_like(vc)
+        _lib.check(_lib.lib().nm_bary_backward(_lib.dev_ptr(vc), _lib.dev_ptr(tri, torch.int32), _lib.dev_ptr(closest), _lib.dev_ptr(g_bary.contiguous().float()),
+                                               tri.shape[0], vc.shape[0], _lib.dev_ptr(g_v), _lib.stream_ptr()), "nm_bary_backward")
+        return g_v, None, None
+
+
+BARY_KERNELS = os.environ.get('NEUMAN_BARY_KERNELS', '1') != '0'       # 0: the reference's torch lines under autograd (the check of the kernels)
+
+
 def _closest_barycentric(p, verts, f3, mesh=None):
     """the closest-point query (libneuman_hip) and the reference's differentiable barycentric lines (ray_utils.py:70-84) ->
     (barycentric [N,3] with autograd to `verts`, face ids [N] long, signed distance [N])"""
     mesh = mesh or Mesh(verts.detach(), f3.to(torch.int32), torch.zeros((verts.shape[0], 16), dtype=torch.float64), verts.device)
     signed_dist, f_id, closest = signed_distance_dev(p, mesh)
     f_id = f_id.long()
+    if BARY_KERNELS and verts.dtype == torch.float32:
+        return _BaryFn.apply(verts, f3[f_id].to(torch.int32).contiguous(), closest.contiguous()), f_id, signed_dist
     closest_tri = verts[f3[f_id]]
     v0v1 = closest_tri[:, 1] - closest_tri[:, 0]
     v0v2 = closest_tri[:, 2] - closest_tri[:, 0]

@@ -93,3 +93,33 @@ def test_fused_warp_apply_equals_the_reference_shaped_lines(body):
         e = np.abs(x - y).max() / (np.abs(y).max() + 1e-30)
         print(f"[warp-apply] {what}: max |fused - lines| / max |lines| = {e:.2e}")
         assert e < (2e-5 if what == "can_pts" else 5e-4), (what, e)
+
+
+def test_barycentric_kernels_equal_the_reference_lines():
+    """nm_bary_forward / nm_bary_backward against the reference's cross / dot / divide lines (utils/ray_utils.py:72-84) in float64 under
+    torch autograd: coordinates and the gradient that reaches the vertices"""
+    from neuman_hip import ray_utils
+    g = torch.Generator(device='cuda').manual_seed(4)
+    V, N = 500, 30000
+    verts = torch.randn((V, 3), device='cuda', generator=g)
+    tri = torch.stack([torch.randperm(V, device='cuda', generator=g)[:3] for _ in range(64)])[torch.randint(0, 64, (N,), device='cuda', generator=g)].to(torch.int32).contiguous()
+    wts = torch.rand((N, 3), device='cuda', generator=g)
+    wts = wts / wts.sum(1, keepdim=True)
+    closest = (verts[tri.long()] * wts[..., None]).sum(1).contiguous()            # points inside their triangles
+    gb = torch.randn((N, 3), device='cuda', generator=g)
+    v32 = verts.clone().requires_grad_(True)
+    bary = ray_utils._BaryFn.apply(v32, tri, closest)
+    (bary * gb).sum().backward()
+    v64 = verts.double().requires_grad_(True)
+    t = v64[tri.long()]
+    c = closest.double()
+    Nn = torch.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0], dim=1)
+    den = (Nn * Nn).sum(1)
+    u = (Nn * torch.cross(t[:, 2] - t[:, 1], c - t[:, 1], dim=1)).sum(1) / den
+    v = (Nn * torch.cross(t[:, 0] - t[:, 2], c - t[:, 2], dim=1)).sum(1) / den
+    ref = torch.stack([u, v, 1 - u - v], 1)
+    (ref * gb.double()).sum().backward()
+    eb = float((bary.double() - ref).abs().max())
+    eg = float((v32.grad.double() - v64.grad).abs().max() / v64.grad.abs().max())
+    print(f"[bary] coordinates Linf {eb:.2e} (they reproduce the blend weights: {float((bary - wts).abs().max()):.2e}); vertex gradient {eg:.2e} of its largest entry")
+    assert eb < 2e-4 and eg < 1e-4
