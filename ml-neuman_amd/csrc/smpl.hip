@@ -718,6 +718,7 @@ int nm_smpl_vertex_forward(nm_smpl_t m, const float* pose, const float* beta, co
     NM_REQUIRE(m && pose && beta && alignment && workspace && world_out && T_out, "nm_smpl_vertex_forward: null pointer");
     hipStream_t st = nm::as_stream(stream);
     hipLaunchKernelGGL(smpl_jreg_kernel, dim3(m->d.J), dim3(256), 0, st, m->d, m->v_template, m->shapedirs, m->j_reg, beta, workspace);
+    if (int rc = nm::check_launch("smpl_jreg_kernel")) return rc;
     hipLaunchKernelGGL(smpl_chain_kernel, dim3(1), dim3(128), 0, st, m->d, m->parents, pose, da_pose ? da_pose : m->da_pose, workspace);
     if (int rc = nm::check_launch("smpl_chain_kernel")) return rc;
     const int64_t n = m->d.V + m->d.J;
@@ -742,12 +743,18 @@ int nm_smpl_vertex_backward(nm_smpl_t m, const float* pose, const float* beta, c
     float* g_beta_part = g_al_part + (size_t)blocks * 16;
     const float* dap = da_pose ? da_pose : m->da_pose;
     hipLaunchKernelGGL(smpl_jreg_kernel, dim3(d.J), dim3(256), 0, st, d, m->v_template, m->shapedirs, m->j_reg, beta, ws);
+    if (int rc = nm::check_launch("smpl_jreg_kernel")) return rc;
     hipLaunchKernelGGL(smpl_chain_kernel, dim3(1), dim3(128), 0, st, d, m->parents, pose, dap, ws);
+    if (int rc = nm::check_launch("smpl_chain_kernel")) return rc;
     hipLaunchKernelGGL(smpl_bw_rows_kernel, dim3(blocks), dim3(256), 0, st, d, m->v_template, m->shapedirs, m->weights, beta, alignment, (float)scale, ws,
                        g_world, g_T, g_rows, g_al_part);
+    if (int rc = nm::check_launch("smpl_bw_rows_kernel")) return rc;
     hipLaunchKernelGGL(smpl_bw_joints_kernel, dim3(2 * d.J), dim3(256), 0, st, d, m->weights, g_rows, g_A);
+    if (int rc = nm::check_launch("smpl_bw_joints_kernel")) return rc;
     hipLaunchKernelGGL(smpl_bw_chain_kernel, dim3(1), dim3(64), 0, st, d, m->parents, pose, dap, ws, g_A, g_pose, g_J);
+    if (int rc = nm::check_launch("smpl_bw_chain_kernel")) return rc;
     hipLaunchKernelGGL(smpl_bw_shape_kernel, dim3(blocks), dim3(256), 0, st, d, m->shapedirs, m->j_reg, g_rows, g_J, g_beta_part);
+    if (int rc = nm::check_launch("smpl_bw_shape_kernel")) return rc;
     hipLaunchKernelGGL(smpl_bw_finish_kernel, dim3(1), dim3(64), 0, st, blocks, d.NB, g_al_part, g_beta_part, g_align, g_beta);
     return nm::check_launch("nm_smpl_vertex_backward");
 }

@@ -236,10 +236,18 @@ class SMPLDiff(torch.nn.Module):
         T = torch.einsum('vj,jab->vab', self.lbs_weights, A)                                        # :338-341
         return T, v_shaped
 
+    def _model_key(self):
+        """identity of the model data behind the device copy: a load_state_dict / .to() / in-place edit of a buffer changes it"""
+        return tuple((t.data_ptr(), t._version, str(t.device)) for t in (self.v_template, self.shapedirs, self.J_regressor, self.lbs_weights, self.da_smpl))
+
     def _hip_handle(self):
-        """the device copy of the model behind the hand-written kernels (created on first use)"""
+        """the device copy of the model behind the hand-written kernels (created on first use, rebuilt when the buffers it was made from change)"""
+        if getattr(self, '_handle', None) is not None and getattr(self, '_handle_key', None) != self._model_key():
+            _lib.lib().nm_smpl_destroy(self._handle)
+            self._handle = None
         if getattr(self, '_handle', None) is None:
             import ctypes
+            self._handle_key = self._model_key()
             f = lambda t: np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float32))      # noqa: E731
             vt, sd, jr, w = f(self.v_template), f(self.shapedirs), f(self.J_regressor), f(self.lbs_weights)
             p32 = np.ascontiguousarray(np.asarray(self.parents_list, np.int32))

@@ -123,3 +123,21 @@ def test_barycentric_kernels_equal_the_reference_lines():
     eg = float((v32.grad.double() - v64.grad).abs().max() / v64.grad.abs().max())
     print(f"[bary] coordinates Linf {eb:.2e} (they reproduce the blend weights: {float((bary - wts).abs().max()):.2e}); vertex gradient {eg:.2e} of its largest entry")
     assert eb < 2e-4 and eg < 1e-4
+
+
+def test_device_copy_follows_the_model_buffers():
+    """the hand-written kernels work on a device copy of the body model made on first use: editing a buffer afterwards (a load_state_dict of
+    HumanNeRF's body_model.* entries, an in-place change) rebuilds it, so they keep agreeing with the torch path that reads the buffers"""
+    from neuman_hip import smpl, synthetic
+    b = smpl.SMPLDiff(synthetic.smpl_like_model(0), 'cuda')
+    pose, betas, align = synthetic.smpl_like_frames(1, 0)
+    al = np.concatenate([align['00000.png'], np.array([[0.], [0.], [0.], [1.]])], 1).astype(np.float32)
+    args = lambda: (leaf(pose[0][None] * 0.5), leaf(betas[0][None] * 0.5), leaf(al), 1.0)      # noqa: E731
+    w0, _ = b.vertex_forward(*args())
+    with torch.no_grad():
+        b.v_template.mul_(1.1)
+        b.shapedirs.add_(0.01)
+    w1, T1 = b.vertex_forward(*args())
+    w2, T2 = b.vertex_forward_torch(*args())
+    assert float((w1 - w0).abs().max()) > 1e-3
+    assert float((w1 - w2).abs().max()) < 2e-5 * float(w2.abs().max()) and float((T1 - T2).abs().max()) < 2e-5 * float(T2.abs().max())
