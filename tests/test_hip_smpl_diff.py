@@ -119,9 +119,9 @@ def test_barycentric_kernels_equal_the_reference_lines():
     v = (Nn * torch.cross(t[:, 0] - t[:, 2], c - t[:, 2], dim=1)).sum(1) / den
     ref = torch.stack([u, v, 1 - u - v], 1)
     (ref * gb.double()).sum().backward()
-    eb = float((bary.double() - ref).abs().max())
+    eb = float((bary.detach().double() - ref.detach()).abs().max())
     eg = float((v32.grad.double() - v64.grad).abs().max() / v64.grad.abs().max())
-    print(f"[bary] coordinates Linf {eb:.2e} (they reproduce the blend weights: {float((bary - wts).abs().max()):.2e}); vertex gradient {eg:.2e} of its largest entry")
+    print(f"[bary] coordinates Linf {eb:.2e} (they reproduce the blend weights: {float((bary.detach() - wts).abs().max()):.2e}); vertex gradient {eg:.2e} of its largest entry")
     assert eb < 2e-4 and eg < 1e-4
 
 
