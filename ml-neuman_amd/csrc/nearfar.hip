@@ -17,12 +17,15 @@ namespace {
 // V in the loop), and a WAVE whose rays all pass that sphere at more than radius + tau -- with a margin far above float32 rounding --
 // cannot reach any vertex's tau-sphere: every discriminant below is negative there, so the loop would leave near = +inf, far = -inf, which
 // is what the wave writes without running it (bit-identical; only for unit directions, as the renderers' rays are: the reference's
-// discriminant is a distance only then).  A frame's hit rays cluster: in the hybrid configurations 4 of 5 waves skip.
+// discriminant is a distance only then).  A frame's hit rays cluster: in the hybrid configurations 4 of 5 waves skip.  The waves
+// that do run the loop apply the same test per cluster of 64 consecutive vertices.
+constexpr int kMaxClusters = 512;                       // 64-vertex clusters: meshes up to 32 768 vertices (SMPL: 108)
 __global__ __launch_bounds__(256) void near_far_kernel(const float* __restrict__ origin, const float* __restrict__ direction,
                                                        int64_t R, const float* __restrict__ verts, int V, float tau2,
                                                        float* __restrict__ near, float* __restrict__ far) {
     __shared__ float red[6][4];
     __shared__ float red_r[4];
+    __shared__ float cl[kMaxClusters][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int v = threadIdx.x; v < V; v += 256)
@@ -56,6 +59,32 @@ __global__ __launch_bounds__(256) void near_far_kernel(const float* __restrict__
     if (lane == 0) red_r[wv] = rad2;
     __syncthreads();
     const float rad = sqrtf(fmaxf(fmaxf(red_r[0], red_r[1]), fmaxf(red_r[2], red_r[3])));
+    // bounding spheres of the clusters of 64 consecutive vertices (box centre, largest distance), one cluster per wave at a time
+    const bool use_cl = (V + 63) / 64 <= kMaxClusters;
+    const int ncl = use_cl ? (V + 63) / 64 : 1;
+    if (use_cl) {
+        for (int k = wv; k < ncl; k += 4) {
+            const int v = 64 * k + lane;
+            const bool in = v < V;
+            const float x = in ? verts[v * 3] : 0.f, y = in ? verts[v * 3 + 1] : 0.f, z = in ? verts[v * 3 + 2] : 0.f;
+            float l3[3] = {in ? x : INFINITY, in ? y : INFINITY, in ? z : INFINITY}, h3[3] = {in ? x : -INFINITY, in ? y : -INFINITY, in ? z : -INFINITY};
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    l3[c] = fminf(l3[c], __shfl_xor(l3[c], o, 64));
+                    h3[c] = fmaxf(h3[c], __shfl_xor(h3[c], o, 64));
+                }
+            const float mx = 0.5f * (l3[0] + h3[0]), my = 0.5f * (l3[1] + h3[1]), mz = 0.5f * (l3[2] + h3[2]);
+            float r2 = in ? (x - mx) * (x - mx) + (y - my) * (y - my) + (z - mz) * (z - mz) : 0.f;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) r2 = fmaxf(r2, __shfl_xor(r2, o, 64));
+            if (lane == 0) { cl[k][0] = mx; cl[k][1] = my; cl[k][2] = mz; cl[k][3] = sqrtf(r2); }
+        }
+    } else if (threadIdx.x == 0) {
+        cl[0][0] = cen[0]; cl[0][1] = cen[1]; cl[0][2] = cen[2]; cl[0][3] = rad;
+    }
+    __syncthreads();
 
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t r = i < R ? i : R - 1;
@@ -71,16 +100,29 @@ __global__ __launch_bounds__(256) void near_far_kernel(const float* __restrict__
         may_hit = !(unit && cc - cd * cd > reach * reach * 1.01f) || !(rad == rad) || !(cc == cc);      // (non-finite anything: run the loop)
     }
     if (__any(may_hit)) {
+        // the same test per CLUSTER of 64 consecutive vertices (their bounding spheres: cl[], built below by this workgroup): a wave skips the
+        // clusters none of its rays can reach -- the vertices it does visit are visited in ascending order with the reference's arithmetic
+        const float tau = sqrtf(tau2);
+        const float ddq = dx * dx + dy * dy + dz * dz;
+        const bool unit_d = fabsf(ddq - 1.f) < 1e-6f;
+        for (int k = 0; k < ncl; ++k) {
+            const float cx = cl[k][0] - ox, cy = cl[k][1] - oy, cz = cl[k][2] - oz, rk = cl[k][3];
+            const float cc = cx * cx + cy * cy + cz * cz, cd = cx * dx + cy * dy + cz * dz;
+            const float reach = (rk + tau) * 1.001f + 1e-3f * (1.f + sqrtf(cc));
+            const bool skip = use_cl && unit_d && cc < 1e6f && cc - cd * cd > reach * reach * 1.01f && rk == rk;
+            if (!__any(!skip)) continue;
+            const int v1 = use_cl ? (64 * k + 64 < V ? 64 * k + 64 : V) : V;
 #pragma unroll 4
-        for (int v = 0; v < V; ++v) {
-            const float vx = verts[v * 3 + 0] - ox, vy = verts[v * 3 + 1] - oy, vz = verts[v * 3 + 2] - oz;  // :209
-            const float z0 = vx * dx + vy * dy + vz * dz;                      // :210
-            const float nrm = sqrtf(vx * vx + vy * vy + vz * vz);              // torch.norm(orig_v, dim=2), :211
-            const float disc = tau2 - (nrm * nrm - z0 * z0);
-            if (disc >= 0.f) {                                                  // sqrt(negative) = NaN -> dropped
-                const float dzv = sqrtf(disc);
-                n = fminf(n, z0 - dzv);
-                f = fmaxf(f, z0 + dzv);
+            for (int v = use_cl ? 64 * k : 0; v < v1; ++v) {
+                const float vx = verts[v * 3 + 0] - ox, vy = verts[v * 3 + 1] - oy, vz = verts[v * 3 + 2] - oz;  // :209
+                const float z0 = vx * dx + vy * dy + vz * dz;                      // :210
+                const float nrm = sqrtf(vx * vx + vy * vy + vz * vz);              // torch.norm(orig_v, dim=2), :211
+                const float disc = tau2 - (nrm * nrm - z0 * z0);
+                if (disc >= 0.f) {                                                  // sqrt(negative) = NaN -> dropped
+                    const float dzv = sqrtf(disc);
+                    n = fminf(n, z0 - dzv);
+                    f = fmaxf(f, z0 + dzv);
+                }
             }
         }
     }

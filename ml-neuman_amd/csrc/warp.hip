@@ -136,14 +136,24 @@ __global__ __launch_bounds__(256) void tri_prep_kernel(const float* __restrict__
     keys[f] = ((unsigned long long)code << 32) | (unsigned)f;
 }
 
-// rank sort: position of record f in Morton order = number of smaller keys.  F^2 compares of wave-uniform (scalar-loaded)
-// keys: 70 us for F = 13,776, and still ~1 ms at F = 100 k -- no multi-pass radix sort for a body mesh.
+// rank sort: position of record f in Morton order = number of smaller keys.  F^2 compares, the keys staged through LDS in chunks and read
+// back as broadcasts (a loop of wave-uniform global loads is one exposed scalar-cache round trip per key: 0.8 ms for F = 13,776; this: tens
+// of microseconds) -- no multi-pass radix sort for a body mesh.
 __global__ __launch_bounds__(256) void rank_scatter_kernel(const unsigned long long* __restrict__ keys, int F, const TriRec* __restrict__ rec,
                                                            TriRec* __restrict__ sorted, int32_t* __restrict__ face_of) {
+    constexpr int kChunk = 2048;
+    __shared__ unsigned long long sk[kChunk];
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned long long mine = f < F ? keys[f] : 0ull;
     int rank = 0;
-    for (int g = 0; g < F; ++g) rank += keys[g] < mine ? 1 : 0;
+    for (int g0 = 0; g0 < F; g0 += kChunk) {
+        const int cnt = F - g0 < kChunk ? F - g0 : kChunk;
+        __syncthreads();
+        for (int i = threadIdx.x; i < kChunk; i += 256) sk[i] = i < cnt ? keys[g0 + i] : ~0ull;       // (padding: never smaller than a key)
+        __syncthreads();
+#pragma unroll 16
+        for (int g = 0; g < kChunk; ++g) rank += sk[g] < mine ? 1 : 0;
+    }
     if (f < F) { sorted[rank] = rec[f]; face_of[rank] = f; }
 }
 

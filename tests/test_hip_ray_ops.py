@@ -282,3 +282,26 @@ def test_merge_sorted_vs_oracle(H, R, Sa, Sb):
     oz, oraw = compositing.merge_sorted([za, zb2], [ra, rb])
     np.testing.assert_array_equal(z.cpu().numpy(), oz)
     np.testing.assert_array_equal(raw.cpu().numpy(), oraw)
+
+
+def test_near_far_cluster_skip_is_bit_identical(H):
+    """near_far_kernel also skips, per wave, the clusters of 64 consecutive vertices none of its rays can reach.  near / far are a min / max
+    over the vertices that pass the reference's test, so the vertex ORDER cannot matter: a random permutation of the vertices (clusters
+    become body-sized: nothing is skipped) must give the same bits as the model's order (compact clusters: most are skipped)."""
+    from neuman_hip import synthetic
+    rng = np.random.default_rng(5)
+    verts = synthetic.human_vertex_cloud(0).astype(np.float32)
+    order = np.argsort(verts[:, 1] * 7 + verts[:, 0])                       # spatially coherent clusters (sorted along the body)
+    v_sorted, v_shuf = verts[order].copy(), verts[rng.permutation(len(verts))].copy()
+    R = 64 * 500
+    o = np.tile(np.array([[0.1, 0.2, -2.5]], np.float32), (R, 1)) + rng.normal(size=(R, 3)).astype(np.float32) * 0.01
+    tgt = verts[rng.integers(0, len(verts), R)] + rng.normal(size=(R, 3)).astype(np.float32) * 0.3
+    d = tgt - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    res = [H.ray.geometry_guided_near_far(cu(o), cu(d), cu(v), 0.05) for v in (v_sorted, v_shuf, verts)]
+    n0, f0 = (x.cpu().numpy() for x in res[0])
+    for n, f in res[1:]:
+        np.testing.assert_array_equal(n0, n.cpu().numpy())
+        np.testing.assert_array_equal(f0, f.cpu().numpy())
+    hit = n0 < f0
+    assert 0.2 < hit.mean() < 0.98
