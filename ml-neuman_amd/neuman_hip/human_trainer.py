@@ -31,6 +31,9 @@ PATCH_SIZE = 32                                    # :8
 CANONICAL_CAMERA_DIST = 3.0                        # :13
 
 
+BATCH_NET_CALLS = os.environ.get('NEUMAN_BATCH_NET_CALLS', '1') != '0'     # the iteration's five human-network evaluations as one call
+
+
 def _occupancy(raw):
     """1 - exp(-relu(sigma)) of a raw network output [..., 4]: the opacity of a unit interval"""
     return 1 - torch.exp(-torch.relu(raw.reshape(-1, 4)[:, 3]))
@@ -98,20 +101,35 @@ class HumanNeRFLoss:
         can_pts = can_pts + offset
         step = can_pts[:, 1:] - can_pts[:, :-1]                                          # view direction of a warped sample: towards the next one
         can_dirs = _unit(torch.cat([step, step[:, -1:]], dim=1))
-        human_out = self.net.coarse_human_net(can_pts, can_dirs)
-        return human_pts, human_dirs, human_z_vals, can_pts, can_dirs, human_out
+        return human_pts, human_dirs, human_z_vals, can_pts, can_dirs
+
+    def _human_net(self, queries):
+        """coarse_human_net on every (points, directions) set of an iteration in ONE call.  The reference calls the network five times
+        (:276 the rays' samples, :286 / :299 / :331 / :364 the regularisers' points); a sample's output does not depend on what else is in
+        the batch, and `cat` / `split` are differentiable, so one forward, one backward-data chain and one set of backward-weights products
+        serve all of them (a fifth of the launches; the parameter gradients are the same sums in another order).  BATCH_NET_CALLS = False:
+        one call per set."""
+        if not BATCH_NET_CALLS or len(queries) == 1:
+            return [self.net.coarse_human_net(p, d) for p, d in queries]
+        sizes = [p.shape[0] for p, _ in queries]
+        out = self.net.coarse_human_net(torch.cat([p for p, _ in queries], 0), torch.cat([d for _, d in queries], 0))
+        return list(torch.split(out, sizes, 0))
 
     # ---- :280-290
-    def _color_range_regularization(self, pts, dirs, tgts):
+    def _color_range_query(self, pts, dirs):
         draw = torch.as_tensor(self.replay['dummy_dirs_randn']).to(dirs) if self.replay else torch.randn_like(dirs)
-        other_view = self.net.coarse_human_net(pts, _unit(draw))                         # the same points seen from random directions
+        return pts, _unit(draw)                                                           # the same points seen from random directions
+
+    def _color_range_regularization(self, other_view, tgts):
         rgb = lambda raw: torch.sigmoid(raw.reshape(-1, 4)[:, :3])                       # noqa: E731
         return self.penalize_color_range * F.mse_loss(rgb(other_view), rgb(tgts))
 
     # ---- :292-304
-    def _smpl_symmetry_regularization(self, pts, dirs, tgts):
+    def _smpl_symmetry_query(self, pts, dirs):
         mirror = torch.tensor([-1.0, 1.0, 1.0], device=pts.device)                      # the canonical body is left-right symmetric in x
-        mirrored = self.net.coarse_human_net(pts.detach() * mirror, dirs.detach())      # (dummy directions: only the occupancy is compared)
+        return pts.detach() * mirror, dirs.detach()                                      # (dummy directions: only the occupancy is compared)
+
+    def _smpl_symmetry_regularization(self, mirrored, tgts):
         squash = lambda raw: torch.tanh(torch.relu(raw[..., 3]))                        # noqa: E731
         return self.penalize_symmetric_alpha * F.mse_loss(squash(tgts), squash(mirrored))
 
@@ -148,23 +166,24 @@ class HumanNeRFLoss:
     _CAN_TREE_MAX = 8
 
     # ---- :305-343
-    def _smpl_shape_regularization(self, batch, pts, dirs, pred):
+    def _dummy_points(self, pts):
+        if not self.penalize_dummy > 0:
+            return None                                                                   # random points of a 3-unit box around the canonical body
+        return ((torch.as_tensor(self.replay['dummy_pts_rand']).to(pts) if self.replay else torch.rand_like(pts)) - 0.5) * 3
+
+    def _smpl_shape_regularization(self, batch, pts, pred, dummy_pts, dummy_out):
         device = pts.device
         smpl_reg = torch.zeros((), device=device)
 
         def filled(raw, mask, weight):                                                   # occupancy 1 where the body is
             return weight * ((1 - _occupancy(raw)[mask]) ** 2).mean() if bool(mask.any()) else 0.0
 
-        dummy_pts = None
-        if self.penalize_dummy > 0:                                                      # random points of a 3-unit box around the canonical body
-            dummy_pts = ((torch.as_tensor(self.replay['dummy_pts_rand']).to(pts) if self.replay else torch.rand_like(pts)) - 0.5) * 3
         # both signed-distance queries of the iteration (:310, :326) go against the same canonical body: ONE search launch
         both = self._signed_distance(pts if dummy_pts is None else torch.cat([pts.reshape(-1, 3), dummy_pts.reshape(-1, 3)], 0), batch.get('cap_id'))
         n_h = pts.reshape(-1, 3).shape[0]
         dist_human = both[:n_h]
         smpl_reg = smpl_reg + filled(pred, dist_human < 0, self.penalize_smpl_alpha)
         if dummy_pts is not None:
-            dummy_out = self.net.coarse_human_net(dummy_pts, dirs)
             dist_dummy = both[n_h:]
             smpl_reg = smpl_reg + filled(dummy_out, dist_dummy < 0, self.penalize_dummy)
             outside = dist_dummy > 0
@@ -176,8 +195,7 @@ class HumanNeRFLoss:
         return smpl_reg
 
     # ---- :345-380
-    def _sparsity_regularization(self, device):
-        sparsity_reg = torch.zeros((), device=device)
+    def _sparsity_query(self, device):
         num_can_rays = 128
         can_cap = self.can_caps[int(self.replay['can_cap'])] if self.replay else self.rng.choice(self.can_caps)
         coords = np.argwhere(np.ones(can_cap.shape))
@@ -187,7 +205,10 @@ class HumanNeRFLoss:
             {'origin': torch.from_numpy(can_orig).float().to(device), 'direction': torch.from_numpy(can_dir).float().to(device),
              'near': torch.zeros(num_can_rays, 1).float().to(device), 'far': torch.ones(num_can_rays, 1).float().to(device) * CANONICAL_CAMERA_DIST * 1.667},
             samples_per_ray=self.opt.samples_per_ray, device=device, perturb=self.opt.perturb)
-        can_out = self.net.coarse_human_net(can_pts, can_dirs)
+        return can_pts, can_dirs, can_z_vals
+
+    def _sparsity_regularization(self, can_out, can_dirs, can_z_vals):
+        sparsity_reg = torch.zeros((), device=can_out.device)
         can_out = torch.cat([can_out[..., :3], can_out[..., 3:] * self.interval_comp], -1)            # `can_out[..., -1] *= interval_comp`, out of place
         _, _, can_mask, can_weights, _ = render_utils.raw2outputs(can_out, can_z_vals.clone(), can_dirs[:, 0, :].clone(), white_bkg=True)
         can_weights, can_mask = can_weights.clamp(0.0, 1.0), can_mask.clamp(0.0, 1.0)
@@ -205,19 +226,40 @@ class HumanNeRFLoss:
         self.last = {}
         hit_index = torch.nonzero(batch['is_hit'].to(device))[:, 0]
         fine_bkg_dir, fine_bkg_z_vals, fine_bkg_out = self._eval_bkg_samples(batch, device)
-        _, human_dirs, human_z_vals, can_pts, can_dirs, human_out = self._eval_human_samples(batch, device)
+        _, human_dirs, human_z_vals, can_pts, can_dirs = self._eval_human_samples(batch, device)
+        # every set of points the human network is asked about in this iteration, in the order the reference draws its random numbers
+        # (:286 directions, :317 dummy points, :347-362 canonical rays), then ONE evaluation
+        queries, slot = [(can_pts, can_dirs)], {}
         if self.penalize_symmetric_alpha > 0:
-            loss_dict['smpl_sym_reg'] = loss_dict['smpl_sym_reg'] + self._smpl_symmetry_regularization(can_pts, can_dirs, human_out)
+            slot['sym'] = len(queries)
+            queries.append(self._smpl_symmetry_query(can_pts, can_dirs))
         if self.penalize_color_range > 0:
-            loss_dict['color_range_reg'] = loss_dict['color_range_reg'] + self._color_range_regularization(can_pts, can_dirs, human_out)
+            slot['color'] = len(queries)
+            queries.append(self._color_range_query(can_pts, can_dirs))
+        dummy_pts = self._dummy_points(can_pts) if self.penalize_smpl_alpha > 0 else None
+        if dummy_pts is not None:
+            slot['dummy'] = len(queries)
+            queries.append((dummy_pts, can_dirs))
+        sparse = None
+        if self.penalize_sharp_edge > 0 or self.penalize_hard_surface > 0:
+            sparse = self._sparsity_query(device)
+            slot['sparse'] = len(queries)
+            queries.append((sparse[0], sparse[1]))
+        outs = self._human_net(queries)
+        human_out = outs[0]
+        if 'sym' in slot:
+            loss_dict['smpl_sym_reg'] = loss_dict['smpl_sym_reg'] + self._smpl_symmetry_regularization(outs[slot['sym']], human_out)
+        if 'color' in slot:
+            loss_dict['color_range_reg'] = loss_dict['color_range_reg'] + self._color_range_regularization(outs[slot['color']], human_out)
         if self.penalize_mask > 0:
             _, _, human_mask, _, _ = render_utils.raw2outputs(human_out, human_z_vals, human_dirs[:, 0, :].contiguous(), white_bkg=self.opt.white_bkg)
             loss_dict['mask_loss'] = loss_dict['mask_loss'] + F.mse_loss(torch.clamp(human_mask, min=0.0, max=1.0),
                                                                          (1 - batch['is_bkg'].to(device)).float()) * self.penalize_mask
         if self.penalize_smpl_alpha > 0:
-            loss_dict['smpl_shape_reg'] = loss_dict['smpl_shape_reg'] + self._smpl_shape_regularization(batch, can_pts, can_dirs, human_out)
-        if self.penalize_sharp_edge > 0 or self.penalize_hard_surface > 0:
-            loss_dict['sparsity_reg'] = loss_dict['sparsity_reg'] + self._sparsity_regularization(device)
+            loss_dict['smpl_shape_reg'] = loss_dict['smpl_shape_reg'] + self._smpl_shape_regularization(
+                batch, can_pts, human_out, dummy_pts, outs[slot['dummy']] if 'dummy' in slot else None)
+        if sparse is not None:
+            loss_dict['sparsity_reg'] = loss_dict['sparsity_reg'] + self._sparsity_regularization(outs[slot['sparse']], sparse[1], sparse[2])
         # RGB loss: the two sample lists merged by depth (:415-422), composited once (:423-428)
         fine_total_zvals, fine_order = torch.sort(torch.cat([fine_bkg_z_vals, human_z_vals], -1), -1)
         fine_total_out = torch.gather(torch.cat([fine_bkg_out, human_out], 1), 1, fine_order[..., None].expand(-1, -1, 4))
