@@ -175,8 +175,12 @@ class HumanNeRFLoss:
         device = pts.device
         smpl_reg = torch.zeros((), device=device)
 
+        def masked_mean(x, mask):                                                        # x[mask].mean(), 0 for an empty mask -- without asking the
+            m = mask.to(x.dtype)                                                         # host whether it is empty (a synchronisation per question)
+            return (x * m).sum() / m.sum().clamp_min(1.0)
+
         def filled(raw, mask, weight):                                                   # occupancy 1 where the body is
-            return weight * ((1 - _occupancy(raw)[mask]) ** 2).mean() if bool(mask.any()) else 0.0
+            return weight * masked_mean((1 - _occupancy(raw)) ** 2, mask)
 
         # both signed-distance queries of the iteration (:310, :326) go against the same canonical body: ONE search launch
         both = self._signed_distance(pts if dummy_pts is None else torch.cat([pts.reshape(-1, 3), dummy_pts.reshape(-1, 3)], 0), batch.get('cap_id'))
@@ -186,10 +190,9 @@ class HumanNeRFLoss:
         if dummy_pts is not None:
             dist_dummy = both[n_h:]
             smpl_reg = smpl_reg + filled(dummy_out, dist_dummy < 0, self.penalize_dummy)
-            outside = dist_dummy > 0
-            if bool(outside.any()):                                                      # occupancy 0 outside, weighted by the distance from the surface
-                falloff = (dist_dummy[outside].abs() * self.opt.penalize_outside_factor) ** self.opt.dist_exponent
-                smpl_reg = smpl_reg + self.penalize_dummy * (_occupancy(dummy_out)[outside] * falloff).abs().mean()
+            outside = dist_dummy > 0                                                     # occupancy 0 outside, weighted by the distance from the surface
+            falloff = (dist_dummy.abs() * self.opt.penalize_outside_factor) ** self.opt.dist_exponent
+            smpl_reg = smpl_reg + self.penalize_dummy * masked_mean((_occupancy(dummy_out) * falloff).abs(), outside)
             self.last.update(dummy_pts=dummy_pts, dist_dummy=dist_dummy, dummy_out=dummy_out)
         self.last.update(dist_human=dist_human)
         return smpl_reg
@@ -224,7 +227,7 @@ class HumanNeRFLoss:
         device = next(self.net.coarse_human_net.parameters()).device
         loss_dict = {name: torch.zeros((), device=device) for name in LOSS_NAMES}
         self.last = {}
-        hit_index = torch.nonzero(batch['is_hit'].to(device))[:, 0]
+        is_hit = batch['is_hit'].to(device).bool()
         fine_bkg_dir, fine_bkg_z_vals, fine_bkg_out = self._eval_bkg_samples(batch, device)
         _, human_dirs, human_z_vals, can_pts, can_dirs = self._eval_human_samples(batch, device)
         # every set of points the human network is asked about in this iteration, in the order the reference draws its random numbers
@@ -265,29 +268,51 @@ class HumanNeRFLoss:
         fine_total_out = torch.gather(torch.cat([fine_bkg_out, human_out], 1), 1, fine_order[..., None].expand(-1, -1, 4))
         fine_rgb_map, _, _, _, _ = render_utils.raw2outputs(fine_total_out, fine_total_zvals, fine_bkg_dir, white_bkg=self.opt.white_bkg)
         color = batch['color'].to(device)
-        loss_dict['fine_rgb_loss'] = loss_dict['fine_rgb_loss'] + F.mse_loss(fine_rgb_map[hit_index], color[hit_index])
+        # mse over the hit rays (:429): a masked mean, so that the host need not wait for the index list of the hits
+        hit_w = is_hit.to(fine_rgb_map.dtype)[:, None]
+        loss_dict['fine_rgb_loss'] = loss_dict['fine_rgb_loss'] + (((fine_rgb_map - color) ** 2) * hit_w).sum() / (hit_w.sum() * fine_rgb_map.shape[1]).clamp_min(1.0)
         if self.penalize_lpips > 0 and int(batch.get('patch_counter', 0)) == 1 and self.lpips_loss_fn is not None:   # :431-435
             n = PATCH_SIZE * PATCH_SIZE
             a = fine_rgb_map[:n].reshape(PATCH_SIZE, PATCH_SIZE, -1).permute(2, 0, 1) * 2 - 1
             b = color[:n].reshape(PATCH_SIZE, PATCH_SIZE, -1).permute(2, 0, 1) * 2 - 1
             loss_dict['lpips_loss'] = loss_dict['lpips_loss'] + (self.lpips_loss_fn(a, b) * self.penalize_lpips).flatten()[0]
         self.last.update(human_out=human_out, can_pts=can_pts, can_dirs=can_dirs, human_z_vals=human_z_vals, fine_bkg_out=fine_bkg_out,
-                         fine_bkg_z_vals=fine_bkg_z_vals, fine_rgb_map=fine_rgb_map, hit_index=hit_index)
-        if float(human_out[..., 3].detach().max()) <= 0.0:                                       # :437-442: a dead network is re-initialised
-            from .vanilla import weight_reset
-            for m in list(self.net.offset_nets) + [self.net.coarse_human_net]:
-                m.apply(weight_reset)
+                         fine_bkg_z_vals=fine_bkg_z_vals, fine_rgb_map=fine_rgb_map, is_hit=is_hit)
+        # :437-442: a dead network (no positive density anywhere) is re-initialised and the iteration's losses are zero.  `defer_dead_check`
+        # (train_step): the flag stays on the device -- the losses are multiplied by it, the host reads it together with the loss values after
+        # the backward pass and re-initialises then (before the optimiser step, as the reference does) -- so that the loss is built without
+        # a host synchronisation
+        alive = (human_out[..., 3].detach().max() > 0.0)
+        if self.defer_dead_check:
+            self.last['alive'] = alive
+            loss_dict = {k: v * alive.to(v.dtype) for k, v in loss_dict.items()}
+        elif not bool(alive):
+            self._reset_dead_networks()
             loss_dict = {name: torch.zeros((), device=device, requires_grad=True) for name in LOSS_NAMES}
         return (loss_dict, fine_rgb_map) if return_rgb else loss_dict
+
+    defer_dead_check = False
+
+    def _reset_dead_networks(self):
+        from .vanilla import weight_reset
+        for m in list(self.net.offset_nets) + [self.net.coarse_human_net]:
+            m.apply(weight_reset)
 
     def train_step(self, batch, optimizer):
         """train_batch (:470-494): zero_grad, loss, backward, step -> {name: float}, total"""
         optimizer.zero_grad()
-        loss_dict = self.loss_func(batch)
+        self.defer_dead_check = True
+        try:
+            loss_dict = self.loss_func(batch)
+        finally:
+            self.defer_dead_check = False
         total = sum(loss_dict.values())
         total.backward()
+        vals = torch.stack([v.detach() for v in loss_dict.values()] + [total.detach(), self.last['alive'].to(total.dtype)]).tolist()   # ONE read-back
+        if vals[-1] == 0.0:
+            self._reset_dead_networks()
         optimizer.step()
-        return {k: float(v.detach()) for k, v in loss_dict.items()}, float(total.detach())
+        return dict(zip(loss_dict.keys(), vals[:-2])), vals[-2]
 
 
 # DensePose body-part labels (1..24) that show a limb, and the SMPL joints whose pose gradient is zeroed when none of them is in
