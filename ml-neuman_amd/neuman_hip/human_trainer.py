@@ -378,14 +378,24 @@ class HumanNeRFTrainer(HumanNeRFLoss):
     def train_batch(self, batch):
         opt, it = self.opt, self.iteration
         self.optim.zero_grad()
-        g = self._grouped(self.loss_func(batch), photometric=it >= opt.delay_iters)
-        report = {k: float(v.detach()) for k, v in g.items()}
+        # the loss is built and differentiated without a question to the host; its values, the NaN test of :476-478 and the dead-network flag
+        # of :437-442 are ONE read-back after the backward pass (a NaN loss: the gradients are dropped, as if backward() had not run)
+        self.defer_dead_check = True
+        try:
+            g = self._grouped(self.loss_func(batch), photometric=it >= opt.delay_iters)
+        finally:
+            self.defer_dead_check = False
+        g['total_loss'].backward()
+        names = list(g.keys())
+        vals = torch.stack([g[k].detach().float() for k in names] + [self.last['alive'].float()]).tolist()
+        report = dict(zip(names, vals[:-1]))
         report['lr'] = self.optim.param_groups[0]['lr']
+        if vals[-1] == 0.0:
+            self._reset_dead_networks()
         if math.isnan(report['total_loss']):
             print('loss is nan during training', report)
             self.optim.zero_grad()
         else:
-            g['total_loss'].backward()
             mask = self.pose_grad_mask(int(batch['cap_id'])) if self.pose_grad_mask is not None else None
             if mask is not None and getattr(self.net, 'poses', None) is not None and self.net.poses.grad is not None:
                 cap = int(batch['cap_id'])
