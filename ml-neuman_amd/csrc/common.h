@@ -26,6 +26,19 @@ inline hipStream_t as_stream(nm_stream_t s) { return reinterpret_cast<hipStream_
         }                              \
     } while (0)
 
+// ---- 16-bit storage of a training step's backward pass (mlp_bwd.hip writes, train.hip's wgrad16 kernels read) -------------------
+// dZ is kept as fp16 of dZ * s, s the power of two that puts `amax` -- the largest magnitude entering the chain (d_feat, d_raw), measured on
+// the device by nm_absmax -- into [2, 4): 2^13 of headroom for growth down the trunk before fp16 saturates (values are clamped, never
+// inf), and entries 2^-16 below the top are still normal numbers.  Every kernel derives s from the same device scalar.
+__device__ __forceinline__ float nm_dz_scale(float amax) {
+    const unsigned e = (__float_as_uint(amax) >> 23) & 0xffu;             // biased exponent: amax = m 2^(e - 127), m in [1, 2)
+    if (e == 0u || e == 255u) return 1.f;                                   // zero / subnormal / not finite: nothing to scale
+    int se = 255 - (int)e;                                                  // s = 2^(1 - (e - 127)) -> biased exponent 127 + 128 - e
+    se = se < 1 ? 1 : (se > 254 ? 254 : se);
+    return __uint_as_float((unsigned)se << 23);
+}
+constexpr float kNmAct16Scale = 32.f;                                       // saved activations: fp16 of 32 x value (mlp_device.h kF16ActScale)
+
 // ---- wave-level primitives (64 lanes) -------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -21,7 +21,7 @@
 namespace {
 
 
-template <int PREC, bool PROF, bool SAVE = false>
+template <int PREC, bool PROF, int SAVE = 0>      // SAVE 1: float32 copies of the activations (nm_mlp_forward_save); 2: fp16 copies of the trunk's (nm_mlp_forward_save16)
 __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_in) {
     const MlpArgs a = resolve_args(a_in);
     unsigned long long pr[6] = {0, 0, 0, 0, 0, 0};
@@ -99,8 +99,10 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
             bias_prefetch(B, a.bias + nm::stage_b_off(st + 1) + 32 * w, g);     // next stage (st + 1 <= 8), block w
             NM_TICK(1)
             if (SAVE) {
+                if (SAVE == 1) {
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) save_block(a.save_h + (int64_t)st * a.n * 256, 256, acc[mb], w, base + 32 * mb + s, acc2out(st), true);
+                    for (int mb = 0; mb < 4; ++mb) save_block(a.save_h + (int64_t)st * a.n * 256, 256, acc[mb], w, base + 32 * mb + s, acc2out(st), true);
+                }
                 if (a.save_bits) {                                     // one bit per saved activation: (value > 0).  A lane's 16 values MSB first
                     // (bits = 2 bits + carry: a compare and an add-with-carry each); the two lane halves of a sample share a word, half g in
                     // bits 16 g .. 16 g + 15: register r = 4 q + j of half g (feature 32 w + 8 q + 4 g + j) is bit 16 g + 15 - r
@@ -122,6 +124,17 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
             __syncthreads();                                              // every wave has finished reading H (and P)
             NM_TICK(2)
             write_act<4, PREC>(ar, lds, w, 0, g, s);
+            if (SAVE == 2 && F16) {                              // the 16-bit copy IS the operand's hi part: fp16(32 x), clamped, k-slot order
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    const int64_t row = base + 32 * mb + s;
+                    if (row < a.n) {
+                        uint4* o = a.save_h16 + ((int64_t)st * a.n + row) * 32 + 4 * w + g;
+                        o[0] = ar.hi[mb][0];
+                        o[2] = ar.hi[mb][1];
+                    }
+                }
+            }
             if (st == 5 && !a.sigma_only) fill_pe_any<F16>(lds, true, a, base, tid);   // P is free after the skip layer: direction PE -> P[0..3]
             NM_TICK(3)
             __syncthreads();
@@ -177,7 +190,8 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
             NM_TICK(1)
             if (SAVE) {
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb) save_block(a.save_h + (int64_t)8 * a.n * 256, 256, acc[mb], w, base + 32 * mb + s, acc2out(8), false);
+                for (int mb = 0; mb < 4; ++mb)
+                    save_block(SAVE == 2 ? a.save_h : a.save_h + (int64_t)8 * a.n * 256, 256, acc[mb], w, base + 32 * mb + s, acc2out(8), false);
             }
             ActRegs<4> ar;
             convert_act<4, false, PREC>(acc, ar, acc2act(8));
@@ -825,7 +839,7 @@ int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, con
     a.pts = pts; a.dirs = dirs; a.origin = origin; a.direction = direction; a.z = z;
     a.out = out; a.dbg = dbg; a.prof = reinterpret_cast<unsigned long long*>(prof); a.n = n; a.S = S; a.in_mode = in_mode; a.stop_stage = stop_stage; a.sigma_scale = sigma_scale;
     a.sigma_only = L.plain_head ? 2 : ((sigma_only && precision != NM_PREC_I8X3) ? 1 : 0);   // (the i8x3 kernel always evaluates the colour head)
-    a.save_h = L.save_h; a.save_hv = L.save_hv; a.save_bits = L.save_bits;
+    a.save_h = L.save_h; a.save_hv = L.save_hv; a.save_bits = L.save_bits; a.save_h16 = reinterpret_cast<uint4*>(L.save_h16);
     a.pos = PeSpec{L.pe_kind, L.pos_nfreq, L.pos_octaves};
     a.dir = PeSpec{L.pe_kind, L.dir_nfreq, L.dir_octaves};
     const int64_t ntiles = (n + kTileM - 1) / kTileM;
@@ -845,7 +859,8 @@ int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, con
         return check_launch("nerf_mlp_i8w_kernel");
     }
     if (L.save_h) {                                               // the training forward: split fp16, the full head, activations kept
-        hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_FP16X3, false, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+        if (L.save_h16) hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_FP16X3, false, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
+        else hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_FP16X3, false, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
         return check_launch("nerf_mlp_kernel (save)");
     }
     if (prof && precision == NM_PREC_FP16X3)

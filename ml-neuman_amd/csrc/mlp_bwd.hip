@@ -34,7 +34,19 @@ struct BwdArgs {
     float* dz_out;             // [NS][n][256]: stage s's output (HEAD: dZ_7, dZ_6 .. dZ_0; else dZ_6 .. dZ_0)
     float* colsum;             // [tiles][NS][256] per-tile column sums of dz_out[s]
     int64_t n;
+    // 16-bit form (nm_mlp_backward_chain16): dz16 != nullptr replaces dz_out's float32 copies by fp16 of dZ * nm_dz_scale(*amax) in k-slot order
+    // (chunk c, element e <-> feature slot_feature(c, e): the order the lanes hold them, and the saved activations' of nm_mlp_forward_save16);
+    // layers listed in dz32 also keep a float32 copy (natural order) for the products that still want one
+    uint4* dz16;               // [NS][n][32]
+    uint4* dfeat16;            // HEAD, nullable: d_feat the same way, [n][32]
+    const float* amax;
+    float* dz32[8];            // by layer, nullable each
 };
+
+__device__ __forceinline__ unsigned pack_f16(float a, float b, float sc) {
+    f32x2 v = {__builtin_amdgcn_fmed3f(a * sc, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b * sc, -65504.f, 65504.f)};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
 
 template <bool HEAD>
 __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs a) {
@@ -48,6 +60,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
     const int voff = lane * 16;
     auto wo = [](int j, int blk) { return (j + (HEAD ? 0 : 1)) * kBwdStageBytes + blk * 16 * nm::kStepBytes; };
     const int64_t ntiles = (a.n + kTileM - 1) / kTileM;
+    const float sc16 = a.dz16 ? nm_dz_scale(*a.amax) : 1.f;
     WPre W;
     w_prefetch<PREC>(W, wsrc, voff, wo(0, w));
 #pragma unroll 1
@@ -68,6 +81,8 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
             split8<false, false>(v, hi, lo);
             lds[H_BASE + c * kChunkU4 + row] = hi;
             lds[H_BASE + c * kChunkU4 + kLoU4 + row] = lo;
+            if (HEAD && a.dfeat16 && i < a.n)                         // (v[e] = feature slot_feature(c, e): the chunk as it stands)
+                a.dfeat16[i * 32 + c] = make_uint4(pack_f16(v[0], v[1], sc16), pack_f16(v[2], v[3], sc16), pack_f16(v[4], v[5], sc16), pack_f16(v[6], v[7], sc16));
         }
         __syncthreads();
 #pragma unroll 1
@@ -90,7 +105,8 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                     wa[4 * q] = t.x; wa[4 * q + 1] = t.y; wa[4 * q + 2] = t.z; wa[4 * q + 3] = t.w;
                 }
             }
-            float* out = a.dz_out + (int64_t)j * a.n * 256;
+            float* out = a.dz16 ? a.dz32[layer] : a.dz_out + (int64_t)j * a.n * 256;   // (16-bit form: float32 only where asked for)
+            uint4* out16 = a.dz16 ? a.dz16 + (int64_t)j * a.n * 32 : nullptr;
             float cs[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) cs[r] = 0.f;
@@ -105,6 +121,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                     for (int r = 0; r < 16; ++r) acc[mb][r] = fmaf(ds, wa[r], acc[mb][r]);
                 }
                 const unsigned word = (mbits && live) ? mbits[row * 8] >> (16 * g) : 0u;    // bit 15 - (4 q + j) of it: register 4 q + j of this lane
+                unsigned pk[8];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     bool k0, k1, k2, k3;
@@ -120,8 +137,15 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                     v.z = k2 ? v.z : 0.f;
                     v.w = k3 ? v.w : 0.f;
                     acc[mb][4 * q] = v.x; acc[mb][4 * q + 1] = v.y; acc[mb][4 * q + 2] = v.z; acc[mb][4 * q + 3] = v.w;
-                    if (live) *reinterpret_cast<float4*>(out + off + 8 * q) = v;
+                    if (live && out) *reinterpret_cast<float4*>(out + off + 8 * q) = v;
+                    pk[2 * q] = pack_f16(v.x, v.y, sc16);
+                    pk[2 * q + 1] = pack_f16(v.z, v.w, sc16);
                     cs[4 * q] += v.x; cs[4 * q + 1] += v.y; cs[4 * q + 2] += v.z; cs[4 * q + 3] += v.w;
+                }
+                if (live && out16) {                                      // registers 0..7 = chunk 4 w + g, 8..15 = chunk 4 w + 2 + g of the row
+                    uint4* o = out16 + row * 32 + 4 * w + g;
+                    o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    o[2] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
                 }
             }
 #pragma unroll
@@ -192,13 +216,17 @@ namespace nm {
 int64_t mlp_bwd_image_bytes() { return kBwdImageBytes + kBwdPadBytes; }
 
 int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_top, const float* d_feat, const float* d_raw, const float* acts,
-                   const unsigned* relu_bits, int64_t n, float* dz_out, float* colsum, float* gb, hipStream_t stream) {
+                   const unsigned* relu_bits, int64_t n, float* dz_out, float* colsum, float* gb, hipStream_t stream, const Bwd16* h) {
     const bool head = d_feat != nullptr;
     hipLaunchKernelGGL(bwd_pack_kernel, dim3((kBwdSlots * 8 * 16 * 64 + 255) / 256), dim3(256), 0, stream, P, kpe, head ? 1 : 0, image);
     BwdArgs a;
     a.wpack = reinterpret_cast<const uint4*>(image);
     a.dz_top = dz_top; a.d_feat = d_feat; a.d_raw = d_raw; a.w_alpha = P.p[P_ALPHA_W];
     a.acts = acts; a.bits = relu_bits; a.dz_out = dz_out; a.colsum = colsum; a.n = n;
+    a.dz16 = h ? reinterpret_cast<uint4*>(h->dz16) : nullptr;
+    a.dfeat16 = h ? reinterpret_cast<uint4*>(h->dfeat16) : nullptr;
+    a.amax = h ? h->amax : nullptr;
+    for (int i = 0; i < 8; ++i) a.dz32[i] = h ? h->dz32[i] : nullptr;
     const int64_t ntiles = (n + kTileM - 1) / kTileM;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {

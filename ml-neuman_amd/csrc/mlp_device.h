@@ -71,6 +71,8 @@ struct MlpArgs {
     float* save_h;           // SAVE instantiation: [9][n][256] f32 outputs of stages 0..7 (after ReLU) and 8 (feature, linear)
     float* save_hv;          //                     [n][128] f32 output of stage 9 (after ReLU)
     unsigned* save_bits;     //                     nullable: [8][n][8] the signs of stages 0..7: word f >> 5 of (stage, sample); feature 32 w + 8 q + 4 g + j = bit 16 g + 15 - (4 q + j)
+    uint4* save_h16;         //                     nullable: [8][n][32] the outputs of stages 0..7 as fp16 of 32 x value (the hi part the next layer's MFMA reads), k-slot
+                             //                     order (chunk c, element e <-> feature slot_feature(c, e)) INSTEAD of their float32 copies; save_h = [n][256] feature only
 };
 
 // ---- positional encoding feature p of a 3-vector (reference models/vanilla.py:60-92) ---------------

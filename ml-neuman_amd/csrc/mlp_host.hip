@@ -760,14 +760,14 @@ int nm_mlp_forward_save(nm_mlp_t m, const float* pts, const float* dirs, int64_t
     return nm_mlp_forward_save_bits(m, pts, dirs, n, save_h, save_hv, nullptr, out, stream);
 }
 
-int nm_mlp_forward_save_bits(nm_mlp_t m, const float* pts, const float* dirs, int64_t n, float* save_h, float* save_hv, uint32_t* save_bits,
-                             float* out, nm_stream_t stream) {
+static int forward_save_impl(nm_mlp_t m, const float* pts, const float* dirs, int64_t n, float* save_h, float* save_hv, uint32_t* save_bits,
+                             void* save_h16, float* out, nm_stream_t stream) {
     NM_REQUIRE(m, "nm_mlp_forward_save: null handle");
     NM_REQUIRE(!m->desc.plain_head, "nm_mlp_forward_save: the plain-head net has no fused training forward");
     NM_REQUIRE(n >= 0, "nm_mlp_forward_save: negative n");
     if (n == 0) return NM_OK;
     NM_REQUIRE(pts && dirs && save_h && save_hv && out, "nm_mlp_forward_save: null pointer");
-    NM_REQUIRE(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(save_h) | reinterpret_cast<uintptr_t>(save_hv)) & 15) == 0,
+    NM_REQUIRE(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(save_h) | reinterpret_cast<uintptr_t>(save_hv) | reinterpret_cast<uintptr_t>(save_h16)) & 15) == 0,
                "nm_mlp_forward_save: outputs must be 16-byte aligned");
     nm::MlpLaunch L;
     L.wpack = m->d_image;
@@ -780,9 +780,20 @@ int nm_mlp_forward_save_bits(nm_mlp_t m, const float* pts, const float* dirs, in
     L.plain_head = 0;
     L.wstream8 = m->d_stream8;
     L.consts8 = m->d_consts8;
-    L.save_h = save_h; L.save_hv = save_hv; L.save_bits = save_bits;
+    L.save_h = save_h; L.save_hv = save_hv; L.save_bits = save_bits; L.save_h16 = save_h16;
     return nm::launch_mlp_mfma(L, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, NM_PREC_FP16X3, -2, 1.f, out, nullptr, nullptr,
                                nm::as_stream(stream), 0, nullptr);
+}
+
+int nm_mlp_forward_save_bits(nm_mlp_t m, const float* pts, const float* dirs, int64_t n, float* save_h, float* save_hv, uint32_t* save_bits,
+                             float* out, nm_stream_t stream) {
+    return forward_save_impl(m, pts, dirs, n, save_h, save_hv, save_bits, nullptr, out, stream);
+}
+
+int nm_mlp_forward_save16(nm_mlp_t m, const float* pts, const float* dirs, int64_t n, uint16_t* save_h16, float* save_feat, float* save_hv,
+                          uint32_t* save_bits, float* out, nm_stream_t stream) {
+    NM_REQUIRE(n == 0 || (save_h16 && save_bits), "nm_mlp_forward_save16: null pointer");
+    return forward_save_impl(m, pts, dirs, n, save_feat, save_hv, save_bits, save_h16, out, stream);
 }
 
 int64_t nm_mlp_backward_chain_workspace_floats(int64_t n) { return ((n + nm::kTileM - 1) / nm::kTileM) * 8 * 256; }
@@ -809,6 +820,34 @@ int nm_mlp_backward_chain(nm_mlp_t m, const float* const* dev_params, const floa
         if (int rc = nm::check_hip(hipMalloc(&m->d_bwd_image, (size_t)nm::mlp_bwd_image_bytes()), "nm_mlp_backward_chain: hipMalloc")) return rc;
     return nm::launch_mlp_bwd(P, 3 + 6 * m->desc.pos_n_freqs, m->d_bwd_image, dz_top, d_feat, d_raw, acts, relu_bits, n, dz_out, workspace, bias_grads,
                               nm::as_stream(stream));
+}
+
+int nm_mlp_backward_chain16(nm_mlp_t m, const float* const* dev_params, const float* d_feat, const float* d_raw, const uint32_t* relu_bits, int64_t n,
+                            const float* amax, uint16_t* dz16, uint16_t* dfeat16, float* dz32_layer5, float* dz32_layer0, float* bias_grads,
+                            float* workspace, int64_t workspace_floats, nm_stream_t stream) {
+    NM_REQUIRE(m && dev_params, "nm_mlp_backward_chain16: null pointer");
+    NM_REQUIRE(n >= 0, "nm_mlp_backward_chain16: negative n");
+    if (n == 0) return NM_OK;
+    NM_REQUIRE(d_feat && d_raw && relu_bits && amax && dz16 && bias_grads && workspace, "nm_mlp_backward_chain16: null pointer");
+    NM_REQUIRE(!m->desc.plain_head, "nm_mlp_backward_chain16: the plain-head net has no feature layer");
+    NM_REQUIRE(workspace_floats >= nm_mlp_backward_chain_workspace_floats(n), "nm_mlp_backward_chain16: workspace of %lld floats, %lld needed",
+               (long long)workspace_floats, (long long)nm_mlp_backward_chain_workspace_floats(n));
+    NM_REQUIRE(((reinterpret_cast<uintptr_t>(d_feat) | reinterpret_cast<uintptr_t>(d_raw) | reinterpret_cast<uintptr_t>(dz16) | reinterpret_cast<uintptr_t>(dfeat16) |
+                 reinterpret_cast<uintptr_t>(dz32_layer5) | reinterpret_cast<uintptr_t>(dz32_layer0) | reinterpret_cast<uintptr_t>(workspace)) & 15) == 0,
+               "nm_mlp_backward_chain16: buffers must be 16-byte aligned");
+    nm::DevParams P;
+    for (int i = 0; i < 24; ++i) {
+        NM_REQUIRE(dev_params[i], "nm_mlp_backward_chain16: dev_params[%d] is null", i);
+        P.p[i] = dev_params[i];
+    }
+    if (!m->d_bwd_image)
+        if (int rc = nm::check_hip(hipMalloc(&m->d_bwd_image, (size_t)nm::mlp_bwd_image_bytes()), "nm_mlp_backward_chain16: hipMalloc")) return rc;
+    nm::Bwd16 h;
+    h.dz16 = dz16; h.dfeat16 = dfeat16; h.amax = amax;
+    for (int i = 0; i < 8; ++i) h.dz32[i] = nullptr;
+    h.dz32[5] = dz32_layer5; h.dz32[0] = dz32_layer0;
+    return nm::launch_mlp_bwd(P, 3 + 6 * m->desc.pos_n_freqs, m->d_bwd_image, nullptr, d_feat, d_raw, nullptr, relu_bits, n, nullptr, workspace, bias_grads,
+                              nm::as_stream(stream), &h);
 }
 
 int nm_mlp_forward_rays(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals, int64_t R, int S,

@@ -21,6 +21,7 @@ struct MlpLaunch {
     float* save_h = nullptr;                      // nm_mlp_forward_save (NM_PREC_FP16X3): [9][n][256] post-activation outputs of layers 0..7, then feature
     float* save_hv = nullptr;                     //   and [n][128] of the views layer: what a training step's backward pass reads
     unsigned* save_bits = nullptr;                //   nullable: [8][n][8] one bit per trunk activation (> 0): what nm_mlp_backward_chain masks with
+    void* save_h16 = nullptr;                     //   nullable: [8][n][256] fp16 trunk activations (x 32, k-slot order) instead of float32; save_h is then [n][256]: feature only
 };
 struct RefLaunch {
     const float* wt; const float* bias; int off[12]; int boff[12]; const float* petab;
@@ -55,8 +56,13 @@ int launch_sigma_f16t(const MlpLaunch& L, const void* stream16t, int stream_ndir
 // first stage forms dZ_7 from d_feat and d_raw's sigma column itself, NS = 8 -> dz_out [8][n][256] = dZ_7 .. dZ_0.  colsum [tiles][NS][256]
 // scratch, gb [NS][256] = the column sums (bias gradients)
 int64_t mlp_bwd_image_bytes();
+// h != nullptr: the 16-bit form -- dz16 [NS][n][256] fp16 of dZ * nm_dz_scale(*amax) in k-slot order instead of dz_out, dfeat16 (nullable) d_feat the
+// same way, dz32[layer] (nullable each) float32 copies of single layers
+struct Bwd16 {
+    void* dz16; void* dfeat16; const float* amax; float* dz32[8];
+};
 int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_top, const float* d_feat, const float* d_raw, const float* acts,
-                   const unsigned* relu_bits, int64_t n, float* dz_out, float* colsum, float* gb, hipStream_t stream);
+                   const unsigned* relu_bits, int64_t n, float* dz_out, float* colsum, float* gb, hipStream_t stream, const Bwd16* h = nullptr);
 int launch_mlp_ref(const RefLaunch& L, const float* pts, const float* dirs, const float* origin, const float* direction,
                    const float* z, int64_t n, int S, int in_mode, int stop_stage, float sigma_scale, float* out, float* dbg,
                    hipStream_t stream);

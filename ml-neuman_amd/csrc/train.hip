@@ -462,6 +462,161 @@ __host__ inline bool wgrad256_ok(int mode, int a_kmajor, int b_kmajor, int M, in
     return mode != 0 && a_kmajor && b_kmajor && M == 256 && N == 256 && K >= 16384 && !(flags & ~NM_GEMM_ACCUMULATE);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// 16-bit operands (round 5): backward-weights of the 256-wide layers from the fp16 copies the fused forward / backward-data chain keep
+// (nm_mlp_forward_save16: 32 x activation; nm_mlp_backward_chain16: dZ x nm_dz_scale(amax); both [n][256] in k-slot order) -- 1 KB per
+// sample and product instead of 2 KB, ONE MFMA per product instead of three, no conversions.  Rounding: 2^-12 relative per element,
+// independent from sample to sample, under a sum over >= 32 k samples.
+//
+// One 256 x 256 tile per workgroup (8 waves of 128 x 64, as wgrad256_kernel), a contiguous range of samples per workgroup, a step = 64
+// samples: thread (operand, octet o, chunk c) loads chunk c (8 features, 16 B) of the 8 samples of octet o -- a wave instruction reads two
+// whole 512-byte rows --, transposes the 8 x 8 halves in registers and writes 8 fragments "8 samples of one feature" (the MFMA operand
+// of a product whose K runs over samples) to T[operand][octet][position e 32 + c]: conflict-free both ways.  The accumulators' rows /
+// columns are those positions; wgrad16_reduce_kernel sums the splits in order, scales by 1 / (32 s) and stores to the natural [out][in].
+struct Wgrad16Args {
+    const uint4* P[8]; const uint4* Q[8];       // per product: dZ16 [n][32] uint4 rows; activation16 [n][NQ / 8] uint4 rows
+    float* C[8]; int ldc[8];                    // per product: the [256][ncols] gradient (row stride ldc)
+    float* partial;                             // [nprod][nsplit][256][NQ]
+    const float* amax;                          // the device scalar dZ16's scale derives from (nm_dz_scale)
+    int64_t n;
+    int k_per_split, nsplit, ncols;             // ncols <= NQ columns are stored
+};
+
+// NQ = 256: the hidden operand of a layer (k-slot order); NQ = 64: the encoded input (natural order, 63 + a zero column), fp16 of 32 x value too
+template <int NQ>
+__global__ __launch_bounds__(512, 2) void wgrad256h_kernel(const Wgrad16Args g) {
+    constexpr int QC = NQ / 8;                                      // 16-byte chunks per Q row
+    constexpr int MI = NQ == 256 ? 4 : 1;                           // 32-row blocks per wave: 8 waves = 2 x 4 of 128 x 64, or 8 x 1 of 32 x 64
+    __shared__ uint4 T[2][8][256];                                  // (Q: the first NQ positions of a row)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int prod = blockIdx.y;
+    const int op = tid >> 8;
+    const int c = op ? (tid & (QC - 1)) : (tid & 31);
+    const int o = op ? (((tid & 255) / QC) & 7) : ((tid >> 5) & 7);
+    const bool loader = !op || (tid & 255) < 8 * QC;
+    const int rowlen = op ? QC : 32;
+    const uint4* __restrict__ src = op ? g.Q[prod] : g.P[prod];
+    const int64_t kbeg = (int64_t)blockIdx.x * g.k_per_split;
+    const int64_t kend = kbeg + g.k_per_split < g.n ? kbeg + g.k_per_split : g.n;
+    const int wm = NQ == 256 ? (w >> 2) * 128 : w * 32, wn = NQ == 256 ? (w & 3) * 64 : 0;
+    floatx16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    unsigned r[8][4];
+    auto load = [&](int64_t k0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t k = k0 + 8 * o + j;
+            uint4 t = make_uint4(0u, 0u, 0u, 0u);
+            if (loader && k < kend) t = src[k * rowlen + c];
+            r[j][0] = t.x; r[j][1] = t.y; r[j][2] = t.z; r[j][3] = t.w;
+        }
+    };
+    if (kbeg < kend) load(kbeg);
+    for (int64_t k0 = kbeg; k0 < kend; k0 += 64) {
+        __syncthreads();                                               // the previous step's fragments have been read
+        if (loader) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {                               // element e of the chunk, samples 0..7 -> one fragment
+                unsigned q[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const unsigned a = r[2 * m][e >> 1], b = r[2 * m + 1][e >> 1];
+                    q[m] = (e & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
+                }
+                T[op][o][e * rowlen + c] = make_uint4(q[0], q[1], q[2], q[3]);
+            }
+        }
+        __syncthreads();
+        if (k0 + 64 < kend) load(k0 + 64);                             // the next step's loads fly during this step's MFMAs
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int oct = 2 * s + (lane >> 5), cc = lane & 31;
+            f16x8 a[MI], b[2];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a[i] = __builtin_bit_cast(f16x8, T[0][oct][wm + 32 * i + cc]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = __builtin_bit_cast(f16x8, T[1][oct][wn + 32 * j + cc]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    float* P = g.partial + ((int64_t)prod * g.nsplit + blockIdx.x) * (256 * NQ);
+    const int gq = lane >> 5, cc = lane & 31;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) P[(wm + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * gq) * NQ + wn + 32 * j + cc] = acc[i][j][v];
+}
+
+// position p = e 32 + c of a fragment row / column -> the feature it is (k-slot (chunk c, element e) of mlp_layout.h)
+__device__ __forceinline__ int pos_feature(int p) {
+    const int c = p & 31, e = p >> 5;
+    return 32 * (c >> 2) + 8 * (2 * ((c >> 1) & 1) + (e >> 2)) + 4 * (c & 1) + (e & 3);
+}
+template <int NQ>
+__global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const Wgrad16Args g) {
+    const int prod = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;                          // (row position, column position): coalesced reads of the partials
+    const float* part = g.partial + (int64_t)prod * g.nsplit * (256 * NQ) + i;
+    float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                 // eight interleaved partial sums, combined in a fixed order (as splitk_reduce_kernel)
+    int z = 0;
+    for (; z + 8 <= g.nsplit; z += 8)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) p[k] += part[(int64_t)(z + k) * (256 * NQ)];
+    for (int k = 0; z < g.nsplit; ++z, ++k) p[k] += part[(int64_t)z * (256 * NQ)];
+    const float sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+    const float inv = 1.f / (nm_dz_scale(*g.amax) * kNmAct16Scale);        // (a power of two: exact)
+    const int pc = i % NQ;
+    const int col = NQ == 256 ? pos_feature(pc) : 8 * (pc % (NQ / 8)) + pc / (NQ / 8);     // (natural-order operand: position e (NQ / 8) + c = column 8 c + e)
+    if (col < g.ncols) g.C[prod][(int64_t)pos_feature(i / NQ) * g.ldc[prod] + col] = sum * inv;
+}
+
+// alpha_linear's weight gradient: out[f] = sum_n d_raw[n][3] H7[n][f] from the fp16 copy (k-slot order, x 32): a thread owns two slots of a
+// band of rows; the bands are summed in order by splitk_reduce_kernel
+constexpr int kAlphaRows = 512;
+__global__ __launch_bounds__(256) void wgrad_alpha16_kernel(const float* __restrict__ d_raw, const unsigned* __restrict__ h16, int64_t n, float* __restrict__ partial) {
+    const int t = threadIdx.x & 127, half = threadIdx.x >> 7;               // slots 2 t, 2 t + 1; rows of parity `half`
+    const int64_t r0 = (int64_t)blockIdx.x * kAlphaRows, r1 = r0 + kAlphaRows < n ? r0 + kAlphaRows : n;
+    float a0 = 0.f, a1 = 0.f;
+    for (int64_t k = r0 + half; k < r1; k += 2) {
+        const unsigned v = h16[k * 128 + t];
+        const float ds = d_raw[k * 4 + 3];
+        a0 = fmaf(ds, (float)__builtin_bit_cast(_Float16, (unsigned short)(v & 0xffffu)), a0);
+        a1 = fmaf(ds, (float)__builtin_bit_cast(_Float16, (unsigned short)(v >> 16)), a1);
+    }
+    __shared__ float sh[2][256];
+    sh[half][2 * t] = a0;
+    sh[half][2 * t + 1] = a1;
+    __syncthreads();
+    if (threadIdx.x < 256) {                                            // slot p = 8 c + e -> feature; x 1/32
+        const int p = threadIdx.x, c = p >> 3, e = p & 7;
+        const int f = 32 * (c >> 2) + 8 * (2 * ((c >> 1) & 1) + (e >> 2)) + 4 * (c & 1) + (e & 3);
+        partial[(int64_t)blockIdx.x * 256 + f] = (sh[0][p] + sh[1][p]) * (1.f / kNmAct16Scale);
+    }
+}
+
+// largest magnitude of x[0 .. count): *out = max(*out, ...) (bit pattern of a non-negative float: unsigned order = float order)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t count, unsigned* __restrict__ out) {
+    float m = 0.f;
+    const int64_t n4 = count >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+
 // second pass of split-K: C (+)= sum over the splits, in split order
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int splits, int M, int N, float* __restrict__ C, int ldc,
                                                             int accumulate) {
@@ -519,6 +674,7 @@ int pick_splits(int M, int N, int K) {
 
 // [x, sin(f0 x), cos(f0 x), sin(f1 x), ...] (posenc, models/vanilla.py:60-79) or [x, sin(x B^T), cos(x B^T)] (rotate, :83-89),
 // then zeros up to `ld`.  One thread per output element.
+template <bool HALF>                                                    // HALF: out is fp16 of 32 x value (the operand of nm_wgrad16)
 __global__ __launch_bounds__(256) void pe_encode_kernel(const float* __restrict__ x, int64_t n, int D, int kind, int nfreq,
                                                         const float* __restrict__ tab, float* __restrict__ out, int ld) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -542,7 +698,8 @@ __global__ __launch_bounds__(256) void pe_encode_kernel(const float* __restrict_
             v = is_cos ? cosf(a) : sinf(a);
         }
     }
-    out[i] = v;
+    if (HALF) reinterpret_cast<_Float16*>(out)[i] = (_Float16)(v * kNmAct16Scale);
+    else out[i] = v;
 }
 
 // adjoint of pe_encode_kernel: dx [n,3] from the gradient g [n,ld] of the encoded features, one thread per row
@@ -825,6 +982,73 @@ int nm_gemm_fp16x3(int a_kmajor, int b_kmajor, int M, int N, int K, const float*
     return gemm_dispatch(2, a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, bias, mask, ldmask, flags, workspace, workspace_floats, stream);
 }
 
+int nm_absmax(const float* x, int64_t count, float* out_max, nm_stream_t stream) {
+    NM_REQUIRE(count >= 0 && out_max, "nm_absmax: bad arguments");
+    if (count == 0) return NM_OK;
+    NM_REQUIRE(x && ((uintptr_t)x & 15) == 0, "nm_absmax: x must be a 16-byte aligned device array");
+    int64_t blocks = (count / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, nm::as_stream(stream), x, count, reinterpret_cast<unsigned*>(out_max));
+    return nm::check_launch("absmax_kernel");
+}
+
+static void wgrad16_split(int nprod, int64_t n, int& k_per_split, int& nsplit) {
+    int want = 1024 / (nprod < 1 ? 1 : nprod);                            // ~1024 workgroups over all products: four rounds of the chip, few partials
+    if (want < 64) want = 64;
+    if (want > 256) want = 256;
+    int64_t per = ((n + want - 1) / want + 63) / 64 * 64;
+    if (per < 64) per = 64;
+    k_per_split = (int)per;
+    nsplit = (int)((n + per - 1) / per);
+}
+int64_t nm_wgrad16_workspace_floats(int nprod, int64_t n, int q_cols) {
+    int k, s;
+    wgrad16_split(nprod, n, k, s);
+    return (int64_t)nprod * s * 256 * (q_cols > 64 ? 256 : 64);
+}
+int nm_wgrad16(int nprod, int q_cols, const uint16_t* const* dz16, const uint16_t* const* act16, float* const* dW, const int* ldw, int64_t n, const float* amax,
+               float* workspace, int64_t workspace_floats, nm_stream_t stream) {
+    NM_REQUIRE(nprod >= 1 && nprod <= 8 && n >= 1 && n < ((int64_t)1 << 31), "nm_wgrad16: nprod %d (1..8), n %lld", nprod, (long long)n);
+    NM_REQUIRE(q_cols == 256 || (q_cols >= 1 && q_cols <= 64), "nm_wgrad16: q_cols %d (256: a hidden operand; <= 64: an encoded input in rows of 64)", q_cols);
+    NM_REQUIRE(dz16 && act16 && dW && ldw && amax && workspace, "nm_wgrad16: null pointer");
+    const int NQ = q_cols == 256 ? 256 : 64;
+    Wgrad16Args g;
+    for (int i = 0; i < 8; ++i) { g.P[i] = nullptr; g.Q[i] = nullptr; g.C[i] = nullptr; g.ldc[i] = 0; }
+    for (int i = 0; i < nprod; ++i) {
+        NM_REQUIRE(dz16[i] && act16[i] && dW[i] && ldw[i] >= q_cols, "nm_wgrad16: product %d: null pointer or ldw < q_cols", i);
+        NM_REQUIRE((((uintptr_t)dz16[i] | (uintptr_t)act16[i]) & 15) == 0, "nm_wgrad16: operands must be 16-byte aligned");
+        g.P[i] = reinterpret_cast<const uint4*>(dz16[i]); g.Q[i] = reinterpret_cast<const uint4*>(act16[i]); g.C[i] = dW[i]; g.ldc[i] = ldw[i];
+    }
+    wgrad16_split(nprod, n, g.k_per_split, g.nsplit);
+    NM_REQUIRE(workspace_floats >= (int64_t)nprod * g.nsplit * 256 * NQ, "nm_wgrad16: needs %lld floats of workspace (nm_wgrad16_workspace_floats)",
+               (long long)nprod * g.nsplit * 256 * NQ);
+    g.partial = workspace; g.amax = amax; g.n = n; g.ncols = q_cols;
+    hipStream_t st = nm::as_stream(stream);
+    if (NQ == 256) {
+        hipLaunchKernelGGL(wgrad256h_kernel<256>, dim3(g.nsplit, nprod), dim3(512), 0, st, g);
+        if (int rc = nm::check_launch("wgrad256h_kernel")) return rc;
+        hipLaunchKernelGGL(wgrad16_reduce_kernel<256>, dim3(256, nprod), dim3(256), 0, st, g);
+    } else {
+        hipLaunchKernelGGL(wgrad256h_kernel<64>, dim3(g.nsplit, nprod), dim3(512), 0, st, g);
+        if (int rc = nm::check_launch("wgrad256h_kernel")) return rc;
+        hipLaunchKernelGGL(wgrad16_reduce_kernel<64>, dim3(64, nprod), dim3(256), 0, st, g);
+    }
+    return nm::check_launch("wgrad16_reduce_kernel");
+}
+
+int64_t nm_wgrad_alpha16_workspace_floats(int64_t n) { return ((n + kAlphaRows - 1) / kAlphaRows) * 256; }
+int nm_wgrad_alpha16(const float* d_raw, const uint16_t* h16, int64_t n, float* out, float* workspace, int64_t workspace_floats, nm_stream_t stream) {
+    NM_REQUIRE(n >= 1 && d_raw && h16 && out && workspace, "nm_wgrad_alpha16: bad arguments");
+    const int bands = (int)((n + kAlphaRows - 1) / kAlphaRows);
+    NM_REQUIRE(workspace_floats >= (int64_t)bands * 256, "nm_wgrad_alpha16: needs %lld floats of workspace", (long long)bands * 256);
+    hipStream_t st = nm::as_stream(stream);
+    hipLaunchKernelGGL(wgrad_alpha16_kernel, dim3(bands), dim3(256), 0, st, d_raw, reinterpret_cast<const unsigned*>(h16), n, workspace);
+    if (int rc = nm::check_launch("wgrad_alpha16_kernel")) return rc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(1), dim3(256), 0, st, workspace, bands, 1, 256, out, 256, 0);
+    return nm::check_launch("splitk_reduce_kernel");
+}
+
 int64_t nm_colsum_workspace_floats(int64_t n, int W) { return ((n + kColsumRows - 1) / kColsumRows) * W; }
 
 int nm_colsum(const float* X, int64_t n, int W, int ld, float* out, float* workspace, int64_t workspace_floats, nm_stream_t stream) {
@@ -848,7 +1072,19 @@ int nm_pe_encode(const float* x, int64_t n, int dims, int kind, int n_freqs, con
     if (n == 0) return NM_OK;
     NM_REQUIRE(x && out && (table || n_freqs == 0), "nm_pe_encode: null pointer");
     const int64_t total = n * ld;
-    hipLaunchKernelGGL(pe_encode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nm::as_stream(stream), x, n, dims, kind, n_freqs, table, out, ld);
+    hipLaunchKernelGGL(pe_encode_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nm::as_stream(stream), x, n, dims, kind, n_freqs, table, out, ld);
+    return nm::check_launch("pe_encode_kernel");
+}
+
+int nm_pe_encode16(const float* x, int64_t n, int dims, int kind, int n_freqs, const float* table, uint16_t* out, int ld, nm_stream_t stream) {
+    NM_REQUIRE(dims == 3 || (dims == 4 && kind == NM_PE_POSENC), "nm_pe_encode16: dims %d (3, or 4 with the posenc mapping)", dims);
+    NM_REQUIRE(n >= 0 && n_freqs >= 0 && ld >= dims + 2 * dims * n_freqs, "nm_pe_encode16: bad sizes n=%lld n_freqs=%d ld=%d", (long long)n, n_freqs, ld);
+    NM_REQUIRE(kind == NM_PE_POSENC || kind == NM_PE_ROTATE, "nm_pe_encode16: mapping %d", kind);
+    if (n == 0) return NM_OK;
+    NM_REQUIRE(x && out && (table || n_freqs == 0), "nm_pe_encode16: null pointer");
+    const int64_t total = n * ld;
+    hipLaunchKernelGGL(pe_encode_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nm::as_stream(stream), x, n, dims, kind, n_freqs, table,
+                       reinterpret_cast<float*>(out), ld);
     return nm::check_launch("pe_encode_kernel");
 }
 

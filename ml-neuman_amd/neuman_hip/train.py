@@ -12,6 +12,7 @@ products into one output.  Gradients reach the parameters and, when asked for, t
 (what the human trainer's pose / offset optimisation differentiates: the differentiable warp, the offset nets and the skinning
 upstream of them are neuman_hip.ray_utils.warp_samples_to_canonical_diff, OffsetNet and smpl.SMPLDiff).
 """
+import ctypes
 import os
 
 import torch
@@ -35,6 +36,13 @@ FUSED_FORWARD = os.environ.get('NEUMAN_TRAIN_FUSED', '1') != '0'
 # ... and the backward-data chain of its trunk in one kernel as well (nm_mlp_backward_chain: dZ of a tile stays on chip from layer 7 to layer 0,
 # bias gradients out of the same pass); the weight-gradient products stay per layer.  NEUMAN_TRAIN_FUSED_BWD=0: the GEMM chain.
 FUSED_BACKWARD = os.environ.get('NEUMAN_TRAIN_FUSED_BWD', '1') != '0'
+# ... and what the two keep between them as fp16 instead of float32 wherever it is only an operand of a weight-gradient product (the trunk's
+# activations: nm_mlp_forward_save16; dZ of every layer: nm_mlp_backward_chain16; the encoded position: nm_pe_encode16), consumed by nm_wgrad16 --
+# half the bytes of the HBM-bound kernels of an iteration, one MFMA per product instead of three.  The 2^-12 roundings of independent samples
+# average out under the sum over the batch, so the form is taken from STORE16_MIN_ROWS samples on (the trainers' batches are 10^5 .. 10^6);
+# smaller calls keep the float32 copies.  NEUMAN_TRAIN_STORE16=0: float32 copies always.
+STORE16 = os.environ.get('NEUMAN_TRAIN_STORE16', '1') != '0'
+STORE16_MIN_ROWS = int(os.environ.get('NEUMAN_TRAIN_STORE16_MIN', '32768'))
 
 
 def _gemm(a_kmajor, b_kmajor, M, N, K, A, lda, B, ldb, C, ldc, bias=None, mask=None, ldmask=0, flags=0, ws=None, precision=None):
@@ -101,6 +109,16 @@ def _encode(emb, x, ld):
     return out
 
 
+def _encode16(emb, x, ld=64):
+    """the encoding as fp16 of 32 x value, rows of `ld` (an operand of nm_wgrad16)"""
+    dev = x.device
+    tab = torch.from_numpy(emb.table()).to(dev).contiguous()
+    out = torch.empty((x.shape[0], ld), device=dev, dtype=torch.float16)
+    _lib.check(_lib.lib().nm_pe_encode16(_lib.dev_ptr(x), x.shape[0], x.shape[1], PE_KINDS[emb.mapping], emb.N_freqs, _lib.dev_ptr(tab),
+                                         ctypes.c_void_p(out.data_ptr()), ld, _lib.stream_ptr()), "nm_pe_encode16")
+    return out
+
+
 def _encode_backward(emb, x, g):
     dev = x.device
     tab = torch.from_numpy(emb.table()).to(dev).contiguous()
@@ -138,25 +156,37 @@ class _MLP(torch.autograd.Function):
         pk = _Packed(nerf, net.pos_pe.out_dim, net.dir_pe.out_dim if views else 0)
         p4 = _pad4(pts)
         n4 = p4.shape[0]
-        X0 = _encode(net.pos_pe, p4, pk.kp)
-        if _fused_ok(net) and dirs is not None:
-            import ctypes
+        fused = _fused_ok(net) and dirs is not None
+        use16 = fused and STORE16 and FUSED_BACKWARD and n4 >= STORE16_MIN_ROWS and pk.kp <= 64
+        X0 = None if use16 else _encode(net.pos_pe, p4, pk.kp)
+        if fused:
             d4 = _pad4(dirs)
             D0 = _encode(net.dir_pe, d4, pk.kd)
             handle = net.train_handle()
-            ptrs = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in nerf.ordered_params()])
+            plist = nerf.ordered_params()
+            ptrs = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in plist])
             _lib.check(_lib.lib().nm_mlp_refresh_f16(handle, ptrs, _lib.stream_ptr()), "nm_mlp_refresh_f16")
-            acts = torch.empty((9, n4, width), device=dev, dtype=torch.float32)
             hv = torch.empty((n4, half), device=dev, dtype=torch.float32)
             raw = torch.empty((n4, 4), device=dev, dtype=torch.float32)
             bits = torch.empty((8, n4, 8), device=dev, dtype=torch.int32) if FUSED_BACKWARD else None     # (what the backward-data chain masks with)
-            _lib.check(_lib.lib().nm_mlp_forward_save_bits(handle, _lib.dev_ptr(p4), _lib.dev_ptr(d4), n4, _lib.dev_ptr(acts), _lib.dev_ptr(hv),
-                                                           ctypes.c_void_p(bits.data_ptr() if bits is not None else 0), _lib.dev_ptr(raw),
-                                                           _lib.stream_ptr()), "nm_mlp_forward_save_bits")
-            H, feat = [acts[i] for i in range(8)], acts[8]
+            ctx.h16 = ctx.x0h = None
+            if use16:
+                h16 = torch.empty((8, n4, width), device=dev, dtype=torch.float16)
+                feat = torch.empty((n4, width), device=dev, dtype=torch.float32)
+                _lib.check(_lib.lib().nm_mlp_forward_save16(handle, _lib.dev_ptr(p4), _lib.dev_ptr(d4), n4, ctypes.c_void_p(h16.data_ptr()), _lib.dev_ptr(feat),
+                                                            _lib.dev_ptr(hv), ctypes.c_void_p(bits.data_ptr()), _lib.dev_ptr(raw), _lib.stream_ptr()),
+                           "nm_mlp_forward_save16")
+                ctx.h16, ctx.x0h, acts, H = h16, _encode16(net.pos_pe, p4), None, None
+            else:
+                acts = torch.empty((9, n4, width), device=dev, dtype=torch.float32)
+                _lib.check(_lib.lib().nm_mlp_forward_save_bits(handle, _lib.dev_ptr(p4), _lib.dev_ptr(d4), n4, _lib.dev_ptr(acts), _lib.dev_ptr(hv),
+                                                               ctypes.c_void_p(bits.data_ptr() if bits is not None else 0), _lib.dev_ptr(raw),
+                                                               _lib.stream_ptr()), "nm_mlp_forward_save_bits")
+                H, feat = [acts[i] for i in range(8)], acts[8]
             ctx.pk, ctx.X0, ctx.D0, ctx.H, ctx.feat, ctx.hv, ctx.n, ctx.net = pk, X0, D0, H, feat, hv, n, net
             ctx.p4, ctx.d4 = p4, d4
             ctx.acts, ctx.bits = acts, bits
+            ctx.versions = [p._version for p in plist]          # the backward pass repacks W^T from the live parameters: they must still be these
             return raw[:n]
         H = []
         h, kh = X0, pk.kp
@@ -185,6 +215,7 @@ class _MLP(torch.autograd.Function):
             _gemm(0, 0, n4, 4, width, h, width, pk.Wo4, width, raw, 4, bias=pk.bo4, flags=BIAS)
         ctx.pk, ctx.X0, ctx.D0, ctx.H, ctx.feat, ctx.hv, ctx.n, ctx.net = pk, X0, D0, H, feat, hv, n, net
         ctx.p4, ctx.d4 = p4, d4
+        ctx.h16 = ctx.x0h = ctx.versions = None
         return raw[:n] if views else raw[:n, :pk.n_out]
 
     @staticmethod
@@ -193,8 +224,15 @@ class _MLP(torch.autograd.Function):
         nerf = net.nerf
         views = nerf.use_viewdirs
         want_in = ctx.needs_input_grad[1] or (views and ctx.needs_input_grad[2])
-        dev = X0.device
-        n4, width, half = X0.shape[0], nerf.width, nerf.width // 2
+        dev = ctx.p4.device
+        n4, width, half = ctx.p4.shape[0], nerf.width, nerf.width // 2
+        if getattr(ctx, 'versions', None) is not None and (FUSED_BACKWARD or ctx.h16 is not None):
+            # nm_mlp_backward_chain repacks W^T from the LIVE parameters while the masks and the weight-gradient operands are the forward's:
+            # an in-place edit between the two passes would make the halves disagree silently
+            now = [p._version for p in nerf.ordered_params()]
+            if now != ctx.versions:
+                raise _lib.NeumanHipError("a parameter of the net was modified in place between the forward and the backward pass of a training step "
+                                          "(the fused backward reads the live weights): run backward before optimizer.step() / weight edits")
         d_raw = torch.zeros((n4, 4), device=dev, dtype=torch.float32)
         d_raw[:n, :g_raw.shape[1]] = g_raw
         ws = [torch.empty(4, device=dev, dtype=torch.float32)]
@@ -231,10 +269,11 @@ class _MLP(torch.autograd.Function):
                                             _lib.stream_ptr()), "nm_colsum")
             return out
 
-        h7 = H[-1]
+        use16 = getattr(ctx, 'h16', None) is not None
+        h7 = None if use16 else H[-1]
         dX0 = dD0 = None
-        dz = torch.empty((n4, width), device=dev, dtype=torch.float32)
-        use_chain = FUSED_BACKWARD and getattr(ctx, 'acts', None) is not None and len(pk.W) == 8 and width == 256
+        dz = None if use16 else torch.empty((n4, width), device=dev, dtype=torch.float32)
+        use_chain = use16 or (FUSED_BACKWARD and getattr(ctx, 'acts', None) is not None and len(pk.W) == 8 and width == 256)
         d_feat = None
         if views:
             g = {}
@@ -250,8 +289,12 @@ class _MLP(torch.autograd.Function):
             d_feat = torch.empty((n4, width), device=dev, dtype=torch.float32)
             _gemm(0, 1, n4, width, half, d_hv, half, pk.Wv[0], width, d_feat, width, flags=COLSUM, ws=cs_buf)
             g['feature_b'] = band_sum(width)
-            g['feature_w'] = wgrad(d_feat, width, h7, width)
-            g['alpha_w'] = wgrad(d_raw, 4, h7, width)[3:4]
+            if use16:                                                            # (both from the fp16 copy of H_7, below)
+                g['feature_w'] = torch.empty((width, width), device=dev, dtype=torch.float32)
+                g['alpha_w'] = torch.empty((1, width), device=dev, dtype=torch.float32)
+            else:
+                g['feature_w'] = wgrad(d_feat, width, h7, width)
+                g['alpha_w'] = wgrad(d_raw, 4, h7, width)[3:4]
             if not use_chain:                                                   # (the chain kernel's first stage forms dZ_7 itself)
                 _gemm(0, 1, n4, width, width, d_feat, width, pk.Wf, width, dz, width)
                 _gemm(0, 1, n4, width, 4, d_raw, 4, pk.Wa4, width, dz, width, mask=h7, ldmask=width, flags=ACC | MASK | COLSUM, ws=cs_buf)
@@ -262,7 +305,57 @@ class _MLP(torch.autograd.Function):
             _gemm(0, 1, n4, width, 4, d_raw, 4, pk.Wo4, width, dz, width, mask=h7, ldmask=width, flags=MASK | COLSUM, ws=cs_buf)
         gw, gb = [None] * len(pk.W), [None] * len(pk.W)
         chain = None
-        if use_chain:
+        if use16:
+            lib = _lib.lib()
+            h16, x0h, n_pos = ctx.h16, ctx.x0h, pk.n_pos
+            amax = torch.zeros(1, device=dev, dtype=torch.float32)             # largest magnitude entering the chain -> the scale of the fp16 copies
+            _lib.check(lib.nm_absmax(_lib.dev_ptr(d_feat), d_feat.numel(), _lib.dev_ptr(amax), _lib.stream_ptr()), "nm_absmax")
+            _lib.check(lib.nm_absmax(_lib.dev_ptr(d_raw), d_raw.numel(), _lib.dev_ptr(amax), _lib.stream_ptr()), "nm_absmax")
+            dz16 = torch.empty((8, n4, width), device=dev, dtype=torch.float16)  # dZ_7 .. dZ_0 (x scale, k-slot order)
+            dfeat16 = torch.empty((n4, width), device=dev, dtype=torch.float16)
+            dz32 = torch.empty((2, n4, width), device=dev, dtype=torch.float32) if want_in else None     # layers 5, 0: the input gradient's products
+            gbs = torch.empty((8, width), device=dev, dtype=torch.float32)
+            need = int(lib.nm_mlp_backward_chain_workspace_floats(n4))
+            if need > ws[0].numel():
+                ws[0] = torch.empty(need, device=dev, dtype=torch.float32)
+            ptrs = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in nerf.ordered_params()])
+            _lib.check(lib.nm_mlp_backward_chain16(net.train_handle(), ptrs, _lib.dev_ptr(d_feat), _lib.dev_ptr(d_raw), ctypes.c_void_p(ctx.bits.data_ptr()), n4,
+                                                   _lib.dev_ptr(amax), ctypes.c_void_p(dz16.data_ptr()), ctypes.c_void_p(dfeat16.data_ptr()),
+                                                   _lib.dev_ptr(dz32[0] if want_in else None), _lib.dev_ptr(dz32[1] if want_in else None), _lib.dev_ptr(gbs),
+                                                   _lib.dev_ptr(ws[0]), ws[0].numel(), _lib.stream_ptr()), "nm_mlp_backward_chain16")
+            for i in range(8):
+                gb[i] = gbs[7 - i]
+                gw[i] = torch.empty((width, (n_pos if i == 0 else width) + (n_pos if len(pk.W[i]) == 2 else 0)), device=dev, dtype=torch.float32)
+
+            def products(q_cols, items):                                         # items: (dz16 rows, activation rows, gradient, column offset)
+                k = len(items)
+                P = (ctypes.c_void_p * k)(*[a.data_ptr() for a, _, _, _ in items])
+                Q = (ctypes.c_void_p * k)(*[b.data_ptr() for _, b, _, _ in items])
+                C = (ctypes.c_void_p * k)(*[c.data_ptr() + 4 * off for _, _, c, off in items])
+                L = (ctypes.c_int * k)(*[c.shape[1] for _, _, c, _ in items])
+                need = int(lib.nm_wgrad16_workspace_floats(k, n4, q_cols))
+                if need > ws[0].numel():
+                    ws[0] = torch.empty(need, device=dev, dtype=torch.float32)
+                _lib.check(lib.nm_wgrad16(k, q_cols, P, Q, C, L, n4, _lib.dev_ptr(amax), _lib.dev_ptr(ws[0]), ws[0].numel(), _lib.stream_ptr()), "nm_wgrad16")
+
+            # the eight 256 x 256 products of the net in one launch: feature_linear, then the hidden columns of layers 7 .. 1
+            products(width, [(dfeat16, h16[7], g['feature_w'], 0)] +
+                     [(dz16[7 - i], h16[i - 1], gw[i], n_pos if len(pk.W[i]) == 2 else 0) for i in range(7, 0, -1)])
+            # ... and the encoded-position columns of layer 0 and of the skip layer in another
+            products(n_pos, [(dz16[7 - i], x0h, gw[i], 0) for i in range(8) if i == 0 or len(pk.W[i]) == 2])
+            need = int(lib.nm_wgrad_alpha16_workspace_floats(n4))
+            if need > ws[0].numel():
+                ws[0] = torch.empty(need, device=dev, dtype=torch.float32)
+            _lib.check(lib.nm_wgrad_alpha16(_lib.dev_ptr(d_raw), ctypes.c_void_p(h16[7].data_ptr()), n4, _lib.dev_ptr(g['alpha_w']), _lib.dev_ptr(ws[0]),
+                                            ws[0].numel(), _lib.stream_ptr()), "nm_wgrad_alpha16")
+            if want_in:                                                          # gradient of the encoded position: the two layers it feeds
+                dX0 = torch.empty((n4, pk.kp), device=dev, dtype=torch.float32)
+                first = True
+                for i, slot in ((5, 0), (0, 1)):
+                    if i == 0 or len(pk.W[i]) == 2:
+                        _gemm(0, 1, n4, pk.kp, width, dz32[slot], width, pk.W[i][0], pk.kp, dX0, pk.kp, flags=0 if first else ACC)
+                        first = False
+        elif use_chain:
             import ctypes
             from_feat = views and d_feat is not None
             ns = 8 if from_feat else 7
@@ -284,6 +377,8 @@ class _MLP(torch.autograd.Function):
             for i in range(7):
                 gb[i] = gbs[off + 6 - i]
         for i in range(len(pk.W) - 1, -1, -1):
+            if use16:
+                break
             Ws = pk.W[i]
             if chain is None:
                 gb[i] = band_sum(width)                                          # of dz: left in cs_buf by the product that made it

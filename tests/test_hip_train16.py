@@ -1,0 +1,278 @@
+"""-m gpu: the 16-bit storage path of a training step (round 5): nm_mlp_forward_save16, nm_mlp_backward_chain16, nm_wgrad16, nm_wgrad_alpha16,
+nm_pe_encode16, nm_absmax -- each against the float32 form it replaces, and the whole step against the reference's own autograd at a batch
+size where the path is taken (tests/golden/train_big.npz: NeRFTrainer.loss_func + backward of the reference, 512 rays x 64 / 128 samples)."""
+import ctypes
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "ml-neuman_amd"))
+from test_oracle_train import check_grads  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from neuman_hip import _lib, render_utils, ray_utils, synthetic, train
+    return types.SimpleNamespace(lib=_lib.lib(), L=_lib, render=render_utils, rays=ray_utils, syn=synthetic, train=train)
+
+
+def slot_perm():
+    """perm[p] = the feature held by k-slot p = 8 c + e of a row (mlp_layout.h slot_feature)"""
+    p = np.arange(256)
+    c, e = p >> 3, p & 7
+    return 32 * (c >> 2) + 8 * (2 * ((c >> 1) & 1) + (e >> 2)) + 4 * (c & 1) + (e & 3)
+
+
+def dz_scale(amax):
+    """nm_dz_scale: the power of two that puts amax into [2, 4)"""
+    m, e = np.frexp(np.float32(amax))                                    # amax = m 2^e, m in [0.5, 1)
+    return float(2.0 ** (2 - e))
+
+
+def test_slot_perm_is_a_permutation():
+    assert sorted(slot_perm().tolist()) == list(range(256))
+
+
+def test_absmax(G):
+    g = torch.Generator(device='cuda').manual_seed(1)
+    for n in (4, 1001, 262144 * 3 + 2):
+        x = torch.randn(n, device='cuda', generator=g)
+        out = torch.zeros(1, device='cuda')
+        G.L.check(G.lib.nm_absmax(G.L.dev_ptr(x), n, G.L.dev_ptr(out), G.L.stream_ptr()), "absmax")
+        assert float(out) == float(x.abs().max()), n
+        G.L.check(G.lib.nm_absmax(G.L.dev_ptr(x * 0.5), n, G.L.dev_ptr(out), G.L.stream_ptr()), "absmax")      # only ever grows
+        assert float(out) == float(x.abs().max())
+
+
+@pytest.mark.parametrize("n", [64, 4100, 40000])
+def test_wgrad16_against_float64(G, n):
+    """dW = (1 / (32 s)) dz16^T act16 with both operands in k-slot order: products exact in float32, the sum in another order"""
+    g = torch.Generator(device='cuda').manual_seed(n)
+    perm = torch.from_numpy(slot_perm()).cuda()
+    amax = torch.tensor([3.7e-5], device='cuda')
+    s = dz_scale(3.7e-5)
+    assert 2.0 <= 3.7e-5 * s < 4.0
+    nprod = 3
+    dz = [(torch.randn((n, 256), device='cuda', generator=g) * 1e-5) for _ in range(nprod)]
+    act = [torch.relu(torch.randn((n, 256), device='cuda', generator=g)) for _ in range(nprod)]
+    dz16 = [(d * s).half()[:, perm].contiguous() for d in dz]            # slot p <- feature perm[p]
+    act16 = [(a * 32).half()[:, perm].contiguous() for a in act]
+    outs = [torch.full((256, 256 + 63), 7.0, device='cuda'), torch.full((256, 256), 7.0, device='cuda'), torch.full((256, 300), 7.0, device='cuda')]
+    offs = [63, 0, 0]
+    P = (ctypes.c_void_p * nprod)(*[t.data_ptr() for t in dz16])
+    Q = (ctypes.c_void_p * nprod)(*[t.data_ptr() for t in act16])
+    C = (ctypes.c_void_p * nprod)(*[o.data_ptr() + 4 * f for o, f in zip(outs, offs)])
+    Ld = (ctypes.c_int * nprod)(*[o.shape[1] for o in outs])
+    ws = torch.empty(int(G.lib.nm_wgrad16_workspace_floats(nprod, n, 256)), device='cuda')
+    G.L.check(G.lib.nm_wgrad16(nprod, 256, P, Q, C, Ld, n, G.L.dev_ptr(amax), G.L.dev_ptr(ws), ws.numel(), G.L.stream_ptr()), "wgrad16")
+    for k in range(nprod):
+        a64 = dz16[k].double() / s
+        b64 = act16[k].double() / 32
+        ref = torch.empty((256, 256), device='cuda', dtype=torch.float64)
+        ref[perm[:, None], perm[None, :]] = a64.T @ b64                 # position (p, q) -> (feature perm[p], feature perm[q])
+        got = outs[k][:, offs[k]:offs[k] + 256].double()
+        err = float((got - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, (k, err)
+        rest = torch.cat([outs[k][:, :offs[k]], outs[k][:, offs[k] + 256:]], 1)
+        assert bool((rest == 7.0).all())                                # nothing outside the [256][256] window
+    # the encoded-input form: 63 natural-order columns out of rows of 64
+    x0 = torch.randn((n, 64), device='cuda', generator=g)
+    x0[:, 63] = 0
+    x016 = (x0 * 32).half().contiguous()
+    o0, o5 = torch.full((256, 63), 7.0, device='cuda'), torch.full((256, 319), 7.0, device='cuda')
+    P = (ctypes.c_void_p * 2)(dz16[0].data_ptr(), dz16[1].data_ptr())
+    Q = (ctypes.c_void_p * 2)(x016.data_ptr(), x016.data_ptr())
+    C = (ctypes.c_void_p * 2)(o0.data_ptr(), o5.data_ptr())
+    Ld = (ctypes.c_int * 2)(63, 319)
+    ws = torch.empty(int(G.lib.nm_wgrad16_workspace_floats(2, n, 63)), device='cuda')
+    G.L.check(G.lib.nm_wgrad16(2, 63, P, Q, C, Ld, n, G.L.dev_ptr(amax), G.L.dev_ptr(ws), ws.numel(), G.L.stream_ptr()), "wgrad16 (63)")
+    for k, o in enumerate((o0, o5)):
+        ref = torch.empty((256, 64), device='cuda', dtype=torch.float64)
+        ref[perm] = (dz16[k].double() / s).T @ (x016.double() / 32)
+        err = float((o[:, :63].double() - ref[:, :63]).abs().max() / ref.abs().max())
+        assert err < 2e-6, (k, err)
+    assert bool((o5[:, 63:] == 7.0).all())
+    # alpha_linear's row: sum_n d_raw[n][3] H7[n][:]
+    d_raw = torch.randn((n, 4), device='cuda', generator=g)
+    out = torch.empty(256, device='cuda')
+    ws = torch.empty(int(G.lib.nm_wgrad_alpha16_workspace_floats(n)), device='cuda')
+    G.L.check(G.lib.nm_wgrad_alpha16(G.L.dev_ptr(d_raw), ctypes.c_void_p(act16[0].data_ptr()), n, G.L.dev_ptr(out), G.L.dev_ptr(ws), ws.numel(), G.L.stream_ptr()), "alpha16")
+    ref = torch.empty(256, device='cuda', dtype=torch.float64)
+    ref[perm] = d_raw[:, 3].double() @ (act16[0].double() / 32)
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+
+
+def test_pe_encode16(G):
+    net = G.syn.make_joiner(0).cuda()
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = (torch.rand((1001, 3), device='cuda', generator=g) * 4 - 2).contiguous()
+    a = G.train._encode(net.pos_pe, x, 64)
+    b = G.train._encode16(net.pos_pe, x, 64)
+    assert torch.equal(b, (a * 32).half())
+
+
+@pytest.mark.parametrize("n", [1000, 4096])
+def test_forward_save16_is_the_rounded_float32_copy(G, n):
+    """save_h16 = fp16(32 x) of exactly the activations nm_mlp_forward_save_bits keeps, in k-slot order; everything else bit-identical"""
+    net = G.syn.make_joiner(1).cuda().train()
+    g = torch.Generator(device='cuda').manual_seed(n)
+    pts = (torch.rand((n, 3), device='cuda', generator=g) * 2 - 1).contiguous()
+    dirs = F.normalize(torch.randn((n, 3), device='cuda', generator=g), dim=-1).contiguous()
+    h = net.train_handle()
+    ptrs = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in net.nerf.ordered_params()])
+    G.L.check(G.lib.nm_mlp_refresh_f16(h, ptrs, G.L.stream_ptr()), "refresh")
+    acts, hv, raw = torch.empty((9, n, 256), device='cuda'), torch.empty((n, 128), device='cuda'), torch.empty((n, 4), device='cuda')
+    bits = torch.zeros((8, n, 8), device='cuda', dtype=torch.int32)
+    G.L.check(G.lib.nm_mlp_forward_save_bits(h, G.L.dev_ptr(pts), G.L.dev_ptr(dirs), n, G.L.dev_ptr(acts), G.L.dev_ptr(hv), ctypes.c_void_p(bits.data_ptr()),
+                                             G.L.dev_ptr(raw), G.L.stream_ptr()), "save_bits")
+    h16 = torch.full((8, n, 256), 7.0, device='cuda', dtype=torch.float16)
+    feat, hv2, raw2 = torch.empty((n, 256), device='cuda'), torch.empty_like(hv), torch.empty_like(raw)
+    bits2 = torch.zeros_like(bits)
+    G.L.check(G.lib.nm_mlp_forward_save16(h, G.L.dev_ptr(pts), G.L.dev_ptr(dirs), n, ctypes.c_void_p(h16.data_ptr()), G.L.dev_ptr(feat), G.L.dev_ptr(hv2),
+                                          ctypes.c_void_p(bits2.data_ptr()), G.L.dev_ptr(raw2), G.L.stream_ptr()), "save16")
+    assert torch.equal(raw, raw2) and torch.equal(hv, hv2) and torch.equal(bits, bits2) and torch.equal(feat, acts[8])
+    perm = torch.from_numpy(slot_perm()).cuda()
+    want = (acts[:8] * 32).half()[:, :, perm]
+    assert torch.equal(h16, want), float((h16.float() - want.float()).abs().max())
+
+
+@pytest.mark.parametrize("n,want_copies", [(1000, True), (4224, False)])
+def test_backward_chain16_is_the_rounded_float32_chain(G, n, want_copies):
+    """dz16 = fp16(s dZ) of exactly what nm_mlp_backward_chain writes as float32, in k-slot order; same bias gradients; the float32 copies of
+    layers 5 and 0 when asked for"""
+    net = G.syn.make_joiner(1).cuda().train()
+    g = torch.Generator(device='cuda').manual_seed(n)
+    pts = (torch.rand((n, 3), device='cuda', generator=g) * 2 - 1).contiguous()
+    dirs = F.normalize(torch.randn((n, 3), device='cuda', generator=g), dim=-1).contiguous()
+    h = net.train_handle()
+    ptrs = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in net.nerf.ordered_params()])
+    G.L.check(G.lib.nm_mlp_refresh_f16(h, ptrs, G.L.stream_ptr()), "refresh")
+    acts, hv, raw = torch.empty((9, n, 256), device='cuda'), torch.empty((n, 128), device='cuda'), torch.empty((n, 4), device='cuda')
+    bits = torch.zeros((8, n, 8), device='cuda', dtype=torch.int32)
+    G.L.check(G.lib.nm_mlp_forward_save_bits(h, G.L.dev_ptr(pts), G.L.dev_ptr(dirs), n, G.L.dev_ptr(acts), G.L.dev_ptr(hv), ctypes.c_void_p(bits.data_ptr()),
+                                             G.L.dev_ptr(raw), G.L.stream_ptr()), "save_bits")
+    d_feat = (torch.randn((n, 256), device='cuda', generator=g) * 3e-5).contiguous()
+    d_raw = (torch.randn((n, 4), device='cuda', generator=g) * 2e-5).contiguous()
+    ws = torch.empty(int(G.lib.nm_mlp_backward_chain_workspace_floats(n)), device='cuda')
+    out8, gb8 = torch.empty((8, n, 256), device='cuda'), torch.empty((8, 256), device='cuda')
+    G.L.check(G.lib.nm_mlp_backward_chain(h, ptrs, None, G.L.dev_ptr(d_feat), G.L.dev_ptr(d_raw), G.L.dev_ptr(acts), ctypes.c_void_p(bits.data_ptr()), n,
+                                          G.L.dev_ptr(out8), G.L.dev_ptr(gb8), G.L.dev_ptr(ws), ws.numel(), G.L.stream_ptr()), "chain")
+    amax = torch.zeros(1, device='cuda')
+    G.L.check(G.lib.nm_absmax(G.L.dev_ptr(d_feat), d_feat.numel(), G.L.dev_ptr(amax), G.L.stream_ptr()), "absmax")
+    G.L.check(G.lib.nm_absmax(G.L.dev_ptr(d_raw), d_raw.numel(), G.L.dev_ptr(amax), G.L.stream_ptr()), "absmax")
+    s = dz_scale(float(amax))
+    assert 2.0 <= float(amax) * s < 4.0
+    dz16 = torch.full((8, n, 256), 7.0, device='cuda', dtype=torch.float16)
+    df16 = torch.full((n, 256), 7.0, device='cuda', dtype=torch.float16)
+    c5, c0 = (torch.empty((n, 256), device='cuda'), torch.empty((n, 256), device='cuda')) if want_copies else (None, None)
+    gb16 = torch.empty((8, 256), device='cuda')
+    G.L.check(G.lib.nm_mlp_backward_chain16(h, ptrs, G.L.dev_ptr(d_feat), G.L.dev_ptr(d_raw), ctypes.c_void_p(bits.data_ptr()), n, G.L.dev_ptr(amax),
+                                            ctypes.c_void_p(dz16.data_ptr()), ctypes.c_void_p(df16.data_ptr()), G.L.dev_ptr(c5), G.L.dev_ptr(c0), G.L.dev_ptr(gb16),
+                                            G.L.dev_ptr(ws), ws.numel(), G.L.stream_ptr()), "chain16")
+    perm = torch.from_numpy(slot_perm()).cuda()
+    assert torch.equal(gb16, gb8)
+    assert torch.equal(dz16, (out8 * s).half()[:, :, perm])
+    assert torch.equal(df16, (d_feat * s).half()[:, perm])
+    if want_copies:
+        assert torch.equal(c5, out8[2]) and torch.equal(c0, out8[7])
+    # saturation instead of inf: an input far beyond the measured amax
+    tiny = torch.tensor([1e-12], device='cuda')
+    G.L.check(G.lib.nm_mlp_backward_chain16(h, ptrs, G.L.dev_ptr(d_feat), G.L.dev_ptr(d_raw), ctypes.c_void_p(bits.data_ptr()), n, G.L.dev_ptr(tiny),
+                                            ctypes.c_void_p(dz16.data_ptr()), None, None, None, G.L.dev_ptr(gb16), G.L.dev_ptr(ws), ws.numel(), G.L.stream_ptr()),
+              "chain16 (saturating)")
+    assert bool(torch.isfinite(dz16.float()).all()) and float(dz16.float().abs().max()) == 65504.0
+
+
+def _step(G, net, pts, dirs, tgt):
+    for p in net.parameters():
+        p.grad = None
+    out = net(pts, dirs)
+    ((out - tgt) ** 2).mean().backward()
+    return out.detach(), [p.grad.clone() for p in net.parameters()]
+
+
+@pytest.mark.parametrize("want_in", [False, True])
+def test_store16_step_against_the_float32_copies(G, monkeypatch, want_in):
+    """one forward + backward of a Joiner on 36000 samples: fp16 storage vs float32 storage of the same fused kernels.  Outputs bit-identical;
+    parameter (and input) gradients within 2e-5 of each tensor's largest entry"""
+    monkeypatch.setattr(G.train, "GEMM_PRECISION", "mixed16")
+    n = 36000
+    g = torch.Generator(device='cuda').manual_seed(3)
+    pts = (torch.rand((n, 3), device='cuda', generator=g) * 2 - 1).requires_grad_(want_in)
+    dirs = F.normalize(torch.randn((n, 3), device='cuda', generator=g), dim=-1).requires_grad_(want_in)
+    tgt = torch.rand((n, 4), device='cuda', generator=g)
+    net = G.syn.make_joiner(1).cuda().train()
+    res = {}
+    for s16 in (True, False):
+        monkeypatch.setattr(G.train, "STORE16", s16)
+        pts.grad = dirs.grad = None
+        out, grads = _step(G, net, pts, dirs, tgt)
+        res[s16] = (out, grads + ([pts.grad.clone(), dirs.grad.clone()] if want_in else []))
+    assert torch.equal(res[True][0], res[False][0])
+    names = [n_ for n_, _ in net.named_parameters()] + (['d_pts', 'd_dirs'] if want_in else [])
+    worst = 0.0
+    for name, a, b in zip(names, res[True][1], res[False][1]):
+        assert torch.isfinite(a).all(), name
+        e = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+        worst = max(worst, e)
+        assert e < 2e-5, (name, e)
+    print(f"[train16] {n} samples, want_in={want_in}: worst gradient deviation of the fp16-storage step from the float32-storage step {worst:.2e} of a tensor's largest entry")
+
+
+def test_store16_rejects_an_in_place_weight_edit_between_the_passes(G, monkeypatch):
+    monkeypatch.setattr(G.train, "GEMM_PRECISION", "mixed16")
+    net = G.syn.make_joiner(1).cuda().train()
+    g = torch.Generator(device='cuda').manual_seed(3)
+    pts = (torch.rand((33000, 3), device='cuda', generator=g) * 2 - 1)
+    dirs = F.normalize(torch.randn((33000, 3), device='cuda', generator=g), dim=-1)
+    out = net(pts, dirs)
+    with torch.no_grad():
+        net.nerf.pts_linears[3].weight.mul_(1.01)
+    with pytest.raises(G.L.NeumanHipError):
+        out.sum().backward()
+
+
+def test_store16_training_step_matches_reference(G, monkeypatch):
+    """the lines of NeRFTrainer.loss_func (vanilla_nerf_trainer.py:66-95) on the HIP modules at 32768 / 65536 evaluations, where both nets take
+    the fp16-storage path, against the reference's own autograd (tests/golden/train_big.npz)"""
+    monkeypatch.setattr(G.train, "GEMM_PRECISION", "mixed16")
+    monkeypatch.setattr(G.train, "STORE16", True)
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "train_big.npz")))
+    cu = lambda x: torch.as_tensor(np.ascontiguousarray(x)).to('cuda', torch.float32).contiguous()
+    tag, white, penalty = 'black_penalty', False, 0.1
+    o, d, color, depth = cu(g['origin']), cu(g['direction']), cu(g['color']), cu(g['depth'])
+    worst_all = 0.0
+    for k, (name, seed) in enumerate((("coarse", 0), ("fine", 1))):
+        p = f'{tag}/{name}'
+        net = G.syn.make_joiner(seed).cuda().train()
+        z = cu(g[f'{p}/z'])
+        assert z.numel() >= G.train.STORE16_MIN_ROWS
+        pts = o[:, None, :] + d[:, None, :] * z[..., None]
+        dirs = d[:, None, :].expand(pts.shape)
+        out = net(pts, dirs)
+        node = out.grad_fn
+        while node is not None and '_MLP' not in type(node).__name__:
+            node = node.next_functions[0][0]
+        assert node.h16 is not None                                      # the path under test was taken
+        rgb_map, _, _, weights, _ = G.render.raw2outputs(out, z, dirs[:, 0, :], raw_noise_std=0, white_bkg=white)
+        loss_rgb = F.mse_loss(rgb_map, color)
+        closer = z < (depth[:, None].repeat(1, z.shape[1]) * 0.9)
+        loss_empty = F.mse_loss(torch.tanh(torch.relu(out[closer][:, 3])), torch.zeros_like(out[closer][:, 3])) * penalty
+        (loss_rgb + loss_empty).backward()
+        np.testing.assert_allclose(rgb_map.detach().cpu().numpy(), g[f'{p}/rgb_map'], atol=2e-5)
+        np.testing.assert_allclose([float(loss_rgb.detach()), float(loss_empty.detach())], g[f'{tag}/losses'][2 * k:2 * k + 2], rtol=2e-5, atol=1e-7)
+        grads = {n: prm.grad.cpu().numpy() for n, prm in net.named_parameters()}
+        worst = check_grads(grads, g, p, tol=2e-5)
+        worst_all = max(worst_all, worst)
+        print(f"[train16] {p} ({z.numel()} evaluations): parameter gradients, worst relative error vs the reference's autograd {worst:.2e}")
+    assert worst_all < 2e-5
