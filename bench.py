@@ -54,7 +54,6 @@ FLOP_PER_EVAL = 1186816            # 593,408 MAC per sample evaluation (SURVEY 8
 PEAK_BF16_TFLOPS = 2500.0          # dense bf16 MFMA, MI355X_MICROARCH.md
 W, H, S, NI = 800, 800, 128, 128
 EVALS_PER_RAY = S + (S + NI)
-MAX_TILE = 8192           # rays per sharding tile at most; parallel.balanced_tile picks the size that gives every rank equally many
 DTYPES = {
     "mixed": "coarse (sampling) pass: split-fp16 hi+lo MFMA x3, f32 accumulate; fine (shading) pass: per-row-scaled int16 as two "
              "int8 limbs on the i8 MFMA x3, exact int32 accumulate, encodings on split bf16",
@@ -322,6 +321,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from neuman_hip import parallel, ray_utils, render_utils, synthetic
+    if args.dist:
+        parallel.FORCE_COLLECTIVE = True                                   # the gather of a group of ONE rank is run too
+    sharded = world > 1 or args.dist
+    parallel.set_frame_sharding(sharded, stats=sharded)                    # the frame renderers' own sharding: the SAME tiling code as the drivers'
     dev = torch.device("cuda", local)
     coarse = synthetic.make_joiner(0).to(dev)
     fine = synthetic.make_joiner(1).to(dev)
@@ -329,9 +332,8 @@ def main():
     cap = synthetic.SimpleCapture(W, H)
     origins, dirs = ray_utils.shot_all_rays_dev(cap, dev)                  # a1 on the device
     total = origins.shape[0]
-    TILE = parallel.balanced_tile(total, world, MAX_TILE)
-    idx = parallel.tile_ray_indices(total, TILE, rank, world, device=dev)
-    o_loc, d_loc = origins[idx].contiguous(), dirs[idx].contiguous()       # this rank's rays, resident in HBM
+    TILE = parallel.balanced_tile(total, world, parallel.FRAME_TILE)       # (what render_frame_sharded picks: reported, not used here)
+    n_local = int(parallel.tile_ray_indices(total, TILE, rank, world, device=dev).shape[0])
 
     # HIP events around every MLP launch (same stream the kernel is launched on: torch's current stream)
     mlp_events = {"coarse": [], "fine": []}
@@ -350,12 +352,13 @@ def main():
     gather_events = []
 
     def step():
-        rgb, depth = render_utils.render_vanilla_rays(coarse, fine, o_loc, d_loc, cap.near['bkg'], cap.far['bkg'], S, NI, True)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        frame = parallel.gather_frame(torch.cat([rgb, depth[:, None]], 1), idx, total, TILE, force_collective=args.dist)
-        e1.record()
-        gather_events.append((e0, e1))
+        """one frame exactly as render_vanilla renders it (render_utils.py:781-797): the frame's rays through render_utils._frame -- this
+        device alone at N = 1; under the process group the rays of this rank's interleaved tiles (parallel.FRAME_TILE) and ONE gather
+        assembling (rgb, depth) on rank 0 (parallel.render_frame_sharded, the code path of all four drivers)"""
+        frame = render_utils._frame(lambda oo, dd: render_utils.render_vanilla_rays(coarse, fine, oo, dd, cap.near['bkg'], cap.far['bkg'], S, NI, True),
+                                    origins, dirs)
+        if sharded:
+            gather_events.append(parallel.LAST_FRAME_STATS.get("_events"))
         return frame
 
     def sync():
@@ -384,8 +387,8 @@ def main():
     def log_sums(which):
         log = mlp_events[which]
         return float(sum(n for _, _, n in log)), float(sum(e0.elapsed_time(e1) for e0, e1, _ in log))
-    mine = torch.tensor([*log_sums("fine"), *log_sums("coarse"), float(len(mlp_events["fine"])), float(o_loc.shape[0]),
-                         float(sum(e0.elapsed_time(e1) for e0, e1 in gather_events))], device=dev, dtype=torch.float64)
+    mine = torch.tensor([*log_sums("fine"), *log_sums("coarse"), float(len(mlp_events["fine"])), float(n_local),
+                         float(sum(ev[1].elapsed_time(ev[2]) for ev in gather_events if ev is not None))], device=dev, dtype=torch.float64)
     per_rank = [mine]
     if world > 1 or args.dist:
         per_rank = [torch.empty_like(mine) for _ in range(world)]
@@ -521,7 +524,8 @@ def main():
                           "fine_launch_ms_per_rank": [r[1] / max(1.0, r[4]) for r in per_rank],
                           "coarse_launch_ms_per_rank": [r[3] / max(1.0, r[4]) for r in per_rank],
                           "frame_assembly_ms_per_rank": [r[6] / max(1, args.steps) for r in per_rank],
-                          "frame_assembly": "one dist.gather per frame to rank 0 + one index_select (parallel.gather_frame); at world 1 a scatter into the frame",
+                          "frame_assembly": "render_utils._frame -> parallel.render_frame_sharded (the drivers' own path): one dist.gather per frame to rank 0 + one "
+                                            "index_select; at N = 1 without a process group the frame's ray list is rendered in place, nothing to assemble",
                           "omitted_at_n_gt_1": None if world == 1 else ["cpu_baseline (rank 0 at N = 1 only)", "parity_vs_oracle (scored in the N = 1 run: the "
                                                "ranks run the same kernels on disjoint rays)", "roofline.traffic (PMC passes are single-process)"]},
             "parity_vs_oracle": parity,

@@ -282,10 +282,12 @@ class HumanNeRFLoss:
         # (train_step): the flag stays on the device -- the losses are multiplied by it, the host reads it together with the loss values after
         # the backward pass and re-initialises then (before the optimiser step, as the reference does) -- so that the loss is built without
         # a host synchronisation
-        alive = (human_out[..., 3].detach().max() > 0.0)
+        # the reference's test is `max <= 0.0` (:437): a NaN density (torch.max propagates it) is NOT a dead network -- the iteration is then
+        # the NaN guard's to drop (:476-478), the trained weights stay
+        alive = ~(human_out[..., 3].detach().max() <= 0.0)
         if self.defer_dead_check:
             self.last['alive'] = alive
-            loss_dict = {k: v * alive.to(v.dtype) for k, v in loss_dict.items()}
+            loss_dict = {k: torch.where(alive, v, torch.zeros_like(v)) for k, v in loss_dict.items()}     # (where, not x 0: an inf loss of a dead network stays 0)
         elif not bool(alive):
             self._reset_dead_networks()
             loss_dict = {name: torch.zeros((), device=device, requires_grad=True) for name in LOSS_NAMES}
@@ -310,7 +312,10 @@ class HumanNeRFLoss:
         total.backward()
         vals = torch.stack([v.detach() for v in loss_dict.values()] + [total.detach(), self.last['alive'].to(total.dtype)]).tolist()   # ONE read-back
         if vals[-1] == 0.0:
+            # :437-442: the reference's zero losses are detached from the graph, so no parameter has a gradient and step() skips every one of
+            # them -- here backward() has filled zeros: drop them, or Adam's moments of the OLD weights would move the re-initialised ones
             self._reset_dead_networks()
+            optimizer.zero_grad(set_to_none=True)
         optimizer.step()
         return dict(zip(loss_dict.keys(), vals[:-2])), vals[-2]
 
@@ -390,12 +395,13 @@ class HumanNeRFTrainer(HumanNeRFLoss):
         vals = torch.stack([g[k].detach().float() for k in names] + [self.last['alive'].float()]).tolist()
         report = dict(zip(names, vals[:-1]))
         report['lr'] = self.optim.param_groups[0]['lr']
-        if vals[-1] == 0.0:
+        if vals[-1] == 0.0:                                                              # (as train_step: no gradient reaches the fresh weights)
             self._reset_dead_networks()
+            self.optim.zero_grad(set_to_none=True)
         if math.isnan(report['total_loss']):
             print('loss is nan during training', report)
             self.optim.zero_grad()
-        else:
+        elif vals[-1] != 0.0:
             mask = self.pose_grad_mask(int(batch['cap_id'])) if self.pose_grad_mask is not None else None
             if mask is not None and getattr(self.net, 'poses', None) is not None and self.net.poses.grad is not None:
                 cap = int(batch['cap_id'])

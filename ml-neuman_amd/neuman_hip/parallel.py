@@ -119,9 +119,27 @@ def render_sharded(render_rays_fn, origins, dirs, tile=8192, dst=0, force_collec
     return gather_frame(local, idx, total, tile, dst, force_collective)
 
 
+# The frame renderers of render_utils shard only when asked to: under a process group they become COLLECTIVES (every rank must make the
+# call, ranks other than 0 get None back), which a caller that renders its validation frames on rank 0 alone -- the usual pattern beside
+# data-parallel training (bkg_trainer / human_trainer under a group) -- must not get by surprise.  NEUMAN_SHARD_FRAMES=1 or
+# set_frame_sharding(True) turns it on (bench.py, tools/bench_configs.py and the multi-GPU render scripts do).
+SHARD_FRAMES = os.environ.get("NEUMAN_SHARD_FRAMES", "0") == "1"
+# per-frame timing of render_frame_sharded (HIP events on the current stream, read by frame_stats(); no host synchronisation in the call)
+FRAME_STATS = os.environ.get("NEUMAN_FRAME_STATS", "0") == "1"
+
+
+def set_frame_sharding(on=True, stats=None):
+    """Opt the four frame renderers in to (out of) sharding under the initialised process group; `stats`: also time every frame."""
+    global SHARD_FRAMES, FRAME_STATS
+    SHARD_FRAMES = bool(on)
+    if stats is not None:
+        FRAME_STATS = bool(stats)
+
+
 def sharding_active():
-    """True when the frame renderers shard: an initialised process group of more than one rank (or of one, with FORCE_COLLECTIVE)."""
-    if not (dist.is_available() and dist.is_initialized()):
+    """True when the frame renderers shard: asked for (SHARD_FRAMES) and an initialised process group of more than one rank (or of one,
+    with FORCE_COLLECTIVE)."""
+    if not SHARD_FRAMES or not (dist.is_available() and dist.is_initialized()):
         return False
     return dist.get_world_size() > 1 or FORCE_COLLECTIVE
 
@@ -129,37 +147,58 @@ def sharding_active():
 LAST_FRAME_STATS = {}
 
 
+def frame_stats():
+    """LAST_FRAME_STATS with the timings resolved to milliseconds (waits for the frame's last event when they are HIP events)."""
+    st = dict(LAST_FRAME_STATS)
+    ev = st.pop("_events", None)
+    if ev is not None:
+        ev[2].synchronize()
+        st["render_ms"], st["gather_ms"] = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    return st
+
+
 def render_frame_sharded(rays_fn, origins, dirs, max_tile=None, dst=0):
-    """What render_vanilla / render_smpl_nerf / render_hybrid_nerf / render_hybrid_nerf_multi_persons call under a process group
-    (reference render_test_views.py:70-90, render_gathering.py:186-200 render one frame on one device; here the frame's rays are
-    split over the ranks).
+    """What render_vanilla / render_smpl_nerf / render_hybrid_nerf / render_hybrid_nerf_multi_persons call under a process group when
+    sharding is on (reference render_test_views.py:70-90, render_gathering.py:186-200 render one frame on one device; here the frame's
+    rays are split over the ranks).  A COLLECTIVE: every rank of the group must call it with the same frame.
 
     rays_fn(o [n,3], d [n,3]) -> tuple of per-ray tensors ([n] or [n,C]) on the rays' device.  Every rank holds the frame's rays,
     the weights and the posed meshes; it renders the rays of its interleaved tiles as ONE list (so the renderers' own batching, hit
     compaction and C calls see a smaller frame, nothing else), the columns travel as one [n_local, sum C] buffer through ONE gather,
     and rank `dst` gets the tuple for the whole frame; the other ranks get None.  Rays are independent: the frame is bit-identical
-    to the unsharded one (tests/test_parallel_gpu.py).  LAST_FRAME_STATS: this rank's tile / ray counts and milliseconds."""
+    to the unsharded one (tests/test_parallel_gpu.py).  A rank without rays (fewer tiles than ranks) renders one ray for the column
+    layout and sends none.  LAST_FRAME_STATS: this rank's tile / ray counts, and with FRAME_STATS its timings (frame_stats())."""
     rank, world = rank_world()
     total = origins.shape[0]
     tile = balanced_tile(total, world, max_tile or FRAME_TILE)
     idx = tile_ray_indices(total, tile, rank, world, device=origins.device)
+    timed = FRAME_STATS
     cuda = origins.is_cuda
-    if cuda:
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    outs = rays_fn(origins[idx].contiguous(), dirs[idx].contiguous())
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if (timed and cuda) else None
+    t = [0.0, 0.0, 0.0]
+
+    def mark(k):
+        if ev is not None:
+            ev[k].record()
+        elif timed:
+            t[k] = time.perf_counter()
+    mark(0)
+    n_local = int(idx.shape[0])
+    take = idx if n_local else torch.zeros(1, dtype=idx.dtype, device=idx.device)
+    outs = rays_fn(origins[take].contiguous(), dirs[take].contiguous())
     cols = [x.reshape(x.shape[0], -1).to(torch.float32) for x in outs]
     local = torch.cat(cols, 1) if len(cols) > 1 else cols[0]
-    if cuda:
-        torch.cuda.synchronize()
-    t1 = time.perf_counter()
+    if not n_local:
+        local = local[:0]
+    mark(1)
     frame = gather_frame(local, idx, total, tile, dst, force_collective=FORCE_COLLECTIVE)
-    if cuda:
-        torch.cuda.synchronize()
-    t2 = time.perf_counter()
+    mark(2)
     LAST_FRAME_STATS.clear()
-    LAST_FRAME_STATS.update(rank=rank, world=world, tile=tile, tiles=(idx.shape[0] + tile - 1) // tile, rays=int(idx.shape[0]),
-                            render_ms=(t1 - t0) * 1e3, gather_ms=(t2 - t1) * 1e3)
+    LAST_FRAME_STATS.update(rank=rank, world=world, tile=tile, tiles=(n_local + tile - 1) // tile, rays=n_local)
+    if ev is not None:
+        LAST_FRAME_STATS["_events"] = ev
+    elif timed:
+        LAST_FRAME_STATS.update(render_ms=(t[1] - t[0]) * 1e3, gather_ms=(t[2] - t[1]) * 1e3)
     if frame is None:
         return None
     res, c0 = [], 0

@@ -58,6 +58,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert not parallel.sharding_active()                         # a process group alone does not turn the renderers into collectives
+    parallel.set_frame_sharding(True)
     assert parallel.sharding_active(), "set NEUMAN_FORCE_COLLECTIVE=1 for a group of one rank"
     report = {"backend": backend, "world": world, "rays": W * H}
     for k, fn in calls.items():

@@ -195,3 +195,73 @@ def test_shape_regulariser_uses_the_frames_own_canonical_mesh():
         assert torch.equal(d0, L._signed_distance(pts, 0))
     L = human_trainer.HumanNeRFLoss(opt, None, faces, (verts, faces), [])
     assert torch.equal(L._signed_distance(pts, 0), L._signed_distance(pts, 1)) and len(L._can_tree) == 1
+
+
+def _human_state(S):
+    return {k: v.detach().clone() for k, v in list(S.net.coarse_human_net.state_dict().items()) + [('off.' + k, v) for k, v in S.net.offset_nets.state_dict().items()]}
+
+
+def test_nan_density_is_not_a_dead_network(setup):
+    """the reference's restart test is `max <= 0.0` (human_nerf_trainer.py:437) -- False for NaN, so a NaN batch only trips the NaN
+    guard (:476-478) and the trained networks survive.  Both forms of the flag (direct, and deferred to the read-back)."""
+    S = setup
+    saved = {k: v.clone() for k, v in S.net.coarse_human_net.state_dict().items()}
+    try:
+        with torch.no_grad():
+            S.net.coarse_human_net.nerf.alpha_linear.bias.fill_(float('nan'))
+        before = _human_state(S)
+        resets = []
+        orig = S.loss._reset_dead_networks
+        S.loss._reset_dead_networks = lambda: resets.append(1) or orig()
+        try:
+            ld = S.loss.loss_func(S.batch)                                  # direct form
+            assert not resets and not np.isfinite(float(sum(ld.values()).detach()))
+            S.loss.defer_dead_check = True
+            try:
+                S.loss.loss_func(S.batch)
+            finally:
+                S.loss.defer_dead_check = False
+            assert bool(S.loss.last['alive']) and not resets
+        finally:
+            S.loss._reset_dead_networks = orig
+        after = _human_state(S)
+        assert all(torch.equal(before[k], after[k]) or (torch.isnan(before[k]).any() and torch.isnan(after[k]).any()) for k in before)
+    finally:
+        S.net.coarse_human_net.load_state_dict(saved)
+
+
+def test_dead_network_restart_leaves_the_fresh_weights_alone(setup):
+    """on a dead network the reference's losses are fresh zero tensors -- no parameter gets a gradient and Adam's step() skips them
+    all (:437-442).  The deferred form multiplies the built loss by 0 and backward() fills zero gradients: they must be dropped, or the OLD
+    moments would move the re-initialised weights."""
+    S = setup
+    saved_h = {k: v.clone() for k, v in S.net.coarse_human_net.state_dict().items()}
+    saved_o = {k: v.clone() for k, v in S.net.offset_nets.state_dict().items()}
+    try:
+        params = list(S.net.coarse_human_net.parameters()) + list(S.net.offset_nets.parameters())
+        optim = torch.optim.Adam(params, lr=1e-2)
+        torch.manual_seed(14)
+        for _ in range(2):                                                  # Adam has moments now
+            S.loss.train_step(S.batch, optim)
+        with torch.no_grad():
+            S.net.coarse_human_net.nerf.alpha_linear.weight.zero_()
+            S.net.coarse_human_net.nerf.alpha_linear.bias.fill_(-5.0)       # sigma <= 0 everywhere: dead
+        snap = {}
+        orig = S.loss._reset_dead_networks
+
+        def spy():
+            orig()
+            snap.update(_human_state(S))
+        S.loss._reset_dead_networks = spy
+        try:
+            terms, total = S.loss.train_step(S.batch, optim)
+        finally:
+            S.loss._reset_dead_networks = orig
+        assert snap and total == 0.0 and all(v == 0.0 for v in terms.values())
+        after = _human_state(S)
+        assert all(torch.equal(snap[k], after[k]) for k in snap)              # step() moved nothing
+        assert all(p.grad is None for p in params)
+        assert float(S.net.coarse_human_net.nerf.alpha_linear.bias.detach().abs().max()) < 1.0      # really re-initialised
+    finally:
+        S.net.coarse_human_net.load_state_dict(saved_h)
+        S.net.offset_nets.load_state_dict(saved_o)

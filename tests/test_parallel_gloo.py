@@ -88,7 +88,7 @@ def _frame_worker(rank, world, port, total, max_tile, q):
     d = torch.randn(total, 3, generator=g)
     out = parallel.render_frame_sharded(_fake_frame, o, d, max_tile=max_tile, dst=0)
     st = dict(parallel.LAST_FRAME_STATS)
-    assert st['rank'] == rank and st['world'] == world and st['rays'] > 0
+    assert st['rank'] == rank and st['world'] == world and (st['rays'] > 0 or total < world)
     if rank == 0:
         q.put([x.numpy() for x in out] + [st['tile']])
     else:
@@ -97,7 +97,7 @@ def _frame_worker(rank, world, port, total, max_tile, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,total,max_tile", [(2, 1003, 64), (3, 500, 1024)])
+@pytest.mark.parametrize("world,total,max_tile", [(2, 1003, 64), (3, 500, 1024), (3, 2, 64)])      # (the last: a rank without rays)
 def test_frame_drivers_shard_and_assemble_tuples(world, total, max_tile):
     """parallel.render_frame_sharded (what render_vanilla / render_smpl_nerf / render_hybrid_nerf / render_hybrid_nerf_multi_persons call
     under a process group): interleaved tiles, the tuple's columns through one gather, the frame on rank 0 only, bit-identical"""

@@ -67,6 +67,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     from neuman_hip import parallel, ray_utils, render_utils, synthetic
+    parallel.set_frame_sharding(True, stats=world > 1)              # the drivers shard only when asked to (a collective per frame)
     small = args.small
     only = set(x for x in args.only.split(",") if x)
     coarse, fine, human = (synthetic.make_joiner(0).to(dev), synthetic.make_joiner(1).to(dev), synthetic.make_joiner(2, 'rotate').to(dev))
@@ -103,14 +104,15 @@ def main():
                 dist.barrier()
             if it:                                                # (the first frame is the warm-up)
                 ts.append(time.perf_counter() - t0)
-                rs.append(parallel.LAST_FRAME_STATS.get("render_ms"))
-                gs.append(parallel.LAST_FRAME_STATS.get("gather_ms"))
+                fs = parallel.frame_stats()
+                rs.append(fs.get("render_ms"))
+                gs.append(fs.get("gather_ms"))
         dt = sorted(ts)[len(ts) // 2]
         total = cap.shape[0] * cap.shape[1]
         line = {"config": name, "rays": total, "n_gpus": world, "ms_per_frame": dt * 1e3, "rays_per_s": total / dt}
         line.update(extra or {})
         if world > 1:
-            st = dict(parallel.LAST_FRAME_STATS)
+            st = parallel.frame_stats()
             idx = parallel.tile_ray_indices(total, st["tile"], rank, world, device=dev)
             mine = {"rank": rank, "tiles": st["tiles"], "rays": st["rays"], "hit_rays": hits_of(o, d, clouds, idx),
                     "render_ms": sorted(rs)[len(rs) // 2], "gather_ms": sorted(gs)[len(gs) // 2]}
