@@ -34,7 +34,13 @@ def fade(iteration, span=60000):
 
 
 class BackgroundNeRFTrainer:
-    def __init__(self, opt, coarse_net, optimizer, fine_net=None, batches=None, val_batches=None, penalize_empty_space=None):
+    """`data_parallel`: train over the initialised process group as the reference's nn.DataParallel nets do over the visible GPUs
+    (train.py:26-28; neuman_hip/dp.py): this rank's rays of every batch, ONE all_reduce of the flat gradient buffer per iteration.
+    None = on when a process group of more than one rank exists.  `batches` must then yield this rank's slice
+    (BackgroundRayBatcher(rank=, world=)) unless `shard_batches` (full batches, identical on every rank, sliced here)."""
+
+    def __init__(self, opt, coarse_net, optimizer, fine_net=None, batches=None, val_batches=None, penalize_empty_space=None,
+                 data_parallel=None, shard_batches=False, group=None):
         self.opt = opt
         self.coarse_net, self.fine_net, self.optim = coarse_net, fine_net, optimizer
         self.batches, self.val_batches = batches, val_batches
@@ -48,6 +54,14 @@ class BackgroundNeRFTrainer:
             self.resume()
         if getattr(opt, 'load_weights', False):
             self.load_pretrained_weights()
+        from . import dp
+        self.rank, self.world = dp.rank_world(group)
+        if data_parallel is None:
+            data_parallel = self.world > 1
+        self.sync, self.shard_batches, self.group = None, shard_batches, group
+        if data_parallel:
+            dp.broadcast_parameters(self._nets(), group=group)    # (after a resume too: every rank starts from rank 0's weights)
+            self.sync = dp.GradSync([p for n in self._nets() for p in n.parameters()], n_extra=4, group=group)
 
     # ---------------------------------------------------------------------------------------------
     def _empty_space(self, raw, z_vals, depth):
@@ -74,16 +88,16 @@ class BackgroundNeRFTrainer:
         _, _, z = ray_utils.sample_z(o, d, batch['near'].reshape(-1), batch['far'].reshape(-1), opt.samples_per_ray, perturb=opt.perturb)
         raw, rgb, weights = self._pass(self.coarse_net, batch, z, time)
         terms = [F.mse_loss(rgb, batch['color']), self._empty_space(raw, z, batch.get('depth'))]
-        alive = raw[..., 3].max() > 0
+        dead = raw[..., 3].max() <= 0.0                           # (:88: `max() <= 0.0` -- a NaN density is the NaN guard's business, not a restart)
         if self.fine_net is not None:
             with torch.no_grad():
                 z_fine = ray_utils.importance_z(z, weights.detach(), opt.importance_samples_per_ray)
             raw_f, rgb_f, _ = self._pass(self.fine_net, batch, z_fine, time)
             terms += [F.mse_loss(rgb_f, batch['color']), self._empty_space(raw_f, z_fine, batch.get('depth'))]
-            alive = alive & (raw_f[..., 3].max() > 0)
+            dead = dead | (raw_f[..., 3].max() <= 0.0)
         else:
             terms += [torch.zeros_like(terms[0]), torch.zeros_like(terms[0])]
-        if not bool(alive):                                       # no sample with positive density anywhere: redraw the weights (:88-94)
+        if bool(dead):                                            # no sample with positive density anywhere: redraw the weights (:88-94)
             print('bad weights, reinitializing')
             for net in (self.coarse_net, self.fine_net):
                 if net is not None:
@@ -91,8 +105,85 @@ class BackgroundNeRFTrainer:
             terms = [torch.zeros((), device=o.device, requires_grad=True) for _ in range(4)]
         return tuple(terms)
 
+    def loss_func_dp(self, batch):
+        """loss_func on THIS RANK'S rays with every mean taken over the whole batch: the four terms are this rank's SHARE of the full-batch
+        terms (their sum over the ranks is what loss_func returns on the concatenated batch, and so are the gradients).  The global
+        element counts and the dead-network test need one small all_gather before the backward pass.  -> (terms, dead)"""
+        from . import dp
+        opt = self.opt
+        o, d = batch['origin'], batch['direction']
+        time = batch['viewf_list'] if getattr(opt, 'ablate_nerft', False) else None
+        _, _, z = ray_utils.sample_z(o, d, batch['near'].reshape(-1), batch['far'].reshape(-1), opt.samples_per_ray, perturb=opt.perturb)
+        depth = batch.get('depth')
+
+        def pieces(raw, rgb, zz):
+            sq = ((rgb - batch['color']) ** 2).sum()
+            if self.penalize_empty_space > 0:
+                closer = zz < depth[:, None] * opt.margin
+                sigma = raw[..., 3][closer]
+                es = self.empty_space_loss_fn(torch.tanh(torch.relu(sigma)), torch.zeros_like(sigma), reduction='sum') * self.penalize_empty_space
+                cnt = closer.sum()
+            else:
+                es, cnt = torch.zeros((), device=raw.device), torch.zeros((), device=raw.device)
+            return sq, es, cnt, raw[..., 3].detach().max()
+        raw, rgb, weights = self._pass(self.coarse_net, batch, z, time)
+        sq_c, es_c, cnt_c, max_c = pieces(raw, rgb, z)
+        sq_f = es_f = None
+        cnt_f, max_f = torch.zeros((), device=o.device), torch.ones((), device=o.device)
+        if self.fine_net is not None:
+            with torch.no_grad():
+                z_fine = ray_utils.importance_z(z, weights.detach(), opt.importance_samples_per_ray)
+            raw_f, rgb_f, _ = self._pass(self.fine_net, batch, z_fine, time)
+            sq_f, es_f, cnt_f, max_f = pieces(raw_f, rgb_f, z_fine)
+        # NaN-aware largest density: `max <= 0` must be False for NaN on any rank (the reference's test on the whole batch)
+        stats = dp.all_gather_floats([float(rgb.numel()), cnt_c, cnt_f, torch.nan_to_num(max_c, nan=1.0), torch.nan_to_num(max_f, nan=1.0)], self.group)
+        n_rgb, n_c, n_f = float(stats[:, 0].sum()), float(stats[:, 1].sum()), float(stats[:, 2].sum())
+        dead = bool(stats[:, 3].max() <= 0.0) or bool(stats[:, 4].max() <= 0.0)
+        zero = torch.zeros((), device=o.device)
+        terms = [sq_c / n_rgb, es_c / n_c if n_c > 0 else zero]
+        terms += [sq_f / n_rgb, es_f / n_f if n_f > 0 else zero] if sq_f is not None else [zero, zero]
+        return terms, dead
+
+    def _train_batch_dp(self, batch):
+        """train_batch over the process group: local share of the loss, backward, ONE all_reduce of gradients + loss values, the NaN guard and
+        the dead-network restart decided on the GLOBAL values (identically on every rank), Adam"""
+        from . import dp
+        if self.shard_batches:
+            batch = dp.shard_batch(batch, self.rank, self.world)
+        self.sync.zero()
+        terms, dead = self.loss_func_dp(batch)
+        rgb_loss, empty_loss = terms[0] + terms[2], terms[1] + terms[3]
+        total = rgb_loss + empty_loss if self.iteration >= self.opt.delay_iters else rgb_loss
+        if dead:                                                  # (:88-94) redraw on rank 0, everybody takes those weights; no step on them
+            print('bad weights, reinitializing')
+            for net in self._nets():
+                net.apply(weight_reset)
+            dp.broadcast_parameters(self._nets(), group=self.group)
+            vals = [0.0, 0.0, 0.0, 0.0]
+            self.sync.zero()
+            for p in self.sync.params:
+                p.grad = None
+        else:
+            if total.requires_grad:
+                total.backward()
+            vals = self.sync.reduce(extra=[t.detach() for t in terms])
+        report = dict(zip(LOSS_TERMS, vals))
+        report.update(rgb_loss=vals[0] + vals[2], empty_space_loss=vals[1] + vals[3], lr=self.optim.param_groups[0]['lr'])
+        report['total_loss'] = report['rgb_loss'] + (report['empty_space_loss'] if self.iteration >= self.opt.delay_iters else 0.0)
+        if math.isnan(report['total_loss']):
+            print('loss is nan during training')
+            self.sync.zero()
+            for p in self.sync.params:
+                p.grad = None
+        self.optim.step()
+        return report
+
     # ---------------------------------------------------------------------------------------------
     def train_batch(self, batch):
+        if self.sync is not None:
+            report = self._train_batch_dp(batch)
+            self._schedules()
+            return report
         self.optim.zero_grad()
         terms = self.loss_func(batch)
         rgb_loss, empty_loss = terms[0] + terms[2], terms[1] + terms[3]
@@ -106,12 +197,15 @@ class BackgroundNeRFTrainer:
         else:
             total.backward()
         self.optim.step()
+        self._schedules()
+        return report
+
+    def _schedules(self):
         if self.opt.lrate_decay is not None:
             for group in self.optim.param_groups:
                 group['lr'] = decayed_rate(self.opt.learning_rate, self.iteration, self.opt.lrate_decay)
         if self.opt.penalize_empty_space > 0:
             self.penalize_empty_space = self.opt.penalize_empty_space * fade(self.iteration)
-        return report
 
     def validate_batch(self, batch):
         self.optim.zero_grad()
@@ -160,10 +254,15 @@ class BackgroundNeRFTrainer:
 
     # ---------------------------------------------------------------------------------------------
     def save_model(self, path=None):
+        """checkpoint with the reference's keys.  Under data parallelism rank 0 writes, and the networks' keys carry the 'module.' prefix of
+        the nn.DataParallel wrappers the reference's train.py saves through (train.py:26-28; both forms load either way, utils/utils.py:225-254)"""
+        if self.sync is not None and self.rank != 0:
+            return
+        pre = 'module.' if (self.sync is not None and getattr(self.opt, 'module_prefix', True)) else ''
         state = {'epoch': self.epoch, 'iteration': self.iteration, 'optim_state_dict': self.optim.state_dict(),
-                 'coarse_model_state_dict': self.coarse_net.state_dict()}
+                 'coarse_model_state_dict': {pre + k: v for k, v in self.coarse_net.state_dict().items()}}
         if self.fine_net is not None:
-            state['fine_model_state_dict'] = self.fine_net.state_dict()
+            state['fine_model_state_dict'] = {pre + k: v for k, v in self.fine_net.state_dict().items()}
         torch.save(state, path or os.path.join(self.out, 'checkpoint.pth.tar'))
 
     def resume(self):

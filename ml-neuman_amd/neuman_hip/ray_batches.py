@@ -213,12 +213,15 @@ class BackgroundRayBatcher:
     """datasets/background_rays.py BackgroundRayDataset.__getitem__ on a FrameStore: `rays_per_batch` random background pixels
     spread over the captures of the split."""
 
-    def __init__(self, opt, store, inclusions=None, dset_type='train', draws='device', seed=0):
+    def __init__(self, opt, store, inclusions=None, dset_type='train', draws='device', seed=0, rank=0, world=1):
         self.opt, self.store, self.dset_type = opt, store, dset_type
         self.batch_size = opt.rays_per_batch
         self.caps = list(range(len(store.captures))) if inclusions is None else [store.fname_to_index[f] for f in inclusions]
         self.draws = draws
         self.gen = torch.Generator(device=store.device).manual_seed(seed)
+        # data-parallel training (neuman_hip/dp.py; reference train.py:26-28): every rank draws the SAME batch (same seed) and builds
+        # the rays rank, rank + world, ... of it -- the union over the ranks is the single-process batch
+        self.rank, self.world = int(rank), int(world)
         self.ablate = bool(getattr(opt, 'ablate_nerft', False))
         if not self.ablate:
             if store.masks is None:
@@ -264,6 +267,8 @@ class BackgroundRayBatcher:
     def next_batch(self):
         st = self.store
         cap_id, pick = self._draw_numpy() if self.draws == 'numpy' else self._draw_device()
+        if self.world > 1:
+            cap_id, pick = cap_id[self.rank::self.world].contiguous(), pick[self.rank::self.world].contiguous()
         flat = pick if self.ablate else st.pool(self.pool_name)[0][pick].long()
         o, d = st.rays(cap_id, flat)
         n = cap_id.shape[0]
