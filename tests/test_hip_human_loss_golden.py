@@ -16,6 +16,7 @@ import numpy as np
 import pytest
 import torch
 
+ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 pytestmark = pytest.mark.gpu
 GOLDEN = {"small": os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "human_loss.npz"),
           # make_golden_human_loss.py --full: the trainer's real sizes -- 512 rays, 128 + 128 background and 128 human samples, the
@@ -112,10 +113,21 @@ def test_loss_terms_and_gradients_vs_the_references_autograd(S):
     assert np.median(e[hit]) < 5e-5 and (e[hit] > 1e-4).mean() < 0.05
     # The gradients of the SMPL parameters are NOT well defined in float32: the reference's own autograd result moves by 7 % / 10 % / 7 %
     # (poses / betas / alignments) when the poses move by 1e-6 (tests/golden/make_golden_human_loss.py stores that floor) -- they run
-    # through d(barycentric)/d(vertex) ~ 1 / edge length of whichever face each sample's foot lands on.  Held to 3 x that floor and to
-    # the direction; the networks' gradients to max(2e-3, 3 x floor) (measured 6e-6 ... 2e-4).
+    # through d(barycentric)/d(vertex) ~ 1 / edge length of whichever face each sample's foot lands on.  Gates:
+    #   network tensors   min(max(2e-3, 3 x floor), 3 x what round 4 measured on this golden)   (profiles/r05_grad_gates.json)
+    #   SMPL parameters   1.5 x floor, cosine >= 0.985; the device's deviation and the reference-vs-reference floor are reported side by side
+    import json
+    with open(os.path.join(ROOT, "profiles", "r05_grad_gates.json")) as f:
+        measured = json.load(f)[S.size]
+    gates = {}
     for k, v in worst.items():
         floor = float(S.g['grad_floor_' + k])
-        assert v < max(2e-3, 3 * floor), (k, v, floor)
-        assert cos[k] > (0.97 if k in ("poses", "betas", "alignments") else 0.9999), (k, cos[k])
+        gates[k] = 1.5 * floor if k in ("poses", "betas", "alignments") else min(max(2e-3, 3 * floor), 3 * measured[k])
+    SUMMARY[S.size].update(smpl_grad_floor={k: float(S.g['grad_floor_' + k]) for k in ("poses", "betas", "alignments")},
+                           smpl_grad_cos={k: cos[k] for k in ("poses", "betas", "alignments")}, network_grad_dev=net_g,
+                           network_grad_gate={k: gates[k] for k in net_g})
+    print("[human loss] gates: " + "  ".join(f"{k} {worst[k]:.2e} <= {gates[k]:.2e}" for k in worst))
+    for k, v in worst.items():
+        assert v < gates[k], (k, v, gates[k])
+        assert cos[k] > (0.985 if k in ("poses", "betas", "alignments") else 0.9999), (k, cos[k])
     assert all(p.grad is None for p in S.net.coarse_bkg_net.parameters())

@@ -99,23 +99,19 @@ FOOT_TOL = 1e-5          # measured on the band: 6 of 275 hit rays beyond it (th
 MULTI_BAND = (560, 720)
 
 
-DIR_TOL = 5e-4           # big frames: a canonical DIRECTION is a finite difference of warped points over one sample spacing (ray_utils.py:62-64)
-SPACING_TOL = 1e-3       # big frames: rays grazing the 0.2 shell have all 128 samples within < 0.13 of depth
 
 
-def foot_jump_rays(trace, k, o, d, verts, faces, T, band, strict=False):
+def foot_jump_rays(trace, k, o, d, verts, faces, T, band):
     """rays of actor k within `band` that hold a sample whose canonical point differs from the oracle's warp of the SAME point by more
     than FOOT_TOL: the closest-point foot is ill conditioned there -- deep inside the body the feet on neighbouring
     faces are equidistant to 1e-7 while lying 1e-5 apart (at the medial axis: on opposite sides of the body), and the float32 search
     (the device, like libigl on float32 input) and the float64 shim pick different ones.  The distance, the query's invariant, agrees to
     6e-8 (test_warp_vs_the_references_own_warp); the finite-difference directions divide the foot's displacement by the sample spacing.
 
-    strict (the 64 x 64 frames, where the statement covers EVERY hit ray of a frame): also the rays with a canonical direction more than
-    DIR_TOL from the oracle's (a foot displaced by 5e-6 over a spacing of 5e-3 turns the direction by 1e-3, and the colour follows the
-    view direction with a slope of ~0.2: measured 1.5e-4 at 7e-4), and the grazing rays whose sample spacing is below SPACING_TOL --
-    there the reference's OWN float32 rounding of the closest point (3e-8, tests/golden/igl_shim.py returns it in the query's dtype
-    like the bindings) turns its directions by 1e-3..1e-2: the CPU oracle and the reference disagree on exactly those rays by the same
-    amounts (ray 2427 of posed_big.npz: spacing 2.2e-5, oracle vs reference 2.9e-3, device vs oracle 4e-6)."""
+    foot_jump_rays.last keeps (rays, can_pts deviation, can_dirs deviation, sample spacing) of the band's hit rays: the big-frame test lists them
+    for the rays beyond 1e-4 (a foot displaced by 5e-6 over a spacing of 5e-3 turns the finite-difference direction by 1e-3 and the colour follows the
+    view direction with a slope of ~0.2; on rays grazing the 0.2 shell the reference's OWN float32 rounding of the closest point turns its directions by
+    1e-3..1e-2 -- the CPU oracle and the reference disagree on exactly those rays by the same amounts, ray 2427 of posed_big.npz)."""
     from oracle import warp
     hit = trace['hit'][k].cpu().numpy()
     if trace['can_pts'][k] is None:
@@ -131,8 +127,6 @@ def foot_jump_rays(trace, k, o, d, verts, faces, T, band, strict=False):
     dev_d = np.abs(ocd - trace['can_dirs'][k].cpu().numpy()[sel]).max((-1, -2))
     spacing = (z[:, -1] - z[:, 0]) / (z.shape[1] - 1)
     foot_jump_rays.last = (rays, dev, dev_d, spacing)
-    if strict:
-        return rays[(dev > FOOT_TOL) | (dev_d > DIR_TOL) | (spacing < SPACING_TOL)]
     return rays[dev > FOOT_TOL]
 
 
@@ -151,21 +145,37 @@ def test_posed_human_frame(S, size):
     ea, ed = np.abs(acc.cpu().numpy() - S['posed_acc'].ravel()), np.abs(depth.cpu().numpy() - S['posed_depth'].ravel())
     hit = S['posed_near'] < S['posed_far']
     a, b = whole or BAND
-    jump = foot_jump_rays(trc, 0, o, d, S['posed_verts'], S['faces'], S['T'], (a, b), strict=size == 'big')
+    jump = foot_jump_rays(trc, 0, o, d, S['posed_verts'], S['faces'], S['T'], (a, b))
     ok = np.ones(NR, bool)
     ok[jump] = False
     band = np.zeros(NR, bool)
     band[a:b] = True
-    print(f"[posed 128 {size}, conditional on the reference's near / far] rays {a}..{b} ({(hit & band).sum()} hit): {jump.size} ray(s) with a sample whose foot is on "
-          f"another face{' / a turned direction / a grazing interval' if size == 'big' else ''} (Linf there {e[jump].max() if jump.size else 0:.2e}); every other ray: rgb Linf {e[band & ok].max():.2e}, acc {ea[band & ok].max():.2e}, "
-          f"depth {ed[band & ok].max():.2e}; whole frame: rays > 1e-4 {(e > 1e-4).sum()} of {hit.sum()} hit, acc Linf {ea.max():.2e}")
-    SUMMARY['posed_' + size] = {'rays': int(band.sum()), 'hit': int((hit & band).sum()), 'cond_linf': float(e[band & ok].max()), 'foot_jump_rays': int(jump.size)}
-    assert e[band & ok].max() < 1e-4 and ea[band & ok].max() < 1e-4 and ed[band & ok].max() < 2e-4
-    # measured: 6 of 275 (2.2 %) on the band; big, with the direction and spacing criteria: 285 of 1896 (15 %), and over the WHOLE
-    # frame 8 rays beyond 1e-4 (3 of them are rays on which the CPU oracle and the reference disagree by the same amount)
-    assert jump.size <= (0.20 if size == 'big' else 0.05) * (hit & band).sum() and ea.max() < 1e-4
-    SUMMARY['posed_' + size]['cond_gt_1e4_whole_frame'] = int((e > 1e-4).sum())
-    assert (e > 1e-4).sum() <= COND_CAP[size]['posed']
+    n_bad = int((e > 1e-4).sum())
+    if size == 'small':
+        print(f"[posed 128 small, conditional on the reference's near / far] rays {a}..{b} ({(hit & band).sum()} hit): {jump.size} ray(s) with a sample whose foot is on "
+              f"another face (Linf there {e[jump].max() if jump.size else 0:.2e}); every other ray: rgb Linf {e[band & ok].max():.2e}, acc {ea[band & ok].max():.2e}, "
+              f"depth {ed[band & ok].max():.2e}; whole frame: rays > 1e-4 {n_bad} of {hit.sum()} hit, acc Linf {ea.max():.2e}")
+        SUMMARY['posed_' + size] = {'rays': int(band.sum()), 'hit': int((hit & band).sum()), 'cond_linf': float(e[band & ok].max()), 'foot_jump_rays': int(jump.size)}
+        assert e[band & ok].max() < 1e-4 and ea[band & ok].max() < 1e-4 and ed[band & ok].max() < 2e-4
+        assert jump.size <= 0.05 * (hit & band).sum()                   # measured: 6 of 275 (2.2 %)
+    else:
+        # The 64 x 64 frame: what carries the statement is the COUNT over the whole frame -- 8 of 1896 hit rays beyond 1e-4 in round 4, cap 11 --
+        # not a per-ray flag: round 4's three-criterion flag (foot on another face / direction turned by 5e-4 / spacing < 1e-3) set 285 rays
+        # aside to account for 8 and is gone.  The deviating rays are LISTED with the three conditioning numbers of
+        # their own samples, so that the log says what each one is; none of it is asserted beyond the count.
+        rays_l, dev_l, devd_l, sp_l = foot_jump_rays.last
+        at = {int(r): i for i, r in enumerate(rays_l)}
+        listing = [(int(r), float(e[r]), float(dev_l[at[int(r)]]), float(devd_l[at[int(r)]]), float(sp_l[at[int(r)]])) for r in np.nonzero(e > 1e-4)[0] if int(r) in at]
+        in_jump = sum(1 for r in np.nonzero(e > 1e-4)[0] if r in set(jump.tolist()))
+        print(f"[posed 128 big, conditional on the reference's near / far] whole 64 x 64 frame, {hit.sum()} hit rays: rays > 1e-4 {n_bad} (cap {COND_CAP[size]['posed']}), "
+              f"Linf {e.max():.2e}, acc Linf {ea.max():.2e}; of those {in_jump} hold a sample whose foot is on another face ({jump.size} such rays in the frame, their Linf "
+              f"{e[jump].max() if jump.size else 0:.2e}); median over hit rays {np.median(e[hit]):.1e}; the rays beyond 1e-4 as (ray, rgb dev, can_pts dev, can_dirs dev, spacing): "
+              + "; ".join(f"({r}, {x:.1e}, {a_:.1e}, {b_:.1e}, {c_:.1e})" for r, x, a_, b_, c_ in listing))
+        SUMMARY['posed_' + size] = {'rays': int(band.sum()), 'hit': int((hit & band).sum()), 'cond_linf_whole_frame': float(e.max()), 'foot_jump_rays': int(jump.size),
+                                    'gt_1e4_with_a_foot_jump': int(in_jump), 'median_dev': float(np.median(e[hit]))}
+    assert ea.max() < 1e-4
+    SUMMARY['posed_' + size]['cond_gt_1e4_whole_frame'] = n_bad
+    assert n_bad <= COND_CAP[size]['posed']
     # the device's own near / far and the end-to-end frame
     tr = {}
     rgb, depth, acc = S['R'].render_smpl_nerf_rays(net, cu(o), cu(d), cu(S['posed_verts']), S['mesh'], 128, True, False, 0.2, 1.0, trace=tr)
@@ -226,7 +236,7 @@ def test_merged_frames(S, which, size):
     a, b = whole or (MULTI_BAND if multi else BAND)
     ok = ~ties
     verts_l, T_l = (S['posed_l'], S['T_l']) if multi else ([S['posed_verts']], [S['T']])
-    jumps = [foot_jump_rays(trc, k, o, d, verts_l[k], S['faces'], T_l[k], (a, b), strict=size == 'big') for k in range(len(verts_l))]
+    jumps = [foot_jump_rays(trc, k, o, d, verts_l[k], S['faces'], T_l[k], (a, b)) for k in range(len(verts_l))]
     for j in jumps:
         ok[j] = False
     band = np.zeros(NR, bool)
@@ -238,7 +248,8 @@ def test_merged_frames(S, which, size):
     SUMMARY[f'{which}_{size}'] = {'rays': int(band.sum()), 'actor_hits': n_hit_band, 'cond_linf': float(e[band & ok].max()), 'tie_rays': int(ties.sum()),
                                   'foot_jump_rays': int(sum(j.size for j in jumps))}
     # measured on the 40 x 32 frames: 1-3 tie rays, displaced feet on 2.2 % of the band's hit rays
-    assert e[band & ok].max() < 1e-4 and ties.sum() <= TIE_CAP[size] and sum(j.size for j in jumps) <= (0.20 if size == 'big' else 0.05) * max(1, n_hit_band)
+    # (the same foot flag on both frame sizes -- round 4's wider one on the big frame is gone: the whole-frame count below carries the statement)
+    assert e[band & ok].max() < 1e-4 and ties.sum() <= TIE_CAP[size] and sum(j.size for j in jumps) <= 0.05 * max(1, n_hit_band)
     SUMMARY[f'{which}_{size}']['cond_gt_1e4_whole_frame'] = int((e > 1e-4).sum())
     assert (e > 1e-4).sum() <= COND_CAP[size][which]
     # ---- end to end

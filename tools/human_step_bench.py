@@ -1,7 +1,13 @@
 """Time one iteration of the human trainer (trainers/human_nerf_trainer.py:180-446 + backward + Adam) on the device pieces at the
 reference's batch: `rays` rays of one frame of an SMPL-sized body (6890 vertices, 13776 faces), frozen background 128 + 128 samples,
 human 128 samples through offset net / differentiable skinning / warp / human net, the seven loss terms.  Prints one JSON line.
-    python tools/human_step_bench.py [rays]"""
+    python tools/human_step_bench.py [rays] [iterations]
+
+A training benchmark that TRAINS (round 5): the target colours are the rendering of the same rays by a second, frozen human net (a field the
+trained one can approach, not torch.rand), the trained net starts from the plain nn.Linear initialisation (mixed-sign density: the
+synthetic-dense preset's 40x alpha weights make Adam overshoot into an all-negative density within ten steps, which the reference's
+restart of human_nerf_trainer.py:437-442 then turns into iterations that train nothing) and the learning rate is 2e-4.  Every timed iteration
+must be alive, and the mean total loss of the last five iterations must be below that of the first five -- asserted, and both are printed."""
 import json
 import os
 import sys
@@ -15,16 +21,17 @@ import torch  # noqa: E402
 from neuman_hip import human_trainer, ray_utils, smpl, synthetic, vanilla  # noqa: E402
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 dev = torch.device('cuda')
 
 
 class HumanNeRFLike(torch.nn.Module):
     """the attributes of models/human_nerf.py HumanNeRF the trainer reads, on the synthetic SMPL-sized body"""
 
-    def __init__(self):
+    def __init__(self, human_seed=2, dense=False):
         super().__init__()
         self.coarse_bkg_net, self.fine_bkg_net = synthetic.make_joiner(0).to(dev), synthetic.make_joiner(1).to(dev)
-        self.coarse_human_net = synthetic.make_joiner(2, 'rotate').to(dev)
+        self.coarse_human_net = synthetic.make_joiner(human_seed, 'rotate', dense=dense).to(dev)
         opt = synthetic.default_opt(offset_scale=0.05, offset_scale_type='linear')
         torch.manual_seed(3)
         self.offset_nets = torch.nn.ModuleList([vanilla.build_offset_net(opt).to(dev)])
@@ -69,17 +76,35 @@ opt = types.SimpleNamespace(samples_per_ray=128, importance_samples_per_ray=128,
                             penalize_lpips=0.0, penalize_sharp_edge=0.1, penalize_outside_factor=2.0, dist_exponent=2.0)
 can_caps = [synthetic.SimpleCapture(64, 64, fx=80., c2w=synthetic.spherical_c2w(a, 0., 3.0)) for a in (0., 90., 200.)]
 loss = human_trainer.HumanNeRFLoss(opt, net, faces, (can_verts, faces), can_caps, interval_comp=0.8, seed=4)
+# the target: the same batch rendered through a second human net (dense preset: an opaque-ish body in front of the same background)
+target = HumanNeRFLike(human_seed=9, dense=True)
+for n in (target.coarse_bkg_net, target.fine_bkg_net, target.coarse_human_net):
+    n.eval()
+target.offset_nets.eval()
+with torch.no_grad():
+    tl = human_trainer.HumanNeRFLoss(opt, target, faces, (can_verts, faces), can_caps, interval_comp=0.8, seed=4)
+    _, rgb_t = tl.loss_func(batch, return_rgb=True)
+batch['color'] = rgb_t.detach().clamp(0.0, 1.0).contiguous()
+del target, tl
 params = list(net.coarse_human_net.parameters()) + list(net.offset_nets.parameters()) + [net.poses, net.betas, net.alignments]
-optim = torch.optim.Adam(params, lr=5e-4)
-for _ in range(2):
+optim = torch.optim.Adam(params, lr=2e-4)
+for _ in range(3):
     loss.train_step(batch, optim)
 torch.cuda.synchronize()
-ts = []
-for _ in range(6):
+ts, totals, alive = [], [], []
+for _ in range(ITERS):
     t0 = time.perf_counter()
     terms, total = loss.train_step(batch, optim)
     torch.cuda.synchronize()
     ts.append(time.perf_counter() - t0)
+    totals.append(total)
+    alive.append(bool(loss.last['alive']))
 ms = sorted(ts)[len(ts) // 2] * 1e3
-print(json.dumps({"rays": R, "hit_rays": int(hit.sum()), "body": [6890, int(faces.shape[0])], "samples": {"bkg": [128, 256], "human": 128},
-                  "ms_per_iteration": ms, "iterations_per_s": 1e3 / ms, "total_loss": total, "terms": terms}))
+first, last = sum(totals[:5]) / 5, sum(totals[-5:]) / 5
+line = {"rays": R, "hit_rays": int(hit.sum()), "body": [6890, int(faces.shape[0])], "samples": {"bkg": [128, 256], "human": 128},
+        "ms_per_iteration": ms, "iterations_per_s": 1e3 / ms, "iterations_timed": ITERS, "alive_on_every_timed_iteration": all(alive),
+        "total_loss_first5_mean": first, "total_loss_last5_mean": last, "total_loss_first": totals[0], "total_loss_last": totals[-1], "terms_last": terms,
+        "learning_rate": 2e-4, "target": "the batch rendered through a second frozen human net (seed 9, dense preset)"}
+print(json.dumps(line), flush=True)
+assert all(alive), "the human net died during the timed iterations"
+assert all(v == v for v in totals) and last < first, (first, last)
