@@ -356,7 +356,6 @@ class _MLP(torch.autograd.Function):
                         _gemm(0, 1, n4, pk.kp, width, dz32[slot], width, pk.W[i][0], pk.kp, dX0, pk.kp, flags=0 if first else ACC)
                         first = False
         elif use_chain:
-            import ctypes
             from_feat = views and d_feat is not None
             ns = 8 if from_feat else 7
             if not from_feat:
