@@ -782,7 +782,14 @@ def render_vanilla(coarse_net, cap, fine_net=None, rays_per_batch=32768, samples
                    white_bkg=True, near_far_source='bkg', return_depth=False, ablate_nerft=False):
     """reference render_utils.py:108-161."""
     device = _device_of(coarse_net)
-    if ablate_nerft:
+    if ablate_nerft and not NERFT_GEMM_CHAIN:
+        # the frame's time is one constant (render_utils.py:134-148): the 4-D-encoding nets at that time ARE 3-D-encoding nets with two
+        # other bias vectors (vanilla.frozen_time_joiner) -- everything below, sharding included, is the ordinary path on the MFMA kernels
+        from . import vanilla
+        cur_time = cap.frame_id['frame_id'] / cap.frame_id['total_frames']
+        coarse_net = vanilla.frozen_time_joiner(coarse_net, cur_time)
+        fine_net = vanilla.frozen_time_joiner(fine_net, cur_time) if fine_net is not None else None
+    elif ablate_nerft:
         return _render_vanilla_with_time(coarse_net, cap, fine_net, samples_per_ray, importance_samples_per_ray, white_bkg, near_far_source,
                                          return_depth, device)
     with torch.no_grad():
@@ -795,6 +802,11 @@ def render_vanilla(coarse_net, cap, fine_net=None, rays_per_batch=32768, samples
         rgb = rgb.reshape(*cap.shape, -1).cpu().numpy()
         depth = depth.reshape(*cap.shape).cpu().numpy()
     return (rgb, depth) if return_depth else rgb
+
+
+# NEUMAN_NERFT_GEMM=1: render_vanilla(ablate_nerft=True) sample by sample with the time as a fourth input coordinate on the float32 GEMM chain
+# (the form that also serves a time varying from sample to sample) instead of the folded-time nets on the MFMA kernels
+NERFT_GEMM_CHAIN = os.environ.get('NEUMAN_NERFT_GEMM', '0') == '1'
 
 
 def _render_vanilla_with_time(coarse_net, cap, fine_net, samples_per_ray, importance_samples_per_ray, white_bkg, near_far_source, return_depth,

@@ -268,6 +268,72 @@ class Joiner(nn.Module):
         return out
 
 
+def time_columns(pe):
+    """Of a space-time posenc Embedder (input_dims = 4: x, y, z, t; vanilla.py:60-79 layout [v, sin(f_0 v), cos(f_0 v), ...] with v the 4-vector):
+    -> (columns of the three spatial coordinates in the order of the 3-D encoding, columns of the time coordinate)"""
+    if pe.mapping != 'posenc' or pe.input_dims != 4:
+        raise _lib.NeumanHipError("time_columns: a 4-D posenc encoding is expected (raw_pos_dim = 4)")
+    N = pe.N_freqs
+    spatial = [0, 1, 2] + [4 + 8 * b + k for b in range(N) for k in (0, 1, 2, 4, 5, 6)]
+    timecol = [3] + [4 + 8 * b + k for b in range(N) for k in (3, 7)]
+    return spatial, timecol
+
+
+def time_encoding(pe, t):
+    """the encoded time coordinate alone, in the order of time_columns()[1]: [t, sin(f_0 t), cos(f_0 t), ...] with the float32 arguments the
+    reference forms (vanilla.py:73-76)"""
+    bands = pe.table().astype(np.float32)
+    tt = np.float32(t)
+    out = [float(tt)]
+    for b in range(pe.N_freqs):
+        a = np.float64(np.float32(tt * bands[b]))
+        out += [float(np.sin(a)), float(np.cos(a))]
+    return np.asarray(out, np.float64)
+
+
+def frozen_time_joiner(joiner, t):
+    """The time-conditioned net of `--ablate_nerft` (raw_pos_dim = 4: every sample point carries the frame's time, ray_utils.py:133-134,
+    158-159) at ONE time t, as an ordinary 3-D-position Joiner the fused MFMA kernels evaluate.
+
+    Within a rendered frame the time is a constant (render_utils.py:134-148: `ones * cur_time`), so the 21 encoded-time inputs of layer 0
+    and of the skip layer contribute a constant vector to those layers' pre-activations: W[:, time columns] . pe(t), folded into the
+    bias.  What is left is exactly the reference's 3-D network shape (63-wide encoding, the same hidden weights -- shared, not copied)
+    with two bias vectors that depend on t.  Cached per (weights version, t): a sequence rendered frame by frame repacks two bias
+    vectors' worth of images per frame."""
+    pe = joiner.pos_pe
+    key = (joiner._key(), float(t))
+    cache = joiner.__dict__.setdefault('_frozen_time', {})
+    if key in cache:
+        return cache[key]
+    spatial, timecol = time_columns(pe)
+    n = joiner.nerf
+    with torch.no_grad():
+        pe3 = Embedder(3, pe.max_freq, pe.N_freqs, pe.log_sampling, pe.include_input, min_freq=pe.min_freq, mapping='posenc')
+        nerf = NeRF(depth=n.depth, width=n.width, input_ch=pe3.out_dim, input_ch_views=n.input_ch_views, use_viewdirs=n.use_viewdirs, skips=list(n.skips),
+                    output_ch=(n.output_linear.out_features if not n.use_viewdirs else 4))
+        dev = n.pts_linears[0].weight.device
+        pt = torch.as_tensor(time_encoding(pe, t), dtype=torch.float64, device=dev)
+        sp, tc = torch.as_tensor(spatial, device=dev), torch.as_tensor(timecol, device=dev)
+        for i, lin in enumerate(n.pts_linears):
+            takes_pe = i == 0 or (i - 1) in n.skips
+            if not takes_pe:
+                nerf.pts_linears[i] = lin                                  # shared: the same Parameter objects
+                continue
+            w = lin.weight.detach()
+            new = nn.Linear(pe3.out_dim + (0 if i == 0 else n.width), n.width)
+            new.weight.copy_(torch.cat([w[:, sp], w[:, pe.out_dim:]], 1) if i else w[:, sp])
+            new.bias.copy_((lin.bias.detach().double() + w[:, tc].double() @ pt).to(torch.float32))
+            nerf.pts_linears[i] = new.to(dev)
+        for name in (('views_linears', 'feature_linear', 'alpha_linear', 'rgb_linear') if n.use_viewdirs else ('output_linear',)):
+            setattr(nerf, name, getattr(n, name))
+        out = Joiner(pe3, joiner.dir_pe, nerf).to(dev).eval()
+        out.precision = joiner.precision
+    while len(cache) >= 4:
+        cache.pop(next(iter(cache)))
+    cache[key] = out
+    return out
+
+
 class OffsetNet(nn.Module):
     """reference vanilla.py:169-178: space-time encoding + a NeRF trunk without view directions, used by the human trainer only
     (human_nerf_trainer.py:261).  Training-only here: it runs on the differentiable float32 path (neuman_hip/train.py)."""
