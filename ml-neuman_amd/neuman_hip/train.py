@@ -69,35 +69,82 @@ def _pad_rows(w, rows, at=0):
 
 
 class _Packed:
-    """The parameters in the shapes the products want (reference layout [out, in], inputs padded to multiples of 4)."""
+    """The parameters in the shapes the products want (reference layout [out, in], inputs padded to multiples of 4) -- each made on first
+    use: the fused forward / backward read the live parameters themselves and need a handful of these at most."""
 
     def __init__(self, nerf, n_pos, n_dir):
-        with torch.no_grad():
-            self.n_pos, self.n_dir = n_pos, n_dir                               # 63 / 84, 27
-            self.kp, self.kd = (n_pos + 3) // 4 * 4, (n_dir + 3) // 4 * 4       # 64 / 84, 28
-            self.W, self.b = [], []
-            for i, lin in enumerate(nerf.pts_linears):
-                w = lin.weight.detach().float()
-                if i == 0:
-                    self.W.append((_pad_cols(w, self.kp),))
-                elif w.shape[1] == nerf.width + n_pos:                           # the layer after the skip: cat([x_pe, h]) (vanilla.py:130)
-                    self.W.append((_pad_cols(w[:, :n_pos], self.kp), w[:, n_pos:].contiguous()))
-                else:
-                    self.W.append((w.contiguous(),))
-                self.b.append(lin.bias.detach().float().contiguous())
-            if nerf.use_viewdirs:
-                wv = nerf.views_linears[0].weight.detach().float()               # cat([feature, d_pe]) (vanilla.py:139)
-                self.Wv = (wv[:, :nerf.width].contiguous(), _pad_cols(wv[:, nerf.width:], self.kd))
-                self.bv = nerf.views_linears[0].bias.detach().float().contiguous()
-                self.Wf, self.bf = nerf.feature_linear.weight.detach().float().contiguous(), nerf.feature_linear.bias.detach().float().contiguous()
-                self.Wa4 = _pad_rows(nerf.alpha_linear.weight.detach().float(), 4, at=3)    # raw[:, 3] = sigma
-                self.Wr4 = _pad_rows(nerf.rgb_linear.weight.detach().float(), 4)            # raw[:, :3] = rgb
-                self.b4 = torch.cat([nerf.rgb_linear.bias.detach().float(), nerf.alpha_linear.bias.detach().float()]).contiguous()
-            else:                                                                # output_linear, <= 4 outputs (vanilla.py:117, 150)
-                self.n_out = nerf.output_linear.weight.shape[0]
-                self.Wo4 = _pad_rows(nerf.output_linear.weight.detach().float(), 4)
-                self.bo4 = torch.zeros(4, device=self.Wo4.device)
-                self.bo4[:self.n_out] = nerf.output_linear.bias.detach().float()
+        self.nerf = nerf
+        self.n_pos, self.n_dir = n_pos, n_dir                               # 63 / 84, 27
+        self.kp, self.kd = (n_pos + 3) // 4 * 4, (n_dir + 3) // 4 * 4       # 64 / 84, 28
+        self.n_layers = len(nerf.pts_linears)
+        self.skip = [i > 0 and lin.weight.shape[1] == nerf.width + n_pos for i, lin in enumerate(nerf.pts_linears)]   # the layer after the skip: cat([x_pe, h]) (vanilla.py:130)
+        if not nerf.use_viewdirs:
+            self.n_out = nerf.output_linear.weight.shape[0]                  # output_linear, <= 4 outputs (vanilla.py:117, 150)
+        self._c = {}
+
+    def _get(self, key, make):
+        if key not in self._c:
+            with torch.no_grad():
+                self._c[key] = make()
+        return self._c[key]
+
+    def Wpe(self, i):
+        """[width, kp]: the encoded-position columns of layer 0 / of the skip layer, zero-padded"""
+        return self._get(('pe', i), lambda: _pad_cols(self.nerf.pts_linears[i].weight.detach().float()[:, :self.n_pos], self.kp))
+
+    def Wh(self, i):
+        """[width, width]: the hidden columns of layer i >= 1"""
+        w = self.nerf.pts_linears[i].weight
+        return self._get(('h', i), lambda: w.detach().float()[:, self.n_pos:].contiguous() if self.skip[i] else w.detach().float().contiguous())
+
+    def b(self, i):
+        return self._get(('b', i), lambda: self.nerf.pts_linears[i].bias.detach().float().contiguous())
+
+    @property
+    def W(self):                                                             # the GEMM chain's view: per layer (W,) or, after the skip, (W_pe, W_hidden)
+        return [(self.Wpe(i),) if i == 0 else ((self.Wpe(i), self.Wh(i)) if self.skip[i] else (self.Wh(i),)) for i in range(self.n_layers)]
+
+    @property
+    def Wv(self):
+        n = self.nerf
+        return self._get('Wv', lambda: (n.views_linears[0].weight.detach().float()[:, :n.width].contiguous(),       # cat([feature, d_pe]) (vanilla.py:139)
+                                        _pad_cols(n.views_linears[0].weight.detach().float()[:, n.width:], self.kd)))
+
+    @property
+    def bv(self):
+        return self._get('bv', lambda: self.nerf.views_linears[0].bias.detach().float().contiguous())
+
+    @property
+    def Wf(self):
+        return self._get('Wf', lambda: self.nerf.feature_linear.weight.detach().float().contiguous())
+
+    @property
+    def bf(self):
+        return self._get('bf', lambda: self.nerf.feature_linear.bias.detach().float().contiguous())
+
+    @property
+    def Wa4(self):
+        return self._get('Wa4', lambda: _pad_rows(self.nerf.alpha_linear.weight.detach().float(), 4, at=3))           # raw[:, 3] = sigma
+
+    @property
+    def Wr4(self):
+        return self._get('Wr4', lambda: _pad_rows(self.nerf.rgb_linear.weight.detach().float(), 4))                   # raw[:, :3] = rgb
+
+    @property
+    def b4(self):
+        return self._get('b4', lambda: torch.cat([self.nerf.rgb_linear.bias.detach().float(), self.nerf.alpha_linear.bias.detach().float()]).contiguous())
+
+    @property
+    def Wo4(self):
+        return self._get('Wo4', lambda: _pad_rows(self.nerf.output_linear.weight.detach().float(), 4))
+
+    @property
+    def bo4(self):
+        def make():
+            out = torch.zeros(4, device=self.nerf.output_linear.weight.device)
+            out[:self.n_out] = self.nerf.output_linear.bias.detach().float()
+            return out
+        return self._get('bo4', make)
 
 
 def _encode(emb, x, ld):
@@ -194,9 +241,9 @@ class _MLP(torch.autograd.Function):
             o = torch.empty((n4, width), device=dev, dtype=torch.float32)
             if len(Ws) == 2:                                                     # skip layer: x_pe W_a^T, then + h W_b^T + b, ReLU
                 _gemm(0, 0, n4, width, pk.kp, X0, pk.kp, Ws[0], pk.kp, o, width)
-                _gemm(0, 0, n4, width, width, h, width, Ws[1], width, o, width, bias=pk.b[i], flags=ACC | BIAS | RELU)
+                _gemm(0, 0, n4, width, width, h, width, Ws[1], width, o, width, bias=pk.b(i), flags=ACC | BIAS | RELU)
             else:
-                _gemm(0, 0, n4, width, kh, h, kh, Ws[0], kh, o, width, bias=pk.b[i], flags=BIAS | RELU)
+                _gemm(0, 0, n4, width, kh, h, kh, Ws[0], kh, o, width, bias=pk.b(i), flags=BIAS | RELU)
             H.append(o)
             h, kh = o, width
         raw = torch.empty((n4, 4), device=dev, dtype=torch.float32)
@@ -273,7 +320,7 @@ class _MLP(torch.autograd.Function):
         h7 = None if use16 else H[-1]
         dX0 = dD0 = None
         dz = None if use16 else torch.empty((n4, width), device=dev, dtype=torch.float32)
-        use_chain = use16 or (FUSED_BACKWARD and getattr(ctx, 'acts', None) is not None and len(pk.W) == 8 and width == 256)
+        use_chain = use16 or (FUSED_BACKWARD and getattr(ctx, 'acts', None) is not None and pk.n_layers == 8 and width == 256)
         d_feat = None
         if views:
             g = {}
@@ -303,7 +350,7 @@ class _MLP(torch.autograd.Function):
         else:
             head = [wgrad(d_raw, 4, h7, width)[:pk.n_out].contiguous(), bgrad(d_raw, 4)[:pk.n_out].contiguous()]
             _gemm(0, 1, n4, width, 4, d_raw, 4, pk.Wo4, width, dz, width, mask=h7, ldmask=width, flags=MASK | COLSUM, ws=cs_buf)
-        gw, gb = [None] * len(pk.W), [None] * len(pk.W)
+        gw, gb = [None] * pk.n_layers, [None] * pk.n_layers
         chain = None
         if use16:
             lib = _lib.lib()
@@ -325,7 +372,7 @@ class _MLP(torch.autograd.Function):
                                                    _lib.dev_ptr(ws[0]), ws[0].numel(), _lib.stream_ptr()), "nm_mlp_backward_chain16")
             for i in range(8):
                 gb[i] = gbs[7 - i]
-                gw[i] = torch.empty((width, (n_pos if i == 0 else width) + (n_pos if len(pk.W[i]) == 2 else 0)), device=dev, dtype=torch.float32)
+                gw[i] = torch.empty((width, (n_pos if i == 0 else width) + (n_pos if pk.skip[i] else 0)), device=dev, dtype=torch.float32)
 
             def products(q_cols, items):                                         # items: (dz16 rows, activation rows, gradient, column offset)
                 k = len(items)
@@ -340,9 +387,9 @@ class _MLP(torch.autograd.Function):
 
             # the eight 256 x 256 products of the net in one launch: feature_linear, then the hidden columns of layers 7 .. 1
             products(width, [(dfeat16, h16[7], g['feature_w'], 0)] +
-                     [(dz16[7 - i], h16[i - 1], gw[i], n_pos if len(pk.W[i]) == 2 else 0) for i in range(7, 0, -1)])
+                     [(dz16[7 - i], h16[i - 1], gw[i], n_pos if pk.skip[i] else 0) for i in range(7, 0, -1)])
             # ... and the encoded-position columns of layer 0 and of the skip layer in another
-            products(n_pos, [(dz16[7 - i], x0h, gw[i], 0) for i in range(8) if i == 0 or len(pk.W[i]) == 2])
+            products(n_pos, [(dz16[7 - i], x0h, gw[i], 0) for i in range(8) if i == 0 or pk.skip[i]])
             need = int(lib.nm_wgrad_alpha16_workspace_floats(n4))
             if need > ws[0].numel():
                 ws[0] = torch.empty(need, device=dev, dtype=torch.float32)
@@ -352,8 +399,8 @@ class _MLP(torch.autograd.Function):
                 dX0 = torch.empty((n4, pk.kp), device=dev, dtype=torch.float32)
                 first = True
                 for i, slot in ((5, 0), (0, 1)):
-                    if i == 0 or len(pk.W[i]) == 2:
-                        _gemm(0, 1, n4, pk.kp, width, dz32[slot], width, pk.W[i][0], pk.kp, dX0, pk.kp, flags=0 if first else ACC)
+                    if i == 0 or pk.skip[i]:
+                        _gemm(0, 1, n4, pk.kp, width, dz32[slot], width, pk.Wpe(i), pk.kp, dX0, pk.kp, flags=0 if first else ACC)
                         first = False
         elif use_chain:
             from_feat = views and d_feat is not None
@@ -375,10 +422,11 @@ class _MLP(torch.autograd.Function):
                 dz, gb[7] = chain[0], gbs[0]
             for i in range(7):
                 gb[i] = gbs[off + 6 - i]
-        for i in range(len(pk.W) - 1, -1, -1):
+        W_all = None if use16 else pk.W
+        for i in range(pk.n_layers - 1, -1, -1):
             if use16:
                 break
-            Ws = pk.W[i]
+            Ws = W_all[i]
             if chain is None:
                 gb[i] = band_sum(width)                                          # of dz: left in cs_buf by the product that made it
             elif i < 7:
@@ -403,7 +451,7 @@ class _MLP(torch.autograd.Function):
                 _gemm(0, 1, n4, width, width, dz, width, Wb, width, nz, width, mask=prev, ldmask=width, flags=MASK | COLSUM, ws=cs_buf)
                 dz = nz
         grads = []
-        for i in range(len(pk.W)):
+        for i in range(pk.n_layers):
             grads += [gw[i].contiguous(), gb[i].contiguous()]
         grads += head
         d_pts = _encode_backward(net.pos_pe, ctx.p4, dX0)[:n] if want_in else None

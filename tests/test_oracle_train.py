@@ -16,6 +16,20 @@ def G():
     return dict(np.load(os.path.join(ROOT, "tests", "golden", "train.npz")))
 
 
+def grad_errors(grads, g, prefix):
+    """per parameter tensor: the larger of check_grads' two deviations (three full rows; sum / sum of magnitudes / a fixed random projection)"""
+    out = {}
+    for name, gr in grads.items():
+        gr = np.asarray(gr, np.float64).reshape(gr.shape[0], -1)
+        rows = sorted({0, gr.shape[0] // 2, gr.shape[0] - 1})
+        ref_rows, stats = g[f'{prefix}/{name}/rows'], g[f'{prefix}/{name}/stats']
+        scale = max(np.abs(gr).max(), 1e-12)
+        proj = np.random.default_rng(sum(map(ord, name))).normal(size=gr.size)
+        mine = np.array([gr.sum(), np.abs(gr).sum(), float(gr.reshape(-1) @ proj)])
+        out[name] = max(float(np.abs(gr[rows] - ref_rows).max() / scale), float(np.abs(mine - stats).max() / max(np.abs(gr).sum(), 1e-12)))
+    return out
+
+
 def check_grads(grads, g, prefix, tol=1e-4):
     """per parameter tensor: three full rows, the sum, the sum of magnitudes and a fixed random projection"""
     worst = 0.0
