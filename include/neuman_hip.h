@@ -189,21 +189,31 @@ int nm_mlp_backward_chain(nm_mlp_t mlp, const float* const* dev_params, const fl
                           const float* acts, const uint32_t* relu_bits, int64_t n, float* dz_out, float* bias_grads, float* workspace,
                           int64_t workspace_floats, nm_stream_t stream);
 /* The 16-bit form of the two calls above (round 5): what a training step keeps between its forward and backward pass -- the reference's autograd
- * keeps every layer's float32 output (models/vanilla.py:126-131 under trainers/vanilla_nerf_trainer.py:45-96) -- is stored as fp16 wherever it is only
+ * keeps every layer's float32 output (models/vanilla.py:126-141 under trainers/vanilla_nerf_trainer.py:45-96) -- is stored as fp16 wherever it is only
  * an operand of a weight-gradient product (a sum over all samples: the 2^-12 roundings of independent samples average out):
  *   nm_mlp_forward_save16: save_h16 [8][n][256] = fp16 of 32 x (output of pts_linears[l], after ReLU) -- the very hi part the next layer's MFMA reads --
  *     in K-SLOT ORDER: 16-byte chunk c, element e of a row holds feature 32 (c >> 2) + 8 (2 ((c >> 1) & 1) + (e >> 2)) + 4 (c & 1) + (e & 3)
- *     (mlp_layout.h slot_feature: the order the producing lanes hold them); save_feat [n][256], save_hv [n][128] float32 as before; save_bits required.
+ *     (mlp_layout.h slot_feature: the order the producing lanes hold them); feature_linear's output as save_feat [n][256] float32 and / or save_feat16
+ *     [n][256] fp16 (x 32, k-slot order) (one of them required); save_hv [n][128] float32; save_bits [8][n][8] required; save_hvbits (nullable) [n][4]:
+ *     the signs of the views layer's output, word f >> 5, bit order as save_bits.
  *   nm_mlp_backward_chain16: from d_feat / d_raw as nm_mlp_backward_chain's second form; dz16 [8][n][256] = fp16 of s x dZ_7 .. dZ_0 in k-slot order,
  *     dfeat16 (nullable) [n][256] = s x d_feat likewise, s = the power of two that puts *amax into [2, 4) (amax: a device scalar >= the largest magnitude
- *     of d_feat and d_raw, nm_absmax; values beyond fp16's range saturate); dz32_layer5 / dz32_layer0 (nullable): float32 copies, natural order, of the
- *     two layers whose encoded-input products / input gradients still want one; bias_grads [8][256] from the unrounded values.
- *   The consumers: nm_wgrad16, nm_wgrad_alpha16 below (section "training"). */
-int nm_mlp_forward_save16(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, uint16_t* save_h16, float* save_feat, float* save_hv,
-                          uint32_t* save_bits, float* out, nm_stream_t stream);
+ *     entering the chain, nm_absmax; values beyond fp16's range saturate); dz32_layer5 / dz32_layer0 (nullable): float32 copies, natural order, of the
+ *     two layers whose input-gradient products still want one; bias_grads [8][256] from the unrounded values.
+ *   nm_mlp_backward_net16: the WHOLE backward-data pass of the net from d_raw [n][4] in one kernel -- autograd's adjoint of models/vanilla.py:133-145 too:
+ *         d_hv = (d_rgb W_rgb) * (hv > 0)      d_feat = d_hv W_views[:, :256]      dZ_7 = (d_feat W_feature + d sigma w_alpha) * (H_7 > 0)  ...
+ *     with the tile's d_hv and d_feat kept on chip.  amax >= max |d_raw| (the scale has 2^13 of headroom for growth through the layers).  Outputs as
+ *     above plus dhv16 [n][128] (fp16 of s x d_hv, k-slot order of a 128-wide row: the views layer's weight-gradient operand), dhv32 (nullable) [n][128]
+ *     float32 natural order (for the view-direction gradient); bias_grads [9][256]: rows 0..7 = layers 7..0, row 8 = feature_linear's.
+ *   Workspace of nm_mlp_backward_chain_workspace_floats(n) floats each.  The consumers: nm_wgrad16, nm_wgrad_alpha16 below (section "training"). */
+int nm_mlp_forward_save16(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, uint16_t* save_h16, float* save_feat, uint16_t* save_feat16,
+                          float* save_hv, uint32_t* save_bits, uint32_t* save_hvbits, float* out, nm_stream_t stream);
 int nm_mlp_backward_chain16(nm_mlp_t mlp, const float* const* dev_params, const float* d_feat, const float* d_raw, const uint32_t* relu_bits,
                             int64_t n, const float* amax, uint16_t* dz16, uint16_t* dfeat16, float* dz32_layer5, float* dz32_layer0,
                             float* bias_grads, float* workspace, int64_t workspace_floats, nm_stream_t stream);
+int nm_mlp_backward_net16(nm_mlp_t mlp, const float* const* dev_params, const float* d_raw, const uint32_t* relu_bits, const uint32_t* hv_bits,
+                          int64_t n, const float* amax, uint16_t* dz16, uint16_t* dfeat16, uint16_t* dhv16, float* dz32_layer5, float* dz32_layer0,
+                          float* dhv32, float* bias_grads, float* workspace, int64_t workspace_floats, nm_stream_t stream);
 /* Same with ray_to_samples' point construction fused: sample (r,s) is at origin[r] + direction[r]*z[r,s]
  * with view direction direction[r] (ray_utils.py:131-132); out [R,S,4]. */
 int nm_mlp_forward_rays(nm_mlp_t mlp, const float* origin, const float* direction, const float* z_vals,
@@ -507,20 +517,22 @@ int nm_gemm_fp16x3(int a_kmajor, int b_kmajor, int M, int N, int K, const float*
                    int64_t workspace_floats, nm_stream_t stream);
 int nm_pe_encode(const float* x, int64_t n, int dims, int kind, int n_freqs, const float* table, float* out, int ld,
                  nm_stream_t stream);
-/* nm_pe_encode with the output as fp16 of 32 x value (an operand of nm_wgrad16; ld a multiple of 8, out 16-byte aligned) */
-int nm_pe_encode16(const float* x, int64_t n, int dims, int kind, int n_freqs, const float* table, uint16_t* out, int ld,
+/* nm_pe_encode with the output as fp16 of 32 x value (an operand of nm_wgrad16; ld a multiple of 8, out 16-byte aligned).  ones_col >= 0 (a padding
+ * column of the row): that column holds 1 (x 32) -- the product with it is the column sum of the other operand, i.e. the layer's bias gradient */
+int nm_pe_encode16(const float* x, int64_t n, int dims, int kind, int n_freqs, const float* table, uint16_t* out, int ld, int ones_col,
                    nm_stream_t stream);
 /* *out_max = max(*out_max, max |x[i]|), i < count: device scalar, updated atomically (zero it first); x 16-byte aligned */
 int nm_absmax(const float* x, int64_t count, float* out_max, nm_stream_t stream);
 /* Backward-weights from 16-bit operands, nprod <= 8 products of one n in ONE launch (+ one deterministic reduction):
- *     dW_p [256][q_cols] = (1 / (32 s)) sum_n dz16_p[n][:]^T act16_p[n][:]          (s from *amax as in nm_mlp_backward_chain16)
- * dz16_p [n][256] fp16 in k-slot order; q_cols == 256: act16_p [n][256] fp16 in k-slot order (nm_mlp_forward_save16's save_h16[l], or dfeat16 x
- * save_h16[7] for feature_linear); q_cols <= 64: act16_p [n][64] fp16 in natural order (nm_pe_encode16, zero beyond the encoding).  dW_p in the
- * natural [out][in] order of nn.Linear, row stride ldw[p] (so the hidden columns of the skip layer land inside its [256][319] gradient).
- * One fp16 MFMA per product, 1 KB per sample and 256-wide product.  dz16 / act16 / dW / ldw: HOST arrays of nprod entries. */
-int64_t nm_wgrad16_workspace_floats(int nprod, int64_t n, int q_cols);
-int nm_wgrad16(int nprod, int q_cols, const uint16_t* const* dz16, const uint16_t* const* act16, float* const* dW, const int* ldw, int64_t n,
-               const float* amax, float* workspace, int64_t workspace_floats, nm_stream_t stream);
+ *     dW_p [p_cols][q_cols] = (1 / (32 s)) sum_n dz16_p[n][:]^T act16_p[n][:]          (s from *amax as in nm_mlp_backward_chain16)
+ * dz16_p [n][p_cols] fp16 in k-slot order, p_cols = 256 (a trunk layer, feature_linear) or 128 (the views layer: dhv16); q_cols == 256: act16_p
+ * [n][256] fp16 in k-slot order (nm_mlp_forward_save16's save_h16[l] / save_feat16); q_cols <= 64: act16_p [n][64] fp16 in natural order
+ * (nm_pe_encode16, zero beyond the encoding).  dW_p in the natural [out][in] order of nn.Linear, row stride ldw[p] (so the hidden columns of the skip
+ * layer land inside its [256][319] gradient).  One fp16 MFMA per product, 1 KB per sample and 256 x 256 product.  dz16 / act16 / dW / ldw: HOST arrays
+ * of nprod entries. */
+int64_t nm_wgrad16_workspace_floats(int nprod, int64_t n, int p_cols, int q_cols);
+int nm_wgrad16(int nprod, int p_cols, int q_cols, const uint16_t* const* dz16, const uint16_t* const* act16, float* const* dW, const int* ldw,
+               int64_t n, const float* amax, float* workspace, int64_t workspace_floats, nm_stream_t stream);
 /* alpha_linear's weight gradient out[256] = sum_n d_raw[n][3] H7[n][:] from save_h16[7] (x 32, k-slot order) */
 int64_t nm_wgrad_alpha16_workspace_floats(int64_t n);
 int nm_wgrad_alpha16(const float* d_raw, const uint16_t* h16, int64_t n, float* out, float* workspace, int64_t workspace_floats,

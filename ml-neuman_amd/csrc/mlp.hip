@@ -188,7 +188,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
             }
             bias_prefetch(B, a.bias + nm::stage_b_off(9) + 32 * (w & 3), g);
             NM_TICK(1)
-            if (SAVE) {
+            if (SAVE == 1 || (SAVE == 2 && a.save_h)) {
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb)
                     save_block(SAVE == 2 ? a.save_h : a.save_h + (int64_t)8 * a.n * 256, 256, acc[mb], w, base + 32 * mb + s, acc2out(8), false);
@@ -199,6 +199,17 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
             __syncthreads();
             NM_TICK(2)
             write_act<4, PREC>(ar, lds, w, 0, g, s);
+            if (SAVE == 2 && F16 && a.save_feat16) {                      // the feature layer's output as the views layer reads it: fp16(32 x), k-slot order
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    const int64_t row = base + 32 * mb + s;
+                    if (row < a.n) {
+                        uint4* o = a.save_feat16 + row * 32 + 4 * w + g;
+                        o[0] = ar.hi[mb][0];
+                        o[2] = ar.hi[mb][1];
+                    }
+                }
+            }
             NM_TICK(3)
             __syncthreads();
             NM_TICK(4)
@@ -226,6 +237,18 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
             if (SAVE) {
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) save_block(a.save_hv, 128, vacc[mb], nb, base + row0 + 32 * mb + s, acc2out(9), true);
+                if (SAVE == 2 && a.save_hvbits) {                          // (the trunk's bit order: register r of lane half g = bit 16 g + 15 - r)
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        unsigned bits = 0;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) bits = bits + bits + (vacc[mb][r] > 0.f ? 1u : 0u);
+                        bits <<= 16 * g;
+                        bits |= (unsigned)__shfl_xor((int)bits, 32, 64);
+                        const int64_t row = base + row0 + 32 * mb + s;
+                        if (g == 0 && row < a.n) a.save_hvbits[row * 4 + nb] = bits;
+                    }
+                }
             }
             ActRegs<2> ar;
             convert_act<2, true, PREC>(vacc, ar, acc2act(9));
@@ -840,6 +863,7 @@ int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, con
     a.out = out; a.dbg = dbg; a.prof = reinterpret_cast<unsigned long long*>(prof); a.n = n; a.S = S; a.in_mode = in_mode; a.stop_stage = stop_stage; a.sigma_scale = sigma_scale;
     a.sigma_only = L.plain_head ? 2 : ((sigma_only && precision != NM_PREC_I8X3) ? 1 : 0);   // (the i8x3 kernel always evaluates the colour head)
     a.save_h = L.save_h; a.save_hv = L.save_hv; a.save_bits = L.save_bits; a.save_h16 = reinterpret_cast<uint4*>(L.save_h16);
+    a.save_feat16 = reinterpret_cast<uint4*>(L.save_feat16); a.save_hvbits = L.save_hvbits;
     a.pos = PeSpec{L.pe_kind, L.pos_nfreq, L.pos_octaves};
     a.dir = PeSpec{L.pe_kind, L.dir_nfreq, L.dir_octaves};
     const int64_t ntiles = (n + kTileM - 1) / kTileM;
@@ -858,7 +882,7 @@ int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, con
         else hipLaunchKernelGGL(nerf_mlp_i8w_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, a8);
         return check_launch("nerf_mlp_i8w_kernel");
     }
-    if (L.save_h) {                                               // the training forward: split fp16, the full head, activations kept
+    if (L.save_h || L.save_h16) {                                 // the training forward: split fp16, the full head, activations kept
         if (L.save_h16) hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_FP16X3, false, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
         else hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_FP16X3, false, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
         return check_launch("nerf_mlp_kernel (save)");

@@ -20,7 +20,9 @@ namespace {
 constexpr int kBwdStages = 7;                                       // trunk layers 7 .. 1
 constexpr int kBwdSlots = kBwdStages + 1;                           // + the head stage (feature_linear), image slot 0
 constexpr int kBwdStageBytes = 8 * 16 * nm::kStepBytes;            // 8 output blocks x 16 k-steps
-constexpr int kBwdImageBytes = kBwdSlots * kBwdStageBytes;
+constexpr int kBwdVBytes = 8 * 8 * nm::kStepBytes;                  // the views-back stage d_feat = d_hv W_views[:, :256]: 8 output blocks x 8 k-steps (K = 128)
+constexpr int kBwdVOff = kBwdSlots * kBwdStageBytes;
+constexpr int kBwdImageBytes = kBwdVOff + kBwdVBytes;
 constexpr int kBwdPadBytes = 4 * nm::kStepBytes;                   // the weight pipeline prefetches two steps past a run's end
 
 struct BwdArgs {
@@ -41,6 +43,12 @@ struct BwdArgs {
     uint4* dfeat16;            // HEAD, nullable: d_feat the same way, [n][32]
     const float* amax;
     float* dz32[8];            // by layer, nullable each
+    // the whole backward pass of the net from d_raw (MODE 2, nm_mlp_backward_net16): the views layer's adjoint is formed in the kernel --
+    //     d_hv = (d_rgb W_rgb) * (hv > 0)   [128]   ->   d_feat = d_hv W_views[:, :256]   ->   the chain above
+    const unsigned* hvbits;    // [n][4] signs of the views layer's output (nm_mlp_forward_save16)
+    const float* w_rgb;        // rgb_linear.weight [3][128]
+    uint4* dhv16;              // [n][16] fp16 of d_hv * scale, k-slot order of a 128-wide row
+    float* dhv32;              // nullable: [n][128] float32, natural order (the view-direction gradient's product)
 };
 
 __device__ __forceinline__ unsigned pack_f16(float a, float b, float sc) {
@@ -48,8 +56,9 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b, float sc) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
 
-template <bool HEAD>
+template <int MODE>                                                 // 0: from dz_top = dZ_7; 1: from d_feat / d_raw; 2: from d_raw alone (the views layer's adjoint too)
 __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs a) {
+    constexpr bool HEAD = MODE >= 1, NET = MODE == 2;
     constexpr int NS = HEAD ? kBwdSlots : kBwdStages;               // stages of a tile; stage s reads image slot s + (HEAD ? 0 : 1)
     __shared__ uint4 lds[LDS_U4];
     constexpr int PREC = NM_PREC_BF16X3;
@@ -61,11 +70,91 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
     auto wo = [](int j, int blk) { return (j + (HEAD ? 0 : 1)) * kBwdStageBytes + blk * 16 * nm::kStepBytes; };
     const int64_t ntiles = (a.n + kTileM - 1) / kTileM;
     const float sc16 = a.dz16 ? nm_dz_scale(*a.amax) : 1.f;
+    const int vo = kBwdVOff + w * 8 * nm::kStepBytes;               // this wave's block of the views-back stage
+    const int first = NET ? vo : wo(0, w);                          // the first run of a tile
     WPre W;
-    w_prefetch<PREC>(W, wsrc, voff, wo(0, w));
+    w_prefetch<PREC>(W, wsrc, voff, first);
 #pragma unroll 1
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t base = tile * kTileM;
+        if (NET) {
+            // ---- d_hv of the tile: item = (chunk c of the 128-wide row, sample): 8 features slot_feature(c, e), d_hv = sum_k d_rgb[k] W_rgb[k][f], masked
+#pragma unroll 1
+            for (int item = tid; item < 16 * kTileM; item += kThreads) {
+                const int c = item >> 7, row = item & (kTileM - 1);
+                const int64_t i = base + row;
+                const int f0 = nm::slot_feature(c, 0);                  // features f0 .. f0 + 3 and f0 + 8 .. f0 + 11
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (i < a.n) {
+                    const float4 dr = *reinterpret_cast<const float4*>(a.d_raw + i * 4);
+                    const unsigned byte = (a.hvbits[i * 4 + (c >> 2)] >> (16 * (c & 1) + 8 - 8 * ((c >> 1) & 1))) & 0xffu;   // element e = bit 7 - e
+                    const float d3[3] = {dr.x, dr.y, dr.z};
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float4 wa = *reinterpret_cast<const float4*>(a.w_rgb + k * 128 + f0), wb = *reinterpret_cast<const float4*>(a.w_rgb + k * 128 + f0 + 8);
+                        v[0] = fmaf(d3[k], wa.x, v[0]); v[1] = fmaf(d3[k], wa.y, v[1]); v[2] = fmaf(d3[k], wa.z, v[2]); v[3] = fmaf(d3[k], wa.w, v[3]);
+                        v[4] = fmaf(d3[k], wb.x, v[4]); v[5] = fmaf(d3[k], wb.y, v[5]); v[6] = fmaf(d3[k], wb.z, v[6]); v[7] = fmaf(d3[k], wb.w, v[7]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = ((byte >> (7 - e)) & 1u) ? v[e] : 0.f;
+                    a.dhv16[i * 16 + c] = make_uint4(pack_f16(v[0], v[1], sc16), pack_f16(v[2], v[3], sc16), pack_f16(v[4], v[5], sc16), pack_f16(v[6], v[7], sc16));
+                    if (a.dhv32) {
+                        *reinterpret_cast<float4*>(a.dhv32 + i * 128 + f0) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(a.dhv32 + i * 128 + f0 + 8) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                }
+                uint4 hi, lo;
+                split8<false, false>(v, hi, lo);
+                lds[H_BASE + c * kChunkU4 + row] = hi;
+                lds[H_BASE + c * kChunkU4 + kLoU4 + row] = lo;
+            }
+            __syncthreads();
+            // ---- views-back stage: d_feat [32 w .. 32 w + 31][128 samples] = W_views[:, :256]^T block x d_hv (K = 128)
+            f32x16 acc[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+            k_run<4, PREC>(acc, W, wsrc, voff, vo, wo(0, w), lds + H_BASE + g * kChunkU4 + s, 8);
+            float cs[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cs[r] = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const int64_t row = base + 32 * mb + s;
+                const bool live = row < a.n;
+                unsigned pk[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pk[2 * q] = pack_f16(acc[mb][4 * q], acc[mb][4 * q + 1], sc16);
+                    pk[2 * q + 1] = pack_f16(acc[mb][4 * q + 2], acc[mb][4 * q + 3], sc16);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cs[4 * q + j] += live ? acc[mb][4 * q + j] : 0.f;
+                }
+                if (live && a.dfeat16) {
+                    uint4* o = a.dfeat16 + row * 32 + 4 * w + g;
+                    o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    o[2] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = cs[r];
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+                cs[r] = v;
+            }
+            if (s == 0) {                                               // feature_linear's bias gradient: column NS of the per-tile sums
+                float* o = a.colsum + ((int64_t)tile * (NS + 1) + NS) * 256 + 32 * w + 4 * g;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(o + 8 * q) = make_float4(cs[4 * q], cs[4 * q + 1], cs[4 * q + 2], cs[4 * q + 3]);
+            }
+            ActRegs<4> ar;
+            convert_act<4, false, PREC>(acc, ar);
+            __syncthreads();                                           // every wave has finished reading d_hv
+            write_act<4, PREC>(ar, lds, w, 0, g, s);
+            __syncthreads();
+        } else {
         // ---- dZ_7 of the tile -> split bf16 in LDS, k-slot order (chunk c, element e) = feature slot_feature(c, e): two runs of 4 features
 #pragma unroll 1
         for (int item = tid; item < nm::kHChunks * kTileM; item += kThreads) {
@@ -85,6 +174,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                 a.dfeat16[i * 32 + c] = make_uint4(pack_f16(v[0], v[1], sc16), pack_f16(v[2], v[3], sc16), pack_f16(v[4], v[5], sc16), pack_f16(v[6], v[7], sc16));
         }
         __syncthreads();
+        }
 #pragma unroll 1
         for (int j = 0; j < NS; ++j) {
             f32x16 acc[4];
@@ -92,7 +182,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-            k_run<4, PREC>(acc, W, wsrc, voff, wo(j, w), j + 1 < NS ? wo(j + 1, w) : wo(0, w), lds + H_BASE + g * kChunkU4 + s, 16);
+            k_run<4, PREC>(acc, W, wsrc, voff, wo(j, w), j + 1 < NS ? wo(j + 1, w) : first, lds + H_BASE + g * kChunkU4 + s, 16);
             // ---- mask with the saved activation of layer 6 - j, store the f32 copy, column sums
             const int layer = NS - 1 - j;                                // the layer whose saved output masks this stage's result (HEAD, j = 0: 7)
             const float* mask = a.acts + (int64_t)layer * a.n * 256;
@@ -156,7 +246,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                 cs[r] = v;
             }
             if (s == 0) {
-                float* o = a.colsum + ((int64_t)tile * NS + j) * 256 + 32 * w + 4 * g;
+                float* o = a.colsum + ((int64_t)tile * (NS + (NET ? 1 : 0)) + j) * 256 + 32 * w + 4 * g;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(o + 8 * q) = make_float4(cs[4 * q], cs[4 * q + 1], cs[4 * q + 2], cs[4 * q + 3]);
             }
@@ -174,15 +264,25 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
 // the transposed hidden weights of layers 7 .. 1 as MFMA A-operand fragments (mlp_layout.h: lane (g, s) of k-step t of output block nb holds
 // output feature 32 nb + s, k-slots (chunk 2 t + g, e = 0 .. 7)), split bf16: stage j multiplies dZ of layer i = 7 - j, so its "output
 // feature" is an INPUT feature of layer i (skip layer 5: behind the encoding columns) and its k index an OUTPUT feature of layer i
-__global__ __launch_bounds__(256) void bwd_pack_kernel(nm::DevParams P, int kpe, int head, uint8_t* __restrict__ img) {
+__global__ __launch_bounds__(256) void bwd_pack_kernel(nm::DevParams P, int kpe, int kdir, int mode, uint8_t* __restrict__ img) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int step = gid >> 6, lane = gid & 63;
-    if (step >= kBwdSlots * 8 * 16) return;
-    const int slot = step / 128, nb = (step % 128) / 16, t = step % 16;
-    if (slot == 0 && !head) return;
-    const int i = 8 - slot;                                           // layer; slot 0: feature_linear
-    const float* Wi = slot == 0 ? P.p[nm::P_FEAT_W] : P.p[nm::P_PTS_W + 2 * i];
-    const int K = i == 5 ? kpe + 256 : 256, col = (i == 5 ? kpe : 0) + 32 * nb + (lane & 31);
+    if (step >= kBwdSlots * 8 * 16 + 8 * 8) return;
+    const float* Wi;
+    int K, col, t;
+    if (step >= kBwdSlots * 8 * 16) {                                   // the views-back stage (mode 2): W_views [128][256 + kdir], its feature columns
+        if (mode < 2) return;
+        const int v = step - kBwdSlots * 8 * 16;
+        t = v % 8;
+        Wi = P.p[nm::P_VIEWS_W]; K = 256 + kdir; col = 32 * (v / 8) + (lane & 31);
+    } else {
+        const int slot = step / 128, nb = (step % 128) / 16;
+        t = step % 16;
+        if (slot == 0 && mode < 1) return;
+        const int i = 8 - slot;                                         // layer; slot 0: feature_linear
+        Wi = slot == 0 ? P.p[nm::P_FEAT_W] : P.p[nm::P_PTS_W + 2 * i];
+        K = i == 5 ? kpe + 256 : 256; col = (i == 5 ? kpe : 0) + 32 * nb + (lane & 31);
+    }
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = Wi[(int64_t)nm::slot_feature(2 * t + (lane >> 5), e) * K + col];
@@ -217,8 +317,10 @@ int64_t mlp_bwd_image_bytes() { return kBwdImageBytes + kBwdPadBytes; }
 
 int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_top, const float* d_feat, const float* d_raw, const float* acts,
                    const unsigned* relu_bits, int64_t n, float* dz_out, float* colsum, float* gb, hipStream_t stream, const Bwd16* h) {
-    const bool head = d_feat != nullptr;
-    hipLaunchKernelGGL(bwd_pack_kernel, dim3((kBwdSlots * 8 * 16 * 64 + 255) / 256), dim3(256), 0, stream, P, kpe, head ? 1 : 0, image);
+    const bool net = h && h->hvbits;                                   // the whole backward pass from d_raw
+    const bool head = d_feat != nullptr || net;
+    const int mode = net ? 2 : (head ? 1 : 0);
+    hipLaunchKernelGGL(bwd_pack_kernel, dim3(((kBwdSlots * 8 * 16 + 8 * 8) * 64 + 255) / 256), dim3(256), 0, stream, P, kpe, h ? h->kdir : 0, mode, image);
     BwdArgs a;
     a.wpack = reinterpret_cast<const uint4*>(image);
     a.dz_top = dz_top; a.d_feat = d_feat; a.d_raw = d_raw; a.w_alpha = P.p[P_ALPHA_W];
@@ -227,6 +329,8 @@ int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_
     a.dfeat16 = h ? reinterpret_cast<uint4*>(h->dfeat16) : nullptr;
     a.amax = h ? h->amax : nullptr;
     for (int i = 0; i < 8; ++i) a.dz32[i] = h ? h->dz32[i] : nullptr;
+    a.hvbits = net ? h->hvbits : nullptr; a.w_rgb = P.p[P_RGB_W];
+    a.dhv16 = net ? reinterpret_cast<uint4*>(h->dhv16) : nullptr; a.dhv32 = net ? h->dhv32 : nullptr;
     const int64_t ntiles = (n + kTileM - 1) / kTileM;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
@@ -234,9 +338,10 @@ int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     const int grid = (int)(ntiles < cus ? ntiles : cus);
-    const int ns = head ? kBwdSlots : kBwdStages;
-    if (head) hipLaunchKernelGGL(nerf_mlp_bwd_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, a);
-    else hipLaunchKernelGGL(nerf_mlp_bwd_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, a);
+    const int ns = (head ? kBwdSlots : kBwdStages) + (net ? 1 : 0);     // rows of the bias-gradient block: the stages (+ feature_linear's)
+    if (net) hipLaunchKernelGGL(nerf_mlp_bwd_kernel<2>, dim3(grid), dim3(kThreads), 0, stream, a);
+    else if (head) hipLaunchKernelGGL(nerf_mlp_bwd_kernel<1>, dim3(grid), dim3(kThreads), 0, stream, a);
+    else hipLaunchKernelGGL(nerf_mlp_bwd_kernel<0>, dim3(grid), dim3(kThreads), 0, stream, a);
     hipLaunchKernelGGL(bwd_colsum_kernel, dim3(ns * 256 / 32), dim3(1024), 0, stream, colsum, ntiles, ns * 256, gb);
     return check_launch("nerf_mlp_bwd_kernel");
 }

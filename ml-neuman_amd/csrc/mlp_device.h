@@ -72,7 +72,9 @@ struct MlpArgs {
     float* save_hv;          //                     [n][128] f32 output of stage 9 (after ReLU)
     unsigned* save_bits;     //                     nullable: [8][n][8] the signs of stages 0..7: word f >> 5 of (stage, sample); feature 32 w + 8 q + 4 g + j = bit 16 g + 15 - (4 q + j)
     uint4* save_h16;         //                     nullable: [8][n][32] the outputs of stages 0..7 as fp16 of 32 x value (the hi part the next layer's MFMA reads), k-slot
-                             //                     order (chunk c, element e <-> feature slot_feature(c, e)) INSTEAD of their float32 copies; save_h = [n][256] feature only
+                             //                     order (chunk c, element e <-> feature slot_feature(c, e)) INSTEAD of their float32 copies; save_h = [n][256] feature only (nullable then)
+    uint4* save_feat16;      //                     nullable (with save_h16): [n][32] the feature layer's output the same way (fp16 of 32 x value, k-slot order)
+    unsigned* save_hvbits;   //                     nullable (with save_h16): [n][4] the signs of stage 9 (views layer): word nb of a sample, bits as save_bits
 };
 
 // ---- positional encoding feature p of a 3-vector (reference models/vanilla.py:60-92) ---------------

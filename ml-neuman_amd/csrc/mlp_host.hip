@@ -761,14 +761,14 @@ int nm_mlp_forward_save(nm_mlp_t m, const float* pts, const float* dirs, int64_t
 }
 
 static int forward_save_impl(nm_mlp_t m, const float* pts, const float* dirs, int64_t n, float* save_h, float* save_hv, uint32_t* save_bits,
-                             void* save_h16, float* out, nm_stream_t stream) {
+                             void* save_h16, float* out, nm_stream_t stream, void* save_feat16 = nullptr, uint32_t* save_hvbits = nullptr) {
     NM_REQUIRE(m, "nm_mlp_forward_save: null handle");
     NM_REQUIRE(!m->desc.plain_head, "nm_mlp_forward_save: the plain-head net has no fused training forward");
     NM_REQUIRE(n >= 0, "nm_mlp_forward_save: negative n");
     if (n == 0) return NM_OK;
-    NM_REQUIRE(pts && dirs && save_h && save_hv && out, "nm_mlp_forward_save: null pointer");
-    NM_REQUIRE(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(save_h) | reinterpret_cast<uintptr_t>(save_hv) | reinterpret_cast<uintptr_t>(save_h16)) & 15) == 0,
-               "nm_mlp_forward_save: outputs must be 16-byte aligned");
+    NM_REQUIRE(pts && dirs && (save_h || (save_h16 && save_feat16)) && save_hv && out, "nm_mlp_forward_save: null pointer");
+    NM_REQUIRE(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(save_h) | reinterpret_cast<uintptr_t>(save_hv) | reinterpret_cast<uintptr_t>(save_h16) |
+                 reinterpret_cast<uintptr_t>(save_feat16)) & 15) == 0, "nm_mlp_forward_save: outputs must be 16-byte aligned");
     nm::MlpLaunch L;
     L.wpack = m->d_image;
     L.bias = reinterpret_cast<const float*>(m->d_image + nm::kWeightBytes + nm::kWeightPadBytes);
@@ -780,7 +780,7 @@ static int forward_save_impl(nm_mlp_t m, const float* pts, const float* dirs, in
     L.plain_head = 0;
     L.wstream8 = m->d_stream8;
     L.consts8 = m->d_consts8;
-    L.save_h = save_h; L.save_hv = save_hv; L.save_bits = save_bits; L.save_h16 = save_h16;
+    L.save_h = save_h; L.save_hv = save_hv; L.save_bits = save_bits; L.save_h16 = save_h16; L.save_feat16 = save_feat16; L.save_hvbits = save_hvbits;
     return nm::launch_mlp_mfma(L, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, NM_PREC_FP16X3, -2, 1.f, out, nullptr, nullptr,
                                nm::as_stream(stream), 0, nullptr);
 }
@@ -790,13 +790,13 @@ int nm_mlp_forward_save_bits(nm_mlp_t m, const float* pts, const float* dirs, in
     return forward_save_impl(m, pts, dirs, n, save_h, save_hv, save_bits, nullptr, out, stream);
 }
 
-int nm_mlp_forward_save16(nm_mlp_t m, const float* pts, const float* dirs, int64_t n, uint16_t* save_h16, float* save_feat, float* save_hv,
-                          uint32_t* save_bits, float* out, nm_stream_t stream) {
-    NM_REQUIRE(n == 0 || (save_h16 && save_bits), "nm_mlp_forward_save16: null pointer");
-    return forward_save_impl(m, pts, dirs, n, save_feat, save_hv, save_bits, save_h16, out, stream);
+int nm_mlp_forward_save16(nm_mlp_t m, const float* pts, const float* dirs, int64_t n, uint16_t* save_h16, float* save_feat, uint16_t* save_feat16,
+                          float* save_hv, uint32_t* save_bits, uint32_t* save_hvbits, float* out, nm_stream_t stream) {
+    NM_REQUIRE(n == 0 || (save_h16 && save_bits && (save_feat || save_feat16)), "nm_mlp_forward_save16: null pointer");
+    return forward_save_impl(m, pts, dirs, n, save_feat, save_hv, save_bits, save_h16, out, stream, save_feat16, save_hvbits);
 }
 
-int64_t nm_mlp_backward_chain_workspace_floats(int64_t n) { return ((n + nm::kTileM - 1) / nm::kTileM) * 8 * 256; }
+int64_t nm_mlp_backward_chain_workspace_floats(int64_t n) { return ((n + nm::kTileM - 1) / nm::kTileM) * 9 * 256; }
 
 int nm_mlp_backward_chain(nm_mlp_t m, const float* const* dev_params, const float* dz_top, const float* d_feat, const float* d_raw, const float* acts,
                           const uint32_t* relu_bits, int64_t n, float* dz_out, float* bias_grads, float* workspace, int64_t workspace_floats,
@@ -847,6 +847,36 @@ int nm_mlp_backward_chain16(nm_mlp_t m, const float* const* dev_params, const fl
     for (int i = 0; i < 8; ++i) h.dz32[i] = nullptr;
     h.dz32[5] = dz32_layer5; h.dz32[0] = dz32_layer0;
     return nm::launch_mlp_bwd(P, 3 + 6 * m->desc.pos_n_freqs, m->d_bwd_image, nullptr, d_feat, d_raw, nullptr, relu_bits, n, nullptr, workspace, bias_grads,
+                              nm::as_stream(stream), &h);
+}
+
+int nm_mlp_backward_net16(nm_mlp_t m, const float* const* dev_params, const float* d_raw, const uint32_t* relu_bits, const uint32_t* hv_bits, int64_t n,
+                          const float* amax, uint16_t* dz16, uint16_t* dfeat16, uint16_t* dhv16, float* dz32_layer5, float* dz32_layer0, float* dhv32,
+                          float* bias_grads, float* workspace, int64_t workspace_floats, nm_stream_t stream) {
+    NM_REQUIRE(m && dev_params, "nm_mlp_backward_net16: null pointer");
+    NM_REQUIRE(n >= 0, "nm_mlp_backward_net16: negative n");
+    if (n == 0) return NM_OK;
+    NM_REQUIRE(d_raw && relu_bits && hv_bits && amax && dz16 && dfeat16 && dhv16 && bias_grads && workspace, "nm_mlp_backward_net16: null pointer");
+    NM_REQUIRE(!m->desc.plain_head, "nm_mlp_backward_net16: the plain-head net has no views layer");
+    NM_REQUIRE(workspace_floats >= nm_mlp_backward_chain_workspace_floats(n), "nm_mlp_backward_net16: workspace of %lld floats, %lld needed",
+               (long long)workspace_floats, (long long)nm_mlp_backward_chain_workspace_floats(n));
+    NM_REQUIRE(((reinterpret_cast<uintptr_t>(d_raw) | reinterpret_cast<uintptr_t>(dz16) | reinterpret_cast<uintptr_t>(dfeat16) | reinterpret_cast<uintptr_t>(dhv16) |
+                 reinterpret_cast<uintptr_t>(dz32_layer5) | reinterpret_cast<uintptr_t>(dz32_layer0) | reinterpret_cast<uintptr_t>(dhv32) |
+                 reinterpret_cast<uintptr_t>(workspace)) & 15) == 0, "nm_mlp_backward_net16: buffers must be 16-byte aligned");
+    nm::DevParams P;
+    for (int i = 0; i < 24; ++i) {
+        NM_REQUIRE(dev_params[i], "nm_mlp_backward_net16: dev_params[%d] is null", i);
+        P.p[i] = dev_params[i];
+    }
+    NM_REQUIRE((reinterpret_cast<uintptr_t>(P.p[nm::P_RGB_W]) & 15) == 0, "nm_mlp_backward_net16: rgb_linear.weight must be 16-byte aligned");
+    if (!m->d_bwd_image)
+        if (int rc = nm::check_hip(hipMalloc(&m->d_bwd_image, (size_t)nm::mlp_bwd_image_bytes()), "nm_mlp_backward_net16: hipMalloc")) return rc;
+    nm::Bwd16 h;
+    h.dz16 = dz16; h.dfeat16 = dfeat16; h.amax = amax;
+    for (int i = 0; i < 8; ++i) h.dz32[i] = nullptr;
+    h.dz32[5] = dz32_layer5; h.dz32[0] = dz32_layer0;
+    h.hvbits = hv_bits; h.dhv16 = dhv16; h.dhv32 = dhv32; h.kdir = 3 + 6 * m->desc.dir_n_freqs;
+    return nm::launch_mlp_bwd(P, 3 + 6 * m->desc.pos_n_freqs, m->d_bwd_image, nullptr, nullptr, d_raw, nullptr, relu_bits, n, nullptr, workspace, bias_grads,
                               nm::as_stream(stream), &h);
 }
 

@@ -21,7 +21,9 @@ struct MlpLaunch {
     float* save_h = nullptr;                      // nm_mlp_forward_save (NM_PREC_FP16X3): [9][n][256] post-activation outputs of layers 0..7, then feature
     float* save_hv = nullptr;                     //   and [n][128] of the views layer: what a training step's backward pass reads
     unsigned* save_bits = nullptr;                //   nullable: [8][n][8] one bit per trunk activation (> 0): what nm_mlp_backward_chain masks with
-    void* save_h16 = nullptr;                     //   nullable: [8][n][256] fp16 trunk activations (x 32, k-slot order) instead of float32; save_h is then [n][256]: feature only
+    void* save_h16 = nullptr;                     //   nullable: [8][n][256] fp16 trunk activations (x 32, k-slot order) instead of float32; save_h is then [n][256]: feature only (nullable)
+    void* save_feat16 = nullptr;                  //   nullable: [n][256] fp16 feature output likewise;  save_hvbits nullable: [n][4] signs of the views layer
+    unsigned* save_hvbits = nullptr;
 };
 struct RefLaunch {
     const float* wt; const float* bias; int off[12]; int boff[12]; const float* petab;
@@ -60,6 +62,9 @@ int64_t mlp_bwd_image_bytes();
 // same way, dz32[layer] (nullable each) float32 copies of single layers
 struct Bwd16 {
     void* dz16; void* dfeat16; const float* amax; float* dz32[8];
+    // hvbits != nullptr: the whole backward pass from d_raw (d_feat unused): the views layer's adjoint is formed in the kernel; dhv16 [n][128] fp16
+    // (x scale, k-slot order), dhv32 (nullable) its float32 copy; the bias-gradient block gets a 9th row: feature_linear's; kdir = encoded view width
+    const unsigned* hvbits = nullptr; void* dhv16 = nullptr; float* dhv32 = nullptr; int kdir = 0;
 };
 int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_top, const float* d_feat, const float* d_raw, const float* acts,
                    const unsigned* relu_bits, int64_t n, float* dz_out, float* colsum, float* gb, hipStream_t stream, const Bwd16* h = nullptr);

@@ -474,36 +474,39 @@ __host__ inline bool wgrad256_ok(int mode, int a_kmajor, int b_kmajor, int M, in
 // of a product whose K runs over samples) to T[operand][octet][position e 32 + c]: conflict-free both ways.  The accumulators' rows /
 // columns are those positions; wgrad16_reduce_kernel sums the splits in order, scales by 1 / (32 s) and stores to the natural [out][in].
 struct Wgrad16Args {
-    const uint4* P[8]; const uint4* Q[8];       // per product: dZ16 [n][32] uint4 rows; activation16 [n][NQ / 8] uint4 rows
-    float* C[8]; int ldc[8];                    // per product: the [256][ncols] gradient (row stride ldc)
-    float* partial;                             // [nprod][nsplit][256][NQ]
+    const uint4* P[8]; const uint4* Q[8];       // per product: dZ16 [n][MP / 8] uint4 rows; activation16 [n][NQ / 8] uint4 rows
+    float* C[8]; int ldc[8];                    // per product: the [MP][ncols] gradient (row stride ldc)
+    float* partial;                             // [nprod][nsplit][MP][NQ]
     const float* amax;                          // the device scalar dZ16's scale derives from (nm_dz_scale)
     int64_t n;
     int k_per_split, nsplit, ncols;             // ncols <= NQ columns are stored
 };
 
-// NQ = 256: the hidden operand of a layer (k-slot order); NQ = 64: the encoded input (natural order, 63 + a zero column), fp16 of 32 x value too
-template <int NQ>
-__global__ __launch_bounds__(512, 2) void wgrad256h_kernel(const Wgrad16Args g) {
-    constexpr int QC = NQ / 8;                                      // 16-byte chunks per Q row
-    constexpr int MI = NQ == 256 ? 4 : 1;                           // 32-row blocks per wave: 8 waves = 2 x 4 of 128 x 64, or 8 x 1 of 32 x 64
-    __shared__ uint4 T[2][8][256];                                  // (Q: the first NQ positions of a row)
+// MP = 256: dZ of a trunk layer / feature_linear; 128: of the views layer (both k-slot order).  NQ = 256: a hidden operand (k-slot order);
+// NQ = 64: an encoded input (natural order, zero beyond the encoding), fp16 of 32 x value too.  8 waves tile the [MP][NQ] output:
+//   (256, 256) 2 x 4 of 128 x 64    (256, 64) 8 x 1 of 32 x 64    (128, 256) 2 x 4 of 64 x 64    (128, 64) 4 x 2 of 32 x 32
+template <int MP, int NQ>
+__global__ __launch_bounds__(512, 2) void wgrad16_kernel(const Wgrad16Args g) {
+    constexpr int PC = MP / 8, QC = NQ / 8;                         // 16-byte chunks per P / Q row
+    constexpr int WN = NQ == 256 ? 4 : (MP == 256 ? 1 : 2);         // waves along the columns
+    constexpr int WM = 8 / WN;
+    constexpr int MI = MP / (32 * WM), NJ = NQ / (32 * WN);         // 32 x 32 blocks per wave
+    __shared__ uint4 T[2][8][256];                                  // [operand][octet][position]: the first MP / NQ positions of a row
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int prod = blockIdx.y;
-    const int op = tid >> 8;
-    const int c = op ? (tid & (QC - 1)) : (tid & 31);
-    const int o = op ? (((tid & 255) / QC) & 7) : ((tid >> 5) & 7);
-    const bool loader = !op || (tid & 255) < 8 * QC;
-    const int rowlen = op ? QC : 32;
+    const int op = tid >> 8, t8 = tid & 255;
+    const int rowlen = op ? QC : PC;
+    const bool loader = t8 < 8 * rowlen;
+    const int c = t8 % rowlen, o = (t8 / rowlen) & 7;
     const uint4* __restrict__ src = op ? g.Q[prod] : g.P[prod];
     const int64_t kbeg = (int64_t)blockIdx.x * g.k_per_split;
     const int64_t kend = kbeg + g.k_per_split < g.n ? kbeg + g.k_per_split : g.n;
-    const int wm = NQ == 256 ? (w >> 2) * 128 : w * 32, wn = NQ == 256 ? (w & 3) * 64 : 0;
-    floatx16 acc[MI][2];
+    const int wm = (w / WN) * (32 * MI), wn = (w % WN) * (32 * NJ);
+    floatx16 acc[MI][NJ];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
     unsigned r[8][4];
@@ -536,48 +539,49 @@ __global__ __launch_bounds__(512, 2) void wgrad256h_kernel(const Wgrad16Args g) 
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int oct = 2 * s + (lane >> 5), cc = lane & 31;
-            f16x8 a[MI], b[2];
+            f16x8 a[MI], b[NJ];
 #pragma unroll
             for (int i = 0; i < MI; ++i) a[i] = __builtin_bit_cast(f16x8, T[0][oct][wm + 32 * i + cc]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = __builtin_bit_cast(f16x8, T[1][oct][wn + 32 * j + cc]);
+            for (int j = 0; j < NJ; ++j) b[j] = __builtin_bit_cast(f16x8, T[1][oct][wn + 32 * j + cc]);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
-    float* P = g.partial + ((int64_t)prod * g.nsplit + blockIdx.x) * (256 * NQ);
+    float* P = g.partial + ((int64_t)prod * g.nsplit + blockIdx.x) * (MP * NQ);
     const int gq = lane >> 5, cc = lane & 31;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) P[(wm + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * gq) * NQ + wn + 32 * j + cc] = acc[i][j][v];
 }
 
-// position p = e 32 + c of a fragment row / column -> the feature it is (k-slot (chunk c, element e) of mlp_layout.h)
+// position p = e (W / 8) + c of a fragment row / column of a W-wide k-slot-order operand -> the feature it is (k-slot (chunk c, element e), mlp_layout.h)
+template <int W>
 __device__ __forceinline__ int pos_feature(int p) {
-    const int c = p & 31, e = p >> 5;
+    const int c = p % (W / 8), e = p / (W / 8);
     return 32 * (c >> 2) + 8 * (2 * ((c >> 1) & 1) + (e >> 2)) + 4 * (c & 1) + (e & 3);
 }
-template <int NQ>
+template <int MP, int NQ>
 __global__ __launch_bounds__(256) void wgrad16_reduce_kernel(const Wgrad16Args g) {
     const int prod = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;                          // (row position, column position): coalesced reads of the partials
-    const float* part = g.partial + (int64_t)prod * g.nsplit * (256 * NQ) + i;
+    const float* part = g.partial + (int64_t)prod * g.nsplit * (MP * NQ) + i;
     float p[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};                 // eight interleaved partial sums, combined in a fixed order (as splitk_reduce_kernel)
     int z = 0;
     for (; z + 8 <= g.nsplit; z += 8)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) p[k] += part[(int64_t)(z + k) * (256 * NQ)];
-    for (int k = 0; z < g.nsplit; ++z, ++k) p[k] += part[(int64_t)z * (256 * NQ)];
+        for (int k = 0; k < 8; ++k) p[k] += part[(int64_t)(z + k) * (MP * NQ)];
+    for (int k = 0; z < g.nsplit; ++z, ++k) p[k] += part[(int64_t)z * (MP * NQ)];
     const float sum = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
     const float inv = 1.f / (nm_dz_scale(*g.amax) * kNmAct16Scale);        // (a power of two: exact)
     const int pc = i % NQ;
-    const int col = NQ == 256 ? pos_feature(pc) : 8 * (pc % (NQ / 8)) + pc / (NQ / 8);     // (natural-order operand: position e (NQ / 8) + c = column 8 c + e)
-    if (col < g.ncols) g.C[prod][(int64_t)pos_feature(i / NQ) * g.ldc[prod] + col] = sum * inv;
+    const int col = NQ == 256 ? pos_feature<256>(pc) : 8 * (pc % (NQ / 8)) + pc / (NQ / 8);     // (natural-order operand: position e (NQ / 8) + c = column 8 c + e)
+    if (col < g.ncols) g.C[prod][(int64_t)pos_feature<MP>(i / NQ) * g.ldc[prod] + col] = sum * inv;
 }
 
 // alpha_linear's weight gradient: out[f] = sum_n d_raw[n][3] H7[n][f] from the fp16 copy (k-slot order, x 32): a thread owns two slots of a
@@ -674,9 +678,9 @@ int pick_splits(int M, int N, int K) {
 
 // [x, sin(f0 x), cos(f0 x), sin(f1 x), ...] (posenc, models/vanilla.py:60-79) or [x, sin(x B^T), cos(x B^T)] (rotate, :83-89),
 // then zeros up to `ld`.  One thread per output element.
-template <bool HALF>                                                    // HALF: out is fp16 of 32 x value (the operand of nm_wgrad16)
+template <bool HALF>                                                    // HALF: out is fp16 of 32 x value (the operand of nm_wgrad16); ones_col >= 0: that column is 1
 __global__ __launch_bounds__(256) void pe_encode_kernel(const float* __restrict__ x, int64_t n, int D, int kind, int nfreq,
-                                                        const float* __restrict__ tab, float* __restrict__ out, int ld) {
+                                                        const float* __restrict__ tab, float* __restrict__ out, int ld, int ones_col = -1) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * ld) return;
     const int64_t r = i / ld;
@@ -698,6 +702,7 @@ __global__ __launch_bounds__(256) void pe_encode_kernel(const float* __restrict_
             v = is_cos ? cosf(a) : sinf(a);
         }
     }
+    if (HALF && p == ones_col) v = 1.f;
     if (HALF) reinterpret_cast<_Float16*>(out)[i] = (_Float16)(v * kNmAct16Scale);
     else out[i] = v;
 }
@@ -882,6 +887,13 @@ __global__ __launch_bounds__(256) void composite_backward_wave_kernel(const floa
 
 }  // namespace
 
+template <int MP, int NQ>
+static int wgrad16_launch(const Wgrad16Args& g, int nprod, hipStream_t st) {
+    hipLaunchKernelGGL((wgrad16_kernel<MP, NQ>), dim3(g.nsplit, nprod), dim3(512), 0, st, g);
+    if (int rc = nm::check_launch("wgrad16_kernel")) return rc;
+    hipLaunchKernelGGL((wgrad16_reduce_kernel<MP, NQ>), dim3(MP * NQ / 256, nprod), dim3(256), 0, st, g);
+    return nm::check_launch("wgrad16_reduce_kernel");
+}
 extern "C" {
 
 int64_t nm_gemm_workspace_floats(int M, int N, int K) {
@@ -1002,14 +1014,15 @@ static void wgrad16_split(int nprod, int64_t n, int& k_per_split, int& nsplit) {
     k_per_split = (int)per;
     nsplit = (int)((n + per - 1) / per);
 }
-int64_t nm_wgrad16_workspace_floats(int nprod, int64_t n, int q_cols) {
+int64_t nm_wgrad16_workspace_floats(int nprod, int64_t n, int p_cols, int q_cols) {
     int k, s;
     wgrad16_split(nprod, n, k, s);
-    return (int64_t)nprod * s * 256 * (q_cols > 64 ? 256 : 64);
+    return (int64_t)nprod * s * (p_cols > 128 ? 256 : 128) * (q_cols > 64 ? 256 : 64);
 }
-int nm_wgrad16(int nprod, int q_cols, const uint16_t* const* dz16, const uint16_t* const* act16, float* const* dW, const int* ldw, int64_t n, const float* amax,
-               float* workspace, int64_t workspace_floats, nm_stream_t stream) {
+int nm_wgrad16(int nprod, int p_cols, int q_cols, const uint16_t* const* dz16, const uint16_t* const* act16, float* const* dW, const int* ldw, int64_t n,
+               const float* amax, float* workspace, int64_t workspace_floats, nm_stream_t stream) {
     NM_REQUIRE(nprod >= 1 && nprod <= 8 && n >= 1 && n < ((int64_t)1 << 31), "nm_wgrad16: nprod %d (1..8), n %lld", nprod, (long long)n);
+    NM_REQUIRE(p_cols == 256 || p_cols == 128, "nm_wgrad16: p_cols %d (256: a trunk layer / feature_linear; 128: the views layer)", p_cols);
     NM_REQUIRE(q_cols == 256 || (q_cols >= 1 && q_cols <= 64), "nm_wgrad16: q_cols %d (256: a hidden operand; <= 64: an encoded input in rows of 64)", q_cols);
     NM_REQUIRE(dz16 && act16 && dW && ldw && amax && workspace, "nm_wgrad16: null pointer");
     const int NQ = q_cols == 256 ? 256 : 64;
@@ -1021,20 +1034,12 @@ int nm_wgrad16(int nprod, int q_cols, const uint16_t* const* dz16, const uint16_
         g.P[i] = reinterpret_cast<const uint4*>(dz16[i]); g.Q[i] = reinterpret_cast<const uint4*>(act16[i]); g.C[i] = dW[i]; g.ldc[i] = ldw[i];
     }
     wgrad16_split(nprod, n, g.k_per_split, g.nsplit);
-    NM_REQUIRE(workspace_floats >= (int64_t)nprod * g.nsplit * 256 * NQ, "nm_wgrad16: needs %lld floats of workspace (nm_wgrad16_workspace_floats)",
-               (long long)nprod * g.nsplit * 256 * NQ);
+    NM_REQUIRE(workspace_floats >= (int64_t)nprod * g.nsplit * p_cols * NQ, "nm_wgrad16: needs %lld floats of workspace (nm_wgrad16_workspace_floats)",
+               (long long)nprod * g.nsplit * p_cols * NQ);
     g.partial = workspace; g.amax = amax; g.n = n; g.ncols = q_cols;
     hipStream_t st = nm::as_stream(stream);
-    if (NQ == 256) {
-        hipLaunchKernelGGL(wgrad256h_kernel<256>, dim3(g.nsplit, nprod), dim3(512), 0, st, g);
-        if (int rc = nm::check_launch("wgrad256h_kernel")) return rc;
-        hipLaunchKernelGGL(wgrad16_reduce_kernel<256>, dim3(256, nprod), dim3(256), 0, st, g);
-    } else {
-        hipLaunchKernelGGL(wgrad256h_kernel<64>, dim3(g.nsplit, nprod), dim3(512), 0, st, g);
-        if (int rc = nm::check_launch("wgrad256h_kernel")) return rc;
-        hipLaunchKernelGGL(wgrad16_reduce_kernel<64>, dim3(64, nprod), dim3(256), 0, st, g);
-    }
-    return nm::check_launch("wgrad16_reduce_kernel");
+    if (p_cols == 256) return NQ == 256 ? wgrad16_launch<256, 256>(g, nprod, st) : wgrad16_launch<256, 64>(g, nprod, st);
+    return NQ == 256 ? wgrad16_launch<128, 256>(g, nprod, st) : wgrad16_launch<128, 64>(g, nprod, st);
 }
 
 int64_t nm_wgrad_alpha16_workspace_floats(int64_t n) { return ((n + kAlphaRows - 1) / kAlphaRows) * 256; }
@@ -1072,11 +1077,12 @@ int nm_pe_encode(const float* x, int64_t n, int dims, int kind, int n_freqs, con
     if (n == 0) return NM_OK;
     NM_REQUIRE(x && out && (table || n_freqs == 0), "nm_pe_encode: null pointer");
     const int64_t total = n * ld;
-    hipLaunchKernelGGL(pe_encode_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nm::as_stream(stream), x, n, dims, kind, n_freqs, table, out, ld);
+    hipLaunchKernelGGL(pe_encode_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nm::as_stream(stream), x, n, dims, kind, n_freqs, table, out, ld, -1);
     return nm::check_launch("pe_encode_kernel");
 }
 
-int nm_pe_encode16(const float* x, int64_t n, int dims, int kind, int n_freqs, const float* table, uint16_t* out, int ld, nm_stream_t stream) {
+int nm_pe_encode16(const float* x, int64_t n, int dims, int kind, int n_freqs, const float* table, uint16_t* out, int ld, int ones_col, nm_stream_t stream) {
+    NM_REQUIRE(ones_col < ld && (ones_col < 0 || ones_col >= dims + 2 * dims * n_freqs), "nm_pe_encode16: ones_col %d must lie in the padding of a row", ones_col);
     NM_REQUIRE(dims == 3 || (dims == 4 && kind == NM_PE_POSENC), "nm_pe_encode16: dims %d (3, or 4 with the posenc mapping)", dims);
     NM_REQUIRE(n >= 0 && n_freqs >= 0 && ld >= dims + 2 * dims * n_freqs, "nm_pe_encode16: bad sizes n=%lld n_freqs=%d ld=%d", (long long)n, n_freqs, ld);
     NM_REQUIRE(kind == NM_PE_POSENC || kind == NM_PE_ROTATE, "nm_pe_encode16: mapping %d", kind);
@@ -1084,7 +1090,7 @@ int nm_pe_encode16(const float* x, int64_t n, int dims, int kind, int n_freqs, c
     NM_REQUIRE(x && out && (table || n_freqs == 0), "nm_pe_encode16: null pointer");
     const int64_t total = n * ld;
     hipLaunchKernelGGL(pe_encode_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nm::as_stream(stream), x, n, dims, kind, n_freqs, table,
-                       reinterpret_cast<float*>(out), ld);
+                       reinterpret_cast<float*>(out), ld, ones_col);
     return nm::check_launch("pe_encode_kernel");
 }
 

@@ -156,13 +156,13 @@ def _encode(emb, x, ld):
     return out
 
 
-def _encode16(emb, x, ld=64):
-    """the encoding as fp16 of 32 x value, rows of `ld` (an operand of nm_wgrad16)"""
+def _encode16(emb, x, ld=64, ones_col=-1):
+    """the encoding as fp16 of 32 x value, rows of `ld` (an operand of nm_wgrad16); ones_col: a padding column that holds 1 instead of 0"""
     dev = x.device
     tab = torch.from_numpy(emb.table()).to(dev).contiguous()
     out = torch.empty((x.shape[0], ld), device=dev, dtype=torch.float16)
     _lib.check(_lib.lib().nm_pe_encode16(_lib.dev_ptr(x), x.shape[0], x.shape[1], PE_KINDS[emb.mapping], emb.N_freqs, _lib.dev_ptr(tab),
-                                         ctypes.c_void_p(out.data_ptr()), ld, _lib.stream_ptr()), "nm_pe_encode16")
+                                         ctypes.c_void_p(out.data_ptr()), ld, ones_col, _lib.stream_ptr()), "nm_pe_encode16")
     return out
 
 
@@ -208,7 +208,7 @@ class _MLP(torch.autograd.Function):
         X0 = None if use16 else _encode(net.pos_pe, p4, pk.kp)
         if fused:
             d4 = _pad4(dirs)
-            D0 = _encode(net.dir_pe, d4, pk.kd)
+            D0 = None if use16 else _encode(net.dir_pe, d4, pk.kd)
             handle = net.train_handle()
             plist = nerf.ordered_params()
             ptrs = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in plist])
@@ -219,11 +219,15 @@ class _MLP(torch.autograd.Function):
             ctx.h16 = ctx.x0h = None
             if use16:
                 h16 = torch.empty((8, n4, width), device=dev, dtype=torch.float16)
-                feat = torch.empty((n4, width), device=dev, dtype=torch.float32)
-                _lib.check(_lib.lib().nm_mlp_forward_save16(handle, _lib.dev_ptr(p4), _lib.dev_ptr(d4), n4, ctypes.c_void_p(h16.data_ptr()), _lib.dev_ptr(feat),
-                                                            _lib.dev_ptr(hv), ctypes.c_void_p(bits.data_ptr()), _lib.dev_ptr(raw), _lib.stream_ptr()),
-                           "nm_mlp_forward_save16")
-                ctx.h16, ctx.x0h, acts, H = h16, _encode16(net.pos_pe, p4), None, None
+                feat16 = torch.empty((n4, width), device=dev, dtype=torch.float16)
+                hvbits = torch.empty((n4, 4), device=dev, dtype=torch.int32)
+                _lib.check(_lib.lib().nm_mlp_forward_save16(handle, _lib.dev_ptr(p4), _lib.dev_ptr(d4), n4, ctypes.c_void_p(h16.data_ptr()), None,
+                                                            ctypes.c_void_p(feat16.data_ptr()), _lib.dev_ptr(hv), ctypes.c_void_p(bits.data_ptr()),
+                                                            ctypes.c_void_p(hvbits.data_ptr()), _lib.dev_ptr(raw), _lib.stream_ptr()), "nm_mlp_forward_save16")
+                # the encodings as fp16 operands of the weight-gradient products; the view encoding's last padding column holds 1: its product
+                # with d_hv is the views layer's bias gradient
+                ctx.h16, ctx.x0h, ctx.d0h, ctx.feat16, ctx.hvbits = h16, _encode16(net.pos_pe, p4), _encode16(net.dir_pe, d4, ones_col=63), feat16, hvbits
+                acts = H = feat = D0 = None
             else:
                 acts = torch.empty((9, n4, width), device=dev, dtype=torch.float32)
                 _lib.check(_lib.lib().nm_mlp_forward_save_bits(handle, _lib.dev_ptr(p4), _lib.dev_ptr(d4), n4, _lib.dev_ptr(acts), _lib.dev_ptr(hv),
@@ -282,6 +286,8 @@ class _MLP(torch.autograd.Function):
                                           "(the fused backward reads the live weights): run backward before optimizer.step() / weight edits")
         d_raw = torch.zeros((n4, 4), device=dev, dtype=torch.float32)
         d_raw[:n, :g_raw.shape[1]] = g_raw
+        if getattr(ctx, 'h16', None) is not None:
+            return _backward16(ctx, d_raw, want_in)
         ws = [torch.empty(4, device=dev, dtype=torch.float32)]
 
         def workspace(m, k):                                                     # split-K partials, grown to the largest product
@@ -316,11 +322,10 @@ class _MLP(torch.autograd.Function):
                                             _lib.stream_ptr()), "nm_colsum")
             return out
 
-        use16 = getattr(ctx, 'h16', None) is not None
-        h7 = None if use16 else H[-1]
+        h7 = H[-1]
         dX0 = dD0 = None
-        dz = None if use16 else torch.empty((n4, width), device=dev, dtype=torch.float32)
-        use_chain = use16 or (FUSED_BACKWARD and getattr(ctx, 'acts', None) is not None and pk.n_layers == 8 and width == 256)
+        dz = torch.empty((n4, width), device=dev, dtype=torch.float32)
+        use_chain = FUSED_BACKWARD and getattr(ctx, 'acts', None) is not None and pk.n_layers == 8 and width == 256
         d_feat = None
         if views:
             g = {}
@@ -336,12 +341,8 @@ class _MLP(torch.autograd.Function):
             d_feat = torch.empty((n4, width), device=dev, dtype=torch.float32)
             _gemm(0, 1, n4, width, half, d_hv, half, pk.Wv[0], width, d_feat, width, flags=COLSUM, ws=cs_buf)
             g['feature_b'] = band_sum(width)
-            if use16:                                                            # (both from the fp16 copy of H_7, below)
-                g['feature_w'] = torch.empty((width, width), device=dev, dtype=torch.float32)
-                g['alpha_w'] = torch.empty((1, width), device=dev, dtype=torch.float32)
-            else:
-                g['feature_w'] = wgrad(d_feat, width, h7, width)
-                g['alpha_w'] = wgrad(d_raw, 4, h7, width)[3:4]
+            g['feature_w'] = wgrad(d_feat, width, h7, width)
+            g['alpha_w'] = wgrad(d_raw, 4, h7, width)[3:4]
             if not use_chain:                                                   # (the chain kernel's first stage forms dZ_7 itself)
                 _gemm(0, 1, n4, width, width, d_feat, width, pk.Wf, width, dz, width)
                 _gemm(0, 1, n4, width, 4, d_raw, 4, pk.Wa4, width, dz, width, mask=h7, ldmask=width, flags=ACC | MASK | COLSUM, ws=cs_buf)
@@ -352,57 +353,7 @@ class _MLP(torch.autograd.Function):
             _gemm(0, 1, n4, width, 4, d_raw, 4, pk.Wo4, width, dz, width, mask=h7, ldmask=width, flags=MASK | COLSUM, ws=cs_buf)
         gw, gb = [None] * pk.n_layers, [None] * pk.n_layers
         chain = None
-        if use16:
-            lib = _lib.lib()
-            h16, x0h, n_pos = ctx.h16, ctx.x0h, pk.n_pos
-            amax = torch.zeros(1, device=dev, dtype=torch.float32)             # largest magnitude entering the chain -> the scale of the fp16 copies
-            _lib.check(lib.nm_absmax(_lib.dev_ptr(d_feat), d_feat.numel(), _lib.dev_ptr(amax), _lib.stream_ptr()), "nm_absmax")
-            _lib.check(lib.nm_absmax(_lib.dev_ptr(d_raw), d_raw.numel(), _lib.dev_ptr(amax), _lib.stream_ptr()), "nm_absmax")
-            dz16 = torch.empty((8, n4, width), device=dev, dtype=torch.float16)  # dZ_7 .. dZ_0 (x scale, k-slot order)
-            dfeat16 = torch.empty((n4, width), device=dev, dtype=torch.float16)
-            dz32 = torch.empty((2, n4, width), device=dev, dtype=torch.float32) if want_in else None     # layers 5, 0: the input gradient's products
-            gbs = torch.empty((8, width), device=dev, dtype=torch.float32)
-            need = int(lib.nm_mlp_backward_chain_workspace_floats(n4))
-            if need > ws[0].numel():
-                ws[0] = torch.empty(need, device=dev, dtype=torch.float32)
-            ptrs = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in nerf.ordered_params()])
-            _lib.check(lib.nm_mlp_backward_chain16(net.train_handle(), ptrs, _lib.dev_ptr(d_feat), _lib.dev_ptr(d_raw), ctypes.c_void_p(ctx.bits.data_ptr()), n4,
-                                                   _lib.dev_ptr(amax), ctypes.c_void_p(dz16.data_ptr()), ctypes.c_void_p(dfeat16.data_ptr()),
-                                                   _lib.dev_ptr(dz32[0] if want_in else None), _lib.dev_ptr(dz32[1] if want_in else None), _lib.dev_ptr(gbs),
-                                                   _lib.dev_ptr(ws[0]), ws[0].numel(), _lib.stream_ptr()), "nm_mlp_backward_chain16")
-            for i in range(8):
-                gb[i] = gbs[7 - i]
-                gw[i] = torch.empty((width, (n_pos if i == 0 else width) + (n_pos if pk.skip[i] else 0)), device=dev, dtype=torch.float32)
-
-            def products(q_cols, items):                                         # items: (dz16 rows, activation rows, gradient, column offset)
-                k = len(items)
-                P = (ctypes.c_void_p * k)(*[a.data_ptr() for a, _, _, _ in items])
-                Q = (ctypes.c_void_p * k)(*[b.data_ptr() for _, b, _, _ in items])
-                C = (ctypes.c_void_p * k)(*[c.data_ptr() + 4 * off for _, _, c, off in items])
-                L = (ctypes.c_int * k)(*[c.shape[1] for _, _, c, _ in items])
-                need = int(lib.nm_wgrad16_workspace_floats(k, n4, q_cols))
-                if need > ws[0].numel():
-                    ws[0] = torch.empty(need, device=dev, dtype=torch.float32)
-                _lib.check(lib.nm_wgrad16(k, q_cols, P, Q, C, L, n4, _lib.dev_ptr(amax), _lib.dev_ptr(ws[0]), ws[0].numel(), _lib.stream_ptr()), "nm_wgrad16")
-
-            # the eight 256 x 256 products of the net in one launch: feature_linear, then the hidden columns of layers 7 .. 1
-            products(width, [(dfeat16, h16[7], g['feature_w'], 0)] +
-                     [(dz16[7 - i], h16[i - 1], gw[i], n_pos if pk.skip[i] else 0) for i in range(7, 0, -1)])
-            # ... and the encoded-position columns of layer 0 and of the skip layer in another
-            products(n_pos, [(dz16[7 - i], x0h, gw[i], 0) for i in range(8) if i == 0 or pk.skip[i]])
-            need = int(lib.nm_wgrad_alpha16_workspace_floats(n4))
-            if need > ws[0].numel():
-                ws[0] = torch.empty(need, device=dev, dtype=torch.float32)
-            _lib.check(lib.nm_wgrad_alpha16(_lib.dev_ptr(d_raw), ctypes.c_void_p(h16[7].data_ptr()), n4, _lib.dev_ptr(g['alpha_w']), _lib.dev_ptr(ws[0]),
-                                            ws[0].numel(), _lib.stream_ptr()), "nm_wgrad_alpha16")
-            if want_in:                                                          # gradient of the encoded position: the two layers it feeds
-                dX0 = torch.empty((n4, pk.kp), device=dev, dtype=torch.float32)
-                first = True
-                for i, slot in ((5, 0), (0, 1)):
-                    if i == 0 or pk.skip[i]:
-                        _gemm(0, 1, n4, pk.kp, width, dz32[slot], width, pk.Wpe(i), pk.kp, dX0, pk.kp, flags=0 if first else ACC)
-                        first = False
-        elif use_chain:
+        if use_chain:
             from_feat = views and d_feat is not None
             ns = 8 if from_feat else 7
             if not from_feat:
@@ -422,10 +373,8 @@ class _MLP(torch.autograd.Function):
                 dz, gb[7] = chain[0], gbs[0]
             for i in range(7):
                 gb[i] = gbs[off + 6 - i]
-        W_all = None if use16 else pk.W
+        W_all = pk.W
         for i in range(pk.n_layers - 1, -1, -1):
-            if use16:
-                break
             Ws = W_all[i]
             if chain is None:
                 gb[i] = band_sum(width)                                          # of dz: left in cs_buf by the product that made it
@@ -457,6 +406,88 @@ class _MLP(torch.autograd.Function):
         d_pts = _encode_backward(net.pos_pe, ctx.p4, dX0)[:n] if want_in else None
         d_dirs = _encode_backward(net.dir_pe, ctx.d4, dD0)[:n] if (want_in and views) else None
         return (None, d_pts, d_dirs) + tuple(grads)
+
+
+def _backward16(ctx, d_raw, want_in):
+    """The backward pass of a step whose forward kept fp16 copies (STORE16): ONE kernel for the whole backward-data pass from d_raw
+    (nm_mlp_backward_net16: the views layer's adjoint, feature_linear's, the eight trunk layers'; dZ of every layer, d_feat and d_hv out as fp16),
+    then the weight gradients as batched fp16 products (nm_wgrad16): the eight 256 x 256 ones in one launch, the encoded-position columns of layer 0
+    and of the skip layer in a second, the views layer's two blocks in a third and fourth -- the last one against the encoded direction whose
+    padding column holds 1, so that it carries the views layer's bias gradient as its 64th column.  What stays on the float32 kernels: the
+    4-row heads (rgb_linear's weight, two bias sums) and, when the inputs want gradients, the three products behind d pts / d dirs."""
+    pk, net, n = ctx.pk, ctx.net, ctx.n
+    nerf = net.nerf
+    lib = _lib.lib()
+    dev = d_raw.device
+    n4, width, half = d_raw.shape[0], nerf.width, nerf.width // 2
+    h16, x0h, d0h, feat16, hv, n_pos, n_dir = ctx.h16, ctx.x0h, ctx.d0h, ctx.feat16, ctx.hv, pk.n_pos, pk.n_dir
+    ws = [torch.empty(4, device=dev, dtype=torch.float32)]
+
+    def grow(need):
+        if need > ws[0].numel():
+            ws[0] = torch.empty(int(need), device=dev, dtype=torch.float32)
+        return ws[0]
+    # ---- the 4-row heads on the float32 kernels: rgb_linear's weight = d_rgb^T hv, the biases of rgb_linear and alpha_linear = column sums of d_raw
+    gWr4 = torch.empty((4, half), device=dev, dtype=torch.float32)
+    _gemm(1, 1, 4, half, n4, d_raw, 4, hv, half, gWr4, half, ws=grow(lib.nm_gemm_workspace_floats(4, half, n4)))
+    gb4 = torch.empty(4, device=dev, dtype=torch.float32)
+    w = grow(lib.nm_colsum_workspace_floats(n4, 4))
+    _lib.check(lib.nm_colsum(_lib.dev_ptr(d_raw), n4, 4, 4, _lib.dev_ptr(gb4), _lib.dev_ptr(w), w.numel(), _lib.stream_ptr()), "nm_colsum")
+    # ---- the backward-data pass
+    amax = torch.zeros(1, device=dev, dtype=torch.float32)                 # largest magnitude entering the pass -> the scale of every fp16 copy
+    _lib.check(lib.nm_absmax(_lib.dev_ptr(d_raw), d_raw.numel(), _lib.dev_ptr(amax), _lib.stream_ptr()), "nm_absmax")
+    dz16 = torch.empty((8, n4, width), device=dev, dtype=torch.float16)    # dZ_7 .. dZ_0 (x scale, k-slot order)
+    dfeat16 = torch.empty((n4, width), device=dev, dtype=torch.float16)
+    dhv16 = torch.empty((n4, half), device=dev, dtype=torch.float16)
+    dz32 = torch.empty((2, n4, width), device=dev, dtype=torch.float32) if want_in else None      # layers 5, 0: the input gradient's products
+    dhv32 = torch.empty((n4, half), device=dev, dtype=torch.float32) if want_in else None
+    gbs = torch.empty((9, width), device=dev, dtype=torch.float32)
+    w = grow(lib.nm_mlp_backward_chain_workspace_floats(n4))
+    ptrs = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in nerf.ordered_params()])
+    _lib.check(lib.nm_mlp_backward_net16(net.train_handle(), ptrs, _lib.dev_ptr(d_raw), ctypes.c_void_p(ctx.bits.data_ptr()), ctypes.c_void_p(ctx.hvbits.data_ptr()), n4,
+                                         _lib.dev_ptr(amax), ctypes.c_void_p(dz16.data_ptr()), ctypes.c_void_p(dfeat16.data_ptr()), ctypes.c_void_p(dhv16.data_ptr()),
+                                         _lib.dev_ptr(dz32[0] if want_in else None), _lib.dev_ptr(dz32[1] if want_in else None), _lib.dev_ptr(dhv32),
+                                         _lib.dev_ptr(gbs), _lib.dev_ptr(w), w.numel(), _lib.stream_ptr()), "nm_mlp_backward_net16")
+    # ---- the weight gradients
+    gw = [torch.empty((width, (n_pos if i == 0 else width) + (n_pos if pk.skip[i] else 0)), device=dev, dtype=torch.float32) for i in range(8)]
+    feature_w = torch.empty((width, width), device=dev, dtype=torch.float32)
+    views_w = torch.empty((half, width + n_dir), device=dev, dtype=torch.float32)
+    views_x = torch.empty((half, 64), device=dev, dtype=torch.float32)      # [:, :n_dir] the encoded-direction columns, [:, 63] the bias gradient
+    alpha_w = torch.empty((1, width), device=dev, dtype=torch.float32)
+
+    def products(p_cols, q_cols, items):                                   # items: (dZ16 rows, activation16 rows, gradient, column offset)
+        k = len(items)
+        P = (ctypes.c_void_p * k)(*[a.data_ptr() for a, _, _, _ in items])
+        Q = (ctypes.c_void_p * k)(*[b.data_ptr() for _, b, _, _ in items])
+        C = (ctypes.c_void_p * k)(*[c.data_ptr() + 4 * off for _, _, c, off in items])
+        L = (ctypes.c_int * k)(*[c.shape[1] for _, _, c, _ in items])
+        w_ = grow(lib.nm_wgrad16_workspace_floats(k, n4, p_cols, q_cols))
+        _lib.check(lib.nm_wgrad16(k, p_cols, q_cols, P, Q, C, L, n4, _lib.dev_ptr(amax), _lib.dev_ptr(w_), w_.numel(), _lib.stream_ptr()), "nm_wgrad16")
+    products(width, width, [(dfeat16, h16[7], feature_w, 0)] + [(dz16[7 - i], h16[i - 1], gw[i], n_pos if pk.skip[i] else 0) for i in range(7, 0, -1)])
+    products(width, n_pos, [(dz16[7 - i], x0h, gw[i], 0) for i in range(8) if i == 0 or pk.skip[i]])
+    products(half, width, [(dhv16, feat16, views_w, 0)])
+    products(half, 64, [(dhv16, d0h, views_x, 0)])
+    views_w[:, width:] = views_x[:, :n_dir]
+    w = grow(lib.nm_wgrad_alpha16_workspace_floats(n4))
+    _lib.check(lib.nm_wgrad_alpha16(_lib.dev_ptr(d_raw), ctypes.c_void_p(h16[7].data_ptr()), n4, _lib.dev_ptr(alpha_w), _lib.dev_ptr(w), w.numel(), _lib.stream_ptr()),
+               "nm_wgrad_alpha16")
+    grads = []
+    for i in range(8):
+        grads += [gw[i], gbs[7 - i]]
+    grads += [views_w, views_x[:, 63].contiguous(), feature_w, gbs[8], alpha_w, gb4[3:4].contiguous(), gWr4[:3].contiguous(), gb4[:3].contiguous()]
+    d_pts = d_dirs = None
+    if want_in:                                                            # the encoded inputs' gradients: the layers they feed, then the encodings' adjoints
+        dX0 = torch.empty((n4, pk.kp), device=dev, dtype=torch.float32)
+        first = True
+        for i, slot in ((5, 0), (0, 1)):
+            if i == 0 or pk.skip[i]:
+                _gemm(0, 1, n4, pk.kp, width, dz32[slot], width, pk.Wpe(i), pk.kp, dX0, pk.kp, flags=0 if first else ACC)
+                first = False
+        dD0 = torch.empty((n4, pk.kd), device=dev, dtype=torch.float32)
+        _gemm(0, 1, n4, pk.kd, half, dhv32, half, pk.Wv[1], pk.kd, dD0, pk.kd)
+        d_pts = _encode_backward(net.pos_pe, ctx.p4, dX0)[:n]
+        d_dirs = _encode_backward(net.dir_pe, ctx.d4, dD0)[:n]
+    return (None, d_pts, d_dirs) + tuple(grads)
 
 
 def train_params(nerf):

@@ -73,8 +73,8 @@ def test_wgrad16_against_float64(G, n):
     Q = (ctypes.c_void_p * nprod)(*[t.data_ptr() for t in act16])
     C = (ctypes.c_void_p * nprod)(*[o.data_ptr() + 4 * f for o, f in zip(outs, offs)])
     Ld = (ctypes.c_int * nprod)(*[o.shape[1] for o in outs])
-    ws = torch.empty(int(G.lib.nm_wgrad16_workspace_floats(nprod, n, 256)), device='cuda')
-    G.L.check(G.lib.nm_wgrad16(nprod, 256, P, Q, C, Ld, n, G.L.dev_ptr(amax), G.L.dev_ptr(ws), ws.numel(), G.L.stream_ptr()), "wgrad16")
+    ws = torch.empty(int(G.lib.nm_wgrad16_workspace_floats(nprod, n, 256, 256)), device='cuda')
+    G.L.check(G.lib.nm_wgrad16(nprod, 256, 256, P, Q, C, Ld, n, G.L.dev_ptr(amax), G.L.dev_ptr(ws), ws.numel(), G.L.stream_ptr()), "wgrad16")
     for k in range(nprod):
         a64 = dz16[k].double() / s
         b64 = act16[k].double() / 32
@@ -94,14 +94,38 @@ def test_wgrad16_against_float64(G, n):
     Q = (ctypes.c_void_p * 2)(x016.data_ptr(), x016.data_ptr())
     C = (ctypes.c_void_p * 2)(o0.data_ptr(), o5.data_ptr())
     Ld = (ctypes.c_int * 2)(63, 319)
-    ws = torch.empty(int(G.lib.nm_wgrad16_workspace_floats(2, n, 63)), device='cuda')
-    G.L.check(G.lib.nm_wgrad16(2, 63, P, Q, C, Ld, n, G.L.dev_ptr(amax), G.L.dev_ptr(ws), ws.numel(), G.L.stream_ptr()), "wgrad16 (63)")
+    ws = torch.empty(int(G.lib.nm_wgrad16_workspace_floats(2, n, 256, 63)), device='cuda')
+    G.L.check(G.lib.nm_wgrad16(2, 256, 63, P, Q, C, Ld, n, G.L.dev_ptr(amax), G.L.dev_ptr(ws), ws.numel(), G.L.stream_ptr()), "wgrad16 (63)")
     for k, o in enumerate((o0, o5)):
         ref = torch.empty((256, 64), device='cuda', dtype=torch.float64)
         ref[perm] = (dz16[k].double() / s).T @ (x016.double() / 32)
         err = float((o[:, :63].double() - ref[:, :63]).abs().max() / ref.abs().max())
         assert err < 2e-6, (k, err)
     assert bool((o5[:, 63:] == 7.0).all())
+    # the views layer's forms: a 128-wide dZ (k-slot order of a 128-wide row) against a hidden operand and against an encoded input whose last column is 1
+    perm128 = perm[:128]
+    assert sorted(perm128.tolist()) == list(range(128))
+    dh = torch.randn((n, 128), device='cuda', generator=g) * 2e-5
+    dh16 = (dh * s).half()[:, perm128].contiguous()
+    x0b = torch.randn((n, 64), device='cuda', generator=g)
+    x0b[:, 27:] = 0
+    x0b[:, 63] = 1
+    x0b16 = (x0b * 32).half().contiguous()
+    ov, ox = torch.full((128, 283), 7.0, device='cuda'), torch.full((128, 64), 7.0, device='cuda')
+    for qc, q16, out in ((256, act16[1], ov), (64, x0b16, ox)):
+        P = (ctypes.c_void_p * 1)(dh16.data_ptr())
+        Q = (ctypes.c_void_p * 1)(q16.data_ptr())
+        C = (ctypes.c_void_p * 1)(out.data_ptr())
+        Ld = (ctypes.c_int * 1)(out.shape[1])
+        ws = torch.empty(int(G.lib.nm_wgrad16_workspace_floats(1, n, 128, qc)), device='cuda')
+        G.L.check(G.lib.nm_wgrad16(1, 128, qc, P, Q, C, Ld, n, G.L.dev_ptr(amax), G.L.dev_ptr(ws), ws.numel(), G.L.stream_ptr()), "wgrad16 (128)")
+    ref = torch.empty((128, 256), device='cuda', dtype=torch.float64)
+    ref[perm128[:, None], perm[None, :]] = (dh16.double() / s).T @ (act16[1].double() / 32)
+    assert float((ov[:, :256].double() - ref).abs().max() / ref.abs().max()) < 2e-6 and bool((ov[:, 256:] == 7.0).all())
+    ref = torch.empty((128, 64), device='cuda', dtype=torch.float64)
+    ref[perm128] = (dh16.double() / s).T @ (x0b16.double() / 32)
+    assert float((ox.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    assert float((ox[:, 63].double() - (dh16.double() / s).sum(0)[torch.argsort(perm128)]).abs().max() / ref[:, 63].abs().max()) < 2e-6      # the ones column = column sums
     # alpha_linear's row: sum_n d_raw[n][3] H7[n][:]
     d_raw = torch.randn((n, 4), device='cuda', generator=g)
     out = torch.empty(256, device='cuda')
@@ -119,6 +143,8 @@ def test_pe_encode16(G):
     a = G.train._encode(net.pos_pe, x, 64)
     b = G.train._encode16(net.pos_pe, x, 64)
     assert torch.equal(b, (a * 32).half())
+    c = G.train._encode16(net.dir_pe, x, 64, ones_col=63)
+    assert torch.equal(c[:, :27], (G.train._encode(net.dir_pe, x, 28)[:, :27] * 32).half()) and bool((c[:, 27:63] == 0).all()) and bool((c[:, 63] == 32).all())
 
 
 @pytest.mark.parametrize("n", [1000, 4096])
@@ -137,13 +163,25 @@ def test_forward_save16_is_the_rounded_float32_copy(G, n):
                                              G.L.dev_ptr(raw), G.L.stream_ptr()), "save_bits")
     h16 = torch.full((8, n, 256), 7.0, device='cuda', dtype=torch.float16)
     feat, hv2, raw2 = torch.empty((n, 256), device='cuda'), torch.empty_like(hv), torch.empty_like(raw)
+    feat16 = torch.full((n, 256), 7.0, device='cuda', dtype=torch.float16)
     bits2 = torch.zeros_like(bits)
-    G.L.check(G.lib.nm_mlp_forward_save16(h, G.L.dev_ptr(pts), G.L.dev_ptr(dirs), n, ctypes.c_void_p(h16.data_ptr()), G.L.dev_ptr(feat), G.L.dev_ptr(hv2),
-                                          ctypes.c_void_p(bits2.data_ptr()), G.L.dev_ptr(raw2), G.L.stream_ptr()), "save16")
+    hvbits = torch.zeros((n, 4), device='cuda', dtype=torch.int32)
+    G.L.check(G.lib.nm_mlp_forward_save16(h, G.L.dev_ptr(pts), G.L.dev_ptr(dirs), n, ctypes.c_void_p(h16.data_ptr()), G.L.dev_ptr(feat), ctypes.c_void_p(feat16.data_ptr()),
+                                          G.L.dev_ptr(hv2), ctypes.c_void_p(bits2.data_ptr()), ctypes.c_void_p(hvbits.data_ptr()), G.L.dev_ptr(raw2), G.L.stream_ptr()), "save16")
     assert torch.equal(raw, raw2) and torch.equal(hv, hv2) and torch.equal(bits, bits2) and torch.equal(feat, acts[8])
     perm = torch.from_numpy(slot_perm()).cuda()
     want = (acts[:8] * 32).half()[:, :, perm]
     assert torch.equal(h16, want), float((h16.float() - want.float()).abs().max())
+    assert torch.equal(feat16, (acts[8] * 32).half()[:, perm])
+    f = torch.arange(32, device='cuda')                                   # feature 8 q + 4 g + j of word nb <-> bit 16 g + 15 - (4 q + j)
+    pos = 16 * ((f >> 2) & 1) + 15 - (4 * (f >> 3) + (f & 3))
+    got = (hvbits.to(torch.int64)[..., None] >> pos) & 1
+    assert torch.equal(got, (hv > 0).reshape(n, 4, 32).to(torch.int64))
+    # without the float32 feature copy
+    feat16b, raw3 = torch.empty_like(feat16), torch.empty_like(raw)
+    G.L.check(G.lib.nm_mlp_forward_save16(h, G.L.dev_ptr(pts), G.L.dev_ptr(dirs), n, ctypes.c_void_p(h16.data_ptr()), None, ctypes.c_void_p(feat16b.data_ptr()),
+                                          G.L.dev_ptr(hv2), ctypes.c_void_p(bits2.data_ptr()), None, G.L.dev_ptr(raw3), G.L.stream_ptr()), "save16 (fp16 feature only)")
+    assert torch.equal(feat16b, feat16) and torch.equal(raw3, raw)
 
 
 @pytest.mark.parametrize("n,want_copies", [(1000, True), (4224, False)])
@@ -191,6 +229,64 @@ def test_backward_chain16_is_the_rounded_float32_chain(G, n, want_copies):
                                             ctypes.c_void_p(dz16.data_ptr()), None, None, None, G.L.dev_ptr(gb16), G.L.dev_ptr(ws), ws.numel(), G.L.stream_ptr()),
               "chain16 (saturating)")
     assert bool(torch.isfinite(dz16.float()).all()) and float(dz16.float().abs().max()) == 65504.0
+
+
+@pytest.mark.parametrize("n,want_copies", [(1000, True), (4224, False)])
+def test_backward_net16_against_float64(G, n, want_copies):
+    """nm_mlp_backward_net16: the views layer's adjoint formed in the kernel -- d_hv = (d_rgb W_rgb) * (hv > 0), d_feat = d_hv W_views[:, :256] -- then the
+    chain; against float64 of the same saved signs, and against nm_mlp_backward_chain16 fed with the float64 d_feat"""
+    net = G.syn.make_joiner(1).cuda().train()
+    g = torch.Generator(device='cuda').manual_seed(n + 1)
+    pts = (torch.rand((n, 3), device='cuda', generator=g) * 2 - 1).contiguous()
+    dirs = F.normalize(torch.randn((n, 3), device='cuda', generator=g), dim=-1).contiguous()
+    h = net.train_handle()
+    params = net.nerf.ordered_params()
+    ptrs = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in params])
+    G.L.check(G.lib.nm_mlp_refresh_f16(h, ptrs, G.L.stream_ptr()), "refresh")
+    h16 = torch.empty((8, n, 256), device='cuda', dtype=torch.float16)
+    feat16 = torch.empty((n, 256), device='cuda', dtype=torch.float16)
+    hv, raw = torch.empty((n, 128), device='cuda'), torch.empty((n, 4), device='cuda')
+    bits, hvbits = torch.zeros((8, n, 8), device='cuda', dtype=torch.int32), torch.zeros((n, 4), device='cuda', dtype=torch.int32)
+    G.L.check(G.lib.nm_mlp_forward_save16(h, G.L.dev_ptr(pts), G.L.dev_ptr(dirs), n, ctypes.c_void_p(h16.data_ptr()), None, ctypes.c_void_p(feat16.data_ptr()),
+                                          G.L.dev_ptr(hv), ctypes.c_void_p(bits.data_ptr()), ctypes.c_void_p(hvbits.data_ptr()), G.L.dev_ptr(raw), G.L.stream_ptr()), "save16")
+    d_raw = (torch.randn((n, 4), device='cuda', generator=g) * 2e-5).contiguous()
+    amax = torch.zeros(1, device='cuda')
+    G.L.check(G.lib.nm_absmax(G.L.dev_ptr(d_raw), d_raw.numel(), G.L.dev_ptr(amax), G.L.stream_ptr()), "absmax")
+    s = dz_scale(float(amax))
+    ws = torch.empty(int(G.lib.nm_mlp_backward_chain_workspace_floats(n)), device='cuda')
+    dz16 = torch.empty((8, n, 256), device='cuda', dtype=torch.float16)
+    df16 = torch.empty((n, 256), device='cuda', dtype=torch.float16)
+    dh16 = torch.full((n, 128), 7.0, device='cuda', dtype=torch.float16)
+    c5, c0, dh32 = ((torch.empty((n, 256), device='cuda'), torch.empty((n, 256), device='cuda'), torch.empty((n, 128), device='cuda')) if want_copies else (None, None, None))
+    gb = torch.empty((9, 256), device='cuda')
+    G.L.check(G.lib.nm_mlp_backward_net16(h, ptrs, G.L.dev_ptr(d_raw), ctypes.c_void_p(bits.data_ptr()), ctypes.c_void_p(hvbits.data_ptr()), n, G.L.dev_ptr(amax),
+                                          ctypes.c_void_p(dz16.data_ptr()), ctypes.c_void_p(df16.data_ptr()), ctypes.c_void_p(dh16.data_ptr()), G.L.dev_ptr(c5), G.L.dev_ptr(c0),
+                                          G.L.dev_ptr(dh32), G.L.dev_ptr(gb), G.L.dev_ptr(ws), ws.numel(), G.L.stream_ptr()), "net16")
+    perm = torch.from_numpy(slot_perm()).cuda()
+    inv256, inv128 = torch.argsort(perm), torch.argsort(perm[:128])
+    P = [p.detach().double() for p in params]
+    Wv, Wf, wa, Wr = P[16], P[18], P[20][0], P[22]                      # views [128][283], feature [256][256], alpha [256], rgb [3][128]
+    d_hv = (d_raw[:, :3].double() @ Wr) * (hv > 0)
+    got_hv = dh16.double()[:, inv128] / s
+    assert float((got_hv - d_hv).abs().max()) < 1e-3 * float(d_hv.abs().max())          # fp16 of an exact float32 sum of three products
+    if want_copies:
+        assert float((dh32.double() - d_hv).abs().max()) < 1e-6 * float(d_hv.abs().max())
+    d_feat = d_hv @ Wv[:, :256]
+    got_feat = df16.double()[:, inv256] / s
+    assert float((got_feat - d_feat).abs().max()) < 1e-3 * float(d_feat.abs().max())
+    assert float((gb[8].double() - d_feat.sum(0)).abs().max()) < 2e-5 * float(d_feat.sum(0).abs().max()) + 1e-12
+    # the chain below it: float64 with the saved signs
+    masks = ((bits.to(torch.int64)[..., None] >> (16 * ((torch.arange(32, device='cuda') >> 2) & 1) + 15 - (4 * (torch.arange(32, device='cuda') >> 3) + (torch.arange(32, device='cuda') & 3)))) & 1).reshape(8, n, 256).bool()
+    d = (d_feat @ Wf + d_raw[:, 3:4].double() * wa[None, :]) * masks[7]
+    W = P[0:16:2]
+    for i in range(7, -1, -1):
+        got = dz16[7 - i].double()[:, inv256] / s
+        assert float((got - d).abs().max()) < 1.5e-3 * float(d.abs().max()), i       # (fp16 storage: 2^-11 of the value, plus the split-bf16 chain's 2e-5)
+        assert float((gb[7 - i].double() - d.sum(0)).abs().max()) < 5e-5 * float(d.sum(0).abs().max()) + 1e-12, i
+        if want_copies and i in (5, 0):
+            assert float(((c5 if i == 5 else c0).double() - d).abs().max()) < 5e-5 * float(d.abs().max()), i
+        if i:
+            d = (d @ W[i][:, -256:]) * masks[i - 1]
 
 
 def _step(G, net, pts, dirs, tgt):
