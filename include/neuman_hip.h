@@ -195,7 +195,9 @@ int nm_mlp_backward_chain(nm_mlp_t mlp, const float* const* dev_params, const fl
  *     in K-SLOT ORDER: 16-byte chunk c, element e of a row holds feature 32 (c >> 2) + 8 (2 ((c >> 1) & 1) + (e >> 2)) + 4 (c & 1) + (e & 3)
  *     (mlp_layout.h slot_feature: the order the producing lanes hold them); feature_linear's output as save_feat [n][256] float32 and / or save_feat16
  *     [n][256] fp16 (x 32, k-slot order) (one of them required); save_hv [n][128] float32; save_bits [8][n][8] required; save_hvbits (nullable) [n][4]:
- *     the signs of the views layer's output, word f >> 5, bit order as save_bits.
+ *     the signs of the views layer's output, word f >> 5, bit order as save_bits; save_x0h / save_d0h (nullable) [n][64] fp16: the encoded position /
+ *     direction exactly as the kernel holds them (32 x value, natural order, zero beyond the encoding; the direction's column 63 holds 1 -- what
+ *     nm_pe_encode16 would give, without the extra launches).
  *   nm_mlp_backward_chain16: from d_feat / d_raw as nm_mlp_backward_chain's second form; dz16 [8][n][256] = fp16 of s x dZ_7 .. dZ_0 in k-slot order,
  *     dfeat16 (nullable) [n][256] = s x d_feat likewise, s = the power of two that puts *amax into [2, 4) (amax: a device scalar >= the largest magnitude
  *     entering the chain, nm_absmax; values beyond fp16's range saturate); dz32_layer5 / dz32_layer0 (nullable): float32 copies, natural order, of the
@@ -207,7 +209,8 @@ int nm_mlp_backward_chain(nm_mlp_t mlp, const float* const* dev_params, const fl
  *     float32 natural order (for the view-direction gradient); bias_grads [9][256]: rows 0..7 = layers 7..0, row 8 = feature_linear's.
  *   Workspace of nm_mlp_backward_chain_workspace_floats(n) floats each.  The consumers: nm_wgrad16, nm_wgrad_alpha16 below (section "training"). */
 int nm_mlp_forward_save16(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, uint16_t* save_h16, float* save_feat, uint16_t* save_feat16,
-                          float* save_hv, uint32_t* save_bits, uint32_t* save_hvbits, float* out, nm_stream_t stream);
+                          float* save_hv, uint32_t* save_bits, uint32_t* save_hvbits, uint16_t* save_x0h, uint16_t* save_d0h, float* out,
+                          nm_stream_t stream);
 int nm_mlp_backward_chain16(nm_mlp_t mlp, const float* const* dev_params, const float* d_feat, const float* d_raw, const uint32_t* relu_bits,
                             int64_t n, const float* amax, uint16_t* dz16, uint16_t* dfeat16, float* dz32_layer5, float* dz32_layer0,
                             float* bias_grads, float* workspace, int64_t workspace_floats, nm_stream_t stream);
@@ -533,6 +536,12 @@ int nm_absmax(const float* x, int64_t count, float* out_max, nm_stream_t stream)
 int64_t nm_wgrad16_workspace_floats(int nprod, int64_t n, int p_cols, int q_cols);
 int nm_wgrad16(int nprod, int p_cols, int q_cols, const uint16_t* const* dz16, const uint16_t* const* act16, float* const* dW, const int* ldw,
                int64_t n, const float* amax, float* workspace, int64_t workspace_floats, nm_stream_t stream);
+/* The 4-row heads of a step in one pass over d_raw [n][4], save_h16[7] and save_hv [n][128]: out[0..255] = alpha_linear's weight gradient
+ * sum_n d_raw[n][3] H7[n][:], out[256..639] = rgb_linear's [3][128] = sum_n d_raw[n][k] hv[n][:], out[640..643] = the column sums of d_raw (rgb_linear's and
+ * alpha_linear's bias gradients); *amax (nullable, a zeroed device scalar) = max |d_raw|: the scale source of nm_mlp_backward_net16 from the same read */
+int64_t nm_wgrad_heads16_workspace_floats(int64_t n);
+int nm_wgrad_heads16(const float* d_raw, const uint16_t* h16_7, const float* hv, int64_t n, float* out644, float* amax, float* workspace,
+                     int64_t workspace_floats, nm_stream_t stream);
 /* alpha_linear's weight gradient out[256] = sum_n d_raw[n][3] H7[n][:] from save_h16[7] (x 32, k-slot order) */
 int64_t nm_wgrad_alpha16_workspace_floats(int64_t n);
 int nm_wgrad_alpha16(const float* d_raw, const uint16_t* h16, int64_t n, float* out, float* workspace, int64_t workspace_floats,

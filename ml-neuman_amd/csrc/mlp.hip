@@ -78,6 +78,12 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
         // ---------------- position PE -> P
         fill_pe_any<F16>(lds, false, a, base, tid);
         __syncthreads();
+        if (SAVE == 2 && F16 && a.save_x0h) {                         // the encoded position as the weight-gradient products of layer 0 / the skip layer read it
+            for (int item = tid; item < nm::kPeChunks * kTileM; item += kThreads) {
+                const int c = item >> 7, row = item & (kTileM - 1);
+                if (base + row < a.n) a.save_x0h[(base + row) * 8 + c] = lds[P_BASE + c * kChunkU4 + row];
+            }
+        }
         NM_TICK(0)
         if (a.stop_stage == -1) { dump_act<F16>(lds, true, 64, a, base, tid); __syncthreads(); continue; }
 
@@ -175,6 +181,14 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
 
         // ---------------- stage 8: feature (linear, 256) + alpha block (waves 0..3, sample block w)
         float sigma = 0.f;
+        if (SAVE == 2 && F16 && a.save_d0h) {                         // P[0..3] holds the direction encoding since the skip layer's epilogue
+            for (int item = tid; item < nm::kPeChunks * kTileM; item += kThreads) {
+                const int c = item >> 7, row = item & (kTileM - 1);
+                uint4 v = make_uint4(0u, 0u, 0u, c == 7 ? 0x50000000u : 0u);      // slot 63 = fp16(32.0): the ones column (x 32)
+                if (c < 4) v = lds[P_BASE + c * kChunkU4 + row];
+                if (base + row < a.n) a.save_d0h[(base + row) * 8 + c] = v;
+            }
+        }
         {
             const nm::StageShape sh = nm::stage_shape(8);
             init_bias<4>(acc, B);
@@ -864,6 +878,7 @@ int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, con
     a.sigma_only = L.plain_head ? 2 : ((sigma_only && precision != NM_PREC_I8X3) ? 1 : 0);   // (the i8x3 kernel always evaluates the colour head)
     a.save_h = L.save_h; a.save_hv = L.save_hv; a.save_bits = L.save_bits; a.save_h16 = reinterpret_cast<uint4*>(L.save_h16);
     a.save_feat16 = reinterpret_cast<uint4*>(L.save_feat16); a.save_hvbits = L.save_hvbits;
+    a.save_x0h = reinterpret_cast<uint4*>(L.save_x0h); a.save_d0h = reinterpret_cast<uint4*>(L.save_d0h);
     a.pos = PeSpec{L.pe_kind, L.pos_nfreq, L.pos_octaves};
     a.dir = PeSpec{L.pe_kind, L.dir_nfreq, L.dir_octaves};
     const int64_t ntiles = (n + kTileM - 1) / kTileM;

@@ -75,6 +75,8 @@ struct MlpArgs {
                              //                     order (chunk c, element e <-> feature slot_feature(c, e)) INSTEAD of their float32 copies; save_h = [n][256] feature only (nullable then)
     uint4* save_feat16;      //                     nullable (with save_h16): [n][32] the feature layer's output the same way (fp16 of 32 x value, k-slot order)
     unsigned* save_hvbits;   //                     nullable (with save_h16): [n][4] the signs of stage 9 (views layer): word nb of a sample, bits as save_bits
+    uint4* save_x0h;         //                     nullable (with save_h16): [n][8] the position encoding as the kernel holds it: fp16 of 32 x value, natural order, slot 63 zero
+    uint4* save_d0h;         //                     nullable (with save_h16): [n][8] the direction encoding likewise in slots 0..31, zeros after, slot 63 = 1 (x 32)
 };
 
 // ---- positional encoding feature p of a 3-vector (reference models/vanilla.py:60-92) ---------------

@@ -761,7 +761,8 @@ int nm_mlp_forward_save(nm_mlp_t m, const float* pts, const float* dirs, int64_t
 }
 
 static int forward_save_impl(nm_mlp_t m, const float* pts, const float* dirs, int64_t n, float* save_h, float* save_hv, uint32_t* save_bits,
-                             void* save_h16, float* out, nm_stream_t stream, void* save_feat16 = nullptr, uint32_t* save_hvbits = nullptr) {
+                             void* save_h16, float* out, nm_stream_t stream, void* save_feat16 = nullptr, uint32_t* save_hvbits = nullptr,
+                             void* save_x0h = nullptr, void* save_d0h = nullptr) {
     NM_REQUIRE(m, "nm_mlp_forward_save: null handle");
     NM_REQUIRE(!m->desc.plain_head, "nm_mlp_forward_save: the plain-head net has no fused training forward");
     NM_REQUIRE(n >= 0, "nm_mlp_forward_save: negative n");
@@ -780,7 +781,7 @@ static int forward_save_impl(nm_mlp_t m, const float* pts, const float* dirs, in
     L.plain_head = 0;
     L.wstream8 = m->d_stream8;
     L.consts8 = m->d_consts8;
-    L.save_h = save_h; L.save_hv = save_hv; L.save_bits = save_bits; L.save_h16 = save_h16; L.save_feat16 = save_feat16; L.save_hvbits = save_hvbits;
+    L.save_h = save_h; L.save_hv = save_hv; L.save_bits = save_bits; L.save_h16 = save_h16; L.save_feat16 = save_feat16; L.save_hvbits = save_hvbits; L.save_x0h = save_x0h; L.save_d0h = save_d0h;
     return nm::launch_mlp_mfma(L, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, NM_PREC_FP16X3, -2, 1.f, out, nullptr, nullptr,
                                nm::as_stream(stream), 0, nullptr);
 }
@@ -791,9 +792,10 @@ int nm_mlp_forward_save_bits(nm_mlp_t m, const float* pts, const float* dirs, in
 }
 
 int nm_mlp_forward_save16(nm_mlp_t m, const float* pts, const float* dirs, int64_t n, uint16_t* save_h16, float* save_feat, uint16_t* save_feat16,
-                          float* save_hv, uint32_t* save_bits, uint32_t* save_hvbits, float* out, nm_stream_t stream) {
+                          float* save_hv, uint32_t* save_bits, uint32_t* save_hvbits, uint16_t* save_x0h, uint16_t* save_d0h, float* out, nm_stream_t stream) {
     NM_REQUIRE(n == 0 || (save_h16 && save_bits && (save_feat || save_feat16)), "nm_mlp_forward_save16: null pointer");
-    return forward_save_impl(m, pts, dirs, n, save_feat, save_hv, save_bits, save_h16, out, stream, save_feat16, save_hvbits);
+    NM_REQUIRE(((reinterpret_cast<uintptr_t>(save_x0h) | reinterpret_cast<uintptr_t>(save_d0h)) & 15) == 0, "nm_mlp_forward_save16: outputs must be 16-byte aligned");
+    return forward_save_impl(m, pts, dirs, n, save_feat, save_hv, save_bits, save_h16, out, stream, save_feat16, save_hvbits, save_x0h, save_d0h);
 }
 
 int64_t nm_mlp_backward_chain_workspace_floats(int64_t n) { return ((n + nm::kTileM - 1) / nm::kTileM) * 9 * 256; }

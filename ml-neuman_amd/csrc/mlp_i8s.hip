@@ -359,7 +359,7 @@ int launch_mlp_i8s(const MlpLaunch& L, const void* image8, const float* pts, con
     a.pts = pts; a.dirs = dirs; a.origin = origin; a.direction = direction; a.z = z;
     a.out = out; a.dbg = nullptr; a.prof = nullptr; a.n = n; a.S = S; a.in_mode = in_mode; a.stop_stage = -2; a.sigma_scale = sigma_scale;
     a.sigma_only = 0;
-    a.save_h = nullptr; a.save_hv = nullptr; a.save_bits = nullptr; a.save_h16 = nullptr; a.save_feat16 = nullptr; a.save_hvbits = nullptr;
+    a.save_h = nullptr; a.save_hv = nullptr; a.save_bits = nullptr; a.save_h16 = nullptr; a.save_feat16 = nullptr; a.save_hvbits = nullptr; a.save_x0h = nullptr; a.save_d0h = nullptr;
     a.pos = PeSpec{L.pe_kind, L.pos_nfreq, L.pos_octaves};
     a.dir = PeSpec{L.pe_kind, L.dir_nfreq, L.dir_octaves};
     A.consts8 = L.consts8;

@@ -24,6 +24,7 @@ struct MlpLaunch {
     void* save_h16 = nullptr;                     //   nullable: [8][n][256] fp16 trunk activations (x 32, k-slot order) instead of float32; save_h is then [n][256]: feature only (nullable)
     void* save_feat16 = nullptr;                  //   nullable: [n][256] fp16 feature output likewise;  save_hvbits nullable: [n][4] signs of the views layer
     unsigned* save_hvbits = nullptr;
+    void* save_x0h = nullptr; void* save_d0h = nullptr;   //   nullable: [n][64] fp16 encodings of position / direction (x 32; the direction's slot 63 holds 1)
 };
 struct RefLaunch {
     const float* wt; const float* bias; int off[12]; int boff[12]; const float* petab;

@@ -608,6 +608,70 @@ __global__ __launch_bounds__(256) void wgrad_alpha16_kernel(const float* __restr
     }
 }
 
+// The 4-row heads of a training step in ONE pass over d_raw, the fp16 copy of H_7 and hv: alpha_linear's weight gradient (sum_n d sigma H7),
+// rgb_linear's (sum_n d rgb_k hv), the column sums of d_raw (their bias gradients) and max |d_raw| (the scale source of the backward-data pass).
+// Thread (row group r of 8, lane c of 32) of a band of kHeadRows rows: chunk c of H7's row (8 halves) and columns 4 c .. 4 c + 3 of hv's; the
+// eight row groups are summed through LDS in order, the bands by splitk_reduce_kernel.
+constexpr int kHeadRows = 512;
+constexpr int kHeadOut = 256 + 3 * 128 + 4;
+__global__ __launch_bounds__(256) void wgrad_heads16_kernel(const float* __restrict__ d_raw, const uint4* __restrict__ h16, const float* __restrict__ hv, int64_t n,
+                                                            float* __restrict__ partial, unsigned* __restrict__ amax) {
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const int64_t r0 = (int64_t)blockIdx.x * kHeadRows, r1 = r0 + kHeadRows < n ? r0 + kHeadRows : n;
+    float aa[8], ar[3][4], ab[4] = {0.f, 0.f, 0.f, 0.f}, m = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) aa[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ar[k][j] = 0.f;
+    for (int64_t row = r0 + r; row < r1; row += 8) {
+        const float4 dr = *reinterpret_cast<const float4*>(d_raw + row * 4);
+        const uint4 h = h16[row * 32 + c];
+        const float4 v = *reinterpret_cast<const float4*>(hv + row * 128 + 4 * c);
+        const unsigned hw[4] = {h.x, h.y, h.z, h.w};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            aa[2 * p] = fmaf(dr.w, (float)__builtin_bit_cast(_Float16, (unsigned short)(hw[p] & 0xffffu)), aa[2 * p]);
+            aa[2 * p + 1] = fmaf(dr.w, (float)__builtin_bit_cast(_Float16, (unsigned short)(hw[p] >> 16)), aa[2 * p + 1]);
+        }
+        const float d3[3] = {dr.x, dr.y, dr.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            ar[k][0] = fmaf(d3[k], v.x, ar[k][0]); ar[k][1] = fmaf(d3[k], v.y, ar[k][1]);
+            ar[k][2] = fmaf(d3[k], v.z, ar[k][2]); ar[k][3] = fmaf(d3[k], v.w, ar[k][3]);
+        }
+        ab[0] += dr.x; ab[1] += dr.y; ab[2] += dr.z; ab[3] += dr.w;
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(dr.x), fabsf(dr.y)), fmaxf(fabsf(dr.z), fabsf(dr.w))));
+    }
+    __shared__ float sh[8][kHeadOut];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sh[r][8 * c + e] = aa[e];                // slot order 8 c + e
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sh[r][256 + 128 * k + 4 * c + j] = ar[k][j];
+    if (c == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sh[r][640 + j] = ab[j];
+    }
+    __syncthreads();
+    float* P = partial + (int64_t)blockIdx.x * kHeadOut;
+    for (int i = threadIdx.x; i < kHeadOut; i += 256) {
+        float s = sh[0][i];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) s += sh[q][i];
+        if (i < 256) {                                                  // slot p = 8 c + e -> feature; x 1/32
+            const int cc = i >> 3, e = i & 7;
+            P[32 * (cc >> 2) + 8 * (2 * ((cc >> 1) & 1) + (e >> 2)) + 4 * (cc & 1) + (e & 3)] = s * (1.f / kNmAct16Scale);
+        } else P[i] = s;
+    }
+    if (amax) {
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));
+    }
+}
+
 // largest magnitude of x[0 .. count): *out = max(*out, ...) (bit pattern of a non-negative float: unsigned order = float order)
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t count, unsigned* __restrict__ out) {
     float m = 0.f;
@@ -708,27 +772,38 @@ __global__ __launch_bounds__(256) void pe_encode_kernel(const float* __restrict_
 }
 
 // adjoint of pe_encode_kernel: dx [n,3] from the gradient g [n,ld] of the encoded features, one thread per row
-__global__ __launch_bounds__(256) void pe_backward_kernel(const float* __restrict__ x, int64_t n, int D, int kind, int nfreq,
-                                                          const float* __restrict__ tab, const float* __restrict__ g, int ld, float* __restrict__ dx) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
+constexpr int kPeRows = 128;
+__global__ __launch_bounds__(kPeRows) void pe_backward_kernel(const float* __restrict__ x, int64_t n, int D, int kind, int nfreq,
+                                                              const float* __restrict__ tab, const float* __restrict__ g, int ld, float* __restrict__ dx) {
+    // a workgroup takes 128 rows: their gradient rows go through LDS with coalesced loads (row stride ld + 1: a thread walking its own
+    // row then hits every bank once per wave), one sincos per (row, band, coordinate) instead of a sin and a cos
+    extern __shared__ float tile[];                                  // [128][ld + 1]
+    const int64_t r0 = (int64_t)blockIdx.x * kPeRows;
+    const int rows = (int)(n - r0 < kPeRows ? n - r0 : kPeRows);
+    const int lds = ld + 1;
+    for (int i = threadIdx.x; i < rows * ld; i += kPeRows) tile[(i / ld) * lds + i % ld] = g[r0 * ld + i];
+    __syncthreads();
+    if ((int)threadIdx.x >= rows) return;
+    const int64_t r = r0 + threadIdx.x;
     float xv[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* gr = g + r * ld;
+    const float* gr = tile + threadIdx.x * lds;
     for (int k = 0; k < D; ++k) { xv[k] = x[r * D + k]; d[k] = gr[k]; }
     if (kind == NM_PE_POSENC) {
         for (int b = 0; b < nfreq; ++b) {
             const float f = tab[b];
             for (int k = 0; k < D; ++k) {
-                const float a = xv[k] * f;
-                d[k] += f * (gr[D + 2 * D * b + k] * cosf(a) - gr[D + 2 * D * b + D + k] * sinf(a));
+                float sn, cs;
+                sincosf(xv[k] * f, &sn, &cs);
+                d[k] += f * (gr[D + 2 * D * b + k] * cs - gr[D + 2 * D * b + D + k] * sn);
             }
         }
     } else {
         const int n3 = 3 * nfreq;
         for (int m = 0; m < n3; ++m) {
             const float* b = tab + 3 * m;
-            const float a = fmaf(xv[2], b[2], fmaf(xv[1], b[1], xv[0] * b[0]));
-            const float t = gr[3 + m] * cosf(a) - gr[3 + n3 + m] * sinf(a);
+            float sn, cs;
+            sincosf(fmaf(xv[2], b[2], fmaf(xv[1], b[1], xv[0] * b[0])), &sn, &cs);
+            const float t = gr[3 + m] * cs - gr[3 + n3 + m] * sn;
 #pragma unroll
             for (int k = 0; k < 3; ++k) d[k] += b[k] * t;
         }
@@ -1042,6 +1117,21 @@ int nm_wgrad16(int nprod, int p_cols, int q_cols, const uint16_t* const* dz16, c
     return NQ == 256 ? wgrad16_launch<128, 256>(g, nprod, st) : wgrad16_launch<128, 64>(g, nprod, st);
 }
 
+int64_t nm_wgrad_heads16_workspace_floats(int64_t n) { return ((n + kHeadRows - 1) / kHeadRows) * kHeadOut; }
+int nm_wgrad_heads16(const float* d_raw, const uint16_t* h16_7, const float* hv, int64_t n, float* out644, float* amax, float* workspace,
+                     int64_t workspace_floats, nm_stream_t stream) {
+    NM_REQUIRE(n >= 1 && d_raw && h16_7 && hv && out644 && workspace, "nm_wgrad_heads16: bad arguments");
+    NM_REQUIRE((((uintptr_t)d_raw | (uintptr_t)h16_7 | (uintptr_t)hv) & 15) == 0, "nm_wgrad_heads16: inputs must be 16-byte aligned");
+    const int bands = (int)((n + kHeadRows - 1) / kHeadRows);
+    NM_REQUIRE(workspace_floats >= (int64_t)bands * kHeadOut, "nm_wgrad_heads16: needs %lld floats of workspace", (long long)bands * kHeadOut);
+    hipStream_t st = nm::as_stream(stream);
+    hipLaunchKernelGGL(wgrad_heads16_kernel, dim3(bands), dim3(256), 0, st, d_raw, reinterpret_cast<const uint4*>(h16_7), hv, n, workspace,
+                       reinterpret_cast<unsigned*>(amax));
+    if (int rc = nm::check_launch("wgrad_heads16_kernel")) return rc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((kHeadOut + 255) / 256), dim3(256), 0, st, workspace, bands, 1, kHeadOut, out644, kHeadOut, 0);
+    return nm::check_launch("splitk_reduce_kernel");
+}
+
 int64_t nm_wgrad_alpha16_workspace_floats(int64_t n) { return ((n + kAlphaRows - 1) / kAlphaRows) * 256; }
 int nm_wgrad_alpha16(const float* d_raw, const uint16_t* h16, int64_t n, float* out, float* workspace, int64_t workspace_floats, nm_stream_t stream) {
     NM_REQUIRE(n >= 1 && d_raw && h16 && out && workspace, "nm_wgrad_alpha16: bad arguments");
@@ -1101,7 +1191,9 @@ int nm_pe_backward(const float* x, int64_t n, int dims, int kind, int n_freqs, c
     NM_REQUIRE(kind == NM_PE_POSENC || kind == NM_PE_ROTATE, "nm_pe_backward: mapping %d", kind);
     if (n == 0) return NM_OK;
     NM_REQUIRE(x && g && dx && (table || n_freqs == 0), "nm_pe_backward: null pointer");
-    hipLaunchKernelGGL(pe_backward_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nm::as_stream(stream), x, n, dims, kind, n_freqs, table, g, ld, dx);
+    NM_REQUIRE(ld <= 120, "nm_pe_backward: ld %d (rows of at most 120 encoded features)", ld);
+    hipLaunchKernelGGL(pe_backward_kernel, dim3((unsigned)((n + kPeRows - 1) / kPeRows)), dim3(kPeRows), (size_t)kPeRows * (ld + 1) * sizeof(float), nm::as_stream(stream), x, n, dims, kind,
+                       n_freqs, table, g, ld, dx);
     return nm::check_launch("pe_backward_kernel");
 }
 

@@ -57,8 +57,8 @@ SIGNATURES = {
     "nm_mlp_backward_chain_workspace_floats": (i64, [i64]),
     "nm_mlp_forward_save_bits": (i32, [ctypes.c_void_p, c_f32p, c_f32p, i64, c_f32p, c_f32p, ctypes.c_void_p, c_f32p, c_stream]),
     "nm_mlp_backward_chain": (i32, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p, i64, c_f32p, c_f32p, c_f32p, i64, c_stream]),
-    "nm_mlp_forward_save16": (i32, [ctypes.c_void_p, c_f32p, c_f32p, i64, ctypes.c_void_p, c_f32p, ctypes.c_void_p, c_f32p, ctypes.c_void_p, ctypes.c_void_p, c_f32p,
-                                    c_stream]),
+    "nm_mlp_forward_save16": (i32, [ctypes.c_void_p, c_f32p, c_f32p, i64, ctypes.c_void_p, c_f32p, ctypes.c_void_p, c_f32p, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_stream]),
     "nm_mlp_backward_net16": (i32, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, ctypes.c_void_p, ctypes.c_void_p, i64, c_f32p, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, c_stream]),
     "nm_mlp_backward_chain16": (i32, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_void_p, i64, c_f32p, ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p,
@@ -101,6 +101,8 @@ SIGNATURES = {
     "nm_wgrad16_workspace_floats": (i64, [i32, i64, i32, i32]),
     "nm_wgrad16": (i32, [i32, i32, i32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), i64,
                          c_f32p, c_f32p, i64, c_stream]),
+    "nm_wgrad_heads16_workspace_floats": (i64, [i64]),
+    "nm_wgrad_heads16": (i32, [c_f32p, ctypes.c_void_p, c_f32p, i64, c_f32p, c_f32p, c_f32p, i64, c_stream]),
     "nm_wgrad_alpha16_workspace_floats": (i64, [i64]),
     "nm_wgrad_alpha16": (i32, [c_f32p, ctypes.c_void_p, i64, c_f32p, c_f32p, i64, c_stream]),
     "nm_colsum_workspace_floats": (i64, [i64, i32]),

@@ -221,12 +221,15 @@ class _MLP(torch.autograd.Function):
                 h16 = torch.empty((8, n4, width), device=dev, dtype=torch.float16)
                 feat16 = torch.empty((n4, width), device=dev, dtype=torch.float16)
                 hvbits = torch.empty((n4, 4), device=dev, dtype=torch.int32)
+                # the encodings as fp16 operands of the weight-gradient products, written by the forward kernel from its own encoding buffers; the
+                # view encoding's last padding column holds 1: its product with d_hv is the views layer's bias gradient
+                x0h = torch.empty((n4, 64), device=dev, dtype=torch.float16)
+                d0h = torch.empty((n4, 64), device=dev, dtype=torch.float16)
                 _lib.check(_lib.lib().nm_mlp_forward_save16(handle, _lib.dev_ptr(p4), _lib.dev_ptr(d4), n4, ctypes.c_void_p(h16.data_ptr()), None,
                                                             ctypes.c_void_p(feat16.data_ptr()), _lib.dev_ptr(hv), ctypes.c_void_p(bits.data_ptr()),
-                                                            ctypes.c_void_p(hvbits.data_ptr()), _lib.dev_ptr(raw), _lib.stream_ptr()), "nm_mlp_forward_save16")
-                # the encodings as fp16 operands of the weight-gradient products; the view encoding's last padding column holds 1: its product
-                # with d_hv is the views layer's bias gradient
-                ctx.h16, ctx.x0h, ctx.d0h, ctx.feat16, ctx.hvbits = h16, _encode16(net.pos_pe, p4), _encode16(net.dir_pe, d4, ones_col=63), feat16, hvbits
+                                                            ctypes.c_void_p(hvbits.data_ptr()), ctypes.c_void_p(x0h.data_ptr()), ctypes.c_void_p(d0h.data_ptr()),
+                                                            _lib.dev_ptr(raw), _lib.stream_ptr()), "nm_mlp_forward_save16")
+                ctx.h16, ctx.x0h, ctx.d0h, ctx.feat16, ctx.hvbits = h16, x0h, d0h, feat16, hvbits
                 acts = H = feat = D0 = None
             else:
                 acts = torch.empty((9, n4, width), device=dev, dtype=torch.float32)
@@ -427,15 +430,15 @@ def _backward16(ctx, d_raw, want_in):
         if need > ws[0].numel():
             ws[0] = torch.empty(int(need), device=dev, dtype=torch.float32)
         return ws[0]
-    # ---- the 4-row heads on the float32 kernels: rgb_linear's weight = d_rgb^T hv, the biases of rgb_linear and alpha_linear = column sums of d_raw
-    gWr4 = torch.empty((4, half), device=dev, dtype=torch.float32)
-    _gemm(1, 1, 4, half, n4, d_raw, 4, hv, half, gWr4, half, ws=grow(lib.nm_gemm_workspace_floats(4, half, n4)))
-    gb4 = torch.empty(4, device=dev, dtype=torch.float32)
-    w = grow(lib.nm_colsum_workspace_floats(n4, 4))
-    _lib.check(lib.nm_colsum(_lib.dev_ptr(d_raw), n4, 4, 4, _lib.dev_ptr(gb4), _lib.dev_ptr(w), w.numel(), _lib.stream_ptr()), "nm_colsum")
+    # ---- the 4-row heads in one pass over d_raw, H_7's fp16 copy and hv: alpha_linear's and rgb_linear's weight gradients, their bias gradients
+    # (column sums of d_raw) and max |d_raw| -> the scale of every fp16 copy below
+    amax = torch.zeros(1, device=dev, dtype=torch.float32)
+    heads = torch.empty(644, device=dev, dtype=torch.float32)
+    w = grow(lib.nm_wgrad_heads16_workspace_floats(n4))
+    _lib.check(lib.nm_wgrad_heads16(_lib.dev_ptr(d_raw), ctypes.c_void_p(h16[7].data_ptr()), _lib.dev_ptr(hv), n4, _lib.dev_ptr(heads), _lib.dev_ptr(amax), _lib.dev_ptr(w),
+                                    w.numel(), _lib.stream_ptr()), "nm_wgrad_heads16")
+    alpha_w, rgb_w, rgb_b, alpha_b = heads[:256].view(1, 256), heads[256:640].view(3, half), heads[640:643], heads[643:644]
     # ---- the backward-data pass
-    amax = torch.zeros(1, device=dev, dtype=torch.float32)                 # largest magnitude entering the pass -> the scale of every fp16 copy
-    _lib.check(lib.nm_absmax(_lib.dev_ptr(d_raw), d_raw.numel(), _lib.dev_ptr(amax), _lib.stream_ptr()), "nm_absmax")
     dz16 = torch.empty((8, n4, width), device=dev, dtype=torch.float16)    # dZ_7 .. dZ_0 (x scale, k-slot order)
     dfeat16 = torch.empty((n4, width), device=dev, dtype=torch.float16)
     dhv16 = torch.empty((n4, half), device=dev, dtype=torch.float16)
@@ -453,7 +456,6 @@ def _backward16(ctx, d_raw, want_in):
     feature_w = torch.empty((width, width), device=dev, dtype=torch.float32)
     views_w = torch.empty((half, width + n_dir), device=dev, dtype=torch.float32)
     views_x = torch.empty((half, 64), device=dev, dtype=torch.float32)      # [:, :n_dir] the encoded-direction columns, [:, 63] the bias gradient
-    alpha_w = torch.empty((1, width), device=dev, dtype=torch.float32)
 
     def products(p_cols, q_cols, items):                                   # items: (dZ16 rows, activation16 rows, gradient, column offset)
         k = len(items)
@@ -468,13 +470,10 @@ def _backward16(ctx, d_raw, want_in):
     products(half, width, [(dhv16, feat16, views_w, 0)])
     products(half, 64, [(dhv16, d0h, views_x, 0)])
     views_w[:, width:] = views_x[:, :n_dir]
-    w = grow(lib.nm_wgrad_alpha16_workspace_floats(n4))
-    _lib.check(lib.nm_wgrad_alpha16(_lib.dev_ptr(d_raw), ctypes.c_void_p(h16[7].data_ptr()), n4, _lib.dev_ptr(alpha_w), _lib.dev_ptr(w), w.numel(), _lib.stream_ptr()),
-               "nm_wgrad_alpha16")
     grads = []
     for i in range(8):
         grads += [gw[i], gbs[7 - i]]
-    grads += [views_w, views_x[:, 63].contiguous(), feature_w, gbs[8], alpha_w, gb4[3:4].contiguous(), gWr4[:3].contiguous(), gb4[:3].contiguous()]
+    grads += [views_w, views_x[:, 63].contiguous(), feature_w, gbs[8], alpha_w, alpha_b, rgb_w, rgb_b]
     d_pts = d_dirs = None
     if want_in:                                                            # the encoded inputs' gradients: the layers they feed, then the encodings' adjoints
         dX0 = torch.empty((n4, pk.kp), device=dev, dtype=torch.float32)

@@ -4,7 +4,7 @@ fp16 copies of the activations / dZ from 32768 samples on), from the REFERENCE I
 Run in the build container only (needs /root/reference):   python tests/golden/make_golden_train_big.py
 
 The reference's own NeRFTrainer.loss_func (trainers/vanilla_nerf_trainer.py:45-96), unmodified, + torch autograd's backward, as
-make_golden_train.py -- 512 rays x 64 coarse / 64 + 64 fine samples (32768 / 65536 evaluations).  Kept: the batch, both z arrays, the
+make_golden_train.py -- 2048 rays x 64 coarse / 64 + 64 fine samples (131072 / 262144 evaluations: the order of the trainers' batches).  Kept: the batch, both z arrays, the
 losses, rgb maps, and per parameter tensor the summary of make_golden_train.grad_summary (three full rows, sum, sum of magnitudes, a fixed
 random projection)."""
 import os
@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 import make_golden_train as M  # noqa: E402  (sets up the reference imports)
 
-R, S, NI = 512, 64, 64
+R, S, NI = 2048, 64, 64
 
 
 def main():
