@@ -185,7 +185,16 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
             for (int item = tid; item < nm::kPeChunks * kTileM; item += kThreads) {
                 const int c = item >> 7, row = item & (kTileM - 1);
                 uint4 v = make_uint4(0u, 0u, 0u, c == 7 ? 0x50000000u : 0u);      // slot 63 = fp16(32.0): the ones column (x 32)
-                if (c < 4) v = lds[P_BASE + c * kChunkU4 + row];
+                if (c < 4) {
+                    v = lds[P_BASE + c * kChunkU4 + row];
+                    // slots beyond the encoding's width still hold this tile's POSITION encoding (the network's weights there are zero; a product with
+                    // these rows must see zeros)
+                    const int keep = 3 + 6 * a.dir.nfreq - 8 * c;                  // leading halves of the chunk that belong to the encoding
+                    unsigned wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) wd[p] &= (2 * p + 1 < keep ? 0xffffffffu : (2 * p < keep ? 0x0000ffffu : 0u));
+                    v = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+                }
                 if (base + row < a.n) a.save_d0h[(base + row) * 8 + c] = v;
             }
         }
