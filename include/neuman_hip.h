@@ -165,7 +165,7 @@ int nm_mlp_forward(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n,
  * ReLU (:140-142) -- written from the kernel's epilogues, so a tile's activations never return from HBM between layers.
  * nm_mlp_refresh_f16 rewrites the handle's split-fp16 weight image from DEVICE-resident parameters (24 device pointers, reference
  * state_dict order) in three small kernels: what nm_mlp_create packs on the host, bit for bit, for weights an optimiser changes every
- * iteration.  Not for the plain-head net. */
+ * iteration.  The plain-head net: 18 tensors (the trunk's 16, output_linear's weight [4][256] and bias [4]). */
 int nm_mlp_refresh_f16(nm_mlp_t mlp, const float* const* dev_params, nm_stream_t stream);
 int nm_mlp_forward_save(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, float* save_h, float* save_hv,
                         float* out, nm_stream_t stream);
@@ -214,6 +214,13 @@ int nm_mlp_forward_save16(nm_mlp_t mlp, const float* pts, const float* dirs, int
 int nm_mlp_backward_chain16(nm_mlp_t mlp, const float* const* dev_params, const float* d_feat, const float* d_raw, const uint32_t* relu_bits,
                             int64_t n, const float* amax, uint16_t* dz16, uint16_t* dfeat16, float* dz32_layer5, float* dz32_layer0,
                             float* bias_grads, float* workspace, int64_t workspace_floats, nm_stream_t stream);
+/* ... of the plain-head net (use_viewdirs=False: output_linear [4][256] straight off layer 7; nm_mlp_forward_save16 then keeps save_h16 / save_bits /
+ * save_x0h only and dev_params are 18 tensors: the trunk's 16, output_linear's weight padded to [4][256] and bias [4]): dZ_7 = (d_out W_out) * (H_7 > 0)
+ * from d_out [n][4], then the trunk; dz16 [8][n][256], bias_grads [8][256] = layers 7 .. 0.  What the offset nets of the human trainer run on
+ * (models/vanilla.py:169-205, 3 outputs: a zero fourth row) once their constant time input is folded into the biases (neuman_hip/train.py). */
+int nm_mlp_backward_plain16(nm_mlp_t mlp, const float* const* dev_params, const float* d_out, const uint32_t* relu_bits, int64_t n, const float* amax,
+                            uint16_t* dz16, float* dz32_layer5, float* dz32_layer0, float* bias_grads, float* workspace, int64_t workspace_floats,
+                            nm_stream_t stream);
 int nm_mlp_backward_net16(nm_mlp_t mlp, const float* const* dev_params, const float* d_raw, const uint32_t* relu_bits, const uint32_t* hv_bits,
                           int64_t n, const float* amax, uint16_t* dz16, uint16_t* dfeat16, uint16_t* dhv16, float* dz32_layer5, float* dz32_layer0,
                           float* dhv32, float* bias_grads, float* workspace, int64_t workspace_floats, nm_stream_t stream);
@@ -542,6 +549,10 @@ int nm_wgrad16(int nprod, int p_cols, int q_cols, const uint16_t* const* dz16, c
 int64_t nm_wgrad_heads16_workspace_floats(int64_t n);
 int nm_wgrad_heads16(const float* d_raw, const uint16_t* h16_7, const float* hv, int64_t n, float* out644, float* amax, float* workspace,
                      int64_t workspace_floats, nm_stream_t stream);
+/* ... and of the plain-head net: out[0..1023] = output_linear's [4][256] = sum_n d_out[n][k] H7[n][:], out[1024..1027] = the column sums of d_out; amax as above */
+int64_t nm_wgrad_out16_workspace_floats(int64_t n);
+int nm_wgrad_out16(const float* d_out, const uint16_t* h16_7, int64_t n, float* out1028, float* amax, float* workspace, int64_t workspace_floats,
+                   nm_stream_t stream);
 /* alpha_linear's weight gradient out[256] = sum_n d_raw[n][3] H7[n][:] from save_h16[7] (x 32, k-slot order) */
 int64_t nm_wgrad_alpha16_workspace_floats(int64_t n);
 int nm_wgrad_alpha16(const float* d_raw, const uint16_t* h16, int64_t n, float* out, float* workspace, int64_t workspace_floats,

@@ -56,9 +56,10 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b, float sc) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
 
-template <int MODE>                                                 // 0: from dz_top = dZ_7; 1: from d_feat / d_raw; 2: from d_raw alone (the views layer's adjoint too)
+template <int MODE>                                                 // 0: from dz_top = dZ_7; 1: from d_feat / d_raw; 2: from d_raw alone (the views layer's adjoint too);
+                                                                    // 3: the plain-head net from d_out [n][4]: stage 0 = d_out W_out (K = 4, as two k-steps), layers 7 .. 0
 __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs a) {
-    constexpr bool HEAD = MODE >= 1, NET = MODE == 2;
+    constexpr bool HEAD = MODE >= 1, NET = MODE == 2, PLAIN = MODE == 3;
     constexpr int NS = HEAD ? kBwdSlots : kBwdStages;               // stages of a tile; stage s reads image slot s + (HEAD ? 0 : 1)
     __shared__ uint4 lds[LDS_U4];
     constexpr int PREC = NM_PREC_BF16X3;
@@ -157,11 +158,16 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
         } else {
         // ---- dZ_7 of the tile -> split bf16 in LDS, k-slot order (chunk c, element e) = feature slot_feature(c, e): two runs of 4 features
 #pragma unroll 1
-        for (int item = tid; item < nm::kHChunks * kTileM; item += kThreads) {
+        for (int item = tid; item < (PLAIN ? 4 : nm::kHChunks) * kTileM; item += kThreads) {
             const int c = item >> 7, row = item & (kTileM - 1);
             const int64_t i = base + row;
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (i < a.n) {
+            if (PLAIN) {                                              // k-slots 0..3 of chunk 0 = d_out's four columns; the rest of the two k-steps zero
+                if (c == 0 && i < a.n) {
+                    const float4 dr = *reinterpret_cast<const float4*>(a.d_raw + i * 4);
+                    v[0] = dr.x; v[1] = dr.y; v[2] = dr.z; v[3] = dr.w;
+                }
+            } else if (i < a.n) {
                 const float* src = (HEAD ? a.d_feat : a.dz_top) + i * 256 + nm::slot_feature(c, 0);
                 const float4 lo4 = *reinterpret_cast<const float4*>(src), hi4 = *reinterpret_cast<const float4*>(src + 8);
                 v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w; v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
@@ -182,13 +188,13 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
             for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-            k_run<4, PREC>(acc, W, wsrc, voff, wo(j, w), j + 1 < NS ? wo(j + 1, w) : first, lds + H_BASE + g * kChunkU4 + s, 16);
+            k_run<4, PREC>(acc, W, wsrc, voff, wo(j, w), j + 1 < NS ? wo(j + 1, w) : first, lds + H_BASE + g * kChunkU4 + s, (PLAIN && j == 0) ? 2 : 16);
             // ---- mask with the saved activation of layer 6 - j, store the f32 copy, column sums
             const int layer = NS - 1 - j;                                // the layer whose saved output masks this stage's result (HEAD, j = 0: 7)
             const float* mask = a.acts + (int64_t)layer * a.n * 256;
             const unsigned* mbits = a.bits ? a.bits + (int64_t)layer * a.n * 8 + w : nullptr;
             float wa[16];
-            if (HEAD && j == 0) {
+            if (HEAD && !PLAIN && j == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float4 t = *reinterpret_cast<const float4*>(a.w_alpha + 32 * w + 4 * g + 8 * q);
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                 const int64_t row = base + 32 * mb + s;
                 const bool live = row < a.n;
                 const int64_t off = (live ? row : 0) * 256 + 32 * w + 4 * g;
-                if (HEAD && j == 0) {                                     // + d sigma x alpha_linear's row (models/vanilla.py:133)
+                if (HEAD && !PLAIN && j == 0) {                           // + d sigma x alpha_linear's row (models/vanilla.py:133)
                     const float ds = live ? a.d_raw[row * 4 + 3] : 0.f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mb][r] = fmaf(ds, wa[r], acc[mb][r]);
@@ -279,6 +285,19 @@ __global__ __launch_bounds__(256) void bwd_pack_kernel(nm::DevParams P, int kpe,
         const int slot = step / 128, nb = (step % 128) / 16;
         t = step % 16;
         if (slot == 0 && mode < 1) return;
+        if (slot == 0 && mode == 3) {                                   // plain head: stage 0 multiplies d_out [4] by output_linear.weight [4][256]: k-slot e < 4 of chunk 0 only
+            if (t >= 2) return;
+            const float* Wo = P.p[nm::P_OUT_W];
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (2 * t + (lane >> 5) == 0 && e < 4) ? Wo[e * 256 + 32 * nb + (lane & 31)] : 0.f;
+            uint4 hi, lo;
+            split8<false, false>(v, hi, lo);
+            uint4* dst = reinterpret_cast<uint4*>(img + (int64_t)step * nm::kStepBytes) + lane;
+            dst[0] = hi;
+            dst[64] = lo;
+            return;
+        }
         const int i = 8 - slot;                                         // layer; slot 0: feature_linear
         Wi = slot == 0 ? P.p[nm::P_FEAT_W] : P.p[nm::P_PTS_W + 2 * i];
         K = i == 5 ? kpe + 256 : 256; col = (i == 5 ? kpe : 0) + 32 * nb + (lane & 31);
@@ -318,8 +337,9 @@ int64_t mlp_bwd_image_bytes() { return kBwdImageBytes + kBwdPadBytes; }
 int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_top, const float* d_feat, const float* d_raw, const float* acts,
                    const unsigned* relu_bits, int64_t n, float* dz_out, float* colsum, float* gb, hipStream_t stream, const Bwd16* h) {
     const bool net = h && h->hvbits;                                   // the whole backward pass from d_raw
-    const bool head = d_feat != nullptr || net;
-    const int mode = net ? 2 : (head ? 1 : 0);
+    const bool plain = h && h->plain;
+    const bool head = d_feat != nullptr || net || plain;
+    const int mode = plain ? 3 : (net ? 2 : (head ? 1 : 0));
     hipLaunchKernelGGL(bwd_pack_kernel, dim3(((kBwdSlots * 8 * 16 + 8 * 8) * 64 + 255) / 256), dim3(256), 0, stream, P, kpe, h ? h->kdir : 0, mode, image);
     BwdArgs a;
     a.wpack = reinterpret_cast<const uint4*>(image);
@@ -339,7 +359,8 @@ int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_
     }
     const int grid = (int)(ntiles < cus ? ntiles : cus);
     const int ns = (head ? kBwdSlots : kBwdStages) + (net ? 1 : 0);     // rows of the bias-gradient block: the stages (+ feature_linear's)
-    if (net) hipLaunchKernelGGL(nerf_mlp_bwd_kernel<2>, dim3(grid), dim3(kThreads), 0, stream, a);
+    if (plain) hipLaunchKernelGGL(nerf_mlp_bwd_kernel<3>, dim3(grid), dim3(kThreads), 0, stream, a);
+    else if (net) hipLaunchKernelGGL(nerf_mlp_bwd_kernel<2>, dim3(grid), dim3(kThreads), 0, stream, a);
     else if (head) hipLaunchKernelGGL(nerf_mlp_bwd_kernel<1>, dim3(grid), dim3(kThreads), 0, stream, a);
     else hipLaunchKernelGGL(nerf_mlp_bwd_kernel<0>, dim3(grid), dim3(kThreads), 0, stream, a);
     hipLaunchKernelGGL(bwd_colsum_kernel, dim3(ns * 256 / 32), dim3(1024), 0, stream, colsum, ntiles, ns * 256, gb);

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void f16_pack_kernel(nm_mlp_desc d, DevParams 
     *hi = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
     hi[64] = make_uint4(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16), l[4] | ((unsigned)l[5] << 16), l[6] | ((unsigned)l[7] << 16));
 }
-__global__ __launch_bounds__(256) void f16_bias_kernel(DevParams P, const float* __restrict__ wscale, float* __restrict__ bias) {
+__global__ __launch_bounds__(256) void f16_bias_kernel(DevParams P, const float* __restrict__ wscale, float* __restrict__ bias, int plain_head = 0) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= kBiasFloats + kF16TabFloats) return;
     if (i >= kBiasFloats) {                                           // [2^-k (11)] [2^-(k + 5) (11)] [2 spare]
@@ -258,6 +258,7 @@ __global__ __launch_bounds__(256) void f16_bias_kernel(DevParams P, const float*
     const int r = i - stage_b_off(st);
     float v = 0.f;
     if (st <= 7) v = P.p[P_PTS_W + 2 * st + 1][r];
+    else if (plain_head) v = (st == 8 && r >= 256 && r < 260) ? P.p[P_OUT_B][r - 256] : 0.f;       // output_linear's four rows sit where the alpha block is
     else if (st == 8) v = r < 256 ? P.p[P_FEAT_B][r] : (r == 256 ? P.p[P_ALPHA_B][0] : 0.f);
     else if (st == 9) v = r < 128 ? P.p[P_VIEWS_B][r] : 0.f;
     else v = r < 3 ? P.p[P_RGB_B][r] : 0.f;
@@ -657,11 +658,11 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
 
 int nm_mlp_refresh_f16(nm_mlp_t m, const float* const* dev_params, nm_stream_t stream) {
     NM_REQUIRE(m && dev_params, "nm_mlp_refresh_f16: null pointer");
-    NM_REQUIRE(!m->desc.plain_head, "nm_mlp_refresh_f16: the plain-head net is not refreshed on the device");
     nm::DevParams P;
+    const int need = m->desc.plain_head ? 18 : 24;                        // the plain-head net: 16 trunk tensors + output_linear's weight [4][256] and bias [4]
     for (int i = 0; i < 24; ++i) {
-        NM_REQUIRE(dev_params[i], "nm_mlp_refresh_f16: dev_params[%d] is null", i);
-        P.p[i] = dev_params[i];
+        NM_REQUIRE(i >= need || dev_params[i], "nm_mlp_refresh_f16: dev_params[%d] is null", i);
+        P.p[i] = i < need ? dev_params[i] : nullptr;
     }
     if (!m->d_wscale16)
         if (int rc = nm::check_hip(hipMalloc(&m->d_wscale16, nm::kStages * sizeof(float)), "nm_mlp_refresh_f16: hipMalloc")) return rc;
@@ -670,7 +671,7 @@ int nm_mlp_refresh_f16(nm_mlp_t m, const float* const* dev_params, nm_stream_t s
     hipLaunchKernelGGL(nm::f16_stage_scale_kernel, dim3(nm::kStages), dim3(1024), 0, st, m->desc, P, m->d_wscale16);
     const int threads = (int)(nm::kWeightBytes / nm::kStepBytes) * 64;
     hipLaunchKernelGGL(nm::f16_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, m->desc, P, m->d_wscale16, m->d_image16);
-    hipLaunchKernelGGL(nm::f16_bias_kernel, dim3((nm::kBiasFloats + nm::kF16TabFloats + 255) / 256), dim3(256), 0, st, P, m->d_wscale16, bias);
+    hipLaunchKernelGGL(nm::f16_bias_kernel, dim3((nm::kBiasFloats + nm::kF16TabFloats + 255) / 256), dim3(256), 0, st, P, m->d_wscale16, bias, m->desc.plain_head);
     if (m->d_stream16t) {                                                  // the density-only stream follows the image
         const int n16 = nm::kSigmaSteps * (nm::kStepBytes / 16);
         hipLaunchKernelGGL(nm::sigma_stream_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4*>(m->d_image16), m->d_sigma_tab,
@@ -764,10 +765,11 @@ static int forward_save_impl(nm_mlp_t m, const float* pts, const float* dirs, in
                              void* save_h16, float* out, nm_stream_t stream, void* save_feat16 = nullptr, uint32_t* save_hvbits = nullptr,
                              void* save_x0h = nullptr, void* save_d0h = nullptr) {
     NM_REQUIRE(m, "nm_mlp_forward_save: null handle");
-    NM_REQUIRE(!m->desc.plain_head, "nm_mlp_forward_save: the plain-head net has no fused training forward");
     NM_REQUIRE(n >= 0, "nm_mlp_forward_save: negative n");
     if (n == 0) return NM_OK;
-    NM_REQUIRE(pts && dirs && (save_h || (save_h16 && save_feat16)) && save_hv && out, "nm_mlp_forward_save: null pointer");
+    const bool plain = m->desc.plain_head != 0;                           // output_linear straight off layer 7: the trunk's copies only, 16-bit form only
+    NM_REQUIRE(!plain || (save_h16 && !save_h && !save_feat16 && !save_hvbits && !save_d0h), "nm_mlp_forward_save: the plain-head net keeps save_h16 / save_bits / save_x0h only");
+    NM_REQUIRE(pts && (dirs || plain) && (plain || ((save_h || (save_h16 && save_feat16)) && save_hv)) && out, "nm_mlp_forward_save: null pointer");
     NM_REQUIRE(((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(save_h) | reinterpret_cast<uintptr_t>(save_hv) | reinterpret_cast<uintptr_t>(save_h16) |
                  reinterpret_cast<uintptr_t>(save_feat16)) & 15) == 0, "nm_mlp_forward_save: outputs must be 16-byte aligned");
     nm::MlpLaunch L;
@@ -778,11 +780,11 @@ static int forward_save_impl(nm_mlp_t m, const float* pts, const float* dirs, in
     L.petab = m->d_petab;
     L.pe_kind = m->desc.pe_kind; L.pos_nfreq = m->desc.pos_n_freqs; L.dir_nfreq = m->desc.dir_n_freqs;
     L.pos_octaves = m->pos_octaves; L.dir_octaves = m->dir_octaves;
-    L.plain_head = 0;
+    L.plain_head = plain ? 1 : 0;
     L.wstream8 = m->d_stream8;
     L.consts8 = m->d_consts8;
     L.save_h = save_h; L.save_hv = save_hv; L.save_bits = save_bits; L.save_h16 = save_h16; L.save_feat16 = save_feat16; L.save_hvbits = save_hvbits; L.save_x0h = save_x0h; L.save_d0h = save_d0h;
-    return nm::launch_mlp_mfma(L, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, NM_PREC_FP16X3, -2, 1.f, out, nullptr, nullptr,
+    return nm::launch_mlp_mfma(L, pts, dirs ? dirs : pts, nullptr, nullptr, nullptr, n, 1, 0, NM_PREC_FP16X3, -2, 1.f, out, nullptr, nullptr,
                                nm::as_stream(stream), 0, nullptr);
 }
 
@@ -793,7 +795,7 @@ int nm_mlp_forward_save_bits(nm_mlp_t m, const float* pts, const float* dirs, in
 
 int nm_mlp_forward_save16(nm_mlp_t m, const float* pts, const float* dirs, int64_t n, uint16_t* save_h16, float* save_feat, uint16_t* save_feat16,
                           float* save_hv, uint32_t* save_bits, uint32_t* save_hvbits, uint16_t* save_x0h, uint16_t* save_d0h, float* out, nm_stream_t stream) {
-    NM_REQUIRE(n == 0 || (save_h16 && save_bits && (save_feat || save_feat16)), "nm_mlp_forward_save16: null pointer");
+    NM_REQUIRE(n == 0 || (save_h16 && save_bits && (save_feat || save_feat16 || (m && m->desc.plain_head))), "nm_mlp_forward_save16: null pointer");
     NM_REQUIRE(((reinterpret_cast<uintptr_t>(save_x0h) | reinterpret_cast<uintptr_t>(save_d0h)) & 15) == 0, "nm_mlp_forward_save16: outputs must be 16-byte aligned");
     return forward_save_impl(m, pts, dirs, n, save_feat, save_hv, save_bits, save_h16, out, stream, save_feat16, save_hvbits, save_x0h, save_d0h);
 }
@@ -879,6 +881,34 @@ int nm_mlp_backward_net16(nm_mlp_t m, const float* const* dev_params, const floa
     h.dz32[5] = dz32_layer5; h.dz32[0] = dz32_layer0;
     h.hvbits = hv_bits; h.dhv16 = dhv16; h.dhv32 = dhv32; h.kdir = 3 + 6 * m->desc.dir_n_freqs;
     return nm::launch_mlp_bwd(P, 3 + 6 * m->desc.pos_n_freqs, m->d_bwd_image, nullptr, nullptr, d_raw, nullptr, relu_bits, n, nullptr, workspace, bias_grads,
+                              nm::as_stream(stream), &h);
+}
+
+int nm_mlp_backward_plain16(nm_mlp_t m, const float* const* dev_params, const float* d_out, const uint32_t* relu_bits, int64_t n, const float* amax,
+                            uint16_t* dz16, float* dz32_layer5, float* dz32_layer0, float* bias_grads, float* workspace, int64_t workspace_floats,
+                            nm_stream_t stream) {
+    NM_REQUIRE(m && dev_params, "nm_mlp_backward_plain16: null pointer");
+    NM_REQUIRE(n >= 0, "nm_mlp_backward_plain16: negative n");
+    if (n == 0) return NM_OK;
+    NM_REQUIRE(d_out && relu_bits && amax && dz16 && bias_grads && workspace, "nm_mlp_backward_plain16: null pointer");
+    NM_REQUIRE(m->desc.plain_head, "nm_mlp_backward_plain16: the net has the view-dependent head (nm_mlp_backward_net16)");
+    NM_REQUIRE(workspace_floats >= nm_mlp_backward_chain_workspace_floats(n), "nm_mlp_backward_plain16: workspace of %lld floats, %lld needed",
+               (long long)workspace_floats, (long long)nm_mlp_backward_chain_workspace_floats(n));
+    NM_REQUIRE(((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(dz16) | reinterpret_cast<uintptr_t>(dz32_layer5) | reinterpret_cast<uintptr_t>(dz32_layer0) |
+                 reinterpret_cast<uintptr_t>(workspace)) & 15) == 0, "nm_mlp_backward_plain16: buffers must be 16-byte aligned");
+    nm::DevParams P;
+    for (int i = 0; i < 24; ++i) {
+        NM_REQUIRE(i >= 18 || dev_params[i], "nm_mlp_backward_plain16: dev_params[%d] is null", i);
+        P.p[i] = i < 18 ? dev_params[i] : nullptr;
+    }
+    if (!m->d_bwd_image)
+        if (int rc = nm::check_hip(hipMalloc(&m->d_bwd_image, (size_t)nm::mlp_bwd_image_bytes()), "nm_mlp_backward_plain16: hipMalloc")) return rc;
+    nm::Bwd16 h;
+    h.dz16 = dz16; h.dfeat16 = nullptr; h.amax = amax;
+    for (int i = 0; i < 8; ++i) h.dz32[i] = nullptr;
+    h.dz32[5] = dz32_layer5; h.dz32[0] = dz32_layer0;
+    h.plain = 1;
+    return nm::launch_mlp_bwd(P, 3 + 6 * m->desc.pos_n_freqs, m->d_bwd_image, nullptr, nullptr, d_out, nullptr, relu_bits, n, nullptr, workspace, bias_grads,
                               nm::as_stream(stream), &h);
 }
 

@@ -66,6 +66,9 @@ struct Bwd16 {
     // hvbits != nullptr: the whole backward pass from d_raw (d_feat unused): the views layer's adjoint is formed in the kernel; dhv16 [n][128] fp16
     // (x scale, k-slot order), dhv32 (nullable) its float32 copy; the bias-gradient block gets a 9th row: feature_linear's; kdir = encoded view width
     const unsigned* hvbits = nullptr; void* dhv16 = nullptr; float* dhv32 = nullptr; int kdir = 0;
+    // plain: the plain-head net (output_linear [4][256] straight off layer 7, no views layer): d_raw = d_out [n][4], dZ_7 = (d_out W_out) * (H_7 > 0)
+    // is the first stage; 8 stages, bias_grads [8][256] = layers 7 .. 0
+    int plain = 0;
 };
 int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_top, const float* d_feat, const float* d_raw, const float* acts,
                    const unsigned* relu_bits, int64_t n, float* dz_out, float* colsum, float* gb, hipStream_t stream, const Bwd16* h = nullptr);

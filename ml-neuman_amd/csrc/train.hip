@@ -672,6 +672,60 @@ __global__ __launch_bounds__(256) void wgrad_heads16_kernel(const float* __restr
     }
 }
 
+// ... and of the plain-head net (output_linear [4][256] straight off layer 7): out[k][f] = sum_n d_out[n][k] H7[n][f], the column sums of d_out, max |d_out|
+constexpr int kOutOut = 4 * 256 + 4;
+__global__ __launch_bounds__(256) void wgrad_out16_kernel(const float* __restrict__ d_out, const uint4* __restrict__ h16, int64_t n, float* __restrict__ partial,
+                                                          unsigned* __restrict__ amax) {
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const int64_t r0 = (int64_t)blockIdx.x * kHeadRows, r1 = r0 + kHeadRows < n ? r0 + kHeadRows : n;
+    float aa[4][8], ab[4] = {0.f, 0.f, 0.f, 0.f}, m = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) aa[k][e] = 0.f;
+    for (int64_t row = r0 + r; row < r1; row += 8) {
+        const float4 dr = *reinterpret_cast<const float4*>(d_out + row * 4);
+        const uint4 h = h16[row * 32 + c];
+        const unsigned hw[4] = {h.x, h.y, h.z, h.w};
+        const float d4[4] = {dr.x, dr.y, dr.z, dr.w};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float lo = (float)__builtin_bit_cast(_Float16, (unsigned short)(hw[p] & 0xffffu)), hi = (float)__builtin_bit_cast(_Float16, (unsigned short)(hw[p] >> 16));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                aa[k][2 * p] = fmaf(d4[k], lo, aa[k][2 * p]);
+                aa[k][2 * p + 1] = fmaf(d4[k], hi, aa[k][2 * p + 1]);
+            }
+        }
+        ab[0] += dr.x; ab[1] += dr.y; ab[2] += dr.z; ab[3] += dr.w;
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(dr.x), fabsf(dr.y)), fmaxf(fabsf(dr.z), fabsf(dr.w))));
+    }
+    __shared__ float sh[8][kOutOut];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sh[r][256 * k + 8 * c + e] = aa[k][e];
+    if (c == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sh[r][1024 + j] = ab[j];
+    }
+    __syncthreads();
+    float* P = partial + (int64_t)blockIdx.x * kOutOut;
+    for (int i = threadIdx.x; i < kOutOut; i += 256) {
+        float s = sh[0][i];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) s += sh[q][i];
+        if (i < 1024) {
+            const int p = i & 255, cc = p >> 3, e = p & 7;
+            P[(i & ~255) + 32 * (cc >> 2) + 8 * (2 * ((cc >> 1) & 1) + (e >> 2)) + 4 * (cc & 1) + (e & 3)] = s * (1.f / kNmAct16Scale);
+        } else P[i] = s;
+    }
+    if (amax) {
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));
+    }
+}
+
 // largest magnitude of x[0 .. count): *out = max(*out, ...) (bit pattern of a non-negative float: unsigned order = float order)
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int64_t count, unsigned* __restrict__ out) {
     float m = 0.f;
@@ -1129,6 +1183,20 @@ int nm_wgrad_heads16(const float* d_raw, const uint16_t* h16_7, const float* hv,
                        reinterpret_cast<unsigned*>(amax));
     if (int rc = nm::check_launch("wgrad_heads16_kernel")) return rc;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((kHeadOut + 255) / 256), dim3(256), 0, st, workspace, bands, 1, kHeadOut, out644, kHeadOut, 0);
+    return nm::check_launch("splitk_reduce_kernel");
+}
+
+int64_t nm_wgrad_out16_workspace_floats(int64_t n) { return ((n + kHeadRows - 1) / kHeadRows) * kOutOut; }
+int nm_wgrad_out16(const float* d_out, const uint16_t* h16_7, int64_t n, float* out1028, float* amax, float* workspace, int64_t workspace_floats,
+                   nm_stream_t stream) {
+    NM_REQUIRE(n >= 1 && d_out && h16_7 && out1028 && workspace, "nm_wgrad_out16: bad arguments");
+    NM_REQUIRE((((uintptr_t)d_out | (uintptr_t)h16_7) & 15) == 0, "nm_wgrad_out16: inputs must be 16-byte aligned");
+    const int bands = (int)((n + kHeadRows - 1) / kHeadRows);
+    NM_REQUIRE(workspace_floats >= (int64_t)bands * kOutOut, "nm_wgrad_out16: needs %lld floats of workspace", (long long)bands * kOutOut);
+    hipStream_t st = nm::as_stream(stream);
+    hipLaunchKernelGGL(wgrad_out16_kernel, dim3(bands), dim3(256), 0, st, d_out, reinterpret_cast<const uint4*>(h16_7), n, workspace, reinterpret_cast<unsigned*>(amax));
+    if (int rc = nm::check_launch("wgrad_out16_kernel")) return rc;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((kOutOut + 255) / 256), dim3(256), 0, st, workspace, bands, 1, kOutOut, out1028, kOutOut, 0);
     return nm::check_launch("splitk_reduce_kernel");
 }
 

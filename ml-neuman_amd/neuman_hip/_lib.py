@@ -59,6 +59,7 @@ SIGNATURES = {
     "nm_mlp_backward_chain": (i32, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p, i64, c_f32p, c_f32p, c_f32p, i64, c_stream]),
     "nm_mlp_forward_save16": (i32, [ctypes.c_void_p, c_f32p, c_f32p, i64, ctypes.c_void_p, c_f32p, ctypes.c_void_p, c_f32p, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_stream]),
+    "nm_mlp_backward_plain16": (i32, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, ctypes.c_void_p, i64, c_f32p, ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, i64, c_stream]),
     "nm_mlp_backward_net16": (i32, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, ctypes.c_void_p, ctypes.c_void_p, i64, c_f32p, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, c_stream]),
     "nm_mlp_backward_chain16": (i32, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_void_p, i64, c_f32p, ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p,
@@ -103,6 +104,8 @@ SIGNATURES = {
                          c_f32p, c_f32p, i64, c_stream]),
     "nm_wgrad_heads16_workspace_floats": (i64, [i64]),
     "nm_wgrad_heads16": (i32, [c_f32p, ctypes.c_void_p, c_f32p, i64, c_f32p, c_f32p, c_f32p, i64, c_stream]),
+    "nm_wgrad_out16_workspace_floats": (i64, [i64]),
+    "nm_wgrad_out16": (i32, [c_f32p, ctypes.c_void_p, i64, c_f32p, c_f32p, c_f32p, i64, c_stream]),
     "nm_wgrad_alpha16_workspace_floats": (i64, [i64]),
     "nm_wgrad_alpha16": (i32, [c_f32p, ctypes.c_void_p, i64, c_f32p, c_f32p, i64, c_stream]),
     "nm_colsum_workspace_floats": (i64, [i64, i32]),

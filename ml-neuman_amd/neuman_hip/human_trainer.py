@@ -91,7 +91,7 @@ class HumanNeRFLoss:
         cur_time = torch.ones_like(human_pts[..., 0:1]) * float(batch['cur_view_f'])
         nets = list(self.net.offset_nets)
         offset_net = nets[int(self.replay['offset_net'])] if self.replay else self.rng.choice(nets)
-        offset = offset_net(torch.cat([human_pts, cur_time], dim=-1))
+        offset = offset_net(torch.cat([human_pts, cur_time], dim=-1), const_time=float(batch['cur_view_f']))
         mesh, raw_Ts = self.net.vertex_forward(int(batch['cap_id']))                      # autograd: pose / shape / alignment refinement
         flat = human_pts.reshape(-1, 3)
         # :262-266: T_interp_inv [p; 1] with T_interp the barycentric blend of the closest triangle's vertex transforms -- one fused

@@ -411,6 +411,81 @@ class _MLP(torch.autograd.Function):
         return (None, d_pts, d_dirs) + tuple(grads)
 
 
+def _products16(n4, amax, grow, p_cols, q_cols, items):
+    """nm_wgrad16 over `items` = (dZ16 rows [n4, p_cols], activation16 rows [n4, q_cols or 64], gradient tensor, column offset into it)"""
+    lib = _lib.lib()
+    k = len(items)
+    P = (ctypes.c_void_p * k)(*[a.data_ptr() for a, _, _, _ in items])
+    Q = (ctypes.c_void_p * k)(*[b.data_ptr() for _, b, _, _ in items])
+    C = (ctypes.c_void_p * k)(*[c.data_ptr() + 4 * off for _, _, c, off in items])
+    L = (ctypes.c_int * k)(*[c.shape[1] for _, _, c, _ in items])
+    w_ = grow(lib.nm_wgrad16_workspace_floats(k, n4, p_cols, q_cols))
+    _lib.check(lib.nm_wgrad16(k, p_cols, q_cols, P, Q, C, L, n4, _lib.dev_ptr(amax), _lib.dev_ptr(w_), w_.numel(), _lib.stream_ptr()), "nm_wgrad16")
+
+
+class _MLPPlain16(torch.autograd.Function):
+    """A plain-head net with a 3-D position encoding -- the 8 x 256 trunk and output_linear [4][256] -- on the fused 16-bit training kernels, its 18
+    parameter tensors GIVEN (they need not be anybody's nn.Parameters: the offset net's folded weights are functions of its parameters that autograd
+    differentiates on its own, offset_forward_train).  `joiner` supplies the encoding's description and the kernel handle.  pts [n, 3] -> [n, 4]."""
+
+    @staticmethod
+    def forward(ctx, joiner, pts, *params):
+        lib = _lib.lib()
+        dev, n = pts.device, pts.shape[0]
+        p4 = _pad4(pts)
+        n4 = p4.shape[0]
+        plist = [p.detach().to(torch.float32).contiguous() for p in params]
+        ptrs = (ctypes.c_void_p * 24)(*([p.data_ptr() for p in plist] + [None] * 6))
+        handle = joiner.train_handle()
+        _lib.check(lib.nm_mlp_refresh_f16(handle, ptrs, _lib.stream_ptr()), "nm_mlp_refresh_f16")
+        h16 = torch.empty((8, n4, 256), device=dev, dtype=torch.float16)
+        bits = torch.empty((8, n4, 8), device=dev, dtype=torch.int32)
+        x0h = torch.empty((n4, 64), device=dev, dtype=torch.float16)
+        raw = torch.empty((n4, 4), device=dev, dtype=torch.float32)
+        _lib.check(lib.nm_mlp_forward_save16(handle, _lib.dev_ptr(p4), None, n4, ctypes.c_void_p(h16.data_ptr()), None, None, None, ctypes.c_void_p(bits.data_ptr()), None,
+                                             ctypes.c_void_p(x0h.data_ptr()), None, _lib.dev_ptr(raw), _lib.stream_ptr()), "nm_mlp_forward_save16 (plain head)")
+        ctx.joiner, ctx.plist, ctx.h16, ctx.bits, ctx.x0h, ctx.n, ctx.n4 = joiner, plist, h16, bits, x0h, n, n4
+        ctx.n_pos = joiner.pos_pe.out_dim
+        return raw[:n]
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        lib = _lib.lib()
+        if ctx.needs_input_grad[1]:
+            raise _lib.NeumanHipError("the fused plain-head path gives no gradient to its input points (the offset net's are not differentiated)")
+        h16, n, n4, n_pos, plist = ctx.h16, ctx.n, ctx.n4, ctx.n_pos, ctx.plist
+        dev = g_raw.device
+        d_out = torch.zeros((n4, 4), device=dev, dtype=torch.float32)
+        d_out[:n] = g_raw
+        ws = [torch.empty(4, device=dev, dtype=torch.float32)]
+
+        def grow(need):
+            if need > ws[0].numel():
+                ws[0] = torch.empty(int(need), device=dev, dtype=torch.float32)
+            return ws[0]
+        amax = torch.zeros(1, device=dev, dtype=torch.float32)
+        head = torch.empty(1028, device=dev, dtype=torch.float32)           # output_linear's [4][256] and its four bias sums
+        w = grow(lib.nm_wgrad_out16_workspace_floats(n4))
+        _lib.check(lib.nm_wgrad_out16(_lib.dev_ptr(d_out), ctypes.c_void_p(h16[7].data_ptr()), n4, _lib.dev_ptr(head), _lib.dev_ptr(amax), _lib.dev_ptr(w), w.numel(),
+                                      _lib.stream_ptr()), "nm_wgrad_out16")
+        dz16 = torch.empty((8, n4, 256), device=dev, dtype=torch.float16)
+        gbs = torch.empty((8, 256), device=dev, dtype=torch.float32)
+        w = grow(lib.nm_mlp_backward_chain_workspace_floats(n4))
+        ptrs = (ctypes.c_void_p * 24)(*([p.data_ptr() for p in plist] + [None] * 6))
+        _lib.check(lib.nm_mlp_backward_plain16(ctx.joiner.train_handle(), ptrs, _lib.dev_ptr(d_out), ctypes.c_void_p(ctx.bits.data_ptr()), n4, _lib.dev_ptr(amax),
+                                               ctypes.c_void_p(dz16.data_ptr()), None, None, _lib.dev_ptr(gbs), _lib.dev_ptr(w), w.numel(), _lib.stream_ptr()),
+                   "nm_mlp_backward_plain16")
+        skip = [i > 0 and plist[2 * i].shape[1] == 256 + n_pos for i in range(8)]
+        gw = [torch.empty((256, (n_pos if i == 0 else 256) + (n_pos if skip[i] else 0)), device=dev, dtype=torch.float32) for i in range(8)]
+        _products16(n4, amax, grow, 256, 256, [(dz16[7 - i], h16[i - 1], gw[i], n_pos if skip[i] else 0) for i in range(7, 0, -1)])
+        _products16(n4, amax, grow, 256, n_pos, [(dz16[7 - i], ctx.x0h, gw[i], 0) for i in range(8) if i == 0 or skip[i]])
+        grads = []
+        for i in range(8):
+            grads += [gw[i], gbs[7 - i]]
+        grads += [head[:1024].view(4, 256), head[1024:1028]]
+        return (None, None) + tuple(grads)
+
+
 def _backward16(ctx, d_raw, want_in):
     """The backward pass of a step whose forward kept fp16 copies (STORE16): ONE kernel for the whole backward-data pass from d_raw
     (nm_mlp_backward_net16: the views layer's adjoint, feature_linear's, the eight trunk layers'; dZ of every layer, d_feat and d_hv out as fp16),
@@ -457,14 +532,8 @@ def _backward16(ctx, d_raw, want_in):
     views_w = torch.empty((half, width + n_dir), device=dev, dtype=torch.float32)
     views_x = torch.empty((half, 64), device=dev, dtype=torch.float32)      # [:, :n_dir] the encoded-direction columns, [:, 63] the bias gradient
 
-    def products(p_cols, q_cols, items):                                   # items: (dZ16 rows, activation16 rows, gradient, column offset)
-        k = len(items)
-        P = (ctypes.c_void_p * k)(*[a.data_ptr() for a, _, _, _ in items])
-        Q = (ctypes.c_void_p * k)(*[b.data_ptr() for _, b, _, _ in items])
-        C = (ctypes.c_void_p * k)(*[c.data_ptr() + 4 * off for _, _, c, off in items])
-        L = (ctypes.c_int * k)(*[c.shape[1] for _, _, c, _ in items])
-        w_ = grow(lib.nm_wgrad16_workspace_floats(k, n4, p_cols, q_cols))
-        _lib.check(lib.nm_wgrad16(k, p_cols, q_cols, P, Q, C, L, n4, _lib.dev_ptr(amax), _lib.dev_ptr(w_), w_.numel(), _lib.stream_ptr()), "nm_wgrad16")
+    def products(p_cols, q_cols, items):
+        _products16(n4, amax, grow, p_cols, q_cols, items)
     products(width, width, [(dfeat16, h16[7], feature_w, 0)] + [(dz16[7 - i], h16[i - 1], gw[i], n_pos if pk.skip[i] else 0) for i in range(7, 0, -1)])
     products(width, n_pos, [(dz16[7 - i], x0h, gw[i], 0) for i in range(8) if i == 0 or pk.skip[i]])
     products(half, width, [(dhv16, feat16, views_w, 0)])
@@ -499,11 +568,56 @@ def train_params(nerf):
     return out
 
 
-def offset_forward_train(net, x):
-    """OffsetNet.forward (vanilla.py:169-178) with autograd: x [..., 4] (point + time) -> offset [..., 3], before the scale"""
+def _offset_fused_ok(net, x, n):
+    nerf, pe = net.nerf, net.pos_pe
+    return (STORE16 and FUSED_FORWARD and FUSED_BACKWARD and GEMM_PRECISION == 'mixed16' and n >= STORE16_MIN_ROWS and not x.requires_grad and x.is_cuda
+            and pe.mapping == 'posenc' and pe.input_dims == 4 and nerf.depth == 8 and nerf.width == 256 and list(nerf.skips) == [4] and not nerf.use_viewdirs
+            and nerf.output_linear.out_features <= 4 and 3 + 6 * pe.N_freqs <= 64)
+
+
+def _offset_fused(net, pts, t):
+    """OffsetNet's network at ONE time t on the fused kernels.  The time coordinate of every sample of a batch is the same number
+    (trainers/human_nerf_trainer.py:258-261: `ones * cur_view_f`), so the 21 encoded-time inputs of layer 0 and of the skip layer add a constant vector
+    W[:, time columns] . pe(t) to those layers' pre-activations: with it folded into the bias the net is a plain-head net over the 63-wide 3-D
+    encoding.  The folded tensors are built with differentiable torch operations from the real parameters, so autograd carries the fused kernels'
+    gradients back to them (the time columns get bias gradient x pe(t), as they must)."""
+    from . import vanilla
+    nerf, pe = net.nerf, net.pos_pe
+    dev = pts.device
+    cache = net.__dict__.setdefault('_fused_cache', {})
+    if cache.get('dev') != dev:
+        sp, tc = vanilla.time_columns(pe)
+        pe3 = vanilla.Embedder(3, pe.max_freq, pe.N_freqs, pe.log_sampling, pe.include_input, min_freq=pe.min_freq, mapping='posenc')
+        dpe = vanilla.Embedder(3, 3, 4)
+        body = vanilla.NeRF(depth=nerf.depth, width=nerf.width, input_ch=pe3.out_dim, input_ch_views=dpe.out_dim, output_ch=4, skips=list(nerf.skips), use_viewdirs=False)
+        cache.update(dev=dev, sp=torch.as_tensor(sp, device=dev), tc=torch.as_tensor(tc, device=dev), joiner=vanilla.Joiner(pe3, dpe, body).to(dev))
+    sp, tc = cache['sp'], cache['tc']
+    pt = torch.as_tensor(vanilla.time_encoding(pe, t), dtype=torch.float32, device=dev)
+    params = []
+    for i, lin in enumerate(nerf.pts_linears):
+        W, b = lin.weight, lin.bias
+        if i == 0 or (i - 1) in nerf.skips:
+            Wf = W[:, sp] if i == 0 else torch.cat([W[:, sp], W[:, pe.out_dim:]], 1)
+            params += [Wf, b + (W[:, tc] * pt[None, :]).sum(1)]
+        else:
+            params += [W, b]
+    Wo, bo = nerf.output_linear.weight, nerf.output_linear.bias
+    k = Wo.shape[0]
+    if k < 4:                                                           # the kernels' head has four rows (r, g, b, sigma): the offset's three + a zero one
+        Wo = torch.cat([Wo, torch.zeros((4 - k, Wo.shape[1]), device=dev, dtype=Wo.dtype)], 0)
+        bo = torch.cat([bo, torch.zeros(4 - k, device=dev, dtype=bo.dtype)], 0)
+    params += [Wo, bo]
+    return _MLPPlain16.apply(cache['joiner'], pts, *params)[:, :k]
+
+
+def offset_forward_train(net, x, const_time=None):
+    """OffsetNet.forward (vanilla.py:169-178) with autograd: x [..., 4] (point + time) -> offset [..., 3], before the scale.  const_time: the caller's
+    promise that x[..., 3] is this one number for every row (the human trainer's batches are one frame): large batches then run on the fused kernels."""
     _lib.require_gpu()
     shp = x.shape[:-1]
     xf = x.reshape(-1, x.shape[-1]).to(torch.float32).contiguous()
+    if const_time is not None and _offset_fused_ok(net, xf, xf.shape[0]):
+        return _offset_fused(net, xf[:, :3].contiguous(), float(const_time)).reshape(*shp, -1)
     return _MLP.apply(net, xf, None, *train_params(net.nerf)).reshape(*shp, -1)
 
 

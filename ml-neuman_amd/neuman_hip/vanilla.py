@@ -342,10 +342,12 @@ class OffsetNet(nn.Module):
         super().__init__()
         self.pos_pe, self.nerf = pos_pe, nerf
 
-    def forward(self, input_pts, cur_iter=None):
+    def forward(self, input_pts, cur_iter=None, const_time=None):
+        """const_time (an extension): the caller's promise that input_pts[..., 3] is this one number on every row -- the human trainer's
+        batches are one frame (human_nerf_trainer.py:258-261) -- which lets a large batch run on the fused training kernels"""
         assert cur_iter is None                                      # as the reference's posenc Embedder (vanilla.py:91)
         from . import train
-        out = train.offset_forward_train(self, input_pts)
+        out = train.offset_forward_train(self, input_pts, const_time=const_time)
         if self.nerf.scale_type == 'no':                             # vanilla.py:146-152
             return out
         if self.nerf.scale_type == 'linear':

@@ -406,3 +406,39 @@ def test_store16_training_step_matches_reference(G, monkeypatch):
         print(f"[train16] {tag}/{name}: parameter gradients vs the reference's autograd, worst tensor: float32 storage {e32[w32]:.2e} ({w32}), fp16 storage {e16[w16]:.2e} ({w16}); "
               f"largest increase on any tensor {added:.2e}")
         assert e32[w32] < 1e-4 and e16[w16] < GATE16, (name, e32[w32], e16[w16], added)
+
+
+def test_offset_net_on_the_fused_kernels(G, monkeypatch):
+    """OffsetNet (models/vanilla.py:169-205: 4-D space-time encoding, 8 x 256 trunk, 3 outputs) on a batch whose time coordinate is one number
+    (human_nerf_trainer.py:258-261): the time folded into two bias vectors, the net as a plain-head 3-D-encoding net on nm_mlp_forward_save16 /
+    nm_mlp_backward_plain16 / nm_wgrad16 -- against the per-layer GEMM chain on the 4-D points themselves: output and every parameter's gradient
+    (the time columns of layer 0 and of the skip layer included)."""
+    from neuman_hip import vanilla
+    monkeypatch.setattr(G.train, "GEMM_PRECISION", "mixed16")
+    monkeypatch.setattr(G.train, "STORE16_MIN_ROWS", 32768)
+    torch.manual_seed(21)
+    net = vanilla.build_offset_net(G.syn.default_opt(offset_scale=0.7, offset_scale_type='linear')).cuda().train()
+    n, t = 40000, 0.35
+    g = torch.Generator(device='cuda').manual_seed(7)
+    x = torch.cat([torch.rand((n, 3), device='cuda', generator=g) * 2 - 1, torch.full((n, 1), t, device='cuda')], 1)
+    tgt = torch.randn((n, 3), device='cuda', generator=g)
+    res = {}
+    for fused in (True, False):
+        for p in net.parameters():
+            p.grad = None
+        out = net(x, const_time=t if fused else None)
+        assert out.shape == (n, 3)
+        ((out - tgt) ** 2).mean().backward()
+        res[fused] = (out.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()})
+    node_ok = G.train._offset_fused_ok(net, x, n)
+    assert node_ok
+    eo = float((res[True][0] - res[False][0]).abs().max() / res[False][0].abs().max())
+    worst, wname = 0.0, None
+    for k in res[True][1]:
+        a, b = res[True][1][k], res[False][1][k]
+        assert torch.isfinite(a).all(), k
+        e = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+        if e > worst:
+            worst, wname = e, k
+    print(f"[train16] offset net, {n} points at time {t}: fused kernels vs the GEMM chain: output {eo:.2e} of its largest value, worst parameter gradient {worst:.2e} ({wname})")
+    assert eo < 2e-5 and worst < 1e-4, (eo, worst, wname)
