@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 5, GPU call 3: full GPU suite + training benches + profiles
+# round 5, GPU call 4: full GPU suite + training benches + profiles
 set -u
 cd "$(dirname "$0")/.."
-OUT=gpurun_out/r05_run3
+OUT=gpurun_out/r05_run4
 mkdir -p $OUT
 export TMPDIR=/tmp
 R=$(pwd)
