@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void bwd_pack_kernel(nm::DevParams P, int kpe,
     const float* Wi;
     int K, col, t;
     if (step >= kBwdSlots * 8 * 16) {                                   // the views-back stage (mode 2): W_views [128][256 + kdir], its feature columns
-        if (mode < 2) return;
+        if (mode != 2) return;
         const int v = step - kBwdSlots * 8 * 16;
         t = v % 8;
         Wi = P.p[nm::P_VIEWS_W]; K = 256 + kdir; col = 32 * (v / 8) + (lane & 31);
