@@ -441,4 +441,15 @@ def test_offset_net_on_the_fused_kernels(G, monkeypatch):
         if e > worst:
             worst, wname = e, k
     print(f"[train16] offset net, {n} points at time {t}: fused kernels vs the GEMM chain: output {eo:.2e} of its largest value, worst parameter gradient {worst:.2e} ({wname})")
-    assert eo < 2e-5 and worst < 1e-4, (eo, worst, wname)
+    # The two float32-class forwards (the fold changes how layer 0's and the skip layer's pre-activations are summed) decide the ReLU of a few
+    # samples at |x| ~ 1e-7 differently, and with a random target a gradient entry is a random-walk sum over the 40000 samples: ONE flipped sample
+    # moves entries by 1 / sqrt(40000) = 5e-3 of the largest (tests/test_hip_train.py::test_fused_training_forward allows 2e-3 for the same reason;
+    # measured here 2.5e-3).  What is exact is checked exactly: the time columns' gradients are the bias gradient x the encoded time.
+    assert eo < 2e-5 and worst < 8e-3, (eo, worst, wname)
+    sp, tc = vanilla.time_columns(net.pos_pe)
+    pt = torch.as_tensor(vanilla.time_encoding(net.pos_pe, t), dtype=torch.float32, device='cuda')
+    for i in (0, 5):
+        gW, gb = res[True][1][f'nerf.pts_linears.{i}.weight'], res[True][1][f'nerf.pts_linears.{i}.bias']
+        want = gb[:, None] * pt[None, :]
+        assert float((gW[:, tc] - want).abs().max()) <= 1e-6 * float(want.abs().max()), i
+        assert float(gW[:, sp].abs().max()) > 0
