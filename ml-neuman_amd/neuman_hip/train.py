@@ -177,6 +177,8 @@ def _encode_backward(emb, x, g):
 
 def _pad4(x):
     n = x.shape[0]
+    if n % 4 == 0 and x.dtype == torch.float32 and x.is_contiguous():
+        return x.detach()                                                  # (the trainers' batches: nothing to pad, no fill + copy)
     out = torch.zeros(((n + 3) // 4 * 4, x.shape[1]), device=x.device, dtype=torch.float32)
     out[:n] = x
     return out
@@ -287,8 +289,11 @@ class _MLP(torch.autograd.Function):
             if now != ctx.versions:
                 raise _lib.NeumanHipError("a parameter of the net was modified in place between the forward and the backward pass of a training step "
                                           "(the fused backward reads the live weights): run backward before optimizer.step() / weight edits")
-        d_raw = torch.zeros((n4, 4), device=dev, dtype=torch.float32)
-        d_raw[:n, :g_raw.shape[1]] = g_raw
+        if n == n4 and g_raw.shape[1] == 4 and g_raw.dtype == torch.float32 and g_raw.is_contiguous() and (g_raw.data_ptr() & 15) == 0:
+            d_raw = g_raw
+        else:
+            d_raw = torch.zeros((n4, 4), device=dev, dtype=torch.float32)
+            d_raw[:n, :g_raw.shape[1]] = g_raw
         if getattr(ctx, 'h16', None) is not None:
             return _backward16(ctx, d_raw, want_in)
         ws = [torch.empty(4, device=dev, dtype=torch.float32)]
@@ -455,8 +460,11 @@ class _MLPPlain16(torch.autograd.Function):
             raise _lib.NeumanHipError("the fused plain-head path gives no gradient to its input points (the offset net's are not differentiated)")
         h16, n, n4, n_pos, plist = ctx.h16, ctx.n, ctx.n4, ctx.n_pos, ctx.plist
         dev = g_raw.device
-        d_out = torch.zeros((n4, 4), device=dev, dtype=torch.float32)
-        d_out[:n] = g_raw
+        if n == n4 and g_raw.dtype == torch.float32 and g_raw.is_contiguous() and (g_raw.data_ptr() & 15) == 0:
+            d_out = g_raw
+        else:
+            d_out = torch.zeros((n4, 4), device=dev, dtype=torch.float32)
+            d_out[:n] = g_raw
         ws = [torch.empty(4, device=dev, dtype=torch.float32)]
 
         def grow(need):
