@@ -261,10 +261,6 @@ int nm_transmittance_chunk(const float* raw, const float* z_vals, const float* r
  * successor in the merged order, and the transmittance the early-termination cut is decided on is the merged list's. */
 int nm_transmittance_chunk_dz(const float* raw, const float* dz, const float* rays_d, const int32_t* ray_idx, const int32_t* n_rays_dev,
                               int64_t n_rays, int s0, int S, int S_total, float* T, nm_stream_t stream);
-/* Debug: the 4-wave / two-sub-tile NM_PREC_I8X3 kernel (csrc/mlp_i8t.hip) on n points, plus the activation state of its FIRST tile after
- * `stage` (0..9): state [256 lanes][130] = the two sub-tiles' resident input fragments of the next stage (128 dwords) and their row scales.
- * What the generated instruction stream is checked against stage by stage (tests/test_hip_i8_as.py). */
-int nm_mlp_forward_i8t_debug(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int stage, uint32_t* state, float* out, nm_stream_t stream);
 /* Debug: the density-only NM_PREC_FP16X3 activation-stationary kernel (csrc/mlp_f16t.hip) on n points (out [n,4] = (0, 0, 0, sigma)), plus the
  * activations of its first tile after `stage` (0..7): state [128 samples][256] float32 in natural feature order (hi + lo parts, unscaled). */
 int nm_mlp_sigma_f16t_debug(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int stage, float* state, float* out, nm_stream_t stream);

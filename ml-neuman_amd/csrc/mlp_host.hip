@@ -396,28 +396,6 @@ static void pack_stream8s(const uint8_t* img8, uint8_t* out) {
     if (dst - out != kWeightBytes8) abort();
 }
 
-// the 4-wave / two-sub-tile kernel's stream (mlp_i8t.hip): pack_stream8s with stage 9 cut like stage 5 -- its four i8 blocks first, then ONE
-// ring block holding the two direction-encoding steps of each of its four output blocks -- so that no ring block exceeds 8 steps (16 KB)
-static void pack_stream8t(const uint8_t* img8, uint8_t* out) {
-    memset(out, 0, (size_t)(kWeightBytes8 + kWeightPadBytes));
-    uint8_t* dst = out;
-    auto put = [&](int st, int nb, int t0, int n) {
-        for (int t = 0; t < n; ++t, dst += kStepBytes) memcpy(dst, img8 + frag_off8(st, nb, t0 + t), (size_t)kStepBytes);
-    };
-    for (int nb = 0; nb < 8; ++nb) put(0, nb, 0, 4);
-    for (int st = 1; st <= 7; ++st) {
-        for (int nb = 0; nb < 8; ++nb) put(st, nb, 0, 8);
-        if (st == 5)
-            for (int nb = 0; nb < 8; ++nb) put(5, nb, 8, 4);
-    }
-    put(8, 8, 0, 8);
-    for (int nb = 0; nb < 8; ++nb) put(8, nb, 0, 8);
-    for (int nb = 0; nb < 4; ++nb) put(9, nb, 0, 8);
-    for (int nb = 0; nb < 4; ++nb) put(9, nb, 8, 2);
-    put(10, 0, 0, 4);
-    if (dst - out != kWeightBytes8) abort();
-}
-
 // ---- the density-only fp16x3 activation-stationary kernel's stream (mlp_f16t.hip): the k-steps of stages 0..7 and of the alpha block of the
 // fp16 image (frag_off) in the order the kernel consumes them -- output blocks in PAIRS (two accumulator chains), a ring unit = 8 steps of
 // block b followed by the same 8 steps of block b + 1 (stage 0: its 4 steps; stage 5: its 4 encoding steps first, as a unit of their own).
@@ -485,7 +463,6 @@ struct nm_mlp_s {
     float* d_consts8;      // NM_PREC_I8X3: units | biases | kappa (the tail of the nm_mlp_pack_i8 image)
     uint8_t* d_stream8;    // NM_PREC_I8X3: the image's fragments as per-wave streams (nerf_mlp_i8w_kernel)
     uint8_t* d_image8;     // NM_PREC_I8X3: the workgroup stream of nerf_mlp_i8s_kernel (pack_stream8s), fragments + prefetch pad
-    uint8_t* d_image8t;    // NM_PREC_I8X3: the workgroup stream of nerf_mlp_i8t_kernel (pack_stream8t)
     uint8_t* d_stream16t;  // NM_PREC_FP16X3, density only: the stream of nerf_sigma_f16t_kernel (sigma_stream_kernel over d_image16)
     int* d_sigma_tab;      //   its piece table
     uint8_t* d_bwd_image;  // the transposed hidden weights of the backward-data chain (mlp_bwd.hip), repacked from live parameters per call
@@ -572,12 +549,10 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     std::vector<uint8_t> img8((size_t)nm::image8_bytes());
     std::vector<uint8_t> str8((size_t)nm::kWeightBytes8w);
     std::vector<uint8_t> str8s((size_t)(nm::kWeightBytes8 + nm::kWeightPadBytes));
-    std::vector<uint8_t> str8t((size_t)(nm::kWeightBytes8 + nm::kWeightPadBytes));
     if (!plain) {                                               // (no i8x3 form of the plain-head net: those buffers stay zero)
         nm::pack_image8(desc, host_params, img8.data());
         nm::pack_stream8(img8.data(), str8.data());
         nm::pack_stream8s(img8.data(), str8s.data());
-        nm::pack_stream8t(img8.data(), str8t.data());
     }
 
     // reference-layout image for the exact-f32 kernel
@@ -618,7 +593,7 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     m->pos_octaves = octaves(tab, desc->pos_n_freqs);
     m->dir_octaves = octaves(tab + 96, desc->dir_n_freqs);
 
-    m->d_image = nullptr; m->d_image16 = nullptr; m->d_consts8 = nullptr; m->d_stream8 = nullptr; m->d_image8 = nullptr; m->d_image8t = nullptr; m->d_stream16t = nullptr; m->d_sigma_tab = nullptr; m->d_bwd_image = nullptr; m->d_petab = nullptr; m->d_ref = nullptr; m->d_wscale16 = nullptr;
+    m->d_image = nullptr; m->d_image16 = nullptr; m->d_consts8 = nullptr; m->d_stream8 = nullptr; m->d_image8 = nullptr; m->d_stream16t = nullptr; m->d_sigma_tab = nullptr; m->d_bwd_image = nullptr; m->d_petab = nullptr; m->d_ref = nullptr; m->d_wscale16 = nullptr;
     int rc = nm::check_hip(hipMalloc(&m->d_image, (size_t)bytes), "nm_mlp_create: hipMalloc(image)");
     const size_t consts_off = (size_t)(nm::kWeightBytes8 + nm::kWeightPadBytes), consts_bytes = img8.size() - consts_off;
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_consts8, consts_bytes), "nm_mlp_create: hipMalloc(consts8)");
@@ -627,8 +602,6 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     if (!rc) rc = nm::check_hip(hipMemcpy(m->d_stream8, str8.data(), str8.size(), hipMemcpyHostToDevice), "nm_mlp_create: upload stream8");
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_image8, consts_off), "nm_mlp_create: hipMalloc(image8)");
     if (!rc) rc = nm::check_hip(hipMemcpy(m->d_image8, str8s.data(), consts_off, hipMemcpyHostToDevice), "nm_mlp_create: upload image8");
-    if (!rc) rc = nm::check_hip(hipMalloc(&m->d_image8t, consts_off), "nm_mlp_create: hipMalloc(image8t)");
-    if (!rc) rc = nm::check_hip(hipMemcpy(m->d_image8t, str8t.data(), consts_off, hipMemcpyHostToDevice), "nm_mlp_create: upload image8t");
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_petab, sizeof(tab)), "nm_mlp_create: hipMalloc(petab)");
     if (!rc) rc = nm::check_hip(hipMalloc(&m->d_ref, ref.size() * 4), "nm_mlp_create: hipMalloc(ref)");
     if (!rc) rc = nm::check_hip(hipMemcpy(m->d_image, img.data(), (size_t)bytes, hipMemcpyHostToDevice), "nm_mlp_create: upload image");
@@ -687,7 +660,6 @@ int nm_mlp_destroy(nm_mlp_t m) {
     if (m->d_consts8) (void)hipFree(m->d_consts8);
     if (m->d_stream8) (void)hipFree(m->d_stream8);
     if (m->d_image8) (void)hipFree(m->d_image8);
-    if (m->d_image8t) (void)hipFree(m->d_image8t);
     if (m->d_stream16t) (void)hipFree(m->d_stream16t);
     if (m->d_sigma_tab) (void)hipFree(m->d_sigma_tab);
     if (m->d_bwd_image) (void)hipFree(m->d_bwd_image);
@@ -740,9 +712,6 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
     const bool sigma_t = !(sk && !strcmp(sk, "w")) && m->d_stream16t;
     if (sigma_t && precision == NM_PREC_FP16X3 && sigma_only == 1 && stop_stage == -2 && !dbg && !prof && !m->desc.plain_head)
         return nm::launch_sigma_f16t(L, m->d_stream16t, m->sigma_ndir, pts, dirs, origin, direction, z, n, S, in_mode, sigma_scale, out, nm::as_stream(stream), chunk, nullptr, -1);
-    static const bool i8_t = [] { const char* e = getenv("NEUMAN_I8_KERNEL"); return e && !strcmp(e, "t"); }();
-    if (i8_t && precision == NM_PREC_I8X3 && stop_stage == -2 && !dbg && !prof && !sigma_only)
-        return nm::launch_mlp_i8t(L, m->d_image8t, pts, dirs, origin, direction, z, n, S, in_mode, sigma_scale, out, nm::as_stream(stream), chunk, nullptr, -1);
     if (i8_as && precision == NM_PREC_I8X3 && stop_stage == -2 && !dbg && !prof && !sigma_only)
         return nm::launch_mlp_i8s(L, m->d_image8, pts, dirs, origin, direction, z, n, S, in_mode, sigma_scale, out, nm::as_stream(stream), chunk);
     return nm::launch_mlp_mfma(L, pts, dirs, origin, direction, z, n, S, in_mode, precision, stop_stage, sigma_scale, out, dbg,
@@ -959,18 +928,6 @@ int nm_mlp_forward_profile(nm_mlp_t mlp, const float* pts, const float* dirs, in
                "nm_mlp_forward_profile: precision %d has no profiling build",
                precision);
     return mlp_dispatch(mlp, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, precision, -2, 1.f, out, nullptr, stream, cycles);
-}
-
-int nm_mlp_forward_i8t_debug(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int stage, uint32_t* state, float* out, nm_stream_t stream) {
-    NM_REQUIRE(mlp && pts && dirs && state && out && n > 0, "nm_mlp_forward_i8t_debug: null pointer");
-    NM_REQUIRE(stage >= 0 && (stage % 100 <= 9 || stage % 100 == 99) && !mlp->desc.plain_head, "nm_mlp_forward_i8t_debug: stage %d outside 0..9 (+ 100 x tile round)", stage);
-    nm::MlpLaunch L;
-    L.petab = mlp->d_petab;
-    L.pe_kind = mlp->desc.pe_kind; L.pos_nfreq = mlp->desc.pos_n_freqs; L.dir_nfreq = mlp->desc.dir_n_freqs;
-    L.pos_octaves = mlp->pos_octaves; L.dir_octaves = mlp->dir_octaves;
-    L.plain_head = 0;
-    L.consts8 = mlp->d_consts8;
-    return nm::launch_mlp_i8t(L, mlp->d_image8t, pts, dirs, nullptr, nullptr, nullptr, n, 1, 0, 1.f, out, nm::as_stream(stream), nullptr, state, stage);
 }
 
 int nm_mlp_sigma_f16t_debug(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, int stage, float* state, float* out, nm_stream_t stream) {

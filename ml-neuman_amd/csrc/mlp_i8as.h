@@ -1,4 +1,4 @@
-// Shared device helpers of the activation-stationary i8x3 kernels (mlp_i8s.hip: 8 waves x 32 samples; mlp_i8t.hip: 4 waves x two
+// Shared device helpers of the activation-stationary i8x3 kernels (mlp_i8s.hip: 8 waves x 32 samples; round 4's mlp_i8t.hip, removed in round 5: 4 waves x two
 // 32-sample sub-tiles): encodings of a wave's rows, the resident activation fragments, LDS-DMA, de- and requantisation -- one definition,
 // so that the kernels run the same arithmetic instruction for instruction (they must agree bit for bit).
 #pragma once

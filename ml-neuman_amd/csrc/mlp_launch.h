@@ -44,11 +44,6 @@ int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, con
 // NM_PREC_I8X3, activation-stationary schedule (mlp_i8s.hip); image8 = the block image of mlp_layout.h frag_off8 on the device
 int launch_mlp_i8s(const MlpLaunch& L, const void* image8, const float* pts, const float* dirs, const float* origin, const float* direction,
                    const float* z, int64_t n, int S, int in_mode, float sigma_scale, float* out, hipStream_t stream, const MlpChunk* chunk);
-// NM_PREC_I8X3, 4 waves x two sub-tiles (mlp_i8t.hip); image8t = pack_stream8t.  dbg (nullable): the first tile's activation state after
-// stage dbg_stage, 130 dwords per lane of workgroup 0 (stage-by-stage checks of the generated instruction stream)
-int launch_mlp_i8t(const MlpLaunch& L, const void* image8t, const float* pts, const float* dirs, const float* origin, const float* direction,
-                   const float* z, int64_t n, int S, int in_mode, float sigma_scale, float* out, hipStream_t stream, const MlpChunk* chunk,
-                   unsigned* dbg, int dbg_stage);
 // NM_PREC_FP16X3 density only, activation-stationary (mlp_f16t.hip); stream16t = sigma_stream_kernel's re-cut of the fp16 image.  dbg (nullable): the
 // activations after stage dbg_stage of the first tile (+ 100 x round) of workgroup 0 as float32 [128 samples][256] in k-slot order
 int launch_sigma_f16t(const MlpLaunch& L, const void* stream16t, int stream_ndir, const float* pts, const float* dirs, const float* origin, const float* direction,

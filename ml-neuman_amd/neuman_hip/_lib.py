@@ -72,7 +72,6 @@ SIGNATURES = {
                                      c_stream]),
     "nm_transmittance_chunk": (i32, [c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, i64, i32, i32, i32, c_f32p, c_stream]),
     "nm_transmittance_chunk_dz": (i32, [c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, i64, i32, i32, i32, c_f32p, c_stream]),
-    "nm_mlp_forward_i8t_debug": (i32, [ctypes.c_void_p, c_f32p, c_f32p, i64, i32, ctypes.c_void_p, c_f32p, c_stream]),
     "nm_mlp_sigma_f16t_debug": (i32, [ctypes.c_void_p, c_f32p, c_f32p, i64, i32, c_f32p, c_f32p, c_stream]),
     "nm_mlp_forward_debug": (i32, [ctypes.c_void_p, c_f32p, c_f32p, i64, i32, i32, c_f32p, c_stream]),
     "nm_mlp_forward_profile": (i32, [ctypes.c_void_p, c_f32p, c_f32p, i64, i32, c_f32p, ctypes.c_void_p, c_stream]),

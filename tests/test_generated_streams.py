@@ -1,5 +1,5 @@
-"""The hand-scheduled kernels' instruction streams (csrc/mlp_i8t_body.h, csrc/mlp_f16t_body.h) are generated files: what is committed is
-what the committed generators emit, and the emitter's bookkeeping holds on them (every LDS read is waited for before its first use; MFMA
+"""The hand-scheduled kernel's instruction stream (csrc/mlp_f16t_body.h) is a generated file: what is committed is
+what the committed generator emits, and the emitter's bookkeeping holds on them (every LDS read is waited for before its first use; MFMA
 results are not touched inside the hazard window)."""
 import os
 import re
@@ -12,7 +12,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 CSRC = os.path.join(ROOT, "ml-neuman_amd", "csrc")
 
 
-@pytest.mark.parametrize("gen,env,header", [("gen_i8t.py", "I8T_OUT", "mlp_i8t_body.h"), ("gen_f16t.py", "F16T_OUT", "mlp_f16t_body.h")])
+@pytest.mark.parametrize("gen,env,header", [("gen_f16t.py", "F16T_OUT", "mlp_f16t_body.h")])
 def test_committed_stream_is_the_generators_output(tmp_path, gen, env, header):
     out = tmp_path / header
     e = {k: v for k, v in os.environ.items() if not k.startswith(("I8T_", "F16T_", "NM_I8T", "NM_F16T"))}
@@ -21,7 +21,7 @@ def test_committed_stream_is_the_generators_output(tmp_path, gen, env, header):
     assert out.read_text() == open(os.path.join(CSRC, header)).read()
 
 
-@pytest.mark.parametrize("header", ["mlp_i8t_body.h", "mlp_f16t_body.h"])
+@pytest.mark.parametrize("header", ["mlp_f16t_body.h"])
 def test_stream_text_is_self_consistent(header):
     """an independent pass over the text: registers written by ds_read_b128 are not read before an s_waitcnt lgkmcnt that covers them
     (in-order return: the wait's count must be <= the number of LDS reads issued after the one in question)"""

@@ -28,19 +28,6 @@ def test_as_kernel_is_bit_identical_to_the_wave_specialised_kernel(tmp_path):
         assert torch.equal(mine[k], theirs[k]), f"{k}: max |diff| {(mine[k] - theirs[k]).abs().max().item():.3e}"
 
 
-def test_two_sub_tile_kernel_is_bit_identical_too(tmp_path):
-    """csrc/mlp_i8t.hip (NEUMAN_I8_KERNEL=t): 4 waves x two 32-sample sub-tiles, the hand-allocated 512-register instruction stream --
-    the same arithmetic once more, the same bits on every entry point"""
-    mine = i8_outputs.outputs()
-    other = tmp_path / "t.pt"
-    env = dict(os.environ, NEUMAN_I8_KERNEL="t")
-    subprocess.run([sys.executable, i8_outputs.__file__, str(other)], check=True, env=env, timeout=900)
-    theirs = torch.load(other)
-    assert set(mine) == set(theirs)
-    for k in sorted(mine):
-        assert torch.equal(mine[k], theirs[k]), f"{k}: max |diff| {(mine[k] - theirs[k]).abs().max().item():.3e}"
-
-
 def test_density_of_the_full_launch_equals_the_density_only_launch():
     """In-process cross-check of the two kernels: the density-only form of a launch stays on the wave-specialised kernel."""
     from neuman_hip import synthetic

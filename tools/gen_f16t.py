@@ -3,7 +3,7 @@
 pass of a two-pass render evaluates, csrc/mlp.hip nerf_mlp_kernel<fp16x3> with sigma_only) as ONE hand-allocated gfx950 instruction stream for
 nerf_sigma_f16t_kernel (csrc/mlp_f16t.hip): activation-stationary, 4 waves per CU with all 512 registers each, 32 samples per wave.
 
-    python tools/gen_f16t.py         (uses the emitter of tools/gen_i8t.py: LDS return queue and wait-state bookkeeping)
+    python tools/gen_f16t.py         (uses the emitter tools/asm_emit.py: LDS return queue and wait-state bookkeeping)
 
 The arithmetic is nerf_mlp_kernel's, MFMA for MFMA: per output block and k-step the products wh.xl, wl.xh, wh.xh on v_mfma_f32_32x32x16_f16
 in that order into an accumulator that starts at the bias, then x 2^-k, clamp, split into two fp16 parts (v_cvt_pk_f16_f32, back-conversion,
@@ -31,7 +31,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from gen_i8t import Asm, ar, f32hex, stage_b_off as _unused, vr  # noqa: E402,F401
+from asm_emit import Asm, ar, f32hex, vr  # noqa: E402
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 OUT = os.environ.get("F16T_OUT") or os.path.join(ROOT, "ml-neuman_amd", "csrc", "mlp_f16t_body.h")
@@ -127,7 +127,7 @@ class GenF:
         n, k = self.units[i % len(self.units)]
         return n * k * 1024
 
-    # ---- ring (the protocol of gen_i8t: hand-over inside the predecessor, copies behind it) ------------------------------------------------
+    # ---- ring (hand-over inside the predecessor, copies behind it) ------------------------------------------------
     def ring_start(self):
         A = self.A
         A.comment(f"---- ring unit {self.unit}")
@@ -524,7 +524,7 @@ __device__ __forceinline__ void sigma_stages_asm(const ArgsF& A, const MlpArgs& 
     register unsigned v_pe asm("v{V_PE}") = (unsigned)(uintptr_t)pw + (unsigned)(g * 1024 + s * 16);
     register unsigned v_cp0 asm("v{V_CP0}") = (unsigned)((uintptr_t)R.src - (uintptr_t)A.stream);       // lane * 16 + wave * 1024
     float4* rec = reinterpret_cast<float4*>(a.out);
-    // (branch-free on purpose: see tools/gen_i8t.py -- hipcc places a spill in front of the exec restore of a divergent region before the statement)
+    // (branch-free on purpose: see profiles/r04_i8t_kernel.md -- hipcc places a spill in front of the exec restore of a divergent region before the statement)
     const int64_t i0 = row0 + s, ci = i0 < a.n ? i0 : a.n - 1;
     const unsigned long long q = (unsigned long long)(uintptr_t)(rec + sample_record(a, ci));
     const unsigned long long po = (g == 0 && i0 < a.n) ? q : 0ull;
