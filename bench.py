@@ -61,7 +61,7 @@ DTYPES = {
     "bf16x3": "bf16x3 (split-bf16 hi+lo MFMA x3, f32 accumulate)",
     "i8x3": "i8x3 (per-row-scaled int16 as 2 int8 limbs, i8 MFMA x3, exact int32 accumulate; encodings on bf16x3)",
     "bf16": "bf16 (f32 accumulate)", "fp32": "f32"}
-PMC_SUMMARIES = ("profiles/r04_bench_pmc_summary.json", "profiles/r03_bench_pmc_summary.json", "profiles/r02_bench_pmc_summary.json", "profiles/r01_bench_pmc_summary.json")
+PMC_SUMMARIES = ("profiles/r05_bench_pmc_summary.json", "profiles/r04_bench_pmc_summary.json", "profiles/r03_bench_pmc_summary.json", "profiles/r02_bench_pmc_summary.json", "profiles/r01_bench_pmc_summary.json")
 KERNEL_OF = {"fp16x3": "nerf_mlp_kernel<4, false>", "bf16x3": "nerf_mlp_kernel<1, false>", "i8x3": "nerf_mlp_i8s_kernel", "bf16": "nerf_mlp_kernel<2, false>",
              "fp32": "nerf_mlp_ref_kernel"}
 
@@ -201,13 +201,16 @@ def train_iteration(dev, origins, dirs, cap, rays=2048, iters=5):
     coarse, fine = synthetic.make_joiner(0).to(dev).train(), synthetic.make_joiner(1).to(dev).train()
     optim = torch.optim.Adam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4)
     g = torch.Generator(device='cpu').manual_seed(0)
-    color = torch.rand((rays, 3), generator=g).to(dev)
+    target = synthetic.make_joiner(7).to(dev).eval()                       # the colours to fit: another net's rendering of the same rays (not noise)
     near = torch.full((rays,), float(cap.near['bkg']), device=dev)
     far = torch.full((rays,), float(cap.far['bkg']), device=dev)
+    losses = []
 
     def step():
         idx = torch.randint(0, origins.shape[0], (rays,), generator=g).to(dev)
         o, d = origins[idx].contiguous(), dirs[idx].contiguous()
+        with torch.no_grad():
+            color = render_utils.render_vanilla_rays(target, None, o, d, cap.near['bkg'], cap.far['bkg'], 32, 0, True)[0]
         optim.zero_grad()
         pts, _, z = ray_utils.sample_z(o, d, near, far, S, want_points=True)
         out = coarse(pts, d[:, None, :].expand(pts.shape))
@@ -220,23 +223,37 @@ def train_iteration(dev, origins, dirs, cap, rays=2048, iters=5):
         loss = loss + F.mse_loss(render_utils.raw2outputs(outf, zf, d, white_bkg=True)[0], color)
         loss.backward()
         optim.step()
+        losses.append(loss.detach())
         return loss
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(iters):
-        t0 = time.perf_counter()
-        loss = step()
+
+    def timed():
+        for _ in range(2):
+            step()
         torch.cuda.synchronize()
-        ts.append(time.perf_counter() - t0)
-    ms = sorted(ts)[len(ts) // 2] * 1e3
+        ts = []
+        for _ in range(iters):
+            t0 = time.perf_counter()
+            loss = step()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2] * 1e3, float(loss.detach())
+    ms, _ = timed()
+    keep = train.STORE16
+    train.STORE16 = False                                           # the float32 copies of round 4, same kernels otherwise: the split, reported beside
+    try:
+        ms32, _ = timed()
+    finally:
+        train.STORE16 = keep
     evals = rays * (S + S + NI)
     return {"rays_per_batch": rays, "samples": [S, S + NI], "ms_per_iteration": ms, "iterations_per_s": 1e3 / ms,
             "mlp_tflops_fwd_bwd": evals * FLOP_PER_EVAL * 3 / ms / 1e9, "gemm_precision": train.GEMM_PRECISION,
-            "loss": float(loss.detach()), "what": "forward with saved activations, backward-data and backward-weights products of both 8x256 "
-            "networks (csrc/train.hip), differentiable compositing, Adam; parameter gradients 6e-6 from the reference's autograd "
-            "(tests/test_hip_train.py)"}
+            "fp16_storage": bool(keep), "ms_per_iteration_float32_storage": ms32,
+            "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "iterations_run": len(losses),
+            "target": "the rays' colours rendered by a second net (seed 7, 32 samples): a field the trained nets approach", "what": "forward with saved activations (one kernel), the whole backward-data pass (one kernel), batched weight-gradient products, "
+            "differentiable compositing, Adam (csrc/mlp.hip, mlp_bwd.hip, train.hip); what the step keeps between its passes is fp16 (activations x 32, dZ x a "
+            "measured power of two) and the weight-gradient products are single fp16 MFMAs with float32 accumulation; ms_per_iteration_float32_storage = "
+            "the same step with float32 copies (NEUMAN_TRAIN_STORE16=0, round 4's arithmetic: parameter gradients 6e-6 from the reference's autograd at the "
+            "small golden; fp16 storage: 2e-5 .. 9e-5 at 131k / 262k evaluations, tests/test_hip_train16.py)"}
 
 
 def self_launch(args):
