@@ -18,5 +18,5 @@ wait
 ASAN=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 cd $R
 ARGS=${@:-tests/test_mlp_pack.py tests/test_abi.py}
-LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=1 NEUMAN_HIP_LIB=$R/ml-neuman_amd/lib/exp/libneuman_hip_asan.so \
+LD_PRELOAD=$ASAN ASAN_OPTIONS=${ASAN_OPTIONS:-detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=1:allocator_may_return_null=1} NEUMAN_HIP_LIB=$R/ml-neuman_amd/lib/exp/libneuman_hip_asan.so \
     python -m pytest -q -x $ARGS
