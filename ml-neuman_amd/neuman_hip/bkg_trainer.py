@@ -61,7 +61,7 @@ class BackgroundNeRFTrainer:
         self.sync, self.shard_batches, self.group = None, shard_batches, group
         if data_parallel:
             dp.broadcast_parameters(self._nets(), group=group)    # (after a resume too: every rank starts from rank 0's weights)
-            self.sync = dp.GradSync([p for n in self._nets() for p in n.parameters()], n_extra=4, group=group)
+            self.sync = dp.GradSync([p for n in self._nets() for p in n.parameters()], n_extra=5, group=group)
 
     # ---------------------------------------------------------------------------------------------
     def _empty_space(self, raw, z_vals, depth):
@@ -118,10 +118,11 @@ class BackgroundNeRFTrainer:
 
         def pieces(raw, rgb, zz):
             sq = ((rgb - batch['color']) ** 2).sum()
-            if self.penalize_empty_space > 0:
+            if self.penalize_empty_space > 0:                                # (:66-72 as masked sums: no index list, no host question)
                 closer = zz < depth[:, None] * opt.margin
-                sigma = raw[..., 3][closer]
-                es = self.empty_space_loss_fn(torch.tanh(torch.relu(sigma)), torch.zeros_like(sigma), reduction='sum') * self.penalize_empty_space
+                x = torch.tanh(torch.relu(raw[..., 3]))
+                fx = x * x if self.empty_space_loss_fn is F.mse_loss else x.abs()
+                es = (fx * closer.to(fx.dtype)).sum() * self.penalize_empty_space
                 cnt = closer.sum()
             else:
                 es, cnt = torch.zeros((), device=raw.device), torch.zeros((), device=raw.device)
@@ -135,14 +136,15 @@ class BackgroundNeRFTrainer:
                 z_fine = ray_utils.importance_z(z, weights.detach(), opt.importance_samples_per_ray)
             raw_f, rgb_f, _ = self._pass(self.fine_net, batch, z_fine, time)
             sq_f, es_f, cnt_f, max_f = pieces(raw_f, rgb_f, z_fine)
-        # NaN-aware largest density: `max <= 0` must be False for NaN on any rank (the reference's test on the whole batch)
-        stats = dp.all_gather_floats([float(rgb.numel()), cnt_c, cnt_f, torch.nan_to_num(max_c, nan=1.0), torch.nan_to_num(max_f, nan=1.0)], self.group)
-        n_rgb, n_c, n_f = float(stats[:, 0].sum()), float(stats[:, 1].sum()), float(stats[:, 2].sum())
-        dead = bool(stats[:, 3].max() <= 0.0) or bool(stats[:, 4].max() <= 0.0)
+        # the global counts and the dead-network test stay ON THE DEVICE (no host question between the two passes): NaN-aware largest density --
+        # `max <= 0` must be False for NaN on any rank (the reference's test on the whole batch)
+        stats = dp.all_gather_floats([float(rgb.numel()), cnt_c, cnt_f, torch.nan_to_num(max_c, nan=1.0), torch.nan_to_num(max_f, nan=1.0)], self.group, on_device=True)
+        n_rgb, n_c, n_f = stats[:, 0].sum().float(), stats[:, 1].sum().float().clamp_min(1.0), stats[:, 2].sum().float().clamp_min(1.0)
+        dead = (stats[:, 3].max() <= 0.0) | (stats[:, 4].max() <= 0.0)
         zero = torch.zeros((), device=o.device)
-        terms = [sq_c / n_rgb, es_c / n_c if n_c > 0 else zero]
-        terms += [sq_f / n_rgb, es_f / n_f if n_f > 0 else zero] if sq_f is not None else [zero, zero]
-        return terms, dead
+        terms = [sq_c / n_rgb, es_c / n_c]                                 # (an empty selection: es = 0 over a count clamped to 1)
+        terms += [sq_f / n_rgb, es_f / n_f] if sq_f is not None else [zero, zero]
+        return [torch.where(dead, torch.zeros_like(t), t) for t in terms], dead
 
     def _train_batch_dp(self, batch):
         """train_batch over the process group: local share of the loss, backward, ONE all_reduce of gradients + loss values, the NaN guard and
@@ -154,24 +156,24 @@ class BackgroundNeRFTrainer:
         terms, dead = self.loss_func_dp(batch)
         rgb_loss, empty_loss = terms[0] + terms[2], terms[1] + terms[3]
         total = rgb_loss + empty_loss if self.iteration >= self.opt.delay_iters else rgb_loss
+        if total.requires_grad:
+            total.backward()
+        # ONE collective for the gradients, the four loss values and the dead flag (identical on every rank already), ONE read-back
+        vals = self.sync.reduce(extra=[t.detach() for t in terms] + [dead.to(torch.float32) / self.world])
+        dead = vals[4] > 0.5
+        vals = vals[:4]
         if dead:                                                  # (:88-94) redraw on rank 0, everybody takes those weights; no step on them
             print('bad weights, reinitializing')
             for net in self._nets():
                 net.apply(weight_reset)
             dp.broadcast_parameters(self._nets(), group=self.group)
             vals = [0.0, 0.0, 0.0, 0.0]
-            self.sync.zero()
-            for p in self.sync.params:
-                p.grad = None
-        else:
-            if total.requires_grad:
-                total.backward()
-            vals = self.sync.reduce(extra=[t.detach() for t in terms])
         report = dict(zip(LOSS_TERMS, vals))
         report.update(rgb_loss=vals[0] + vals[2], empty_space_loss=vals[1] + vals[3], lr=self.optim.param_groups[0]['lr'])
         report['total_loss'] = report['rgb_loss'] + (report['empty_space_loss'] if self.iteration >= self.opt.delay_iters else 0.0)
-        if math.isnan(report['total_loss']):
-            print('loss is nan during training')
+        if dead or math.isnan(report['total_loss']):
+            if not dead:
+                print('loss is nan during training')
             self.sync.zero()
             for p in self.sync.params:
                 p.grad = None

@@ -34,16 +34,19 @@ def _collective_device(t):
     return t.cpu() if (t.is_cuda and dist.get_backend() == "gloo") else t
 
 
-def all_gather_floats(values, group=None):
-    """[world, len(values)] float64 on the host: each rank's small vector of python / 0-d tensor numbers (ONE collective, one read-back)"""
+def all_gather_floats(values, group=None, on_device=False):
+    """[world, len(values)] float64: each rank's small vector of python / 0-d tensor numbers through ONE collective -- on the host (one read-back),
+    or with on_device left where the values live (no host synchronisation: what the trainer's iteration uses between its forward and backward pass)"""
     rank, world = rank_world(group)
-    mine = torch.stack([torch.as_tensor(v, dtype=torch.float64).reshape(()).to(values_device(values)) for v in values])
+    dev = values_device(values)
+    mine = torch.stack([torch.as_tensor(v, dtype=torch.float64).reshape(()).to(dev) for v in values])
     if world == 1 and not (dist.is_available() and dist.is_initialized()):
-        return mine[None].cpu()
+        return mine[None] if on_device else mine[None].cpu()
     send = _collective_device(mine)
     out = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(out, send, group=group)
-    return torch.stack(out).cpu()
+    got = torch.stack(out)
+    return got.to(dev) if on_device else got.cpu()
 
 
 def values_device(values):
@@ -111,10 +114,11 @@ class GradSync:
                     v.copy_(p.grad)
                 p.grad = v
             if extra is not None:
-                self.extra.copy_(torch.stack([torch.as_tensor(e, dtype=torch.float32, device=self.flat.device).reshape(()) for e in extra]))
+                self.extra.zero_()
+                self.extra[:len(extra)].copy_(torch.stack([torch.as_tensor(e, dtype=torch.float32, device=self.flat.device).reshape(()) for e in extra]))
             if dist.is_available() and dist.is_initialized():
                 buf = _collective_device(self.flat)
                 dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
                 if buf.data_ptr() != self.flat.data_ptr():
                     self.flat.copy_(buf)
-        return self.extra.tolist() if extra is not None else []
+        return self.extra[:len(extra)].tolist() if extra is not None else []
