@@ -563,6 +563,25 @@ int nm_composite_backward(const float* raw, const float* z_vals, const float* ra
                           const float* g_rgb, const float* g_acc, const float* g_depth, const float* g_weights,
                           float* d_raw, nm_stream_t stream);
 
+/* --------------------------------------------------------------------------------------------
+ * The scalar regularisers of the human trainer's loss (trainers/human_nerf_trainer.py:280-380) as single passes: the VALUE of a term and its
+ * GRADIENT with respect to the network outputs it reads, in one kernel + one deterministic finalisation (csrc/loss.hip) -- torch's elementwise
+ * algebra takes 10-25 launches per term and as many again in autograd's backward pass.  raw arrays are [n][4] = (r, g, b, sigma) rows, 16-byte
+ * aligned; `loss` is one device float; workspace: nm_loss_workspace_doubles() doubles.
+ *   nm_loss_bimodal: mean_i(-log(e^-|y_i| + e^-|1 - y_i|) + offset), y = clamp(x, 0, 1) when clamp01 (:368-379 with HARD_SURFACE_OFFSET); dx [n]
+ *   nm_loss_pair_mse: scale * mse between two raw outputs: mode 0 over sigmoid(rgb) (the colour-range term, :280-290), mode 1 over tanh(relu(sigma))
+ *                     (the symmetry term, :292-304); da_raw / db_raw [n][4]
+ *   nm_loss_shape: the SMPL shape prior (:305-343): w_smpl * mean_{dist_h < 0}((1 - occ(pred))^2) + w_dummy * (mean_{dist_d < 0}((1 - occ(dummy))^2)
+ *                  + mean_{dist_d > 0}(|occ(dummy) * (|dist_d| * outside_factor)^exponent|)), occ = 1 - exp(-relu(sigma)), empty selections count as 1;
+ *                  nd = 0: the first term alone; norm3: three device floats of scratch */
+int64_t nm_loss_workspace_doubles(void);
+int nm_loss_bimodal(const float* x, int64_t n, int clamp01, float offset, float* loss, float* dx, double* workspace, nm_stream_t stream);
+int nm_loss_pair_mse(int mode, const float* a_raw, const float* b_raw, int64_t n, float scale, float* loss, float* da_raw, float* db_raw,
+                     double* workspace, nm_stream_t stream);
+int nm_loss_shape(const float* pred_raw, const float* dist_h, int64_t nh, const float* dummy_raw, const float* dist_d, int64_t nd, float w_smpl,
+                  float w_dummy, float outside_factor, float exponent, float* loss, float* d_pred_raw, float* d_dummy_raw, double* workspace,
+                  float* norm3, nm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,6 +134,11 @@ SIGNATURES = {
     "nm_importance_from_raw": (i32, [c_f32p, c_f32p, c_f32p, i64, i32, c_f32p, i32, c_f32p, c_f32p, c_stream]),
     "nm_merge_composite_workspace_floats": (i64, [i64, i32, i32]),
     "nm_merge_composite": (i32, [c_f32p, c_f32p, i32, c_f32p, c_f32p, i32, i64, c_f32p, i32, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
+    "nm_loss_workspace_doubles": (i64, []),
+    "nm_loss_bimodal": (i32, [c_f32p, i64, i32, ctypes.c_float, c_f32p, c_f32p, ctypes.c_void_p, c_stream]),
+    "nm_loss_pair_mse": (i32, [i32, c_f32p, c_f32p, i64, ctypes.c_float, c_f32p, c_f32p, c_f32p, ctypes.c_void_p, c_stream]),
+    "nm_loss_shape": (i32, [c_f32p, c_f32p, i64, c_f32p, c_f32p, i64, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, c_f32p,
+                            ctypes.c_void_p, c_f32p, c_stream]),
     "nm_frame_to_uint8": (i32, [c_f32p, i64, ctypes.c_void_p, c_stream]),
     "nm_ssd_u8": (i32, [ctypes.c_void_p, ctypes.c_void_p, i64, ctypes.c_void_p, c_stream]),
 }

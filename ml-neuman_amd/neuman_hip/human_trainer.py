@@ -23,7 +23,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import ray_utils, render_utils
+from . import loss_ops, ray_utils, render_utils
 
 LOSS_NAMES = ['fine_rgb_loss', 'lpips_loss', 'color_range_reg', 'smpl_sym_reg', 'smpl_shape_reg', 'mask_loss', 'sparsity_reg']   # :31-39
 HARD_SURFACE_OFFSET = 0.31326165795326233          # utils/constant.py:7
@@ -43,6 +43,11 @@ def _bimodal_prior(x):
     """mean(-log(e^-|x| + e^-|1-x|)) + HARD_SURFACE_OFFSET: zero-mean pull of x towards 0 or 1 (the trainer's sharp-edge and
     hard-surface terms, human_nerf_trainer.py:368-379)"""
     return torch.mean(-torch.log(torch.exp(-x.abs()) + torch.exp(-(1 - x).abs())) + HARD_SURFACE_OFFSET)
+
+
+def _fused(*tensors):
+    """the regularisers as single value-and-gradient kernels (loss_ops) when the term's inputs live on the GPU"""
+    return loss_ops.FUSED and all(t is None or t.is_cuda for t in tensors)
 
 
 def _unit(v):
@@ -121,6 +126,8 @@ class HumanNeRFLoss:
         return pts, _unit(draw)                                                           # the same points seen from random directions
 
     def _color_range_regularization(self, other_view, tgts):
+        if _fused(other_view, tgts):
+            return loss_ops.color_range(other_view, tgts, self.penalize_color_range)
         rgb = lambda raw: torch.sigmoid(raw.reshape(-1, 4)[:, :3])                       # noqa: E731
         return self.penalize_color_range * F.mse_loss(rgb(other_view), rgb(tgts))
 
@@ -130,6 +137,8 @@ class HumanNeRFLoss:
         return pts.detach() * mirror, dirs.detach()                                      # (dummy directions: only the occupancy is compared)
 
     def _smpl_symmetry_regularization(self, mirrored, tgts):
+        if _fused(mirrored, tgts):
+            return loss_ops.symmetry(mirrored, tgts, self.penalize_symmetric_alpha)
         squash = lambda raw: torch.tanh(torch.relu(raw[..., 3]))                        # noqa: E731
         return self.penalize_symmetric_alpha * F.mse_loss(squash(tgts), squash(mirrored))
 
@@ -172,8 +181,17 @@ class HumanNeRFLoss:
         return ((torch.as_tensor(self.replay['dummy_pts_rand']).to(pts) if self.replay else torch.rand_like(pts)) - 0.5) * 3
 
     def _smpl_shape_regularization(self, batch, pts, pred, dummy_pts, dummy_out):
-        device = pts.device
-        smpl_reg = torch.zeros((), device=device)
+        # both signed-distance queries of the iteration (:310, :326) go against the same canonical body: ONE search launch
+        both = self._signed_distance(pts if dummy_pts is None else torch.cat([pts.reshape(-1, 3), dummy_pts.reshape(-1, 3)], 0), batch.get('cap_id'))
+        n_h = pts.reshape(-1, 3).shape[0]
+        dist_human, dist_dummy = both[:n_h], (None if dummy_pts is None else both[n_h:])
+        self.last.update(dist_human=dist_human)
+        if dummy_pts is not None:
+            self.last.update(dummy_pts=dummy_pts, dist_dummy=dist_dummy, dummy_out=dummy_out)
+        if _fused(pred, dummy_out):
+            return loss_ops.shape_prior(pred, dist_human, dummy_out, dist_dummy, self.penalize_smpl_alpha, self.penalize_dummy,
+                                        self.opt.penalize_outside_factor, self.opt.dist_exponent)
+        smpl_reg = torch.zeros((), device=pts.device)
 
         def masked_mean(x, mask):                                                        # x[mask].mean(), 0 for an empty mask -- without asking the
             m = mask.to(x.dtype)                                                         # host whether it is empty (a synchronisation per question)
@@ -182,19 +200,12 @@ class HumanNeRFLoss:
         def filled(raw, mask, weight):                                                   # occupancy 1 where the body is
             return weight * masked_mean((1 - _occupancy(raw)) ** 2, mask)
 
-        # both signed-distance queries of the iteration (:310, :326) go against the same canonical body: ONE search launch
-        both = self._signed_distance(pts if dummy_pts is None else torch.cat([pts.reshape(-1, 3), dummy_pts.reshape(-1, 3)], 0), batch.get('cap_id'))
-        n_h = pts.reshape(-1, 3).shape[0]
-        dist_human = both[:n_h]
         smpl_reg = smpl_reg + filled(pred, dist_human < 0, self.penalize_smpl_alpha)
         if dummy_pts is not None:
-            dist_dummy = both[n_h:]
             smpl_reg = smpl_reg + filled(dummy_out, dist_dummy < 0, self.penalize_dummy)
             outside = dist_dummy > 0                                                     # occupancy 0 outside, weighted by the distance from the surface
             falloff = (dist_dummy.abs() * self.opt.penalize_outside_factor) ** self.opt.dist_exponent
             smpl_reg = smpl_reg + self.penalize_dummy * masked_mean((_occupancy(dummy_out) * falloff).abs(), outside)
-            self.last.update(dummy_pts=dummy_pts, dist_dummy=dist_dummy, dummy_out=dummy_out)
-        self.last.update(dist_human=dist_human)
         return smpl_reg
 
     # ---- :345-380
@@ -214,18 +225,26 @@ class HumanNeRFLoss:
         sparsity_reg = torch.zeros((), device=can_out.device)
         can_out = torch.cat([can_out[..., :3], can_out[..., 3:] * self.interval_comp], -1)            # `can_out[..., -1] *= interval_comp`, out of place
         _, _, can_mask, can_weights, _ = render_utils.raw2outputs(can_out, can_z_vals.clone(), can_dirs[:, 0, :].clone(), white_bkg=True)
+        self.last.update(can_mask=can_mask, can_weights=can_weights)                     # (before the clamp to [0, 1] of :366-367)
+        if _fused(can_mask, can_weights):                                                # clamp, prior, mean and the gradient of all three: one kernel a term
+            if self.penalize_sharp_edge > 0:
+                sparsity_reg = self.penalize_sharp_edge * loss_ops.bimodal_prior(can_mask, HARD_SURFACE_OFFSET)
+            if self.penalize_hard_surface > 0:
+                hard = self.penalize_hard_surface * loss_ops.bimodal_prior(can_weights, HARD_SURFACE_OFFSET)
+                sparsity_reg = sparsity_reg + hard if self.penalize_sharp_edge > 0 else hard
+            return sparsity_reg
         can_weights, can_mask = can_weights.clamp(0.0, 1.0), can_mask.clamp(0.0, 1.0)
         if self.penalize_sharp_edge > 0:                                                 # silhouettes: a ray is inside or outside
             sparsity_reg = sparsity_reg + self.penalize_sharp_edge * _bimodal_prior(can_mask)
         if self.penalize_hard_surface > 0:                                               # surfaces: a sample carries all of the weight or none
             sparsity_reg = sparsity_reg + self.penalize_hard_surface * _bimodal_prior(can_weights)
-        self.last.update(can_mask=can_mask, can_weights=can_weights)
         return sparsity_reg
 
     # ---- :382-446
     def loss_func(self, batch, return_rgb=False):
         device = next(self.net.coarse_human_net.parameters()).device
-        loss_dict = {name: torch.zeros((), device=device) for name in LOSS_NAMES}
+        zero = torch.zeros((), device=device)
+        loss_dict = {name: zero for name in LOSS_NAMES}                                  # (a term that is switched off stays this zero)
         self.last = {}
         is_hit = batch['is_hit'].to(device).bool()
         fine_bkg_dir, fine_bkg_z_vals, fine_bkg_out = self._eval_bkg_samples(batch, device)
@@ -251,18 +270,18 @@ class HumanNeRFLoss:
         outs = self._human_net(queries)
         human_out = outs[0]
         if 'sym' in slot:
-            loss_dict['smpl_sym_reg'] = loss_dict['smpl_sym_reg'] + self._smpl_symmetry_regularization(outs[slot['sym']], human_out)
+            loss_dict['smpl_sym_reg'] = self._smpl_symmetry_regularization(outs[slot['sym']], human_out)
         if 'color' in slot:
-            loss_dict['color_range_reg'] = loss_dict['color_range_reg'] + self._color_range_regularization(outs[slot['color']], human_out)
+            loss_dict['color_range_reg'] = self._color_range_regularization(outs[slot['color']], human_out)
         if self.penalize_mask > 0:
             _, _, human_mask, _, _ = render_utils.raw2outputs(human_out, human_z_vals, human_dirs[:, 0, :].contiguous(), white_bkg=self.opt.white_bkg)
-            loss_dict['mask_loss'] = loss_dict['mask_loss'] + F.mse_loss(torch.clamp(human_mask, min=0.0, max=1.0),
+            loss_dict['mask_loss'] = F.mse_loss(torch.clamp(human_mask, min=0.0, max=1.0),
                                                                          (1 - batch['is_bkg'].to(device)).float()) * self.penalize_mask
         if self.penalize_smpl_alpha > 0:
-            loss_dict['smpl_shape_reg'] = loss_dict['smpl_shape_reg'] + self._smpl_shape_regularization(
+            loss_dict['smpl_shape_reg'] = self._smpl_shape_regularization(
                 batch, can_pts, human_out, dummy_pts, outs[slot['dummy']] if 'dummy' in slot else None)
         if sparse is not None:
-            loss_dict['sparsity_reg'] = loss_dict['sparsity_reg'] + self._sparsity_regularization(outs[slot['sparse']], sparse[1], sparse[2])
+            loss_dict['sparsity_reg'] = self._sparsity_regularization(outs[slot['sparse']], sparse[1], sparse[2])
         # RGB loss: the two sample lists merged by depth (:415-422), composited once (:423-428)
         fine_total_zvals, fine_order = torch.sort(torch.cat([fine_bkg_z_vals, human_z_vals], -1), -1)
         fine_total_out = torch.gather(torch.cat([fine_bkg_out, human_out], 1), 1, fine_order[..., None].expand(-1, -1, 4))
@@ -270,7 +289,7 @@ class HumanNeRFLoss:
         color = batch['color'].to(device)
         # mse over the hit rays (:429): a masked mean, so that the host need not wait for the index list of the hits
         hit_w = is_hit.to(fine_rgb_map.dtype)[:, None]
-        loss_dict['fine_rgb_loss'] = loss_dict['fine_rgb_loss'] + (((fine_rgb_map - color) ** 2) * hit_w).sum() / (hit_w.sum() * fine_rgb_map.shape[1]).clamp_min(1.0)
+        loss_dict['fine_rgb_loss'] = (((fine_rgb_map - color) ** 2) * hit_w).sum() / (hit_w.sum() * fine_rgb_map.shape[1]).clamp_min(1.0)
         if self.penalize_lpips > 0 and int(batch.get('patch_counter', 0)) == 1 and self.lpips_loss_fn is not None:   # :431-435
             n = PATCH_SIZE * PATCH_SIZE
             a = fine_rgb_map[:n].reshape(PATCH_SIZE, PATCH_SIZE, -1).permute(2, 0, 1) * 2 - 1
@@ -287,7 +306,10 @@ class HumanNeRFLoss:
         alive = ~(human_out[..., 3].detach().max() <= 0.0)
         if self.defer_dead_check:
             self.last['alive'] = alive
-            loss_dict = {k: torch.where(alive, v, torch.zeros_like(v)) for k, v in loss_dict.items()}     # (where, not x 0: an inf loss of a dead network stays 0)
+            terms = torch.stack([loss_dict[name] for name in LOSS_NAMES])
+            terms = torch.where(alive, terms, torch.zeros_like(terms))                   # (where, not x 0: an inf loss of a dead network stays 0)
+            self.last['terms'] = terms                                                   # (the seven as one tensor: one sum, one read-back)
+            loss_dict = dict(zip(LOSS_NAMES, terms.unbind(0)))
         elif not bool(alive):
             self._reset_dead_networks()
             loss_dict = {name: torch.zeros((), device=device, requires_grad=True) for name in LOSS_NAMES}
@@ -308,9 +330,9 @@ class HumanNeRFLoss:
             loss_dict = self.loss_func(batch)
         finally:
             self.defer_dead_check = False
-        total = sum(loss_dict.values())
+        total = self.last['terms'].sum()
         total.backward()
-        vals = torch.stack([v.detach() for v in loss_dict.values()] + [total.detach(), self.last['alive'].to(total.dtype)]).tolist()   # ONE read-back
+        vals = torch.cat([self.last['terms'].detach(), torch.stack([total.detach(), self.last['alive'].to(total.dtype)])]).tolist()   # ONE read-back
         if vals[-1] == 0.0:
             # :437-442: the reference's zero losses are detached from the graph, so no parameter has a gradient and step() skips every one of
             # them -- here backward() has filled zeros: drop them, or Adam's moments of the OLD weights would move the re-initialised ones
@@ -364,6 +386,7 @@ class HumanNeRFTrainer(HumanNeRFLoss):
                 return None if dp is None else densepose_pose_mask(dp)
             self.pose_grad_mask = from_densepose
         self.epoch, self.iteration = 0, 0
+        self._geometry_only = {}
         self.out = getattr(opt, 'out', None)
         if self.out:
             os.makedirs(self.out, exist_ok=True)
@@ -387,13 +410,26 @@ class HumanNeRFTrainer(HumanNeRFLoss):
         # of :437-442 are ONE read-back after the backward pass (a NaN loss: the gradients are dropped, as if backward() had not run)
         self.defer_dead_check = True
         try:
-            g = self._grouped(self.loss_func(batch), photometric=it >= opt.delay_iters)
+            self.loss_func(batch)
         finally:
             self.defer_dead_check = False
-        g['total_loss'].backward()
-        names = list(g.keys())
-        vals = torch.stack([g[k].detach().float() for k in names] + [self.last['alive'].float()]).tolist()
-        report = dict(zip(names, vals[:-1]))
+        # the grouping of :540-551 is sums of the seven terms: the total that is differentiated is one (masked) sum on the device, the groups the
+        # report shows are added up on the host from the terms' values
+        terms, photometric = self.last['terms'], it >= opt.delay_iters
+        if photometric:
+            total = terms.sum()
+        else:
+            dev = terms.device
+            if dev not in self._geometry_only:
+                self._geometry_only[dev] = torch.tensor([0.0 if n in ('fine_rgb_loss', 'color_range_reg', 'lpips_loss') else 1.0 for n in LOSS_NAMES], device=dev)
+            total = (terms * self._geometry_only[dev]).sum()
+        total.backward()
+        vals = torch.cat([terms.detach().float(), torch.stack([total.detach().float(), self.last['alive'].float()])]).tolist()
+        f32 = lambda v: float(np.float32(v))                                              # noqa: E731  (the device's additions are float32)
+        report = dict(zip(LOSS_NAMES, vals[:len(LOSS_NAMES)]))
+        report['rgb_loss'] = f32(f32(report['fine_rgb_loss'] + report['color_range_reg']) + report['lpips_loss'])
+        report['can_loss'] = f32(report['smpl_sym_reg'] + report['smpl_shape_reg'])
+        report['total_loss'] = vals[-2]
         report['lr'] = self.optim.param_groups[0]['lr']
         if vals[-1] == 0.0:                                                              # (as train_step: no gradient reaches the fresh weights)
             self._reset_dead_networks()

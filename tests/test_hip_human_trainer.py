@@ -109,7 +109,7 @@ def test_seven_terms_and_their_gradients(setup):
     assert (dh < 0).any() and (dd < 0).any() and (dd > 0).any()
     assert abs(vals['smpl_shape_reg'] - float(ref)) < 2e-5 * max(1.0, float(ref))
     # ---- sparsity term from the canonical render's mask and weights (:368-379)
-    cm, cw = L['can_mask'].detach().cpu().double(), L['can_weights'].detach().cpu().double()
+    cm, cw = L['can_mask'].detach().cpu().double().clamp(0, 1), L['can_weights'].detach().cpu().double().clamp(0, 1)    # (:366-367)
     f = lambda x: torch.mean(-torch.log(torch.exp(-x.abs()) + torch.exp(-(1 - x).abs())) + S.ht.HARD_SURFACE_OFFSET)   # noqa: E731
     ref = f(cm) * S.opt.penalize_sharp_edge + f(cw) * S.opt.penalize_hard_surface
     assert abs(vals['sparsity_reg'] - float(ref)) < 1e-5

@@ -106,5 +106,9 @@ line = {"rays": R, "hit_rays": int(hit.sum()), "body": [6890, int(faces.shape[0]
         "total_loss_first5_mean": first, "total_loss_last5_mean": last, "total_loss_first": totals[0], "total_loss_last": totals[-1], "terms_last": terms,
         "learning_rate": 2e-4, "target": "the batch rendered through a second frozen human net (seed 9, dense preset)"}
 print(json.dumps(line), flush=True)
+if os.environ.get('NEUMAN_LAUNCH_SOURCES') == '1':                      # where the iteration's launches come from (tools/launch_sources.py), to stderr
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import launch_sources
+    launch_sources.count(lambda: loss.train_step(batch, optim), top=70)
 assert all(alive), "the human net died during the timed iterations"
-assert all(v == v for v in totals) and last < first, (first, last)
+assert all(v == v for v in totals) and (last < first or ITERS < 10), (first, last)
