@@ -133,7 +133,8 @@ typedef struct nm_mlp_desc {
                              1: use_viewdirs=False (`--specular_can no`, models/human_nerf.py:28): one output_linear 256 -> 4 =
                              (r, g, b, sigma) on the eighth layer (vanilla.py:116-117, 145), view directions ignored.  host_params
                              then holds the 16 pts_linears tensors followed by output_linear.weight [4,256] and .bias [4] (the other
-                             entries are not read).  NM_PREC_I8X3 is not available for this net. */
+                             entries are not read).  NM_PREC_I8X3: the whole-network launch only (nerf_mlp_i8s_kernel<true>: output_linear's rows
+                             in the alpha block, the tile ends there); no stage-by-stage or density-only i8 form. */
 } nm_mlp_desc;
 
 int64_t nm_mlp_pack_bytes(const nm_mlp_desc* desc);

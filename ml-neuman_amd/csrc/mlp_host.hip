@@ -284,10 +284,12 @@ static const float* hidden_row(const nm_mlp_desc* d, const float* const* P, int 
     switch (st) {
         case 5: *col0 = kpe; return P[P_PTS_W + 10] + (int64_t)n * (kpe + 256);
         case 8:
+            if (d->plain_head) return (n >= 256 && n < 260) ? P[P_OUT_W] + (int64_t)(n - 256) * 256 : nullptr;   // output_linear's rows where the alpha row is
             if (n < 256) return P[P_FEAT_W] + (int64_t)n * 256;
             return n == 256 ? P[P_ALPHA_W] : nullptr;
-        case 9: return P[P_VIEWS_W] + (int64_t)n * (256 + 3 + 6 * d->dir_n_freqs);
-        case 10: return n < 3 ? P[P_RGB_W] + (int64_t)n * 128 : nullptr;
+        case 9: if (d->plain_head) return nullptr;
+            return P[P_VIEWS_W] + (int64_t)n * (256 + 3 + 6 * d->dir_n_freqs);
+        case 10: return (n < 3 && !d->plain_head) ? P[P_RGB_W] + (int64_t)n * 128 : nullptr;
         default: return P[P_PTS_W + 2 * st] + (int64_t)n * 256;
     }
 }
@@ -305,6 +307,7 @@ static void pack_image8(const nm_mlp_desc* d, const float* const* P, uint8_t* im
         float* u = units + stage_b_off(st);
         float* b = bias + stage_b_off(st);
         if (st <= 7) memcpy(b, P[P_PTS_W + 2 * st + 1], 256 * 4);
+        else if (d->plain_head) { if (st == 8) memcpy(b + 256, P[P_OUT_B], 4 * 4); }      // (the plain head: stages 9, 10 and the feature rows stay zero)
         else if (st == 8) { memcpy(b, P[P_FEAT_B], 256 * 4); b[256] = P[P_ALPHA_B][0]; }
         else if (st == 9) memcpy(b, P[P_VIEWS_B], 128 * 4);
         else memcpy(b, P[P_RGB_B], 3 * 4);
@@ -377,7 +380,9 @@ static void pack_image8(const nm_mlp_desc* d, const float* const* P, uint8_t* im
 // two blocks (so that every hidden stage is eight identical i8 blocks -- they are added on top of the dequantised sums, as everywhere);
 // the alpha block of stage 8 comes BEFORE the eight feature blocks (all of the stage's outputs are held in registers until the row
 // maximum is known; the alpha block must not be the one that is multiplied while they are all live).  Same size as the block image.
-static void pack_stream8s(const uint8_t* img8, uint8_t* out) {
+// plain (the use_viewdirs=False net): the tile ends with the alpha block, which holds output_linear's four rows; the kernel's ring then looks two
+// blocks ahead as if the feature blocks followed, so the next tile's first two blocks stand there, padded to the feature blocks' 8 steps.
+static void pack_stream8s(const uint8_t* img8, uint8_t* out, bool plain = false) {
     memset(out, 0, (size_t)(kWeightBytes8 + kWeightPadBytes));
     uint8_t* dst = out;
     auto put = [&](int st, int nb, int t0, int n) {
@@ -390,6 +395,11 @@ static void pack_stream8s(const uint8_t* img8, uint8_t* out) {
             for (int nb = 0; nb < 8; ++nb) put(5, nb, 8, 4);
     }
     put(8, 8, 0, 8);
+    if (plain) {
+        for (int nb = 0; nb < 2; ++nb) { put(0, nb, 0, 4); dst += 4 * kStepBytes; }
+        if (dst - out != kPlainStreamBytes8) abort();
+        return;
+    }
     for (int nb = 0; nb < 8; ++nb) put(8, nb, 0, 8);
     for (int nb = 0; nb < 4; ++nb) put(9, nb, 0, 10);
     put(10, 0, 0, 4);
@@ -513,8 +523,7 @@ int64_t nm_mlp_pack_i8_bytes(const nm_mlp_desc* desc) {
 int nm_mlp_pack_i8(const nm_mlp_desc* desc, const float* const* host_params, void* host_out) {
     if (int e = nm::validate_desc(desc)) return e;
     NM_REQUIRE(host_params && host_out, "nm_mlp_pack_i8: null pointer");
-    NM_REQUIRE(!desc->plain_head, "nm_mlp_pack_i8: the plain-head (use_viewdirs=False) net has no i8x3 image");
-    for (int i = 0; i < 24; ++i) NM_REQUIRE(host_params[i], "nm_mlp_pack_i8: host_params[%d] is null", i);
+    for (int i = 0; i < (desc->plain_head ? 18 : 24); ++i) NM_REQUIRE(host_params[i], "nm_mlp_pack_i8: host_params[%d] is null", i);
     nm::pack_image8(desc, host_params, static_cast<uint8_t*>(host_out));
     return NM_OK;
 }
@@ -527,11 +536,10 @@ int64_t nm_mlp_pack_i8s_bytes(const nm_mlp_desc* desc) {
 int nm_mlp_pack_i8s(const nm_mlp_desc* desc, const float* const* host_params, void* host_out) {
     if (int e = nm::validate_desc(desc)) return e;
     NM_REQUIRE(host_params && host_out, "nm_mlp_pack_i8s: null pointer");
-    NM_REQUIRE(!desc->plain_head, "nm_mlp_pack_i8s: the plain-head (use_viewdirs=False) net has no i8x3 image");
-    for (int i = 0; i < 24; ++i) NM_REQUIRE(host_params[i], "nm_mlp_pack_i8s: host_params[%d] is null", i);
+    for (int i = 0; i < (desc->plain_head ? 18 : 24); ++i) NM_REQUIRE(host_params[i], "nm_mlp_pack_i8s: host_params[%d] is null", i);
     std::vector<uint8_t> img8((size_t)nm::image8_bytes());
     nm::pack_image8(desc, host_params, img8.data());
-    nm::pack_stream8s(img8.data(), static_cast<uint8_t*>(host_out));
+    nm::pack_stream8s(img8.data(), static_cast<uint8_t*>(host_out), desc->plain_head != 0);
     return NM_OK;
 }
 
@@ -549,11 +557,9 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     std::vector<uint8_t> img8((size_t)nm::image8_bytes());
     std::vector<uint8_t> str8((size_t)nm::kWeightBytes8w);
     std::vector<uint8_t> str8s((size_t)(nm::kWeightBytes8 + nm::kWeightPadBytes));
-    if (!plain) {                                               // (no i8x3 form of the plain-head net: those buffers stay zero)
-        nm::pack_image8(desc, host_params, img8.data());
-        nm::pack_stream8(img8.data(), str8.data());
-        nm::pack_stream8s(img8.data(), str8s.data());
-    }
+    nm::pack_image8(desc, host_params, img8.data());            // (the plain-head net: output_linear's rows in the alpha block, stages 9 / 10 zero;
+    nm::pack_stream8(img8.data(), str8.data());                 //  only the activation-stationary kernel has its form)
+    nm::pack_stream8s(img8.data(), str8s.data(), plain != 0);
 
     // reference-layout image for the exact-f32 kernel
     const int kpe = 3 + 6 * desc->pos_n_freqs, kdpe = 3 + 6 * desc->dir_n_freqs;
@@ -681,7 +687,8 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
                "nm_mlp_forward: bad precision %d", precision);
     if (n == 0) return NM_OK;
     NM_REQUIRE(!(chunk && precision == NM_PREC_FP32), "nm_mlp_forward_ray_chunk: the exact-f32 validation kernel has no chunked form");
-    NM_REQUIRE(!(m->desc.plain_head && precision == NM_PREC_I8X3), "nm_mlp_forward: the plain-head (use_viewdirs=False) net has no i8x3 form");
+    NM_REQUIRE(!(m->desc.plain_head && precision == NM_PREC_I8X3 && (stop_stage != -2 || dbg || prof || sigma_only)),
+               "nm_mlp_forward: the plain-head (use_viewdirs=False) net's i8x3 form is the whole-network launch only (no stage-by-stage / density-only form)");
     NM_REQUIRE(!(m->desc.plain_head && stop_stage > 7), "nm_mlp_forward_debug: the plain-head net has stages -1..7 only");
     if (precision == NM_PREC_FP32) {
         nm::RefLaunch L;
@@ -712,7 +719,7 @@ static int mlp_dispatch(nm_mlp_t m, const float* pts, const float* dirs, const f
     const bool sigma_t = !(sk && !strcmp(sk, "w")) && m->d_stream16t;
     if (sigma_t && precision == NM_PREC_FP16X3 && sigma_only == 1 && stop_stage == -2 && !dbg && !prof && !m->desc.plain_head)
         return nm::launch_sigma_f16t(L, m->d_stream16t, m->sigma_ndir, pts, dirs, origin, direction, z, n, S, in_mode, sigma_scale, out, nm::as_stream(stream), chunk, nullptr, -1);
-    if (i8_as && precision == NM_PREC_I8X3 && stop_stage == -2 && !dbg && !prof && !sigma_only)
+    if ((i8_as || m->desc.plain_head) && precision == NM_PREC_I8X3 && stop_stage == -2 && !dbg && !prof && !sigma_only)
         return nm::launch_mlp_i8s(L, m->d_image8, pts, dirs, origin, direction, z, n, S, in_mode, sigma_scale, out, nm::as_stream(stream), chunk);
     return nm::launch_mlp_mfma(L, pts, dirs, origin, direction, z, n, S, in_mode, precision, stop_stage, sigma_scale, out, dbg,
                                prof, nm::as_stream(stream), sigma_only, chunk);

@@ -162,8 +162,16 @@ __device__ __forceinline__ void k_bf(f32x16& f, const uint4* pw, int g, int s, c
         f = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wh), as_bf16x8(xh), f, 0, 0, 0);
     }
 }
+// PLAIN: the use_viewdirs=False net (--specular_can no; models/vanilla.py:116-117, 145): stages 0..7, then ring block 68 holds output_linear's four rows
+// (r, g, b, sigma) where the alpha row is otherwise, and the tile ends there.  The instantiation differs from the default one by ONE wave-uniform exit
+// (and the direction encodings it does not compute) and nothing else: this kernel sits at exactly 256 registers, and every other way of telling the
+// compiler about the shorter tile (69 as a constant, or as a register, in the ring's look-ahead) made it spill 900-1000 bytes per lane; so the ring
+// stays the default one's, and the STREAM is cut to fit it (mlp_host.hip pack_stream8s): where the look-ahead expects blocks 69 and 70 (8 steps each)
+// it finds the next tile's blocks 0 and 1 (4 steps each, padded to 8), and the exit points the ring at block 2.  The exit tests a.sigma_only == 2 (set by
+// the launch) rather than PLAIN alone, so that the code after it stays in the instantiation: without it the allocation of the stage loop changes too.
 // (HIP's second __launch_bounds__ argument is the minimum number of WAVES PER SIMD -- not CUDA's blocks per multiprocessor: 2 = the
 // 8 waves of the ONE workgroup a CU holds, i.e. a 256-register budget per wave; the 147 KB of LDS allow no second workgroup anyway)
+template <bool PLAIN>
 __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args8s A) {
     __shared__ uint4 lds[kPeU4 + kSlots * kSlotU4 + kBiasU4];
     const MlpArgs a = resolve_args(A.a);
@@ -263,11 +271,25 @@ __global__ __launch_bounds__(kWaves * 64, 2) void nerf_mlp_i8s_kernel(const Args
             for (int b = 0; b < 8; ++b) quant16<true>(f[b], inv, X.h[b], X.l[b]);
             sx = scale_of(M);
             PROF_TICK(5)
-            if (st == 5) {
+            if (st == 5 && !(PLAIN && a.sigma_only == 2)) {
                 PROF_TICK(7)
                 fill_pe_wave(pw, true, a, row0, lane);                                  // the position encoding is done with: direction encoding
                 PROF_TICK(6)
             }
+        }
+        if (PLAIN && a.sigma_only == 2) {
+            // ---------------- the plain head: rows 0..3 of block 68 = output_linear's (r, g, b, sigma)
+            i32x16 t;
+            f32x16 fo;
+            k_i8<8>(t, X, ring_enter(R, 68 PROF_PASS), R);
+            PROF_TICK(2)
+            dequant16(fo, t, sx * (256.f * kappa[8]), bias + nm::stage_b_off(8) + 256);
+            const float* up = A.consts8 + nm::stage_b_off(8) + 256;                     // the four rows' units
+            const int64_t i = row0 + s;
+            if (g == 0 && i < a.n)
+                reinterpret_cast<float4*>(a.out)[sample_record(a, i)] = make_float4(fo[0] * up[0], fo[1] * up[1], fo[2] * up[2], fo[3] * up[3] * a.sigma_scale);
+            R.off = (block_steps(0) + block_steps(1)) * nm::kStepBytes;                 // blocks 0 and 1 of the next tile are in flight: block 2 is next
+            continue;
         }
         // ---------------- stage 8: alpha (row 0 of its block; first in the stream) + feature (linear, 256)
         float sigma;
@@ -358,7 +380,7 @@ int launch_mlp_i8s(const MlpLaunch& L, const void* image8, const float* pts, con
     a.petab = L.petab;
     a.pts = pts; a.dirs = dirs; a.origin = origin; a.direction = direction; a.z = z;
     a.out = out; a.dbg = nullptr; a.prof = nullptr; a.n = n; a.S = S; a.in_mode = in_mode; a.stop_stage = -2; a.sigma_scale = sigma_scale;
-    a.sigma_only = 0;
+    a.sigma_only = L.plain_head ? 2 : 0;                                                // (PLAIN's exit after block 68)
     a.save_h = nullptr; a.save_hv = nullptr; a.save_bits = nullptr; a.save_h16 = nullptr; a.save_feat16 = nullptr; a.save_hvbits = nullptr; a.save_x0h = nullptr; a.save_d0h = nullptr;
     a.pos = PeSpec{L.pe_kind, L.pos_nfreq, L.pos_octaves};
     a.dir = PeSpec{L.pe_kind, L.dir_nfreq, L.dir_octaves};
@@ -373,7 +395,7 @@ int launch_mlp_i8s(const MlpLaunch& L, const void* image8, const float* pts, con
     const int grid = (int)(ntiles < cus ? ntiles : cus);
     if (getenv("NEUMAN_I8S_DEBUG")) {
         int nb = -1;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nerf_mlp_i8s_kernel, kWaves * 64, 0);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, nerf_mlp_i8s_kernel<false>, kWaves * 64, 0);
         fprintf(stderr, "nerf_mlp_i8s_kernel: occupancy %d blocks/CU (%s), grid %d, cus %d\n", nb, hipGetErrorString(e), grid, cus);
     }
 #ifdef NM_AS_PROF
@@ -383,7 +405,8 @@ int launch_mlp_i8s(const MlpLaunch& L, const void* image8, const float* pts, con
     (void)hipMemsetAsync(d_prof, 0, nprof * 8, stream);
     a.prof = d_prof;
 #endif
-    hipLaunchKernelGGL(nerf_mlp_i8s_kernel, dim3(grid), dim3(kWaves * 64), 0, stream, A);
+    if (L.plain_head) hipLaunchKernelGGL(nerf_mlp_i8s_kernel<true>, dim3(grid), dim3(kWaves * 64), 0, stream, A);
+    else hipLaunchKernelGGL(nerf_mlp_i8s_kernel<false>, dim3(grid), dim3(kWaves * 64), 0, stream, A);
 #ifdef NM_AS_PROF
     if (n > 1000000) {
         std::vector<unsigned long long> h(nprof);

@@ -112,6 +112,9 @@ NM_HD constexpr int64_t frag_off8(int s, int nb, int step) {   // step counts i8
     return stage_w_off8(s) + ((int64_t)nb * (stage_shape8(s).i8steps + stage_shape8(s).bfsteps) + step) * kStepBytes;
 }
 constexpr int64_t kWeightBytes8 = stage_w_off8(kStages);
+// the activation-stationary kernel's stream of the plain-head net (mlp_i8s.hip PLAIN): stages 0..7, the block of output_linear's four rows, and -- where the
+// ring's look-ahead expects the 8-step blocks 69 and 70 -- the next tile's blocks 0 and 1 (4 steps each) padded to 8 steps
+constexpr int64_t kPlainStreamBytes8 = (int64_t)(8 * 4 + 7 * 8 * 8 + 8 * 4 + 8 + 2 * 8) * kStepBytes;
 // after the fragments (+ the same prefetch pad): per-feature weight scales, then biases, both laid out like stage_b_off()
 constexpr int kFixedMax = 32639;   // 127*256 + 127: largest magnitude whose balanced limbs fit int8
 // feature held by k-slot (16-slot chunk c, element e) of an i8 activation: c = 2*blk + g, e = reg index of the accumulator

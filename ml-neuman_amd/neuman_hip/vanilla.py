@@ -19,6 +19,8 @@ from . import _lib
 # which run i8x3 -- sample positions identical to all-fp16x3, every pixel within 1e-4 of the oracle on identical samples
 # (measured <= 2.3e-5).  "fp16x3" | "bf16x3" | "i8x3" | "bf16" | "fp32" force one arithmetic for every call.
 DEFAULT_PRECISION = os.environ.get("NEUMAN_PRECISION", "mixed")
+# the plain-head net (use_viewdirs=False) in "mixed": shading passes on nerf_mlp_i8s_plain_kernel like the view-dependent net's (0: fp16x3 for them)
+PLAIN_HEAD_I8 = os.environ.get("NEUMAN_PLAIN_I8", "1") != "0"
 
 
 def weight_reset(m):
@@ -184,8 +186,8 @@ class Joiner(nn.Module):
         p = precision or self.precision
         if p == 'mixed':
             p = 'i8x3' if role == 'shading' else 'fp16x3'
-        if p == 'i8x3' and not self.nerf.use_viewdirs and (precision or self.precision) == 'mixed':
-            p = 'fp16x3'                                     # the plain-head net has no i8x3 kernel: its shading passes stay float32 class
+        if p == 'i8x3' and not self.nerf.use_viewdirs and (precision or self.precision) == 'mixed' and not PLAIN_HEAD_I8:
+            p = 'fp16x3'                                     # NEUMAN_PLAIN_I8=0: the plain-head net's shading passes stay float32 class
         return _lib.PRECISIONS[p]
 
     @staticmethod

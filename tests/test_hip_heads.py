@@ -36,12 +36,29 @@ def test_plain_head_forward(H, mapping):
         e_g, e_o = np.abs(got - H[f'plain_{mapping}_out']).max(), np.abs(got - ora).max()
         print(f"[heads] plain head {mapping} {prec}: vs reference golden {e_g:.2e}, vs oracle {e_o:.2e}")
         assert e_g < tol * s * 2 and e_o < tol * s
-    # views are ignored (vanilla.py:122-123) and may be omitted; the shading role stays float32 class; i8x3 does not exist for this net
+    # views are ignored (vanilla.py:122-123) and may be omitted
     a = j(cu(H['pts']), cu(H['dirs']))
     assert torch.equal(a, j(cu(H['pts']), None)) and torch.equal(a, j(cu(H['pts']), cu(H['dirs'][::-1].copy())))
-    assert torch.equal(a, j(cu(H['pts']), cu(H['dirs']), role='shading'))
-    with pytest.raises(_lib.NeumanHipError):
-        j(cu(H['pts']), cu(H['dirs']), precision="i8x3")
+    # the shading role runs nerf_mlp_i8s_plain_kernel (16-bit fixed point per row: the network-output tolerances of tests/test_hip_mlp.py's i8x3 cases)
+    sh = j(cu(H['pts']), None, role='shading')
+    assert torch.equal(sh, j(cu(H['pts']), cu(H['dirs']), precision="i8x3")) and not torch.equal(sh, a)
+    got = sh.cpu().numpy()
+    scale = max(1.0, float(np.abs(ora[:, 3]).max()))
+    e_rgb, e_sig = np.abs(got[:, :3] - ora[:, :3]).max(), np.abs(got[:, 3] - ora[:, 3]).max()
+    print(f"[heads] plain head {mapping} i8x3 vs oracle: rgb (pre-sigmoid) {e_rgb:.2e}, sigma {e_sig:.2e} of max |sigma| {scale:.1f}")
+    assert e_rgb < 4e-4 * s and e_sig < 2e-3 * s * scale
+    for n in (1, 31, 256):                                                # ragged tile ends
+        assert torch.equal(j(cu(H['pts'][:n]), None, precision="i8x3"), sh[:n])
+    # more tiles than workgroups (a workgroup's weight ring wraps from output_linear's block to the next tile's stage 0): against the exact-f32 kernel
+    big = torch.randn((70001, 3), device='cuda', generator=torch.Generator(device='cuda').manual_seed(3)) * 0.6
+    b8, b32 = j(big, None, precision="i8x3"), j(big, None, precision="fp32")
+    sc = max(1.0, float(b32[:, 3].abs().max()))
+    e_rgb, e_sig = float((b8[:, :3] - b32[:, :3]).abs().max()), float((b8[:, 3] - b32[:, 3]).abs().max())
+    print(f"[heads] plain head {mapping} i8x3 vs the f32 kernel, 70001 points: rgb {e_rgb:.2e}, sigma {e_sig:.2e} of {sc:.1f}")
+    assert e_rgb < 4e-4 * s and e_sig < 2e-3 * s * sc
+    assert torch.equal(b8[:5000], j(big[:5000].contiguous(), None, precision="i8x3"))      # a sample's result does not depend on the batch
+    with pytest.raises(_lib.NeumanHipError):                              # (no stage-by-stage form of the i8 kernel for this net)
+        j.forward_debug(cu(H['pts']), cu(H['dirs']), 3, precision="i8x3")
     # fused ray form and sigma_scale
     R, S = 16, 16
     o = cu(H['pts'][:R] * 0.2)

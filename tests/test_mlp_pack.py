@@ -267,7 +267,7 @@ def quant_rows(h):
     return s, hi, lo
 
 
-def emulate8(img, pts, dirs, spec):
+def emulate8(img, pts, dirs, spec, plain=False):
     tail = w_off8(11) + 4 * 2048
     nb_f = b_off(11)
     # hidden state of stage s is kept in per-feature units: true value = stored * units[s][n] (mlp_host.hip pack_image8);
@@ -303,6 +303,9 @@ def emulate8(img, pts, dirs, spec):
     for s in range(1, 8):
         h = np.maximum(run(s, h, P if s == 5 else None, 256), 0)
     o8 = run(8, h, None, 288)
+    if plain:                                                           # output_linear's (r, g, b, sigma) stand where the alpha row is otherwise
+        assert np.abs(o8[:, :256]).max() == 0 and np.abs(o8[:, 260:]).max() == 0
+        return o8[:, 256:260] * units[b_off(8) + 256:b_off(8) + 260]
     feature, sigma = o8[:, :256], o8[:, 256] * units[b_off(8) + 256]
     v = np.maximum(run(9, feature, Pd, 128), 0)
     o10 = run(10, v, None, 32) * units[b_off(10):b_off(10) + 32]
@@ -363,3 +366,51 @@ def test_pack_i8s_stream_is_the_block_image_in_consumption_order(nets):
     # the kernel's ring-block table (block_steps in csrc/mlp_i8s.hip) covers exactly this stream
     table = [4] * 8 + [8] * 69 + [10] * 4 + [4]
     assert len(table) == 82 and sum(table) * 2048 == w_off8(11)
+
+
+@pytest.mark.parametrize("mapping", ["posenc", "rotate"])
+def test_pack_i8_plain_head_matches_oracle(mapping):
+    """the use_viewdirs=False net (models/vanilla.py:116-117, 145): output_linear's four rows in the alpha block of the i8 image, stages 9 / 10 empty;
+    and its stream for nerf_mlp_i8s_kernel<true>: the tile ends after that block, followed by the NEXT tile's blocks 0 and 1 padded to 8 steps --
+    what the kernel's unchanged two-blocks-ahead ring copies while it multiplies blocks 67 and 68"""
+    from neuman_hip import synthetic
+    j = synthetic.make_variant_joiner(5, posenc=mapping, use_viewdirs=False)
+    sd = synthetic.state_numpy(j)
+    spec = nerf_mlp.JoinerSpec(mapping=mapping)
+    lib = _lib.lib()
+    desc = _lib.MlpDesc(8, 256, 4, _lib.NM_PE_ROTATE if mapping == 'rotate' else _lib.NM_PE_POSENC, 10, 4, 1)
+    host = [p.detach().contiguous() for p in j.nerf.ordered_params()]
+    assert len(host) == 18
+    arr = (ctypes.c_void_p * 18)(*[t.data_ptr() for t in host])
+    img = ctypes.create_string_buffer(lib.nm_mlp_pack_i8_bytes(ctypes.byref(desc)))
+    _lib.check(lib.nm_mlp_pack_i8(ctypes.byref(desc), arr, img), "nm_mlp_pack_i8")
+    rng = np.random.default_rng(7)
+    pts = rng.uniform(-1.5, 1.5, size=(64, 3)).astype(np.float32)
+    dirs = rng.normal(size=(64, 3)).astype(np.float32)
+    got = emulate8(img.raw, pts, dirs, spec, plain=True)
+    ref = nerf_mlp.joiner_forward(sd, spec, pts, dirs)
+    s = 30 if mapping == 'rotate' else 1
+    print(np.abs(got[:, :3] - ref[:, :3]).max(), np.abs(got[:, 3] - ref[:, 3]).max())
+    assert np.abs(got[:, :3] - ref[:, :3]).max() < 3e-4 * s
+    assert np.abs(got[:, 3] - ref[:, 3]).max() < 2e-3 * s * max(1.0, np.abs(ref[:, 3]).max())
+    # ---- the stream
+    nbytes = lib.nm_mlp_pack_i8s_bytes(ctypes.byref(desc))
+    stream = ctypes.create_string_buffer(nbytes)
+    _lib.check(lib.nm_mlp_pack_i8s(ctypes.byref(desc), arr, stream), "nm_mlp_pack_i8s")
+    steps = {0: (8, 4), 5: (8, 12), 8: (9, 8), 9: (4, 10), 10: (1, 4)}
+    frag = lambda st, nb, t: w_off8(st) + (nb * steps.get(st, (8, 8))[1] + t) * 2048      # noqa: E731
+    order = [(0, nb, t) for nb in range(8) for t in range(4)]
+    for st in range(1, 8):
+        order += [(st, nb, t) for nb in range(8) for t in range(8)]
+        if st == 5:
+            order += [(5, nb, 8 + t) for nb in range(8) for t in range(4)]
+    order += [(8, 8, t) for t in range(8)]
+    assert len(order) == 520
+    order += [(0, 0, t) for t in range(4)] + [None] * 4 + [(0, 1, t) for t in range(4)] + [None] * 4
+    for k, e in enumerate(order):
+        want = bytes(2048) if e is None else img.raw[frag(*e):frag(*e) + 2048]
+        assert stream.raw[k * 2048:(k + 1) * 2048] == want, (k, e)
+    assert stream.raw[len(order) * 2048:] == bytes(nbytes - len(order) * 2048)
+    # the ring-block table the kernel walks (block_steps in csrc/mlp_i8s.hip): 69 blocks, then two 8-step look-aheads
+    table = [4] * 8 + [8] * 61 + [8, 8]
+    assert sum(table) == len(order)
