@@ -769,12 +769,45 @@ __global__ __launch_bounds__(256) void warp_apply_forward_kernel(const float* __
     for (int k = 0; k < 3; ++k) can[i * 3 + k] = inv[k * 4] * x + inv[k * 4 + 1] * y + inv[k * 4 + 2] * z + inv[k * 4 + 3];
 }
 
+// Consecutive samples -- neighbours on a ray -- mostly share their closest triangle, and a float atomic to one address is served one lane at a time: the
+// scatter kernels below first add up, inside the wave, the contributions of every RUN of lanes with the same triangle and let the run's first lane issue
+// the atomics (human trainer batch: 5x fewer of them).  Runs(): which lanes d = 1, 2, 4 .. 32 above this one still belong to its run (bit log2(d)), and
+// whether this lane is its run's first; run_sum(): the run's total, valid in the first lane (a suffix sum by doubling that stops at run ends).
+struct Runs {
+    unsigned ok;       // bit j: lane + 2^j is in this lane's run
+    bool head;
+};
+__device__ __forceinline__ Runs find_runs(int k0, int k1, int k2, bool valid) {
+    const int lane = threadIdx.x & 63;
+    const int p0 = __shfl_up(k0, 1, 64), p1 = __shfl_up(k1, 1, 64), p2 = __shfl_up(k2, 1, 64);
+    const bool pvalid = __shfl_up((int)valid, 1, 64) != 0;
+    Runs r;
+    r.head = lane == 0 || !valid || !pvalid || p0 != k0 || p1 != k1 || p2 != k2;          // (a lane past the end is a run of its own, adding zeros)
+    const unsigned long long heads = __ballot(r.head);
+    const unsigned long long above = lane == 63 ? ~0ull : ((heads >> (lane + 1)) | (~0ull << (63 - lane)));   // bit j: lane + 1 + j starts a run (or is past the wave)
+    r.ok = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+        if ((above & ((1ull << (1 << j)) - 1ull)) == 0) r.ok |= 1u << j;
+    return r;
+}
+__device__ __forceinline__ float run_sum(float v, const Runs& r) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const float t = __shfl_down(v, 1 << j, 64);
+        v += ((r.ok >> j) & 1u) ? t : 0.f;
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(256) void warp_apply_backward_kernel(const float* __restrict__ T, const int32_t* __restrict__ tri,
                                                                   const float* __restrict__ bary, const float* __restrict__ pts,
                                                                   const float* __restrict__ g_can, int64_t N, float* __restrict__ g_T,
                                                                   float* __restrict__ g_bary) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    const int64_t i_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i_raw < N;
+    const int64_t i = valid ? i_raw : N - 1;                                             // (past the end: the last sample's arithmetic, nothing stored)
+    const Runs runs = find_runs(tri[i * 3], tri[i * 3 + 1], tri[i * 3 + 2], valid);
     float inv[16];
     blend_inverse(T, tri, bary, i, inv);
     const float h[4] = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], 1.f};
@@ -791,7 +824,7 @@ __global__ __launch_bounds__(256) void warp_apply_backward_kernel(const float* _
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int64_t v = tri[i * 3 + k];
-        const float b = bary[i * 3 + k];
+        const float b = valid ? bary[i * 3 + k] : 0.f;
         const float* Tv = T + v * 16;
         float* gTv = g_T + v * 16;
 #pragma unroll
@@ -800,11 +833,13 @@ __global__ __launch_bounds__(256) void warp_apply_backward_kernel(const float* _
             for (int c = 0; c < 4; ++c) {
                 const float gm = -u[a] * w[c];
                 gb[k] += gm * Tv[a * 4 + c];
-                atomicAdd(gTv + a * 4 + c, b * gm);
+                const float total = run_sum(b * gm, runs);
+                if (runs.head && valid) atomicAdd(gTv + a * 4 + c, total);
             }
     }
+    if (valid)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) g_bary[i * 3 + k] = gb[k];
+        for (int k = 0; k < 3; ++k) g_bary[i * 3 + k] = gb[k];
 }
 
 // ---- barycentric coordinates of the closest point in its triangle, the reference's lines (utils/ray_utils.py:72-84) in float32, forward and adjoint.
@@ -827,14 +862,16 @@ __global__ __launch_bounds__(256) void bary_forward_kernel(const float* __restri
 }
 __global__ __launch_bounds__(256) void bary_backward_kernel(const float* __restrict__ verts, const int32_t* __restrict__ tri, const float* __restrict__ closest,
                                                             const float* __restrict__ g_bary, int64_t N, float* __restrict__ g_verts) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    const int64_t i_raw = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i_raw < N;
+    const int64_t i = valid ? i_raw : N - 1;
     const int64_t ia = tri[i * 3], ib = tri[i * 3 + 1], ic = tri[i * 3 + 2];
+    const Runs runs = find_runs((int)ia, (int)ib, (int)ic, valid);
     const V3 A = ld3(verts + ia * 3), B = ld3(verts + ib * 3), C = ld3(verts + ic * 3), P = ld3(closest + i * 3);
     const V3 e01 = sub3(B, A), e02 = sub3(C, A), e12 = sub3(C, B), e20 = sub3(A, C), p1 = sub3(P, B), p2 = sub3(P, C);
     const V3 Nn = crs3(e01, e02), a = crs3(e12, p1), b = crs3(e20, p2);
     const float den = dot3(Nn, Nn), u = dot3(Nn, a) / den, v = dot3(Nn, b) / den;
-    const float gw = g_bary[i * 3 + 2], gu = g_bary[i * 3] - gw, gv = g_bary[i * 3 + 1] - gw;
+    const float gw = valid ? g_bary[i * 3 + 2] : 0.f, gu = (valid ? g_bary[i * 3] : 0.f) - gw, gv = (valid ? g_bary[i * 3 + 1] : 0.f) - gw;
     const float k = 2.f * (gu * u + gv * v) / den;
     const V3 gN = {(gu * a.x + gv * b.x) / den - k * Nn.x, (gu * a.y + gv * b.y) / den - k * Nn.y, (gu * a.z + gv * b.z) / den - k * Nn.z};
     const V3 ga = {gu * Nn.x / den, gu * Nn.y / den, gu * Nn.z / den}, gb = {gv * Nn.x / den, gv * Nn.y / den, gv * Nn.z / den};
@@ -843,9 +880,13 @@ __global__ __launch_bounds__(256) void bary_backward_kernel(const float* __restr
     const V3 gA = {-g01.x - g02.x + g20.x, -g01.y - g02.y + g20.y, -g01.z - g02.z + g20.z};
     const V3 gB = {g01.x - g12.x - gp1.x, g01.y - g12.y - gp1.y, g01.z - g12.z - gp1.z};
     const V3 gC = {g02.x + g12.x - g20.x - gp2.x, g02.y + g12.y - g20.y - gp2.y, g02.z + g12.z - g20.z - gp2.z};
-    atomicAdd(g_verts + ia * 3, gA.x); atomicAdd(g_verts + ia * 3 + 1, gA.y); atomicAdd(g_verts + ia * 3 + 2, gA.z);
-    atomicAdd(g_verts + ib * 3, gB.x); atomicAdd(g_verts + ib * 3 + 1, gB.y); atomicAdd(g_verts + ib * 3 + 2, gB.z);
-    atomicAdd(g_verts + ic * 3, gC.x); atomicAdd(g_verts + ic * 3 + 1, gC.y); atomicAdd(g_verts + ic * 3 + 2, gC.z);
+    const float vals[9] = {gA.x, gA.y, gA.z, gB.x, gB.y, gB.z, gC.x, gC.y, gC.z};
+    const int64_t at[3] = {ia, ib, ic};
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const float total = run_sum(vals[q], runs);                                   // (the triangle's samples of this wave: one atomic per run)
+        if (runs.head && valid) atomicAdd(g_verts + at[q / 3] * 3 + q % 3, total);
+    }
 }
 
 }  // namespace

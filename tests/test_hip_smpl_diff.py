@@ -60,8 +60,11 @@ def test_run_to_run_bit_identical_and_no_leftover_state(body):
         assert torch.equal(x, y)
 
 
-def test_fused_warp_apply_equals_the_reference_shaped_lines(body):
-    """ray_utils.warp_points_to_canonical_diff (one kernel each way for blend + inverse + product) against
+@pytest.mark.parametrize("runs", [False, True])
+def test_fused_warp_apply_equals_the_reference_shaped_lines(body, runs):
+    """(runs: consecutive points near one vertex, as neighbouring samples of a ray are -- the backward kernels add up a wave's runs of equal triangles
+    before their atomics -- and a ragged count)
+    ray_utils.warp_points_to_canonical_diff (one kernel each way for blend + inverse + product) against
     warp_samples_to_canonical_diff followed by the batched product, both under autograd: canonical points and the gradients to the
     vertex transforms and the posed vertices"""
     from neuman_hip import ray_utils
@@ -79,9 +82,13 @@ def test_fused_warp_apply_equals_the_reference_shaped_lines(body):
             g.manual_seed(9)
         else:
             g.manual_seed(9)
-        pts = (verts.detach()[torch.randint(0, verts.shape[0], (20000,), device='cuda', generator=g)]
-               + 0.03 * torch.randn((20000, 3), device='cuda', generator=g)).contiguous()
-        gc = torch.randn((20000, 3), device='cuda', generator=g)
+        n = 20001 if runs else 20000
+        at = torch.randint(0, verts.shape[0], (n,), device='cuda', generator=g)
+        if runs:                                                                     # runs of 1..12 points around one vertex
+            at = torch.repeat_interleave(at[:n // 4], torch.randint(1, 13, (n // 4,), device='cuda', generator=g))[:n]
+            assert at.shape[0] == n
+        pts = (verts.detach()[at] + (0.004 if runs else 0.03) * torch.randn((n, 3), device='cuda', generator=g)).contiguous()
+        gc = torch.randn((n, 3), device='cuda', generator=g)
         if name == "fused":
             can, _, _ = ray_utils.warp_points_to_canonical_diff(pts, verts, faces, T)
         else:
@@ -95,14 +102,19 @@ def test_fused_warp_apply_equals_the_reference_shaped_lines(body):
         assert e < (2e-5 if what == "can_pts" else 5e-4), (what, e)
 
 
-def test_barycentric_kernels_equal_the_reference_lines():
+@pytest.mark.parametrize("runs", [False, True])
+def test_barycentric_kernels_equal_the_reference_lines(runs):
     """nm_bary_forward / nm_bary_backward against the reference's cross / dot / divide lines (utils/ray_utils.py:72-84) in float64 under
     torch autograd: coordinates and the gradient that reaches the vertices"""
     from neuman_hip import ray_utils
     g = torch.Generator(device='cuda').manual_seed(4)
-    V, N = 500, 30000
+    V, N = 500, (30001 if runs else 30000)
     verts = torch.randn((V, 3), device='cuda', generator=g)
-    tri = torch.stack([torch.randperm(V, device='cuda', generator=g)[:3] for _ in range(64)])[torch.randint(0, 64, (N,), device='cuda', generator=g)].to(torch.int32).contiguous()
+    pick = torch.randint(0, 64, (N,), device='cuda', generator=g)
+    if runs:                                                                         # runs of 1..100 samples of one triangle (longer than a wave too), ragged count
+        pick = torch.repeat_interleave(pick[:N // 8], torch.randint(1, 101, (N // 8,), device='cuda', generator=g))[:N]
+        assert pick.shape[0] == N
+    tri = torch.stack([torch.randperm(V, device='cuda', generator=g)[:3] for _ in range(64)])[pick].to(torch.int32).contiguous()
     wts = torch.rand((N, 3), device='cuda', generator=g)
     wts = wts / wts.sum(1, keepdim=True)
     closest = (verts[tri.long()] * wts[..., None]).sum(1).contiguous()            # points inside their triangles
