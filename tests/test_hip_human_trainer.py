@@ -76,8 +76,14 @@ def setup():
     return types.SimpleNamespace(net=net, batch=batch, loss=loss, opt=opt, ht=human_trainer)
 
 
-def test_seven_terms_and_their_gradients(setup):
+@pytest.mark.parametrize("fused", [True, False])
+def test_seven_terms_and_their_gradients(setup, fused, monkeypatch):
+    """(fused: the five regularisers as csrc/loss.hip's value-and-gradient kernels; False: NEUMAN_FUSED_LOSS=0's torch spelling of the same terms)"""
+    from neuman_hip import loss_ops
+    monkeypatch.setattr(loss_ops, 'FUSED', fused)
     S = setup
+    for p in list(S.net.parameters()):
+        p.grad = None
     torch.manual_seed(11)
     ld = S.loss.loss_func(S.batch)
     assert list(ld.keys()) == S.ht.LOSS_NAMES
