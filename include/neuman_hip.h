@@ -208,6 +208,8 @@ int nm_mlp_backward_chain(nm_mlp_t mlp, const float* const* dev_params, const fl
  *     with the tile's d_hv and d_feat kept on chip.  amax >= max |d_raw| (the scale has 2^13 of headroom for growth through the layers).  Outputs as
  *     above plus dhv16 [n][128] (fp16 of s x d_hv, k-slot order of a 128-wide row: the views layer's weight-gradient operand), dhv32 (nullable) [n][128]
  *     float32 natural order (for the view-direction gradient); bias_grads [9][256]: rows 0..7 = layers 7..0, row 8 = feature_linear's.
+ *     d_feat_add (nullable) [n][256] float32: a gradient that reaches feature_linear's output from elsewhere -- a second evaluation of the views head on the
+ *     same features with other view directions (human_nerf_trainer.py:280-290 asks the net about the SAME points twice) -- added to the kernel's d_feat.
  *   Workspace of nm_mlp_backward_chain_workspace_floats(n) floats each.  The consumers: nm_wgrad16, nm_wgrad_alpha16 below (section "training"). */
 int nm_mlp_forward_save16(nm_mlp_t mlp, const float* pts, const float* dirs, int64_t n, uint16_t* save_h16, float* save_feat, uint16_t* save_feat16,
                           float* save_hv, uint32_t* save_bits, uint32_t* save_hvbits, uint16_t* save_x0h, uint16_t* save_d0h, float* out,
@@ -222,8 +224,8 @@ int nm_mlp_backward_chain16(nm_mlp_t mlp, const float* const* dev_params, const 
 int nm_mlp_backward_plain16(nm_mlp_t mlp, const float* const* dev_params, const float* d_out, const uint32_t* relu_bits, int64_t n, const float* amax,
                             uint16_t* dz16, float* dz32_layer5, float* dz32_layer0, float* bias_grads, float* workspace, int64_t workspace_floats,
                             nm_stream_t stream);
-int nm_mlp_backward_net16(nm_mlp_t mlp, const float* const* dev_params, const float* d_raw, const uint32_t* relu_bits, const uint32_t* hv_bits,
-                          int64_t n, const float* amax, uint16_t* dz16, uint16_t* dfeat16, uint16_t* dhv16, float* dz32_layer5, float* dz32_layer0,
+int nm_mlp_backward_net16(nm_mlp_t mlp, const float* const* dev_params, const float* d_raw, const float* d_feat_add, const uint32_t* relu_bits,
+                          const uint32_t* hv_bits, int64_t n, const float* amax, uint16_t* dz16, uint16_t* dfeat16, uint16_t* dhv16, float* dz32_layer5, float* dz32_layer0,
                           float* dhv32, float* bias_grads, float* workspace, int64_t workspace_floats, nm_stream_t stream);
 /* Same with ray_to_samples' point construction fused: sample (r,s) is at origin[r] + direction[r]*z[r,s]
  * with view direction direction[r] (ray_utils.py:131-132); out [R,S,4]. */
@@ -290,6 +292,10 @@ int nm_mlp_forward_profile(nm_mlp_t mlp, const float* pts, const float* dirs, in
  *   handle; F <= 2^24.  NM_SEARCH_ALL makes the query loop over every triangle instead (diagnostics and
  *   tests: both modes return bit-identical results, ties between equidistant triangles going to the lowest
  *   face id).  The call synchronises the stream once (non-finite vertices are an error).
+ *   nm_mesh_update: the SAME topology with moved vertices (verts [V,3], device) -- what a training iteration has (the posed SMPL mesh of
+ *   human_nerf_trainer.py:262-271 after every optimiser step): the tree, and on the next nm_signed_distance the normals, are rebuilt into the handle's
+ *   buffers; no allocation, no read-back, no synchronisation (a non-finite vertex is NOT reported here: the queries then fall back to the
+ *   all-triangles loop point by point).
  *   nm_warp_to_canonical: pts [R,S,3] f32, T [*,16] f64 -> can_pts, can_dirs [R,S,3] f32,
  *   closest [R,S,3] f32 (optional).
  * ------------------------------------------------------------------------------------------- */
@@ -299,6 +305,7 @@ int nm_mlp_forward_profile(nm_mlp_t mlp, const float* pts, const float* dirs, in
 typedef struct nm_mesh_s* nm_mesh_t;
 int nm_mesh_create(const float* verts, int V, const int32_t* faces, int F, int search, nm_mesh_t* out,
                    nm_stream_t stream);
+int nm_mesh_update(nm_mesh_t mesh, const float* verts, nm_stream_t stream);
 int nm_mesh_destroy(nm_mesh_t mesh);
 /* tree levels, node count and device bytes of a built mesh (diagnostics) */
 int nm_mesh_info(nm_mesh_t mesh, int32_t* levels, int64_t* nodes, int64_t* bytes);

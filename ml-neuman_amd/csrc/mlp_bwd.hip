@@ -28,7 +28,7 @@ constexpr int kBwdPadBytes = 4 * nm::kStepBytes;                   // the weight
 struct BwdArgs {
     const uint4* wpack;        // [8][8 blocks][16 steps] fragments, split bf16: slot 0 = feature_linear's W^T, slot 1 + j = layer 7 - j's W^T (hidden columns)
     const float* dz_top;       // [n][256] gradient of layer 7's pre-activation (masked by H7 > 0 already); HEAD: unused
-    const float* d_feat;       // HEAD: [n][256] gradient of feature_linear's output, d_raw [n][4] (column 3 = d sigma), w_alpha [256]:
+    const float* d_feat;       // HEAD: [n][256] gradient of feature_linear's output (MODE 2: nullable, ADDED to the one the kernel forms), d_raw [n][4] (column 3 = d sigma), w_alpha [256]:
     const float* d_raw;        //   the first stage forms dZ_7 = (d_feat W_f + d sigma w_alpha) * (H_7 > 0) itself
     const float* w_alpha;
     const float* acts;         // [9][n][256] saved post-activation outputs of layers 0..7 (+ feature): stage j masks with acts[6 - j]
@@ -110,12 +110,19 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                 lds[H_BASE + c * kChunkU4 + kLoU4 + row] = lo;
             }
             __syncthreads();
-            // ---- views-back stage: d_feat [32 w .. 32 w + 31][128 samples] = W_views[:, :256]^T block x d_hv (K = 128)
+            // ---- views-back stage: d_feat [32 w .. 32 w + 31][128 samples] = W_views[:, :256]^T block x d_hv (K = 128), on top of a.d_feat when given:
+            // what a second evaluation of the views head on the same features (train.py's second view) sends back to them
             f32x16 acc[4];
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+            for (int mb = 0; mb < 4; ++mb) {
+                const int64_t row = base + 32 * mb + s;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+                for (int q = 0; q < 4; ++q) {
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (a.d_feat && row < a.n) t = *reinterpret_cast<const float4*>(a.d_feat + row * 256 + 32 * w + 4 * g + 8 * q);
+                    acc[mb][4 * q] = t.x; acc[mb][4 * q + 1] = t.y; acc[mb][4 * q + 2] = t.z; acc[mb][4 * q + 3] = t.w;
+                }
+            }
             k_run<4, PREC>(acc, W, wsrc, voff, vo, wo(0, w), lds + H_BASE + g * kChunkU4 + s, 8);
             float cs[16];
 #pragma unroll

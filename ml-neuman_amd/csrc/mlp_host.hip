@@ -830,8 +830,8 @@ int nm_mlp_backward_chain16(nm_mlp_t m, const float* const* dev_params, const fl
                               nm::as_stream(stream), &h);
 }
 
-int nm_mlp_backward_net16(nm_mlp_t m, const float* const* dev_params, const float* d_raw, const uint32_t* relu_bits, const uint32_t* hv_bits, int64_t n,
-                          const float* amax, uint16_t* dz16, uint16_t* dfeat16, uint16_t* dhv16, float* dz32_layer5, float* dz32_layer0, float* dhv32,
+int nm_mlp_backward_net16(nm_mlp_t m, const float* const* dev_params, const float* d_raw, const float* d_feat_add, const uint32_t* relu_bits,
+                          const uint32_t* hv_bits, int64_t n, const float* amax, uint16_t* dz16, uint16_t* dfeat16, uint16_t* dhv16, float* dz32_layer5, float* dz32_layer0, float* dhv32,
                           float* bias_grads, float* workspace, int64_t workspace_floats, nm_stream_t stream) {
     NM_REQUIRE(m && dev_params, "nm_mlp_backward_net16: null pointer");
     NM_REQUIRE(n >= 0, "nm_mlp_backward_net16: negative n");
@@ -840,8 +840,8 @@ int nm_mlp_backward_net16(nm_mlp_t m, const float* const* dev_params, const floa
     NM_REQUIRE(!m->desc.plain_head, "nm_mlp_backward_net16: the plain-head net has no views layer");
     NM_REQUIRE(workspace_floats >= nm_mlp_backward_chain_workspace_floats(n), "nm_mlp_backward_net16: workspace of %lld floats, %lld needed",
                (long long)workspace_floats, (long long)nm_mlp_backward_chain_workspace_floats(n));
-    NM_REQUIRE(((reinterpret_cast<uintptr_t>(d_raw) | reinterpret_cast<uintptr_t>(dz16) | reinterpret_cast<uintptr_t>(dfeat16) | reinterpret_cast<uintptr_t>(dhv16) |
-                 reinterpret_cast<uintptr_t>(dz32_layer5) | reinterpret_cast<uintptr_t>(dz32_layer0) | reinterpret_cast<uintptr_t>(dhv32) |
+    NM_REQUIRE(((reinterpret_cast<uintptr_t>(d_raw) | reinterpret_cast<uintptr_t>(d_feat_add) | reinterpret_cast<uintptr_t>(dz16) | reinterpret_cast<uintptr_t>(dfeat16) |
+                 reinterpret_cast<uintptr_t>(dhv16) | reinterpret_cast<uintptr_t>(dz32_layer5) | reinterpret_cast<uintptr_t>(dz32_layer0) | reinterpret_cast<uintptr_t>(dhv32) |
                  reinterpret_cast<uintptr_t>(workspace)) & 15) == 0, "nm_mlp_backward_net16: buffers must be 16-byte aligned");
     nm::DevParams P;
     for (int i = 0; i < 24; ++i) {
@@ -856,7 +856,7 @@ int nm_mlp_backward_net16(nm_mlp_t m, const float* const* dev_params, const floa
     for (int i = 0; i < 8; ++i) h.dz32[i] = nullptr;
     h.dz32[5] = dz32_layer5; h.dz32[0] = dz32_layer0;
     h.hvbits = hv_bits; h.dhv16 = dhv16; h.dhv32 = dhv32; h.kdir = 3 + 6 * m->desc.dir_n_freqs;
-    return nm::launch_mlp_bwd(P, 3 + 6 * m->desc.pos_n_freqs, m->d_bwd_image, nullptr, nullptr, d_raw, nullptr, relu_bits, n, nullptr, workspace, bias_grads,
+    return nm::launch_mlp_bwd(P, 3 + 6 * m->desc.pos_n_freqs, m->d_bwd_image, nullptr, d_feat_add, d_raw, nullptr, relu_bits, n, nullptr, workspace, bias_grads,
                               nm::as_stream(stream), &h);
 }
 

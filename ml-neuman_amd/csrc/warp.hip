@@ -47,7 +47,8 @@ struct Tree {
     int L;                       // levels of nodes; level L = triangles
     int first_lp;                // first node of level L-1 (the "leaf parents", whose children are triangles)
     int F;
-    float scale;                 // largest |coordinate| of the mesh: sizes the absolute part of the pruning margin
+    const float* scale;          // DEVICE: largest |coordinate| of the mesh (bbox_kernel's out[7]): sizes the absolute part of the pruning margin.  On the
+                                 // device so that nm_mesh_update can rebuild the tree for moved vertices without a read-back
 };
 // Nodes are stored in heap order -- level l starts at (4^l - 1) / 3, the children of node g are 4g+1 .. 4g+4 -- so a
 // stack entry is one integer and a descent needs no per-level table.  Slots of a level beyond its last node are never
@@ -58,7 +59,7 @@ constexpr int kPending = 8;              // a lane keeps walking until it holds 
 constexpr int kTriSlots = kPending + 3;  // one more expansion can add four
 
 // ---- build ---------------------------------------------------------------------------------------------------------
-// vertex AABB + a non-finite flag: out[0..2] = lo, out[3..5] = hi, out[6] = 1 if any coordinate is NaN/Inf
+// vertex AABB + a non-finite flag: out[0..2] = lo, out[3..5] = hi, out[6] = 1 if any coordinate is NaN/Inf, out[7] = the largest |lo| / |hi|
 __global__ __launch_bounds__(1024) void bbox_kernel(const float* __restrict__ verts, int V, float* __restrict__ out) {
     __shared__ float red[16][7];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, bad = 0.f;
@@ -90,6 +91,13 @@ __global__ __launch_bounds__(1024) void bbox_kernel(const float* __restrict__ ve
         float r = red[0][k];
         for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = k < 3 ? fminf(r, red[i][k]) : fmaxf(r, red[i][k]);
         out[k] = r;
+        red[0][k] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float sc = 0.f;
+        for (int k = 0; k < 6; ++k) sc = fmaxf(sc, fabsf(red[0][k]));
+        out[7] = sc;
     }
 }
 
@@ -371,6 +379,7 @@ __global__ __launch_bounds__(64) void search_kernel(Tree tr, int search_all_mode
     int64_t i = 0;
     V3 p = {0.f, 0.f, 0.f};
     float slack = 0.f;
+    const float mesh_scale = *tr.scale;
     Best b;
     b.d2 = INFINITY; b.sd = INFINITY; b.thr2 = FLT_MAX; b.f = 0x7fffffff; b.q = p;
     bool has_cur = false;
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(64) void search_kernel(Tree tr, int search_all_mode
                 i = next + rank;
                 p = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]};
                 const float pmax = fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z)));
-                slack = 1e-5f * (1.f + fmaxf(pmax, tr.scale));
+                slack = 1e-5f * (1.f + fmaxf(pmax, mesh_scale));
                 b.d2 = INFINITY; b.sd = INFINITY; b.thr2 = FLT_MAX; b.f = 0x7fffffff; b.q = p;
                 has_cur = pmax <= FLT_MAX && !search_all_mode;                   // NaN / Inf, all-triangles mode: straight to the loop
                 ck = 0.f; cid = 0; nsp = 0; ntri = 0;                            // the root
@@ -715,6 +724,11 @@ struct nm_mesh_s {
     Node* d_nodes;
     float* d_pn;         // pseudonormals [F][21], built by the first nm_signed_distance
     void* d_pn_scratch;  // face / vertex normals and the vertex -> faces table of that build (freed with the handle: no sync on the way)
+    bool pn_stale;       // nm_mesh_update moved the vertices: the normals (not the vertex -> faces table) are rebuilt by the next nm_signed_distance
+    TriRec* d_tmp;       // the build's scratch, kept for nm_mesh_update: unsorted records, sort keys,
+    unsigned long long* d_keys;
+    float* d_bbox;       //   and the vertex box [8] (Tree::scale points at its last entry)
+    int n_level[kMaxLevels + 1];
 };
 
 // =====================================================================================================================================
@@ -911,8 +925,26 @@ int nm_bary_backward(const float* verts, const int32_t* tri, const float* closes
     return nm::check_launch("bary_backward_kernel");
 }
 
+// the tree of m->d_verts / m->d_faces into the handle's buffers: five kernels, nothing read back
+static int build_tree(nm_mesh_s* m, hipStream_t st) {
+    const Tree& tr = m->tr;
+    const int F = m->F;
+    hipLaunchKernelGGL(bbox_kernel, dim3(1), dim3(1024), 0, st, m->d_verts, m->V, m->d_bbox);
+    hipLaunchKernelGGL(tri_prep_kernel, dim3((F + 255) / 256), dim3(256), 0, st, m->d_verts, m->d_faces, F, m->d_bbox, m->d_tmp, m->d_keys);
+    hipLaunchKernelGGL(rank_scatter_kernel, dim3((F + 255) / 256), dim3(256), 0, st, m->d_keys, F, m->d_tmp, m->d_rec, m->d_face);
+    hipLaunchKernelGGL(leaf_nodes_kernel, dim3((m->n_level[tr.L - 1] + 255) / 256), dim3(256), 0, st, m->d_verts, m->d_faces, m->d_face, F,
+                       m->n_level[tr.L - 1], m->d_nodes + tr.first_lp);
+    for (int l = tr.L - 2; l >= 0; --l)
+        hipLaunchKernelGGL(upper_nodes_kernel, dim3((m->n_level[l] + 255) / 256), dim3(256), 0, st, m->d_nodes + level_base(l + 1),
+                           m->n_level[l + 1], m->n_level[l], m->d_nodes + level_base(l));
+    return nm::check_launch("mesh build kernels");
+}
+
 int nm_mesh_destroy(nm_mesh_t m) {
     if (!m) return NM_OK;
+    if (m->d_tmp) (void)hipFree(m->d_tmp);
+    if (m->d_keys) (void)hipFree(m->d_keys);
+    if (m->d_bbox) (void)hipFree(m->d_bbox);
     if (m->d_verts) (void)hipFree(m->d_verts);
     if (m->d_faces) (void)hipFree(m->d_faces);
     if (m->d_rec) (void)hipFree(m->d_rec);
@@ -938,15 +970,12 @@ int nm_mesh_create(const float* verts, int V, const int32_t* faces, int F, int s
     tr.F = F;
     tr.L = 1;
     while ((1ll << (2 * tr.L)) < F) ++tr.L;                          // 4^L >= F
-    int n_level[kMaxLevels + 1];
+    int* n_level = m->n_level;
     n_level[tr.L] = F;
     for (int l = tr.L - 1; l >= 0; --l) n_level[l] = (n_level[l + 1] + 3) / 4;
     tr.first_lp = level_base(tr.L - 1);
     const int total = tr.first_lp + n_level[tr.L - 1];               // heap order: the last level is stored up to its last node
     m->n_nodes = total;
-    TriRec* d_tmp = nullptr;
-    unsigned long long* d_keys = nullptr;
-    float* d_bbox = nullptr;
     int rc = NM_OK;
 #define NM_TRY(expr, what) if (!rc) rc = nm::check_hip((expr), what)
     NM_TRY(hipMalloc(&m->d_verts, (size_t)V * 12), "nm_mesh_create: hipMalloc(verts)");
@@ -954,36 +983,30 @@ int nm_mesh_create(const float* verts, int V, const int32_t* faces, int F, int s
     NM_TRY(hipMalloc(&m->d_rec, (size_t)F * sizeof(TriRec)), "nm_mesh_create: hipMalloc(records)");
     NM_TRY(hipMalloc(&m->d_face, (size_t)F * 4), "nm_mesh_create: hipMalloc(face ids)");
     NM_TRY(hipMalloc(&m->d_nodes, (size_t)total * sizeof(Node)), "nm_mesh_create: hipMalloc(nodes)");
-    NM_TRY(hipMalloc(&d_tmp, (size_t)F * sizeof(TriRec)), "nm_mesh_create: hipMalloc(unsorted records)");
-    NM_TRY(hipMalloc(&d_keys, (size_t)F * 8), "nm_mesh_create: hipMalloc(keys)");
-    NM_TRY(hipMalloc(&d_bbox, 8 * 4), "nm_mesh_create: hipMalloc(bbox)");
+    NM_TRY(hipMalloc(&m->d_tmp, (size_t)F * sizeof(TriRec)), "nm_mesh_create: hipMalloc(unsorted records)");
+    NM_TRY(hipMalloc(&m->d_keys, (size_t)F * 8), "nm_mesh_create: hipMalloc(keys)");
+    NM_TRY(hipMalloc(&m->d_bbox, 8 * 4), "nm_mesh_create: hipMalloc(bbox)");
+    tr.scale = m->d_bbox + 7;
     NM_TRY(hipMemcpyAsync(m->d_verts, verts, (size_t)V * 12, hipMemcpyDeviceToDevice, st), "nm_mesh_create: copy verts");
     NM_TRY(hipMemcpyAsync(m->d_faces, faces, (size_t)F * 12, hipMemcpyDeviceToDevice, st), "nm_mesh_create: copy faces");
     float hb[7] = {0, 0, 0, 0, 0, 0, 0};
-    if (!rc) {
-        hipLaunchKernelGGL(bbox_kernel, dim3(1), dim3(1024), 0, st, m->d_verts, V, d_bbox);
-        hipLaunchKernelGGL(tri_prep_kernel, dim3((F + 255) / 256), dim3(256), 0, st, m->d_verts, m->d_faces, F, d_bbox, d_tmp, d_keys);
-        hipLaunchKernelGGL(rank_scatter_kernel, dim3((F + 255) / 256), dim3(256), 0, st, d_keys, F, d_tmp, m->d_rec, m->d_face);
-        hipLaunchKernelGGL(leaf_nodes_kernel, dim3((n_level[tr.L - 1] + 255) / 256), dim3(256), 0, st, m->d_verts, m->d_faces, m->d_face, F,
-                           n_level[tr.L - 1], m->d_nodes + tr.first_lp);
-        for (int l = tr.L - 2; l >= 0; --l)
-            hipLaunchKernelGGL(upper_nodes_kernel, dim3((n_level[l] + 255) / 256), dim3(256), 0, st, m->d_nodes + level_base(l + 1),
-                               n_level[l + 1], n_level[l], m->d_nodes + level_base(l));
-        rc = nm::check_launch("nm_mesh_create: build kernels");
-    }
-    // one read-back: the vertex box sizes the pruning margin and carries the non-finite flag (also orders the frees below)
-    NM_TRY(hipMemcpyAsync(hb, d_bbox, 7 * 4, hipMemcpyDeviceToHost, st), "nm_mesh_create: read bbox");
+    if (!rc) rc = build_tree(m, st);
+    // one read-back, at creation only: the non-finite flag of the vertex box (a mesh with a NaN / Inf vertex is refused)
+    NM_TRY(hipMemcpyAsync(hb, m->d_bbox, 7 * 4, hipMemcpyDeviceToHost, st), "nm_mesh_create: read bbox");
     NM_TRY(hipStreamSynchronize(st), "nm_mesh_create: sync");
 #undef NM_TRY
-    if (d_tmp) (void)hipFree(d_tmp);
-    if (d_keys) (void)hipFree(d_keys);
-    if (d_bbox) (void)hipFree(d_bbox);
     if (!rc && hb[6] != 0.f) { nm::set_error("nm_mesh_create: non-finite vertex coordinate"); rc = NM_ERR_ARG; }
     if (rc) { nm_mesh_destroy(m); return rc; }
-    tr.scale = 0.f;
-    for (int k = 0; k < 6; ++k) tr.scale = fmaxf(tr.scale, fabsf(hb[k]));
     *out = m;
     return NM_OK;
+}
+
+int nm_mesh_update(nm_mesh_t m, const float* verts, nm_stream_t stream) {
+    NM_REQUIRE(m && verts, "nm_mesh_update: null pointer");
+    hipStream_t st = nm::as_stream(stream);
+    if (int rc = nm::check_hip(hipMemcpyAsync(m->d_verts, verts, (size_t)m->V * 12, hipMemcpyDeviceToDevice, st), "nm_mesh_update: copy verts")) return rc;
+    m->pn_stale = true;
+    return build_tree(m, st);
 }
 
 int nm_mesh_info(nm_mesh_t m, int32_t* levels, int64_t* nodes, int64_t* bytes) {
@@ -1055,6 +1078,18 @@ int nm_signed_distance(nm_mesh_t m, const float* pts, int64_t N, float* sdist, i
             m->d_pn = nullptr; m->d_pn_scratch = nullptr;
             return rc;
         }
+        m->pn_stale = false;
+    } else if (m->pn_stale) {                                            // nm_mesh_update moved the vertices: the normals again, on the table of the first build
+        const int F = m->F, V = m->V;
+        float* fn = reinterpret_cast<float*>(m->d_pn_scratch);
+        float* vn = fn + (size_t)F * 3;
+        int* cnt = reinterpret_cast<int*>(vn + (size_t)V * 3);
+        int *off = cnt + 2 * V, *adj = off + V + 1;
+        hipLaunchKernelGGL(face_normal_kernel, dim3((F + 255) / 256), dim3(256), 0, st, m->d_verts, m->d_faces, F, fn);
+        hipLaunchKernelGGL(vertex_normal_adj_kernel, dim3((V + 255) / 256), dim3(256), 0, st, m->d_verts, m->d_faces, V, off, adj, fn, vn);
+        hipLaunchKernelGGL(pseudonormal_pack_adj_kernel, dim3((3 * F + 255) / 256), dim3(256), 0, st, m->d_faces, F, V, off, adj, fn, vn, m->d_pn);
+        if (int rc = nm::check_launch("pseudonormal kernels (update)")) return rc;
+        m->pn_stale = false;
     }
     const bool small = m->n_nodes <= 65536 && m->F <= 65536 && !m->force_wide;
     const int chunk = chunk_for(N);

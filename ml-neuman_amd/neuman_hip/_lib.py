@@ -60,7 +60,7 @@ SIGNATURES = {
     "nm_mlp_forward_save16": (i32, [ctypes.c_void_p, c_f32p, c_f32p, i64, ctypes.c_void_p, c_f32p, ctypes.c_void_p, c_f32p, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_stream]),
     "nm_mlp_backward_plain16": (i32, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, ctypes.c_void_p, i64, c_f32p, ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, i64, c_stream]),
-    "nm_mlp_backward_net16": (i32, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, ctypes.c_void_p, ctypes.c_void_p, i64, c_f32p, ctypes.c_void_p, ctypes.c_void_p,
+    "nm_mlp_backward_net16": (i32, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_void_p, i64, c_f32p, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, i64, c_stream]),
     "nm_mlp_backward_chain16": (i32, [ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_void_p, i64, c_f32p, ctypes.c_void_p, ctypes.c_void_p, c_f32p, c_f32p,
                                       c_f32p, c_f32p, i64, c_stream]),
@@ -76,6 +76,7 @@ SIGNATURES = {
     "nm_mlp_forward_debug": (i32, [ctypes.c_void_p, c_f32p, c_f32p, i64, i32, i32, c_f32p, c_stream]),
     "nm_mlp_forward_profile": (i32, [ctypes.c_void_p, c_f32p, c_f32p, i64, i32, c_f32p, ctypes.c_void_p, c_stream]),
     "nm_mesh_create": (i32, [c_f32p, i32, c_i32p, i32, i32, ctypes.POINTER(ctypes.c_void_p), c_stream]),
+    "nm_mesh_update": (i32, [ctypes.c_void_p, c_f32p, c_stream]),
     "nm_mesh_destroy": (i32, [ctypes.c_void_p]),
     "nm_mesh_info": (i32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "nm_warp_to_canonical": (i32, [ctypes.c_void_p, c_f32p, i64, i32, ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_stream]),

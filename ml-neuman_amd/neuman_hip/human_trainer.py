@@ -24,6 +24,7 @@ import torch
 import torch.nn.functional as F
 
 from . import loss_ops, ray_utils, render_utils
+from .train import upload as train_upload
 
 LOSS_NAMES = ['fine_rgb_loss', 'lpips_loss', 'color_range_reg', 'smpl_sym_reg', 'smpl_shape_reg', 'mask_loss', 'sparsity_reg']   # :31-39
 HARD_SURFACE_OFFSET = 0.31326165795326233          # utils/constant.py:7
@@ -114,11 +115,26 @@ class HumanNeRFLoss:
         the batch, and `cat` / `split` are differentiable, so one forward, one backward-data chain and one set of backward-weights products
         serve all of them (a fifth of the launches; the parameter gradients are the same sums in another order).  BATCH_NET_CALLS = False:
         one call per set."""
-        if not BATCH_NET_CALLS or len(queries) == 1:
-            return [self.net.coarse_human_net(p, d) for p, d in queries]
-        sizes = [p.shape[0] for p, _ in queries]
-        out = self.net.coarse_human_net(torch.cat([p for p, _ in queries], 0), torch.cat([d for _, d in queries], 0))
-        return list(torch.split(out, sizes, 0))
+        net = self.net.coarse_human_net
+        outs = [None] * len(queries)
+        # a query set that asks about the FIRST set's points again (the colour-range term: the same tensor, other directions) does not need the trunk a
+        # second time: its colours come from the first call's feature vectors through the views head alone (Joiner.forward_two_views; the gradients are
+        # the sums the separate calls would give)
+        twin = next((i for i in range(1, len(queries)) if queries[i][0] is queries[0][0]), None)
+        if twin is not None and hasattr(net, 'forward_two_views'):
+            pair = net.forward_two_views(queries[0][0], queries[0][1], queries[twin][1])
+            if pair is not None:
+                outs[0], outs[twin] = pair
+        rest = [i for i in range(len(queries)) if outs[i] is None]
+        if not BATCH_NET_CALLS or len(rest) == 1:
+            for i in rest:
+                outs[i] = net(*queries[i])
+        elif rest:
+            sizes = [queries[i][0].shape[0] for i in rest]
+            out = net(torch.cat([queries[i][0] for i in rest], 0), torch.cat([queries[i][1] for i in rest], 0))
+            for i, o in zip(rest, torch.split(out, sizes, 0)):
+                outs[i] = o
+        return outs
 
     # ---- :280-290
     def _color_range_query(self, pts, dirs):
@@ -133,8 +149,9 @@ class HumanNeRFLoss:
 
     # ---- :292-304
     def _smpl_symmetry_query(self, pts, dirs):
-        mirror = torch.tensor([-1.0, 1.0, 1.0], device=pts.device)                      # the canonical body is left-right symmetric in x
-        return pts.detach() * mirror, dirs.detach()                                      # (dummy directions: only the occupancy is compared)
+        if self._mirror is None or self._mirror.device != pts.device:                   # the canonical body is left-right symmetric in x
+            self._mirror = torch.tensor([-1.0, 1.0, 1.0], device=pts.device)
+        return pts.detach() * self._mirror, dirs.detach()                                      # (dummy directions: only the occupancy is compared)
 
     def _smpl_symmetry_regularization(self, mirrored, tgts):
         if _fused(mirrored, tgts):
@@ -173,6 +190,7 @@ class HumanNeRFLoss:
         return ray_utils.signed_distance_dev(pts.reshape(-1, 3).detach(), self._can_tree[key])[0]
 
     _CAN_TREE_MAX = 8
+    _mirror = None
 
     # ---- :305-343
     def _dummy_points(self, pts):
@@ -216,8 +234,9 @@ class HumanNeRFLoss:
         coords = coords[np.asarray(self.replay['can_pixel_choice']) if self.replay else self.np_rng.integers(0, len(coords), num_can_rays)][:, ::-1]
         can_orig, can_dir = ray_utils.shot_rays(can_cap, coords)
         can_pts, can_dirs, can_z_vals = ray_utils.ray_to_samples(
-            {'origin': torch.from_numpy(can_orig).float().to(device), 'direction': torch.from_numpy(can_dir).float().to(device),
-             'near': torch.zeros(num_can_rays, 1).float().to(device), 'far': torch.ones(num_can_rays, 1).float().to(device) * CANONICAL_CAMERA_DIST * 1.667},
+            # (the rays change every iteration: through pinned memory, so that the copy does not wait for the kernels queued before it)
+            {'origin': train_upload(can_orig, device), 'direction': train_upload(can_dir, device),
+             'near': torch.zeros((num_can_rays, 1), device=device), 'far': torch.full((num_can_rays, 1), CANONICAL_CAMERA_DIST * 1.667, device=device)},
             samples_per_ray=self.opt.samples_per_ray, device=device, perturb=self.opt.perturb)
         return can_pts, can_dirs, can_z_vals
 

@@ -284,14 +284,18 @@ class Mesh:
     SEARCH = {'tree': 0, 'all': 1, 'tree_wide': 2}      # NM_SEARCH_TREE / NM_SEARCH_ALL (the all-triangles loop: tests and diagnostics)
 
     def __init__(self, verts, faces, T, device, search='tree'):
+        """T = None: a mesh for closest-point / signed-distance queries only (no per-vertex transforms: nm_warp_to_canonical is not for it)"""
         import ctypes
         _lib.require_gpu()
         v = verts if isinstance(verts, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(verts, dtype=np.float32))
         f = faces[:, :3] if isinstance(faces, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(np.asarray(faces)[:, :3], dtype=np.int32))
-        t = T if isinstance(T, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(T, dtype=np.float64))
         self.verts = v.to(device, torch.float32).contiguous()
         self.faces = f.to(device, torch.int32).contiguous()          # cols 3-5 of scene.faces are UV ids (utils/utils.py:213-221)
-        self.T = t.to(device, torch.float64).reshape(-1, 16).contiguous()
+        if T is None:
+            self.T = None
+        else:
+            t = T if isinstance(T, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(T, dtype=np.float64))
+            self.T = t.to(device, torch.float64).reshape(-1, 16).contiguous()
         # the kernels index verts and T by face entries without bounds checks: refuse UV ids, 1-based or out-of-range indices
         # and a transform table shorter than the vertex list here, once per mesh (the check is a reduction on the device;
         # nm_mesh_create syncs for the bounding box anyway)
@@ -299,12 +303,22 @@ class Mesh:
         if self.faces.numel() and (int(self.faces.min()) < 0 or int(self.faces.max()) >= V):
             raise _lib.NeumanHipError(f"Mesh: face indices must lie in [0, {V}) (got {int(self.faces.min())}..{int(self.faces.max())}): "
                                       "pass the vertex-id columns of a 0-based face array")
-        if self.T.shape[0] < V:
+        if self.T is not None and self.T.shape[0] < V:
             raise _lib.NeumanHipError(f"Mesh: T has {self.T.shape[0]} rows for {V} vertices (one 4x4 per vertex is required)")
         self.handle = ctypes.c_void_p()
         _lib.check(_lib.lib().nm_mesh_create(_lib.dev_ptr(self.verts), self.verts.shape[0], _lib.dev_ptr(self.faces, torch.int32),
                                              self.faces.shape[0], self.SEARCH[search], ctypes.byref(self.handle), _lib.stream_ptr()),
                    "nm_mesh_create")
+
+    def update(self, verts):
+        """the same faces with moved vertices ([V,3] on the mesh's device): the tree is rebuilt inside the handle (nm_mesh_update) -- no allocation, no
+        question to the host.  What a training iteration does with the posed body after every optimiser step."""
+        v = verts.detach().to(self.verts.device, torch.float32).contiguous()
+        if v.shape != self.verts.shape:
+            raise _lib.NeumanHipError(f"Mesh.update: {tuple(v.shape)} vertices for a mesh of {tuple(self.verts.shape)}")
+        self.verts = v
+        _lib.check(_lib.lib().nm_mesh_update(self.handle, _lib.dev_ptr(v), _lib.stream_ptr()), "nm_mesh_update")
+        return self
 
     def info(self):
         import ctypes
@@ -436,10 +450,39 @@ class _BaryFn(torch.autograd.Function):
 BARY_KERNELS = os.environ.get('NEUMAN_BARY_KERNELS', '1') != '0'       # 0: the reference's torch lines under autograd (the check of the kernels)
 
 
+# The differentiable warp is called once per training iteration with the SAME face array and moved vertices: the device copies of the faces and the
+# search handle are kept (keyed by the face array object) and the handle is updated in place -- building a Mesh costs eight allocations, a
+# host-to-device copy of the faces, three read-backs and as many frees, every one of which stalls the queue the iteration's kernels wait in.
+_DIFF_CACHE = {}
+_DIFF_CACHE_MAX = 4
+
+
+def _diff_faces(faces, dev):
+    """-> (faces int64 [F,3] on dev, faces int32 [F,3] on dev, cache entry) for a numpy / tensor face array, by object identity"""
+    key = (id(faces), str(dev))
+    e = _DIFF_CACHE.get(key)
+    if e is None or e['src'] is not faces:
+        f64 = torch.as_tensor(np.ascontiguousarray(np.asarray(faces.cpu() if isinstance(faces, torch.Tensor) else faces)[:, :3]).astype(np.int64)).to(dev)
+        while len(_DIFF_CACHE) >= _DIFF_CACHE_MAX:
+            _DIFF_CACHE.pop(next(iter(_DIFF_CACHE)))
+        e = _DIFF_CACHE[key] = {'src': faces, 'f64': f64, 'f32': f64.to(torch.int32).contiguous(), 'mesh': None}
+    return e['f64'], e['f32'], e
+
+
+def _diff_mesh(e, verts):
+    """the cache entry's search handle on the vertices `verts` (built on first use, updated in place afterwards)"""
+    m = e['mesh']
+    if m is None or m.verts.shape != verts.shape or m.verts.device != verts.device:
+        m = e['mesh'] = Mesh(verts.detach(), e['f32'], None, verts.device)
+    else:
+        m.update(verts)
+    return m
+
+
 def _closest_barycentric(p, verts, f3, mesh=None):
     """the closest-point query (libneuman_hip) and the reference's differentiable barycentric lines (ray_utils.py:70-84) ->
     (barycentric [N,3] with autograd to `verts`, face ids [N] long, signed distance [N])"""
-    mesh = mesh or Mesh(verts.detach(), f3.to(torch.int32), torch.zeros((verts.shape[0], 16), dtype=torch.float64), verts.device)
+    mesh = mesh or Mesh(verts.detach(), f3.to(torch.int32), None, verts.device)
     signed_dist, f_id, closest = signed_distance_dev(p, mesh)
     f_id = f_id.long()
     if BARY_KERNELS and verts.dtype == torch.float32:
@@ -464,9 +507,9 @@ def warp_points_to_canonical_diff(pts, verts, faces, T):
     applied to the very points they were found for), fused: pts [N,3] (detached), verts [V,3] / T [V,4,4] CUDA tensors that may
     require grad -> (canonical points [N,3] with autograd to T and, through the barycentric coordinates, to verts; f_id; signed_dist)."""
     dev = verts.device
-    f3 = torch.as_tensor(np.ascontiguousarray(np.asarray(faces)[:, :3]).astype(np.int64)).to(dev)
+    f3, _, entry = _diff_faces(faces, dev)
     p = pts.detach().to(dev, torch.float32).contiguous()
-    bary, f_id, signed_dist = _closest_barycentric(p, verts, f3)
+    bary, f_id, signed_dist = _closest_barycentric(p, verts, f3, _diff_mesh(entry, verts))
     tri = f3[f_id].to(torch.int32).contiguous()
     return _WarpApplyFn.apply(T.to(dev), bary, tri, p), f_id, signed_dist
 

@@ -147,9 +147,27 @@ class _Packed:
         return self._get('bo4', make)
 
 
+def _pe_table(emb, dev):
+    """the encoding's frequency table on the device, uploaded once per embedder (a pageable host-to-device copy per call waits for the queue to drain)"""
+    cache = emb.__dict__.setdefault('_dev_tables', {})
+    key = str(dev)
+    if key not in cache:
+        cache[key] = torch.from_numpy(emb.table()).to(dev).contiguous()
+    return cache[key]
+
+
+def upload(array, dev, dtype=torch.float32):
+    """a small host array -> device tensor through pinned memory, without waiting for the device (what changes every iteration: a frame time's encoding,
+    the pixels of the canonical rays)"""
+    t = torch.as_tensor(array)
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous().pin_memory().to(dev, non_blocking=True)
+
+
 def _encode(emb, x, ld):
     dev = x.device
-    tab = torch.from_numpy(emb.table()).to(dev).contiguous()
+    tab = _pe_table(emb, dev)
     out = torch.empty((x.shape[0], ld), device=dev, dtype=torch.float32)
     _lib.check(_lib.lib().nm_pe_encode(_lib.dev_ptr(x), x.shape[0], x.shape[1], PE_KINDS[emb.mapping], emb.N_freqs, _lib.dev_ptr(tab),
                                        _lib.dev_ptr(out), ld, _lib.stream_ptr()), "nm_pe_encode")
@@ -159,7 +177,7 @@ def _encode(emb, x, ld):
 def _encode16(emb, x, ld=64, ones_col=-1):
     """the encoding as fp16 of 32 x value, rows of `ld` (an operand of nm_wgrad16); ones_col: a padding column that holds 1 instead of 0"""
     dev = x.device
-    tab = torch.from_numpy(emb.table()).to(dev).contiguous()
+    tab = _pe_table(emb, dev)
     out = torch.empty((x.shape[0], ld), device=dev, dtype=torch.float16)
     _lib.check(_lib.lib().nm_pe_encode16(_lib.dev_ptr(x), x.shape[0], x.shape[1], PE_KINDS[emb.mapping], emb.N_freqs, _lib.dev_ptr(tab),
                                          ctypes.c_void_p(out.data_ptr()), ld, ones_col, _lib.stream_ptr()), "nm_pe_encode16")
@@ -168,7 +186,7 @@ def _encode16(emb, x, ld=64, ones_col=-1):
 
 def _encode_backward(emb, x, g):
     dev = x.device
-    tab = torch.from_numpy(emb.table()).to(dev).contiguous()
+    tab = _pe_table(emb, dev)
     dx = torch.empty_like(x)
     _lib.check(_lib.lib().nm_pe_backward(_lib.dev_ptr(x), x.shape[0], x.shape[1], PE_KINDS[emb.mapping], emb.N_freqs, _lib.dev_ptr(tab),
                                          _lib.dev_ptr(g), g.shape[1], _lib.dev_ptr(dx), _lib.stream_ptr()), "nm_pe_backward")
@@ -197,6 +215,11 @@ class _MLP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, pts, dirs, *params):
+        # net may be a pair (net, 'feature'): the call then also returns feature_linear's output [n, 256] as a differentiable tensor, and a
+        # gradient that reaches it is added to the kernel's own d_feat in the backward pass (two_views below)
+        want_feat = isinstance(net, tuple)
+        if want_feat:
+            net = net[0]
         nerf = net.nerf
         dev = pts.device
         n = pts.shape[0]
@@ -227,12 +250,15 @@ class _MLP(torch.autograd.Function):
                 # view encoding's last padding column holds 1: its product with d_hv is the views layer's bias gradient
                 x0h = torch.empty((n4, 64), device=dev, dtype=torch.float16)
                 d0h = torch.empty((n4, 64), device=dev, dtype=torch.float16)
-                _lib.check(_lib.lib().nm_mlp_forward_save16(handle, _lib.dev_ptr(p4), _lib.dev_ptr(d4), n4, ctypes.c_void_p(h16.data_ptr()), None,
+                feat32 = torch.empty((n4, width), device=dev, dtype=torch.float32) if want_feat else None
+                _lib.check(_lib.lib().nm_mlp_forward_save16(handle, _lib.dev_ptr(p4), _lib.dev_ptr(d4), n4, ctypes.c_void_p(h16.data_ptr()), _lib.dev_ptr(feat32),
                                                             ctypes.c_void_p(feat16.data_ptr()), _lib.dev_ptr(hv), ctypes.c_void_p(bits.data_ptr()),
                                                             ctypes.c_void_p(hvbits.data_ptr()), ctypes.c_void_p(x0h.data_ptr()), ctypes.c_void_p(d0h.data_ptr()),
                                                             _lib.dev_ptr(raw), _lib.stream_ptr()), "nm_mlp_forward_save16")
                 ctx.h16, ctx.x0h, ctx.d0h, ctx.feat16, ctx.hvbits = h16, x0h, d0h, feat16, hvbits
                 acts = H = feat = D0 = None
+            elif want_feat:
+                raise _lib.NeumanHipError("the feature output of a training forward exists in the fp16-storage form only (train.two_views_ok)")
             else:
                 acts = torch.empty((9, n4, width), device=dev, dtype=torch.float32)
                 _lib.check(_lib.lib().nm_mlp_forward_save_bits(handle, _lib.dev_ptr(p4), _lib.dev_ptr(d4), n4, _lib.dev_ptr(acts), _lib.dev_ptr(hv),
@@ -243,7 +269,13 @@ class _MLP(torch.autograd.Function):
             ctx.p4, ctx.d4 = p4, d4
             ctx.acts, ctx.bits = acts, bits
             ctx.versions = [p._version for p in plist]          # the backward pass repacks W^T from the live parameters: they must still be these
+            ctx.want_feat = want_feat
+            if want_feat:
+                ctx.set_materialize_grads(False)
+                return raw[:n], feat32[:n]
             return raw[:n]
+        if want_feat:
+            raise _lib.NeumanHipError("the feature output of a training forward exists in the fused fp16-storage form only (train.two_views_ok)")
         H = []
         h, kh = X0, pk.kp
         for i, Ws in enumerate(pk.W):
@@ -275,9 +307,11 @@ class _MLP(torch.autograd.Function):
         return raw[:n] if views else raw[:n, :pk.n_out]
 
     @staticmethod
-    def backward(ctx, g_raw):
+    def backward(ctx, g_raw, g_feat=None):
         pk, X0, D0, H, feat, hv, n, net = ctx.pk, ctx.X0, ctx.D0, ctx.H, ctx.feat, ctx.hv, ctx.n, ctx.net
         nerf = net.nerf
+        if g_raw is None:                                                        # (the feature output alone was used)
+            g_raw = torch.zeros((n, 4), device=ctx.p4.device, dtype=torch.float32)
         views = nerf.use_viewdirs
         want_in = ctx.needs_input_grad[1] or (views and ctx.needs_input_grad[2])
         dev = ctx.p4.device
@@ -295,7 +329,7 @@ class _MLP(torch.autograd.Function):
             d_raw = torch.zeros((n4, 4), device=dev, dtype=torch.float32)
             d_raw[:n, :g_raw.shape[1]] = g_raw
         if getattr(ctx, 'h16', None) is not None:
-            return _backward16(ctx, d_raw, want_in)
+            return _backward16(ctx, d_raw, want_in, g_feat)
         ws = [torch.empty(4, device=dev, dtype=torch.float32)]
 
         def workspace(m, k):                                                     # split-K partials, grown to the largest product
@@ -494,7 +528,7 @@ class _MLPPlain16(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
-def _backward16(ctx, d_raw, want_in):
+def _backward16(ctx, d_raw, want_in, g_feat=None):
     """The backward pass of a step whose forward kept fp16 copies (STORE16): ONE kernel for the whole backward-data pass from d_raw
     (nm_mlp_backward_net16: the views layer's adjoint, feature_linear's, the eight trunk layers'; dZ of every layer, d_feat and d_hv out as fp16),
     then the weight gradients as batched fp16 products (nm_wgrad16): the eight 256 x 256 ones in one launch, the encoded-position columns of layer 0
@@ -530,7 +564,14 @@ def _backward16(ctx, d_raw, want_in):
     gbs = torch.empty((9, width), device=dev, dtype=torch.float32)
     w = grow(lib.nm_mlp_backward_chain_workspace_floats(n4))
     ptrs = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in nerf.ordered_params()])
-    _lib.check(lib.nm_mlp_backward_net16(net.train_handle(), ptrs, _lib.dev_ptr(d_raw), ctypes.c_void_p(ctx.bits.data_ptr()), ctypes.c_void_p(ctx.hvbits.data_ptr()), n4,
+    feat_add = None
+    if g_feat is not None:                                                 # a second evaluation of the views head on these features (two_views): its share of d_feat
+        if g_feat.shape[0] == n4 and g_feat.dtype == torch.float32 and g_feat.is_contiguous() and (g_feat.data_ptr() & 15) == 0:
+            feat_add = g_feat
+        else:
+            feat_add = torch.zeros((n4, width), device=dev, dtype=torch.float32)
+            feat_add[:g_feat.shape[0]] = g_feat
+    _lib.check(lib.nm_mlp_backward_net16(net.train_handle(), ptrs, _lib.dev_ptr(d_raw), _lib.dev_ptr(feat_add), ctypes.c_void_p(ctx.bits.data_ptr()), ctypes.c_void_p(ctx.hvbits.data_ptr()), n4,
                                          _lib.dev_ptr(amax), ctypes.c_void_p(dz16.data_ptr()), ctypes.c_void_p(dfeat16.data_ptr()), ctypes.c_void_p(dhv16.data_ptr()),
                                          _lib.dev_ptr(dz32[0] if want_in else None), _lib.dev_ptr(dz32[1] if want_in else None), _lib.dev_ptr(dhv32),
                                          _lib.dev_ptr(gbs), _lib.dev_ptr(w), w.numel(), _lib.stream_ptr()), "nm_mlp_backward_net16")
@@ -600,7 +641,7 @@ def _offset_fused(net, pts, t):
         body = vanilla.NeRF(depth=nerf.depth, width=nerf.width, input_ch=pe3.out_dim, input_ch_views=dpe.out_dim, output_ch=4, skips=list(nerf.skips), use_viewdirs=False)
         cache.update(dev=dev, sp=torch.as_tensor(sp, device=dev), tc=torch.as_tensor(tc, device=dev), joiner=vanilla.Joiner(pe3, dpe, body).to(dev))
     sp, tc = cache['sp'], cache['tc']
-    pt = torch.as_tensor(vanilla.time_encoding(pe, t), dtype=torch.float32, device=dev)
+    pt = upload(vanilla.time_encoding(pe, t), dev)                   # (the one thing that changes with the frame)
     params = []
     for i, lin in enumerate(nerf.pts_linears):
         W, b = lin.weight, lin.bias
@@ -636,6 +677,102 @@ def mlp_forward_train(joiner, pts, dirs):
     p = pts.reshape(-1, pts.shape[-1]).to(torch.float32).contiguous()             # (3, or 4 with the time channel of ray_utils.py:133-134)
     d = dirs.reshape(-1, 3).to(torch.float32).contiguous()
     return _MLP.apply(joiner, p, d, *train_params(joiner.nerf)).reshape(*shp, 4)
+
+
+class _ViewsHead(torch.autograd.Function):
+    """The view-dependent head alone (models/vanilla.py:139-144): rgb = rgb_linear(relu(views_linears[0](cat([feature, embed(dirs)])))) on features
+    an _MLP call returned -- a second colour of the same points seen from other directions without a second pass through the trunk.  Returns [n, 4]
+    with a zero density column (the layout the loss terms read).  The per-layer products of the GEMM chain (nm_gemm_*)."""
+
+    @staticmethod
+    def forward(ctx, net, feat, dirs, Wv, bv, Wr, br):
+        nerf = net.nerf
+        dev = feat.device
+        n = feat.shape[0]
+        width, half = nerf.width, nerf.width // 2
+        pk = _Packed(nerf, net.pos_pe.out_dim, net.dir_pe.out_dim)
+        f4, d4 = _pad4(feat), _pad4(dirs)
+        n4 = f4.shape[0]
+        D0 = _encode(net.dir_pe, d4, pk.kd)
+        hv = torch.empty((n4, half), device=dev, dtype=torch.float32)
+        _gemm(0, 0, n4, half, width, f4, width, pk.Wv[0], width, hv, half)
+        _gemm(0, 0, n4, half, pk.kd, D0, pk.kd, pk.Wv[1], pk.kd, hv, half, bias=pk.bv, flags=ACC | BIAS | RELU)
+        raw = torch.empty((n4, 4), device=dev, dtype=torch.float32)
+        b4 = torch.cat([br.detach().float(), torch.zeros(1, device=dev)])
+        _gemm(0, 0, n4, 4, half, hv, half, pk.Wr4, half, raw, 4, bias=b4, flags=BIAS)
+        ctx.net, ctx.pk, ctx.f4, ctx.d4, ctx.D0, ctx.hv, ctx.n = net, pk, f4, d4, D0, hv, n
+        ctx.versions = [p._version for p in (Wv, bv, Wr, br)]
+        ctx.live = (Wv, bv, Wr, br)
+        return raw[:n]
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        net, pk, f4, d4, D0, hv, n = ctx.net, ctx.pk, ctx.f4, ctx.d4, ctx.D0, ctx.hv, ctx.n
+        if [p._version for p in ctx.live] != ctx.versions:
+            raise _lib.NeumanHipError("a parameter of the views head was modified in place between the forward and the backward pass of a training step")
+        nerf = net.nerf
+        dev = f4.device
+        n4, width, half = f4.shape[0], nerf.width, nerf.width // 2
+        lib = _lib.lib()
+        d_raw = torch.zeros((n4, 4), device=dev, dtype=torch.float32)
+        d_raw[:n, :3] = g_raw[:, :3]                                             # (the density column is a constant zero)
+        ws = [torch.empty(4, device=dev, dtype=torch.float32)]
+
+        def grow(need):
+            if need > ws[0].numel():
+                ws[0] = torch.empty(int(need), device=dev, dtype=torch.float32)
+            return ws[0]
+
+        def wgrad(dz, m, a, k):
+            out = torch.empty((m, k), device=dev, dtype=torch.float32)
+            _gemm(1, 1, m, k, n4, dz, dz.shape[1], a, a.shape[1], out, k, ws=grow(lib.nm_gemm_workspace_floats(m, k, n4)))
+            return out
+
+        def colsum(x, rows, m):
+            out = torch.empty(m, device=dev, dtype=torch.float32)
+            w = grow(lib.nm_colsum_workspace_floats(rows, m))
+            _lib.check(lib.nm_colsum(_lib.dev_ptr(x), rows, m, x.shape[1], _lib.dev_ptr(out), _lib.dev_ptr(w), w.numel(), _lib.stream_ptr()), "nm_colsum")
+            return out
+        rgb_w, rgb_b = wgrad(d_raw, 4, hv, half)[:3].contiguous(), colsum(d_raw, n4, 4)[:3].contiguous()
+        bands = (n4 + 63) // 64
+        cs_buf = torch.empty((bands, half), device=dev, dtype=torch.float32)      # per-64-row column sums out of the product's epilogue (row stride = its N)
+        d_hv = torch.empty((n4, half), device=dev, dtype=torch.float32)
+        _gemm(0, 1, n4, half, 4, d_raw, 4, pk.Wr4, half, d_hv, half, mask=hv, ldmask=half, flags=MASK | COLSUM, ws=cs_buf)
+        views_b = colsum(cs_buf, bands, half)
+        views_w = torch.cat([wgrad(d_hv, half, f4, width), wgrad(d_hv, half, D0, pk.kd)[:, :pk.n_dir]], 1)
+        d_dirs = None
+        if ctx.needs_input_grad[2]:
+            dD0 = torch.empty((n4, pk.kd), device=dev, dtype=torch.float32)
+            _gemm(0, 1, n4, pk.kd, half, d_hv, half, pk.Wv[1], pk.kd, dD0, pk.kd)
+            d_dirs = _encode_backward(net.dir_pe, d4, dD0)[:n]
+        d_feat = None
+        if ctx.needs_input_grad[1]:
+            d_feat = torch.empty((n4, width), device=dev, dtype=torch.float32)
+            _gemm(0, 1, n4, width, half, d_hv, half, pk.Wv[0], width, d_feat, width)
+            d_feat = d_feat[:n]
+        return None, d_feat, d_dirs, views_w, views_b, rgb_w, rgb_b
+
+
+def two_views_ok(joiner, n):
+    """can `two_views` serve n points of this net?  (the fused fp16-storage step: the only form whose forward hands out feature_linear's output)"""
+    return (_fused_ok(joiner) and STORE16 and FUSED_BACKWARD and (n + 3) // 4 * 4 >= STORE16_MIN_ROWS and joiner.pos_pe.out_dim <= 64
+            and os.environ.get("NEUMAN_TWO_VIEWS", "1") != "0")
+
+
+def two_views(joiner, pts, dirs, dirs2):
+    """(joiner(pts, dirs), joiner(pts, dirs2) with a zero density column) for the price of one pass through the trunk: the second colour comes from
+    the first call's feature vector through the views head alone.  The human trainer's colour-range term asks exactly this (human_nerf_trainer.py:280-290:
+    the rays' canonical points seen from random directions); every gradient is the sum the two separate calls would give."""
+    _lib.require_gpu()
+    shp = pts.shape[:-1]
+    p = pts.reshape(-1, 3).to(torch.float32).contiguous()
+    d = dirs.reshape(-1, 3).to(torch.float32).contiguous()
+    d2 = dirs2.reshape(-1, 3).to(torch.float32).contiguous()
+    nerf = joiner.nerf
+    raw, feat = _MLP.apply((joiner, 'feature'), p, d, *train_params(nerf))
+    v = nerf.views_linears[0]
+    raw2 = _ViewsHead.apply(joiner, feat, d2, v.weight, v.bias, nerf.rgb_linear.weight, nerf.rgb_linear.bias)
+    return raw.reshape(*shp, 4), raw2.reshape(*shp, 4)
 
 
 class _Composite(torch.autograd.Function):

@@ -230,6 +230,15 @@ class Joiner(nn.Module):
                                              _lib.stream_ptr()), "nm_mlp_forward")
         return out.reshape(*shp, 4)
 
+    def forward_two_views(self, input_pts, input_views, other_views):
+        """(self(input_pts, input_views), self(input_pts, other_views) with a zero density column), the trunk evaluated once -- a training step only
+        (neuman_hip/train.py two_views; None when this net / batch cannot take it: call forward twice then)"""
+        from . import train
+        n = input_pts.reshape(-1, input_pts.shape[-1]).shape[0]
+        if not (self.training and torch.is_grad_enabled() and self.nerf.use_viewdirs and self.pos_pe.input_dims == 3 and train.two_views_ok(self, n)):
+            return None
+        return train.two_views(self, input_pts, input_views, other_views)
+
     def forward_rays(self, origin, direction, z_vals, precision=None, sigma_scale=1.0, role=None, sigma_only=False):
         """Fused ray_to_samples point construction + forward: origin/direction [R,3], z_vals [R,S] -> [R,S,4].
         sigma_only: the caller uses nothing but out[..., 3] (a coarse pass that only places importance samples) -- the

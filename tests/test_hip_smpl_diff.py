@@ -153,3 +153,35 @@ def test_device_copy_follows_the_model_buffers():
     w2, T2 = b.vertex_forward_torch(*args())
     assert float((w1 - w0).abs().max()) > 1e-3
     assert float((w1 - w2).abs().max()) < 2e-5 * float(w2.abs().max()) and float((T1 - T2).abs().max()) < 2e-5 * float(T2.abs().max())
+
+
+def test_mesh_update_equals_a_fresh_build():
+    """nm_mesh_update (the same faces, moved vertices: what every training iteration has) against a mesh built from scratch on the moved vertices:
+    closest points, face ids and signed distances bit for bit, through two updates, and through the cached handle of the differentiable warp"""
+    from neuman_hip import ray_utils, synthetic
+    model = synthetic.smpl_like_model(0)
+    faces = model['f'].astype(np.int32)
+    g = torch.Generator(device='cuda').manual_seed(17)
+    v0 = torch.as_tensor(np.asarray(model['v_template'], np.float32)).cuda()
+    pts = (v0[torch.randint(0, v0.shape[0], (30000,), device='cuda', generator=g)] + 0.05 * torch.randn((30000, 3), device='cuda', generator=g)).contiguous()
+    mesh = ray_utils.Mesh(v0, faces, None, 'cuda')
+    ray_utils.signed_distance_dev(pts, mesh)                             # (builds the normals: the update must refresh them)
+    for step in (1, 2):
+        v = (v0 * (1.0 + 0.03 * step) + 0.01 * step * torch.sin(7.0 * v0.flip(1))).contiguous()       # a smooth, non-rigid move
+        got = ray_utils.signed_distance_dev(pts, mesh.update(v))
+        want = ray_utils.signed_distance_dev(pts, ray_utils.Mesh(v, faces, None, 'cuda'))
+        for a, b, what in zip(got, want, ("signed distance", "face", "closest point")):
+            assert torch.equal(a, b), (step, what)
+        assert float((got[0] < 0).float().mean()) > 0.2 and float((got[0] > 0).float().mean()) > 0.2
+    with pytest.raises(Exception):
+        mesh.update(v[:-1])
+    # the differentiable warp keeps ONE handle per face array and updates it: the second call (moved vertices) equals a cold call
+    T = torch.eye(4, device='cuda').repeat(v0.shape[0], 1, 1).contiguous()
+    ray_utils._DIFF_CACHE.clear()
+    ray_utils.warp_points_to_canonical_diff(pts, v0, faces, T)
+    warm = ray_utils.warp_points_to_canonical_diff(pts, v, faces, T)
+    assert len(ray_utils._DIFF_CACHE) == 1
+    ray_utils._DIFF_CACHE.clear()
+    cold = ray_utils.warp_points_to_canonical_diff(pts, v, faces, T)
+    for a, b in zip(warm, cold):
+        assert torch.equal(a, b)

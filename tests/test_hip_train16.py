@@ -255,8 +255,8 @@ def test_backward_chain16_is_the_rounded_float32_chain(G, n, want_copies):
     assert bool(torch.isfinite(dz16.float()).all()) and float(dz16.float().abs().max()) == 65504.0
 
 
-@pytest.mark.parametrize("n,want_copies", [(1000, True), (4224, False)])
-def test_backward_net16_against_float64(G, n, want_copies):
+@pytest.mark.parametrize("n,want_copies,add", [(1000, True, False), (4224, False, False), (1001, False, True)])
+def test_backward_net16_against_float64(G, n, want_copies, add):
     """nm_mlp_backward_net16: the views layer's adjoint formed in the kernel -- d_hv = (d_rgb W_rgb) * (hv > 0), d_feat = d_hv W_views[:, :256] -- then the
     chain; against float64 of the same saved signs, and against nm_mlp_backward_chain16 fed with the float64 d_feat"""
     net = G.syn.make_joiner(1).cuda().train()
@@ -283,7 +283,9 @@ def test_backward_net16_against_float64(G, n, want_copies):
     dh16 = torch.full((n, 128), 7.0, device='cuda', dtype=torch.float16)
     c5, c0, dh32 = ((torch.empty((n, 256), device='cuda'), torch.empty((n, 256), device='cuda'), torch.empty((n, 128), device='cuda')) if want_copies else (None, None, None))
     gb = torch.empty((9, 256), device='cuda')
-    G.L.check(G.lib.nm_mlp_backward_net16(h, ptrs, G.L.dev_ptr(d_raw), ctypes.c_void_p(bits.data_ptr()), ctypes.c_void_p(hvbits.data_ptr()), n, G.L.dev_ptr(amax),
+    # add: a gradient that reaches feature_linear's output from a second evaluation of the views head (train.py's second view), summed inside the kernel
+    extra = (torch.randn((n, 256), device='cuda', generator=g) * 3e-6).contiguous() if add else None
+    G.L.check(G.lib.nm_mlp_backward_net16(h, ptrs, G.L.dev_ptr(d_raw), G.L.dev_ptr(extra), ctypes.c_void_p(bits.data_ptr()), ctypes.c_void_p(hvbits.data_ptr()), n, G.L.dev_ptr(amax),
                                           ctypes.c_void_p(dz16.data_ptr()), ctypes.c_void_p(df16.data_ptr()), ctypes.c_void_p(dh16.data_ptr()), G.L.dev_ptr(c5), G.L.dev_ptr(c0),
                                           G.L.dev_ptr(dh32), G.L.dev_ptr(gb), G.L.dev_ptr(ws), ws.numel(), G.L.stream_ptr()), "net16")
     perm = torch.from_numpy(slot_perm()).cuda()
@@ -295,7 +297,7 @@ def test_backward_net16_against_float64(G, n, want_copies):
     assert float((got_hv - d_hv).abs().max()) < 1e-3 * float(d_hv.abs().max())          # fp16 of an exact float32 sum of three products
     if want_copies:
         assert float((dh32.double() - d_hv).abs().max()) < 1e-6 * float(d_hv.abs().max())
-    d_feat = d_hv @ Wv[:, :256]
+    d_feat = d_hv @ Wv[:, :256] + (extra.double() if add else 0.0)
     got_feat = df16.double()[:, inv256] / s
     assert float((got_feat - d_feat).abs().max()) < 1e-3 * float(d_feat.abs().max())
     assert float((gb[8].double() - d_feat.sum(0)).abs().max()) < 2e-5 * float(d_feat.sum(0).abs().max()) + 1e-12
@@ -453,3 +455,40 @@ def test_offset_net_on_the_fused_kernels(G, monkeypatch):
         want = gb[:, None] * pt[None, :]
         assert float((gW[:, tc] - want).abs().max()) <= 1e-6 * float(want.abs().max()), i
         assert float(gW[:, sp].abs().max()) > 0
+
+
+def test_two_views_share_the_trunk(G, monkeypatch):
+    """train.two_views: net(pts, dirs) and net(pts, dirs2)'s colours from ONE pass through the trunk (the second through the views head alone, its gradient
+    added to d_feat inside the backward kernel) against the two separate calls the reference makes (human_nerf_trainer.py:276, 286): outputs and every
+    gradient -- parameters, points, both direction sets"""
+    monkeypatch.setattr(G.train, "GEMM_PRECISION", "mixed16")
+    n = 40000
+    net = G.syn.make_joiner(2, 'rotate').cuda().train()
+    g = torch.Generator(device='cuda').manual_seed(21)
+    base = (torch.rand((n, 3), device='cuda', generator=g) * 1.6 - 0.8)
+    d1 = F.normalize(torch.randn((n, 3), device='cuda', generator=g), dim=-1)
+    d2 = F.normalize(torch.randn((n, 3), device='cuda', generator=g), dim=-1)
+    t1, t2 = torch.randn((n, 4), device='cuda', generator=g), torch.randn((n, 3), device='cuda', generator=g)
+    assert G.train.two_views_ok(net, n)
+
+    def run(shared):
+        for p in net.parameters():
+            p.grad = None
+        pts, a, b = base.clone().requires_grad_(True), d1.clone().requires_grad_(True), d2.clone().requires_grad_(True)
+        if shared:
+            o1, o2 = net.forward_two_views(pts, a, b)
+            assert float(o2[:, 3].abs().max()) == 0.0
+        else:
+            o1, o2 = net(pts, a), net(pts, b)
+        loss = ((o1 - t1) ** 2).mean() + 0.7 * ((torch.sigmoid(o2[:, :3]) - torch.sigmoid(o1[:, :3].detach() + t2 * 0.1)) ** 2).mean()
+        loss.backward()
+        return o1.detach(), o2.detach(), [p.grad.clone() for p in net.parameters()] + [pts.grad, a.grad, b.grad]
+    o1s, o2s, gs = run(True)
+    o1r, o2r, gr = run(False)
+    assert torch.equal(o1s, o1r)
+    e2 = float((o2s[:, :3] - o2r[:, :3]).abs().max())
+    names = [k for k, _ in net.named_parameters()] + ['pts', 'dirs', 'dirs2']
+    worst = max((float((a - b).abs().max() / b.abs().max()), k) for a, b, k in zip(gs, gr, names))
+    print(f"[train16] two views, {n} points: second colour vs the separate call {e2:.2e}; worst gradient deviation {worst[0]:.2e} of its largest entry ({worst[1]})")
+    assert e2 < 5e-6 and worst[0] < 5e-5
+    assert all(float(b.abs().max()) > 0 for b in gr)

@@ -106,6 +106,18 @@ line = {"rays": R, "hit_rays": int(hit.sum()), "body": [6890, int(faces.shape[0]
         "total_loss_first5_mean": first, "total_loss_last5_mean": last, "total_loss_first": totals[0], "total_loss_last": totals[-1], "terms_last": terms,
         "learning_rate": 2e-4, "target": "the batch rendered through a second frozen human net (seed 9, dense preset)"}
 print(json.dumps(line), flush=True)
+if os.environ.get('NEUMAN_HOST_PROFILE') == '1':                        # where the HOST's time goes (cProfile over 20 iterations, by own time), to stderr
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    t0 = time.perf_counter()
+    pr.enable()
+    for _ in range(20):
+        loss.train_step(batch, optim)
+    pr.disable()
+    torch.cuda.synchronize()
+    print(f"[host profile] 20 iterations in {(time.perf_counter() - t0) * 1e3:.1f} ms under cProfile", file=sys.stderr)
+    pstats.Stats(pr, stream=sys.stderr).sort_stats('tottime').print_stats(45)
 if os.environ.get('NEUMAN_LAUNCH_SOURCES') == '1':                      # where the iteration's launches come from (tools/launch_sources.py), to stderr
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import launch_sources
