@@ -90,11 +90,11 @@ class HumanNeRFLoss:
 
     # ---- :241-278
     def _eval_human_samples(self, batch, device):
-        human_batch = {'origin': batch['origin'].clone().to(device), 'direction': batch['direction'].clone().to(device),
-                       'near': batch['human_near'].clone().to(device), 'far': batch['human_far'].clone().to(device)}
+        human_batch = {'origin': batch['origin'].to(device), 'direction': batch['direction'].to(device),          # (ray_to_samples writes none of them)
+                       'near': batch['human_near'].to(device), 'far': batch['human_far'].to(device)}
         human_pts, human_dirs, human_z_vals = ray_utils.ray_to_samples(human_batch, self.opt.samples_per_ray, device=device, perturb=self.opt.perturb)
         b, n, _ = human_pts.shape
-        cur_time = torch.ones_like(human_pts[..., 0:1]) * float(batch['cur_view_f'])
+        cur_time = torch.full_like(human_pts[..., 0:1], float(batch['cur_view_f']))
         nets = list(self.net.offset_nets)
         offset_net = nets[int(self.replay['offset_net'])] if self.replay else self.rng.choice(nets)
         offset = offset_net(torch.cat([human_pts, cur_time], dim=-1), const_time=float(batch['cur_view_f']))
@@ -243,7 +243,7 @@ class HumanNeRFLoss:
     def _sparsity_regularization(self, can_out, can_dirs, can_z_vals):
         sparsity_reg = torch.zeros((), device=can_out.device)
         can_out = torch.cat([can_out[..., :3], can_out[..., 3:] * self.interval_comp], -1)            # `can_out[..., -1] *= interval_comp`, out of place
-        _, _, can_mask, can_weights, _ = render_utils.raw2outputs(can_out, can_z_vals.clone(), can_dirs[:, 0, :].clone(), white_bkg=True)
+        _, _, can_mask, can_weights, _ = render_utils.raw2outputs(can_out, can_z_vals, can_dirs[:, 0, :].contiguous(), white_bkg=True)
         self.last.update(can_mask=can_mask, can_weights=can_weights)                     # (before the clamp to [0, 1] of :366-367)
         if _fused(can_mask, can_weights):                                                # clamp, prior, mean and the gradient of all three: one kernel a term
             if self.penalize_sharp_edge > 0:
