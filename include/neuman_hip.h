@@ -421,6 +421,11 @@ int nm_merge_composite_lists(int k, const float* const* z, const float* const* r
  * the weights are written only when weights_out [R,S] != NULL.  Bit-identical to nm_composite + nm_importance_z. */
 int nm_importance_from_raw(const float* raw, const float* z_vals, const float* rays_d, int64_t R, int S, const float* u, int N, float* z_out,
                            float* weights_out, nm_stream_t stream);
+/* The intervals the samples of k <= 4 sorted lists per ray (z[l] [R,S[l]]) will be composited with ONCE MERGED: for every sample the distance
+ * to its successor in the stable merged order (ties: the earlier list first -- nm_merge_sorted's order, the reference's sort(cat(...)),
+ * utils/render_utils.py:330-337, 441-448), 1e10 for the last sample of the merged list (:86) -> dz[l] [R,S[l]].  What an early-termination
+ * cut is decided on before the lists are merged.  z / S / dz are HOST arrays of k entries. */
+int nm_merged_intervals(int k, const float* const* z, const int* S, int64_t R, float* const* dz, nm_stream_t stream);
 int64_t nm_merge_composite_workspace_floats(int64_t R, int Sa, int Sb);
 int nm_merge_composite(const float* za, const float* rawa, int Sa, const float* zb, const float* rawb, int Sb, int64_t R, const float* rays_d,
                        int white_bkg, float* workspace, float* rgb, float* depth, float* acc, nm_stream_t stream);

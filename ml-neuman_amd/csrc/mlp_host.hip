@@ -476,7 +476,7 @@ struct nm_mlp_s {
     uint8_t* d_stream16t;  // NM_PREC_FP16X3, density only: the stream of nerf_sigma_f16t_kernel (sigma_stream_kernel over d_image16)
     int* d_sigma_tab;      //   its piece table
     uint8_t* d_bwd_image;  // the transposed hidden weights of the backward-data chain (mlp_bwd.hip), repacked from live parameters per call
-    int sigma_ndir;        //   parts of a pair k-step that bypass the LDS ring (the kernel is generated for one value: NEUMAN_F16T_NDIR is for experiments)
+    int sigma_ndir;        //   parts of a pair k-step that bypass the LDS ring: the value the kernel body was generated for (mlp_f16t.hip sigma_f16t_ndir)
     float* d_petab;        // 192 floats
     float* d_ref;          // transposed f32 weights | natural biases (NM_PREC_FP32 path)
     float* d_wscale16;     // nm_mlp_refresh_f16: the per-stage weight scales of the fp16 image (device scratch)
@@ -617,7 +617,7 @@ int nm_mlp_create(const nm_mlp_desc* desc, const float* const* host_params, cons
     if (!rc) rc = nm::check_hip(hipMemcpy(m->d_ref, ref.data(), ref.size() * 4, hipMemcpyHostToDevice), "nm_mlp_create: upload ref");
     if (!rc && !plain) {
         std::vector<int> stab;
-        m->sigma_ndir = [] { const char* e = getenv("NEUMAN_F16T_NDIR"); return e ? atoi(e) : 0; }();
+        m->sigma_ndir = nm::sigma_f16t_ndir();                                          // what the generated kernel body was emitted for
         nm::sigma_stream_table(stab, m->sigma_ndir);
         rc = nm::check_hip(hipMalloc(&m->d_sigma_tab, stab.size() * sizeof(int)), "nm_mlp_create: hipMalloc(sigma table)");
         if (!rc) rc = nm::check_hip(hipMemcpy(m->d_sigma_tab, stab.data(), stab.size() * sizeof(int), hipMemcpyHostToDevice), "nm_mlp_create: upload sigma table");

@@ -46,6 +46,7 @@ int launch_mlp_i8s(const MlpLaunch& L, const void* image8, const float* pts, con
                    const float* z, int64_t n, int S, int in_mode, float sigma_scale, float* out, hipStream_t stream, const MlpChunk* chunk);
 // NM_PREC_FP16X3 density only, activation-stationary (mlp_f16t.hip); stream16t = sigma_stream_kernel's re-cut of the fp16 image.  dbg (nullable): the
 // activations after stage dbg_stage of the first tile (+ 100 x round) of workgroup 0 as float32 [128 samples][256] in k-slot order
+int sigma_f16t_ndir();       // the NDIR tools/gen_f16t.py emitted mlp_f16t_body.h for: the stream is cut for exactly that
 int launch_sigma_f16t(const MlpLaunch& L, const void* stream16t, int stream_ndir, const float* pts, const float* dirs, const float* origin, const float* direction,
                       const float* z, int64_t n, int S, int in_mode, float sigma_scale, float* out, hipStream_t stream, const MlpChunk* chunk,
                       float* dbg, int dbg_stage);

@@ -488,6 +488,44 @@ __global__ __launch_bounds__(256) void rows_kernel(const float* __restrict__ src
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// For every sample of k <= 4 sorted lists per ray: the distance to its successor in the MERGED (stable, earlier list first) order of the
+// reference's sort(cat(...)) (render_utils.py:330-337, 441-448); the last sample of the merged list gets raw2outputs' 1e10 (:86).  The
+// successor of sample i of list a is the nearest of: its own list's sample i + 1, the first sample >= z of every LATER list (equal values
+// of a later list come after) and the first sample > z of every EARLIER list.  One thread per sample, binary searches in the other rows
+// (a row is at most a few hundred floats: L1 / L2 resident); nothing is sorted, nothing is written but dz.  Bound: HBM (4 B in, 4 B out).
+// ------------------------------------------------------------------------------------------------
+struct IntervalLists {
+    const float* z[kMaxMergeLists];
+    float* dz[kMaxMergeLists];
+    int S[kMaxMergeLists];
+    int k, S_total;
+};
+__global__ __launch_bounds__(256) void merged_intervals_kernel(const IntervalLists L, int64_t R) {
+    const int64_t total = R * L.S_total;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t ray = t / L.S_total;
+        int i = (int)(t - ray * L.S_total), a = 0;
+        while (i >= L.S[a]) { i -= L.S[a]; ++a; }
+        const float* za = L.z[a] + ray * L.S[a];
+        const float z = za[i];
+        float next = i + 1 < L.S[a] ? za[i + 1] : INFINITY;
+        for (int b = 0; b < L.k; ++b) {
+            if (b == a) continue;
+            const float* zb = L.z[b] + ray * L.S[b];
+            int lo = 0, hi = L.S[b];                       // first index whose sample comes after (a, i) in the stable order
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const float v = zb[mid];
+                if (b > a ? v >= z : v > z) hi = mid; else lo = mid + 1;
+            }
+            if (lo < L.S[b]) next = fminf(next, zb[lo]);
+        }
+        L.dz[a][ray * L.S[a] + i] = next == INFINITY ? 1e10f : next - z;
+    }
+}
+
+
 inline int grid_for(int64_t work_items, int per_block, int max_blocks = 256 * 16) {
     int64_t b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -603,6 +641,27 @@ int nm_merge_composite_lists(int k, const float* const* z, const float* const* r
     hipLaunchKernelGGL(merge_composite_kernel, dim3(grid_for(R, wpb)), dim3(64 * wpb), per_wave * wpb, nm::as_stream(stream), L, R, rays_d, white_bkg, rgb,
                        depth, acc);
     return nm::check_launch("merge_composite_kernel");
+}
+
+int nm_merged_intervals(int k, const float* const* z, const int* S, int64_t R, float* const* dz, nm_stream_t stream) {
+    NM_REQUIRE(k >= 1 && k <= kMaxMergeLists && z && S && dz, "nm_merged_intervals: 1 <= k <= %d lists (k=%d)", kMaxMergeLists, k);
+    IntervalLists L;
+    L.k = k;
+    L.S_total = 0;
+    for (int l = 0; l < kMaxMergeLists; ++l) {
+        const bool on = l < k;
+        L.z[l] = on ? z[l] : nullptr;
+        L.dz[l] = on ? dz[l] : nullptr;
+        L.S[l] = on ? S[l] : 0;
+        if (on) {
+            NM_REQUIRE(S[l] >= 1, "nm_merged_intervals: list %d is empty", l);
+            NM_REQUIRE(R == 0 || (z[l] && dz[l]), "nm_merged_intervals: list %d is null", l);
+            L.S_total += S[l];
+        }
+    }
+    if (R == 0) return NM_OK;
+    hipLaunchKernelGGL(merged_intervals_kernel, dim3(grid_for(R * L.S_total, 256)), dim3(256), 0, nm::as_stream(stream), L, R);
+    return nm::check_launch("merged_intervals_kernel");
 }
 
 int nm_merge_sorted(const float* za, const float* rawa, int Sa, const float* zb, const float* rawb, int Sb, int64_t R,

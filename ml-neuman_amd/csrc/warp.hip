@@ -348,6 +348,10 @@ __global__ __launch_bounds__(64) void search_kernel(Tree tr, int search_all_mode
                                                                  int32_t* __restrict__ f_out, int f_stride, int chunk) {
     extern __shared__ double lds_raw[];
     const int depth = 3 * (tr.L - 1);
+    // A mesh whose vertices went non-finite AFTER creation (nm_mesh_update never reads back: a training iteration must not stall; the flag is
+    // bbox_kernel's out[6], next to the scale): boxes and margins built from NaN order nothing, so the tree is not descended at all -- every sample
+    // takes the all-triangles loop, whose answer is defined (NaN distances never win: face 0, q = p) and whose NaN reaches the trainer's loss guard.
+    if (tr.scale[-1] != 0.f) search_all_mode = 1;
     // node stack entry: {distance^2, node} as float2, or -- SMALL: at most 65,536 nodes and triangles -- one dword holding the
     // distance^2 truncated to its upper 16 bits (rounded towards zero: still a lower bound) above the node index, and
     // uint16 pending triangles.  LDS per lane decides how many waves share a CU, and the walk is latency-bound.
@@ -991,7 +995,8 @@ int nm_mesh_create(const float* verts, int V, const int32_t* faces, int F, int s
     NM_TRY(hipMemcpyAsync(m->d_faces, faces, (size_t)F * 12, hipMemcpyDeviceToDevice, st), "nm_mesh_create: copy faces");
     float hb[7] = {0, 0, 0, 0, 0, 0, 0};
     if (!rc) rc = build_tree(m, st);
-    // one read-back, at creation only: the non-finite flag of the vertex box (a mesh with a NaN / Inf vertex is refused)
+    // one read-back, at creation only: the non-finite flag of the vertex box (a mesh with a NaN / Inf vertex is refused; after an nm_mesh_update the
+    // same flag, left on the device, switches search_kernel to its all-triangles loop)
     NM_TRY(hipMemcpyAsync(hb, m->d_bbox, 7 * 4, hipMemcpyDeviceToHost, st), "nm_mesh_create: read bbox");
     NM_TRY(hipStreamSynchronize(st), "nm_mesh_create: sync");
 #undef NM_TRY

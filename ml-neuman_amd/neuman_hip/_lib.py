@@ -132,6 +132,7 @@ SIGNATURES = {
                                     c_stream]),
     "nm_merge_composite_lists": (i32, [i32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
                                        ctypes.POINTER(ctypes.c_int), i64, c_f32p, i32, c_f32p, c_f32p, c_f32p, c_stream]),
+    "nm_merged_intervals": (i32, [i32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), i64, ctypes.POINTER(ctypes.c_void_p), c_stream]),
     "nm_importance_from_raw": (i32, [c_f32p, c_f32p, c_f32p, i64, i32, c_f32p, i32, c_f32p, c_f32p, c_stream]),
     "nm_merge_composite_workspace_floats": (i64, [i64, i32, i32]),
     "nm_merge_composite": (i32, [c_f32p, c_f32p, i32, c_f32p, c_f32p, i32, i64, c_f32p, i32, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),

@@ -60,7 +60,10 @@ class BackgroundNeRFTrainer:
             data_parallel = self.world > 1
         self.sync, self.shard_batches, self.group = None, shard_batches, group
         if data_parallel:
-            dp.broadcast_parameters(self._nets(), group=group)    # (after a resume too: every rank starts from rank 0's weights)
+            dp.broadcast_parameters(self._nets(), group=group)    # (after a resume too: every rank starts from rank 0's weights ...
+            if getattr(opt, 'resume', False):
+                dp.broadcast_optimizer_state(self.optim, group=group)      # ... and rank 0's Adam moments and step counts)
+            dp.decorrelate_device_rng(self.rank)                  # same batches on every rank, independent per-sample jitter / noise on the shards
             self.sync = dp.GradSync([p for n in self._nets() for p in n.parameters()], n_extra=5, group=group)
 
     # ---------------------------------------------------------------------------------------------

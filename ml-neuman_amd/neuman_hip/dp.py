@@ -75,6 +75,30 @@ def broadcast_parameters(modules, src=0, group=None):
             off += n
 
 
+def broadcast_optimizer_state(optim, src=0, group=None):
+    """rank src's optimiser state (Adam's moments, step counts, the groups' hyper-parameters) on every rank: after a resume() the ranks may have
+    read different or missing checkpoints, and parameters that agree step apart again if the moments do not.  One object broadcast (the state
+    is the size of the parameters; this runs once per resume, not per iteration)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    rank, _ = rank_world(group)
+    box = [optim.state_dict() if rank == src else None]
+    if rank == src:
+        box[0] = {'state': {k: {n: (v.cpu() if torch.is_tensor(v) else v) for n, v in st.items()} for k, st in box[0]['state'].items()},
+                  'param_groups': box[0]['param_groups']}
+    dist.broadcast_object_list(box, src=src, group=group)
+    if rank != src:
+        optim.load_state_dict(box[0])                           # (load_state_dict moves the tensors to the parameters' device)
+
+
+def decorrelate_device_rng(rank):
+    """The ranks of a data-parallel trainer are seeded alike so that they draw the same batches; the per-SAMPLE draws of an iteration (the
+    stratified jitter of sample_z, raw2outputs' density noise) come from the device's global generator and would then repeat rank 0's pattern on
+    every rank's shard.  Re-seed that generator with seed + rank: independent jitter per ray across the whole batch, as in a single process."""
+    if torch.cuda.is_available() and rank > 0:
+        torch.cuda.manual_seed((torch.cuda.initial_seed() + 7919 * rank) % (1 << 63))
+
+
 class GradSync:
     """The gradients of `params` as views of one flat float32 buffer (+ `n_extra` trailing floats), summed over the ranks by ONE all_reduce.
 

@@ -438,10 +438,13 @@ class HumanNeRFTrainer(HumanNeRFLoss):
         if photometric:
             total = terms.sum()
         else:
+            # before delay_iters the reference leaves the rgb group out of the sum (:540-551): the geometry terms are SELECTED (an index, not a
+            # multiplication by zero: a NaN photometric term must not reach the total, and the rgb graph stays out of the backward pass)
             dev = terms.device
             if dev not in self._geometry_only:
-                self._geometry_only[dev] = torch.tensor([0.0 if n in ('fine_rgb_loss', 'color_range_reg', 'lpips_loss') else 1.0 for n in LOSS_NAMES], device=dev)
-            total = (terms * self._geometry_only[dev]).sum()
+                self._geometry_only[dev] = torch.tensor([i for i, n in enumerate(LOSS_NAMES) if n not in ('fine_rgb_loss', 'color_range_reg', 'lpips_loss')],
+                                                        device=dev, dtype=torch.long)
+            total = terms.index_select(0, self._geometry_only[dev]).sum()
         total.backward()
         vals = torch.cat([terms.detach().float(), torch.stack([total.detach().float(), self.last['alive'].float()])]).tolist()
         f32 = lambda v: float(np.float32(v))                                              # noqa: E731  (the device's additions are float32)

@@ -122,7 +122,8 @@ def render_sharded(render_rays_fn, origins, dirs, tile=8192, dst=0, force_collec
 # The frame renderers of render_utils shard only when asked to: under a process group they become COLLECTIVES (every rank must make the
 # call, ranks other than 0 get None back), which a caller that renders its validation frames on rank 0 alone -- the usual pattern beside
 # data-parallel training (bkg_trainer / human_trainer under a group) -- must not get by surprise.  NEUMAN_SHARD_FRAMES=1 or
-# set_frame_sharding(True) turns it on (bench.py, tools/bench_configs.py and the multi-GPU render scripts do).
+# set_frame_sharding(True) turns it on (bench.py and tools/bench_configs.py do; a torchrun render driver must too -- left off under a group of
+# more than one rank, every rank renders the whole frame and sharding_active() says so once, on stderr).
 SHARD_FRAMES = os.environ.get("NEUMAN_SHARD_FRAMES", "0") == "1"
 # per-frame timing of render_frame_sharded (HIP events on the current stream, read by frame_stats(); no host synchronisation in the call)
 FRAME_STATS = os.environ.get("NEUMAN_FRAME_STATS", "0") == "1"
@@ -139,12 +140,22 @@ def set_frame_sharding(on=True, stats=None):
 def sharding_active():
     """True when the frame renderers shard: asked for (SHARD_FRAMES) and an initialised process group of more than one rank (or of one,
     with FORCE_COLLECTIVE)."""
-    if not SHARD_FRAMES or not (dist.is_available() and dist.is_initialized()):
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    if not SHARD_FRAMES:
+        global _WARNED_UNSHARDED
+        if not _WARNED_UNSHARDED and dist.get_world_size() > 1:
+            _WARNED_UNSHARDED = True
+            import sys
+            print(f"neuman_hip.parallel: a process group of {dist.get_world_size()} ranks is up but frame sharding is off: every rank renders the "
+                  "WHOLE frame (and gets it back).  Render drivers set NEUMAN_SHARD_FRAMES=1 or parallel.set_frame_sharding(True); trainers that "
+                  "render validation frames on one rank leave it off.", file=sys.stderr, flush=True)
         return False
     return dist.get_world_size() > 1 or FORCE_COLLECTIVE
 
 
 LAST_FRAME_STATS = {}
+_WARNED_UNSHARDED = False
 
 
 def frame_stats():

@@ -487,19 +487,18 @@ def _closest_barycentric(p, verts, f3, mesh=None):
     f_id = f_id.long()
     if BARY_KERNELS and verts.dtype == torch.float32:
         return _BaryFn.apply(verts, f3[f_id].to(torch.int32).contiguous(), closest.contiguous()), f_id, signed_dist
-    closest_tri = verts[f3[f_id]]
-    v0v1 = closest_tri[:, 1] - closest_tri[:, 0]
-    v0v2 = closest_tri[:, 2] - closest_tri[:, 0]
-    v1v2 = closest_tri[:, 2] - closest_tri[:, 1]
-    v2v0 = closest_tri[:, 0] - closest_tri[:, 2]
-    v1p = closest - closest_tri[:, 1]
-    v2p = closest - closest_tri[:, 2]
-    N = torch.cross(v0v1, v0v2, dim=1)
-    denom = (N * N).sum(1)
-    u = (N * torch.cross(v1v2, v1p, dim=1)).sum(1) / denom
-    v = (N * torch.cross(v2v0, v2p, dim=1)).sum(1) / denom
-    w = 1 - u - v
-    return torch.stack([u, v, w], dim=1), f_id, signed_dist
+    return _barycentric_torch(verts[f3[f_id]], closest), f_id, signed_dist
+
+
+def _barycentric_torch(corners, p):
+    """Barycentric coordinates of points p [N,3] in triangles corners [N,3,3] as ratios of signed areas: the sub-triangle opposite corner k
+    (spanned from corner k+1 to corner k+2 and to p), projected on the triangle's normal, over the triangle's own -- the quantity
+    ray_utils.py:73-84 computes; plain torch under autograd (the check of nm_bary_forward / _backward, and the path for non-float32 vertices)."""
+    nxt, prv = corners.roll(-1, 1), corners.roll(-2, 1)
+    normal = torch.linalg.cross(corners[:, 1] - corners[:, 0], corners[:, 2] - corners[:, 0])
+    sub = torch.linalg.cross(prv - nxt, p[:, None, :] - nxt)
+    uv = (sub[:, :2] * normal[:, None, :]).sum(-1) / (normal * normal).sum(-1, keepdim=True)
+    return torch.cat([uv, 1 - uv.sum(1, keepdim=True)], 1)
 
 
 def warp_points_to_canonical_diff(pts, verts, faces, T):
@@ -516,28 +515,13 @@ def warp_points_to_canonical_diff(pts, verts, faces, T):
 
 def warp_samples_to_canonical_diff(pts, verts, faces, T):
     """reference ray_utils.py:69-93: pts [N,3] numpy (detached), verts [V,3] / T [V,4,4] torch tensors that may require grad
-    -> (T_interp_inv [N,4,4], f_id, signed_dist).  The closest-point query and its sign run in libneuman_hip; the barycentric
-    blend and the 4x4 inverse are the reference's own differentiable torch lines, on the device."""
+    -> (T_interp_inv [N,4,4], f_id, signed_dist).  The closest-point query, its sign and the barycentric coordinates (with their adjoint to
+    the vertices) run in libneuman_hip (_closest_barycentric); the blend of the three corner transforms and the 4x4 inverse are
+    differentiable torch operations on the device (callers that only apply the inverse to the points: warp_points_to_canonical_diff)."""
     dev = verts.device if isinstance(verts, torch.Tensor) and verts.is_cuda else torch.device('cuda')
-    verts = verts.to(dev)
-    T = T.to(dev)
-    f3 = torch.as_tensor(np.ascontiguousarray(np.asarray(faces)[:, :3]).astype(np.int64)).to(dev)
+    verts, T = verts.to(dev), T.to(dev)
+    f3, _, entry = _diff_faces(faces, dev)
     p = pts.detach().to(dev, torch.float32) if isinstance(pts, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(pts, dtype=np.float32)).to(dev)
-    mesh = Mesh(verts.detach(), f3.to(torch.int32), torch.zeros((verts.shape[0], 16), dtype=torch.float64), dev)
-    signed_dist, f_id, closest = signed_distance_dev(p, mesh)
-    f_id = f_id.long()
-    closest_tri = verts[f3[f_id]]
-    v0v1 = closest_tri[:, 1] - closest_tri[:, 0]
-    v0v2 = closest_tri[:, 2] - closest_tri[:, 0]
-    v1v2 = closest_tri[:, 2] - closest_tri[:, 1]
-    v2v0 = closest_tri[:, 0] - closest_tri[:, 2]
-    v1p = closest - closest_tri[:, 1]
-    v2p = closest - closest_tri[:, 2]
-    N = torch.cross(v0v1, v0v2, dim=1)
-    denom = (N * N).sum(1)
-    u = (N * torch.cross(v1v2, v1p, dim=1)).sum(1) / denom
-    v = (N * torch.cross(v2v0, v2p, dim=1)).sum(1) / denom
-    w = 1 - u - v
-    barycentric = torch.stack([u, v, w], dim=1)
-    T_interp = (T[f3[f_id]] * barycentric[..., None, None]).sum(axis=1)
-    return torch.inverse(T_interp), f_id.cpu().numpy(), signed_dist.cpu().numpy()
+    bary, f_id, signed_dist = _closest_barycentric(p.contiguous(), verts, f3, _diff_mesh(entry, verts))
+    blended = torch.einsum('nk,nkij->nij', bary.to(T.dtype), T[f3[f_id]])
+    return torch.linalg.inv(blended), f_id.cpu().numpy(), signed_dist.cpu().numpy()

@@ -110,15 +110,19 @@ def _transmittance_chunk(raw, z, dz, d, live, counts, R, s0, c, S, T):
 
 
 def merged_intervals(z_lists):
-    """For every sample of every list ([R, S_k] each, sorted per ray): the distance to its successor in the MERGED order of all the
+    """For every sample of every list ([R, S_k] each, sorted per ray; k <= 4): the distance to its successor in the MERGED order of all the
     lists (stable, earlier list first -- the order of the reference's sort(cat(...)), render_utils.py:330-337, 441-448); the last
     sample of the merged list gets raw2outputs' 1e10 (render_utils.py:86).  -> one [R, S_k] tensor per list.  These are the
-    intervals the samples will be composited with once the lists are merged: what an early-termination cut has to be decided on."""
-    z = torch.cat(z_lists, 1)
-    zs, order = torch.sort(z, dim=1, stable=True)
-    dz_s = torch.cat([zs[:, 1:] - zs[:, :-1], torch.full_like(zs[:, :1], 1e10)], 1)
-    dz = torch.empty_like(z).scatter_(1, order, dz_s)
-    return [t.contiguous() for t in torch.split(dz, [zl.shape[1] for zl in z_lists], 1)]
+    intervals the samples will be composited with once the lists are merged: what an early-termination cut has to be decided on.
+    One kernel (nm_merged_intervals: a binary search per foreign list, nothing sorted)."""
+    _lib.require_gpu()
+    k, R = len(z_lists), z_lists[0].shape[0]
+    zs = [z.to(torch.float32).contiguous() for z in z_lists]
+    dz = [torch.empty_like(z) for z in zs]
+    arr = ctypes.c_void_p * k
+    _lib.check(_lib.lib().nm_merged_intervals(k, arr(*[z.data_ptr() for z in zs]), (ctypes.c_int * k)(*[int(z.shape[1]) for z in zs]), R,
+                                              arr(*[x.data_ptr() for x in dz]), _lib.stream_ptr()), "nm_merged_intervals")
+    return dz
 
 
 def march_pass_rays(net, o, d, z, eps, chunk=None, precision=None, role='shading', stats=None, sigma_only=False, occluder=None,

@@ -202,6 +202,19 @@ def _pad4(x):
     return out
 
 
+def _input_versions(*xs):
+    """_pad4 hands back an ALIAS of the caller's tensor when nothing needs padding (detach() shares the version counter): the versions are
+    recorded at forward and compared at backward, so an in-place edit of pts / dirs between the two passes (`can_pts += offset`) is an error
+    instead of a silently wrong input gradient -- what ctx.save_for_backward would have checked had the tensors gone through it"""
+    return tuple(None if x is None else x._version for x in xs)
+
+
+def _check_input_versions(ctx, *xs):
+    if getattr(ctx, 'in_versions', None) is not None and _input_versions(*xs) != ctx.in_versions:
+        raise _lib.NeumanHipError("an input of the net (points / directions) was modified in place between the forward and the backward pass of a "
+                                  "training step: the backward pass reads the tensor the forward was given (clone it before editing)")
+
+
 def _fused_ok(net):
     nerf = net.nerf
     return (FUSED_FORWARD and GEMM_PRECISION == 'mixed16' and hasattr(net, 'train_handle') and nerf.use_viewdirs and net.pos_pe.input_dims == 3
@@ -267,6 +280,7 @@ class _MLP(torch.autograd.Function):
                 H, feat = [acts[i] for i in range(8)], acts[8]
             ctx.pk, ctx.X0, ctx.D0, ctx.H, ctx.feat, ctx.hv, ctx.n, ctx.net = pk, X0, D0, H, feat, hv, n, net
             ctx.p4, ctx.d4 = p4, d4
+            ctx.in_versions = _input_versions(p4, d4)
             ctx.acts, ctx.bits = acts, bits
             ctx.versions = [p._version for p in plist]          # the backward pass repacks W^T from the live parameters: they must still be these
             ctx.want_feat = want_feat
@@ -303,6 +317,7 @@ class _MLP(torch.autograd.Function):
             _gemm(0, 0, n4, 4, width, h, width, pk.Wo4, width, raw, 4, bias=pk.bo4, flags=BIAS)
         ctx.pk, ctx.X0, ctx.D0, ctx.H, ctx.feat, ctx.hv, ctx.n, ctx.net = pk, X0, D0, H, feat, hv, n, net
         ctx.p4, ctx.d4 = p4, d4
+        ctx.in_versions = _input_versions(p4, d4)
         ctx.h16 = ctx.x0h = ctx.versions = None
         return raw[:n] if views else raw[:n, :pk.n_out]
 
@@ -315,6 +330,7 @@ class _MLP(torch.autograd.Function):
         views = nerf.use_viewdirs
         want_in = ctx.needs_input_grad[1] or (views and ctx.needs_input_grad[2])
         dev = ctx.p4.device
+        _check_input_versions(ctx, ctx.p4, ctx.d4)
         n4, width, half = ctx.p4.shape[0], nerf.width, nerf.width // 2
         if getattr(ctx, 'versions', None) is not None and (FUSED_BACKWARD or ctx.h16 is not None):
             # nm_mlp_backward_chain repacks W^T from the LIVE parameters while the masks and the weight-gradient operands are the forward's:
@@ -703,6 +719,7 @@ class _ViewsHead(torch.autograd.Function):
         ctx.net, ctx.pk, ctx.f4, ctx.d4, ctx.D0, ctx.hv, ctx.n = net, pk, f4, d4, D0, hv, n
         ctx.versions = [p._version for p in (Wv, bv, Wr, br)]
         ctx.live = (Wv, bv, Wr, br)
+        ctx.in_versions = _input_versions(f4, d4)
         return raw[:n]
 
     @staticmethod
@@ -710,6 +727,7 @@ class _ViewsHead(torch.autograd.Function):
         net, pk, f4, d4, D0, hv, n = ctx.net, ctx.pk, ctx.f4, ctx.d4, ctx.D0, ctx.hv, ctx.n
         if [p._version for p in ctx.live] != ctx.versions:
             raise _lib.NeumanHipError("a parameter of the views head was modified in place between the forward and the backward pass of a training step")
+        _check_input_versions(ctx, f4, d4)
         nerf = net.nerf
         dev = f4.device
         n4, width, half = f4.shape[0], nerf.width, nerf.width // 2

@@ -106,3 +106,12 @@ def cross_list_ties(z_lists, zero=None):
         isz = np.take_along_axis(zmask, ss, 1)
         tie &= ~(isz[:, 1:] & isz[:, :-1])
     return tie.any(1) & ~np.isnan(z).any(1)
+
+
+def arbiter(g, which, big=False):
+    """The ARBITER of an end-to-end statement on one of the posed scenes: the reference's own renderer run in float64 on the frame
+    (tests/golden/arbiter.npz, tests/golden/make_golden_f64.py) beside its float32 run (posed.npz / posed_big.npz: `g`) -> the dict
+    oracle.attribution.against_arbiter takes"""
+    from oracle import attribution
+    a = attribution.load_arbiter(which + ('big' if big else ''))
+    return {'rgb64': a['rgb64'].reshape(-1, 3), 'rgb32': g[f'{which}_rgb'].reshape(-1, 3)}

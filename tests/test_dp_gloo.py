@@ -1,4 +1,4 @@
-"""CPU, gloo, world 2: the collectives of neuman_hip/dp.py (data-parallel training of the background NeRF; reference train.py:26-28) on a toy
+"""CPU, gloo, world 2 and 8: the collectives of neuman_hip/dp.py (data-parallel training of the background NeRF; reference train.py:26-28) on a toy
 model -- the flat gradient buffer's ONE all_reduce gives the full-batch gradient when every rank's loss is its share of the global mean, the
 small all_gather carries counts and maxima, broadcast_parameters makes the ranks equal, shard_batch takes rank-strided rays."""
 import os
@@ -55,12 +55,13 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_flat_gradient_all_reduce_gives_the_full_batch_gradient():
+@pytest.mark.parametrize("world", [2, 8])
+def test_flat_gradient_all_reduce_gives_the_full_batch_gradient(world):
+    """world 8: the node's real size -- eight normaliser contributions in the all_gather, ranks with 5 and with 4 of the 37 rays"""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
@@ -71,8 +72,9 @@ def test_flat_gradient_all_reduce_gives_the_full_batch_gradient():
         p.join(timeout=60)
         assert p.exitcode == 0
     net = _model(10)                                               # rank 0's weights are everybody's
-    for a, b in zip(got[0][2], got[1][2]):
-        np.testing.assert_array_equal(a, b)
+    for other in got[1:]:
+        for a, b in zip(got[0][2], other[2]):
+            np.testing.assert_array_equal(a, b)
     for a, b in zip(got[0][2], net.parameters()):
         np.testing.assert_array_equal(a, b.detach().numpy())
     batch = _batch()
@@ -95,3 +97,48 @@ def test_single_process_without_a_group_is_the_identity():
     assert vals == [3.0] and all(torch.equal(a, p.grad) for a, p in zip(before, net.parameters()))
     assert dp.rank_world() == (0, 1) and dp.shard_batch({'origin': x}, 0, 1)['origin'] is x
     assert dp.all_gather_floats([1.0, torch.tensor(2.0)]).tolist() == [[1.0, 2.0]]
+
+
+def _optim_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _model(3)
+    optim = torch.optim.Adam(net.parameters(), lr=1e-3 * (rank + 1))
+    for _ in range(rank + 1):                                      # ranks "resumed" from different checkpoints: other moments, other step counts
+        optim.zero_grad()
+        net(torch.full((4, 5), float(rank + 1))).sum().backward()
+        optim.step()
+    dp.broadcast_parameters([net])
+    dp.broadcast_optimizer_state(optim)
+    st = optim.state_dict()
+    q.put((rank, [p.detach().numpy() for p in net.parameters()],
+           {k: {n: (v.numpy() if torch.is_tensor(v) else v) for n, v in e.items()} for k, e in st['state'].items()}, st['param_groups'][0]['lr']))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_optimizer_state_follows_rank_0_after_a_resume():
+    """broadcast_parameters after resume() made the weights equal but left Adam's moments and step counts per rank"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_optim_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for other in got[1:]:
+        assert other[3] == got[0][3] == 1e-3
+        for a, b in zip(got[0][1], other[1]):
+            np.testing.assert_array_equal(a, b)
+        assert other[2].keys() == got[0][2].keys()
+        for k in got[0][2]:
+            for n in got[0][2][k]:
+                np.testing.assert_array_equal(np.asarray(got[0][2][k][n]), np.asarray(other[2][k][n]))
+            assert float(np.asarray(other[2][k]['step'])) == 1.0

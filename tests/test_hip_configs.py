@@ -7,10 +7,10 @@
 
 Two kinds of statement are made:
 
-* end to end against the oracle's own rendering, with the deviation ATTRIBUTED quantitatively (oracle/attribution.py): the device's
-  shading pass on the oracle's samples and the oracle's on the device's both within 1e-4 on every ray, the coarse weights within
-  2e-5, every ray beyond 1e-4 among the 6 % most displaced ones, a first-order bound with a measured Lipschitz constant on every
-  ray, and no more such rays than 1.5 x what the oracle and the reference's own renderer disagree on on the same rays;
+* end to end, with the deviation ATTRIBUTED quantitatively (oracle/attribution.py): the device's shading pass on the oracle's samples and
+  the oracle's on the device's both within 1e-4 on every ray, the coarse weights within 2e-5, every ray beyond 1e-4 among the 6 % most
+  displaced ones, and -- against the ARBITER, the reference's own renderer run in float64 (tests/golden/arbiter.npz) -- no more rays beyond
+  1e-4 than the reference's own float32 run leaves (+ a quarter);
 * conditional parity at 1e-4 on EVERY pixel: the oracle evaluates its networks, merge and compositing on the device's own
   sample positions and (for posed humans) the device's own warped points -- the renderer's product code path is what
   runs on the device (the `trace` hook records its intermediates), the warp itself is checked against the oracle in
@@ -54,25 +54,35 @@ def oracle_two_pass(nets, o, d, near, far, S, NI):
 
 @pytest.mark.parametrize("precision", ["mixed", "fp16x3", "bf16x3"])
 def test_c2_slice_vs_oracle(G, precision):
-    """2048 rays from the middle of the 800x800 frame, 128 + 128 samples, against the oracle end to end: statements (a)-(d) of
-    oracle/attribution.py (the slice's floor and Lipschitz constant: profiles/r03_parity_floor.json, r03_lipschitz.json)"""
+    """2048 rays from the middle of the 800x800 frame, 128 + 128 samples, end to end: statements (a)-(c) of oracle/attribution.py against the
+    oracle, statement (d) against the ARBITER -- the reference's own render_vanilla run in float64 on these very rays (tests/golden/arbiter.npz,
+    case 'c2'): the device may be beyond 1e-4 of it on no more rays than the reference's own float32 run is (+ margin) -- and, conditional on
+    the REFERENCE's sample positions (its float64 run's), every ray within 1e-4 of the reference's float64 pixels."""
     from oracle import attribution
     coarse, fine = G.syn.make_joiner(0).cuda(), G.syn.make_joiner(1).cuda()
     cap = G.syn.SimpleCapture(800, 800)
     o, d = O.shot_all_rays(cap.intrinsic_matrix, cap.cam_pose.camera_to_world, cap.shape)
-    sl = slice(400 * 800 + 100, 400 * 800 + 100 + 2048)
+    arb = attribution.load_arbiter('c2')
+    first = int(arb['first'])
+    sl = slice(first, first + 2048)
+    assert first == 400 * 800 + 100
     o, d = o[sl].astype(np.float32), d[sl].astype(np.float32)
     ora = attribution.oracle_two_pass([G.nets[0][1], G.nets[1][1]], o, d, 0.0, 3.14, 128, 128)
     rgb, z, w, rgb_on = attribution.device_two_pass(G.render, coarse, fine, cu(o), cu(d), 0.0, 3.14, 128, 128, cu(ora["z"]), precision=precision)
-    print(f"[C2 {precision}] PSNR vs oracle {psnr(rgb, ora['rgb']):.1f} dB")
-    rep, fails = attribution.two_pass(rgb, z, w, rgb_on, ora["rgb"], ora["z"], ora["w"], ora["fine_on"], case="c2_slice_2048_128+128",
-                                      tag=f"C2 {precision}")
+    print(f"[C2 {precision}] PSNR vs oracle {psnr(rgb, ora['rgb']):.1f} dB, vs the reference in float64 {psnr(rgb, arb['rgb64']):.1f} dB "
+          f"(the reference's own float32 frame: {psnr(arb['rgb32'], arb['rgb64']):.1f} dB)")
+    rep, fails = attribution.two_pass(rgb, z, w, rgb_on, ora["rgb"], ora["z"], ora["w"], ora["fine_on"], arbiter=arb, tag=f"C2 {precision}")
+    # conditional on the reference's own (float64) sample positions: the device's shading pass against the reference's float64 pixels, every ray
+    rgb_on64 = G.render.render_vanilla_rays(coarse, fine, cu(o), cu(d), 0.0, 3.14, 128, 128, True, precision=precision, given={'bkg_z': cu(arb['z64'])})[0].cpu().numpy()
+    e64 = np.abs(rgb_on64.astype(np.float64) - arb['rgb64']).max(-1)
+    print(f"[C2 {precision}] device shading pass on the reference's float64 sample positions vs the reference's float64 pixels: Linf {e64.max():.2e} (every ray)")
+    assert e64.max() < 1e-4
     if precision == "bf16x3":
         # round 1's parity mode, kept as a cross-check of the float32-class default: its sigma error (2e-5) displaces more samples,
-        # so statements (d) and (c)-rank are relaxed for it (measured 3x the fp16x3 count); everything conditional on the samples, the
-        # coarse weights and the first-order bound still bind
+        # so statements (d) and (c)-rank are relaxed for it (measured 3x the fp16x3 count); everything conditional on the samples and the
+        # coarse weights still binds
         fails = [f for f in fails if not (f.startswith("(d)") or "most displaced" in f)]
-        assert rep["rays_gt_1e-4"] <= 60
+        assert rep["d_device_vs_reference_f64"]["rays_gt_1e-4"] <= 4 * rep["d_allowed_rays_gt_1e-4"]
     assert not fails, fails
     assert psnr(rgb, ora["rgb"]) > (80.0 if precision != "bf16x3" else 70.0)
 

@@ -220,3 +220,30 @@ def test_renderers_with_termination(body, which):
     e = (a - b).abs().max().item()
     print(msg + f", colour Linf vs every sample {e:.2e} (bound {bound:g})" + (" [semi-transparent body]" if semi else ""))
     assert (semi or he < 0.8 * ht) and e <= bound
+
+
+@pytest.mark.parametrize("sizes", [(256, 128), (320, 192, 192, 192), (7,), (5, 1, 3)])
+def test_merged_intervals_equal_the_sorted_lists_differences(sizes):
+    """render_utils.merged_intervals (nm_merged_intervals: binary searches, nothing sorted) against the definition: stable argsort of
+    cat(lists) (ties: the earlier list first, the order of render_utils.py:330-337), differences of the sorted values, 1e10 at the end,
+    scattered back -- bit for bit, with exact cross-list ties and repeated values inside a list in the data"""
+    from neuman_hip import render_utils
+    rng = np.random.default_rng(sum(sizes))
+    R = 777
+    lists = [np.sort(rng.uniform(0.5, 4.0, size=(R, S)).astype(np.float32), 1) for S in sizes]
+    if len(lists) > 1:
+        lists[1][:, 0] = lists[0][:, min(2, sizes[0] - 1)]                      # a cross-list tie on every ray
+        lists[-1][::3, -1] = lists[0][::3, -1]                                   # ... and one at the very end of the merged list
+    if sizes[0] > 4:
+        lists[0][:, 4] = lists[0][:, 3]                                          # a repeated value inside a list
+    z = np.concatenate(lists, 1)
+    order = np.argsort(z, 1, kind='stable')
+    zs = np.take_along_axis(z, order, 1)
+    dz_s = np.concatenate([zs[:, 1:] - zs[:, :-1], np.full((R, 1), 1e10, np.float32)], 1).astype(np.float32)
+    want = np.empty_like(z)
+    np.put_along_axis(want, order, dz_s, 1)
+    got = render_utils.merged_intervals([cu(x) for x in lists])
+    off = 0
+    for S, g in zip(sizes, got):
+        assert np.array_equal(g.cpu().numpy(), want[:, off:off + S])
+        off += S

@@ -84,7 +84,7 @@ def test_c1_two_pass_frame(G, golden):
     ora = attribution.oracle_two_pass([G.nets[0][1], G.nets[1][1]], o, d, 0.0, 3.14, 32, 32)
     rgb_a, zf, w_a, rgb_on = attribution.device_two_pass(G.render, coarse, fine, o_t, d_t, 0.0, 3.14, 32, 32, cu(ora["z"]))
     assert np.array_equal(rgb_a, rgb.reshape(-1, 3))
-    rep, fails = attribution.two_pass(rgb_a, zf, w_a, rgb_on, ora["rgb"], ora["z"], ora["w"], ora["fine_on"], case="c1_64x64_32+32", tag="C1 two-pass vs oracle")
+    rep, fails = attribution.two_pass(rgb_a, zf, w_a, rgb_on, ora["rgb"], ora["z"], ora["w"], ora["fine_on"], arbiter=attribution.load_arbiter('c1'), tag="C1 two-pass vs oracle")
     assert not fails, fails
     z = O.ray_to_samples(o, d, np.zeros((R, 1), np.float32), np.full((R, 1), 3.14, np.float32), 32)[2]
     c_depth = compositing.raw2outputs(nerf_mlp.joiner_forward(*G.nets[1][1], (o[:, None, :] + d[:, None, :] * zf[..., None]).astype(np.float32),

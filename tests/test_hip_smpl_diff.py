@@ -185,3 +185,27 @@ def test_mesh_update_equals_a_fresh_build():
     cold = ray_utils.warp_points_to_canonical_diff(pts, v, faces, T)
     for a, b in zip(warm, cold):
         assert torch.equal(a, b)
+
+
+def test_mesh_update_with_non_finite_vertices_is_defined_and_recovers():
+    """nm_mesh_update takes no read-back, so vertices that went NaN (diverged SMPL parameters) are not refused the way nm_mesh_create
+    refuses them; the search must then not descend a tree built from NaN boxes: it finishes (the all-triangles loop on the device-side flag), and
+    the next update with finite vertices gives a fresh build's answers again, bit for bit"""
+    from neuman_hip import ray_utils, synthetic
+    model = synthetic.smpl_like_model(0)
+    faces = model['f'].astype(np.int32)
+    v0 = torch.as_tensor(np.asarray(model['v_template'], np.float32)).cuda()
+    g = torch.Generator(device='cuda').manual_seed(3)
+    pts = (v0[torch.randint(0, v0.shape[0], (2048,), device='cuda', generator=g)] + 0.05 * torch.randn((2048, 3), device='cuda', generator=g)).contiguous()
+    with pytest.raises(Exception):
+        ray_utils.Mesh(torch.full_like(v0, float('nan')), faces, None, 'cuda')          # creation still refuses
+    mesh = ray_utils.Mesh(v0, faces, None, 'cuda')
+    want = ray_utils.signed_distance_dev(pts, mesh)
+    bad = v0.clone()
+    bad[100] = float('nan')
+    s, f, c = ray_utils.signed_distance_dev(pts, mesh.update(bad))
+    torch.cuda.synchronize()                                                            # (finishes: no descent of NaN boxes)
+    assert int(f.min()) >= 0 and int(f.max()) < faces.shape[0]
+    got = ray_utils.signed_distance_dev(pts, mesh.update(v0))
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)

@@ -1,4 +1,4 @@
-"""Multi-rank ray-tile sharding + frame gather, on CPU with gloo (world_size 1, 2 and 4)."""
+"""Multi-rank ray-tile sharding + frame gather, on CPU with gloo (world_size 1, 2, 3, 4 and 8: the node's real size)."""
 import os
 import socket
 
@@ -54,7 +54,7 @@ def _worker(rank, world, port, total, tile, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,total,tile", [(2, 1000, 64), (4, 777, 32)])
+@pytest.mark.parametrize("world,total,tile", [(2, 1000, 64), (4, 777, 32), (8, 5000, 128)])
 def test_sharded_render_matches_single_rank(world, total, tile):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -97,7 +97,8 @@ def _frame_worker(rank, world, port, total, max_tile, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,total,max_tile", [(2, 1003, 64), (3, 500, 1024), (3, 2, 64)])      # (the last: a rank without rays)
+@pytest.mark.parametrize("world,total,max_tile", [(2, 1003, 64), (3, 500, 1024), (3, 2, 64),      # (3, 2): a rank without rays
+                                                  (8, 6401, 100), (8, 5, 64)])                    # the node's size: 8 padded shards; three ranks without rays
 def test_frame_drivers_shard_and_assemble_tuples(world, total, max_tile):
     """parallel.render_frame_sharded (what render_vanilla / render_smpl_nerf / render_hybrid_nerf / render_hybrid_nerf_multi_persons call
     under a process group): interleaved tiles, the tuple's columns through one gather, the frame on rank 0 only, bit-identical"""
@@ -131,20 +132,24 @@ def test_world_size_one_needs_no_process_group():
     assert torch.equal(frame, _fake_render(o, d))
 
 
-def test_bench_launches_itself_at_n_gt_1():
-    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment re-executes under torch.distributed.run, both ranks reach
-    init_process_group and assemble a frame through parallel.gather_frame (gloo + host tensors: what runs without GPUs)."""
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_launches_itself_at_n_gt_1(n):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment re-executes under torch.distributed.run, all ranks reach
+    init_process_group and assemble a frame through parallel.gather_frame (gloo + host tensors: what runs without GPUs); N = 8 is
+    the driver's own launch at the node's size."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--launch-check"], env=env,
-                       capture_output=True, text=True, timeout=600)
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--backend", "gloo", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line == {"launch_check": True, "world": 2, "backend": "gloo", "frame_assembled": True, "tiles_per_rank": [8, 8]}
+    assert line["launch_check"] and line["world"] == n and line["backend"] == "gloo" and line["frame_assembled"]
+    assert len(line["tiles_per_rank"]) == n and sum(line["tiles_per_rank"]) * line["tile"] >= 1000 and max(line["tiles_per_rank"]) - min(line["tiles_per_rank"]) <= 1
 
 
 def test_bench_refuses_more_gpus_than_visible_with_a_json_line():
