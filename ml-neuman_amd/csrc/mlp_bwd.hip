@@ -14,6 +14,7 @@
 // the tile's column sums inside the wave (its 32 features' 128 samples are all its own) and writes the split bf16 operand of the next stage.
 // The weight-gradient products stay separate launches: their 256 x 256 accumulators per layer do not fit a workgroup beside this.
 #include "mlp_device.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -56,13 +57,19 @@ __device__ __forceinline__ unsigned pack_f16(float a, float b, float sc) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
 }
 
-template <int MODE>                                                 // 0: from dz_top = dZ_7; 1: from d_feat / d_raw; 2: from d_raw alone (the views layer's adjoint too);
+// HALF (modes 2 and 3, the 16-bit form only): the operand of every stage is dZ * s as ONE fp16 number -- the very value the stage stores for the
+// weight-gradient products -- against split-fp16 weights (W^T * 2^8 as hi + lo, bwd_pack_kernel): two MFMAs per k-step instead of three and half the LDS
+// operand traffic.  What is propagated is then exactly what is stored: the step's weight gradients are the gradients of ONE chain of fp16-rounded dZ's
+// (float32 accumulation everywhere), instead of float32-class dZ's whose fp16 copies feed the products.  Accumulators carry 2^8 s dZ; `amax` scales as before.
+template <int MODE, bool HALF = false>                              // 0: from dz_top = dZ_7; 1: from d_feat / d_raw; 2: from d_raw alone (the views layer's adjoint too);
                                                                     // 3: the plain-head net from d_out [n][4]: stage 0 = d_out W_out (K = 4, as two k-steps), layers 7 .. 0
 __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs a) {
     constexpr bool HEAD = MODE >= 1, NET = MODE == 2, PLAIN = MODE == 3;
     constexpr int NS = HEAD ? kBwdSlots : kBwdStages;               // stages of a tile; stage s reads image slot s + (HEAD ? 0 : 1)
+    static_assert(!HALF || NET || PLAIN, "the two-MFMA form exists for the whole-pass modes");
     __shared__ uint4 lds[LDS_U4];
-    constexpr int PREC = NM_PREC_BF16X3;
+    constexpr int PREC = HALF ? kPrecF16W2 : NM_PREC_BF16X3;
+    constexpr float kWScale = 256.f;                                 // HALF: the image holds W^T * 2^8 (mlp_device.h: lo parts of small weights stay normal numbers)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, s = lane & 31;
@@ -71,6 +78,16 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
     auto wo = [](int j, int blk) { return (j + (HEAD ? 0 : 1)) * kBwdStageBytes + blk * 16 * nm::kStepBytes; };
     const int64_t ntiles = (a.n + kTileM - 1) / kTileM;
     const float sc16 = a.dz16 ? nm_dz_scale(*a.amax) : 1.f;
+    const float pk_sc = HALF ? 1.f : sc16;                           // HALF: the values in flight are s dZ already
+    const float out_sc = HALF ? 1.f / sc16 : 1.f;                    //       and float32 results (copies, column sums) are divided by s (a power of two: exact)
+    auto unscale = [&](f32x16 (&acc)[4]) {                           // 2^8 s dZ -> s dZ
+        if (HALF) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mb][r] *= (1.f / kWScale);
+        }
+    };
     const int vo = kBwdVOff + w * 8 * nm::kStepBytes;               // this wave's block of the views-back stage
     const int first = NET ? vo : wo(0, w);                          // the first run of a tile
     WPre W;
@@ -104,10 +121,14 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                         *reinterpret_cast<float4*>(a.dhv32 + i * 128 + f0 + 8) = make_float4(v[4], v[5], v[6], v[7]);
                     }
                 }
-                uint4 hi, lo;
-                split8<false, false>(v, hi, lo);
-                lds[H_BASE + c * kChunkU4 + row] = hi;
-                lds[H_BASE + c * kChunkU4 + kLoU4 + row] = lo;
+                if (HALF) {
+                    lds[H_BASE + c * kChunkU4 + row] = make_uint4(pack_f16(v[0], v[1], sc16), pack_f16(v[2], v[3], sc16), pack_f16(v[4], v[5], sc16), pack_f16(v[6], v[7], sc16));
+                } else {
+                    uint4 hi, lo;
+                    split8<false, false>(v, hi, lo);
+                    lds[H_BASE + c * kChunkU4 + row] = hi;
+                    lds[H_BASE + c * kChunkU4 + kLoU4 + row] = lo;
+                }
             }
             __syncthreads();
             // ---- views-back stage: d_feat [32 w .. 32 w + 31][128 samples] = W_views[:, :256]^T block x d_hv (K = 128), on top of a.d_feat when given:
@@ -120,10 +141,13 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                 for (int q = 0; q < 4; ++q) {
                     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (a.d_feat && row < a.n) t = *reinterpret_cast<const float4*>(a.d_feat + row * 256 + 32 * w + 4 * g + 8 * q);
-                    acc[mb][4 * q] = t.x; acc[mb][4 * q + 1] = t.y; acc[mb][4 * q + 2] = t.z; acc[mb][4 * q + 3] = t.w;
+                    const float in_sc = HALF ? kWScale * sc16 : 1.f;
+                    acc[mb][4 * q] = t.x * in_sc; acc[mb][4 * q + 1] = t.y * in_sc; acc[mb][4 * q + 2] = t.z * in_sc; acc[mb][4 * q + 3] = t.w * in_sc;
                 }
             }
             k_run<4, PREC>(acc, W, wsrc, voff, vo, wo(0, w), lds + H_BASE + g * kChunkU4 + s, 8);
+            unscale(acc);
+            uint4 nx[4][2];                                              // HALF: the next stage's operand = the stored fp16 values
             float cs[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) cs[r] = 0.f;
@@ -134,11 +158,13 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                 unsigned pk[8];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    pk[2 * q] = pack_f16(acc[mb][4 * q], acc[mb][4 * q + 1], sc16);
-                    pk[2 * q + 1] = pack_f16(acc[mb][4 * q + 2], acc[mb][4 * q + 3], sc16);
+                    pk[2 * q] = pack_f16(acc[mb][4 * q], acc[mb][4 * q + 1], pk_sc);
+                    pk[2 * q + 1] = pack_f16(acc[mb][4 * q + 2], acc[mb][4 * q + 3], pk_sc);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) cs[4 * q + j] += live ? acc[mb][4 * q + j] : 0.f;
                 }
+                nx[mb][0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                nx[mb][1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
                 if (live && a.dfeat16) {
                     uint4* o = a.dfeat16 + row * 32 + 4 * w + g;
                     o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
@@ -150,17 +176,25 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                 float v = cs[r];
 #pragma unroll
                 for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-                cs[r] = v;
+                cs[r] = v * out_sc;
             }
             if (s == 0) {                                               // feature_linear's bias gradient: column NS of the per-tile sums
                 float* o = a.colsum + ((int64_t)tile * (NS + 1) + NS) * 256 + 32 * w + 4 * g;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(o + 8 * q) = make_float4(cs[4 * q], cs[4 * q + 1], cs[4 * q + 2], cs[4 * q + 3]);
             }
-            ActRegs<4> ar;
-            convert_act<4, false, PREC>(acc, ar);
-            __syncthreads();                                           // every wave has finished reading d_hv
-            write_act<4, PREC>(ar, lds, w, 0, g, s);
+            if (HALF) {
+                __syncthreads();                                       // every wave has finished reading d_hv
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int qp = 0; qp < 2; ++qp) lds[H_BASE + (4 * w + 2 * qp + g) * kChunkU4 + 32 * mb + s] = nx[mb][qp];
+            } else {
+                ActRegs<4> ar;
+                convert_act<4, false, NM_PREC_BF16X3>(acc, ar);
+                __syncthreads();                                       // every wave has finished reading d_hv
+                write_act<4, NM_PREC_BF16X3>(ar, lds, w, 0, g, s);
+            }
             __syncthreads();
         } else {
         // ---- dZ_7 of the tile -> split bf16 in LDS, k-slot order (chunk c, element e) = feature slot_feature(c, e): two runs of 4 features
@@ -179,10 +213,14 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                 const float4 lo4 = *reinterpret_cast<const float4*>(src), hi4 = *reinterpret_cast<const float4*>(src + 8);
                 v[0] = lo4.x; v[1] = lo4.y; v[2] = lo4.z; v[3] = lo4.w; v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
             }
-            uint4 hi, lo;
-            split8<false, false>(v, hi, lo);
-            lds[H_BASE + c * kChunkU4 + row] = hi;
-            lds[H_BASE + c * kChunkU4 + kLoU4 + row] = lo;
+            if (HALF) {
+                lds[H_BASE + c * kChunkU4 + row] = make_uint4(pack_f16(v[0], v[1], sc16), pack_f16(v[2], v[3], sc16), pack_f16(v[4], v[5], sc16), pack_f16(v[6], v[7], sc16));
+            } else {
+                uint4 hi, lo;
+                split8<false, false>(v, hi, lo);
+                lds[H_BASE + c * kChunkU4 + row] = hi;
+                lds[H_BASE + c * kChunkU4 + kLoU4 + row] = lo;
+            }
             if (HEAD && a.dfeat16 && i < a.n)                         // (v[e] = feature slot_feature(c, e): the chunk as it stands)
                 a.dfeat16[i * 32 + c] = make_uint4(pack_f16(v[0], v[1], sc16), pack_f16(v[2], v[3], sc16), pack_f16(v[4], v[5], sc16), pack_f16(v[6], v[7], sc16));
         }
@@ -196,6 +234,8 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
             k_run<4, PREC>(acc, W, wsrc, voff, wo(j, w), j + 1 < NS ? wo(j + 1, w) : first, lds + H_BASE + g * kChunkU4 + s, (PLAIN && j == 0) ? 2 : 16);
+            unscale(acc);
+            uint4 nx[4][2];
             // ---- mask with the saved activation of layer 6 - j, store the f32 copy, column sums
             const int layer = NS - 1 - j;                                // the layer whose saved output masks this stage's result (HEAD, j = 0: 7)
             const float* mask = a.acts + (int64_t)layer * a.n * 256;
@@ -219,7 +259,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                 const bool live = row < a.n;
                 const int64_t off = (live ? row : 0) * 256 + 32 * w + 4 * g;
                 if (HEAD && !PLAIN && j == 0) {                           // + d sigma x alpha_linear's row (models/vanilla.py:133)
-                    const float ds = live ? a.d_raw[row * 4 + 3] : 0.f;
+                    const float ds = live ? a.d_raw[row * 4 + 3] * (HALF ? sc16 : 1.f) : 0.f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mb][r] = fmaf(ds, wa[r], acc[mb][r]);
                 }
@@ -240,11 +280,13 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                     v.z = k2 ? v.z : 0.f;
                     v.w = k3 ? v.w : 0.f;
                     acc[mb][4 * q] = v.x; acc[mb][4 * q + 1] = v.y; acc[mb][4 * q + 2] = v.z; acc[mb][4 * q + 3] = v.w;
-                    if (live && out) *reinterpret_cast<float4*>(out + off + 8 * q) = v;
-                    pk[2 * q] = pack_f16(v.x, v.y, sc16);
-                    pk[2 * q + 1] = pack_f16(v.z, v.w, sc16);
+                    if (live && out) *reinterpret_cast<float4*>(out + off + 8 * q) = HALF ? make_float4(v.x * out_sc, v.y * out_sc, v.z * out_sc, v.w * out_sc) : v;
+                    pk[2 * q] = pack_f16(v.x, v.y, pk_sc);
+                    pk[2 * q + 1] = pack_f16(v.z, v.w, pk_sc);
                     cs[4 * q] += v.x; cs[4 * q + 1] += v.y; cs[4 * q + 2] += v.z; cs[4 * q + 3] += v.w;
                 }
+                nx[mb][0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                nx[mb][1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
                 if (live && out16) {                                      // registers 0..7 = chunk 4 w + g, 8..15 = chunk 4 w + 2 + g of the row
                     uint4* o = out16 + row * 32 + 4 * w + g;
                     o[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
@@ -256,7 +298,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                 float v = cs[r];
 #pragma unroll
                 for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-                cs[r] = v;
+                cs[r] = v * out_sc;
             }
             if (s == 0) {
                 float* o = a.colsum + ((int64_t)tile * (NS + (NET ? 1 : 0)) + j) * 256 + 32 * w + 4 * g;
@@ -264,10 +306,18 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
                 for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(o + 8 * q) = make_float4(cs[4 * q], cs[4 * q + 1], cs[4 * q + 2], cs[4 * q + 3]);
             }
             if (j + 1 < NS) {
-                ActRegs<4> ar;
-                convert_act<4, false, PREC>(acc, ar);
-                __syncthreads();                                   // every wave has finished reading this stage's operand
-                write_act<4, PREC>(ar, lds, w, 0, g, s);
+                if (HALF) {
+                    __syncthreads();                               // every wave has finished reading this stage's operand
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                        for (int qp = 0; qp < 2; ++qp) lds[H_BASE + (4 * w + 2 * qp + g) * kChunkU4 + 32 * mb + s] = nx[mb][qp];
+                } else {
+                    ActRegs<4> ar;
+                    convert_act<4, false, NM_PREC_BF16X3>(acc, ar);
+                    __syncthreads();                               // every wave has finished reading this stage's operand
+                    write_act<4, NM_PREC_BF16X3>(ar, lds, w, 0, g, s);
+                }
             }
             __syncthreads();
         }
@@ -277,7 +327,8 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_bwd_kernel(const BwdArgs
 // the transposed hidden weights of layers 7 .. 1 as MFMA A-operand fragments (mlp_layout.h: lane (g, s) of k-step t of output block nb holds
 // output feature 32 nb + s, k-slots (chunk 2 t + g, e = 0 .. 7)), split bf16: stage j multiplies dZ of layer i = 7 - j, so its "output
 // feature" is an INPUT feature of layer i (skip layer 5: behind the encoding columns) and its k index an OUTPUT feature of layer i
-__global__ __launch_bounds__(256) void bwd_pack_kernel(nm::DevParams P, int kpe, int kdir, int mode, uint8_t* __restrict__ img) {
+// half: split fp16 of W^T * 2^8 (nerf_mlp_bwd_kernel<., true>) instead of split bf16 of W^T
+__global__ __launch_bounds__(256) void bwd_pack_kernel(nm::DevParams P, int kpe, int kdir, int mode, int half, uint8_t* __restrict__ img) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int step = gid >> 6, lane = gid & 63;
     if (step >= kBwdSlots * 8 * 16 + 8 * 8) return;
@@ -299,7 +350,8 @@ __global__ __launch_bounds__(256) void bwd_pack_kernel(nm::DevParams P, int kpe,
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (2 * t + (lane >> 5) == 0 && e < 4) ? Wo[e * 256 + 32 * nb + (lane & 31)] : 0.f;
             uint4 hi, lo;
-            split8<false, false>(v, hi, lo);
+            if (half) split8<false, true>(v, hi, lo, 256.f);
+            else split8<false, false>(v, hi, lo);
             uint4* dst = reinterpret_cast<uint4*>(img + (int64_t)step * nm::kStepBytes) + lane;
             dst[0] = hi;
             dst[64] = lo;
@@ -313,7 +365,8 @@ __global__ __launch_bounds__(256) void bwd_pack_kernel(nm::DevParams P, int kpe,
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = Wi[(int64_t)nm::slot_feature(2 * t + (lane >> 5), e) * K + col];
     uint4 hi, lo;
-    split8<false, false>(v, hi, lo);
+    if (half) split8<false, true>(v, hi, lo, 256.f);
+    else split8<false, false>(v, hi, lo);
     uint4* dst = reinterpret_cast<uint4*>(img + (int64_t)step * nm::kStepBytes) + lane;
     dst[0] = hi;
     dst[64] = lo;
@@ -347,7 +400,12 @@ int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_
     const bool plain = h && h->plain;
     const bool head = d_feat != nullptr || net || plain;
     const int mode = plain ? 3 : (net ? 2 : (head ? 1 : 0));
-    hipLaunchKernelGGL(bwd_pack_kernel, dim3(((kBwdSlots * 8 * 16 + 8 * 8) * 64 + 255) / 256), dim3(256), 0, stream, P, kpe, h ? h->kdir : 0, mode, image);
+    // the two-MFMA form (single fp16 dZ against split-fp16 weights) is OPT-IN (NEUMAN_BWD_HALF=1): it takes 7 % off a training iteration (measured, round 6:
+    // 9.6 -> 8.9 ms) but what it propagates is dZ rounded to fp16 at EVERY layer -- 2^-12 per element, and a gradient that is itself a cancelling sum does not
+    // average that away: 3e-4 of the largest entry in tests/test_hip_train16.py's float64 comparison, against the 2e-5 the split-bf16 x3 default holds
+    static const bool half_ok = [] { const char* e = getenv("NEUMAN_BWD_HALF"); return e && e[0] == '1'; }();
+    const bool half = half_ok && (net || plain) && h && h->dz16 && h->amax;
+    hipLaunchKernelGGL(bwd_pack_kernel, dim3(((kBwdSlots * 8 * 16 + 8 * 8) * 64 + 255) / 256), dim3(256), 0, stream, P, kpe, h ? h->kdir : 0, mode, half ? 1 : 0, image);
     BwdArgs a;
     a.wpack = reinterpret_cast<const uint4*>(image);
     a.dz_top = dz_top; a.d_feat = d_feat; a.d_raw = d_raw; a.w_alpha = P.p[P_ALPHA_W];
@@ -366,7 +424,9 @@ int launch_mlp_bwd(const DevParams& P, int kpe, uint8_t* image, const float* dz_
     }
     const int grid = (int)(ntiles < cus ? ntiles : cus);
     const int ns = (head ? kBwdSlots : kBwdStages) + (net ? 1 : 0);     // rows of the bias-gradient block: the stages (+ feature_linear's)
-    if (plain) hipLaunchKernelGGL(nerf_mlp_bwd_kernel<3>, dim3(grid), dim3(kThreads), 0, stream, a);
+    if (plain && half) hipLaunchKernelGGL((nerf_mlp_bwd_kernel<3, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+    else if (net && half) hipLaunchKernelGGL((nerf_mlp_bwd_kernel<2, true>), dim3(grid), dim3(kThreads), 0, stream, a);
+    else if (plain) hipLaunchKernelGGL(nerf_mlp_bwd_kernel<3>, dim3(grid), dim3(kThreads), 0, stream, a);
     else if (net) hipLaunchKernelGGL(nerf_mlp_bwd_kernel<2>, dim3(grid), dim3(kThreads), 0, stream, a);
     else if (head) hipLaunchKernelGGL(nerf_mlp_bwd_kernel<1>, dim3(grid), dim3(kThreads), 0, stream, a);
     else hipLaunchKernelGGL(nerf_mlp_bwd_kernel<0>, dim3(grid), dim3(kThreads), 0, stream, a);

@@ -24,6 +24,10 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 // split (the per-stage factors sit behind the bias table).  Parts that fall below fp16's normal range lose at most
 // 2^-25 * 2^-5 (activations) / 2^-25 * 2^-k_s (weights) absolutely, flushed or not.
 constexpr bool is_split(int prec) { return prec == NM_PREC_BF16X3 || prec == NM_PREC_FP16X3; }
+// internal (mlp_bwd.hip's 16-bit form): split-fp16 WEIGHTS against a SINGLE fp16 operand -- two MFMAs per k-step (wl x, wh x), half the operand
+// reads; the operand is dZ * s already rounded to fp16 for the weight-gradient products, so nothing is dropped that the step keeps elsewhere
+constexpr int kPrecF16W2 = 101;
+constexpr bool w_is_split(int prec) { return is_split(prec) || prec == kPrecF16W2; }
 constexpr float kF16ActScale = 32.f;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -197,7 +201,7 @@ __device__ __forceinline__ void w_prefetch(WPre& W, __amdgpu_buffer_rsrc_t wsrc,
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         W.h[u] = ld_w(wsrc, voff, soff + u * nm::kStepBytes);
-        if (is_split(PREC)) W.l[u] = ld_w(wsrc, voff, soff + u * nm::kStepBytes + 1024);
+        if (w_is_split(PREC)) W.l[u] = ld_w(wsrc, voff, soff + u * nm::kStepBytes + 1024);
     }
 }
 
@@ -212,6 +216,14 @@ __device__ __forceinline__ void x_load(uint4 (&h)[MB], uint4 (&l)[MB], const uin
 __device__ __forceinline__ f16x8 as_f16x8(uint4 v) { return __builtin_bit_cast(f16x8, v); }
 template <int MB, int PREC>
 __device__ __forceinline__ void mfma_step(f32x16 (&acc)[MB], bf16x8 wh, bf16x8 wl, const uint4 (&xh)[MB], const uint4 (&xl)[MB]) {
+    if (PREC == kPrecF16W2) {
+        const f16x8 fh = __builtin_bit_cast(f16x8, wh), fl = __builtin_bit_cast(f16x8, wl);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl, as_f16x8(xh[mb]), acc[mb], 0, 0, 0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, as_f16x8(xh[mb]), acc[mb], 0, 0, 0);
+        return;
+    }
     if (PREC == NM_PREC_FP16X3) {                       // (the fragment registers hold fp16 bit patterns in this mode)
         const f16x8 fh = __builtin_bit_cast(f16x8, wh), fl = __builtin_bit_cast(f16x8, wl);
 #pragma unroll

@@ -21,7 +21,7 @@ namespace {
 // that do run the loop apply the same test per cluster of 64 consecutive vertices.
 constexpr int kMaxClusters = 512;                       // 64-vertex clusters: meshes up to 32 768 vertices (SMPL: 108)
 __global__ __launch_bounds__(256) void near_far_kernel(const float* __restrict__ origin, const float* __restrict__ direction,
-                                                       int64_t R, const float* __restrict__ verts, int V, float tau2,
+                                                       int64_t R, const float* __restrict__ verts, int V, float tau2, double tau2d,
                                                        float* __restrict__ near, float* __restrict__ far) {
     __shared__ float red[6][4];
     __shared__ float red_r[4];
@@ -114,14 +114,20 @@ __global__ __launch_bounds__(256) void near_far_kernel(const float* __restrict__
             const int v1 = use_cl ? (64 * k + 64 < V ? 64 * k + 64 : V) : V;
 #pragma unroll 4
             for (int v = use_cl ? 64 * k : 0; v < v1; ++v) {
-                const float vx = verts[v * 3 + 0] - ox, vy = verts[v * 3 + 1] - oy, vz = verts[v * 3 + 2] - oz;  // :209
-                const float z0 = vx * dx + vy * dy + vz * dz;                      // :210
-                const float nrm = sqrtf(vx * vx + vy * vy + vz * vz);              // torch.norm(orig_v, dim=2), :211
-                const float disc = tau2 - (nrm * nrm - z0 * z0);
-                if (disc >= 0.f) {                                                  // sqrt(negative) = NaN -> dropped
-                    const float dzv = sqrtf(disc);
-                    n = fminf(n, z0 - dzv);
-                    f = fmaxf(f, z0 + dzv);
+                // The reference's expression :209-211 -- tau^2 - (|v - o|^2 - z0^2) -- cancels two numbers of size |v - o|^2 ~ 10 down to ~ tau^2 =
+                // 0.04: in float32 the bracket is right to ~1e-6 and the root divides that by 2 dz, so near / far of a float32 evaluation carry
+                // 3e-5 (grazing rays 1e-3) -- the reference's own torch and numpy branches differ by that much, and every sample of the ray moves
+                // with them.  The differences v - o are exact in float32 for points this close; the products and the cancellation are done in
+                // float64 here (same rate as scalar float32 FMAs on gfx950), so near / far are the values of a float64 evaluation of the
+                // reference's formula rounded once: the device's bounds sit 1e-7 from the exact ones instead of adding a float32 error of their own
+                const float vxf = verts[v * 3 + 0] - ox, vyf = verts[v * 3 + 1] - oy, vzf = verts[v * 3 + 2] - oz;  // :209
+                const double vx = vxf, vy = vyf, vz = vzf;
+                const double z0 = fma(vz, (double)dz, fma(vy, (double)dy, vx * (double)dx));                       // :210
+                const double disc = tau2d - (fma(vz, vz, fma(vy, vy, vx * vx)) - z0 * z0);                  // :211
+                if (disc >= 0.0) {                                                  // sqrt(negative) = NaN -> dropped
+                    const float dzv = sqrtf((float)disc), z0f = (float)z0;
+                    n = fminf(n, z0f - dzv);
+                    f = fmaxf(f, z0f + dzv);
                 }
             }
         }
@@ -216,10 +222,11 @@ int nm_near_far(const float* origin, const float* direction, int64_t R, const fl
     NM_REQUIRE(R == 0 || (origin && direction && verts && near && far), "nm_near_far: null pointer");
     NM_REQUIRE(R >= 0 && V >= 1, "nm_near_far: bad sizes");
     if (R == 0) return NM_OK;
-    const float tau2 = (float)(geo_threshold * geo_threshold);             // python float ** 2, then f32 (ray_utils.py:211)
+    const float tau2 = (float)(geo_threshold * geo_threshold);             // python float ** 2 (ray_utils.py:211): float32 for the skip tests' margins,
+    const double tau2d = geo_threshold * geo_threshold;                    // the double itself in the discriminant
     const int blocks = (int)((R + 255) / 256);
     hipLaunchKernelGGL(near_far_kernel, dim3(blocks), dim3(256), 0, nm::as_stream(stream), origin, direction, R, verts, V,
-                       tau2, near, far);
+                       tau2, tau2d, near, far);
     return nm::check_launch("near_far_kernel");
 }
 

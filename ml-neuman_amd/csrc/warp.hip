@@ -251,6 +251,11 @@ struct Best {
     float thr2;     // prune a box when its squared distance exceeds this: (sqrt(d2) 1.0001 + slack)^2, capped at FLT_MAX
     int f;          // caller's face id of the best triangle
     V3 q;
+    // RUNNER (the warp's search): the best triangle that did NOT win -- float32 distances decide between two feet only down to ~1e-6 of the
+    // distance, and deep inside a body two feet on different faces are that close (every edge's bisector plane is a medial sheet there) while
+    // lying centimetres apart: the canonical point jumps with the choice.  tail_kernel settles winner against runner-up in float64.
+    float d2b;      // its squared distance (INFINITY: none)
+    int fb;         // its face id
 };
 
 // Exact closest point of sorted triangle t to p: the Voronoi-region test (Ericson, RTCD 5.1.5) without branches -- 64 lanes
@@ -259,6 +264,7 @@ struct Best {
 // |bc|^2 and va + vb + vc = |ab x ac|^2 -- are constants of the triangle, stored as reciprocals.  The seven regions become
 // selects applied in reverse priority.  Ties between equidistant triangles go to the lowest face id, so the result does not
 // depend on the visiting order; the face id is read only when a triangle ties or wins.
+template <bool RUNNER = false>
 __device__ __forceinline__ void exact_tri(const TriRec* __restrict__ rec, const int32_t* __restrict__ face_of, int t, V3 p, float slack,
                                           Best& b) {
     const float4 r0 = reinterpret_cast<const float4*>(&rec[t])[0];      // ax ay az abx
@@ -292,17 +298,24 @@ __device__ __forceinline__ void exact_tri(const TriRec* __restrict__ rec, const 
     if (dd <= b.d2) {
         const int f = face_of[t];
         if (dd < b.d2 || f < b.f) {
+            if (RUNNER) { b.d2b = b.d2; b.fb = b.f; }                      // the dethroned winner is the best loser so far
             b.d2 = dd; b.sd = sqrtf(dd); b.f = f; b.q = c;
             const float thr = b.sd * 1.0001f + slack;
             b.thr2 = fminf(thr * thr, FLT_MAX);
+        } else if (RUNNER && (dd < b.d2b || f < b.fb)) {                   // (an exact tie with the winner, higher face id: dd == d2 <= d2b)
+            b.d2b = dd; b.fb = f;
         }
+    } else if (RUNNER && dd <= b.d2b) {
+        const int f = face_of[t];
+        if (dd < b.d2b || f < b.fb) { b.d2b = dd; b.fb = f; }              // ties among losers: the lowest face id, whatever the visiting order
     }
 }
 
 // the all-triangles loop (search mode NM_SEARCH_ALL, and the fallback for points the tree search cannot order)
+template <bool RUNNER = false>
 __device__ __forceinline__ void search_all(const TriRec* __restrict__ rec, const int32_t* __restrict__ face_of, int F, V3 p, float slack,
                                            Best& b) {
-    for (int t = 0; t < F; ++t) exact_tri(rec, face_of, t, p, slack, b);
+    for (int t = 0; t < F; ++t) exact_tri<RUNNER>(rec, face_of, t, p, slack, b);
 }
 
 __device__ __forceinline__ float slab(float lo, float hi, float x) { return fmaxf(fmaxf(lo - x, x - hi), 0.f); }
@@ -341,7 +354,7 @@ inline int chunk_for(int64_t N) {
 }
 constexpr int kRefill = 8;                            // idle lanes that trigger a refill (or any, when no lane has work)
 
-template <bool SMALL>
+template <bool SMALL, bool RUNNER = false>      // RUNNER: f_out[i * f_stride + 1] = face id of the best loser within the pruning bound (else -1); f_stride >= 2
 __global__ __launch_bounds__(64) void search_kernel(Tree tr, int search_all_mode, const float* __restrict__ pts, int64_t N,
                                                                  const TriRec* __restrict__ rec, const int32_t* __restrict__ face_of,
                                                                  const Node* __restrict__ nodes, float* __restrict__ q_out,
@@ -385,7 +398,7 @@ __global__ __launch_bounds__(64) void search_kernel(Tree tr, int search_all_mode
     float slack = 0.f;
     const float mesh_scale = *tr.scale;
     Best b;
-    b.d2 = INFINITY; b.sd = INFINITY; b.thr2 = FLT_MAX; b.f = 0x7fffffff; b.q = p;
+    b.d2 = INFINITY; b.sd = INFINITY; b.thr2 = FLT_MAX; b.f = 0x7fffffff; b.q = p; b.d2b = INFINITY; b.fb = 0x7fffffff;
     bool has_cur = false;
     float ck = 0.f;
     int cid = 0, nsp = 0, ntri = 0;
@@ -400,7 +413,7 @@ __global__ __launch_bounds__(64) void search_kernel(Tree tr, int search_all_mode
                 p = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]};
                 const float pmax = fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z)));
                 slack = 1e-5f * (1.f + fmaxf(pmax, mesh_scale));
-                b.d2 = INFINITY; b.sd = INFINITY; b.thr2 = FLT_MAX; b.f = 0x7fffffff; b.q = p;
+                b.d2 = INFINITY; b.sd = INFINITY; b.thr2 = FLT_MAX; b.f = 0x7fffffff; b.q = p; b.d2b = INFINITY; b.fb = 0x7fffffff;
                 has_cur = pmax <= FLT_MAX && !search_all_mode;                   // NaN / Inf, all-triangles mode: straight to the loop
                 ck = 0.f; cid = 0; nsp = 0; ntri = 0;                            // the root
                 active = true;
@@ -458,21 +471,53 @@ __global__ __launch_bounds__(64) void search_kernel(Tree tr, int search_all_mode
                 }
             }
         } else if (bt) {                                                         // ---- TEST: one pending triangle per lane
-            if (active && ntri > 0) exact_tri(rec, face_of, pop_tri(--ntri), p, slack, b);
+            if (active && ntri > 0) exact_tri<RUNNER>(rec, face_of, pop_tri(--ntri), p, slack, b);
         }
         if (active && !has_cur && nsp == 0 && ntri == 0) {                       // ---- this lane's sample is done
             if (b.f == 0x7fffffff) {
                 // all-triangles mode, or nothing found (non-finite point, overflowing distances): the plain loop, whose
                 // answer for such points is face 0 and q = p
-                b.d2 = INFINITY; b.sd = INFINITY; b.thr2 = FLT_MAX; b.f = 0; b.q = p;
-                search_all(rec, face_of, tr.F, p, slack, b);
+                b.d2 = INFINITY; b.sd = INFINITY; b.thr2 = FLT_MAX; b.f = 0; b.q = p; b.d2b = INFINITY; b.fb = 0x7fffffff;
+                search_all<RUNNER>(rec, face_of, tr.F, p, slack, b);
             }
             q_out[i * 3] = b.q.x; q_out[i * 3 + 1] = b.q.y; q_out[i * 3 + 2] = b.q.z;
             f_out[i * f_stride] = b.f;
+            // every triangle within the final pruning bound has been tested (a box is only dropped beyond the bound of its time, and bounds only shrink):
+            // the runner-up reported is the same triangle whatever the visiting order, tree or all-triangles mode
+            if (RUNNER) f_out[i * f_stride + 1] = (b.d2b <= b.thr2 && b.fb != 0x7fffffff) ? b.fb : -1;
             active = false;
         }
         if (next >= end && !__any(active)) break;
     }
+}
+
+// closest point of triangle `face` to p in float64 (Ericson 5.1.5, with branches: one lane, one or two triangles) -> out = {x, y, z, squared distance};
+// false when the result is not finite
+__device__ __forceinline__ bool foot64(const float* __restrict__ verts, const int32_t* __restrict__ faces, int face, V3 p, double* out) {
+    const int i0 = faces[face * 3], i1 = faces[face * 3 + 1], i2 = faces[face * 3 + 2];
+    const double ax = verts[i0 * 3], ay = verts[i0 * 3 + 1], az = verts[i0 * 3 + 2];
+    const double v0x = (double)verts[i1 * 3] - ax, v0y = (double)verts[i1 * 3 + 1] - ay, v0z = (double)verts[i1 * 3 + 2] - az;
+    const double v1x = (double)verts[i2 * 3] - ax, v1y = (double)verts[i2 * 3 + 1] - ay, v1z = (double)verts[i2 * 3 + 2] - az;
+    const double px_ = p.x, py_ = p.y, pz_ = p.z;
+    const double apx = px_ - ax, apy = py_ - ay, apz = pz_ - az;
+    const double e1 = v0x * apx + v0y * apy + v0z * apz, e2 = v1x * apx + v1y * apy + v1z * apz;      // d1, d2
+    const double bpx = apx - v0x, bpy = apy - v0y, bpz = apz - v0z;
+    const double e3 = v0x * bpx + v0y * bpy + v0z * bpz, e4 = v1x * bpx + v1y * bpy + v1z * bpz;      // d3, d4
+    const double cpx = apx - v1x, cpy = apy - v1y, cpz = apz - v1z;
+    const double e5 = v0x * cpx + v0y * cpy + v0z * cpz, e6 = v1x * cpx + v1y * cpy + v1z * cpz;      // d5, d6
+    const double vc = e1 * e4 - e3 * e2, vb = e5 * e2 - e1 * e6, va = e3 * e6 - e5 * e4;
+    double fv, fw;
+    if (e1 <= 0 && e2 <= 0) { fv = 0; fw = 0; }                                       // vertex A
+    else if (e3 >= 0 && e4 <= e3) { fv = 1; fw = 0; }                                 // vertex B
+    else if (vc <= 0 && e1 >= 0 && e3 <= 0) { fv = e1 / (e1 - e3); fw = 0; }          // edge AB
+    else if (e6 >= 0 && e5 <= e6) { fv = 0; fw = 1; }                                 // vertex C
+    else if (vb <= 0 && e2 >= 0 && e6 <= 0) { fv = 0; fw = e2 / (e2 - e6); }          // edge AC
+    else if (va <= 0 && (e4 - e3) >= 0 && (e5 - e6) >= 0) { fw = (e4 - e3) / ((e4 - e3) + (e5 - e6)); fv = 1 - fw; }   // edge BC
+    else { const double dn = 1.0 / (va + vb + vc); fv = vb * dn; fw = vc * dn; }      // interior
+    const double tx = ax + v0x * fv + v1x * fw, ty = ay + v0y * fv + v1y * fw, tz = az + v0z * fv + v1z * fw;
+    out[0] = tx; out[1] = ty; out[2] = tz;
+    out[3] = (tx - px_) * (tx - px_) + (ty - py_) * (ty - py_) + (tz - pz_) * (tz - pz_);
+    return tx == tx && ty == ty && tz == tz && fabs(tx) <= DBL_MAX && fabs(ty) <= DBL_MAX && fabs(tz) <= DBL_MAX;
 }
 
 // ---- tail_kernel: one workgroup per ray, one lane per sample ---------------------------------------------------------------------
@@ -488,11 +533,25 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ pts
         if (!live) continue;
         const int64_t i = r * S + s;
         const V3 p = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]};
-        Best b;
-        b.f = reinterpret_cast<const int32_t*>(can_dirs)[i * 3];
-        b.q = {can_pts[i * 3], can_pts[i * 3 + 1], can_pts[i * 3 + 2]};
-        const int bf = b.f;
-        const V3 q = b.q;
+        int bf = reinterpret_cast<const int32_t*>(can_dirs)[i * 3];
+        const int rf = reinterpret_cast<const int32_t*>(can_dirs)[i * 3 + 1];       // the search's runner-up (-1: none within its bound)
+        const V3 q = {can_pts[i * 3], can_pts[i * 3 + 1], can_pts[i * 3 + 2]};
+        // The search's distances are float32 arithmetic (like libigl's on float32 input): two feet whose distances differ by less than ~1e-6 of the
+        // distance are decided by rounding, and inside a body such feet lie on different faces centimetres apart.  Winner and runner-up are both
+        // re-evaluated here in float64 (the same Voronoi-region test, Ericson 5.1.5) and the nearer one -- ties: the lower face id -- is the foot, as in
+        // a float64 evaluation of utils/ray_utils.py:53; its closest point is the float64 one either way: canonical points to ~1e-7, finite-difference
+        // directions to ~1e-5 of that evaluation.  A non-finite query keeps the search's q.
+        double qx = q.x, qy = q.y, qz = q.z;
+        {
+            double f0[4], f1[4];
+            const bool ok0 = foot64(verts, faces, bf, p, f0);
+            if (rf >= 0 && ok0 && foot64(verts, faces, rf, p, f1) && (f1[3] < f0[3] || (f1[3] == f0[3] && rf < bf))) {
+                bf = rf;
+                qx = f1[0]; qy = f1[1]; qz = f1[2];
+            } else if (ok0) {
+                qx = f0[0]; qy = f0[1]; qz = f0[2];
+            }
+        }
         // ---- barycentrics of q in the winning triangle, igl.barycentric_coordinates_tri (ray_utils.py:55), f64
         const int i0 = faces[bf * 3], i1 = faces[bf * 3 + 1], i2 = faces[bf * 3 + 2];
         const double ax = verts[i0 * 3], ay = verts[i0 * 3 + 1], az = verts[i0 * 3 + 2];
@@ -500,31 +559,6 @@ __global__ __launch_bounds__(256) void tail_kernel(const float* __restrict__ pts
         const double v1x = (double)verts[i2 * 3] - ax, v1y = (double)verts[i2 * 3 + 1] - ay, v1z = (double)verts[i2 * 3 + 2] - az;
         const double d00 = v0x * v0x + v0y * v0y + v0z * v0z, d01 = v0x * v1x + v0y * v1y + v0z * v1z;
         const double d11 = v1x * v1x + v1y * v1y + v1z * v1z;
-        // The search's foot q is float32 arithmetic (like libigl's on float32 input): right to ~1e-6, which the finite-difference
-        // directions below divide by a sample spacing of ~1e-2.  The winner is settled, so its foot is recomputed here in float64
-        // (the same Voronoi-region test, Ericson 5.1.5): canonical points to ~1e-7, directions to ~1e-5 of a float64 evaluation of
-        // utils/ray_utils.py:53-64.  A non-finite query keeps the search's q.
-        double qx = q.x, qy = q.y, qz = q.z;
-        {
-            const double px_ = p.x, py_ = p.y, pz_ = p.z;
-            const double apx = px_ - ax, apy = py_ - ay, apz = pz_ - az;
-            const double e1 = v0x * apx + v0y * apy + v0z * apz, e2 = v1x * apx + v1y * apy + v1z * apz;      // d1, d2
-            const double bpx = apx - v0x, bpy = apy - v0y, bpz = apz - v0z;
-            const double e3 = v0x * bpx + v0y * bpy + v0z * bpz, e4 = v1x * bpx + v1y * bpy + v1z * bpz;      // d3, d4
-            const double cpx = apx - v1x, cpy = apy - v1y, cpz = apz - v1z;
-            const double e5 = v0x * cpx + v0y * cpy + v0z * cpz, e6 = v1x * cpx + v1y * cpy + v1z * cpz;      // d5, d6
-            const double vc = e1 * e4 - e3 * e2, vb = e5 * e2 - e1 * e6, va = e3 * e6 - e5 * e4;
-            double fv, fw;
-            if (e1 <= 0 && e2 <= 0) { fv = 0; fw = 0; }                                       // vertex A
-            else if (e3 >= 0 && e4 <= e3) { fv = 1; fw = 0; }                                 // vertex B
-            else if (vc <= 0 && e1 >= 0 && e3 <= 0) { fv = e1 / (e1 - e3); fw = 0; }          // edge AB
-            else if (e6 >= 0 && e5 <= e6) { fv = 0; fw = 1; }                                 // vertex C
-            else if (vb <= 0 && e2 >= 0 && e6 <= 0) { fv = 0; fw = e2 / (e2 - e6); }          // edge AC
-            else if (va <= 0 && (e4 - e3) >= 0 && (e5 - e6) >= 0) { fw = (e4 - e3) / ((e4 - e3) + (e5 - e6)); fv = 1 - fw; }   // edge BC
-            else { const double dn = 1.0 / (va + vb + vc); fv = vb * dn; fw = vc * dn; }      // interior
-            const double tx = ax + v0x * fv + v1x * fw, ty = ay + v0y * fv + v1y * fw, tz = az + v0z * fv + v1z * fw;
-            if (tx == tx && ty == ty && tz == tz && fabs(tx) <= DBL_MAX && fabs(ty) <= DBL_MAX && fabs(tz) <= DBL_MAX) { qx = tx; qy = ty; qz = tz; }
-        }
         const double v2x = qx - ax, v2y = qy - ay, v2z = qz - az;
         const double d20 = v2x * v0x + v2y * v0y + v2z * v0z, d21 = v2x * v1x + v2y * v1y + v2z * v1z;
         const double den = d00 * d11 - d01 * d01;
@@ -1039,8 +1073,8 @@ int nm_warp_to_canonical(nm_mesh_t m, const float* pts, int64_t R, int S, const 
     hipStream_t st = nm::as_stream(stream);
     int32_t* f_out = reinterpret_cast<int32_t*>(can_dirs);
     const int all = m->search == NM_SEARCH_ALL ? 1 : 0;
-    if (small) hipLaunchKernelGGL(search_kernel<true>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, can_pts, f_out, 3, chunk);
-    else hipLaunchKernelGGL(search_kernel<false>, dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, can_pts, f_out, 3, chunk);
+    if (small) hipLaunchKernelGGL((search_kernel<true, true>), dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, can_pts, f_out, 3, chunk);
+    else hipLaunchKernelGGL((search_kernel<false, true>), dim3(waves), dim3(64), lds, st, m->tr, all, pts, N, m->d_rec, m->d_face, m->d_nodes, can_pts, f_out, 3, chunk);
     if (int rc = nm::check_launch("search_kernel")) return rc;
     const int threads = S <= 64 ? 64 : (S <= 128 ? 128 : 256);
     hipLaunchKernelGGL(tail_kernel, dim3((unsigned)R), dim3(threads), (size_t)S * 24, st, pts, S, m->d_verts, m->d_faces, T, can_pts, can_dirs, closest);

@@ -171,23 +171,28 @@ def ray_to_importance_samples(origin, direction, z_vals, weights, n_importance, 
 # ----------------------------------------------------------------------------
 # SMPL-guided near/far
 # ----------------------------------------------------------------------------
-def geometry_guided_near_far(orig, direction, vert, geo_threshold=DEFAULT_GEO_THRESH, chunk=512):
+def geometry_guided_near_far(orig, direction, vert, geo_threshold=DEFAULT_GEO_THRESH, chunk=512, dtype=F32):
     """reference utils/ray_utils.py:204-219 (torch branch, f32) == :222-233 (numpy branch).
 
     Union of radius-tau spheres round the vertices: per vertex
     ``z0 = (v-o).d``, ``dz = sqrt(tau^2 - (|v-o|^2 - z0^2))``; NaN -> +-inf;
     near = min(z0-dz), far = max(z0+dz).  A miss gives near=+inf > far=-inf.
+
+    ``dtype``: the arithmetic.  float32 (default) is what the reference computes on the float32 rays its renderers hand it; float64 is the same
+    expression on the same values without float32's cancellation error in the bracket (the reference's numpy branch given float64 arrays: pinned on
+    tests/golden/arbiter.npz's recorded float64 near / far) -- the yardstick for the device's bounds, whose discriminant is float64 (csrc/nearfar.hip).
     """
-    o, d, v = orig.astype(F32), direction.astype(F32), vert.astype(F32)
-    tau2 = F32(geo_threshold ** 2)
-    near = np.empty(o.shape[0], F32)
-    far = np.empty(o.shape[0], F32)
+    T = np.dtype(dtype).type
+    o, d, v = orig.astype(F32).astype(T), direction.astype(F32).astype(T), vert.astype(F32).astype(T)
+    tau2 = T(geo_threshold ** 2)
+    near = np.empty(o.shape[0], T)
+    far = np.empty(o.shape[0], T)
     with np.errstate(invalid='ignore'):
         for s in range(0, o.shape[0], chunk):
             ov = v[None, :, :] - o[s:s + chunk, None, :]                     # [r,V,3]
-            z0 = np.einsum('rvi,ri->rv', ov, d[s:s + chunk]).astype(F32)
-            nrm = np.sqrt(np.sum(ov * ov, axis=2, dtype=F32)).astype(F32)    # torch.norm
-            dz = np.sqrt(tau2 - (nrm * nrm - z0 * z0)).astype(F32)
+            z0 = np.einsum('rvi,ri->rv', ov, d[s:s + chunk]).astype(T)
+            nrm = np.sqrt(np.sum(ov * ov, axis=2, dtype=T)).astype(T)        # torch.norm
+            dz = np.sqrt(tau2 - (nrm * nrm - z0 * z0)).astype(T)
             n_ = z0 - dz
             f_ = z0 + dz
             n_[n_ != n_] = np.inf

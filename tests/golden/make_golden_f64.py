@@ -25,7 +25,8 @@ What is stored (float64 results as float32: 6e-8 of rounding against a 1e-4 gate
               frame (rows 5, 15, ... 795: 64 000 rays), rgb of both runs: `fog00` (synthetic.make_joiner(0, preset='fog'): density positive
               everywhere, the inverse CDF well conditioned on every ray -- the reference's float32 run sits 3e-7 from its float64 one) and
               `opaque00` (surfaces: 3 of the 64 000 rays beyond 1e-4 in the reference's own float32 run)
-  posed / hybrid / multi   the 40 x 32 frames of make_golden_posed.py again in float64: rgb (+ depth), near / far, background z
+  posed / hybrid / multi   the 40 x 32 frames of make_golden_posed.py again in float64: rgb (+ depth), near / far, background z, and the frame's rays
+                           exactly as the reference shot them (float32 arithmetic of utils/ray_utils.py:23-29 on its float32 camera centre)
   posedbig / hybridbig     the 64 x 64 frames of make_golden_posed.py --big in float64: rgb
 """
 import contextlib
@@ -50,6 +51,9 @@ ROWS = np.arange(5, 800, 10)                       # the strided rows of the wel
 WELL_CONDITIONED = {"fog00": ((0, 'fog'), (0, 'fog')), "opaque00": ((0, 'opaque'), (0, 'opaque'))}
 
 
+RAYS = []                                         # (origins, directions) of every shot_rays call under float64_mode, as float32
+
+
 def f32_values(x):
     return np.asarray(x).astype(np.float32).astype(np.float64)
 
@@ -69,6 +73,7 @@ def float64_mode():
 
     def shot_rounded(cap, xys):
         o, d = shot(cap, xys)
+        RAYS.append((np.asarray(o, np.float32).copy(), np.asarray(d, np.float32).copy()))      # the very rays of the frame (posed_part stores them)
         return f32_values(o), f32_values(d)
     R_ray.shot_all_rays, R_ray.shot_rays = shot_all_rounded, shot_rounded
     try:
@@ -228,6 +233,7 @@ def posed_part(out):
                 rgb, depth, acc = R_render.render_smpl_nerf(net, cap, posed, faces, T, rays_per_batch=512, samples_per_ray=128, white_bkg=True,
                                                             render_can=False, geo_threshold=0.2, return_depth=True, return_mask=True)
             n_, f_ = nf()
+            out.update(posed_rays_o=RAYS[-1][0], posed_rays_d=RAYS[-1][1])
             out.update(posed_rgb64=rgb.astype(np.float32), posed_depth64=depth.astype(np.float32), posed_acc64=acc.astype(np.float32), posed_near64=n_[0], posed_far64=f_[0])
             print(f"[posed] float64 {time.time() - t0:.0f} s; reference float32 vs float64: {stats(g32['posed_rgb'].reshape(-1, 3), rgb.reshape(-1, 3))}", flush=True)
             near_far.clear()
@@ -236,6 +242,7 @@ def posed_part(out):
                 rgb, depth = R_render.render_hybrid_nerf(net, cap, posed, faces, T, rays_per_batch=512, samples_per_ray=128, importance_samples_per_ray=128,
                                                          white_bkg=True, geo_threshold=0.2, return_depth=True)
             n_, f_ = nf()
+            out.update(hybrid_rays_o=RAYS[-1][0], hybrid_rays_d=RAYS[-1][1])
             out.update(hybrid_rgb64=rgb.astype(np.float32), hybrid_depth64=depth.astype(np.float32), hybrid_bkg_z64=np.concatenate(rec.z).astype(np.float32),
                        hybrid_near64=n_[0], hybrid_far64=f_[0])
             print(f"[hybrid] float64 {time.time() - t0:.0f} s; reference float32 vs float64: {stats(g32['hybrid_rgb'].reshape(-1, 3), rgb.reshape(-1, 3))}", flush=True)
@@ -253,6 +260,7 @@ def posed_part(out):
                 rgb, depth = R_render.render_hybrid_nerf_multi_persons(net, cap5, [net] * 3, posed_l, [faces] * 3, T_l, rays_per_batch=512, samples_per_ray=192,
                                                                        importance_samples_per_ray=128, white_bkg=True, geo_threshold=0.2, return_depth=True)
             n_, f_ = nf(3)
+            out.update(multi_rays_o=RAYS[-1][0], multi_rays_d=RAYS[-1][1])
             out.update(multi_rgb64=rgb.astype(np.float32), multi_depth64=depth.astype(np.float32), multi_bkg_z64=np.concatenate(rec.z).astype(np.float32),
                        multi_near64=n_, multi_far64=f_)
             print(f"[multi] float64 {time.time() - t0:.0f} s; reference float32 vs float64: {stats(g32['multi_rgb'].reshape(-1, 3), rgb.reshape(-1, 3))}", flush=True)
@@ -272,12 +280,14 @@ def posed_big_part(out):
         with contextlib.redirect_stdout(io.StringIO()):
             rgb = R_render.render_smpl_nerf(net, cap, posed, faces, T, rays_per_batch=1024, samples_per_ray=128, white_bkg=True, render_can=False, geo_threshold=0.2)
         out['posedbig_rgb64'] = rgb.astype(np.float32)
+        out['posedbig_rays_o'], out['posedbig_rays_d'] = RAYS[-1]
         print(f"[posedbig] float64 {time.time() - t0:.0f} s; reference float32 vs float64: {stats(g32['posed_rgb'].reshape(-1, 3), rgb.reshape(-1, 3))}", flush=True)
         t0 = time.time()
         with contextlib.redirect_stdout(io.StringIO()):
             rgb = R_render.render_hybrid_nerf(net, cap, posed, faces, T, rays_per_batch=1024, samples_per_ray=128, importance_samples_per_ray=128, white_bkg=True,
                                               geo_threshold=0.2)
         out['hybridbig_rgb64'] = rgb.astype(np.float32)
+        out['hybridbig_rays_o'], out['hybridbig_rays_d'] = RAYS[-1]
         print(f"[hybridbig] float64 {time.time() - t0:.0f} s; reference float32 vs float64: {stats(g32['hybrid_rgb'].reshape(-1, 3), rgb.reshape(-1, 3))}", flush=True)
 
 

@@ -45,9 +45,23 @@ def load_big():
     return g
 
 
-def cap_big(g):
+def _reference_rays(case):
+    """the frame's rays exactly as the reference shot them (float32 arithmetic on its float32 camera centre, utils/ray_utils.py:23-29), recorded by
+    tests/golden/make_golden_f64.py: the contract is parity on IDENTICAL rays, and a ray direction off by one float32 ulp moves a grazing ray's near / far
+    by up to 1e-4 (the discriminant's root divides by 2 dz).  None when the fixture does not hold them."""
+    from oracle import attribution
+    try:
+        a = attribution.load_arbiter(case)
+    except KeyError:
+        return None
+    return (a['rays_o'].astype(np.float32), a['rays_d'].astype(np.float32)) if 'rays_o' in a else None
+
+
+def cap_big(g, which='posed'):
     near, far = (float(x) for x in g['hybrid_near_far'])
-    return synthetic.SimpleCapture(g['W'], g['H'], fx=float(g['big_fx']), c2w=g['cam_c2w'], near=near, far=far)
+    c = synthetic.SimpleCapture(g['W'], g['H'], fx=float(g['big_fx']), c2w=g['cam_c2w'], near=near, far=far)
+    c._rays = _reference_rays(which + 'big')
+    return c
 
 
 def oracle_nets():
@@ -57,10 +71,15 @@ def oracle_nets():
 def cap(g, which):
     fx = float(g[f'{which}_fx'])
     near, far = (0.5, 4.0) if which == 'posed' else tuple(float(x) for x in g[f'{which}_near_far'])
-    return synthetic.SimpleCapture(W, H, fx=fx, c2w=g['cam_c2w'], near=near, far=far)
+    c = synthetic.SimpleCapture(W, H, fx=fx, c2w=g['cam_c2w'], near=near, far=far)
+    c._rays = _reference_rays(which)
+    return c
 
 
 def frame_rays(c):
+    """the capture's rays: the reference's own recording when the fixture holds it (cap / cap_big), else the oracle's shot_rays (1 ulp from it)"""
+    if getattr(c, '_rays', None) is not None:
+        return c._rays
     o, d = O.shot_rays(c.intrinsic_matrix, c.cam_pose.camera_to_world, O.all_pixel_coords(c.shape))
     return o.astype(np.float32), d.astype(np.float32)
 

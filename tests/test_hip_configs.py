@@ -181,13 +181,13 @@ def test_c4_hybrid_slice_128_128_128(G):
           f"warped points: Linf {e.max():.2e} (hit rays {e[hits[0]].max():.2e})")
     assert e.max() < 1e-4
     # hit list and the human samples are what the oracle derives from the same rays
-    near, far = O.geometry_guided_near_far(o, d, posed, 0.2)
+    near, far = (x.astype(np.float32) for x in O.geometry_guided_near_far(o, d, posed, 0.2, dtype=np.float64))       # (the device's discriminant is float64)
     o_hit = np.nonzero(near < far)[0]
     assert np.intersect1d(o_hit, hits[0]).size >= 0.99 * max(o_hit.size, hits[0].size)
     common = np.intersect1d(o_hit, hits[0])
     _, _, hz = O.ray_to_samples(o[common], d[common], near[common][:, None], far[common][:, None], 128)
     dev_hz = trace['human_z'][0].cpu().numpy()[np.searchsorted(hits[0], common)]
-    assert np.abs(dev_hz - hz).max() < 3e-5                                        # near / far carry ~1e-5 of sqrt rounding
+    assert np.abs(dev_hz - hz).max() < 2e-6                                        # both are float64 bounds rounded once
 
 
 def test_c5_three_actor_slice_192_128_3x192(G):

@@ -48,14 +48,17 @@ def check(rep, world):
         assert abs(a - b) <= 2e-3 * max(abs(a), 1e-3), (rep["curve_full"], rep["curve_dp"])
 
 
-def test_two_ranks_share_the_gpu_gradients_over_gloo():
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_share_the_gpu_gradients_over_gloo(world):
+    """world 8 = the node's size: eight shards of every batch, eight normaliser contributions and dead-flag votes in the all_gather, one all_reduce of
+    the flat gradient buffer -- the summed gradient equals the full-batch one"""
     port = free_port()
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "helpers", "dist_train_check.py"), "gloo"], env=env_for(r, 2, port),
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=600) for p in procs]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "helpers", "dist_train_check.py"), "gloo"], env=env_for(r, world, port),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=900) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-3000:]
-    check(last_json(outs[0][0]), 2)
+    check(last_json(outs[0][0]), world)
 
 
 def test_rccl_collectives_on_a_group_of_one_rank():

@@ -208,7 +208,7 @@ def test_merged_frames(S, which, size):
     multi = which == 'multi'
     S, whole = pick(S, size)
     NR = S['nrays']
-    c = PS.cap(S, which) if size == 'small' else PS.cap_big(S)
+    c = PS.cap(S, which) if size == 'small' else PS.cap_big(S, which)
     o, d = PS.frame_rays(c)
     nets = S['dev_nets']
     ref = S[f'{which}_rgb'].reshape(-1, 3)

@@ -194,14 +194,21 @@ def test_near_far_and_compaction(H, golden):
     d = rng.normal(size=(R, 3)).astype(np.float32) * np.array([0.25, 0.4, 0.05], np.float32) + np.array([0, 0, 1], np.float32)
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     n, f = H.ray.geometry_guided_near_far(cu(o), cu(d), cu(verts), 0.2)
-    on, of = O.geometry_guided_near_far(o, d, verts, 0.2)
+    # the device's discriminant is float64 (csrc/nearfar.hip): held to the float64 evaluation of the reference's expression at float32 rounding of the
+    # result, and to the float32 one at what float32's cancellation leaves (the reference's own torch and numpy branches differ by as much)
+    on, of = O.geometry_guided_near_far(o, d, verts, 0.2, dtype=np.float64)
+    on32, of32 = O.geometry_guided_near_far(o, d, verts, 0.2)
     hn, hf = n.cpu().numpy(), f.cpu().numpy()
     flips = (hn < hf) != (on < of)
-    assert flips.mean() < 2e-3
+    assert flips.sum() == 0
     both = (hn < hf) & (on < of)
     assert 0.2 < both.mean() < 0.95
-    np.testing.assert_allclose(hn[both], on[both], atol=3e-5)
-    np.testing.assert_allclose(hf[both], of[both], atol=3e-5)
+    np.testing.assert_allclose(hn[both], on[both], atol=1e-6)
+    np.testing.assert_allclose(hf[both], of[both], atol=1e-6)
+    b32 = both & (on32 < of32)
+    e32 = np.maximum(np.abs(hn - on32), np.abs(hf - of32))[b32]
+    print(f"[near / far] device vs the float64 evaluation: {np.abs(hn[both] - on[both]).max():.1e}; vs the float32 one: 99 % {np.percentile(e32, 99):.1e}, max {e32.max():.1e}")
+    assert ((on32 < of32) != (on < of)).mean() < 2e-3 and np.percentile(e32, 99) < 1e-4 and e32.max() < 1e-3
     hit_idx, miss_idx = H.ray.compact_hits(n, f)
     np.testing.assert_array_equal(hit_idx.cpu().numpy(), np.nonzero(hn < hf)[0])           # integer work: bit exact, ascending
     np.testing.assert_array_equal(miss_idx.cpu().numpy(), np.nonzero(~(hn < hf))[0])

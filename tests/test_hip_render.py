@@ -119,9 +119,13 @@ def test_c3_canonical_human_frame(G, golden):
     # the canonical net uses the 'rotate' PE whose argument (x.B^T, up to ~1e3 rad) carries f32 summation-order noise of
     # ~1e-4 rad in the reference itself; the oracle shows the same spread against the golden (test_oracle_golden)
     assert e < 1e-4 and np.abs(acc - g['c3_acc'])[ok].max() < 1e-4                       # measured 4.6e-5 / (r01)
+    # (the device's near / far are a float64 evaluation rounded once, csrc/nearfar.hip: the oracle renders on those bounds, its own float32 ones are
+    #  checked against them in tests/test_hip_ray_ops.py)
+    oo, dd = O.shot_rays(cap.intrinsic_matrix, cap.cam_pose.camera_to_world, O.all_pixel_coords(cap.shape))
+    nf64 = [tuple(x.astype(np.float32) for x in O.geometry_guided_near_far(oo, dd, verts, 0.2, dtype=np.float64))]
     o_rgb, o_depth, o_acc = OR.render_smpl_nerf(G.nets[2][1], cap, verts, None, None, rays_per_batch=4096, samples_per_ray=32,
                                                 render_can=True, geo_threshold=0.2, return_depth=True, return_mask=True,
-                                                interval_comp=0.7)
+                                                interval_comp=0.7, given={'near_far': nf64})
     ok = (acc > 0) == (o_acc > 0)
     e = np.abs(rgb - o_rgb)[ok].max()
     print(f"[render] C3 canonical vs oracle: Linf {e:.3e}")
@@ -140,8 +144,10 @@ def test_posed_human_frame_with_warp(G):
     net = types.SimpleNamespace(coarse_human_net=G.nets[2][0], parameters=G.nets[2][0].parameters)
     rgb, depth, acc = G.render.render_smpl_nerf(net, cap, posed, faces, T, samples_per_ray=16, render_can=False,
                                                 geo_threshold=0.2, return_depth=True, return_mask=True)
+    oo, dd = O.shot_rays(cap.intrinsic_matrix, cap.cam_pose.camera_to_world, O.all_pixel_coords(cap.shape))
+    nf64 = [tuple(x.astype(np.float32) for x in O.geometry_guided_near_far(oo, dd, posed, 0.2, dtype=np.float64))]       # (the device's bounds: float64 discriminant)
     o_rgb, o_depth, o_acc = OR.render_smpl_nerf(G.nets[2][1], cap, posed, faces, T, samples_per_ray=16, render_can=False,
-                                                geo_threshold=0.2, return_depth=True, return_mask=True)
+                                                geo_threshold=0.2, return_depth=True, return_mask=True, given={'near_far': nf64})
     ok = (acc > 0) == (o_acc > 0)
     e = np.abs(rgb - o_rgb)[ok].max()
     print(f"[render] posed human (warp) vs oracle: hit rays {(o_acc > 0).sum()}, Linf {e:.3e}")

@@ -71,3 +71,28 @@ def test_well_conditioned_workload_every_ray_within_1e_4():
     y = np.abs(arb["rgb32"].astype(np.float64) - arb["rgb64"]).max()
     print(f"[oracle fog00] {e.size} rays vs the reference's float64 frame: Linf {e.max():.2e} (the reference's own float32 frame over all 64 000 stored rays: {y:.2e})")
     assert y < 1e-5 and e.max() < 1e-5
+
+
+def test_float64_near_far_equals_the_references_float64_run():
+    """oracle.ray_ops.geometry_guided_near_far(dtype=float64) -- the yardstick the device's float64-discriminant near / far are held to -- against what the
+    reference's own geometry_guided_near_far returned inside its float64 renders of the posed scenes (tests/golden/arbiter.npz: torch branch in
+    render_smpl_nerf, numpy branch in render_hybrid_nerf, three actors in the multi-person renderer)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers"))
+    import posed_scene as PS
+    S = PS.load()
+    for which, verts_l in (("posed", [S['posed_verts']]), ("hybrid", [S['posed_verts']]), ("multi", S['posed_l'])):
+        arb = attribution.load_arbiter(which)
+        o, d = PS.frame_rays(PS.cap(S, which))
+        for k, verts in enumerate(verts_l):
+            n, f = O.geometry_guided_near_far(o, d, verts, 0.2, dtype=np.float64)
+            rn, rf = (arb['near64'], arb['far64']) if arb['near64'].ndim == 1 else (arb['near64'][k], arb['far64'][k])
+            hit = rn < rf
+            assert np.array_equal(n < f, hit) and hit.sum() > 100
+            e = max(np.abs(n[hit] - rn[hit]).max(), np.abs(f[hit] - rf[hit]).max())
+            n32, f32 = O.geometry_guided_near_far(o, d, verts, 0.2)
+            b = hit & (n32 < f32)
+            e32 = max(np.abs(n32[b] - rn[b]).max(), np.abs(f32[b] - rf[b]).max())
+            print(f"[near / far {which} actor {k}] float64 oracle vs the reference's float64 run: {e:.1e} (stored as float32); the float32 evaluation vs the same: {e32:.1e}")
+            assert e < 5e-7

@@ -119,7 +119,7 @@ def test_big_hybrid_frame_conditional_on_every_ray():
     without an exact background / human z tie."""
     S = PS.load_big()
     nets = PS.oracle_nets()
-    c = PS.cap_big(S)
+    c = PS.cap_big(S, 'hybrid')
     given = {'near_far': [(S['hybrid_near'], S['hybrid_far'])], 'bkg_z': S['hybrid_bkg_z']}
     rgb, depth = render.render_hybrid_nerf(nets[0], nets[1], nets[2], c, S['posed_verts'], S['faces'], S['T'], rays_per_batch=1024, samples_per_ray=128,
                                            importance_samples_per_ray=128, return_depth=True, given=given)

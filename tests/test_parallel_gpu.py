@@ -107,22 +107,23 @@ def test_frame_drivers_shard_through_rccl_on_a_group_of_one_rank():
     assert 0.02 < out["render_hybrid_nerf"]["hit_fraction"] < 0.9
 
 
-def test_frame_drivers_shard_across_two_ranks_sharing_the_gpu():
-    """two ranks, each rendering the rays of its interleaved tiles through the SAME driver call (hit compaction, the hybrid C call and
+@pytest.mark.parametrize("world", [2, 8])
+def test_frame_drivers_shard_across_ranks_sharing_the_gpu(world):
+    """two ranks -- and eight, the node's size --, each rendering the rays of its interleaved tiles through the SAME driver call (hit compaction, the hybrid C call and
     the three-actor merge all see half a frame), gloo assembly: the hybrid and the three-actor frames are bit-identical to the
     unsharded ones"""
     port = free_port()
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "helpers", "dist_drivers_check.py"), "gloo"], env=env_for(r, 2, port),
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=900) for p in procs]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "helpers", "dist_drivers_check.py"), "gloo"], env=env_for(r, world, port),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=1200) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-3000:]
     out = last_json(outs[0][0])
     print(out)
-    assert out["world"] == 2
+    assert out["world"] == world
     for k in DRIVERS:
         assert out[k]["bit_identical"] and out[k]["finite"], (k, out[k])
-        assert sum(out[k]["rays_per_rank"]) == out["rays"] and len(out[k]["rays_per_rank"]) == 2
+        assert sum(out[k]["rays_per_rank"]) == out["rays"] and len(out[k]["rays_per_rank"]) == world
 
 
 def test_interleaved_tiles_balance_the_hit_rays_at_world_8():
