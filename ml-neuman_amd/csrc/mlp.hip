@@ -22,14 +22,11 @@
 namespace {
 
 
-// SAVE 1: float32 copies of the activations (nm_mlp_forward_save); 2: fp16 copies of the trunk's (nm_mlp_forward_save16); 3: the same copies, each stage's issued
-// one stage LATER, read back from LDS after the next stage's k-loop -- loads and stores share one in-order counter on gfx9-class hardware, so a wait for a
-// prefetched weight fragment issued after the stores is a wait for the stores' acknowledgements: issued right after write_act they have the second barrier and two
-// k-steps to land before the k-loop needs the first such fragment; issued after the following k-loop they have its whole epilogue and both barriers on top
-template <int PREC, bool PROF, int SAVE_ = 0>
+// SAVE 1: float32 copies of the activations (nm_mlp_forward_save); 2: fp16 copies of the trunk's (nm_mlp_forward_save16).  (Round 6 tried issuing each stage's
+// copies one stage later, read back from LDS after the next k-loop, on the theory that the stores' acknowledgements stall the weight prefetch through the shared
+// in-order counter: the launch took 1578.0 / 1580.2 us against 1573.8 / 1582.9 -- no effect; profiles/r06_train_experiments.md.)
+template <int PREC, bool PROF, int SAVE = 0>
 __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_in) {
-    constexpr bool DEFER = SAVE_ == 3;
-    constexpr int SAVE = SAVE_ == 3 ? 2 : SAVE_;
     const MlpArgs a = resolve_args(a_in);
     unsigned long long pr[6] = {0, 0, 0, 0, 0, 0};
     unsigned long long t_prev = PROF ? __builtin_readcyclecounter() : 0;
@@ -60,18 +57,6 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
             float4 v = make_float4(acc[4 * q] * scale, acc[4 * q + 1] * scale, acc[4 * q + 2] * scale, acc[4 * q + 3] * scale);
             if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
             *reinterpret_cast<float4*>(o + 8 * q) = v;
-        }
-    };
-    // DEFER: the fp16 copy of trunk stage `st` (this wave's block: chunks 4 w + g and 4 w + 2 + g of its 128 rows) from the LDS operand it became
-    auto save_h16_from_lds = [&](int st, int64_t base) {
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
-            const int64_t row = base + 32 * mb + s;
-            if (row < a.n) {
-                uint4* o = a.save_h16 + ((int64_t)st * a.n + row) * 32 + 4 * w + g;
-                o[0] = lds[H_BASE + (4 * w + g) * kChunkU4 + 32 * mb + s];
-                o[2] = lds[H_BASE + (4 * w + 2 + g) * kChunkU4 + 32 * mb + s];
-            }
         }
     };
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -122,7 +107,6 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
                 k_run<4, PREC>(acc, W, wsrc, voff, soff + sh.pe_steps * nm::kStepBytes, next, lds + H_BASE + g * kChunkU4 + s,
                                sh.steps - sh.pe_steps);
             bias_prefetch(B, a.bias + nm::stage_b_off(st + 1) + 32 * w, g);     // next stage (st + 1 <= 8), block w
-            if (DEFER && F16 && st > 0) save_h16_from_lds(st - 1, base);       // H still holds stage st - 1's output: every wave is before the barrier below
             NM_TICK(1)
             if (SAVE) {
                 if (SAVE == 1) {
@@ -150,7 +134,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
             __syncthreads();                                              // every wave has finished reading H (and P)
             NM_TICK(2)
             write_act<4, PREC>(ar, lds, w, 0, g, s);
-            if (SAVE == 2 && F16 && !DEFER) {                    // the 16-bit copy IS the operand's hi part: fp16(32 x), clamped, k-slot order
+            if (SAVE == 2 && F16) {                              // the 16-bit copy IS the operand's hi part: fp16(32 x), clamped, k-slot order
 #pragma unroll
                 for (int mb = 0; mb < 4; ++mb) {
                     const int64_t row = base + 32 * mb + s;
@@ -193,7 +177,6 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
                 }
             }
             bias_prefetch(B, a.bias + nm::stage_b_off(0) + 32 * w, g);
-            if (DEFER && F16) save_h16_from_lds(7, base);
             NM_TICK(1)
             __syncthreads();                                      // H / P are rewritten by the next tile
             NM_TICK(5)
@@ -231,7 +214,6 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_mlp_kernel(const MlpArgs a_i
                 sigma = aacc[0][0] * acc2out(8);                     // feature row 0 of the block: lanes 0..31 (g == 0)
             }
             bias_prefetch(B, a.bias + nm::stage_b_off(9) + 32 * (w & 3), g);
-            if (DEFER && F16) save_h16_from_lds(7, base);
             NM_TICK(1)
             if (SAVE == 1 || (SAVE == 2 && a.save_h)) {
 #pragma unroll
@@ -929,9 +911,7 @@ int launch_mlp_mfma(const MlpLaunch& L, const float* pts, const float* dirs, con
         return check_launch("nerf_mlp_i8w_kernel");
     }
     if (L.save_h || L.save_h16) {                                 // the training forward: split fp16, the full head, activations kept
-        static const bool defer = [] { const char* e = getenv("NEUMAN_FWD_DEFER"); return !(e && e[0] == '0'); }();     // 0: round 5's order (A/B)
-        if (L.save_h16 && defer) hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_FP16X3, false, 3>), dim3(grid), dim3(kThreads), 0, stream, a);
-        else if (L.save_h16) hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_FP16X3, false, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
+        if (L.save_h16) hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_FP16X3, false, 2>), dim3(grid), dim3(kThreads), 0, stream, a);
         else hipLaunchKernelGGL((nerf_mlp_kernel<NM_PREC_FP16X3, false, 1>), dim3(grid), dim3(kThreads), 0, stream, a);
         return check_launch("nerf_mlp_kernel (save)");
     }

@@ -23,7 +23,11 @@ def default_opt(**over):
 
 class _Pose:
     def __init__(self, c2w):
-        self.camera_to_world = np.asarray(c2w, dtype=np.float64)
+        # the matrix keeps a float32 dtype when it is given one: the reference's CameraPose builds its matrix from float32 quaternions, and shot_rays'
+        # subtraction, norm and division then run in float32 (numpy's result type; utils/ray_utils.py:23-29) -- a capture rebuilt from a recorded float32
+        # matrix must shoot the reference's rays bit for bit (csrc/frame.hip mode 2), not the float64 chain's, which differ in the last place
+        c2w = np.asarray(c2w)
+        self.camera_to_world = c2w if c2w.dtype == np.float32 else c2w.astype(np.float64)
 
     @property
     def camera_center_in_world(self):

@@ -87,9 +87,12 @@ def test_plain_head_canonical_frame(H):
     # 4.9e-4 (acc) from this golden itself (this net reads colour and a x40 density straight off the 256-wide layer).  The device
     # is therefore held to the oracle tightly and to the reference's own output at that level.
     assert ok.mean() > 0.998 and e < 1e-3 and np.abs(acc - H['plain_c3_acc'])[ok].max() < 1e-3
+    from oracle import ray_ops as O
+    oo, dd = O.shot_rays(cap.intrinsic_matrix, cap.cam_pose.camera_to_world, O.all_pixel_coords(cap.shape))
+    nf64 = [tuple(x.astype(np.float32) for x in O.geometry_guided_near_far(oo, dd, verts, 0.2, dtype=np.float64))]   # the device's bounds: float64 discriminant (csrc/nearfar.hip)
     o_rgb, o_depth, o_acc = OR.render_smpl_nerf((synthetic.state_numpy(j), JoinerSpec(mapping='rotate')), cap, verts, None, None, rays_per_batch=4096,
                                                 samples_per_ray=24, render_can=True, geo_threshold=0.2, return_depth=True, return_mask=True,
-                                                interval_comp=0.8)
+                                                interval_comp=0.8, given={'near_far': nf64})
     ok = (acc > 0) == (o_acc > 0)
     eo = np.abs(rgb - o_rgb)[ok].max()
     print(f"[heads] plain-head canonical frame vs oracle: rgb Linf {eo:.2e}, acc Linf {np.abs(acc - o_acc)[ok].max():.2e}")

@@ -113,18 +113,16 @@ def test_loss_terms_and_gradients_vs_the_references_autograd(S):
     assert np.median(e[hit]) < 5e-5 and (e[hit] > 1e-4).mean() < 0.05
     # The gradients of the SMPL parameters are NOT well defined in float32: the reference's own autograd result moves by 7 % / 10 % / 7 %
     # (poses / betas / alignments) when the poses move by 1e-6 (tests/golden/make_golden_human_loss.py stores that floor) -- they run
-    # through d(barycentric)/d(vertex) ~ 1 / edge length of whichever face each sample's foot lands on.  Gates:
-    #   network tensors   min(max(2e-3, 3 x floor), max(3 x what round 4 measured on this golden, 1.5 x floor))   (profiles/r05_grad_gates.json; the
-    #                     1.5 x floor arm: no tensor is held tighter than 1.5 x what the reference's own float32 autograd moves by -- views_linears.0.weight
-    #                     of the full golden sits at 2.0e-4 with the fp16 operands of round 5 against a floor of 1.7e-4 and 3 x r04 = 1.9e-4)
+    # through d(barycentric)/d(vertex) ~ 1 / edge length of whichever face each sample's foot lands on.  Gates, anchored on the REFERENCE's own numbers
+    # alone (the floor stored in the golden; nothing is read from profiles/ and nothing refers to what the device measured in an earlier round):
+    #   network tensors   max(2e-4, 1.5 x floor): no tensor is held tighter than 1.5 x what the reference's own float32 autograd moves by, nor tighter than
+    #                     2e-4 of its largest entry -- the level of a step that keeps fp16 copies between its passes (2e-5 .. 9e-5 on the
+    #                     background trainer's goldens against the reference's autograd)
     #   SMPL parameters   1.5 x floor, cosine >= 0.985; the device's deviation and the reference-vs-reference floor are reported side by side
-    import json
-    with open(os.path.join(ROOT, "profiles", "r05_grad_gates.json")) as f:
-        measured = json.load(f)[S.size]
     gates = {}
     for k, v in worst.items():
         floor = float(S.g['grad_floor_' + k])
-        gates[k] = 1.5 * floor if k in ("poses", "betas", "alignments") else min(max(2e-3, 3 * floor), max(3 * measured[k], 1.5 * floor))
+        gates[k] = 1.5 * floor if k in ("poses", "betas", "alignments") else max(2e-4, 1.5 * floor)
     SUMMARY[S.size].update(smpl_grad_floor={k: float(S.g['grad_floor_' + k]) for k in ("poses", "betas", "alignments")},
                            smpl_grad_cos={k: cos[k] for k in ("poses", "betas", "alignments")}, network_grad_dev=net_g,
                            network_grad_gate={k: gates[k] for k in net_g})
