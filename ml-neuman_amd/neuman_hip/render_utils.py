@@ -604,6 +604,26 @@ def render_multi_rays(coarse_bkg, fine_bkg, human_nets, o, d, bkg_near, bkg_far,
             hn, hf = ray_utils.gather_rows(near, hit), ray_utils.gather_rows(far, hit)
             return hit, (ho, hd, hn, hf), h_z
 
+        def actor_lists_compact(a_):
+            """the actor's list as COMPACT arrays for merge_composite_lists' `rows` indirection: the evaluated rows of the hit rays followed by ONE placeholder row
+            (the zero-density samples at linspace(2 far, 3 far), render_utils.py:418-419) that every missed ray points at -> (z [n_hit + 1, S], raw [n_hit + 1, S, 4],
+            rows [nr] int32).  The same values the full [nr, S] arrays hold, without filling, scattering and streaming 16 KB per missed ray and actor."""
+            near, far = _given_near_far(given, a_, i, j, oc, dc, posed_verts[a_], geo_threshold)
+            _note(trace, near=near, far=far)
+            hit, _ = ray_utils.compact_hits(near, far)
+            _note(trace, hit=hit + i)
+            n_hit = int(hit.numel())
+            rows = torch.full((nr,), n_hit, device=o.device, dtype=torch.int32)
+            pad_raw = torch.zeros((1, samples_per_ray, 4), device=o.device, dtype=torch.float32)
+            if n_hit == 0:
+                _note(trace, human_z=None, can_pts=None, can_dirs=None)
+                return far_z[None].contiguous(), pad_raw, rows
+            ho, hd = ray_utils.gather_rows(oc, hit), ray_utils.gather_rows(dc, hit)
+            hn, hf = ray_utils.gather_rows(near, hit), ray_utils.gather_rows(far, hit)
+            r_, z_ = human_pass_rays(human_nets[a_], ho, hd, hn, hf, samples_per_ray, meshes[a_], False, 1.0, precision, trace)
+            rows[hit.to(torch.int64)] = torch.arange(n_hit, device=o.device, dtype=torch.int32)
+            return torch.cat([z_, far_z[None]], 0), torch.cat([r_, pad_raw], 0), rows
+
         def actor_lists(a_, rays=None, dz=None):
             """the actor's list evaluated -> (h_z [nr,S], h_raw [nr,S,4], (hit, far, transmittance over `dz`) when marched)"""
             hit, hr, h_z = rays if rays is not None else actor_rays(a_)
@@ -662,6 +682,10 @@ def render_multi_rays(coarse_bkg, fine_bkg, human_nets, o, d, bkg_near, bkg_far,
             if TERMINATION_EPS > 0:                                                              # a sample the march never reached stays unevaluated
                 last = torch.where((raw_all[:, -1, :] == 0).all(-1, keepdim=True), raw_all[:, -1, :], last)
             raw_all[:, -1, :] = last
+        if lists is None and len(human_nets) <= 3 and MULTI_COMPACT:
+            cl = [actor_lists_compact(a_) for a_ in range(len(human_nets))]
+            rgb[i:j], depth[i:j], _ = merge_composite_lists([z_all] + [c[0] for c in cl], [raw_all] + [c[1] for c in cl], dc, white_bkg, rows=[None] + [c[2] for c in cl])
+            continue
         if lists is None:
             lists = [actor_lists(a_) for a_ in range(len(human_nets))]
         if len(lists) <= 3:                                                                      # :441-456 as one kernel: 4-way merge + composite
@@ -683,6 +707,7 @@ def _device_of(net):
     return dev
 
 
+MULTI_COMPACT = os.environ.get("NEUMAN_MULTI_COMPACT", "1") != "0"   # the multi-person merge reads compact per-actor lists through row indices (0: full [R, S] arrays, A/B)
 HOST_RAYS = os.environ.get("NEUMAN_HOST_RAYS", "0") == "1"     # A/B switch: generate rays with the host (numpy) mirror and upload them
 
 

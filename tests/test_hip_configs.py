@@ -218,6 +218,27 @@ def test_c5_three_actor_slice_192_128_3x192(G):
     e = np.abs(rgb.cpu().numpy() - c_rgb).max(-1)
     print(f"[C5] {o.shape[0]} rays, hits per actor {n_hit}, merged 896 samples: conditional Linf {e.max():.2e}")
     assert e.max() < 1e-4
+    # the merge reads compact per-actor lists through row indices (one shared placeholder row for every missed ray): bit-identical to the full [R, S] arrays
+    assert G.render.MULTI_COMPACT
+    G.render.MULTI_COMPACT = False
+    try:
+        rgb_full, depth_full = G.render.render_multi_rays(coarse[0], fine[0], [human[0]] * 3, cu(o), cu(d), cap.near['bkg'], cap.far['bkg'],
+                                                          [cu(p) for p in posed_l], meshes, 192, 128)
+    finally:
+        G.render.MULTI_COMPACT = True
+    assert torch.equal(rgb, rgb_full) and torch.equal(depth, depth_full)
+    # ... and with an actor nobody hits (its list is the placeholder row alone)
+    far_l = [cu(p) for p in posed_l[:2]] + [cu(posed_l[2] + np.array([50., 0., 0.], np.float32))]
+    far_T = T_l[2].copy()
+    far_T[:, :3, 3] += np.array([50., 0., 0.])
+    far_mesh = meshes[:2] + [G.ray.mesh_to_device(posed_l[2] + np.array([50., 0., 0.], np.float32), faces, far_T, 'cuda')]
+    a = G.render.render_multi_rays(coarse[0], fine[0], [human[0]] * 3, cu(o), cu(d), cap.near['bkg'], cap.far['bkg'], far_l, far_mesh, 192, 128)
+    G.render.MULTI_COMPACT = False
+    try:
+        b = G.render.render_multi_rays(coarse[0], fine[0], [human[0]] * 3, cu(o), cu(d), cap.near['bkg'], cap.far['bkg'], far_l, far_mesh, 192, 128)
+    finally:
+        G.render.MULTI_COMPACT = True
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
 def test_c4_c5_full_size_frame_properties(G):
