@@ -37,7 +37,8 @@ def tile_ray_indices(total_rays, tile, rank, world, device='cpu'):
     if hit is not None:
         return hit
     n_tiles = (total_rays + tile - 1) // tile
-    tiles = torch.arange(rank, n_tiles, world, device=device)
+    # (a rank beyond the last tile owns nothing: torch.arange refuses start > end -- a frame of fewer tiles than ranks, found by the world-8 test)
+    tiles = torch.arange(rank, n_tiles, world, device=device) if rank < n_tiles else torch.zeros(0, dtype=torch.int64, device=device)
     idx = (tiles[:, None] * tile + torch.arange(tile, device=device)[None, :]).reshape(-1)
     idx = idx[idx < total_rays]
     if len(_INDEX_CACHE) > 256:
