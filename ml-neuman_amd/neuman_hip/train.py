@@ -633,6 +633,35 @@ def train_params(nerf):
     return out
 
 
+def _full_input(net):
+    """A net over encodings WITHOUT the raw input (include_input=False, vanilla.py:56-58, 87-88) as one over the full encodings the kernels form:
+    -> (shadow net, derived parameters).  The derived tensors are the real parameters with zero columns where the absent inputs would be read
+    (torch.cat: autograd slices the kernels' gradients back onto the real parameters); the shadow holds their values for the kernels, which read
+    parameter storage.  With include_input=True: (net, its own parameters)."""
+    from . import vanilla
+    nerf, pos, dpe = net.nerf, net.pos_pe, getattr(net, 'dir_pe', None)
+    pads = vanilla.absent_input_columns(pos, dpe, nerf)
+    if not pads:
+        return net, train_params(nerf)
+    dev = nerf.pts_linears[0].weight.device
+    cache = net.__dict__.setdefault('_full_input_cache', {})
+    if cache.get('dev') != dev:
+        def full(pe):
+            return vanilla.Embedder(pe.input_dims, pe.max_freq, pe.N_freqs, pe.log_sampling, True, min_freq=pe.min_freq, mapping=pe.mapping)
+        fp, fd = full(pos), (full(dpe) if dpe is not None else None)
+        body = vanilla.NeRF(depth=nerf.depth, width=nerf.width, input_ch=fp.out_dim, input_ch_views=fd.out_dim if fd is not None else 0, skips=list(nerf.skips),
+                            output_ch=4 if nerf.use_viewdirs else nerf.output_linear.out_features, use_viewdirs=nerf.use_viewdirs,
+                            scale=getattr(nerf, 'scale', 1.0), scale_type=getattr(nerf, 'scale_type', 'no'))
+        shadow = vanilla.Joiner(fp, fd, body) if dpe is not None else vanilla.OffsetNet(fp, body)
+        cache.update(dev=dev, shadow=shadow.to(dev).train())
+    shadow = cache['shadow']
+    derived = vanilla.with_absent_columns(train_params(nerf), pads)
+    with torch.no_grad():
+        for sp, dp in zip(train_params(shadow.nerf), derived):
+            sp.copy_(dp)
+    return shadow, derived
+
+
 def _offset_fused_ok(net, x, n):
     nerf, pe = net.nerf, net.pos_pe
     return (STORE16 and FUSED_FORWARD and FUSED_BACKWARD and GEMM_PRECISION == 'mixed16' and n >= STORE16_MIN_ROWS and not x.requires_grad and x.is_cuda
@@ -652,7 +681,7 @@ def _offset_fused(net, pts, t):
     cache = net.__dict__.setdefault('_fused_cache', {})
     if cache.get('dev') != dev:
         sp, tc = vanilla.time_columns(pe)
-        pe3 = vanilla.Embedder(3, pe.max_freq, pe.N_freqs, pe.log_sampling, pe.include_input, min_freq=pe.min_freq, mapping='posenc')
+        pe3 = vanilla.Embedder(3, pe.max_freq, pe.N_freqs, pe.log_sampling, True, min_freq=pe.min_freq, mapping='posenc')
         dpe = vanilla.Embedder(3, 3, 4)
         body = vanilla.NeRF(depth=nerf.depth, width=nerf.width, input_ch=pe3.out_dim, input_ch_views=dpe.out_dim, output_ch=4, skips=list(nerf.skips), use_viewdirs=False)
         cache.update(dev=dev, sp=torch.as_tensor(sp, device=dev), tc=torch.as_tensor(tc, device=dev), joiner=vanilla.Joiner(pe3, dpe, body).to(dev))
@@ -672,6 +701,8 @@ def _offset_fused(net, pts, t):
         Wo = torch.cat([Wo, torch.zeros((4 - k, Wo.shape[1]), device=dev, dtype=Wo.dtype)], 0)
         bo = torch.cat([bo, torch.zeros(4 - k, device=dev, dtype=bo.dtype)], 0)
     params += [Wo, bo]
+    if not pe.include_input:                                            # the folded net has no raw-input columns: zero ones for the kernels' full encoding
+        params = vanilla.with_absent_columns(params, {0: (0, 3), **{2 * (s_ + 1): (0, 3) for s_ in nerf.skips}})
     return _MLPPlain16.apply(cache['joiner'], pts, *params)[:, :k]
 
 
@@ -683,7 +714,8 @@ def offset_forward_train(net, x, const_time=None):
     xf = x.reshape(-1, x.shape[-1]).to(torch.float32).contiguous()
     if const_time is not None and _offset_fused_ok(net, xf, xf.shape[0]):
         return _offset_fused(net, xf[:, :3].contiguous(), float(const_time)).reshape(*shp, -1)
-    return _MLP.apply(net, xf, None, *train_params(net.nerf)).reshape(*shp, -1)
+    full, params = _full_input(net)
+    return _MLP.apply(full, xf, None, *params).reshape(*shp, -1)
 
 
 def mlp_forward_train(joiner, pts, dirs):
@@ -692,7 +724,8 @@ def mlp_forward_train(joiner, pts, dirs):
     shp = pts.shape[:-1]
     p = pts.reshape(-1, pts.shape[-1]).to(torch.float32).contiguous()             # (3, or 4 with the time channel of ray_utils.py:133-134)
     d = dirs.reshape(-1, 3).to(torch.float32).contiguous()
-    return _MLP.apply(joiner, p, d, *train_params(joiner.nerf)).reshape(*shp, 4)
+    full, params = _full_input(joiner)
+    return _MLP.apply(full, p, d, *params).reshape(*shp, 4)
 
 
 class _ViewsHead(torch.autograd.Function):
@@ -774,6 +807,7 @@ class _ViewsHead(torch.autograd.Function):
 def two_views_ok(joiner, n):
     """can `two_views` serve n points of this net?  (the fused fp16-storage step: the only form whose forward hands out feature_linear's output)"""
     return (_fused_ok(joiner) and STORE16 and FUSED_BACKWARD and (n + 3) // 4 * 4 >= STORE16_MIN_ROWS and joiner.pos_pe.out_dim <= 64
+            and joiner.pos_pe.include_input and joiner.dir_pe.include_input          # (include_input=False: two plain calls through _full_input)
             and os.environ.get("NEUMAN_TWO_VIEWS", "1") != "0")
 
 

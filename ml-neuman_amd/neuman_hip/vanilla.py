@@ -36,11 +36,14 @@ class Embedder(nn.Module):
         super().__init__()
         if mapping not in ('posenc', 'rotate'):
             raise ValueError(mapping)
-        if not (log_sampling and include_input):
-            raise NotImplementedError("the HIP path implements the reference defaults log_sampling=include_input=True")
+        # log_sampling=False: the reference's posenc constructor stops at `assert 0` (vanilla.py:69-71); its rotate encoding never reads the flag
+        assert log_sampling or mapping == 'rotate', "log_sampling=False is not a configuration of the reference (models/vanilla.py:70)"
         self.input_dims, self.max_freq, self.min_freq, self.N_freqs = input_dims, max_freq, min_freq, N_freqs
-        self.log_sampling, self.include_input, self.mapping = log_sampling, include_input, mapping
-        self.out_dim = input_dims + 2 * input_dims * N_freqs if mapping == 'posenc' else 3 + 6 * N_freqs
+        self.log_sampling, self.include_input, self.mapping = log_sampling, bool(include_input), mapping
+        # include_input=False (vanilla.py:56-58, 63-65, 87-88): the encoding without its leading copy of the input.  The kernels always form the
+        # full encoding; the weight columns of the absent inputs are zero in the packed image (Joiner.kernel_params)
+        raw = input_dims if mapping == 'posenc' else 3
+        self.out_dim = (raw if self.include_input else 0) + (2 * input_dims * N_freqs if mapping == 'posenc' else 6 * N_freqs)
 
     def table(self):
         """f32 table the kernel consumes: posenc -> bands[N]; rotate -> bvals[3N,3] (vanilla.py:44-55, 67-68)."""
@@ -95,6 +98,31 @@ class NeRF(nn.Module):
 
     def forward(self, input_pts, input_views=None):
         raise _lib.NeumanHipError("NeRF.forward on pre-encoded inputs is not exposed: the HIP kernel fuses PE + MLP (use Joiner)")
+
+
+def absent_input_columns(pos_pe, dir_pe, nerf):
+    """{index into NeRF.ordered_params(): (column, count)}: where zero columns go so that a net built over encodings WITHOUT the raw input
+    (include_input=False: vanilla.py:56-58, 87-88 -- the encoding loses its leading `input_dims` columns) reads the full encoding the kernels
+    form.  Layer 0 and the layer after a skip take cat([x_pe, h]) (vanilla.py:127-131), the views layer cat([feature, d_pe]) (:139)."""
+    pads = {}
+    if not pos_pe.include_input:
+        raw = pos_pe.input_dims if pos_pe.mapping == 'posenc' else 3
+        pads[0] = (0, raw)
+        for s in nerf.skips:
+            if s + 1 < nerf.depth:
+                pads[2 * (s + 1)] = (0, raw)
+    if nerf.use_viewdirs and not dir_pe.include_input:
+        pads[2 * nerf.depth] = (nerf.width, dir_pe.input_dims if dir_pe.mapping == 'posenc' else 3)
+    return pads
+
+
+def with_absent_columns(tensors, pads):
+    """ordered_params() widened by the zero columns of absent_input_columns (torch.cat: differentiable, the training path's derived parameters)"""
+    out = list(tensors)
+    for i, (at, cnt) in pads.items():
+        w = out[i]
+        out[i] = torch.cat([w[:, :at], torch.zeros((w.shape[0], cnt), device=w.device, dtype=w.dtype), w[:, at:]], 1)
+    return out
 
 
 class Joiner(nn.Module):
@@ -155,7 +183,9 @@ class Joiner(nn.Module):
             desc = _lib.MlpDesc(n.depth, n.width, n.skips[0] if len(n.skips) == 1 else -1,
                                 _lib.NM_PE_ROTATE if self.pos_pe.mapping == 'rotate' else _lib.NM_PE_POSENC,
                                 self.pos_pe.N_freqs, self.dir_pe.N_freqs, 0 if n.use_viewdirs else 1)
-            host = [p.detach().to('cpu', torch.float32).contiguous() for p in n.ordered_params()]
+            # (include_input=False: zero weight columns where the kernels' encoding carries the raw input)
+            host = [p.to('cpu', torch.float32).contiguous()
+                    for p in with_absent_columns([q.detach() for q in n.ordered_params()], absent_input_columns(self.pos_pe, self.dir_pe, n))]
             arr = (ctypes.c_void_p * 24)(*([t.data_ptr() for t in host] + [None] * (24 - len(host))))
             pos_tab, dir_tab = self.pos_pe.table(), self.dir_pe.table()
             out = ctypes.c_void_p()
@@ -285,8 +315,9 @@ def time_columns(pe):
     if pe.mapping != 'posenc' or pe.input_dims != 4:
         raise _lib.NeumanHipError("time_columns: a 4-D posenc encoding is expected (raw_pos_dim = 4)")
     N = pe.N_freqs
-    spatial = [0, 1, 2] + [4 + 8 * b + k for b in range(N) for k in (0, 1, 2, 4, 5, 6)]
-    timecol = [3] + [4 + 8 * b + k for b in range(N) for k in (3, 7)]
+    raw = 4 if pe.include_input else 0                                  # (include_input=False: no leading copy of v, vanilla.py:63-65)
+    spatial = [0, 1, 2][:raw] + [raw + 8 * b + k for b in range(N) for k in (0, 1, 2, 4, 5, 6)]
+    timecol = [3][:raw] + [raw + 8 * b + k for b in range(N) for k in (3, 7)]
     return spatial, timecol
 
 
@@ -295,7 +326,7 @@ def time_encoding(pe, t):
     reference forms (vanilla.py:73-76)"""
     bands = pe.table().astype(np.float32)
     tt = np.float32(t)
-    out = [float(tt)]
+    out = [float(tt)] if pe.include_input else []
     for b in range(pe.N_freqs):
         a = np.float64(np.float32(tt * bands[b]))
         out += [float(np.sin(a)), float(np.cos(a))]

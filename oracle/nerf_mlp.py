@@ -56,8 +56,8 @@ def embed_rotate(x, min_freq, max_freq, n_freqs, include_input=True):
     return out.numpy()
 
 
-def embed(x, mapping, min_freq, max_freq, n_freqs):
-    return (embed_rotate if mapping == 'rotate' else embed_posenc)(x, min_freq, max_freq, n_freqs)
+def embed(x, mapping, min_freq, max_freq, n_freqs, include_input=True):
+    return (embed_rotate if mapping == 'rotate' else embed_posenc)(x, min_freq, max_freq, n_freqs, include_input)
 
 
 def _linear(h, w, b):
@@ -101,8 +101,9 @@ class JoinerSpec:
     """What the reference's Joiner(pos_pe, dir_pe, nerf) is configured with (options/options.py:60-71)."""
 
     def __init__(self, mapping='posenc', pos_min_freq=0, pos_max_freq=9, pos_n_freqs=10,
-                 dir_max_freq=3, dir_n_freqs=4, depth=8, width=256, skips=(4,)):
+                 dir_max_freq=3, dir_n_freqs=4, depth=8, width=256, skips=(4,), include_input=True):
         self.mapping = mapping
+        self.include_input = include_input                       # options.py:70; both Embedders take it (vanilla.py:208-227)
         self.pos = (pos_min_freq, pos_max_freq, pos_n_freqs)
         self.dir = (0, dir_max_freq, dir_n_freqs)
         self.depth, self.width, self.skips = depth, width, tuple(skips)
@@ -115,8 +116,8 @@ def joiner_forward(weights, spec, pts, dirs, chunk=65536, return_hidden=False):
     d = dirs.reshape(-1, 3).astype(F32)
     outs, hid = [], None
     for s in range(0, p.shape[0], chunk):
-        x_pe = embed(p[s:s + chunk], spec.mapping, *spec.pos)
-        d_pe = embed(d[s:s + chunk], spec.mapping, *spec.dir)
+        x_pe = embed(p[s:s + chunk], spec.mapping, *spec.pos, include_input=getattr(spec, 'include_input', True))
+        d_pe = embed(d[s:s + chunk], spec.mapping, *spec.dir, include_input=getattr(spec, 'include_input', True))
         r = nerf_forward(weights, x_pe, d_pe, spec.depth, spec.skips, return_hidden)
         if return_hidden:
             outs.append(r[0])
