@@ -347,9 +347,12 @@ __device__ __forceinline__ void cswap(uint32_t& a, uint32_t& b) {               
 constexpr int kChunk = 512;
 // samples per wave of a launch: kChunk when there are enough samples to fill the chip that way (a frame's warp: millions), fewer for the
 // small batches of a training iteration (92 k samples = 180 waves of 512 on 256 CUs: 2.5 ms per search, latency-bound; 2048 waves of 64
-// take a tenth of that).  A sample's result does not depend on the chunking.
+// take a tenth of that).  A sample's result does not depend on the chunking.  Round 6 (tools/search_small_batch.py): such a launch lasts as
+// long as its slowest sample's chain of dependent loads (92 k ray samples: 0.95 ms at 16, 32, 64 or 128 samples per wave alike), so a lane should
+// not queue a second sample behind its first while SIMDs idle: one sample per lane up to 262 k samples (184 k points: 0.97 ms against 1.27 at 128).
 inline int chunk_for(int64_t N) {
-    int64_t c = (N / 2048 + 63) / 64 * 64;
+    if (const char* e = getenv("NEUMAN_SEARCH_CHUNK")) { const int v = atoi(e); if (v >= 8 && v <= kChunk) return v; }     // (tools: sweeps)
+    int64_t c = (N / 4096 + 63) / 64 * 64;
     return (int)(c < 64 ? 64 : c > kChunk ? kChunk : c);
 }
 constexpr int kRefill = 8;                            // idle lanes that trigger a refill (or any, when no lane has work)
