@@ -104,6 +104,18 @@ def _f32c(t, device=None):
     return t.contiguous()
 
 
+def _batch_f32c(t):
+    """A ray batch as the reference's DataLoader hands it to a trainer lives on the HOST (datasets/*.py; vanilla_nerf_trainer.py:51-60 samples first
+    and moves the samples to the device afterwards): the two sampling entry points upload it.  An upload, not a host evaluation -- without a HIP
+    device this raises like everything else."""
+    _lib.require_gpu()
+    if isinstance(t, np.ndarray):
+        t = torch.from_numpy(t)
+    if not t.is_cuda:
+        t = t.to(torch.device('cuda', torch.cuda.current_device()))
+    return _f32c(t)
+
+
 def sample_z(origin, direction, near, far, samples_per_ray, lindisp=False, perturb=0., want_points=False):
     """Core of ray_to_samples on device tensors.  Returns (pts|None, dirs|None, z)."""
     _lib.require_gpu()
@@ -124,9 +136,10 @@ def sample_z(origin, direction, near, far, samples_per_ray, lindisp=False, pertu
 
 
 def ray_to_samples(ray_batch, samples_per_ray, lindisp=False, perturb=0., device='cpu', append_t=None):
-    """reference ray_utils.py:96-135.  ray_batch tensors must live on the HIP device."""
-    o, d = _f32c(ray_batch['origin']), _f32c(ray_batch['direction'])
-    near, far = _f32c(ray_batch['near']).reshape(-1), _f32c(ray_batch['far']).reshape(-1)
+    """reference ray_utils.py:96-135.  The batch may live on the host (the reference's trainers sample before they move anything to the device):
+    it is uploaded; the samples come back on the HIP device whatever `device` says (the callers' `.to(device)` is then a no-op)."""
+    o, d = _batch_f32c(ray_batch['origin']), _batch_f32c(ray_batch['direction'])
+    near, far = _batch_f32c(ray_batch['near']).reshape(-1), _batch_f32c(ray_batch['far']).reshape(-1)
     assert near.shape[0] == far.shape[0] == o.shape[0]
     pts, dirs, z = sample_z(o, d, near, far, samples_per_ray, lindisp, perturb, want_points=True)
     if append_t is not None:
@@ -192,9 +205,9 @@ def importance_z_from_raw(raw, z_vals, rays_d, importance_samples_per_ray, want_
 
 def ray_to_importance_samples(ray_batch, z_vals, weights, importance_samples_per_ray, device='cpu', including_old=True,
                               append_t=None):
-    """reference ray_utils.py:138-160."""
-    o, d = _f32c(ray_batch['origin']), _f32c(ray_batch['direction'])
-    z = importance_z(z_vals, weights, importance_samples_per_ray, including_old)
+    """reference ray_utils.py:138-160 (a host batch is uploaded, as in ray_to_samples)."""
+    o, d = _batch_f32c(ray_batch['origin']), _batch_f32c(ray_batch['direction'])
+    z = importance_z(_batch_f32c(z_vals), _batch_f32c(weights.detach()), importance_samples_per_ray, including_old)
     pts, dirs = z_to_points(o, d, z)
     if append_t is not None:
         pts = torch.cat([pts, append_t.to(pts.device)], dim=-1)

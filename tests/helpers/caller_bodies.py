@@ -46,3 +46,67 @@ def scene_inputs():
     posed, T = synthetic.twist_transforms(verts_c)
     posed2, T2 = synthetic.twist_transforms(verts_c, twist=0.5, shift=(-0.04, 0.03, 0.02))
     return {'static_vert': verts_c, 'faces': faces, 'verts': [posed, posed2], 'Ts': [T, T2]}
+
+
+# ---- train.py's background trainer: the iteration body -------------------------------------------------------------------------------
+R_TR, S_TR, NI_TR, ITERS_TR = 64, 24, 16, 5
+
+
+def trainer_opt():
+    import types
+    return types.SimpleNamespace(ablate_nerft=False, samples_per_ray=S_TR, importance_samples_per_ray=NI_TR, perturb=0.0, raw_noise_std=0.0, white_bkg=True,
+                                 margin=0.9, delay_iters=2, lrate_decay=250, learning_rate=5e-4, penalize_empty_space=0.1)
+
+
+def trainer_batch():
+    rng = np.random.default_rng(2024)
+    ro = (rng.normal(size=(R_TR, 3)) * 0.3).astype(np.float32)
+    rd = rng.normal(size=(R_TR, 3)).astype(np.float32)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    near = rng.uniform(0.1, 0.6, size=(R_TR, 1)).astype(np.float32)
+    far = (near + rng.uniform(1.0, 2.5, size=(R_TR, 1))).astype(np.float32)
+    return dict(origin=ro, direction=rd, near=near, far=far, color=rng.uniform(size=(R_TR, 3)).astype(np.float32),
+                depth=rng.uniform(0.8, 2.0, size=(R_TR,)).astype(np.float32))
+
+
+def background_trainer_iterations(M, coarse_net, fine_net, optim, opt, batch, device, n_iter):
+    """n_iter iterations of train.py's background trainer on one batch, the calls of trainers/vanilla_nerf_trainer.py:45-96 (loss_func: ray_to_samples,
+    the coarse net, raw2outputs, MSE, the empty-space term, ray_to_importance_samples, the fine net, raw2outputs, MSE) and :206-248 (train_batch:
+    the delay, backward, Adam, the learning-rate and penalty schedules) resolved through the namespace M (`ray_utils`, `render_utils`) -> [n_iter, 4] terms.
+    The batch has no DataLoader axis (utils.remove_first_axis is the script's own plumbing)."""
+    import torch
+    import torch.nn.functional as F
+    terms_log = []
+    penalty = opt.penalize_empty_space
+    color = batch['color'].to(device)
+    for it in range(n_iter):
+        optim.zero_grad()
+        pts, dirs, z_vals = M.ray_utils.ray_to_samples(batch, opt.samples_per_ray, perturb=opt.perturb, append_t=None)
+        pts, dirs, z_vals = pts.to(device), dirs.to(device), z_vals.to(device)
+        n = pts.shape[1]
+        out = coarse_net(pts, dirs)
+        rgb_map, _, _, weights, _ = M.render_utils.raw2outputs(out, z_vals, dirs[:, 0, :], raw_noise_std=opt.raw_noise_std, white_bkg=opt.white_bkg)
+        terms = [F.mse_loss(rgb_map, color), torch.zeros((), device=device)]
+        if penalty > 0:
+            closer = z_vals < (batch['depth'][:, None].repeat(1, n).to(device) * opt.margin)
+            sel = out[closer][:, 3]
+            terms[1] = terms[1] + F.mse_loss(torch.tanh(torch.relu(sel)), torch.zeros_like(sel)) * penalty
+        F_pts, F_dirs, F_z = M.ray_utils.ray_to_importance_samples(batch, z_vals, weights, opt.importance_samples_per_ray, device=device, append_t=None)
+        F_out = fine_net(F_pts, F_dirs)
+        F_rgb, _, _, _, _ = M.render_utils.raw2outputs(F_out, F_z, F_dirs[:, 0, :], raw_noise_std=opt.raw_noise_std, white_bkg=opt.white_bkg)
+        terms += [F.mse_loss(F_rgb, color), torch.zeros((), device=device)]
+        if penalty > 0:
+            F_closer = F_z < (batch['depth'][:, None].repeat(1, F_z.shape[1]).to(device) * opt.margin)
+            sel = F_out[F_closer][:, 3]
+            terms[3] = terms[3] + F.mse_loss(torch.tanh(torch.relu(sel)), torch.zeros_like(sel)) * penalty
+        assert float(out.detach()[..., 3].max()) > 0.0 and float(F_out.detach()[..., 3].max()) > 0.0, "a dead network (:88-94: the restart) is not a case of this fixture"
+        rgb_loss, empty = terms[0] + terms[2], terms[1] + terms[3]
+        total = rgb_loss + empty if it >= opt.delay_iters else rgb_loss
+        total.backward()
+        optim.step()
+        terms_log.append([float(t.detach()) for t in terms])
+        lr = opt.learning_rate * (0.1 ** (it / (opt.lrate_decay * 1000)))
+        for group in optim.param_groups:
+            group['lr'] = lr
+        penalty = opt.penalize_empty_space * max(0, 1 - (it / 60000))
+    return np.asarray(terms_log, np.float64)

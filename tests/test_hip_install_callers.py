@@ -112,3 +112,60 @@ def test_test_views_loop_through_install(installed):
     print(f"[render_test_views loop through install()] {frames.shape[0]} frames of {CB.HTV} x {CB.WTV}: median {np.median(e):.1e}, rays > 1e-4: {(e > 1e-4).sum()} of {e.size} "
           f"({(e > 1e-4).mean() * 100:.1f} %; the hybrid golden's yardstick rate {rate * 100:.1f} %)")
     assert np.median(e) < 2e-5 and (e > 1e-4).mean() <= 2.0 * rate + 0.01
+
+
+def test_background_trainer_iterations_through_install(installed):
+    """train.py's background trainer: five iterations of the calls of NeRFTrainer.loss_func / train_batch (vanilla_nerf_trainer.py:45-96, 206-248) resolved
+    through the installed names (tests/helpers/caller_bodies.py background_trainer_iterations), on a HOST batch as the reference's DataLoader hands it over --
+    against (i) what the reference's own, unmodified train_batch did on the same batch and weights (tests/golden/callers_train.npz) and (ii) the repo's own
+    trainer (neuman_hip.bkg_trainer.BackgroundNeRFTrainer) on the same batch."""
+    from neuman_hip import bkg_trainer, synthetic
+    g = np.load(os.path.join(os.path.dirname(GOLDEN), "callers_train.npz"))
+    opt, b = CB.trainer_opt(), CB.trainer_batch()
+
+    def nets():
+        c, f = installed.vanilla.build_nerf(synthetic.default_opt(use_cuda=True))
+        assert type(c).__module__ == 'neuman_hip.vanilla'
+        c.load_state_dict(synthetic.make_joiner(0).state_dict(), strict=True)
+        f.load_state_dict(synthetic.make_joiner(1).state_dict(), strict=True)
+        return c.train(), f.train()
+
+    def adam(c, f):
+        return torch.optim.Adam([{"params": c.parameters(), "lr": opt.learning_rate}, {"params": f.parameters(), "lr": opt.learning_rate}], betas=(0.9, 0.999))   # train.py:57-61
+    coarse, fine = nets()
+    host_batch = {k: torch.from_numpy(v) for k, v in b.items()}                             # on the host, like the DataLoader's
+    terms = CB.background_trainer_iterations(installed, coarse, fine, adam(coarse, fine), opt, host_batch, torch.device('cuda'), CB.ITERS_TR)
+    ref = g['terms']
+    dev_first = np.abs(terms[0] - ref[0]).max() / np.abs(ref[0]).max()
+    dev_all = np.abs(terms - ref).max() / np.abs(ref).max()
+    print(f"[callers] background trainer through install(): loss terms vs the reference's own train_batch: iteration 0 {dev_first:.2e}, all {CB.ITERS_TR} iterations {dev_all:.2e} "
+          f"(relative to the largest term); last iteration {terms[-1].round(6).tolist()} vs {ref[-1].round(6).tolist()}")
+    # iteration 0 is one forward pass on identical weights; from iteration 1 on the weights have taken Adam steps, whose first is lr * sign(gradient): an entry
+    # whose gradient is at rounding level moves by +-lr on either side, and the next losses see that
+    # -- measured on MI355X: 7.5e-6 at iteration 0 AND over all five (the losses average the flipped entries out)
+    assert dev_first < 2e-5 and dev_all < 1e-4
+    worst = 0.0
+    for tag, net in (('coarse', coarse), ('fine', fine)):
+        sd = net.state_dict()
+        for k in [k for k in g.files if k.startswith(tag + '/nerf.')]:
+            got, want = sd[k.split('/', 1)[1]].cpu().numpy(), g[k]
+            assert got.shape == want.shape
+            worst = max(worst, float(np.abs(got - want).max()))
+    print(f"[callers] parameters after {CB.ITERS_TR} iterations vs the reference's: largest difference {worst:.2e} (an Adam step is {opt.learning_rate:.0e})")
+    assert worst <= 2.5 * CB.ITERS_TR * opt.learning_rate
+    # (ii) the repo's own trainer on the same batch and weights: the same kernels behind its own entry points (sample_z / importance_z instead of the
+    # reference-shaped ray_to_samples / ray_to_importance_samples): the loss terms of every iteration bit for bit
+    c2, f2 = nets()
+    t_opt = types.SimpleNamespace(**vars(opt), empty_space_loss_fn='mse', out=None)
+    tr = bkg_trainer.BackgroundNeRFTrainer(t_opt, c2, adam(c2, f2), fine_net=f2)
+    dev_batch = {k: v.cuda() for k, v in host_batch.items()}
+    direct = []
+    for it in range(CB.ITERS_TR):
+        tr.iteration = it
+        rep = tr.train_batch(dev_batch)
+        direct.append([rep[n] for n in bkg_trainer.LOSS_TERMS])
+    direct = np.asarray(direct, np.float64)
+    print(f"[callers] the installed-names iterations vs bkg_trainer.BackgroundNeRFTrainer.train_batch: largest difference of a loss term {np.abs(direct - terms).max():.2e}")
+    assert np.array_equal(direct, terms)
+    for a, b_ in zip(list(coarse.parameters()) + list(fine.parameters()), list(c2.parameters()) + list(f2.parameters())):
+        assert torch.equal(a, b_)
