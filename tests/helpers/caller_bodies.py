@@ -34,10 +34,43 @@ def test_views(M, net, make_cap, frame_ids, verts, faces, Ts, opt):
     return np.stack(frames)
 
 
+
+def gathering(M, bkg_net, nets_list, make_cap, n_frames, verts_list, faces, Ts_list, opt):
+    """render_gathering.py:189-202 (main's loop): every novel camera through render_hybrid_nerf_multi_persons, the actors' vertices and transforms
+    sliced out of the stacked arrays as the script slices them (verts_list [A, frames, V, 3], Ts_list [A, frames, V, 4, 4]) -> [n, H, W, 3]"""
+    frames = []
+    for i in range(n_frames):
+        out = M.render_utils.render_hybrid_nerf_multi_persons(
+            bkg_net, make_cap(i), nets_list, verts_list[:, i, ...], [faces] * len(nets_list), Ts_list[:, i, ...],
+            rays_per_batch=opt.rays_per_batch, samples_per_ray=opt.samples_per_ray, geo_threshold=opt.geo_threshold, return_depth=False)
+        frames.append(np.asarray(out))
+    return np.stack(frames)
+
 # the synthetic stand-in for what the scripts read from a scene directory (both sides build it from these definitions)
 W360, H360, N360, S360 = 48, 40, 3, 64
 WTV, HTV, STV = 40, 32, 64
 TV_FRAMES = (0, 1)
+
+
+WG, HG, SG, NG = 40, 32, 48, 2
+G_SHIFTS = ((0.0, 0.0, 0.0), (0.35, 0.0, 0.2), (-0.3, 0.05, -0.15))                 # three actors side by side (tests/golden/make_golden_posed.py's)
+
+
+def gathering_inputs():
+    """what read_actors (render_gathering.py:155-165) stacks: per actor and frame the posed vertices and the Da-pose -> scene transforms"""
+    inp = scene_inputs()
+    verts, Ts = [], []
+    for s in G_SHIFTS:
+        s = np.asarray(s, np.float64)
+        v_f, t_f = [], []
+        for k in range(NG):
+            t = np.array(inp['Ts'][k], dtype=np.float64, copy=True)
+            t[:, :3, 3] += s
+            v_f.append((np.asarray(inp['verts'][k], np.float64) + s).astype(np.float32))
+            t_f.append(t)
+        verts.append(v_f)
+        Ts.append(t_f)
+    return {'faces': inp['faces'], 'verts_list': np.array(verts), 'Ts_list': np.array(Ts)}
 
 
 def scene_inputs():

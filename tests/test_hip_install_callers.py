@@ -114,6 +114,44 @@ def test_test_views_loop_through_install(installed):
     assert np.median(e) < 2e-5 and (e > 1e-4).mean() <= 2.0 * rate + 0.01
 
 
+
+def human_nerf_net_seed(seed):
+    from neuman_hip import human_nerf, synthetic
+    opt = synthetic.default_opt(use_cuda=True, posenc='posenc', can_posenc='rotate', num_offset_nets=1, offset_scale=1.0, offset_scale_type='linear')
+    net = human_nerf.HumanNeRF(opt)
+    for sub, s_, mp in ((net.coarse_bkg_net, 0, 'posenc'), (net.fine_bkg_net, 1, 'posenc'), (net.coarse_human_net, seed, 'rotate')):
+        sub.load_state_dict(synthetic.make_joiner(s_, mp).state_dict(), strict=True)
+    return net.eval()
+
+
+def test_gathering_loop_through_install(installed):
+    """render_gathering.py:189-202 (BASELINE config 5's script: three actors in one scene) on the installed names, the actors' vertices and transforms sliced out
+    of the stacked arrays as the script slices them, against the frames the reference made through the same loop (tests/golden/callers_gathering.npz)"""
+    from neuman_hip import render_utils, synthetic
+    from oracle import attribution
+    g = np.load(os.path.join(os.path.dirname(GOLDEN), "callers_gathering.npz"))
+    inp = CB.gathering_inputs()
+    bkg_net = human_nerf_net_seed(2)
+    nets_list = [human_nerf_net_seed(int(s)) for s in g['actor_seeds']]
+    opt = types.SimpleNamespace(rays_per_batch=512, samples_per_ray=CB.SG, geo_threshold=0.2)
+
+    def cap(i):
+        return synthetic.SimpleCapture(CB.WG, CB.HG, fx=70.0, c2w=g['c2w'][i], near=0.5, far=3.14)
+    frames = CB.gathering(installed, bkg_net, nets_list, cap, CB.NG, inp['verts_list'], inp['faces'], inp['Ts_list'], opt)
+    direct = np.stack([render_utils.render_hybrid_nerf_multi_persons(bkg_net, cap(i), nets_list, [inp['verts_list'][a, i] for a in range(3)], [inp['faces']] * 3,
+                                                                     [inp['Ts_list'][a, i] for a in range(3)], rays_per_batch=512, samples_per_ray=CB.SG,
+                                                                     geo_threshold=0.2) for i in range(CB.NG)])
+    assert frames.dtype == np.float32 and frames.shape == (CB.NG, CB.HG, CB.WG, 3) and np.array_equal(frames, direct)
+    e = np.abs(frames - g['frames']).max(-1)
+    # three warped bodies in front of the two-pass background: against another float32 evaluation (the reference's) the frame differs on about as many rays as
+    # the three-actor golden's yardstick (the reference's own float32 frame against its float64 one: 79 of 1280 = 6.2 %)
+    y = attribution.load_arbiter('multi')['rgb64'].reshape(-1, 3)
+    y32 = np.load(os.path.join(os.path.dirname(GOLDEN), 'posed.npz'))['multi_rgb'].reshape(-1, 3)
+    rate = float((np.abs(y32.astype(np.float64) - y).max(-1) > 1e-4).mean())
+    print(f"[render_gathering loop through install()] {frames.shape[0]} frames of {CB.HG} x {CB.WG}, three actors: median {np.median(e):.1e}, rays > 1e-4: {(e > 1e-4).sum()} of {e.size} "
+          f"({(e > 1e-4).mean() * 100:.1f} %; the three-actor golden's yardstick rate {rate * 100:.1f} %)")
+    assert np.median(e) < 2e-5 and (e > 1e-4).mean() <= 2.0 * rate + 0.01
+
 def test_background_trainer_iterations_through_install(installed):
     """train.py's background trainer: five iterations of the calls of NeRFTrainer.loss_func / train_batch (vanilla_nerf_trainer.py:45-96, 206-248) resolved
     through the installed names (tests/helpers/caller_bodies.py background_trainer_iterations), on a HOST batch as the reference's DataLoader hands it over --
