@@ -35,6 +35,18 @@ def test_views(M, net, make_cap, frame_ids, verts, faces, Ts, opt):
 
 
 
+
+def posed_360(M, net, make_cap, n_frames, verts, faces, Ts, opt):
+    """render_360.py:108-126 (main_posed_360's loop): the posed body of frame 0 from every pose of the 360 path through render_smpl_nerf(render_can=False)
+    -> [n, H, W, 3]"""
+    frames = []
+    for i in range(n_frames):
+        out = M.render_utils.render_smpl_nerf(
+            net, make_cap(i), verts, faces, Ts, rays_per_batch=opt.rays_per_batch, samples_per_ray=opt.samples_per_ray, white_bkg=opt.white_bkg,
+            render_can=False, geo_threshold=opt.geo_threshold)
+        frames.append(np.asarray(out))
+    return np.stack(frames)
+
 def gathering(M, bkg_net, nets_list, make_cap, n_frames, verts_list, faces, Ts_list, opt):
     """render_gathering.py:189-202 (main's loop): every novel camera through render_hybrid_nerf_multi_persons, the actors' vertices and transforms
     sliced out of the stacked arrays as the script slices them (verts_list [A, frames, V, 3], Ts_list [A, frames, V, 4, 4]) -> [n, H, W, 3]"""
@@ -52,6 +64,7 @@ WTV, HTV, STV = 40, 32, 64
 TV_FRAMES = (0, 1)
 
 
+WP, HP, SP, NP = 40, 48, 64, 2
 WG, HG, SG, NG = 40, 32, 48, 2
 G_SHIFTS = ((0.0, 0.0, 0.0), (0.35, 0.0, 0.2), (-0.3, 0.05, -0.15))                 # three actors side by side (tests/golden/make_golden_posed.py's)
 

@@ -88,6 +88,37 @@ def test_canonical_360_loop_through_install(installed):
     assert hit_ref.sum() > 300 and flips.sum() <= 4 and e[~flips].max() < 1e-4
 
 
+
+def test_posed_360_loop_through_install(installed):
+    """render_360.py:108-126 (main_posed_360: the posed body seen from the 360 path, render_smpl_nerf(render_can=False): the observation -> canonical warp
+    behind every sample) on the installed names against the frames the reference made through the same loop (tests/golden/callers_posed360.npz)"""
+    from neuman_hip import render_utils, synthetic
+    from oracle import attribution
+    g = np.load(os.path.join(os.path.dirname(GOLDEN), "callers_posed360.npz"))
+    inp = CB.scene_inputs()
+    net = human_nerf_net()
+    K = g['K']
+    opt = types.SimpleNamespace(rays_per_batch=1024, samples_per_ray=CB.SP, geo_threshold=0.2, white_bkg=True)
+
+    def cap(i):
+        return synthetic.SimpleCapture(CB.WP, CB.HP, fx=K[0, 0], fy=K[1, 1], cx=K[0, 2], cy=K[1, 2], c2w=g['c2w'][i])
+    frames = CB.posed_360(installed, net, cap, CB.NP, inp['verts'][0], inp['faces'], inp['Ts'][0], opt)
+    direct = np.stack([render_utils.render_smpl_nerf(net, cap(i), inp['verts'][0], inp['faces'], inp['Ts'][0], rays_per_batch=1024, samples_per_ray=CB.SP,
+                                                     white_bkg=True, render_can=False, geo_threshold=0.2) for i in range(CB.NP)])
+    assert frames.dtype == np.float32 and np.array_equal(frames, direct)
+    ref = g['frames']
+    e = np.abs(frames - ref).max(-1)
+    hit_ref, hit_dev = ref.min(-1) < 1.0, frames.min(-1) < 1.0
+    flips = hit_ref != hit_dev
+    # against another float32 evaluation (the reference's: float32 near / far, float32 closest-point feet) the posed frame differs where that evaluation is itself
+    # off its float64 frame: the yardstick is the posed golden's rate (the reference's float32 frame against its float64 one, 14 of 1280 rays)
+    y = attribution.load_arbiter('posed')['rgb64'].reshape(-1, 3)
+    y32 = np.load(os.path.join(os.path.dirname(GOLDEN), 'posed.npz'))['posed_rgb'].reshape(-1, 3)
+    rate = float((np.abs(y32.astype(np.float64) - y).max(-1) > 1e-4).mean())
+    print(f"[render_360 posed loop through install()] {frames.shape[0]} frames of {CB.HP} x {CB.WP}, {hit_ref.sum()} hit pixels: median {np.median(e[hit_ref]):.1e}, rays > 1e-4: "
+          f"{(e > 1e-4).sum()} of {e.size} ({(e > 1e-4).mean() * 100:.1f} %; the posed golden's yardstick rate {rate * 100:.1f} %), hit / miss flips {flips.sum()}")
+    assert hit_ref.sum() > 1500 and flips.sum() <= 6 and np.median(e[hit_ref]) < 2e-5 and (e > 1e-4).mean() <= 2.0 * rate + 0.01
+
 def test_test_views_loop_through_install(installed):
     """render_test_views.py:69-82 on the installed names against the frames the reference made through the same loop"""
     from neuman_hip import render_utils, synthetic
