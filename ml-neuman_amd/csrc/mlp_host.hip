@@ -198,12 +198,16 @@ static void pack_image(const nm_mlp_desc* d, const float* const* P, uint8_t* img
 // a training loop whose weights change every iteration (a host repack would cost a 2.4 MB download, a CPU pass and an upload per
 // network and step).  Same scale rule, same rounding (RNE to fp16 twice), same layout: the forward through a refreshed handle is
 // bit-identical to the forward through a handle created from the same values (tests/test_hip_train.py).
-__global__ __launch_bounds__(1024) void f16_stage_scale_kernel(nm_mlp_desc d, DevParams P, float* __restrict__ wscale) {
+// (round 6: kScaleSlices workgroups per stage instead of one -- 45 -> a few microseconds in front of every training forward; the largest magnitude is
+//  the same number in whatever order it is found, so the image is bit-identical.  work = [kStages] running maxima as uint bits | [kStages] arrival counters,
+//  zeroed by the caller; the last slice of a stage to arrive turns its maximum into the scale.)
+constexpr int kScaleSlices = 16;
+__global__ __launch_bounds__(1024) void f16_stage_scale_kernel(nm_mlp_desc d, DevParams P, unsigned* __restrict__ work, float* __restrict__ wscale) {
     const int st = blockIdx.x;
     const StageShape sh = stage_shape(st);
     const int per_row = 2 * sh.steps * 8, total = sh.nblk * 32 * per_row;
     float mx = 0.f;
-    for (int i = threadIdx.x; i < total; i += 1024) {
+    for (int i = blockIdx.y * 1024 + threadIdx.x; i < total; i += 1024 * kScaleSlices) {
         const int n = i / per_row, r = i - n * per_row;
         mx = fmaxf(mx, fabsf(stage_weight(&d, P.p, st, n, r >> 3, r & 7)));
     }
@@ -215,9 +219,14 @@ __global__ __launch_bounds__(1024) void f16_stage_scale_kernel(nm_mlp_desc d, De
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        int k = 8;
-        while (k > -40 && part[0] * ldexpf(1.f, k) > 32000.f) --k;
-        wscale[st] = ldexpf(1.f, k);
+        atomicMax(&work[st], __float_as_uint(part[0]));                  // (magnitudes: non-negative floats order like their bit patterns; a NaN weight never raised mx)
+        __threadfence();
+        if (atomicAdd(&work[kStages + st], 1u) == kScaleSlices - 1) {
+            const float all = __uint_as_float(atomicMax(&work[st], 0u));
+            int k = 8;
+            while (k > -40 && all * ldexpf(1.f, k) > 32000.f) --k;
+            wscale[st] = ldexpf(1.f, k);
+        }
     }
 }
 __global__ __launch_bounds__(256) void f16_pack_kernel(nm_mlp_desc d, DevParams P, const float* __restrict__ wscale, uint8_t* __restrict__ img) {
@@ -644,10 +653,12 @@ int nm_mlp_refresh_f16(nm_mlp_t m, const float* const* dev_params, nm_stream_t s
         P.p[i] = i < need ? dev_params[i] : nullptr;
     }
     if (!m->d_wscale16)
-        if (int rc = nm::check_hip(hipMalloc(&m->d_wscale16, nm::kStages * sizeof(float)), "nm_mlp_refresh_f16: hipMalloc")) return rc;
+        if (int rc = nm::check_hip(hipMalloc(&m->d_wscale16, 3 * nm::kStages * sizeof(float)), "nm_mlp_refresh_f16: hipMalloc")) return rc;     // scales | maxima | counters
     hipStream_t st = nm::as_stream(stream);
     float* bias = reinterpret_cast<float*>(m->d_image16 + nm::kWeightBytes + nm::kWeightPadBytes);
-    hipLaunchKernelGGL(nm::f16_stage_scale_kernel, dim3(nm::kStages), dim3(1024), 0, st, m->desc, P, m->d_wscale16);
+    unsigned* scale_work = reinterpret_cast<unsigned*>(m->d_wscale16 + nm::kStages);
+    if (int rc = nm::check_hip(hipMemsetAsync(scale_work, 0, 2 * nm::kStages * sizeof(unsigned), st), "nm_mlp_refresh_f16: clear")) return rc;
+    hipLaunchKernelGGL(nm::f16_stage_scale_kernel, dim3(nm::kStages, nm::kScaleSlices), dim3(1024), 0, st, m->desc, P, scale_work, m->d_wscale16);
     const int threads = (int)(nm::kWeightBytes / nm::kStepBytes) * 64;
     hipLaunchKernelGGL(nm::f16_pack_kernel, dim3((threads + 255) / 256), dim3(256), 0, st, m->desc, P, m->d_wscale16, m->d_image16);
     hipLaunchKernelGGL(nm::f16_bias_kernel, dim3((nm::kBiasFloats + nm::kF16TabFloats + 255) / 256), dim3(256), 0, st, P, m->d_wscale16, bias, m->desc.plain_head);
