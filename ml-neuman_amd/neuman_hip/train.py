@@ -655,10 +655,16 @@ def _full_input(net):
         shadow = vanilla.Joiner(fp, fd, body) if dpe is not None else vanilla.OffsetNet(fp, body)
         cache.update(dev=dev, shadow=shadow.to(dev).train())
     shadow = cache['shadow']
-    derived = vanilla.with_absent_columns(train_params(nerf), pads)
-    with torch.no_grad():
-        for sp, dp in zip(train_params(shadow.nerf), derived):
-            sp.copy_(dp)
+    real = train_params(nerf)
+    derived = vanilla.with_absent_columns(real, pads)
+    # the shadow's storage follows the real parameters' VERSIONS: a second forward of the same iteration (the human trainer evaluates a net on several
+    # query sets before its one backward pass) must not touch it -- the fused backward checks that the weights it reads are the forward's
+    key = tuple((p.data_ptr(), p._version) for p in real)
+    if cache.get('key') != key:
+        with torch.no_grad():
+            for sp, dp in zip(train_params(shadow.nerf), derived):
+                sp.copy_(dp)
+        cache['key'] = key
     return shadow, derived
 
 

@@ -110,6 +110,12 @@ def test_large_batch_equals_the_full_encoding_net_with_zero_columns(N, monkeypat
         assert a.shape == b.shape and torch.equal(a, b), i
     # and the views head alone through forward_two_views' fallback: two plain calls
     assert j.forward_two_views(pts, dirs, dirs) is None
+    # two forwards of one iteration before its one backward pass (the human trainer's query sets): the second must not disturb what the first's backward reads
+    for q in j.parameters():
+        q.grad = None
+    a, b = j(pts[:33000], dirs[:33000]), j(pts[3000:], dirs[3000:])
+    (((a - tgt[:33000]) ** 2).mean() + ((b - tgt[3000:]) ** 2).mean()).backward()
+    assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in j.parameters())
 
 
 def test_plain_head_frames_and_time_conditioned(N):
