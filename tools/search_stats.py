@@ -25,6 +25,9 @@ ho, hd, hn, hf = o[idx].contiguous(), d[idx].contiguous(), near[idx].contiguous(
 pts, _, z = ray_utils.sample_z(ho, hd, hn, hf, 128, want_points=True)
 mesh = ray_utils.mesh_to_device(posed, faces, T, dev)
 raw = ctypes.CDLL(_lib.LIB_PATH)
+if not hasattr(raw, 'nm_debug_search_stats'):
+    raise SystemExit("this library carries no search counters: apply profiles/r06_search_disc.patch (or add the NM_STAT lines to csrc/warp.hip), compile with "
+                     "-DNM_SEARCH_STATS and point NEUMAN_HIP_LIB at the result (profiles/r06_search_disc_experiment.md)")
 out = (ctypes.c_ulonglong * 16)()
 raw.nm_debug_search_stats(out)
 ray_utils.warp_to_canonical_dev(pts, mesh)
